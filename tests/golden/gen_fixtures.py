@@ -1,0 +1,350 @@
+#!/usr/bin/env python
+"""Generate the committed golden vectors by RUNNING THE REFERENCE ITSELF (unmodified, on CPU).
+
+    cd /root/repo && python tests/golden/gen_fixtures.py
+
+Needs /root/reference (present only in the build container).  Outputs (all small, committed):
+  tests/golden/constants.json       config-derived constants
+  tests/golden/gae.npz              RolloutStorage.compute_returns: the §8c known answer + a seeded case
+  tests/golden/policy_example.npz   weights of logs/XBot_ppo/exported/policies/policy_example.pt (trained
+                                    actor, a data artefact not source) + its outputs on fixed inputs
+  tests/golden/env_trace.npz        XBotLFreeEnv.step over a seeded synthetic sim trace: inputs, every RNG
+                                    draw (scattered to full-N tables), outputs, final state
+  tests/golden/ppo_update.npz       PPO.act / process_env_step / compute_returns / update on a small net
+The oracle (oracle/*.py) is pinned against these in tests/test_oracle_golden.py; the HIP path is then
+compared against the oracle on the GPU.
+"""
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_harness as H  # noqa: E402
+
+torch.set_num_threads(1)  # deterministic reductions
+
+
+def npy(t):
+    return t.detach().cpu().numpy().copy()
+
+
+# ------------------------------------------------------------------------------------------------
+def gen_constants(R):
+    e, cfg = H.make_ref_env(4)
+    ppo = R.XBotLCfgPPO()
+    d = dict(
+        dt=float(e.dt), max_episode_length=float(e.max_episode_length),
+        resample_steps=int(cfg.commands.resampling_time / e.dt),
+        push_interval=float(cfg.domain_rand.push_interval),
+        reward_names=list(e.reward_names),
+        reward_scales_dt=[float(e.reward_scales[k]) for k in e.reward_names],
+        p_gains=e.p_gains[0].tolist(), d_gains=e.d_gains[0].tolist(), torque_limits=e.torque_limits.tolist(),
+        noise_scale_vec=e.noise_scale_vec.tolist(), commands_scale=e.commands_scale.tolist(),
+        base_init_state=e.base_init_state.tolist(),
+        num_obs=e.num_obs, num_privileged_obs=e.num_privileged_obs,
+        gamma=ppo.algorithm.gamma, lam=ppo.algorithm.lam, clip_param=ppo.algorithm.clip_param,
+        entropy_coef=ppo.algorithm.entropy_coef, learning_rate=ppo.algorithm.learning_rate,
+        value_loss_coef=ppo.algorithm.value_loss_coef, max_grad_norm=ppo.algorithm.max_grad_norm,
+        desired_kl=ppo.algorithm.desired_kl, schedule=ppo.algorithm.schedule,
+        num_learning_epochs=ppo.algorithm.num_learning_epochs, num_mini_batches=ppo.algorithm.num_mini_batches,
+        num_steps_per_env=ppo.runner.num_steps_per_env, seed=ppo.seed,
+        actor_hidden_dims=ppo.policy.actor_hidden_dims, critic_hidden_dims=ppo.policy.critic_hidden_dims,
+    )
+    ac = R.ActorCritic(e.num_obs, e.num_privileged_obs, 12, **R.class_to_dict(ppo.policy))
+    d["param_counts"] = dict(actor=sum(p.numel() for p in ac.actor.parameters()),
+                             critic=sum(p.numel() for p in ac.critic.parameters()), std=ac.std.numel())
+    d["state_dict_keys"] = list(ac.state_dict().keys())
+    d["train_cfg_keys"] = sorted(R.class_to_dict(ppo).keys())
+    json.dump(d, open(os.path.join(HERE, "constants.json"), "w"), indent=1)
+    print("constants.json", d["param_counts"])
+
+
+# ------------------------------------------------------------------------------------------------
+def run_gae(R, rewards, values, dones, last_values, gamma, lam):
+    T, N = rewards.shape
+    st = R.RolloutStorage(N, T, [4], [4], [2])
+    st.rewards[:] = rewards.unsqueeze(-1)
+    st.values[:] = values.unsqueeze(-1)
+    st.dones[:] = dones.unsqueeze(-1).byte()
+    st.compute_returns(last_values.view(N, 1), gamma, lam)
+    return st.returns.squeeze(-1), st.advantages.squeeze(-1)
+
+
+def gen_gae(R):
+    out = {}
+    r = torch.tensor([[1, .5], [0, -1], [2, .25], [.5, 1]])
+    v = torch.tensor([[.1, .2], [.3, .4], [.5, .6], [.7, .8]])
+    d = torch.tensor([[0, 0], [1, 0], [0, 0], [0, 1]])
+    lv = torch.tensor([0.9, 1.0])
+    ret, adv = run_gae(R, r, v, d, lv, 0.994, 0.9)
+    out.update(kat_rewards=npy(r), kat_values=npy(v), kat_dones=npy(d).astype(np.uint8), kat_last=npy(lv),
+               kat_returns=npy(ret), kat_adv=npy(adv))
+    g = torch.Generator().manual_seed(1234)
+    T, N = 60, 24
+    r = torch.rand(T, N, generator=g) * 0.3
+    v = torch.randn(T, N, generator=g) * 2 + 3
+    d = (torch.rand(T, N, generator=g) < 0.03)
+    d[-1, 3] = True
+    d[0, 5] = True
+    lv = torch.randn(N, generator=g) * 2 + 3
+    ret, adv = run_gae(R, r, v, d, lv, 0.994, 0.9)
+    out.update(rnd_rewards=npy(r), rnd_values=npy(v), rnd_dones=npy(d).astype(np.uint8), rnd_last=npy(lv),
+               rnd_returns=npy(ret), rnd_adv=npy(adv), gamma=0.994, lam=0.9)
+    np.savez_compressed(os.path.join(HERE, "gae.npz"), **out)
+    print("gae.npz kat returns", out["kat_returns"].ravel())
+
+
+# ------------------------------------------------------------------------------------------------
+def gen_policy_example():
+    path = os.path.join(H.REFERENCE_ROOT, "logs/XBot_ppo/exported/policies/policy_example.pt")
+    sha = hashlib.sha256(open(path, "rb").read()).hexdigest()
+    pol = torch.jit.load(path, map_location="cpu")
+    sd = pol.state_dict()
+    out = {("w_" + k.replace(".", "_")): npy(v) for k, v in sd.items()}
+    g = torch.Generator().manual_seed(7)
+    x_rand = torch.randn(16, 705, generator=g).clamp(-18, 18)
+    with torch.no_grad():
+        out["y_zeros"] = npy(pol(torch.zeros(1, 705)))
+        out["y_linspace"] = npy(pol(torch.linspace(-1, 1, 705)[None]))
+        out["x_rand"] = npy(x_rand)
+        out["y_rand"] = npy(pol(x_rand))
+    out["sha256"] = np.frombuffer(sha.encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(HERE, "policy_example.npz"), **out)
+    print("policy_example.npz", sha[:8], list(sd.keys()), out["y_zeros"].ravel()[:4])
+
+
+# ------------------------------------------------------------------------------------------------
+def gen_env_trace(R, N=32, S=36, seed=11):
+    torch.manual_seed(seed)
+    g = torch.Generator().manual_seed(seed)
+    fr = 0.1 + 1.9 * torch.rand(N, 1, generator=g)
+    bm = 15.0 + 10.0 * torch.rand(N, 1, generator=g) - 5.0
+    e, cfg = H.make_ref_env(N, frictions=fr, body_mass=bm)
+    ids_log = []
+    orig_resample = e._resample_commands
+    orig_reset_dofs = e._reset_dofs
+
+    def resample(env_ids):
+        ids_log.append(("cmd", env_ids.clone()))
+        return orig_resample(env_ids)
+
+    def reset_dofs(env_ids):
+        ids_log.append(("dof", env_ids.clone()))
+        return orig_reset_dofs(env_ids)
+
+    e._resample_commands = resample
+    e._reset_dofs = reset_dofs
+
+    def take(log, tag_prefix):
+        tag, t = log.pop(0)
+        assert tag.startswith(tag_prefix), (tag, tag_prefix)
+        return t
+
+    def scatter(ids, vals, width):
+        full = torch.zeros(N, width)
+        if len(ids):
+            full[ids] = vals.view(len(ids), width)
+        return full
+
+    H.RECORDER.enabled = True
+    with H.recording_rng():
+        H.finish_init(e)
+    log = H.RECORDER.pop_all()
+    ids = ids_log[:]
+    del ids_log[:]
+    assert [k for k, _ in ids] == ["dof", "cmd"]
+    prime_u_dof = take(log, "rand_float")
+    prime_u_cmd = torch.cat([take(log, "rand_float") for _ in range(3)], dim=1)
+    prime_z_obs = take(log, "randn_like")
+    assert not log
+    out = dict(friction=npy(fr), body_mass=npy(bm), prime_u_dof=npy(prime_u_dof), prime_u_cmd=npy(prime_u_cmd),
+               prime_z_obs=npy(prime_z_obs), prime_obs=npy(e.obs_buf), prime_priv=npy(e.privileged_obs_buf),
+               prime_commands=npy(e.commands), prime_dof_pos=npy(e.dof_pos))
+
+    # plant episode lengths so that time-outs, command resampling and pushes all fire inside S steps
+    ep = torch.randint(0, 2300, (N,), generator=g)
+    ep[0:4] = torch.tensor([2399, 2398, 2396, 2390])       # time-outs at steps 2,3,5,11
+    ep[4:8] = torch.tensor([799, 1598, 795, 2396])         # resamples at steps 1,2,5 ; 2396 -> t/o step 5
+    ep[8] = 0
+    e.episode_length_buf = ep.clone()                       # rebinding, as on_policy_runner.py:104-106 does
+    e.common_step_counter = 388                             # push fires at step 12
+    out["init_ep_len"] = npy(ep)
+    out["init_common_step_counter"] = 388
+
+    frames = [H.synth_sim_state(g, N) for _ in range(S)]
+    counter = {"n": 0, "t": 0}
+
+    def simulate(sim):
+        counter["n"] += 1
+        if counter["n"] % cfg.control.decimation == 0:
+            H.write_sim_state(e, frames[counter["t"]])
+
+    e.gym.simulate = simulate
+    keys = ["actions_in", "u_delay", "z_act", "u_cmd", "u_dof", "u_push", "z_obs", "root", "dof", "contact", "rigid",
+            "frame", "priv_frame", "rew", "reset", "time_out", "commands", "ep_len", "episode_sums", "torques",
+            "actions", "any_reset", "pushed", "extras_time_outs", "extras_episode", "root_after", "dof_after"]
+    rec = {k: [] for k in keys}
+    full_steps = [0, 5, 14, 24, S - 1]
+    for t in range(S):
+        counter["t"] = t
+        a_in = torch.randn(N, 12, generator=g) * 1.5
+        if t % 7 == 3:
+            a_in[t % N] *= 40.0                              # exercise the +-18 clip
+        with H.recording_rng():
+            obs, priv, rew, reset, extras = e.step(a_in.clone())
+        log = H.RECORDER.pop_all()
+        ids = ids_log[:]
+        del ids_log[:]
+        u_delay = take(log, "rand(").view(N)
+        z_act = take(log, "randn_like")
+        kind, cb_ids = ids.pop(0)
+        assert kind == "cmd"
+        u_cmd = torch.zeros(N, 6)
+        u_cmd[:, 0:3] = scatter(cb_ids, torch.cat([take(log, "rand_float") for _ in range(3)], dim=1), 3)
+        pushed = (e.common_step_counter % cfg.domain_rand.push_interval == 0)
+        u_push = torch.zeros(N, 5)
+        if pushed:
+            u_push[:, 0:2] = take(log, "rand_float")
+            u_push[:, 2:5] = take(log, "rand_float")
+        u_dof = torch.zeros(N, 12)
+        any_reset = bool(reset.any())
+        if any_reset:
+            kind, r_ids = ids.pop(0)
+            assert kind == "dof"
+            u_dof = scatter(r_ids, take(log, "rand_float"), 12)
+            kind, r_ids2 = ids.pop(0)
+            assert kind == "cmd" and torch.equal(r_ids, r_ids2)
+            u_cmd[:, 3:6] = scatter(r_ids, torch.cat([take(log, "rand_float") for _ in range(3)], dim=1), 3)
+        z_obs = take(log, "randn_like")
+        assert not log and not ids, (log, ids)
+        root, dof, contact, rigid = frames[t]
+        vals = dict(actions_in=a_in, u_delay=u_delay, z_act=z_act, u_cmd=u_cmd, u_dof=u_dof, u_push=u_push, z_obs=z_obs,
+                    root=root, dof=dof, contact=contact, rigid=rigid,
+                    frame=e.obs_history[-1], priv_frame=e.critic_history[-1], rew=rew, reset=reset,
+                    time_out=e.time_out_buf, commands=e.commands, ep_len=e.episode_length_buf,
+                    episode_sums=torch.stack([e.episode_sums[k] for k in e.reward_names], dim=1),
+                    torques=e.torques, actions=e.actions, any_reset=torch.tensor(any_reset),
+                    pushed=torch.tensor(bool(pushed)), extras_time_outs=extras["time_outs"],
+                    extras_episode=torch.stack([extras["episode"]["rew_" + k] for k in e.reward_names]),
+                    root_after=e.root_states, dof_after=e.dof_state)
+        for k in keys:
+            rec[k].append(npy(vals[k]))
+        if t in full_steps:
+            out["obs_step%d" % t] = npy(obs)
+            out["priv_step%d" % t] = npy(priv)
+    for k in keys:
+        out[k] = np.stack(rec[k])
+    out["full_steps"] = np.array(full_steps)
+    out.update(final_feet_air_time=npy(e.feet_air_time), final_last_contacts=npy(e.last_contacts),
+               final_feet_height=npy(e.feet_height), final_last_feet_z=npy(e.last_feet_z),
+               final_last_actions=npy(e.last_actions), final_last_last_actions=npy(e.last_last_actions),
+               final_last_dof_vel=npy(e.last_dof_vel), final_last_root_vel=npy(e.last_root_vel),
+               final_ref_dof_pos=npy(e.ref_dof_pos), final_push_force=npy(e.rand_push_force),
+               final_push_torque=npy(e.rand_push_torque), final_base_lin_vel=npy(e.base_lin_vel),
+               final_base_ang_vel=npy(e.base_ang_vel), final_projected_gravity=npy(e.projected_gravity),
+               final_base_euler=npy(e.base_euler_xyz))
+    np.savez_compressed(os.path.join(HERE, "env_trace.npz"), **out)
+    n_reset = int(out["reset"].sum())
+    n_to = int(out["time_out"].sum())
+    print("env_trace.npz N=%d S=%d resets=%d timeouts=%d pushed_steps=%s resample_rows=%d size=%.2f MB" % (
+        N, S, n_reset, n_to, np.nonzero(out["pushed"])[0].tolist(), int((out["u_cmd"][:, :, 0] != 0).sum()),
+        os.path.getsize(os.path.join(HERE, "env_trace.npz")) / 1e6))
+    H.RECORDER.enabled = False
+
+
+# ------------------------------------------------------------------------------------------------
+def gen_ppo_update(R, N=24, T=8, seed=3):
+    """Drive the reference PPO through one full iteration on a small actor/critic (same 705/219/12 interface)."""
+    torch.manual_seed(seed)
+    g = torch.Generator().manual_seed(seed)
+    ah, ch = [48, 32, 16], [40, 32, 16]
+    ac = R.ActorCritic(705, 219, 12, actor_hidden_dims=ah, critic_hidden_dims=ch, init_noise_std=1.0)
+    alg = R.PPO(ac, num_learning_epochs=2, num_mini_batches=4, clip_param=0.2, gamma=0.994, lam=0.9,
+                value_loss_coef=1.0, entropy_coef=0.001, learning_rate=1e-3, max_grad_norm=1.0,
+                use_clipped_value_loss=True, schedule="adaptive", desired_kl=0.01, device="cpu")
+    alg.init_storage(N, T, [705], [219], [12])
+    out = {("p0_" + k.replace(".", "_")): npy(v) for k, v in ac.state_dict().items()}
+    out["actor_hidden"] = np.array(ah)
+    out["critic_hidden"] = np.array(ch)
+    obs_l, priv_l, z_l, rew_l, done_l, to_l = [], [], [], [], [], []
+    act_l, val_l, logp_l, mu_l, sig_l = [], [], [], [], []
+    _orig_normal = torch.normal
+    for t in range(T):
+        obs = (torch.randn(N, 705, generator=g) * 1.2).clamp(-18, 18)
+        priv = (torch.randn(N, 219, generator=g) * 1.2).clamp(-18, 18)
+        z = torch.randn(N, 12, generator=g)
+        # Normal.sample() = torch.normal(loc.expand, scale.expand); substitute the recorded standard draw
+        torch.normal = lambda mean, std, **k: mean + std * z
+        try:
+            with torch.inference_mode():
+                a = alg.act(obs, priv)
+        finally:
+            torch.normal = _orig_normal
+        act_l.append(npy(a)); val_l.append(npy(alg.transition.values)); logp_l.append(npy(alg.transition.actions_log_prob))
+        mu_l.append(npy(alg.transition.action_mean)); sig_l.append(npy(alg.transition.action_sigma))
+        rew = torch.rand(N, generator=g) * 0.2
+        done = torch.rand(N, generator=g) < 0.15
+        tout = done & (torch.rand(N, generator=g) < 0.5)
+        with torch.inference_mode():
+            alg.process_env_step(rew, done, {"time_outs": tout})
+        obs_l.append(npy(obs)); priv_l.append(npy(priv)); z_l.append(npy(z)); rew_l.append(npy(rew))
+        done_l.append(npy(done)); to_l.append(npy(tout))
+    last_priv = (torch.randn(N, 219, generator=g) * 1.2).clamp(-18, 18)
+    with torch.inference_mode():
+        alg.compute_returns(last_priv)
+    st = alg.storage
+    out.update(obs=np.stack(obs_l), priv=np.stack(priv_l), z=np.stack(z_l), rew_in=np.stack(rew_l), done=np.stack(done_l),
+               time_outs=np.stack(to_l), actions=np.stack(act_l), values=np.stack(val_l), logp=np.stack(logp_l),
+               mu=np.stack(mu_l), sigma=np.stack(sig_l), last_priv=npy(last_priv),
+               st_rewards=npy(st.rewards), st_returns=npy(st.returns), st_advantages=npy(st.advantages))
+    perm_holder = {}
+    _orig_randperm = torch.randperm
+
+    def randperm(n, **k):
+        p = _orig_randperm(n, generator=g)
+        perm_holder["p"] = p.clone()
+        return p
+
+    lrs, losses = [], []
+    _orig_step = alg.optimizer.step
+
+    def step(*a, **k):
+        lrs.append(alg.optimizer.param_groups[0]["lr"])
+        if len(lrs) == 1:   # gradients of the first minibatch, after clipping
+            for kname, p in ac.named_parameters():
+                out["g0_" + kname.replace(".", "_")] = npy(p.grad)
+        r = _orig_step(*a, **k)
+        if len(lrs) == 1:
+            for kname, p in ac.named_parameters():
+                out["p1_" + kname.replace(".", "_")] = npy(p.data)
+        return r
+
+    alg.optimizer.step = step
+    torch.randperm = randperm
+    try:
+        mvl, msl = alg.update()
+    finally:
+        torch.randperm = _orig_randperm
+    out["perm"] = npy(perm_holder["p"])
+    out["lrs"] = np.array(lrs)
+    out["mean_value_loss"] = np.array(mvl)
+    out["mean_surrogate_loss"] = np.array(msl)
+    out["final_lr"] = np.array(alg.learning_rate)
+    for k, v in ac.state_dict().items():
+        out["pF_" + k.replace(".", "_")] = npy(v)
+    np.savez_compressed(os.path.join(HERE, "ppo_update.npz"), **out)
+    print("ppo_update.npz lrs", lrs, "losses", mvl, msl)
+
+
+if __name__ == "__main__":
+    R = H.load_reference()
+    gen_constants(R)
+    gen_gae(R)
+    gen_policy_example()
+    gen_env_trace(R)
+    gen_ppo_update(R)

@@ -1,0 +1,298 @@
+"""Fixture-generation harness: runs the UNMODIFIED reference (`/root/reference/humanoid`) on CPU.
+
+Test infrastructure only.  It is imported by `tests/golden/gen_fixtures.py` (which writes the
+committed `tests/golden/*.npz` vectors) and by the in-container-only cross-check tests
+(`tests/test_oracle_vs_reference.py`, skipped when `/root/reference` is absent, e.g. on the GPU box).
+
+Recipe = SURVEY.md Appendix B: stub the three absent third-party imports (`isaacgym`, `wandb`,
+`torch.utils.tensorboard`), restate `isaacgym.torch_utils` (closed source, Isaac Gym Preview 4,
+pinned only by the comment at reference `setup.py:43`) as standard xyzw-quaternion math, build
+`XBotLFreeEnv` with `object.__new__` and hand it four synthetic sim tensors where
+`legged_robot.py:438-457` would acquire PhysX buffers.
+
+Every random draw the reference makes on the path is recorded so that parity runs can replay
+them through noise tables.
+"""
+import sys
+import types
+
+import numpy as np
+import torch
+
+REFERENCE_ROOT = "/root/reference"
+
+DOF_NAMES = [  # URDF order, resources/robots/XBot/urdf/XBot-L.urdf:1415-2516
+    "left_leg_roll_joint", "left_leg_yaw_joint", "left_leg_pitch_joint",
+    "left_knee_joint", "left_ankle_pitch_joint", "left_ankle_roll_joint",
+    "right_leg_roll_joint", "right_leg_yaw_joint", "right_leg_pitch_joint",
+    "right_knee_joint", "right_ankle_pitch_joint", "right_ankle_roll_joint",
+]
+EFFORT = [100., 100., 250., 250., 100., 100., 100., 100., 250., 250., 100., 100.]
+NUM_BODIES = 13
+FEET_INDICES = [6, 12]
+KNEE_INDICES = [4, 10]
+BASE_INDICES = [0]
+
+
+class DrawRecorder:
+    """Records every call of the reference's RNG entry points, in call order."""
+
+    def __init__(self):
+        self.enabled = False
+        self.log = []  # list of (tag, tensor)
+
+    def rec(self, tag, t):
+        if self.enabled:
+            self.log.append((tag, t.detach().clone()))
+        return t
+
+    def pop_all(self):
+        out, self.log = self.log, []
+        return out
+
+
+RECORDER = DrawRecorder()
+_LOADED = {}
+_ORIG_RAND = torch.rand  # the harness's own draws bypass the recording wrapper below
+
+
+def load_reference():
+    """Import the reference's packages under stubs; returns a namespace of its classes."""
+    if _LOADED:
+        return types.SimpleNamespace(**_LOADED)
+    if REFERENCE_ROOT not in sys.path:
+        sys.path.insert(0, REFERENCE_ROOT)
+    if "humanoid" in sys.modules and not getattr(sys.modules["humanoid"], "__file__", "").startswith(REFERENCE_ROOT):
+        raise RuntimeError("a different `humanoid` package is already imported in this process; "
+                           "run the reference harness in its own interpreter")
+    for n in ["isaacgym", "isaacgym.gymapi", "isaacgym.gymtorch", "isaacgym.gymutil",
+              "isaacgym.torch_utils", "isaacgym.terrain_utils", "wandb", "torch.utils.tensorboard"]:
+        sys.modules[n] = types.ModuleType(n)
+    ig = sys.modules["isaacgym"]
+    for s in ["gymapi", "gymtorch", "gymutil", "torch_utils", "terrain_utils"]:
+        setattr(ig, s, sys.modules["isaacgym." + s])
+    sys.modules["wandb"].init = lambda **k: None
+
+    class _SW:
+        def __init__(self, *a, **k):
+            self.scalars = []
+
+        def add_scalar(self, *a, **k):
+            self.scalars.append(a)
+
+    sys.modules["torch.utils.tensorboard"].SummaryWriter = _SW
+
+    tu = sys.modules["isaacgym.torch_utils"]
+
+    def torch_rand_float(lo, hi, shape, device):
+        r = RECORDER.rec("rand_float%s" % (tuple(shape),), _ORIG_RAND(*shape, device=device))
+        return (hi - lo) * r + lo
+
+    def quat_rotate_inverse(q, v):
+        w = q[:, -1]
+        u = q[:, :3]
+        a = v * (2.0 * w ** 2 - 1.0).unsqueeze(-1)
+        b = torch.cross(u, v, dim=-1) * w.unsqueeze(-1) * 2.0
+        c = u * torch.bmm(u.view(-1, 1, 3), v.view(-1, 3, 1)).squeeze(-1) * 2.0
+        return a - b + c
+
+    def quat_apply(a, b):
+        sh = b.shape
+        a = a.reshape(-1, 4)
+        b = b.reshape(-1, 3)
+        u = a[:, :3]
+        t = u.cross(b, dim=-1) * 2
+        return (b + a[:, 3:] * t + u.cross(t, dim=-1)).view(sh)
+
+    def get_euler_xyz(q):
+        x, y, z, w = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+        roll = torch.atan2(2.0 * (w * x + y * z), w * w - x * x - y * y + z * z)
+        sp = 2.0 * (w * y - z * x)
+        pitch = torch.where(sp.abs() >= 1, torch.sign(sp) * (np.pi / 2.0), torch.asin(sp))
+        yaw = torch.atan2(2.0 * (w * z + x * y), w * w + x * x - y * y - z * z)
+        return roll % (2 * np.pi), pitch % (2 * np.pi), yaw % (2 * np.pi)
+
+    tu.torch_rand_float = torch_rand_float
+    tu.quat_rotate_inverse = quat_rotate_inverse
+    tu.quat_apply = quat_apply
+    tu.get_euler_xyz = get_euler_xyz
+    tu.normalize = lambda x, eps=1e-9: x / x.norm(p=2, dim=-1).clamp(min=eps).unsqueeze(-1)
+    tu.to_torch = lambda x, dtype=torch.float, device="cpu", requires_grad=False: torch.tensor(
+        x, dtype=dtype, device=device, requires_grad=requires_grad)
+    tu.get_axis_params = lambda v, idx: [0., 0., v]
+    tu.__all__ = [k for k in vars(tu) if not k.startswith("_")]
+    gt = sys.modules["isaacgym.gymtorch"]
+    gt.unwrap_tensor = lambda t: t
+    gt.wrap_tensor = lambda t: t
+
+    from humanoid.envs import XBotLCfg, XBotLCfgPPO, XBotLFreeEnv  # noqa: E402
+    from humanoid.algo import PPO, ActorCritic, RolloutStorage, OnPolicyRunner  # noqa: E402
+    from humanoid.utils.helpers import class_to_dict  # noqa: E402
+    import humanoid.envs.custom.humanoid_env as henv  # noqa: E402
+
+    _LOADED.update(dict(XBotLCfg=XBotLCfg, XBotLCfgPPO=XBotLCfgPPO, XBotLFreeEnv=XBotLFreeEnv, PPO=PPO,
+                        ActorCritic=ActorCritic, RolloutStorage=RolloutStorage, OnPolicyRunner=OnPolicyRunner,
+                        class_to_dict=class_to_dict, henv=henv, tu=tu))
+    return types.SimpleNamespace(**_LOADED)
+
+
+class _NoopGym:
+    """Stands where `gymapi.acquire_gym()` would: every attribute is a no-op callable."""
+
+    def __getattr__(self, name):
+        return lambda *a, **k: None
+
+
+class _recording_rng:
+    """Context manager wrapping torch.rand / torch.randn_like so the env's direct draws are recorded
+    (`humanoid_env.py:194,196,251`)."""
+
+    def __enter__(self):
+        self._rand, self._randn_like = torch.rand, torch.randn_like
+
+        def rand(*a, **k):
+            t = self._rand(*a, **k)
+            if RECORDER.enabled:
+                RECORDER.log.append(("rand%s" % (tuple(t.shape),), t.detach().clone()))
+            return t
+
+        def randn_like(x, *a, **k):
+            t = self._randn_like(x, *a, **k)
+            if RECORDER.enabled:
+                RECORDER.log.append(("randn_like%s" % (tuple(t.shape),), t.detach().clone()))
+            return t
+
+        torch.rand, torch.randn_like = rand, randn_like
+        return self
+
+    def __exit__(self, *a):
+        torch.rand, torch.randn_like = self._rand, self._randn_like
+
+
+def make_ref_env(num_envs, frictions=None, body_mass=None, frame_stack=15, c_frame_stack=3):
+    """Build the reference's XBotLFreeEnv without PhysX."""
+    R = load_reference()
+    gt = sys.modules["isaacgym.gymtorch"]
+    cfg = R.XBotLCfg()
+    cfg.env.num_envs = num_envs
+    cfg.env.frame_stack = frame_stack
+    cfg.env.c_frame_stack = c_frame_stack
+    cfg.env.num_observations = frame_stack * cfg.env.num_single_obs
+    cfg.env.num_privileged_obs = c_frame_stack * cfg.env.single_num_privileged_obs
+    N = num_envs
+    e = object.__new__(R.XBotLFreeEnv)
+    e.cfg = cfg
+    e.sim_params = types.SimpleNamespace(dt=cfg.sim.dt)
+    e.height_samples = None
+    e.debug_viz = False
+    e.init_done = False
+    e._parse_cfg(cfg)
+    e.gym = _NoopGym()
+    e.sim = None
+    e.viewer = None
+    e.headless = True
+    e.enable_viewer_sync = False
+    e.device = "cpu"
+    e.sim_device = "cpu"
+    e.physics_engine = None
+    e.num_envs = N
+    e.num_obs = cfg.env.num_observations
+    e.num_privileged_obs = cfg.env.num_privileged_obs
+    e.num_actions = cfg.env.num_actions
+    e.num_dof = e.num_dofs = 12
+    e.num_bodies = NUM_BODIES
+    e.dof_names = list(DOF_NAMES)
+    e.up_axis_idx = 2
+    e.custom_origins = False
+    # BaseTask buffers, base_task.py:71-94
+    e.obs_buf = torch.zeros(N, e.num_obs)
+    e.rew_buf = torch.zeros(N)
+    e.neg_reward_buf = torch.zeros(N)
+    e.pos_reward_buf = torch.zeros(N)
+    e.reset_buf = torch.ones(N, dtype=torch.long)
+    e.episode_length_buf = torch.zeros(N, dtype=torch.long)
+    e.time_out_buf = torch.zeros(N, dtype=torch.bool)
+    e.privileged_obs_buf = torch.zeros(N, e.num_privileged_obs)
+    e.extras = {}
+    # what _create_envs (legged_robot.py:588-681) would have produced
+    e.env_origins = torch.zeros(N, 3)
+    num_cols = np.floor(np.sqrt(N))
+    num_rows = np.ceil(N / num_cols)
+    xx, yy = torch.meshgrid(torch.arange(num_rows), torch.arange(num_cols), indexing="ij")
+    e.env_origins[:, 0] = cfg.env.env_spacing * xx.flatten()[:N]
+    e.env_origins[:, 1] = cfg.env.env_spacing * yy.flatten()[:N]
+    st = cfg.init_state
+    e.base_init_state = torch.tensor(st.pos + st.rot + st.lin_vel + st.ang_vel, dtype=torch.float)
+    e.env_frictions = torch.ones(N, 1) if frictions is None else frictions.clone().view(N, 1)
+    e.body_mass = torch.full((N, 1), 15.0) if body_mass is None else body_mass.clone().view(N, 1)
+    e.torque_limits = torch.tensor(EFFORT) * cfg.safety.torque_limit
+    e.feet_indices = torch.tensor(FEET_INDICES, dtype=torch.long)
+    e.knee_indices = torch.tensor(KNEE_INDICES, dtype=torch.long)
+    e.penalised_contact_indices = torch.tensor(BASE_INDICES, dtype=torch.long)
+    e.termination_contact_indices = torch.tensor(BASE_INDICES, dtype=torch.long)
+    # the four sim tensors, acquisition order legged_robot.py:438-441
+    e._sim_root = torch.zeros(N, 13)
+    e._sim_root[:, :] = e.base_init_state
+    e._sim_root[:, :3] += e.env_origins
+    e._sim_dof = torch.zeros(N * 12, 2)
+    e._sim_contact = torch.zeros(N * NUM_BODIES, 3)
+    e._sim_rigid = torch.zeros(N * NUM_BODIES, 13)
+    e.gym.acquire_actor_root_state_tensor = lambda sim: e._sim_root
+    e.gym.acquire_dof_state_tensor = lambda sim: e._sim_dof
+    e.gym.acquire_net_contact_force_tensor = lambda sim: e._sim_contact
+    e.gym.acquire_rigid_body_state_tensor = lambda sim: e._sim_rigid
+    gt.wrap_tensor = lambda t: t
+    e._init_buffers()
+    e._prepare_reward_function()
+    e.init_done = True
+    # XBotLFreeEnv.__init__, humanoid_env.py:78-81
+    e.last_feet_z = 0.05
+    e.feet_height = torch.zeros((N, 2))
+    return e, cfg
+
+
+def finish_init(e):
+    """The tail of XBotLFreeEnv.__init__ (humanoid_env.py:80-81): reset all + prime observations."""
+    e.reset_idx(torch.tensor(range(e.num_envs)))
+    e.compute_observations()
+
+
+def synth_sim_state(gen, N, stance_hint=None):
+    """One frame of seeded synthetic sim-state tensors, AoS like Isaac Gym's."""
+    root = torch.zeros(N, 13)
+    root[:, 0:2] = torch.randn(N, 2, generator=gen) * 0.5
+    root[:, 2] = 0.9 + 0.02 * (2 * torch.rand(N, generator=gen) - 1)
+    q = torch.cat([torch.randn(N, 3, generator=gen) * 0.15, torch.ones(N, 1)], dim=1)
+    root[:, 3:7] = q / q.norm(dim=1, keepdim=True)
+    root[:, 7:13] = torch.randn(N, 6, generator=gen) * 0.3
+    dof = torch.zeros(N, 12, 2)
+    dof[:, :, 0] = torch.randn(N, 12, generator=gen) * 0.2
+    dof[:, :, 1] = torch.randn(N, 12, generator=gen) * 1.5
+    contact = torch.zeros(N, NUM_BODIES, 3)
+    u = torch.rand(N, 2, generator=gen)
+    on = (torch.rand(N, 2, generator=gen) > 0.4).float()
+    contact[:, FEET_INDICES, 2] = 900.0 * u * on
+    contact[:, FEET_INDICES, 0:2] = torch.randn(N, 2, 2, generator=gen) * 40.0 * on.unsqueeze(-1)
+    hit = (torch.rand(N, generator=gen) < 0.04).float()
+    contact[:, 0, :] = torch.randn(N, 3, generator=gen) * 2.0 * hit.unsqueeze(-1)
+    small = (torch.rand(N, generator=gen) < 0.05).float() * (1 - hit)
+    contact[:, 0, :] += torch.randn(N, 3, generator=gen) * 0.2 * small.unsqueeze(-1)
+    rigid = torch.randn(N, NUM_BODIES, 13, generator=gen) * 0.2
+    rigid[:, FEET_INDICES, 2] = 0.03 + 0.09 * torch.rand(N, 2, generator=gen)
+    rigid[:, FEET_INDICES[0], 1] += 0.15
+    rigid[:, FEET_INDICES[1], 1] -= 0.15
+    rigid[:, KNEE_INDICES[0], 1] += 0.12
+    rigid[:, KNEE_INDICES[1], 1] -= 0.12
+    return root, dof.reshape(N * 12, 2), contact.reshape(N * NUM_BODIES, 3), rigid.reshape(N * NUM_BODIES, 13)
+
+
+def write_sim_state(e, frame):
+    root, dof, contact, rigid = frame
+    e._sim_root.copy_(root)
+    e._sim_dof.copy_(dof)
+    e._sim_contact.copy_(contact)
+    e._sim_rigid.copy_(rigid)
+
+
+def recording_rng():
+    return _recording_rng()

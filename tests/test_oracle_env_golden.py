@@ -1,0 +1,94 @@
+"""Pins oracle/xbot_env_oracle.py against tests/golden/env_trace.npz, which was recorded by running the
+reference's own XBotLFreeEnv.step (tests/golden/gen_fixtures.py).  CPU only."""
+import os
+
+import numpy as np
+import torch
+
+from oracle import xbot_constants as C
+from oracle.xbot_env_oracle import XBotEnvOracle
+
+T = lambda a: torch.from_numpy(np.asarray(a))
+
+
+def _load(golden_dir):
+    return np.load(os.path.join(golden_dir, "env_trace.npz"))
+
+
+def _prime(G):
+    N = G["friction"].shape[0]
+    o = XBotEnvOracle(N, frictions=T(G["friction"]), body_mass=T(G["body_mass"]))
+    o.prime(T(G["prime_u_dof"]), T(G["prime_u_cmd"]), T(G["prime_z_obs"]))
+    return o
+
+
+def test_prime_matches_reference(golden_dir):
+    G = _load(golden_dir)
+    o = _prime(G)
+    assert torch.equal(o.obs, T(G["prime_obs"]))
+    assert torch.equal(o.priv, T(G["prime_priv"]))
+    assert torch.equal(o.commands, T(G["prime_commands"]))
+    assert torch.equal(o.sim.dof_pos, T(G["prime_dof_pos"]))
+
+
+def test_trace_matches_reference(golden_dir):
+    G = _load(golden_dir)
+    o = _prime(G)
+    o.ep_len = T(G["init_ep_len"]).clone()
+    o.common_step_counter = int(G["init_common_step_counter"])
+    S = G["rew"].shape[0]
+    full = {int(s) for s in G["full_steps"]}
+    saw = dict(reset=0, timeout=0, push=0, resample=0, stale=0)
+    for t in range(S):
+        a = o.pre_physics(T(G["actions_in"][t]), T(G["u_delay"][t]), T(G["z_act"][t]))
+        tq = o.pd_torques()
+        o.sim.load(T(G["root"][t]), T(G["dof"][t]), T(G["contact"][t]), T(G["rigid"][t]))
+        obs, priv, rew, reset, info = o.post_physics(T(G["u_cmd"][t]), T(G["u_dof"][t]), T(G["u_push"][t]), T(G["z_obs"][t]))
+        # masks / indices: bit exact
+        assert torch.equal(reset, T(G["reset"][t])), t
+        assert torch.equal(o.time_out, T(G["time_out"][t])), t
+        assert torch.equal(o.ep_len, T(G["ep_len"][t])), t
+        assert info["any_reset"] == bool(G["any_reset"][t]) and info["pushed"] == bool(G["pushed"][t])
+        # floats: the restatement uses the same torch ops in the same order -> identical bits
+        assert torch.equal(tq, T(G["torques"][t])), t
+        assert torch.equal(o.actions, T(G["actions"][t])), t
+        assert torch.equal(info["frame"], T(G["frame"][t])), t
+        assert torch.equal(info["priv_frame"], T(G["priv_frame"][t])), t
+        assert torch.equal(rew, T(G["rew"][t])), t
+        assert torch.equal(o.commands, T(G["commands"][t])), t
+        assert torch.equal(o.episode_sums, T(G["episode_sums"][t])), t
+        assert torch.equal(o.sim.root, T(G["root_after"][t])), t
+        assert torch.equal(torch.stack((o.sim.dof_pos, o.sim.dof_vel), -1).view(-1, 2), T(G["dof_after"][t])), t
+        assert torch.equal(o.extras_time_outs, T(G["extras_time_outs"][t])), t   # stale-by-design (App. A item 2)
+        np.testing.assert_allclose(o.extras_episode.numpy(), G["extras_episode"][t], rtol=2e-6, atol=1e-9)
+        if t in full:
+            assert torch.equal(obs, T(G["obs_step%d" % t])), t
+            assert torch.equal(priv, T(G["priv_step%d" % t])), t
+        saw["reset"] += int(reset.sum()); saw["timeout"] += int(o.time_out.sum()); saw["push"] += int(info["pushed"])
+        saw["resample"] += int((o.ep_len % C.RESAMPLE_STEPS == 0).sum() - reset.sum())
+        saw["stale"] += int((not info["any_reset"]) and bool(o.extras_time_outs.any()))
+    # the trace must have exercised every event class
+    assert saw["reset"] > 10 and saw["timeout"] >= 3 and saw["push"] == 1
+    for k in ("feet_air_time", "last_contacts", "feet_height", "last_feet_z", "last_actions", "last_last_actions",
+              "last_dof_vel", "last_root_vel", "ref_dof_pos", "base_lin_vel", "base_ang_vel", "projected_gravity"):
+        assert torch.equal(getattr(o, k), T(G["final_" + k])), k
+    assert torch.equal(o.base_euler, T(G["final_base_euler"]))
+    assert torch.equal(o.push_force, T(G["final_push_force"])) and torch.equal(o.push_torque, T(G["final_push_torque"]))
+
+
+def test_constants_match_reference(golden_dir):
+    import json
+    K = json.load(open(os.path.join(golden_dir, "constants.json")))
+    assert K["reward_names"] == C.REWARD_NAMES
+    assert K["reward_scales_dt"] == C.REWARD_SCALES_DT
+    assert K["dt"] == C.DT and K["max_episode_length"] == C.MAX_EPISODE_LENGTH
+    assert K["resample_steps"] == C.RESAMPLE_STEPS and K["push_interval"] == C.PUSH_INTERVAL
+    assert K["p_gains"] == C.P_GAINS and K["d_gains"] == C.D_GAINS
+    assert np.allclose(K["torque_limits"], np.array(C.EFFORT, dtype=np.float32) * np.float32(C.TORQUE_LIMIT_FACTOR))
+    assert K["base_init_state"] == [float(np.float32(x)) for x in C.BASE_INIT_STATE]
+    assert K["param_counts"] == dict(actor=527244, critic=398849, std=12)
+    assert K["num_obs"] == 705 and K["num_privileged_obs"] == 219
+    assert (K["gamma"], K["lam"], K["clip_param"], K["entropy_coef"]) == (C.GAMMA, C.LAM, C.CLIP_PARAM, C.ENTROPY_COEF)
+    assert (K["learning_rate"], K["desired_kl"], K["max_grad_norm"]) == (C.LEARNING_RATE, C.DESIRED_KL, C.MAX_GRAD_NORM)
+    assert K["actor_hidden_dims"] == C.ACTOR_HIDDEN and K["critic_hidden_dims"] == C.CRITIC_HIDDEN
+    assert K["num_steps_per_env"] == C.NUM_STEPS_PER_ENV and K["seed"] == C.SEED
