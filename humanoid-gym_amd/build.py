@@ -1,0 +1,59 @@
+#!/usr/bin/env python
+"""Builds libhgym_hip.so (gfx950) in-tree: `python humanoid-gym_amd/build.py [--force]`.
+
+hipcc cross-compiles without a GPU, so this runs in the build container; the resulting
+`humanoid-gym_amd/lib/libhgym_hip.so` is git-ignored but travels to the GPU box with the snapshot.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+OBJDIR = os.path.join(LIBDIR, "obj")
+LIB = os.path.join(LIBDIR, "libhgym_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+ARCH = "gfx950"
+COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
+# per-file extra flags: the env / GAE arithmetic mirrors the reference's un-fused fp32 op order
+EXTRA = {
+    "hgym_env.hip": ["-ffp-contract=off"],
+    "hgym_gae.hip": ["-ffp-contract=off"],
+}
+
+
+def _newer(src, dst, deps):
+    if not os.path.exists(dst):
+        return True
+    t = os.path.getmtime(dst)
+    return any(os.path.getmtime(p) > t for p in [src] + deps)
+
+
+def build(force=False, verbose=True):
+    os.makedirs(OBJDIR, exist_ok=True)
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".h"))]
+    headers.append(os.path.join(os.path.dirname(HERE), "include", "hgym.h"))
+    srcs = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+    objs, rebuilt = [], False
+    for f in srcs:
+        src = os.path.join(CSRC, f)
+        obj = os.path.join(OBJDIR, f.replace(".hip", ".o"))
+        objs.append(obj)
+        if force or _newer(src, obj, headers):
+            cmd = [HIPCC] + COMMON + EXTRA.get(f, []) + ["-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+            rebuilt = True
+    if rebuilt or not os.path.exists(LIB):
+        cmd = [HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)
+    print(LIB)

@@ -1,0 +1,120 @@
+// hgym_common.hpp -- error plumbing, launch helpers, Philox4x32-10, small math shared by all kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/hgym.h"
+
+#define HG_HD __host__ __device__ __forceinline__
+
+namespace hgym {
+
+// ---------------------------------------------------------------------------------------------- errors
+char* last_error_buf();  // thread-local, defined in hgym_capi.hip
+
+#define HG_FAIL(code, ...)                                            \
+    do {                                                              \
+        snprintf(::hgym::last_error_buf(), 512, __VA_ARGS__);         \
+        return (code);                                                \
+    } while (0)
+
+#define HG_REQUIRE(cond, code, ...) \
+    do {                            \
+        if (!(cond)) HG_FAIL(code, __VA_ARGS__); \
+    } while (0)
+
+#define HG_CHECK_LAUNCH(what)                                                                   \
+    do {                                                                                        \
+        hipError_t e_ = hipGetLastError();                                                      \
+        if (e_ != hipSuccess) HG_FAIL(HGYM_E_LAUNCH, "%s: %s", what, hipGetErrorString(e_));     \
+    } while (0)
+
+static inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+static inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
+
+// ---------------------------------------------------------------------------------------------- Philox4x32-10
+// Counter-based RNG (Salmon et al. 2011), keyed by (seed); counter = (env, step_lo, step_hi, slot).
+// Pure 32-bit integer arithmetic: identical on host (oracle/philox.py restates it) and device.
+struct U4 {
+    uint32_t x, y, z, w;
+};
+
+HG_HD uint32_t mulhi32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * (uint64_t)b) >> 32); }
+
+HG_HD U4 philox4x32_10(U4 c, uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = mulhi32(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
+        const uint32_t hi1 = mulhi32(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+        U4 n;
+        n.x = hi1 ^ c.y ^ k0;
+        n.y = lo1;
+        n.z = hi0 ^ c.w ^ k1;
+        n.w = lo0;
+        c = n;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return c;
+}
+
+// 24-bit mantissa uniform in [0,1): exact in fp32, never 1.0
+HG_HD float u01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
+
+struct RngKey {
+    uint32_t k0, k1;     // seed
+    uint32_t s0, s1;     // step
+};
+
+HG_HD U4 rng4(const RngKey& k, uint32_t env, uint32_t slot) {
+    U4 c;
+    c.x = env;
+    c.y = k.s0;
+    c.z = k.s1;
+    c.w = slot;
+    return philox4x32_10(c, k.k0, k.k1);
+}
+
+// Box-Muller on two uniforms; u1 is mapped to (0,1] so that log() is finite.
+HG_HD void box_muller(uint32_t a, uint32_t b, float& z0, float& z1) {
+    const float u1 = 1.0f - u01(a);
+    const float u2 = u01(b);
+    const float r = sqrtf(-2.0f * logf(u1));
+    const float t = 6.2831855f * u2;
+    z0 = r * cosf(t);
+    z1 = r * sinf(t);
+}
+
+// Philox slot map (one counter word); every consumer owns a disjoint range.
+enum : uint32_t {
+    SLOT_DELAY_CMD = 0,   // x: action delay, y,z,w: callback command resample
+    SLOT_CMD_RESET = 1,   // x,y,z: reset command resample
+    SLOT_ACT = 2,         // 2..4  : 12 action-noise normals
+    SLOT_DOF = 5,         // 5..7  : 12 reset joint offsets
+    SLOT_PUSH = 8,        // 8..9  : 5 push draws
+    SLOT_OBS = 16,        // 16..27: 47 observation-noise normals (pairs)
+    SLOT_PHYS = 32,       // 32..47: synthetic physics
+    SLOT_POLICY = 64      // 64..66: 12 policy-sampling normals
+};
+
+// standard normal number `i` of a block of normals starting at slot `base` (2 normals per uniform pair)
+HG_HD float normal_at(const RngKey& k, uint32_t env, uint32_t base, int i) {
+    const int pair = i >> 1;                 // pair index
+    const U4 r = rng4(k, env, base + (uint32_t)(pair >> 1));
+    float z0, z1;
+    if (pair & 1) box_muller(r.z, r.w, z0, z1);
+    else box_muller(r.x, r.y, z0, z1);
+    return (i & 1) ? z1 : z0;
+}
+
+HG_HD float uniform_at(const RngKey& k, uint32_t env, uint32_t base, int i) {
+    const U4 r = rng4(k, env, base + (uint32_t)(i >> 2));
+    const int j = i & 3;
+    return u01(j == 0 ? r.x : j == 1 ? r.y : j == 2 ? r.z : r.w);
+}
+
+HG_HD float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+
+}  // namespace hgym

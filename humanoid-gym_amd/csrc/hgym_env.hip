@@ -1,0 +1,254 @@
+// hgym_env.hip -- env-side kernels of the XBot-L hot path for gfx950.
+//
+// One launch per vec-step.  A workgroup owns a contiguous slice of `envs_per_block` envs:
+//   phase A  one lane per env: (optionally) action processing + synthetic physics, then the whole
+//            post-physics pipeline -- derived state, command resampling, termination, the 22 reward
+//            terms, mask-driven reset -- on env-major SoA state (lane i <-> env i: every load/store of a
+//            state component is one coalesced 256-B wavefront access).  The clean new 47/73-float
+//            frames are staged in LDS.
+//   phase B  all lanes: the 15x47 / 3x73 history stack is produced as ONE contiguous run of the
+//            row-major output per workgroup (coalesced stores), reading the older frames from an
+//            HBM ring buffer, adding observation noise to the newest frame, pushing it into the
+//            ring, zeroing the history of envs that reset, clipping to +-18.
+// HBM traffic per env-step is the algorithmic minimum of SURVEY.md §8d: read 14x47+2x73 old frames,
+// write 15x47+3x73 stacked outputs + 47+73 ring frames, ~250 floats of sim input / env state.
+// The kernel is bandwidth/latency bound; no MFMA here by design.
+#include "hgym_env_math.hpp"
+
+namespace hgym {
+
+template <int H_T, int HC_T>
+__global__ __launch_bounds__(256) void env_step_kernel(const EnvArgs A) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int64_t csc0 = A.st.counters[0];
+    const int64_t ring_step = A.st.counters[2];
+    env_step_phase_a(A, blockIdx.x, threadIdx.x, smem, csc0);
+    __syncthreads();
+    env_step_phase_b<H_T, HC_T>(A, blockIdx.x, threadIdx.x, blockDim.x, smem, csc0, ring_step);
+}
+
+__global__ __launch_bounds__(256) void env_finalize_kernel(const EnvArgs A) {
+    env_finalize_part1(A, threadIdx.x, blockDim.x);
+    __syncthreads();
+    if (threadIdx.x == 0) env_finalize_part2(A);
+}
+
+__global__ __launch_bounds__(256) void pre_physics_kernel(const EnvArgs A) {
+    const int N = A.cfg.num_envs;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= N) return;
+    const int64_t csc0 = A.st.counters[0];
+    RngKey rk = {(uint32_t)A.cfg.seed, (uint32_t)(A.cfg.seed >> 32), (uint32_t)csc0, (uint32_t)(csc0 >> 32)};
+    pre_physics_env(A, rk, e, N);
+}
+
+__global__ __launch_bounds__(256) void pd_torques_kernel(const EnvArgs A) {
+    const int N = A.cfg.num_envs;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= N) return;
+    pd_torques_env(A, e, N);
+}
+
+__global__ __launch_bounds__(256) void synth_physics_kernel(const EnvArgs A) {
+    const int N = A.cfg.num_envs;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= N) return;
+    const int64_t csc0 = A.st.counters[0];
+    RngKey rk = {(uint32_t)A.cfg.seed, (uint32_t)(A.cfg.seed >> 32), (uint32_t)csc0, (uint32_t)(csc0 >> 32)};
+    synth_physics_env(A, rk, e, N);
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+int device_cus() {
+    static int cus = -1;
+    if (cus < 0) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) cus = 0;
+        else cus = p.multiProcessorCount;
+    }
+    return cus;
+}
+
+static int pick_envs_per_block(int N) {
+    const int cus = device_cus() > 0 ? device_cus() : 256;
+    int E = N / (2 * cus);           // aim for ~2 workgroups per CU so phase A of one hides under phase B of another
+    E = (E / 4) * 4;                 // slices start on 16-byte boundaries of the row-major outputs
+    if (E < 4) E = 4;
+    if (E > 64) E = 64;
+    return E;
+}
+
+static int32_t check_common(const HgymEnvConfig* cfg, const HgymSimTensors* sim, const HgymEnvState* st) {
+    HG_REQUIRE(cfg && st, HGYM_E_BADARG, "null cfg/state");
+    HG_REQUIRE(cfg->num_envs > 0, HGYM_E_SHAPE, "num_envs=%d", cfg->num_envs);
+    HG_REQUIRE(cfg->frame_stack >= 1 && cfg->c_frame_stack >= 1, HGYM_E_SHAPE, "frame_stack/c_frame_stack must be >= 1");
+    HG_REQUIRE(cfg->heading_command == 1, HGYM_E_UNSUPPORTED, "only heading_command=True is implemented (XBotLCfg)");
+    if (sim) HG_REQUIRE(sim->root.base && sim->dof_pos.base && sim->dof_vel.base && sim->contact.base && sim->rigid.base,
+                        HGYM_E_BADARG, "null sim tensor");
+    HG_REQUIRE(st->episode_length && st->counters && st->commands && st->actions, HGYM_E_BADARG, "null env state field");
+    return HGYM_OK;
+}
+
+static int32_t launch_step(const HgymEnvConfig* cfg, const HgymSimTensors* sim, const HgymEnvState* st, const HgymEnvOut* out,
+                           const HgymEnvNoise* noise, const float* actions_in, int mode, int fused, hipStream_t s) {
+    int32_t rc = check_common(cfg, sim, st);
+    if (rc) return rc;
+    HG_REQUIRE(sim && out, HGYM_E_BADARG, "null sim/out");
+    HG_REQUIRE(out->obs && out->priv_obs && out->rew && out->reset && out->time_out && out->extras_time_outs && out->extras_episode,
+               HGYM_E_BADARG, "null output buffer");
+    HG_REQUIRE(st->obs_ring && st->priv_ring && st->episode_acc, HGYM_E_BADARG, "null ring/episode_acc");
+    EnvArgs A;
+    memset(&A, 0, sizeof(A));
+    A.cfg = *cfg;
+    A.sim = *sim;
+    A.st = *st;
+    A.out = *out;
+    if (noise) A.noise = *noise;
+    A.actions_in = actions_in;
+    A.mode = mode;
+    A.fused = fused;
+    A.envs_per_block = pick_envs_per_block(cfg->num_envs);
+    const int blocks = ceil_div(cfg->num_envs, A.envs_per_block);
+    const size_t lds = step_smem_bytes(A.envs_per_block);
+    if (cfg->frame_stack == 15 && cfg->c_frame_stack == 3)
+        hipLaunchKernelGGL((env_step_kernel<15, 3>), dim3(blocks), dim3(256), lds, s, A);
+    else
+        hipLaunchKernelGGL((env_step_kernel<0, 0>), dim3(blocks), dim3(256), lds, s, A);
+    HG_CHECK_LAUNCH("env_step_kernel");
+    hipLaunchKernelGGL(env_finalize_kernel, dim3(1), dim3(256), 0, s, A);
+    HG_CHECK_LAUNCH("env_finalize_kernel");
+    return HGYM_OK;
+}
+
+}  // namespace hgym
+
+using namespace hgym;
+
+extern "C" {
+
+int32_t hgym_env_config_default(HgymEnvConfig* c, int32_t num_envs) {
+    HG_REQUIRE(c, HGYM_E_BADARG, "null cfg");
+    memset(c, 0, sizeof(*c));
+    // envs/custom/humanoid_config.py:34-227 ; python-double arithmetic first, fp32 rounding last
+    c->num_envs = num_envs;
+    c->frame_stack = 15;
+    c->c_frame_stack = 3;
+    c->decimation = 10;
+    c->sim_dt = 0.001f;
+    c->dt = (float)(10 * 0.001);
+    c->max_episode_length = 2400;   // ceil(24 / 0.01), legged_robot.py:717-718
+    c->resample_steps = 800;        // int(8. / 0.01), legged_robot.py:309
+    c->push_interval = 400;         // ceil(4 / 0.01), legged_robot.py:720
+    c->push_robots = 1;
+    c->add_noise = 1;
+    c->heading_command = 1;
+    c->clip_actions = 18.f;
+    c->clip_obs = 18.f;
+    c->action_scale = 0.25f;
+    c->action_delay = 0.5f;
+    c->action_noise = 0.02f;
+    c->noise_level = 0.6f;
+    for (int k = 5; k < 17; ++k) c->obs_noise[k] = (float)(0.05 * 1.0);
+    for (int k = 17; k < 29; ++k) c->obs_noise[k] = (float)(0.5 * 0.05);
+    for (int k = 41; k < 44; ++k) c->obs_noise[k] = (float)(0.1 * 1.0);
+    for (int k = 44; k < 47; ++k) c->obs_noise[k] = (float)(0.03 * 1.0);
+    c->scale_lin_vel = 2.f;
+    c->scale_ang_vel = 1.f;
+    c->scale_dof_pos = 1.f;
+    c->scale_dof_vel = 0.05f;
+    c->scale_quat = 1.f;
+    c->cmd_x_lo = -0.3f;  c->cmd_x_span = (float)(0.6 - (-0.3));
+    c->cmd_y_lo = -0.3f;  c->cmd_y_span = (float)(0.3 - (-0.3));
+    c->cmd_h_lo = -3.14f; c->cmd_h_span = (float)(3.14 - (-3.14));
+    c->dof_reset_lo = -0.1f; c->dof_reset_span = (float)(0.1 - (-0.1));
+    c->push_vel_lo = -0.2f;  c->push_vel_span = (float)(0.2 - (-0.2));
+    c->push_ang_lo = -0.4f;  c->push_ang_span = (float)(0.4 - (-0.4));
+    const float kp[6] = {200.f, 200.f, 350.f, 350.f, 15.f, 15.f};
+    const float eff[6] = {100.f, 100.f, 250.f, 250.f, 100.f, 100.f};
+    const float lo[12] = {-0.44f, -1.05f, -1.57f, -1.05f, -0.70f, -0.44f, -1.57f, -1.05f, -1.31f, -1.10f, -0.87f, -0.44f};
+    const float hi[12] = {1.57f, 1.05f, 1.31f, 1.10f, 0.87f, 0.44f, 0.44f, 1.05f, 1.57f, 1.05f, 0.70f, 0.44f};
+    for (int j = 0; j < 12; ++j) {
+        c->p_gains[j] = kp[j % 6];
+        c->d_gains[j] = 10.f;
+        c->torque_limits[j] = eff[j % 6] * 0.85f;   // fp32 product, legged_robot.py:293
+        c->default_dof_pos[j] = 0.f;
+        c->dof_lower[j] = lo[j];
+        c->dof_upper[j] = hi[j];
+    }
+    const float init[13] = {0.f, 0.f, 0.95f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < 13; ++i) c->base_init_state[i] = init[i];
+    c->base_body = 0;
+    c->feet_bodies[0] = 6;  c->feet_bodies[1] = 12;
+    c->knee_bodies[0] = 4;  c->knee_bodies[1] = 10;
+    const double raw[HGYM_NUM_REWARDS] = {-0.002, 0.2, 0.2, -1.0, 0.5, -1e-7, -5e-4, 1.0, 1.0, -0.01, 1.2, 0.2, -0.05, 1.6,
+                                          0.2, 0.2, 1.0, -1e-5, 0.5, 1.1, 1.2, 0.5};
+    for (int k = 0; k < HGYM_NUM_REWARDS; ++k) c->reward_scales[k] = (float)(raw[k] * (10 * 0.001));
+    c->only_positive_rewards = 1;
+    c->base_height_target = 0.89f;
+    c->min_dist = 0.2f;
+    c->max_dist = 0.5f;
+    c->target_joint_pos_scale = 0.17f;
+    c->target_feet_height = 0.06f;
+    c->cycle_time = 0.64f;
+    c->tracking_sigma = 5.f;
+    c->max_contact_force = 700.f;
+    c->episode_length_s = 24.f;
+    c->seed = 5;
+    return HGYM_OK;
+}
+
+int32_t hgym_env_prime(const HgymEnvConfig* cfg, const HgymSimTensors* sim, const HgymEnvState* st, const HgymEnvOut* out,
+                       const HgymEnvNoise* noise, void* stream) {
+    return launch_step(cfg, sim, st, out, noise, nullptr, MODE_PRIME, 0, (hipStream_t)stream);
+}
+
+int32_t hgym_env_reset_all(const HgymEnvConfig* cfg, const HgymSimTensors* sim, const HgymEnvState* st, const HgymEnvOut* out,
+                           const HgymEnvNoise* noise, void* stream) {
+    return launch_step(cfg, sim, st, out, noise, nullptr, MODE_RESET_ALL, 0, (hipStream_t)stream);
+}
+
+int32_t hgym_post_physics(const HgymEnvConfig* cfg, const HgymSimTensors* sim, const HgymEnvState* st, const HgymEnvOut* out,
+                          const HgymEnvNoise* noise, void* stream) {
+    return launch_step(cfg, sim, st, out, noise, nullptr, MODE_STEP, 0, (hipStream_t)stream);
+}
+
+int32_t hgym_env_step_synth(const HgymEnvConfig* cfg, const HgymSimTensors* sim, const HgymEnvState* st, const HgymEnvOut* out,
+                            const float* actions_in, void* stream) {
+    HG_REQUIRE(actions_in, HGYM_E_BADARG, "null actions");
+    return launch_step(cfg, sim, st, out, nullptr, actions_in, MODE_STEP, 1, (hipStream_t)stream);
+}
+
+static int32_t launch_simple(void (*kern)(const EnvArgs), const char* name, const HgymEnvConfig* cfg, const HgymSimTensors* sim,
+                             const HgymEnvState* st, const HgymEnvNoise* noise, const float* actions_in, void* stream) {
+    int32_t rc = check_common(cfg, sim, st);
+    if (rc) return rc;
+    EnvArgs A;
+    memset(&A, 0, sizeof(A));
+    A.cfg = *cfg;
+    if (sim) A.sim = *sim;
+    A.st = *st;
+    if (noise) A.noise = *noise;
+    A.actions_in = actions_in;
+    hipLaunchKernelGGL(kern, dim3(ceil_div(cfg->num_envs, 256)), dim3(256), 0, (hipStream_t)stream, A);
+    HG_CHECK_LAUNCH(name);
+    return HGYM_OK;
+}
+
+int32_t hgym_pre_physics(const HgymEnvConfig* cfg, const HgymEnvState* st, const float* actions_in, const HgymEnvNoise* noise,
+                         void* stream) {
+    HG_REQUIRE(actions_in, HGYM_E_BADARG, "null actions");
+    return launch_simple(pre_physics_kernel, "pre_physics_kernel", cfg, nullptr, st, noise, actions_in, stream);
+}
+
+int32_t hgym_pd_torques(const HgymEnvConfig* cfg, const HgymSimTensors* sim, const HgymEnvState* st, void* stream) {
+    HG_REQUIRE(sim, HGYM_E_BADARG, "null sim");
+    return launch_simple(pd_torques_kernel, "pd_torques_kernel", cfg, sim, st, nullptr, nullptr, stream);
+}
+
+int32_t hgym_synth_physics(const HgymEnvConfig* cfg, const HgymSimTensors* sim, const HgymEnvState* st, void* stream) {
+    HG_REQUIRE(sim, HGYM_E_BADARG, "null sim");
+    return launch_simple(synth_physics_kernel, "synth_physics_kernel", cfg, sim, st, nullptr, nullptr, stream);
+}
+
+}  // extern "C"

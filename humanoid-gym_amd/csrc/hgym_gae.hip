@@ -1,0 +1,176 @@
+// hgym_gae.hip -- rollout-storage side: time-out bootstrap store, GAE(lambda), advantage normalisation.
+//
+// GAE (algo/ppo/rollout_storage.py:122-133) is the backward linear recurrence
+//     A_t = delta_t + c_t * A_{t+1},   delta_t = r_t + nt_t*gamma*V_{t+1} - V_t,   c_t = nt_t*gamma*lambda
+// i.e. a suffix composition of affine maps x -> b + a*x.  One 64-lane wavefront owns one env and one lane one
+// timestep, so the whole T=60 rollout is a single 6-step Kogge-Stone scan done with wavefront shuffles
+// (no LDS traffic in the scan, no 60-step serial dependency); longer rollouts are walked in 64-step tiles
+// from the end with a scalar carry.  Loads/stores of the time-major (T,N) arrays go through an LDS tile
+// [64 steps][16 envs] so that HBM sees 64-byte runs instead of 4-byte gathers.  HBM-bound: 25 B/env-step.
+#include "hgym_common.hpp"
+
+namespace hgym {
+
+constexpr int GAE_ENVS = 16;   // envs per workgroup (4 per wavefront)
+constexpr int GAE_PAD = 17;    // LDS row stride (odd: conflict-free column reads)
+
+__global__ __launch_bounds__(256) void gae_kernel(int T, int N, const float* __restrict__ rewards,
+                                                  const float* __restrict__ values, const uint8_t* __restrict__ dones,
+                                                  const float* __restrict__ last_values, float gamma, float lam,
+                                                  float* __restrict__ returns, float* __restrict__ advantages,
+                                                  double* __restrict__ stats) {
+    __shared__ float s_r[64][GAE_PAD];
+    __shared__ float s_v[65][GAE_PAD];
+    __shared__ float s_d[64][GAE_PAD];
+    __shared__ float s_carry[GAE_ENVS];
+    __shared__ double s_sum[4][2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int e0 = blockIdx.x * GAE_ENVS;
+    const int nE = min(GAE_ENVS, N - e0);
+    if (tid < GAE_ENVS) s_carry[tid] = 0.0f;
+    double sum1 = 0.0, sum2 = 0.0;
+    const int ntiles = (T + 63) / 64;
+    for (int tile = ntiles - 1; tile >= 0; --tile) {
+        const int t0 = tile * 64;
+        const int nT = min(64, T - t0);
+        __syncthreads();
+        // stage [nT (+1 row of next values)][nE]
+        for (int i = tid; i < 65 * GAE_ENVS; i += 256) {
+            const int t = i / GAE_ENVS, el = i % GAE_ENVS;
+            if (el < nE) {
+                const int tg = t0 + t;
+                if (t < nT) {
+                    s_r[t][el] = rewards[(int64_t)tg * N + e0 + el];
+                    s_d[t][el] = (float)dones[(int64_t)tg * N + e0 + el];
+                    s_v[t][el] = values[(int64_t)tg * N + e0 + el];
+                } else if (t == nT) {
+                    s_v[t][el] = (tg >= T) ? last_values[e0 + el] : values[(int64_t)tg * N + e0 + el];
+                }
+            }
+        }
+        __syncthreads();
+        for (int q = 0; q < GAE_ENVS / 4; ++q) {
+            const int el = wave * (GAE_ENVS / 4) + q;
+            if (el >= nE) break;                       // wave-uniform
+            const bool valid = lane < nT;
+            float a = 1.0f, b = 0.0f, v = 0.0f;
+            if (valid) {
+                v = s_v[lane][el];
+                const float nt = 1.0f - s_d[lane][el];
+                b = s_r[lane][el] + nt * gamma * s_v[lane + 1][el] - v;
+                a = nt * gamma * lam;
+            }
+            // inclusive suffix scan of affine maps: after the loop lane t holds F_t = f_t o f_{t+1} o ... o f_63
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const float a2 = __shfl_down(a, off, 64);
+                const float b2 = __shfl_down(b, off, 64);
+                if (lane + off < 64) {
+                    b = b + a * b2;
+                    a = a * a2;
+                }
+            }
+            const float carry = s_carry[el];
+            const float adv_t = b + a * carry;        // A_t
+            const float ret = adv_t + v;
+            const float adv = ret - v;                // rollout_storage.py:135 forms returns - values
+            const float head = __shfl(adv_t, 0, 64);
+            if (valid) {
+                s_r[lane][el] = ret;                  // reuse the tile as the output staging area
+                s_d[lane][el] = adv;
+                sum1 += (double)adv;
+                sum2 += (double)adv * (double)adv;
+            }
+            if (lane == 0) s_carry[el] = head;
+        }
+        __syncthreads();
+        for (int i = tid; i < 64 * GAE_ENVS; i += 256) {
+            const int t = i / GAE_ENVS, el = i % GAE_ENVS;
+            if (t < nT && el < nE) {
+                returns[(int64_t)(t0 + t) * N + e0 + el] = s_r[t][el];
+                advantages[(int64_t)(t0 + t) * N + e0 + el] = s_d[t][el];
+            }
+        }
+    }
+    // advantage statistics for the normalisation: wave reduce -> block reduce -> one fp64 atomic pair per block
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        sum1 += __shfl_down(sum1, off, 64);
+        sum2 += __shfl_down(sum2, off, 64);
+    }
+    if (lane == 0) {
+        s_sum[wave][0] = sum1;
+        s_sum[wave][1] = sum2;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        atomicAdd(&stats[0], s_sum[0][0] + s_sum[1][0] + s_sum[2][0] + s_sum[3][0]);
+        atomicAdd(&stats[1], s_sum[0][1] + s_sum[1][1] + s_sum[2][1] + s_sum[3][1]);
+        if (blockIdx.x == 0) stats[2] = (double)T * (double)N;
+    }
+}
+
+__global__ void zero_stats_kernel(double* stats) {
+    if (threadIdx.x < 3) stats[threadIdx.x] = 0.0;
+}
+
+// rollout_storage.py:136: (adv - mean) / (std_unbiased + 1e-8), mean/std from fp64 sums, arithmetic in fp32
+__global__ __launch_bounds__(256) void adv_normalize_kernel(int64_t count, float* __restrict__ adv, const double* __restrict__ stats) {
+    const double n = stats[2];
+    const double mean_d = stats[0] / n;
+    double var = (stats[1] - stats[0] * stats[0] / n) / (n - 1.0);
+    if (var < 0.0) var = 0.0;
+    const float mean = (float)mean_d;
+    const float denom = (float)sqrt(var) + 1e-8f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x)
+        adv[i] = (adv[i] - mean) / denom;
+}
+
+// ppo.py:103-113 + rollout_storage.py:91-94 for the scalar columns of one step
+__global__ __launch_bounds__(256) void store_step_kernel(int n, const float* __restrict__ rew, const float* __restrict__ values,
+                                                         const uint8_t* __restrict__ time_outs, const uint8_t* __restrict__ dones,
+                                                         float gamma, float* __restrict__ rewards_slot, uint8_t* __restrict__ dones_slot) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float to = time_outs ? (float)(time_outs[i] != 0) : 0.0f;
+    rewards_slot[i] = rew[i] + gamma * (values[i] * to);
+    dones_slot[i] = dones[i] != 0;
+}
+
+}  // namespace hgym
+
+using namespace hgym;
+
+extern "C" {
+
+int32_t hgym_store_step(int32_t n, const float* rew, const float* values, const uint8_t* time_outs, const uint8_t* dones,
+                        float gamma, float* rewards_slot, uint8_t* dones_slot, void* stream) {
+    HG_REQUIRE(n > 0, HGYM_E_SHAPE, "n=%d", n);
+    HG_REQUIRE(rew && values && dones && rewards_slot && dones_slot, HGYM_E_BADARG, "null pointer");
+    hipLaunchKernelGGL(store_step_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, n, rew, values, time_outs, dones,
+                       gamma, rewards_slot, dones_slot);
+    HG_CHECK_LAUNCH("store_step_kernel");
+    return HGYM_OK;
+}
+
+int32_t hgym_gae(int32_t T, int32_t n, const float* rewards, const float* values, const uint8_t* dones, const float* last_values,
+                 float gamma, float lam, float* returns, float* advantages, double* stats, void* stream) {
+    HG_REQUIRE(T > 0 && n > 0, HGYM_E_SHAPE, "T=%d n=%d", T, n);
+    HG_REQUIRE(rewards && values && dones && last_values && returns && advantages && stats, HGYM_E_BADARG, "null pointer");
+    hipLaunchKernelGGL(zero_stats_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, stats);
+    hipLaunchKernelGGL(gae_kernel, dim3(ceil_div(n, GAE_ENVS)), dim3(256), 0, (hipStream_t)stream, T, n, rewards, values, dones,
+                       last_values, gamma, lam, returns, advantages, stats);
+    HG_CHECK_LAUNCH("gae_kernel");
+    return HGYM_OK;
+}
+
+int32_t hgym_adv_normalize(int64_t count, float* advantages, const double* stats, void* stream) {
+    HG_REQUIRE(count > 1, HGYM_E_SHAPE, "count=%lld", (long long)count);
+    HG_REQUIRE(advantages && stats, HGYM_E_BADARG, "null pointer");
+    const int blocks = (int)((count + 255) / 256 > 2048 ? 2048 : (count + 255) / 256);
+    hipLaunchKernelGGL(adv_normalize_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, count, advantages, stats);
+    HG_CHECK_LAUNCH("adv_normalize_kernel");
+    return HGYM_OK;
+}
+
+}  // extern "C"

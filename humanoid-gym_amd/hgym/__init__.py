@@ -1,0 +1,4 @@
+"""hgym: thin Python layer over libhgym_hip.so (ctypes).  Importing it requires the built HIP library."""
+from . import _lib
+from ._lib import lib, check, HgymError
+from .env_buffers import EnvBuffers, default_env_config

@@ -1,0 +1,160 @@
+"""Caller-owned buffers of the env side: allocates the env-major SoA state, the sim tensors and the step
+outputs as torch tensors and presents them to the C-ABI as the pointer structs of include/hgym.h."""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+
+def default_env_config(num_envs, seed=5, frame_stack=15, c_frame_stack=3):
+    cfg = L.EnvConfig()
+    L.check(L.lib.hgym_env_config_default(C.byref(cfg), int(num_envs)), "hgym_env_config_default")
+    cfg.seed = int(seed)
+    cfg.frame_stack = int(frame_stack)
+    cfg.c_frame_stack = int(c_frame_stack)
+    return cfg
+
+
+def grid_origins(n, spacing=3.0):
+    """Env origins of a plane terrain: regular grid (reference legged_robot.py:699-708)."""
+    import math
+    cols = math.floor(math.sqrt(n))
+    rows = math.ceil(n / cols)
+    xx, yy = torch.meshgrid(torch.arange(rows), torch.arange(cols), indexing="ij")
+    o = torch.zeros(n, 3)
+    o[:, 0] = spacing * xx.flatten()[:n]
+    o[:, 1] = spacing * yy.flatten()[:n]
+    return o
+
+
+class EnvBuffers:
+    """All device memory of one env shard.
+
+    State fields are stored [C][N] (env-major SoA); `view(name)` returns the (N,C) transposed view the
+    reference API exposes.  Sim tensors are either library-native SoA (`sim_layout="soa"`, used by the
+    synthetic physics backend) or Isaac-Gym-shaped AoS (`"aos"`: root (N,13), dof_state (N*12,2),
+    contact (N*13,3), rigid (N*13,13)), both described to the kernels by strides.
+    """
+
+    def __init__(self, cfg, device, sim_layout="soa", obs_out=None, priv_out=None):
+        self.cfg = cfg
+        self.device = torch.device(device)
+        N = self.N = int(cfg.num_envs)
+        H, HC = int(cfg.frame_stack), int(cfg.c_frame_stack)
+        dev = self.device
+        z = lambda *s, dtype=torch.float32: torch.zeros(*s, dtype=dtype, device=dev)
+        self.f = {name: z(c, N) for name, c in L.ENV_STATE_FIELDS}
+        self.episode_length = z(N, dtype=torch.int64)
+        self.counters = z(4, dtype=torch.int64)
+        self.obs_ring = z(N, H, L.OBS_FRAME)
+        self.priv_ring = z(N, HC, L.PRIV_FRAME)
+        self.episode_acc = z(24)
+        # outputs
+        self.obs = z(N, H * L.OBS_FRAME) if obs_out is None else obs_out
+        self.priv_obs = z(N, HC * L.PRIV_FRAME) if priv_out is None else priv_out
+        self.rew = z(N)
+        self.reset = torch.ones(N, dtype=torch.bool, device=dev)
+        self.time_out = z(N, dtype=torch.bool)
+        self.extras_time_outs = z(N, dtype=torch.bool)
+        self.extras_episode = z(L.NUM_REWARDS)
+        # sim tensors
+        self.sim_layout = sim_layout
+        if sim_layout == "soa":
+            self.root = z(13, N)
+            self.dof_pos = z(12, N)
+            self.dof_vel = z(12, N)
+            self.contact = z(L.NUM_BODIES * 3, N)
+            self.rigid = z(L.NUM_BODIES * 13, N)
+        elif sim_layout == "aos":
+            self.root = z(N, 13)
+            self.dof_state = z(N * 12, 2)
+            self.contact = z(N * L.NUM_BODIES, 3)
+            self.rigid = z(N * L.NUM_BODIES, 13)
+        else:
+            raise ValueError(sim_layout)
+        # constants the reference draws at construction (legged_robot.py:257-302): friction, base mass, origins
+        self.f["friction"].fill_(1.0)
+        self.f["body_mass"].fill_(15.0)
+        self.f["env_origins"].copy_(grid_origins(N).t())
+        self.set_initial_root()
+        self._structs = None
+
+    # ---- views with the reference's shapes -------------------------------------------------------
+    def view(self, name):
+        """(N, C) view of a state field (transposed, non-contiguous)."""
+        return self.f[name].t()
+
+    def root_view(self):
+        return self.root.t() if self.sim_layout == "soa" else self.root
+
+    def dof_pos_view(self):
+        return self.dof_pos.t() if self.sim_layout == "soa" else self.dof_state.view(self.N, 12, 2)[..., 0]
+
+    def dof_vel_view(self):
+        return self.dof_vel.t() if self.sim_layout == "soa" else self.dof_state.view(self.N, 12, 2)[..., 1]
+
+    def contact_view(self):
+        return (self.contact.t() if self.sim_layout == "soa" else self.contact).reshape(self.N, L.NUM_BODIES, 3)
+
+    def rigid_view(self):
+        return (self.rigid.t() if self.sim_layout == "soa" else self.rigid).reshape(self.N, L.NUM_BODIES, 13)
+
+    def set_initial_root(self):
+        init = torch.tensor(list(self.cfg.base_init_state), device=self.device).view(1, 13).repeat(self.N, 1)
+        init[:, :3] += self.view("env_origins")
+        self.root_view().copy_(init)
+
+    def load_sim(self, root, dof_state, contact, rigid):
+        """Copy Isaac-Gym-shaped host tensors into whatever layout this object uses."""
+        N = self.N
+        dev = self.device
+        self.root_view().copy_(root.to(dev))
+        d = dof_state.to(dev).view(N, 12, 2)
+        self.dof_pos_view().copy_(d[..., 0])
+        self.dof_vel_view().copy_(d[..., 1])
+        if self.sim_layout == "soa":
+            self.contact.copy_(contact.to(dev).view(N, -1).t())
+            self.rigid.copy_(rigid.to(dev).view(N, -1).t())
+        else:
+            self.contact.copy_(contact.to(dev).view_as(self.contact))
+            self.rigid.copy_(rigid.to(dev).view_as(self.rigid))
+
+    # ---- C structs ---------------------------------------------------------------------------------
+    def _strided(self, t, soa):
+        N = self.N
+        return L.Strided(L.fptr(t), 1 if soa else t.numel() // N, N if soa else 1)
+
+    def sim_struct(self):
+        if self.sim_layout == "soa":
+            return L.SimTensors(self._strided(self.root, True), self._strided(self.dof_pos, True),
+                                self._strided(self.dof_vel, True), self._strided(self.contact, True),
+                                self._strided(self.rigid, True))
+        dof = self.dof_state
+        pos = L.Strided(L.fptr(dof), 24, 2)
+        vel = L.Strided(C.cast(dof.data_ptr() + 4, L.c_float_p), 24, 2)
+        return L.SimTensors(self._strided(self.root, False), pos, vel, self._strided(self.contact, False),
+                            self._strided(self.rigid, False))
+
+    def state_struct(self):
+        st = L.EnvState()
+        st.episode_length = L.i64ptr(self.episode_length)
+        st.counters = L.i64ptr(self.counters)
+        for name, _ in L.ENV_STATE_FIELDS:
+            setattr(st, name, L.fptr(self.f[name]))
+        st.obs_ring = L.fptr(self.obs_ring)
+        st.priv_ring = L.fptr(self.priv_ring)
+        st.episode_acc = L.fptr(self.episode_acc)
+        return st
+
+    def out_struct(self, obs=None, priv=None):
+        return L.EnvOut(L.fptr(self.obs if obs is None else obs), L.fptr(self.priv_obs if priv is None else priv),
+                        L.fptr(self.rew), L.u8ptr(self.reset), L.u8ptr(self.time_out), L.u8ptr(self.extras_time_outs),
+                        L.fptr(self.extras_episode))
+
+    @staticmethod
+    def noise_struct(u_delay=None, z_act=None, u_cmd=None, u_dof=None, u_push=None, z_obs=None):
+        """Row-major (N,k) fp32 tables (or None -> internal Philox).  The caller keeps the tensors alive."""
+        for t in (u_delay, z_act, u_cmd, u_dof, u_push, z_obs):
+            assert t is None or (t.is_contiguous() and t.dtype == torch.float32)
+        return L.EnvNoise(L.fptr(u_delay), L.fptr(z_act), L.fptr(u_cmd), L.fptr(u_dof), L.fptr(u_push), L.fptr(z_obs))

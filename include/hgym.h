@@ -1,0 +1,306 @@
+/*
+ * hgym.h -- C-ABI of libhgym_hip.so: the MI355X (gfx950) hot path of roboterax/humanoid-gym.
+ *
+ * The reference (pure Python/PyTorch) has no FFI of its own; its replaceable seam is the Python API
+ * of humanoid.envs / humanoid.algo.ppo.  Each entry point below states the reference
+ * interface (file:line under /root/reference/humanoid) it stands in for.  INTEGRATION.md shows the
+ * ctypes binding a maintainer adds on the reference side.
+ *
+ * Conventions
+ *   - every function returns 0 (HGYM_OK) or a negative HGYM_E_* code; hgym_last_error() gives the
+ *     thread-local message of the last failure.
+ *   - the CALLER owns every buffer (PyTorch allocates them); the library never allocates or frees
+ *     device memory and keeps no pointer past the call.
+ *   - all device work is enqueued on the hipStream_t passed as `void* stream`; no call synchronises,
+ *     all calls are hipGraph-capturable, and per-step counters live in device memory so that a
+ *     replayed graph advances them.
+ *   - plain pointers and sizes only: no torch types cross this boundary.
+ *   - per-env state is env-major SoA: a field with C components is a [C][N] fp32 array, so that
+ *     lane i of a wavefront touches env i of every component (coalesced).  The (N,C) tensors of the
+ *     reference API are transposed views of these arrays.
+ */
+#ifndef HGYM_H_
+#define HGYM_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HGYM_VERSION 1
+
+enum {
+    HGYM_OK = 0,
+    HGYM_E_BADARG = -1,      /* null pointer, negative size ... */
+    HGYM_E_SHAPE = -2,       /* sizes inconsistent with the configuration */
+    HGYM_E_LAUNCH = -3,      /* HIP reported an error at launch */
+    HGYM_E_UNSUPPORTED = -4, /* configuration outside what the kernels were built for */
+    HGYM_E_NODEVICE = -5     /* no gfx950 device visible */
+};
+
+#define HGYM_NUM_DOF 12
+#define HGYM_NUM_ACTIONS 12
+#define HGYM_NUM_BODIES 13
+#define HGYM_NUM_REWARDS 22
+#define HGYM_OBS_FRAME 47   /* num_single_obs,           envs/custom/humanoid_config.py:41 */
+#define HGYM_PRIV_FRAME 73  /* single_num_privileged_obs, envs/custom/humanoid_config.py:43 */
+#define HGYM_MAX_LAYERS 8
+
+int32_t hgym_version(void);
+const char* hgym_last_error(void);
+/* number of compute units of the current device (0 if none); also a cheap "is there a GPU" probe */
+int32_t hgym_device_cus(void);
+/* sizeof() of a struct of this header by name ("HgymEnvConfig", ...), -1 if unknown: lets a binding in
+ * another language verify its mirror of the layouts */
+int64_t hgym_sizeof(const char* name);
+
+/* ------------------------------------------------------------------------------------------------
+ * Env configuration = the constants of XBotLCfg the hot path reads
+ * (envs/custom/humanoid_config.py:34-227, envs/base/legged_robot.py:710-720).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct HgymEnvConfig {
+    int32_t num_envs;
+    int32_t frame_stack;          /* 15 */
+    int32_t c_frame_stack;        /* 3  */
+    int32_t decimation;           /* 10 */
+    float sim_dt;                 /* 0.001 */
+    float dt;                     /* decimation*sim_dt as fp32(python double product) = 0.01f */
+    int32_t max_episode_length;   /* 2400 */
+    int32_t resample_steps;       /* 800 */
+    int32_t push_interval;        /* 400 */
+    int32_t push_robots;          /* 1 */
+    int32_t add_noise;            /* 1 */
+    int32_t heading_command;      /* 1 (only mode supported) */
+    float clip_actions, clip_obs; /* 18, 18 */
+    float action_scale;           /* 0.25 */
+    float action_delay, action_noise; /* 0.5, 0.02 */
+    float noise_level;            /* 0.6 */
+    float obs_noise[HGYM_OBS_FRAME];   /* noise_scale_vec, humanoid_env.py:166-186 */
+    float scale_lin_vel, scale_ang_vel, scale_dof_pos, scale_dof_vel, scale_quat;
+    /* torch_rand_float(lo,hi) = (hi-lo)*u + lo with (hi-lo) formed in python double: carry lo and the
+       double-rounded span so the fp32 arithmetic is the reference's (legged_robot.py:328-331,367) */
+    float cmd_x_lo, cmd_x_span, cmd_y_lo, cmd_y_span, cmd_h_lo, cmd_h_span;
+    float dof_reset_lo, dof_reset_span;       /* -0.1, 0.2 */
+    float push_vel_lo, push_vel_span;         /* -0.2, 0.4   humanoid_env.py:86-89 */
+    float push_ang_lo, push_ang_span;         /* -0.4, 0.8   humanoid_env.py:92-93 */
+    float p_gains[HGYM_NUM_DOF], d_gains[HGYM_NUM_DOF], torque_limits[HGYM_NUM_DOF];
+    float default_dof_pos[HGYM_NUM_DOF];
+    float dof_lower[HGYM_NUM_DOF], dof_upper[HGYM_NUM_DOF]; /* synthetic physics only */
+    float base_init_state[13];
+    int32_t base_body, feet_bodies[2], knee_bodies[2];
+    /* rewards (humanoid_config.py:174-216); scales already multiplied by dt, alphabetical order */
+    float reward_scales[HGYM_NUM_REWARDS];
+    int32_t only_positive_rewards;
+    float base_height_target, min_dist, max_dist, target_joint_pos_scale, target_feet_height;
+    float cycle_time, tracking_sigma, max_contact_force, episode_length_s;
+    uint64_t seed;                /* Philox key for internally generated noise */
+} HgymEnvConfig;
+
+/* fills *cfg with the XBot-L values (the reference defaults) for num_envs environments */
+int32_t hgym_env_config_default(HgymEnvConfig* cfg, int32_t num_envs);
+
+/* A strided view of one simulator tensor: element (env, comp) is base[env*env_stride + comp*comp_stride].
+ * Isaac Gym's AoS buffers (legged_robot.py:449-457) and the library's own SoA synthetic backend are both
+ * expressible.  comps: root 13 | dof_pos 12 | dof_vel 12 | contact body*3+axis (39) | rigid body*13+c (169). */
+typedef struct HgymStrided {
+    float* base;
+    int64_t env_stride;
+    int64_t comp_stride;
+} HgymStrided;
+
+typedef struct HgymSimTensors {
+    HgymStrided root, dof_pos, dof_vel, contact, rigid;
+} HgymSimTensors;
+
+/* Per-env state, every field [C][N] fp32 SoA unless noted (legged_robot.py:434-516, base_task.py:71-94,
+ * humanoid_env.py:78-79). */
+typedef struct HgymEnvState {
+    int64_t* episode_length;   /* [N] int64, VecEnv.episode_length_buf */
+    int64_t* counters;         /* [4] int64 device scalars: [0] common_step_counter, [1] resets this step,
+                                  [2] ring step (frames pushed so far), [3] reserved */
+    float* commands;           /* 4 */
+    float* actions;            /* 12 */
+    float* last_actions;       /* 12 */
+    float* last_last_actions;  /* 12 */
+    float* last_dof_vel;       /* 12 */
+    float* last_root_vel;      /* 6 */
+    float* torques;            /* 12 */
+    float* feet_air_time;      /* 2 */
+    float* last_contacts;      /* 2 (0/1) */
+    float* feet_height;        /* 2 */
+    float* last_feet_z;        /* 2 */
+    float* ref_dof_pos;        /* 12 */
+    float* push_force;         /* 3 */
+    float* push_torque;        /* 3 */
+    float* episode_sums;       /* 22 */
+    float* base_lin_vel;       /* 3 */
+    float* base_ang_vel;       /* 3 */
+    float* projected_gravity;  /* 3 */
+    float* base_euler;         /* 3 */
+    float* friction;           /* 1 */
+    float* body_mass;          /* 1 */
+    float* env_origins;        /* 3 */
+    float* obs_ring;           /* [N][frame_stack][47]   unclipped noisy frames, ring slot = ring step % frame_stack */
+    float* priv_ring;          /* [N][c_frame_stack][73] */
+    float* episode_acc;        /* [24] fp32 device scalars: sum over resetting envs of episode_sums[k]; [22] unused */
+} HgymEnvState;
+
+/* Outputs of one env step = the 5-tuple of VecEnv.step (algo/vec_env.py:50-51) plus the extras tensors. */
+typedef struct HgymEnvOut {
+    float* obs;                /* (N, frame_stack*47) row-major, clipped */
+    float* priv_obs;           /* (N, c_frame_stack*73) row-major, clipped */
+    float* rew;                /* (N,) */
+    uint8_t* reset;            /* (N,) bool */
+    uint8_t* time_out;         /* (N,) bool: this step's time_out_buf */
+    uint8_t* extras_time_outs; /* (N,) bool: extras["time_outs"], refreshed only on steps with >=1 reset
+                                  (legged_robot.py:173-174,209-210) */
+    float* extras_episode;     /* (22,) extras["episode"]["rew_<term>"], same staleness rule */
+} HgymEnvOut;
+
+/* Optional externally supplied random draws (parity mode), row-major (N,k) tables indexed by env id.
+ * A NULL member means "draw it from the internal Philox4x32-10 stream keyed by (seed, step, env, slot)". */
+typedef struct HgymEnvNoise {
+    const float* u_delay;      /* (N,)    U[0,1)  humanoid_env.py:194 */
+    const float* z_act;        /* (N,12)  N(0,1)  humanoid_env.py:196 */
+    const float* u_cmd;        /* (N,6)   U[0,1)  [0:3] callback resample, [3:6] reset resample (legged_robot.py:328-331) */
+    const float* u_dof;        /* (N,12)  U[0,1)  legged_robot.py:367 */
+    const float* u_push;       /* (N,5)   U[0,1)  humanoid_env.py:88-93 */
+    const float* z_obs;        /* (N,47)  N(0,1)  humanoid_env.py:251 */
+} HgymEnvNoise;
+
+/* XBotLFreeEnv.__init__ tail (humanoid_env.py:78-81): state defaults, reset_idx(all), compute_observations. */
+int32_t hgym_env_prime(const HgymEnvConfig* cfg, const HgymSimTensors* sim, const HgymEnvState* st,
+                       const HgymEnvOut* out, const HgymEnvNoise* noise, void* stream);
+
+/* LeggedRobot.reset's reset_idx(all) (legged_robot.py:112-114): the reset branch for every env, history
+ * cleared, no observation pushed (the caller follows with a zero-action step, :115-116). */
+int32_t hgym_env_reset_all(const HgymEnvConfig* cfg, const HgymSimTensors* sim, const HgymEnvState* st,
+                           const HgymEnvOut* out, const HgymEnvNoise* noise, void* stream);
+
+/* XBotLFreeEnv.step head + LeggedRobot.step clip (humanoid_env.py:189-197, legged_robot.py:90-91):
+ * st->actions <- clip(blend(clip(actions_in), st->actions) * (1 + noise)).  actions_in (N,12) row-major. */
+int32_t hgym_pre_physics(const HgymEnvConfig* cfg, const HgymEnvState* st, const float* actions_in,
+                         const HgymEnvNoise* noise, void* stream);
+
+/* LeggedRobot._compute_torques (legged_robot.py:340-356) on the current dof state -> st->torques. */
+int32_t hgym_pd_torques(const HgymEnvConfig* cfg, const HgymSimTensors* sim, const HgymEnvState* st, void* stream);
+
+/* Stands where gym.simulate x decimation is (legged_robot.py:94-101,124-126): the synthetic physics of
+ * SURVEY.md §8d (benchmark backend).  Runs `decimation` PD + semi-implicit Euler substeps and draws the
+ * root / contact / rigid-body tensors from Philox. */
+int32_t hgym_synth_physics(const HgymEnvConfig* cfg, const HgymSimTensors* sim, const HgymEnvState* st, void* stream);
+
+/* LeggedRobot.post_physics_step + obs clip (legged_robot.py:119-151,105-108) with XBotLFreeEnv's
+ * callbacks, 22 reward terms, mask-driven reset_idx and observation stacking. */
+int32_t hgym_post_physics(const HgymEnvConfig* cfg, const HgymSimTensors* sim, const HgymEnvState* st,
+                          const HgymEnvOut* out, const HgymEnvNoise* noise, void* stream);
+
+/* Fast path: pre_physics + synth_physics + post_physics in ONE launch, then the step finaliser. */
+int32_t hgym_env_step_synth(const HgymEnvConfig* cfg, const HgymSimTensors* sim, const HgymEnvState* st,
+                            const HgymEnvOut* out, const float* actions_in, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Rollout storage side (algo/ppo/rollout_storage.py, algo/ppo/ppo.py:103-117)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* PPO.process_env_step + RolloutStorage.add_transitions for the scalar columns (ppo.py:103-113,
+ * rollout_storage.py:87-100): rewards_slot = rew + gamma*values*time_outs ; dones_slot = dones. */
+int32_t hgym_store_step(int32_t n, const float* rew, const float* values, const uint8_t* time_outs,
+                        const uint8_t* dones, float gamma, float* rewards_slot, uint8_t* dones_slot, void* stream);
+
+/* RolloutStorage.compute_returns (rollout_storage.py:122-136): GAE(lambda) as a wavefront suffix scan.
+ * rewards/values/returns/advantages are (T,N) time-major fp32, dones (T,N) uint8, last_values (N,).
+ * stats: 3 doubles on the device [sum adv, sum adv^2, count], accumulated (zeroed by this call). */
+int32_t hgym_gae(int32_t T, int32_t n, const float* rewards, const float* values, const uint8_t* dones,
+                 const float* last_values, float gamma, float lam, float* returns, float* advantages,
+                 double* stats, void* stream);
+
+/* advantages = (adv - mean) / (std_unbiased + 1e-8) from stats (possibly all-reduced by the caller). */
+int32_t hgym_adv_normalize(int64_t count, float* advantages, const double* stats, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Actor / critic (algo/ppo/actor_critic.py) and PPO update (algo/ppo/ppo.py:119-184)
+ * ---------------------------------------------------------------------------------------------- */
+enum { HGYM_F32 = 0, HGYM_BF16 = 1 };
+
+typedef struct HgymNetConfig {
+    int32_t num_obs, num_priv, num_actions;
+    int32_t actor_layers, critic_layers;                 /* number of Linear layers (4, 4) */
+    int32_t actor_dims[HGYM_MAX_LAYERS + 1];             /* 705,512,256,128,12 */
+    int32_t critic_dims[HGYM_MAX_LAYERS + 1];            /* 219,768,256,128,1  */
+    int32_t precision;                                   /* HGYM_F32 (parity) or HGYM_BF16 (MFMA fast path) */
+    int32_t max_batch;                                   /* largest M any call will use */
+} HgymNetConfig;
+
+typedef struct HgymPPOConfig {
+    float clip_param, value_loss_coef, entropy_coef, max_grad_norm, desired_kl;
+    float beta1, beta2, adam_eps;
+    double lr_min, lr_max;          /* 1e-5, 1e-2 (ppo.py:142-145) */
+    int32_t adaptive_lr;            /* schedule == 'adaptive' */
+    int32_t world_size;             /* >1: gradients are averaged by the caller between grad and apply */
+} HgymPPOConfig;
+
+/* Sizes (bytes) of the caller-allocated blocks, as functions of the configuration. */
+int64_t hgym_net_param_count(const HgymNetConfig* net);          /* 926105 for XBot-L */
+int64_t hgym_net_workspace_bytes(const HgymNetConfig* net);
+
+/* Master parameters are ONE flat fp32 array in state_dict order
+ * (std, actor.{0,2,4,6}.{weight,bias}, critic.{0,2,4,6}.{weight,bias}; SURVEY.md §5 checkpoint row);
+ * grads/adam_m/adam_v have the same layout.  opt_state: doubles on the device
+ * [0] learning rate, [1] adam step count, [2] kl sum, [3] surrogate sum, [4] value-loss sum,
+ * [5] entropy sum, [6] grad norm, [7] minibatches accumulated. */
+typedef struct HgymNet {
+    float* params;
+    float* grads;
+    float* adam_m;
+    float* adam_v;
+    double* opt_state;     /* [8] */
+    void* workspace;       /* hgym_net_workspace_bytes() bytes, 256-byte aligned */
+} HgymNet;
+
+/* re-derive the compute-precision operand copies (padded W and W^T) from the fp32 master parameters;
+ * call after loading a checkpoint.  The Adam kernel keeps them current afterwards. */
+int32_t hgym_net_sync_shadow(const HgymNetConfig* cfg, const HgymNet* net, void* stream);
+
+/* ActorCritic.act_inference / evaluate (actor_critic.py:122-128): which = 0 actor, 1 critic.
+ * x (M, in) row-major fp32 with leading dimension ldx; y (M, out) row-major fp32. */
+int32_t hgym_mlp_forward(const HgymNetConfig* cfg, const HgymNet* net, int32_t which, int32_t M,
+                         const float* x, int64_t ldx, float* y, void* stream);
+
+/* PPO.act (ppo.py:91-101): mu = actor(obs); sigma = std; a = mu + sigma*z; V = critic(priv);
+ * logp = sum log N(a; mu, sigma).  z (M,12) standard normal draws or NULL -> Philox(seed, *step_counter).
+ * Outputs row-major: actions/mu/sigma (M,12), logp (M,), values (M,). */
+int32_t hgym_policy_act(const HgymNetConfig* cfg, const HgymNet* net, int32_t M, const float* obs,
+                        const float* priv, const float* z, uint64_t seed, const int64_t* step_counter,
+                        float* actions, float* mu, float* sigma, float* logp, float* values, void* stream);
+
+/* One minibatch of PPO.update up to and including backward (ppo.py:128-171), device side only:
+ * gathers rows `idx[0..B)` (indices into the flattened (T*N) storage, rollout_storage.py:151-182) of the
+ * nine storage tensors, forward, KL -> learning-rate adaptation (written to opt_state[0]), clipped
+ * surrogate + clipped value loss + entropy bonus, hand-written backward -> net->grads (un-clipped). */
+typedef struct HgymBatch {
+    const float* obs;        /* (T*N, num_obs)   */
+    const float* priv;       /* (T*N, num_priv)  */
+    const float* actions;    /* (T*N, 12) */
+    const float* values;     /* (T*N,)    */
+    const float* advantages; /* (T*N,)    */
+    const float* returns;    /* (T*N,)    */
+    const float* logp;       /* (T*N,)    */
+    const float* mu;         /* (T*N, 12) */
+    const float* sigma;      /* (T*N, 12) */
+    const int64_t* idx;      /* (B,) */
+    int32_t B;
+} HgymBatch;
+
+int32_t hgym_ppo_grad(const HgymNetConfig* cfg, const HgymPPOConfig* ppo, const HgymNet* net,
+                      const HgymBatch* batch, void* stream);
+
+/* clip_grad_norm_ + Adam.step (ppo.py:173-174) on net->grads (already averaged across ranks when
+ * world_size > 1), refreshes the compute-precision shadows, bumps opt_state. */
+int32_t hgym_ppo_apply(const HgymNetConfig* cfg, const HgymPPOConfig* ppo, const HgymNet* net, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HGYM_H_ */

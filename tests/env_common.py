@@ -1,0 +1,228 @@
+"""Shared driver for the env parity tests: runs the same seeded trace through a backend (the HIP library on a
+GPU, or the host emulation of the same kernel source) and through the oracle, and compares everything.
+
+Bars (BASELINE.json north_star / SURVEY.md §8c): termination / time-out / indexing masks and integer state
+bit-exact; rewards, observations and float state within 1e-5 relative (+ a small absolute floor for values
+that pass through the reference's add-2pi-subtract-2pi angle wrap, which quantises to ~5e-7).
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "humanoid-gym_amd"))
+
+from oracle import xbot_constants as K  # noqa: E402
+from oracle.xbot_env_oracle import XBotEnvOracle  # noqa: E402
+
+RTOL, ATOL = 1e-5, 2e-6
+
+
+def synth_frames(gen, N):
+    """One Isaac-Gym-shaped frame of seeded synthetic sim state (same recipe as tests/golden/ref_harness.py)."""
+    root = torch.zeros(N, 13)
+    root[:, 0:2] = torch.randn(N, 2, generator=gen) * 0.5
+    root[:, 2] = 0.9 + 0.02 * (2 * torch.rand(N, generator=gen) - 1)
+    q = torch.cat([torch.randn(N, 3, generator=gen) * 0.15, torch.ones(N, 1)], dim=1)
+    root[:, 3:7] = q / q.norm(dim=1, keepdim=True)
+    root[:, 7:13] = torch.randn(N, 6, generator=gen) * 0.3
+    dof = torch.zeros(N, 12, 2)
+    dof[:, :, 0] = torch.randn(N, 12, generator=gen) * 0.2
+    dof[:, :, 1] = torch.randn(N, 12, generator=gen) * 1.5
+    contact = torch.zeros(N, K.NUM_BODIES, 3)
+    feet, knees = list(K.FEET_BODIES), list(K.KNEE_BODIES)
+    u = torch.rand(N, 2, generator=gen)
+    on = (torch.rand(N, 2, generator=gen) > 0.4).float()
+    contact[:, feet, 2] = 900.0 * u * on
+    contact[:, feet, 0:2] = torch.randn(N, 2, 2, generator=gen) * 40.0 * on.unsqueeze(-1)
+    hit = (torch.rand(N, generator=gen) < 0.04).float()
+    contact[:, 0, :] = torch.randn(N, 3, generator=gen) * 2.0 * hit.unsqueeze(-1)
+    small = (torch.rand(N, generator=gen) < 0.05).float() * (1 - hit)
+    contact[:, 0, :] += torch.randn(N, 3, generator=gen) * 0.2 * small.unsqueeze(-1)
+    rigid = torch.randn(N, K.NUM_BODIES, 13, generator=gen) * 0.2
+    rigid[:, feet, 2] = 0.03 + 0.09 * torch.rand(N, 2, generator=gen)
+    rigid[:, feet[0], 1] += 0.15
+    rigid[:, feet[1], 1] -= 0.15
+    rigid[:, knees[0], 1] += 0.12
+    rigid[:, knees[1], 1] -= 0.12
+    return root, dof.reshape(N * 12, 2), contact.reshape(N * K.NUM_BODIES, 3), rigid.reshape(N * K.NUM_BODIES, 13)
+
+
+class HipBackend:
+    """Calls libhgym_hip.so on the current CUDA(HIP) stream."""
+
+    name = "hip"
+    device = "cuda"
+
+    def __init__(self):
+        from hgym import _lib as L
+        self.L = L
+
+    def stream(self):
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def step_call(self, mode, cfg, sim, st, out, noise):
+        L = self.L
+        fn = {"prime": L.lib.hgym_env_prime, "reset_all": L.lib.hgym_env_reset_all, "post": L.lib.hgym_post_physics}[mode]
+        L.check(fn(C.byref(cfg), C.byref(sim), C.byref(st), C.byref(out), C.byref(noise), self.stream()), mode)
+
+    def pre_physics(self, cfg, st, actions, noise):
+        self.L.check(self.L.lib.hgym_pre_physics(C.byref(cfg), C.byref(st), self.L.fptr(actions), C.byref(noise), self.stream()))
+
+    def pd_torques(self, cfg, sim, st):
+        self.L.check(self.L.lib.hgym_pd_torques(C.byref(cfg), C.byref(sim), C.byref(st), self.stream()))
+
+    def sync(self):
+        torch.cuda.synchronize()
+
+
+class HostBackend:
+    """Drives tests/hostcheck/libhgym_hostcheck.so: the product's kernel source compiled for the host."""
+
+    name = "host"
+    device = "cpu"
+
+    def __init__(self, envs_per_block=8, nthreads=64):
+        sys.path.insert(0, os.path.join(ROOT, "tests", "hostcheck"))
+        import build_hostcheck
+        self.lib = C.CDLL(build_hostcheck.build())
+        self.epb, self.nthreads = envs_per_block, nthreads
+
+    def step_call(self, mode, cfg, sim, st, out, noise):
+        m = {"post": 0, "prime": 1, "reset_all": 2}[mode]
+        self.lib.hc_env_step(C.byref(cfg), C.byref(sim), C.byref(st), C.byref(out), C.byref(noise), None, m, 0,
+                             self.epb, self.nthreads)
+
+    def pre_physics(self, cfg, st, actions, noise):
+        self.lib.hc_pre_physics(C.byref(cfg), C.byref(st), C.cast(actions.data_ptr(), C.POINTER(C.c_float)), C.byref(noise))
+
+    def pd_torques(self, cfg, sim, st):
+        self.lib.hc_pd_torques(C.byref(cfg), C.byref(sim), C.byref(st))
+
+    def sync(self):
+        pass
+
+
+def close(a, b, what, rtol=RTOL, atol=ATOL):
+    a = a.detach().cpu().float().numpy() if torch.is_tensor(a) else np.asarray(a)
+    b = b.detach().cpu().float().numpy() if torch.is_tensor(b) else np.asarray(b)
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol, err_msg=what)
+
+
+def exact(a, b, what):
+    a = a.detach().cpu() if torch.is_tensor(a) else torch.as_tensor(a)
+    b = b.detach().cpu() if torch.is_tensor(b) else torch.as_tensor(b)
+    assert torch.equal(a.to(torch.int64), b.to(torch.int64)), what
+
+
+class EnvUnderTest:
+    """Product-side buffers + the call sequence of one vec-step in parity mode (external noise, external sim frames)."""
+
+    def __init__(self, backend, N, friction, body_mass, sim_layout="soa", frame_stack=15, c_frame_stack=3):
+        from hgym import EnvBuffers, default_env_config
+        self.be = backend
+        self.cfg = default_env_config(N, frame_stack=frame_stack, c_frame_stack=c_frame_stack)
+        self.buf = EnvBuffers(self.cfg, backend.device, sim_layout=sim_layout)
+        self.buf.f["friction"].copy_(friction.view(1, N))
+        self.buf.f["body_mass"].copy_(body_mass.view(1, N))
+        self.sim, self.st, self.out = self.buf.sim_struct(), self.buf.state_struct(), self.buf.out_struct()
+        self.dev = backend.device
+
+    def _noise(self, **kw):
+        self._keep = {k: (None if v is None else v.to(self.dev).float().contiguous()) for k, v in kw.items()}
+        return self.buf.noise_struct(**self._keep)
+
+    def prime(self, u_dof, u_cmd3, z_obs):
+        N = self.buf.N
+        u_cmd = torch.zeros(N, 6)
+        u_cmd[:, 3:6] = u_cmd3
+        self.be.step_call("prime", self.cfg, self.sim, self.st, self.out, self._noise(u_dof=u_dof, u_cmd=u_cmd, z_obs=z_obs))
+
+    def reset_all(self, u_dof, u_cmd3):
+        N = self.buf.N
+        u_cmd = torch.zeros(N, 6)
+        u_cmd[:, 3:6] = u_cmd3
+        self.be.step_call("reset_all", self.cfg, self.sim, self.st, self.out, self._noise(u_dof=u_dof, u_cmd=u_cmd))
+
+    def step(self, actions_in, frame, u_delay, z_act, u_cmd, u_dof, u_push, z_obs):
+        a = actions_in.to(self.dev).float().contiguous()
+        self.be.pre_physics(self.cfg, self.st, a, self._noise(u_delay=u_delay, z_act=z_act))
+        self.be.pd_torques(self.cfg, self.sim, self.st)
+        self.be.sync()
+        self.buf.load_sim(*frame)
+        self.be.step_call("post", self.cfg, self.sim, self.st, self.out,
+                          self._noise(u_cmd=u_cmd, u_dof=u_dof, u_push=u_push, z_obs=z_obs))
+        self.be.sync()
+
+
+def compare_state(env, o, tag, check_obs=True):
+    """Every observable of the product env against the oracle object `o` (after the same step)."""
+    b = env.buf
+    exact(b.reset, o.reset, tag + " reset mask")
+    exact(b.time_out, o.time_out, tag + " time_out mask")
+    exact(b.episode_length, o.ep_len, tag + " episode_length")
+    if o.extras_time_outs is not None:
+        exact(b.extras_time_outs, o.extras_time_outs, tag + " extras time_outs (stale-by-design)")
+    for name, ref in [("commands", o.commands), ("actions", o.actions), ("last_actions", o.last_actions),
+                      ("last_last_actions", o.last_last_actions), ("last_dof_vel", o.last_dof_vel),
+                      ("last_root_vel", o.last_root_vel), ("torques", o.torques), ("feet_air_time", o.feet_air_time),
+                      ("feet_height", o.feet_height), ("last_feet_z", o.last_feet_z), ("ref_dof_pos", o.ref_dof_pos),
+                      ("push_force", o.push_force), ("push_torque", o.push_torque), ("episode_sums", o.episode_sums),
+                      ("base_lin_vel", o.base_lin_vel), ("base_ang_vel", o.base_ang_vel),
+                      ("projected_gravity", o.projected_gravity), ("base_euler", o.base_euler)]:
+        close(b.view(name), ref, tag + " " + name)
+    exact(b.view("last_contacts") > 0.5, o.last_contacts, tag + " last_contacts")
+    close(b.rew, o.rew, tag + " rew")
+    close(b.root_view(), o.sim.root, tag + " root_states (reset / push write-back)")
+    close(b.dof_pos_view(), o.sim.dof_pos, tag + " dof_pos")
+    close(b.dof_vel_view(), o.sim.dof_vel, tag + " dof_vel")
+    if o.extras_episode is not None:
+        close(b.extras_episode, o.extras_episode, tag + " extras episode means", rtol=1e-5, atol=1e-7)
+    if check_obs:
+        close(b.obs, torch.clip(o.obs, -K.CLIP_OBS, K.CLIP_OBS), tag + " obs")
+        close(b.priv_obs, torch.clip(o.priv, -K.CLIP_OBS, K.CLIP_OBS), tag + " priv_obs")
+
+
+def run_random_trace(backend, N, steps, seed, sim_layout="soa", frame_stack=15, c_frame_stack=3, check_every=1):
+    """Seeded random trace through product + oracle with identical inputs; returns event counts."""
+    g = torch.Generator().manual_seed(seed)
+    fr = 0.1 + 1.9 * torch.rand(N, 1, generator=g)
+    bm = 10.0 + 10.0 * torch.rand(N, 1, generator=g)
+    o = XBotEnvOracle(N, frictions=fr, body_mass=bm, frame_stack=frame_stack, c_frame_stack=c_frame_stack)
+    env = EnvUnderTest(backend, N, fr, bm, sim_layout=sim_layout, frame_stack=frame_stack, c_frame_stack=c_frame_stack)
+    u_dof, u_cmd3, z_obs = torch.rand(N, 12, generator=g), torch.rand(N, 3, generator=g), torch.randn(N, 47, generator=g)
+    o.prime(u_dof, u_cmd3, z_obs)
+    env.prime(u_dof, u_cmd3, z_obs)
+    backend.sync()
+    compare_state(env, o, "prime")
+    ep = torch.randint(0, 2400, (N,), generator=g)
+    ep[: min(N, 6)] = torch.tensor([2399, 2398, 799, 1598, 0, 2396])[: min(N, 6)]
+    o.ep_len = ep.clone()
+    env.buf.episode_length.copy_(ep)
+    csc = 397
+    o.common_step_counter = csc
+    env.buf.counters[0] = csc
+    counts = dict(reset=0, timeout=0, push=0, stale=0)
+    for t in range(steps):
+        a_in = torch.randn(N, 12, generator=g) * 1.5
+        if t % 5 == 2:
+            a_in[t % N] *= 40.0
+        frame = synth_frames(g, N)
+        u_delay, z_act = torch.rand(N, generator=g), torch.randn(N, 12, generator=g)
+        u_cmd, u_dof = torch.rand(N, 6, generator=g), torch.rand(N, 12, generator=g)
+        u_push, z_obs = torch.rand(N, 5, generator=g), torch.randn(N, 47, generator=g)
+        o.pre_physics(a_in, u_delay, z_act)
+        o.pd_torques()
+        o.sim.load(*frame)
+        _, _, _, _, info = o.post_physics(u_cmd, u_dof, u_push, z_obs)
+        env.step(a_in, frame, u_delay, z_act, u_cmd, u_dof, u_push, z_obs)
+        if t % check_every == 0 or t == steps - 1:
+            compare_state(env, o, "step %d" % t)
+        counts["reset"] += int(o.reset.sum())
+        counts["timeout"] += int(o.time_out.sum())
+        counts["push"] += int(info["pushed"])
+        counts["stale"] += int((not info["any_reset"]) and o.extras_time_outs is not None and bool(o.extras_time_outs.any()))
+    return counts, env, o

@@ -1,0 +1,21 @@
+"""Builds tests/hostcheck/libhgym_hostcheck.so (host emulation of the env kernels; test tool only)."""
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "hostcheck.hip")
+LIB = os.path.join(HERE, "libhgym_hostcheck.so")
+CSRC = os.path.join(os.path.dirname(os.path.dirname(HERE)), "humanoid-gym_amd", "csrc")
+
+
+def build(force=False):
+    deps = [SRC] + [os.path.join(CSRC, f) for f in ("hgym_env_math.hpp", "hgym_common.hpp")]
+    if not force and os.path.exists(LIB) and all(os.path.getmtime(d) <= os.path.getmtime(LIB) for d in deps):
+        return LIB
+    subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--offload-arch=gfx950", "-O2", "-std=c++17",
+                           "-ffp-contract=off", "-fPIC", "-shared", SRC, "-o", LIB])
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force=True))

@@ -1,0 +1,89 @@
+// tests/hostcheck/hostcheck.hip -- TEST TOOL, not product code.
+// Builds the product's __host__ __device__ env arithmetic (humanoid-gym_amd/csrc/hgym_env_math.hpp) for the
+// HOST and drives it with plain loops that emulate the launch geometry of env_step_kernel (phase A over the
+// block's first lanes, barrier, phase B over all lanes, then the finaliser).  It lets the CPU-only test suite
+// compare the kernels' source-level arithmetic with the oracle before any GPU time is spent.  It is never
+// linked into libhgym_hip.so and nothing in the product path loads it.
+#include <vector>
+
+#include "../../humanoid-gym_amd/csrc/hgym_env_math.hpp"
+
+namespace hgym {
+char* last_error_buf() {
+    static thread_local char buf[512];
+    return buf;
+}
+}  // namespace hgym
+using namespace hgym;
+
+static EnvArgs make_args(const HgymEnvConfig* cfg, const HgymSimTensors* sim, const HgymEnvState* st, const HgymEnvOut* out,
+                         const HgymEnvNoise* noise, const float* actions_in, int mode, int fused, int epb) {
+    EnvArgs A;
+    memset(&A, 0, sizeof(A));
+    A.cfg = *cfg;
+    if (sim) A.sim = *sim;
+    A.st = *st;
+    if (out) A.out = *out;
+    if (noise) A.noise = *noise;
+    A.actions_in = actions_in;
+    A.mode = mode;
+    A.fused = fused;
+    A.envs_per_block = epb;
+    return A;
+}
+
+extern "C" {
+
+int hc_env_step(const HgymEnvConfig* cfg, const HgymSimTensors* sim, const HgymEnvState* st, const HgymEnvOut* out,
+                const HgymEnvNoise* noise, const float* actions_in, int mode, int fused, int epb, int nthreads) {
+    const EnvArgs A = make_args(cfg, sim, st, out, noise, actions_in, mode, fused, epb);
+    const int N = cfg->num_envs;
+    const int blocks = (N + epb - 1) / epb;
+    const int64_t csc0 = st->counters[0], ring = st->counters[2];
+    std::vector<float> smem(step_smem_bytes(epb) / sizeof(float));
+    for (int b = 0; b < blocks; ++b) {
+        for (int t = 0; t < nthreads; ++t) env_step_phase_a(A, b, t, smem.data(), csc0);
+        for (int t = 0; t < nthreads; ++t) {
+            if (cfg->frame_stack == 15 && cfg->c_frame_stack == 3) env_step_phase_b<15, 3>(A, b, t, nthreads, smem.data(), csc0, ring);
+            else env_step_phase_b<0, 0>(A, b, t, nthreads, smem.data(), csc0, ring);
+        }
+    }
+    for (int t = 0; t < nthreads; ++t) env_finalize_part1(A, t, nthreads);
+    env_finalize_part2(A);
+    return 0;
+}
+
+int hc_pre_physics(const HgymEnvConfig* cfg, const HgymEnvState* st, const float* actions_in, const HgymEnvNoise* noise) {
+    const EnvArgs A = make_args(cfg, nullptr, st, nullptr, noise, actions_in, MODE_STEP, 0, 4);
+    const RngKey rk = make_rng_key(A, st->counters[0]);
+    for (int e = 0; e < cfg->num_envs; ++e) pre_physics_env(A, rk, e, cfg->num_envs);
+    return 0;
+}
+
+int hc_pd_torques(const HgymEnvConfig* cfg, const HgymSimTensors* sim, const HgymEnvState* st) {
+    const EnvArgs A = make_args(cfg, sim, st, nullptr, nullptr, nullptr, MODE_STEP, 0, 4);
+    for (int e = 0; e < cfg->num_envs; ++e) pd_torques_env(A, e, cfg->num_envs);
+    return 0;
+}
+
+int hc_synth_physics(const HgymEnvConfig* cfg, const HgymSimTensors* sim, const HgymEnvState* st) {
+    const EnvArgs A = make_args(cfg, sim, st, nullptr, nullptr, nullptr, MODE_STEP, 0, 4);
+    const RngKey rk = make_rng_key(A, st->counters[0]);
+    for (int e = 0; e < cfg->num_envs; ++e) synth_physics_env(A, rk, e, cfg->num_envs);
+    return 0;
+}
+
+// raw Philox / normal streams for pinning oracle/philox.py
+void hc_philox(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t* out4) {
+    U4 c = {c0, c1, c2, c3};
+    const U4 r = philox4x32_10(c, k0, k1);
+    out4[0] = r.x; out4[1] = r.y; out4[2] = r.z; out4[3] = r.w;
+}
+void hc_streams(uint64_t seed, int64_t step, uint32_t env, uint32_t slot, int n, float* uniforms, float* normals) {
+    RngKey rk = {(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)step, (uint32_t)(step >> 32)};
+    for (int i = 0; i < n; ++i) {
+        uniforms[i] = uniform_at(rk, env, slot, i);
+        normals[i] = normal_at(rk, env, slot, i);
+    }
+}
+}

@@ -1,0 +1,48 @@
+"""CPU-only: libhgym_hip.so loads and exports every symbol include/hgym.h declares, and the ctypes mirrors of
+the structs have the C sizes.  No compute calls (there is no GPU here)."""
+import ctypes as C
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_header_symbols_exported():
+    from hgym import _lib as L
+    hdr = open(os.path.join(ROOT, "include", "hgym.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(hgym_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    assert declared == set(L.SYMBOLS), (declared ^ set(L.SYMBOLS))
+    for name in declared:
+        assert hasattr(L.lib, name), name
+    assert L.lib.hgym_version() == 1
+
+
+def test_struct_layouts_match():
+    from hgym import _lib as L
+    for name, st in L.STRUCTS.items():
+        assert C.sizeof(st) == L.lib.hgym_sizeof(name.encode()), name
+    assert L.lib.hgym_sizeof(b"nope") == -1
+
+
+def test_default_config_matches_reference_constants(golden_dir):
+    import json
+    import numpy as np
+    from hgym import default_env_config
+    K = json.load(open(os.path.join(golden_dir, "constants.json")))
+    c = default_env_config(64)
+    f32 = lambda x: float(np.float32(x))
+    assert [f32(x) for x in K["reward_scales_dt"]] == list(c.reward_scales)
+    assert [f32(x) for x in K["noise_scale_vec"]] == list(c.obs_noise)
+    assert [f32(x) for x in K["p_gains"]] == list(c.p_gains) and [f32(x) for x in K["d_gains"]] == list(c.d_gains)
+    assert [f32(x) for x in K["torque_limits"]] == list(c.torque_limits)
+    assert [f32(x) for x in K["base_init_state"]] == list(c.base_init_state)
+    assert c.dt == f32(K["dt"]) and c.max_episode_length == K["max_episode_length"]
+    assert c.resample_steps == K["resample_steps"] and c.push_interval == K["push_interval"]
+
+
+def test_errors_are_reported_not_swallowed():
+    from hgym import _lib as L
+    rc = L.lib.hgym_gae(0, 0, None, None, None, None, 0.9, 0.9, None, None, None, None)
+    assert rc == -2 and b"T=0" in L.lib.hgym_last_error()

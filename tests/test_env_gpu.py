@@ -1,0 +1,100 @@
+"""-m gpu: the env kernels of libhgym_hip.so on a real MI355X, through the C-ABI, against the oracle
+(identical seeded inputs and noise tables) and against the golden trace recorded from the reference."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import env_common as EC
+
+pytestmark = pytest.mark.gpu
+T = lambda a: torch.from_numpy(np.asarray(a))
+
+
+@pytest.fixture(scope="module")
+def hip():
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    return EC.HipBackend()
+
+
+def test_golden_trace_gpu(hip, golden_dir):
+    G = np.load(os.path.join(golden_dir, "env_trace.npz"))
+    N = G["friction"].shape[0]
+    env = EC.EnvUnderTest(hip, N, T(G["friction"]), T(G["body_mass"]), sim_layout="aos")
+    env.prime(T(G["prime_u_dof"]), T(G["prime_u_cmd"]), T(G["prime_z_obs"]))
+    hip.sync()
+    EC.close(env.buf.obs, G["prime_obs"], "prime obs")
+    EC.close(env.buf.priv_obs, G["prime_priv"], "prime priv")
+    env.buf.episode_length.copy_(T(G["init_ep_len"]))
+    env.buf.counters[0] = int(G["init_common_step_counter"])
+    full = {int(s) for s in G["full_steps"]}
+    for t in range(G["rew"].shape[0]):
+        frame = (T(G["root"][t]), T(G["dof"][t]), T(G["contact"][t]), T(G["rigid"][t]))
+        env.step(T(G["actions_in"][t]), frame, T(G["u_delay"][t]), T(G["z_act"][t]), T(G["u_cmd"][t]), T(G["u_dof"][t]),
+                 T(G["u_push"][t]), T(G["z_obs"][t]))
+        b = env.buf
+        EC.exact(b.reset, G["reset"][t], "reset %d" % t)                       # bit-exact masks
+        EC.exact(b.time_out, G["time_out"][t], "time_out %d" % t)
+        EC.exact(b.episode_length, G["ep_len"][t], "ep_len %d" % t)
+        EC.exact(b.extras_time_outs, G["extras_time_outs"][t], "extras time_outs %d" % t)
+        EC.close(b.rew, G["rew"][t], "rew %d" % t)                              # 1e-5 relative
+        EC.close(b.view("torques"), G["torques"][t], "torques %d" % t)
+        EC.close(b.view("actions"), G["actions"][t], "actions %d" % t)
+        EC.close(b.view("commands"), G["commands"][t], "commands %d" % t)
+        EC.close(b.view("episode_sums"), G["episode_sums"][t], "episode_sums %d" % t)
+        EC.close(b.root, G["root_after"][t], "root %d" % t)
+        EC.close(b.dof_state, G["dof_after"][t], "dof %d" % t)
+        EC.close(b.extras_episode, G["extras_episode"][t], "extras episode %d" % t, rtol=1e-5, atol=1e-7)
+        if t in full:
+            EC.close(b.obs, G["obs_step%d" % t], "obs %d" % t)
+            EC.close(b.priv_obs, G["priv_step%d" % t], "priv %d" % t)
+
+
+@pytest.mark.parametrize("N,layout,steps", [(37, "soa", 20), (256, "aos", 16), (4096, "soa", 12)])
+def test_random_trace_gpu(hip, N, layout, steps):
+    counts, env, o = EC.run_random_trace(hip, N, steps=steps, seed=100 + N, sim_layout=layout,
+                                         check_every=1 if N < 1000 else 4)
+    assert counts["push"] == 1 and counts["timeout"] >= 1 and counts["reset"] >= 3
+
+
+def test_generic_frame_stack_gpu(hip):
+    EC.run_random_trace(hip, 100, steps=10, seed=7, frame_stack=4, c_frame_stack=2)
+
+
+def test_fused_synthetic_step_properties(hip):
+    """Full-size fused fast path (pre_physics + synthetic physics + post_physics in one launch, internal
+    Philox): size-independent properties instead of an element-wise oracle --
+    obs rows are the shifted previous rows plus a new frame, masks are consistent, counters advance."""
+    import ctypes as C
+    from hgym import EnvBuffers, default_env_config, _lib as L
+    N = 4096
+    cfg = default_env_config(N, seed=123)
+    buf = EnvBuffers(cfg, "cuda")
+    sim, st, out = buf.sim_struct(), buf.state_struct(), buf.out_struct()
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    noise = buf.noise_struct()
+    L.check(L.lib.hgym_env_prime(C.byref(cfg), C.byref(sim), C.byref(st), C.byref(out), C.byref(noise), s))
+    buf.episode_length.copy_(torch.randint(0, 2400, (N,)).cuda())
+    prev_obs = buf.obs.clone()
+    prev_ep = buf.episode_length.clone()
+    total_resets = 0
+    for t in range(30):
+        a = torch.randn(N, 12, device="cuda")
+        L.check(L.lib.hgym_env_step_synth(C.byref(cfg), C.byref(sim), C.byref(st), C.byref(out), L.fptr(a), s))
+        torch.cuda.synchronize()
+        obs, reset = buf.obs, buf.reset
+        assert torch.isfinite(obs).all() and torch.isfinite(buf.priv_obs).all() and torch.isfinite(buf.rew).all()
+        assert float(obs.abs().max()) <= 18.0 and float(buf.rew.min()) >= 0.0
+        keep = ~reset
+        # history shift: frames 0..13 of the new obs are frames 1..14 of the previous obs for non-reset envs
+        assert torch.equal(obs[keep, : 14 * 47], prev_obs[keep, 47:])
+        # reset envs: history zeroed, episode length back to 0, others advanced by exactly 1
+        assert float(obs[reset, : 14 * 47].abs().max()) == 0.0 if bool(reset.any()) else True
+        assert torch.equal(buf.episode_length[keep], prev_ep[keep] + 1)
+        assert int(buf.episode_length[reset].abs().sum()) == 0
+        assert bool((buf.time_out <= reset).all())
+        total_resets += int(reset.sum())
+        prev_obs, prev_ep = obs.clone(), buf.episode_length.clone()
+    assert int(buf.counters[0]) == 30 and int(buf.counters[2]) == 31
+    assert total_resets > 0

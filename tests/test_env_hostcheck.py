@@ -1,0 +1,88 @@
+"""CPU-only: the product's env kernel SOURCE (compiled for the host by tests/hostcheck) against the oracle and
+against the golden trace recorded from the reference.  Catches arithmetic / indexing / ring-buffer mistakes
+without a GPU; the `-m gpu` twin of this file (test_env_gpu.py) runs the real kernels."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import env_common as EC
+
+T = lambda a: torch.from_numpy(np.asarray(a))
+
+
+@pytest.fixture(scope="module")
+def host():
+    return EC.HostBackend(envs_per_block=8, nthreads=64)
+
+
+def test_golden_trace_host(host, golden_dir):
+    """The reference's own recorded trace (tests/golden/env_trace.npz) through the kernel source."""
+    G = np.load(os.path.join(golden_dir, "env_trace.npz"))
+    N = G["friction"].shape[0]
+    env = EC.EnvUnderTest(host, N, T(G["friction"]), T(G["body_mass"]), sim_layout="aos")
+    env.prime(T(G["prime_u_dof"]), T(G["prime_u_cmd"]), T(G["prime_z_obs"]))
+    EC.close(env.buf.obs, G["prime_obs"], "prime obs")
+    EC.close(env.buf.priv_obs, G["prime_priv"], "prime priv")
+    env.buf.episode_length.copy_(T(G["init_ep_len"]))
+    env.buf.counters[0] = int(G["init_common_step_counter"])
+    full = {int(s) for s in G["full_steps"]}
+    for t in range(G["rew"].shape[0]):
+        frame = (T(G["root"][t]), T(G["dof"][t]), T(G["contact"][t]), T(G["rigid"][t]))
+        env.step(T(G["actions_in"][t]), frame, T(G["u_delay"][t]), T(G["z_act"][t]), T(G["u_cmd"][t]), T(G["u_dof"][t]),
+                 T(G["u_push"][t]), T(G["z_obs"][t]))
+        b = env.buf
+        EC.exact(b.reset, G["reset"][t], "reset %d" % t)
+        EC.exact(b.time_out, G["time_out"][t], "time_out %d" % t)
+        EC.exact(b.episode_length, G["ep_len"][t], "ep_len %d" % t)
+        EC.exact(b.extras_time_outs, G["extras_time_outs"][t], "extras time_outs %d" % t)
+        EC.close(b.rew, G["rew"][t], "rew %d" % t)
+        EC.close(b.view("torques"), G["torques"][t], "torques %d" % t)
+        EC.close(b.view("actions"), G["actions"][t], "actions %d" % t)
+        EC.close(b.view("commands"), G["commands"][t], "commands %d" % t)
+        EC.close(b.view("episode_sums"), G["episode_sums"][t], "episode_sums %d" % t)
+        EC.close(b.root, G["root_after"][t], "root %d" % t)
+        EC.close(b.dof_state, G["dof_after"][t], "dof %d" % t)
+        EC.close(b.extras_episode, G["extras_episode"][t], "extras episode %d" % t, rtol=1e-5, atol=1e-7)
+        if t in full:
+            EC.close(b.obs, G["obs_step%d" % t], "obs %d" % t)
+            EC.close(b.priv_obs, G["priv_step%d" % t], "priv %d" % t)
+    for k in ("feet_air_time", "feet_height", "last_feet_z", "last_actions", "last_last_actions", "last_dof_vel",
+              "last_root_vel", "ref_dof_pos", "base_lin_vel", "base_ang_vel", "projected_gravity"):
+        EC.close(env.buf.view(k), G["final_" + k], k)
+    EC.close(env.buf.view("base_euler"), G["final_base_euler"], "base_euler")
+
+
+@pytest.mark.parametrize("N,layout,epb,nthreads", [(37, "soa", 8, 64), (64, "aos", 16, 256), (5, "soa", 4, 32)])
+def test_random_trace_host(N, layout, epb, nthreads):
+    be = EC.HostBackend(envs_per_block=epb, nthreads=nthreads)
+    counts, env, o = EC.run_random_trace(be, N, steps=24, seed=100 + N, sim_layout=layout)
+    assert counts["push"] == 1 and counts["timeout"] >= 1 and counts["reset"] >= 3
+
+
+def test_generic_frame_stack_host():
+    """frame_stack / c_frame_stack other than 15/3 take the runtime-sized kernel instantiation."""
+    be = EC.HostBackend(envs_per_block=4, nthreads=64)
+    EC.run_random_trace(be, 12, steps=12, seed=7, frame_stack=4, c_frame_stack=2)
+
+
+def test_reset_all_then_step_host():
+    """LeggedRobot.reset(): reset_idx(all) + a zero-action step (legged_robot.py:112-117)."""
+    be = EC.HostBackend()
+    counts, env, o = EC.run_random_trace(be, 16, steps=3, seed=5)
+    g = torch.Generator().manual_seed(1)
+    N = 16
+    u_dof, u_cmd3 = torch.rand(N, 12, generator=g), torch.rand(N, 3, generator=g)
+    o._reset_masked(torch.ones(N, dtype=torch.bool), u_dof, u_cmd3)
+    env.reset_all(u_dof, u_cmd3)
+    assert float(env.buf.obs_ring.abs().max()) == 0.0 and float(env.buf.priv_ring.abs().max()) == 0.0
+    EC.close(env.buf.view("commands"), o.commands, "commands after reset_all")
+    EC.exact(env.buf.episode_length, o.ep_len, "ep_len after reset_all")
+    frame = EC.synth_frames(g, N)
+    a = torch.zeros(N, 12)
+    nz = [torch.rand(N, generator=g), torch.randn(N, 12, generator=g), torch.rand(N, 6, generator=g),
+          torch.rand(N, 12, generator=g), torch.rand(N, 5, generator=g), torch.randn(N, 47, generator=g)]
+    o.pre_physics(a, nz[0], nz[1]); o.pd_torques(); o.sim.load(*frame); o.post_physics(*nz[2:])
+    env.step(a, frame, *nz)
+    EC.compare_state(env, o, "step after reset_all")
