@@ -1,12 +1,734 @@
-// placeholder, replaced by the real implementation
-#include "hgym_common.hpp"
-using namespace hgym;
-extern "C" {
-int64_t hgym_net_param_count(const HgymNetConfig*) { return -1; }
-int64_t hgym_net_workspace_bytes(const HgymNetConfig*) { return -1; }
-int32_t hgym_net_sync_shadow(const HgymNetConfig*, const HgymNet*, void*) { HG_FAIL(HGYM_E_UNSUPPORTED, "not built"); }
-int32_t hgym_mlp_forward(const HgymNetConfig*, const HgymNet*, int32_t, int32_t, const float*, int64_t, float*, void*) { HG_FAIL(HGYM_E_UNSUPPORTED, "not built"); }
-int32_t hgym_policy_act(const HgymNetConfig*, const HgymNet*, int32_t, const float*, const float*, const float*, uint64_t, const int64_t*, float*, float*, float*, float*, float*, void*) { HG_FAIL(HGYM_E_UNSUPPORTED, "not built"); }
-int32_t hgym_ppo_grad(const HgymNetConfig*, const HgymPPOConfig*, const HgymNet*, const HgymBatch*, void*) { HG_FAIL(HGYM_E_UNSUPPORTED, "not built"); }
-int32_t hgym_ppo_apply(const HgymNetConfig*, const HgymPPOConfig*, const HgymNet*, void*) { HG_FAIL(HGYM_E_UNSUPPORTED, "not built"); }
+// hgym_net.hip -- actor/critic forward, PPO loss + hand-written backward, grad-norm clip + Adam
+// (SURVEY.md §8a rows A1, A2, A8, A10, A11).  All dense products go through gemm_nt_kernel (hgym_gemm.hpp);
+// everything else here is the HBM-bound glue: operand packing / transposes, the per-sample Gaussian / PPO
+// arithmetic, reductions, the optimiser.
+//
+// Memory plan (caller-allocated workspace, zero-filled once; layout from ws_layout()):
+//   per layer l of each net:  Wp  [N16][Kp]   operand-precision copy of W (rows padded to 16, K to a stage)
+//                             WTp [K16][Ncp]  operand-precision copy of W^T (for dX = dY * W)
+//   per layer input:          X   [maxM][Kp]  row-major activations (X0 = packed observations)
+//                             XT  [K16][Mp]   their transposes (for dW = dY^T * X), update path only
+//   per layer output grad:    dY  [maxM][Ncp] and dYT [N16][Mp]
+//   split-K slabs             [splits][P] fp32, loss partial sums, scalar outputs
+// Pad rows/columns are never written with non-zero data, so zero-fill at allocation keeps every padded
+// contraction exact.
+#include "hgym_gemm.hpp"
+
+namespace hgym {
+
+// ------------------------------------------------------------------------------------------------ layouts
+struct LayerLayout {
+    int K, N;                // in, out features
+    int Kp, Ncp, N16, K16;   // padded sizes (see above)
+    int64_t w_off, b_off;    // offsets (floats) into the flat fp32 parameter vector
+    int64_t Wp, WTp;         // byte offsets into the workspace
+    int64_t X, XT, dY, dYT;  // byte offsets: layer input, its transpose, output grad, its transpose
+};
+
+struct NetLayout {
+    int L;
+    LayerLayout layer[HGYM_MAX_LAYERS];
+    int64_t out_f32;         // [maxM][N_last] fp32 output of the last layer (update path)
+};
+
+struct WsLayout {
+    int es;                  // operand element size
+    int SE;                  // stage elements (contraction padding unit)
+    int64_t maxM, Mp;        // max batch and its contraction padding (row stride of every transposed buffer)
+    int64_t P;               // total parameters
+    NetLayout net[2];        // 0 actor, 1 critic
+    int splits;
+    int64_t slabs;           // [splits][P] fp32
+    int64_t partials;        // [MAX_LOSS_BLOCKS][16] fp32
+    int64_t total_bytes;
+};
+
+constexpr int MAX_LOSS_BLOCKS = 1024;
+constexpr int MAX_SPLITS = 32;
+
+static int32_t ws_layout(const HgymNetConfig* c, WsLayout* w) {
+    HG_REQUIRE(c, HGYM_E_BADARG, "null net config");
+    HG_REQUIRE(c->precision == HGYM_F32 || c->precision == HGYM_BF16, HGYM_E_BADARG, "precision=%d", c->precision);
+    HG_REQUIRE(c->actor_layers >= 1 && c->actor_layers <= HGYM_MAX_LAYERS && c->critic_layers >= 1 &&
+                   c->critic_layers <= HGYM_MAX_LAYERS, HGYM_E_SHAPE, "layer counts %d/%d", c->actor_layers, c->critic_layers);
+    HG_REQUIRE(c->max_batch > 0, HGYM_E_SHAPE, "max_batch=%d", c->max_batch);
+    HG_REQUIRE(c->actor_dims[0] == c->num_obs && c->critic_dims[0] == c->num_priv &&
+                   c->actor_dims[c->actor_layers] == c->num_actions && c->critic_dims[c->critic_layers] == 1,
+               HGYM_E_SHAPE, "layer dims inconsistent with num_obs/num_priv/num_actions");
+    HG_REQUIRE(c->num_actions >= 1 && c->num_actions <= 16, HGYM_E_UNSUPPORTED, "num_actions=%d (kernels hold <=16 per lane)",
+               c->num_actions);
+    memset(w, 0, sizeof(*w));
+    w->es = c->precision == HGYM_F32 ? 4 : 2;
+    w->SE = c->precision == HGYM_F32 ? stage_elems<float>() : stage_elems<__bf16>();
+    w->maxM = c->max_batch;
+    w->Mp = round_up(c->max_batch, w->SE);
+    int64_t off = 0, poff = c->num_actions;  // std first (state_dict order)
+    auto take = [&](int64_t bytes) {
+        const int64_t o = off;
+        off += round_up(bytes, 256);
+        return o;
+    };
+    for (int which = 0; which < 2; ++which) {
+        NetLayout& n = w->net[which];
+        n.L = which == 0 ? c->actor_layers : c->critic_layers;
+        const int32_t* dims = which == 0 ? c->actor_dims : c->critic_dims;
+        for (int l = 0; l < n.L; ++l) {
+            LayerLayout& y = n.layer[l];
+            y.K = dims[l];
+            y.N = dims[l + 1];
+            HG_REQUIRE(y.K > 0 && y.N > 0, HGYM_E_SHAPE, "non-positive layer dim");
+            y.Kp = (int)round_up(y.K, w->SE);
+            y.Ncp = (int)round_up(y.N, w->SE);
+            y.N16 = (int)round_up(y.N, 16);
+            y.K16 = (int)round_up(y.K, 16);
+            y.w_off = poff;
+            poff += (int64_t)y.N * y.K;
+            y.b_off = poff;
+            poff += y.N;
+            y.Wp = take((int64_t)y.N16 * y.Kp * w->es);
+            y.WTp = take((int64_t)y.K16 * y.Ncp * w->es);
+            y.X = take(w->maxM * y.Kp * w->es);
+            y.XT = take((int64_t)y.K16 * w->Mp * w->es);
+            y.dY = take(w->maxM * y.Ncp * w->es);
+            y.dYT = take((int64_t)y.N16 * w->Mp * w->es);
+        }
+        n.out_f32 = take(w->maxM * (int64_t)dims[n.L] * 4);
+    }
+    w->P = poff;
+    w->splits = MAX_SPLITS;
+    w->slabs = take((int64_t)w->splits * w->P * 4);
+    w->partials = take((int64_t)MAX_LOSS_BLOCKS * 16 * 4);
+    w->total_bytes = off;
+    return HGYM_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ small kernels
+// dst[m][k] = T(src[row(m)][k]) for k < K; row(m) = idx ? idx[m] : m.  Pad columns are left untouched (zero).
+template <typename T>
+__global__ __launch_bounds__(256) void pack_rows_kernel(int M, int K, const float* __restrict__ src, int64_t ld_src,
+                                                        const int64_t* __restrict__ idx, T* __restrict__ dst, int64_t ld_dst) {
+    const int64_t total = (int64_t)M * K;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int m = (int)(i / K), k = (int)(i - (int64_t)m * K);
+        const int64_t r = idx ? idx[m] : m;
+        dst[(int64_t)m * ld_dst + k] = from_f32<T>(src[r * ld_src + k]);
+    }
+}
+
+// out[c][m] = in[m][c] for c < C, m < M; out[c][m] = 0 for M <= m < Mp  (Mp = contraction padding of this call)
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_kernel(int M, int Mp, int C, const T* __restrict__ in, int64_t ld_in,
+                                                        T* __restrict__ out, int64_t ld_out) {
+    __shared__ T tile[64][66];
+    const int m0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // 4 row groups
+    for (int r = ty; r < 64; r += 4) {
+        const int m = m0 + r, c = c0 + tx;
+        tile[r][tx] = (m < M && c < C) ? in[(int64_t)m * ld_in + c] : from_f32<T>(0.0f);
+    }
+    __syncthreads();
+    for (int r = ty; r < 64; r += 4) {
+        const int c = c0 + r, m = m0 + tx;
+        if (c < C && m < Mp) out[(int64_t)c * ld_out + m] = tile[tx][r];
+    }
+}
+
+// out[r] = sum_m in[r][m], one workgroup per row (bias gradients from dY^T)
+template <typename T>
+__global__ __launch_bounds__(256) void rowsum_kernel(int M, const T* __restrict__ in, int64_t ld_in, float* __restrict__ out) {
+    __shared__ float red[4];
+    const T* row = in + (int64_t)blockIdx.x * ld_in;
+    float s = 0.0f;
+    for (int m = threadIdx.x; m < M; m += blockDim.x) s += to_f32<T>(row[m]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// PPO.act epilogue (actor_critic.py:111-120): a = mu + sigma*z, logp = sum log N(a; mu, sigma); sigma = std.
+__global__ __launch_bounds__(256) void act_sample_kernel(int M, int A, const float* __restrict__ mu, const float* __restrict__ std_,
+                                                         const float* __restrict__ z, uint64_t seed, const int64_t* __restrict__ step,
+                                                         float* __restrict__ actions, float* __restrict__ sigma, float* __restrict__ logp) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    RngKey rk = {(uint32_t)seed, (uint32_t)(seed >> 32), 0u, 0u};
+    if (!z) {
+        const int64_t s = step ? step[0] : 0;
+        rk.s0 = (uint32_t)s;
+        rk.s1 = (uint32_t)(s >> 32);
+    }
+    float lp = 0.0f;
+    for (int j = 0; j < A; ++j) {
+        const float mj = mu[(int64_t)m * A + j];
+        const float sg = mj * 0.0f + std_[j];            // actor_critic.py:113 (propagates NaN like the reference)
+        const float zz = z ? z[(int64_t)m * A + j] : normal_at(rk, (uint32_t)m, SLOT_POLICY, j);
+        const float a = mj + sg * zz;
+        actions[(int64_t)m * A + j] = a;
+        sigma[(int64_t)m * A + j] = sg;
+        const float d = a - mj;
+        lp += -(d * d) / (2.0f * sg * sg) - logf(sg) - 0.9189385332046727f;
+    }
+    logp[m] = lp;
+}
+
+// One thread per sample of the minibatch: ppo.py:128-168 forward scalars + the hand-written backward of `loss`
+// w.r.t. mu, std and V (oracle/ppo_oracle.py:ppo_loss_and_grads is the executable specification).
+struct LossArgs {
+    HgymBatch b;
+    int A;                       // num_actions
+    const float* mu;             // [B][A] current policy mean (fp32 output of the actor)
+    const float* val;            // [B]    current value
+    const float* std_;           // [A]
+    float clip, value_coef, entropy_coef;
+    void* dmu;  int64_t ld_dmu;  // [B][Ncp] operand type
+    void* dmuT; int64_t ld_t;    // [A16][Mp]
+    void* dval; int64_t ld_dval; // [B][Ncp]
+    void* dvalT;                 // [16][Mp]
+    int Bp;                      // contraction padding of B for this call
+    float* partials;             // [gridDim.x][16]: surrogate, value loss, entropy, kl, dstd[12]
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void ppo_loss_kernel(const LossArgs a) {
+    __shared__ float red[4][16];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int B = a.b.B, A = a.A;
+    const float invB = 1.0f / (float)B;
+    float acc[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc[k] = 0.0f;
+    T* dmu = (T*)a.dmu;
+    T* dmuT = (T*)a.dmuT;
+    T* dval = (T*)a.dval;
+    T* dvalT = (T*)a.dvalT;
+    if (i < B) {
+        const int64_t r = a.b.idx[i];
+        const float adv = a.b.advantages[r], ret = a.b.returns[r], vold = a.b.values[r], lpold = a.b.logp[r];
+        const float v = a.val[i];
+        float lp = 0.0f, ent = 0.0f, kl = 0.0f;
+        float diff[16], sg[16];
+        for (int j = 0; j < A; ++j) {
+            const float m = a.mu[(int64_t)i * A + j];
+            const float s = m * 0.0f + a.std_[j];
+            const float act = a.b.actions[r * A + j];
+            const float mo = a.b.mu[r * A + j], so = a.b.sigma[r * A + j];
+            const float d = act - m;
+            diff[j] = d;
+            sg[j] = s;
+            lp += -(d * d) / (2.0f * s * s) - logf(s) - 0.9189385332046727f;
+            ent += 0.5f + 0.9189385332046727f + logf(s);
+            kl += logf(s / so + 1.e-5f) + (so * so + (mo - m) * (mo - m)) / (2.0f * (s * s)) - 0.5f;
+        }
+        const float ratio = expf(lp - lpold);
+        const float s1 = -adv * ratio;
+        const float s2 = -adv * clampf(ratio, 1.0f - a.clip, 1.0f + a.clip);
+        const float surr = fmaxf(s1, s2);
+        const float vc = vold + clampf(v - vold, -a.clip, a.clip);
+        const float l1 = (v - ret) * (v - ret), l2 = (vc - ret) * (vc - ret);
+        const float vl = fmaxf(l1, l2);
+        // backward (torch.max splits ties evenly between its operands; clamp passes gradient on the closed range)
+        const float in_range = (ratio >= 1.0f - a.clip && ratio <= 1.0f + a.clip) ? 1.0f : 0.0f;
+        const float w1 = s1 > s2 ? 1.0f : (s1 == s2 ? 0.5f : 0.0f);
+        const float d_lp = (-adv) * (w1 + (1.0f - w1) * in_range) * invB * ratio;
+        const float v_in = ((v - vold) >= -a.clip && (v - vold) <= a.clip) ? 1.0f : 0.0f;
+        const float u1 = l1 > l2 ? 1.0f : (l1 == l2 ? 0.5f : 0.0f);
+        const float d_v = a.value_coef * invB * (u1 * 2.0f * (v - ret) + (1.0f - u1) * 2.0f * (vc - ret) * v_in);
+        for (int j = 0; j < A; ++j) {
+            const float s = sg[j], d = diff[j];
+            const float g_mu = d_lp * d / (s * s);
+            const float g_sg = d_lp * (d * d / (s * s * s) - 1.0f / s) - (a.entropy_coef * invB) / s;
+            dmu[(int64_t)i * a.ld_dmu + j] = from_f32<T>(g_mu);
+            dmuT[(int64_t)j * a.ld_t + i] = from_f32<T>(g_mu);
+            acc[4 + j < 16 ? 4 + j : 15] += (4 + j < 16) ? g_sg : 0.0f;
+        }
+        dval[(int64_t)i * a.ld_dval] = from_f32<T>(d_v);
+        dvalT[i] = from_f32<T>(d_v);
+        acc[0] = surr;
+        acc[1] = vl;
+        acc[2] = ent;
+        acc[3] = kl;
+    } else if (i < a.Bp) {   // zero the contraction padding of the transposed gradients
+        for (int j = 0; j < A; ++j) dmuT[(int64_t)j * a.ld_t + i] = from_f32<T>(0.0f);
+        dvalT[i] = from_f32<T>(0.0f);
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        float s = acc[k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 16) a.partials[(int64_t)blockIdx.x * 16 + threadIdx.x] =
+        red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+// opt_state: [0] lr [1] adam step [2] kl sum [3] surrogate sum [4] value-loss sum [5] entropy sum [6] grad norm
+//            [7] minibatches accumulated [8] last minibatch mean KL [9] grad sq-norm accumulator
+__global__ __launch_bounds__(256) void ppo_scalars_kernel(int nblocks, int B, int A, const float* __restrict__ partials,
+                                                          float* __restrict__ grads_std, double* __restrict__ opt) {
+    __shared__ double red[16][17];
+    const int k = threadIdx.x & 15, part = threadIdx.x >> 4;   // 16 partial sums per quantity
+    double s = 0.0;
+    for (int b = part; b < nblocks; b += 16) s += (double)partials[(int64_t)b * 16 + k];
+    red[part][k] = s;
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        double t = 0.0;
+        for (int p = 0; p < 16; ++p) t += red[p][threadIdx.x];
+        const int q = threadIdx.x;
+        if (q == 0) opt[3] += t / B;
+        if (q == 1) opt[4] += t / B;
+        if (q == 2) opt[5] += t / B;
+        if (q == 3) {
+            opt[2] += t / B;
+            opt[8] = t / B;
+            opt[7] += 1.0;
+        }
+        if (q >= 4 && q - 4 < A) grads_std[q - 4] = (float)t;
+    }
+}
+
+// gradient finalise: sum the split-K slabs of every weight matrix into the flat gradient vector
+struct Segment {
+    int64_t off;     // offset in the flat parameter vector
+    int rows, cols;  // N, K  (bias / std: rows = count, cols = 1, no shadow)
+    int splits;      // slabs to sum (0: gradient already final in `grads`)
+    void* Wp;        // operand-precision shadow [N16][ldw] or null
+    int64_t ldw;
+    void* WTp;       // operand-precision transposed shadow [K16][ldwt] or null
+    int64_t ldwt;
+};
+struct SegTable {
+    int n;
+    Segment s[2 * HGYM_MAX_LAYERS * 2 + 1];
+};
+
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const SegTable tab, int64_t P, const float* __restrict__ slabs,
+                                                           float* __restrict__ grads) {
+    const Segment& sg = tab.s[blockIdx.y];
+    if (sg.splits == 0) return;
+    const int64_t n = (int64_t)sg.rows * sg.cols;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float s = 0.0f;
+        for (int z = 0; z < sg.splits; ++z) s += slabs[(int64_t)z * P + sg.off + i];
+        grads[sg.off + i] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void sqnorm_kernel(int64_t P, const float* __restrict__ g, double* __restrict__ opt) {
+    __shared__ double red[4];
+    double s = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (int64_t)gridDim.x * blockDim.x)
+        s += (double)g[i] * (double)g[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(&opt[9], red[0] + red[1] + red[2] + red[3]);
+}
+
+// ppo.py:140-148 (adaptive-KL learning rate, python-double arithmetic) + Adam step counter + norm accumulator reset
+__global__ void apply_prologue_kernel(const HgymPPOConfig p, double* __restrict__ opt) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (p.adaptive_lr) {
+        const double kl = opt[8];
+        double lr = opt[0];
+        if (kl > (double)p.desired_kl * 2.0) lr = fmax(p.lr_min, lr / 1.5);
+        else if (kl < (double)p.desired_kl / 2.0 && kl > 0.0) lr = fmin(p.lr_max, lr * 1.5);
+        opt[0] = lr;
+    }
+    opt[1] += 1.0;
+    opt[9] = 0.0;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void adam_kernel(const SegTable tab, const HgymPPOConfig p, float* __restrict__ params,
+                                                   float* __restrict__ grads, float* __restrict__ m_, float* __restrict__ v_,
+                                                   double* __restrict__ opt) {
+    const Segment& sg = tab.s[blockIdx.y];
+    const int64_t n = (int64_t)sg.rows * sg.cols;
+    // nn.utils.clip_grad_norm_: coef = max_norm / (total_norm + 1e-6), clamped to 1 (fp32 tensor arithmetic)
+    const float total = (float)sqrt(opt[9]);
+    float coef = p.max_grad_norm / (total + 1e-6f);
+    coef = fminf(coef, 1.0f);
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) opt[6] = (double)total;
+    const double t = opt[1];
+    const double bc1 = 1.0 - pow((double)p.beta1, t), bc2 = 1.0 - pow((double)p.beta2, t);
+    const float step_size = (float)(opt[0] / bc1);
+    const float sqrt_bc2 = (float)sqrt(bc2);
+    T* Wp = (T*)sg.Wp;
+    T* WTp = (T*)sg.WTp;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t q = sg.off + i;
+        const float g = grads[q] * coef;
+        grads[q] = g;
+        const float m = m_[q] * p.beta1 + (1.0f - p.beta1) * g;
+        const float v = v_[q] * p.beta2 + (1.0f - p.beta2) * (g * g);
+        m_[q] = m;
+        v_[q] = v;
+        const float denom = sqrtf(v) / sqrt_bc2 + p.adam_eps;
+        const float w = params[q] + (-step_size * m) / denom;
+        params[q] = w;
+        if (Wp) {
+            const int r = (int)(i / sg.cols), c = (int)(i - (int64_t)r * sg.cols);
+            Wp[(int64_t)r * sg.ldw + c] = from_f32<T>(w);
+            if (WTp) WTp[(int64_t)c * sg.ldwt + r] = from_f32<T>(w);
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void sync_shadow_kernel(const SegTable tab, const float* __restrict__ params) {
+    const Segment& sg = tab.s[blockIdx.y];
+    if (!sg.Wp) return;
+    T* Wp = (T*)sg.Wp;
+    T* WTp = (T*)sg.WTp;
+    const int64_t n = (int64_t)sg.rows * sg.cols;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / sg.cols), c = (int)(i - (int64_t)r * sg.cols);
+        const float w = params[sg.off + i];
+        Wp[(int64_t)r * sg.ldw + c] = from_f32<T>(w);
+        if (WTp) WTp[(int64_t)c * sg.ldwt + r] = from_f32<T>(w);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ GEMM dispatch
+template <typename T, int BM, int BN, int WMs, int WNs>
+static void launch_cfg(const GemmArgs& g, int splits, hipStream_t s) {
+    dim3 grid(ceil_div(g.N, BN), ceil_div(g.M, BM), splits);
+    hipLaunchKernelGGL((gemm_nt_kernel<T, BM, BN, WMs, WNs>), grid, dim3(WMs * WNs * 64), 0, s, g);
+}
+
+template <typename T>
+int32_t launch_gemm(const GemmArgs& g0, int splits, hipStream_t s) {
+    GemmArgs g = g0;
+    constexpr int SE = stage_elems<T>();
+    HG_REQUIRE(g.K % SE == 0 && g.K > 0, HGYM_E_SHAPE, "gemm K=%d not a multiple of %d", g.K, SE);
+    HG_REQUIRE(g.lda * (int64_t)sizeof(T) % 16 == 0 && g.ldb * (int64_t)sizeof(T) % 16 == 0, HGYM_E_SHAPE, "gemm operand rows must be 16-byte aligned");
+    if (splits < 1) splits = 1;
+    int stages = g.K / SE;
+    if (splits > stages) splits = stages;
+    const int per = ceil_div(stages, splits);
+    splits = ceil_div(stages, per);
+    g.k_chunk = per * SE;
+    if (g.N <= 16) launch_cfg<T, 128, 16, 4, 1>(g, splits, s);
+    else if (g.M <= 16) launch_cfg<T, 16, 128, 1, 4>(g, splits, s);
+    else if ((int64_t)ceil_div(g.M, 128) * ceil_div(g.N, 128) * splits >= 192) launch_cfg<T, 128, 128, 2, 2>(g, splits, s);
+    else launch_cfg<T, 64, 64, 2, 2>(g, splits, s);
+    HG_CHECK_LAUNCH("gemm_nt_kernel");
+    return splits;
+}
+
+// ------------------------------------------------------------------------------------------------ orchestration
+template <typename T>
+struct NetRunner {
+    const HgymNetConfig& cfg;
+    const HgymNet& net;
+    WsLayout w;
+    hipStream_t s;
+    char* ws;
+
+    template <typename U> U* at(int64_t off) const { return reinterpret_cast<U*>(ws + off); }
+
+    SegTable segments(bool with_slabs) const {
+        SegTable t;
+        memset(&t, 0, sizeof(t));
+        Segment& sd = t.s[t.n++];
+        sd.off = 0;
+        sd.rows = cfg.num_actions;
+        sd.cols = 1;
+        for (int which = 0; which < 2; ++which)
+            for (int l = 0; l < w.net[which].L; ++l) {
+                const LayerLayout& y = w.net[which].layer[l];
+                Segment& a = t.s[t.n++];
+                a.off = y.w_off;
+                a.rows = y.N;
+                a.cols = y.K;
+                a.splits = with_slabs ? split_count(y) : 0;
+                a.Wp = ws + y.Wp;
+                a.ldw = y.Kp;
+                a.WTp = ws + y.WTp;
+                a.ldwt = y.Ncp;
+                Segment& b = t.s[t.n++];
+                b.off = y.b_off;
+                b.rows = y.N;
+                b.cols = 1;
+            }
+        return t;
+    }
+
+    int cur_Mp = 0;   // contraction padding of the current batch
+    int split_count(const LayerLayout& y) const {
+        // enough workgroups to fill 256 CUs: tiles(N x K) x splits ~ 512
+        const int tiles = ceil_div(y.N, y.N <= 16 ? 16 : 128) * ceil_div(y.K, 128);
+        int sp = ceil_div(512, tiles);
+        if (sp > w.splits) sp = w.splits;
+        const int stages = cur_Mp / w.SE;
+        if (sp > stages) sp = stages;
+        if (sp < 1) sp = 1;
+        const int per = ceil_div(stages, sp);
+        return ceil_div(stages, per);
+    }
+
+    int32_t forward(int which, int M, const float* x, int64_t ldx, const int64_t* idx, float* y_out, int64_t ld_out, bool train) {
+        const NetLayout& n = w.net[which];
+        HG_REQUIRE(M > 0 && M <= w.maxM, HGYM_E_SHAPE, "batch %d exceeds max_batch %lld", M, (long long)w.maxM);
+        const LayerLayout& l0 = n.layer[0];
+        const int64_t total = (int64_t)M * l0.K;
+        hipLaunchKernelGGL((pack_rows_kernel<T>), dim3((int)std::min<int64_t>(ceil_div(total, 256), 4096)), dim3(256), 0, s, M, l0.K, x,
+                           ldx, idx, at<T>(l0.X), (int64_t)l0.Kp);
+        HG_CHECK_LAUNCH("pack_rows_kernel");
+        const int Mp = (int)round_up(M, w.SE);
+        for (int l = 0; l < n.L; ++l) {
+            const LayerLayout& y = n.layer[l];
+            const bool last = l == n.L - 1;
+            if (train) {
+                hipLaunchKernelGGL((transpose_kernel<T>), dim3(ceil_div(Mp, 64), ceil_div(y.K, 64)), dim3(256), 0, s, M, Mp, y.K,
+                                   at<T>(y.X), (int64_t)y.Kp, at<T>(y.XT), w.Mp);
+                HG_CHECK_LAUNCH("transpose_kernel");
+            }
+            GemmArgs g;
+            memset(&g, 0, sizeof(g));
+            g.A = at<T>(y.X);
+            g.lda = y.Kp;
+            g.rowsA = M;
+            g.B = at<T>(y.Wp);
+            g.ldb = y.Kp;
+            g.rowsB = y.N16;
+            g.M = M;
+            g.N = y.N;
+            g.K = y.Kp;
+            g.bias = net.params + y.b_off;
+            if (last) {
+                g.Cf = y_out;
+                g.ldcf = ld_out;
+            } else {
+                g.act = ACT_ELU;
+                g.Ct = at<T>(n.layer[l + 1].X);
+                g.ldct = n.layer[l + 1].Kp;
+            }
+            const int32_t rc = launch_gemm<T>(g, 1, s);
+            if (rc < 0) return rc;
+        }
+        return HGYM_OK;
+    }
+
+    // backward of one net given dY / dYT of its last layer already in the workspace
+    int32_t backward(int which, int M) {
+        const NetLayout& n = w.net[which];
+        const int Mp = (int)round_up(M, w.SE);
+        cur_Mp = Mp;
+        for (int l = n.L - 1; l >= 0; --l) {
+            const LayerLayout& y = n.layer[l];
+            {   // dW_l[N][K] = sum_m dY[m][n] * X[m][k]  (contraction over the batch, split-K slabs)
+                GemmArgs g;
+                memset(&g, 0, sizeof(g));
+                g.A = at<T>(y.dYT);
+                g.lda = w.Mp;
+                g.rowsA = y.N16;
+                g.B = at<T>(y.XT);
+                g.ldb = w.Mp;
+                g.rowsB = y.K16;
+                g.M = y.N;
+                g.N = y.K;
+                g.K = Mp;
+                g.Cf = at<float>(w.slabs) + y.w_off;
+                g.ldcf = y.K;
+                g.slab_stride = w.P;
+                const int want = split_count(y);
+                const int32_t got = launch_gemm<T>(g, want, s);
+                if (got < 0) return got;
+                HG_REQUIRE(got == want, HGYM_E_LAUNCH, "split-K mismatch %d vs %d", got, want);
+                hipLaunchKernelGGL((rowsum_kernel<T>), dim3(y.N), dim3(256), 0, s, M, at<T>(y.dYT), w.Mp, net.grads + y.b_off);
+                HG_CHECK_LAUNCH("rowsum_kernel");
+            }
+            if (l > 0) {   // dX = (dY * W) .* elu'(X_l)  -> dY of layer l-1
+                const LayerLayout& p = n.layer[l - 1];
+                GemmArgs g;
+                memset(&g, 0, sizeof(g));
+                g.A = at<T>(y.dY);
+                g.lda = y.Ncp;
+                g.rowsA = M;
+                g.B = at<T>(y.WTp);
+                g.ldb = y.Ncp;
+                g.rowsB = y.K16;
+                g.M = M;
+                g.N = y.K;
+                g.K = y.Ncp;
+                g.aux = at<T>(y.X);
+                g.ldaux = y.Kp;
+                g.Ct = at<T>(p.dY);
+                g.ldct = p.Ncp;
+                const int32_t rc = launch_gemm<T>(g, 1, s);
+                if (rc < 0) return rc;
+                hipLaunchKernelGGL((transpose_kernel<T>), dim3(ceil_div(Mp, 64), ceil_div(p.N, 64)), dim3(256), 0, s, M, Mp, p.N,
+                                   at<T>(p.dY), (int64_t)p.Ncp, at<T>(p.dYT), w.Mp);
+                HG_CHECK_LAUNCH("transpose_kernel");
+            }
+        }
+        return HGYM_OK;
+    }
+
+    int32_t grad(const HgymPPOConfig& ppo, const HgymBatch& b) {
+        const int B = b.B, A = cfg.num_actions;
+        HG_REQUIRE(B > 0 && B <= w.maxM, HGYM_E_SHAPE, "minibatch %d exceeds max_batch %lld", B, (long long)w.maxM);
+        float* mu = at<float>(w.net[0].out_f32);
+        float* val = at<float>(w.net[1].out_f32);
+        int32_t rc = forward(0, B, b.obs, cfg.num_obs, b.idx, mu, A, true);
+        if (rc) return rc;
+        rc = forward(1, B, b.priv, cfg.num_priv, b.idx, val, 1, true);
+        if (rc) return rc;
+        const int Bp = (int)round_up(B, w.SE);
+        const int nblocks = ceil_div(Bp, 256);
+        HG_REQUIRE(nblocks <= MAX_LOSS_BLOCKS, HGYM_E_UNSUPPORTED, "minibatch %d too large for the loss partial buffer", B);
+        const LayerLayout& la = w.net[0].layer[w.net[0].L - 1];
+        const LayerLayout& lc = w.net[1].layer[w.net[1].L - 1];
+        LossArgs a;
+        memset(&a, 0, sizeof(a));
+        a.b = b;
+        a.A = A;
+        a.mu = mu;
+        a.val = val;
+        a.std_ = net.params;
+        a.clip = ppo.clip_param;
+        a.value_coef = ppo.value_loss_coef;
+        a.entropy_coef = ppo.entropy_coef;
+        a.dmu = at<T>(la.dY);
+        a.ld_dmu = la.Ncp;
+        a.dmuT = at<T>(la.dYT);
+        a.ld_t = w.Mp;
+        a.dval = at<T>(lc.dY);
+        a.ld_dval = lc.Ncp;
+        a.dvalT = at<T>(lc.dYT);
+        a.Bp = Bp;
+        a.partials = at<float>(w.partials);
+        hipLaunchKernelGGL((ppo_loss_kernel<T>), dim3(nblocks), dim3(256), 0, s, a);
+        HG_CHECK_LAUNCH("ppo_loss_kernel");
+        hipLaunchKernelGGL(ppo_scalars_kernel, dim3(1), dim3(256), 0, s, nblocks, B, A, at<float>(w.partials), net.grads, net.opt_state);
+        HG_CHECK_LAUNCH("ppo_scalars_kernel");
+        cur_Mp = Bp;
+        rc = backward(0, B);
+        if (rc) return rc;
+        rc = backward(1, B);
+        if (rc) return rc;
+        const SegTable tab = segments(true);
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(64, tab.n), dim3(256), 0, s, tab, w.P, at<float>(w.slabs), net.grads);
+        HG_CHECK_LAUNCH("reduce_slabs_kernel");
+        return HGYM_OK;
+    }
+
+    int32_t apply(const HgymPPOConfig& ppo) {
+        hipLaunchKernelGGL(apply_prologue_kernel, dim3(1), dim3(64), 0, s, ppo, net.opt_state);
+        hipLaunchKernelGGL(sqnorm_kernel, dim3(256), dim3(256), 0, s, w.P, net.grads, net.opt_state);
+        const SegTable tab = segments(false);
+        hipLaunchKernelGGL((adam_kernel<T>), dim3(64, tab.n), dim3(256), 0, s, tab, ppo, net.params, net.grads, net.adam_m, net.adam_v,
+                           net.opt_state);
+        HG_CHECK_LAUNCH("adam_kernel");
+        return HGYM_OK;
+    }
+
+    int32_t sync_shadow() {
+        const SegTable tab = segments(false);
+        hipLaunchKernelGGL((sync_shadow_kernel<T>), dim3(64, tab.n), dim3(256), 0, s, tab, net.params);
+        HG_CHECK_LAUNCH("sync_shadow_kernel");
+        return HGYM_OK;
+    }
+};
+
+static int32_t check_net(const HgymNetConfig* cfg, const HgymNet* net, WsLayout* w) {
+    HG_REQUIRE(cfg && net, HGYM_E_BADARG, "null net config / net");
+    const int32_t rc = ws_layout(cfg, w);
+    if (rc) return rc;
+    HG_REQUIRE(net->params && net->workspace, HGYM_E_BADARG, "null params / workspace");
+    HG_REQUIRE(((uintptr_t)net->workspace & 255) == 0, HGYM_E_BADARG, "workspace must be 256-byte aligned");
+    return HGYM_OK;
+}
+
+#define HG_DISPATCH(cfg, net, w, stream, expr)                                                     \
+    do {                                                                                           \
+        if ((cfg)->precision == HGYM_F32) {                                                        \
+            NetRunner<float> R{*(cfg), *(net), (w), (hipStream_t)(stream), (char*)(net)->workspace}; \
+            return R.expr;                                                                         \
+        } else {                                                                                   \
+            NetRunner<__bf16> R{*(cfg), *(net), (w), (hipStream_t)(stream), (char*)(net)->workspace}; \
+            return R.expr;                                                                         \
+        }                                                                                          \
+    } while (0)
+
+}  // namespace hgym
+
+using namespace hgym;
+
+extern "C" {
+
+int64_t hgym_net_param_count(const HgymNetConfig* cfg) {
+    WsLayout w;
+    if (ws_layout(cfg, &w)) return -1;
+    return w.P;
+}
+
+int64_t hgym_net_workspace_bytes(const HgymNetConfig* cfg) {
+    WsLayout w;
+    if (ws_layout(cfg, &w)) return -1;
+    return w.total_bytes;
+}
+
+int32_t hgym_net_sync_shadow(const HgymNetConfig* cfg, const HgymNet* net, void* stream) {
+    WsLayout w;
+    const int32_t rc = check_net(cfg, net, &w);
+    if (rc) return rc;
+    HG_DISPATCH(cfg, net, w, stream, sync_shadow());
+}
+
+int32_t hgym_mlp_forward(const HgymNetConfig* cfg, const HgymNet* net, int32_t which, int32_t M, const float* x, int64_t ldx, float* y,
+                         void* stream) {
+    WsLayout w;
+    const int32_t rc = check_net(cfg, net, &w);
+    if (rc) return rc;
+    HG_REQUIRE(which == 0 || which == 1, HGYM_E_BADARG, "which=%d", which);
+    HG_REQUIRE(x && y, HGYM_E_BADARG, "null x / y");
+    const int nout = which == 0 ? cfg->num_actions : 1;
+    HG_DISPATCH(cfg, net, w, stream, forward(which, M, x, ldx, nullptr, y, nout, false));
+}
+
+int32_t hgym_policy_act(const HgymNetConfig* cfg, const HgymNet* net, int32_t M, const float* obs, const float* priv, const float* z,
+                        uint64_t seed, const int64_t* step_counter, float* actions, float* mu, float* sigma, float* logp, float* values,
+                        void* stream) {
+    WsLayout w;
+    int32_t rc = check_net(cfg, net, &w);
+    if (rc) return rc;
+    HG_REQUIRE(obs && priv && actions && mu && sigma && logp && values, HGYM_E_BADARG, "null pointer");
+    rc = hgym_mlp_forward(cfg, net, 0, M, obs, cfg->num_obs, mu, stream);
+    if (rc) return rc;
+    rc = hgym_mlp_forward(cfg, net, 1, M, priv, cfg->num_priv, values, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(act_sample_kernel, dim3(ceil_div(M, 256)), dim3(256), 0, (hipStream_t)stream, M, cfg->num_actions, mu, net->params, z,
+                       seed, step_counter, actions, sigma, logp);
+    HG_CHECK_LAUNCH("act_sample_kernel");
+    return HGYM_OK;
+}
+
+int32_t hgym_ppo_grad(const HgymNetConfig* cfg, const HgymPPOConfig* ppo, const HgymNet* net, const HgymBatch* batch, void* stream) {
+    WsLayout w;
+    const int32_t rc = check_net(cfg, net, &w);
+    if (rc) return rc;
+    HG_REQUIRE(ppo && batch, HGYM_E_BADARG, "null ppo / batch");
+    HG_REQUIRE(net->grads && net->opt_state, HGYM_E_BADARG, "null grads / opt_state");
+    HG_REQUIRE(batch->obs && batch->priv && batch->actions && batch->values && batch->advantages && batch->returns && batch->logp &&
+                   batch->mu && batch->sigma && batch->idx, HGYM_E_BADARG, "null batch tensor");
+    HG_DISPATCH(cfg, net, w, stream, grad(*ppo, *batch));
+}
+
+int32_t hgym_ppo_apply(const HgymNetConfig* cfg, const HgymPPOConfig* ppo, const HgymNet* net, void* stream) {
+    WsLayout w;
+    const int32_t rc = check_net(cfg, net, &w);
+    if (rc) return rc;
+    HG_REQUIRE(ppo, HGYM_E_BADARG, "null ppo");
+    HG_REQUIRE(net->grads && net->adam_m && net->adam_v && net->opt_state, HGYM_E_BADARG, "null optimiser buffers");
+    HG_DISPATCH(cfg, net, w, stream, apply(*ppo));
+}
+
+}  // extern "C"

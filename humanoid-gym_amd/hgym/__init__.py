@@ -2,3 +2,4 @@
 from . import _lib
 from ._lib import lib, check, HgymError
 from .env_buffers import EnvBuffers, default_env_config
+from .net import NetBuffers, make_net_config, make_ppo_config, make_batch

@@ -1,0 +1,122 @@
+"""Caller-owned buffers of the actor/critic + PPO optimiser and thin call wrappers over the C-ABI."""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+
+def make_net_config(num_obs, num_priv, num_actions, actor_hidden, critic_hidden, precision, max_batch):
+    c = L.NetConfig()
+    c.num_obs, c.num_priv, c.num_actions = int(num_obs), int(num_priv), int(num_actions)
+    ad = [num_obs] + list(actor_hidden) + [num_actions]
+    cd = [num_priv] + list(critic_hidden) + [1]
+    c.actor_layers, c.critic_layers = len(ad) - 1, len(cd) - 1
+    for i, d in enumerate(ad):
+        c.actor_dims[i] = int(d)
+    for i, d in enumerate(cd):
+        c.critic_dims[i] = int(d)
+    c.precision = {"f32": L.F32, "fp32": L.F32, "bf16": L.BF16}[precision] if isinstance(precision, str) else int(precision)
+    c.max_batch = int(max_batch)
+    return c
+
+
+def make_ppo_config(clip_param=0.2, value_loss_coef=1.0, entropy_coef=0.001, max_grad_norm=1.0, desired_kl=0.01,
+                    adaptive=True, world_size=1):
+    p = L.PPOConfig()
+    p.clip_param, p.value_loss_coef, p.entropy_coef = clip_param, value_loss_coef, entropy_coef
+    p.max_grad_norm, p.desired_kl = max_grad_norm, desired_kl
+    p.beta1, p.beta2, p.adam_eps = 0.9, 0.999, 1e-8
+    p.lr_min, p.lr_max = 1e-5, 1e-2
+    p.adaptive_lr = 1 if adaptive else 0
+    p.world_size = int(world_size)
+    return p
+
+
+class NetBuffers:
+    """Flat fp32 master parameters (state_dict order), Adam state, optimiser scalars and the zero-filled
+    workspace; exposes per-tensor views named like the reference's ActorCritic.state_dict()."""
+
+    def __init__(self, cfg, device, learning_rate=1e-5):
+        self.cfg = cfg
+        self.device = torch.device(device)
+        self.P = int(L.lib.hgym_net_param_count(C.byref(cfg)))
+        nbytes = int(L.lib.hgym_net_workspace_bytes(C.byref(cfg)))
+        if self.P <= 0 or nbytes <= 0:
+            raise L.HgymError("bad net config: %s" % L.lib.hgym_last_error().decode())
+        z = lambda n, dt=torch.float32: torch.zeros(n, dtype=dt, device=self.device)
+        self.params, self.grads, self.adam_m, self.adam_v = z(self.P), z(self.P), z(self.P), z(self.P)
+        self.opt_state = z(16, torch.float64)
+        self.opt_state[0] = learning_rate
+        self.workspace = torch.zeros(nbytes + 256, dtype=torch.uint8, device=self.device)
+        off = (-self.workspace.data_ptr()) % 256
+        self._ws_ptr = self.workspace.data_ptr() + off
+        self.struct = L.Net(L.fptr(self.params), L.fptr(self.grads), L.fptr(self.adam_m), L.fptr(self.adam_v),
+                            L.f64ptr(self.opt_state), C.c_void_p(self._ws_ptr))
+        # named views
+        self.views = {}
+        A = cfg.num_actions
+        self.views["std"] = self.params[:A]
+        off = A
+        for name, dims, n in (("actor", cfg.actor_dims, cfg.actor_layers), ("critic", cfg.critic_dims, cfg.critic_layers)):
+            for l in range(n):
+                k, o = dims[l], dims[l + 1]
+                self.views["%s.%d.weight" % (name, 2 * l)] = self.params[off:off + o * k].view(o, k)
+                off += o * k
+                self.views["%s.%d.bias" % (name, 2 * l)] = self.params[off:off + o]
+                off += o
+        assert off == self.P
+
+    def stream(self):
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream) if self.device.type == "cuda" else None
+
+    def load_state_dict(self, sd):
+        for k, v in self.views.items():
+            v.copy_(torch.as_tensor(sd[k]).to(self.device).view_as(v))
+        self.sync_shadow()
+
+    def state_dict(self):
+        return {k: v.detach().clone() for k, v in self.views.items()}
+
+    def grad_views(self):
+        out, base = {}, self.params.data_ptr()
+        for k, v in self.views.items():
+            o = (v.data_ptr() - base) // 4
+            out[k] = self.grads[o:o + v.numel()].view_as(v)
+        return out
+
+    def sync_shadow(self):
+        L.check(L.lib.hgym_net_sync_shadow(C.byref(self.cfg), C.byref(self.struct), self.stream()), "hgym_net_sync_shadow")
+
+    def forward(self, which, x):
+        M = x.shape[0]
+        y = torch.empty(M, self.cfg.num_actions if which == 0 else 1, device=self.device)
+        L.check(L.lib.hgym_mlp_forward(C.byref(self.cfg), C.byref(self.struct), which, M, L.fptr(x), x.stride(0), L.fptr(y),
+                                       self.stream()), "hgym_mlp_forward")
+        return y
+
+    def act(self, obs, priv, z=None, seed=0, step_counter=None, out=None):
+        M = obs.shape[0]
+        A = self.cfg.num_actions
+        if out is None:
+            e = lambda *s: torch.empty(*s, device=self.device)
+            out = dict(actions=e(M, A), mu=e(M, A), sigma=e(M, A), logp=e(M), values=e(M, 1))
+        L.check(L.lib.hgym_policy_act(C.byref(self.cfg), C.byref(self.struct), M, L.fptr(obs), L.fptr(priv), L.fptr(z), int(seed),
+                                      L.i64ptr(step_counter), L.fptr(out["actions"]), L.fptr(out["mu"]), L.fptr(out["sigma"]),
+                                      L.fptr(out["logp"]), L.fptr(out["values"]), self.stream()), "hgym_policy_act")
+        return out
+
+    def ppo_grad(self, ppo, batch):
+        L.check(L.lib.hgym_ppo_grad(C.byref(self.cfg), C.byref(ppo), C.byref(self.struct), C.byref(batch), self.stream()), "hgym_ppo_grad")
+
+    def ppo_apply(self, ppo):
+        L.check(L.lib.hgym_ppo_apply(C.byref(self.cfg), C.byref(ppo), C.byref(self.struct), self.stream()), "hgym_ppo_apply")
+
+
+def make_batch(obs, priv, actions, values, advantages, returns, logp, mu, sigma, idx):
+    """All (T*N, *) flattened, contiguous fp32; idx int64 (B,)."""
+    for t in (obs, priv, actions, values, advantages, returns, logp, mu, sigma):
+        assert t.is_contiguous() and t.dtype == torch.float32
+    assert idx.dtype == torch.int64 and idx.is_contiguous()
+    return L.Batch(L.fptr(obs), L.fptr(priv), L.fptr(actions), L.fptr(values), L.fptr(advantages), L.fptr(returns), L.fptr(logp),
+                   L.fptr(mu), L.fptr(sigma), L.i64ptr(idx), int(idx.numel()))

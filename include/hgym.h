@@ -247,15 +247,20 @@ int64_t hgym_net_workspace_bytes(const HgymNetConfig* net);
 
 /* Master parameters are ONE flat fp32 array in state_dict order
  * (std, actor.{0,2,4,6}.{weight,bias}, critic.{0,2,4,6}.{weight,bias}; SURVEY.md §5 checkpoint row);
- * grads/adam_m/adam_v have the same layout.  opt_state: doubles on the device
- * [0] learning rate, [1] adam step count, [2] kl sum, [3] surrogate sum, [4] value-loss sum,
- * [5] entropy sum, [6] grad norm, [7] minibatches accumulated. */
+ * grads/adam_m/adam_v have the same layout.  opt_state: 16 doubles on the device
+ * [0] learning rate (python-double semantics of ppo.py:142-148)   [1] Adam step count
+ * [2] sum of minibatch mean KL  [3] sum of surrogate losses  [4] sum of value losses  [5] sum of mean entropies
+ * [6] gradient norm of the last step (before clipping)  [7] minibatches accumulated in [2..5]
+ * [8] mean KL of the last minibatch (average it across ranks before hgym_ppo_apply when world_size > 1)
+ * [9..15] internal.
+ * workspace: hgym_net_workspace_bytes() bytes, 256-byte aligned, ZERO-FILLED once by the caller before first use
+ * (padding rows/columns of the operand buffers rely on it). */
 typedef struct HgymNet {
     float* params;
     float* grads;
     float* adam_m;
     float* adam_v;
-    double* opt_state;     /* [8] */
+    double* opt_state;     /* [16] */
     void* workspace;       /* hgym_net_workspace_bytes() bytes, 256-byte aligned */
 } HgymNet;
 

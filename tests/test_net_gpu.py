@@ -1,0 +1,246 @@
+"""-m gpu: actor/critic forward, PPO.act, and one full PPO iteration of libhgym_hip.so through the C-ABI against
+(a) the golden vectors recorded from the reference and (b) the oracle on seeded inputs.
+
+Tolerances: fp32 path <= 1e-5 relative (scale-relative for gradients); bf16 MFMA path <= 1e-2
+relative, reported separately."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ppo_oracle as P
+from oracle import xbot_constants as K
+
+pytestmark = pytest.mark.gpu
+T = lambda a: torch.from_numpy(np.asarray(a))
+NAMES = ["std"] + ["actor.%d.%s" % (i, k) for i in (0, 2, 4, 6) for k in ("weight", "bias")] + \
+        ["critic.%d.%s" % (i, k) for i in (0, 2, 4, 6) for k in ("weight", "bias")]
+
+
+def _net(num_obs, num_priv, ah, ch, precision, max_batch, lr=1e-3):
+    from hgym import NetBuffers, make_net_config
+    cfg = make_net_config(num_obs, num_priv, 12, ah, ch, precision, max_batch)
+    return NetBuffers(cfg, "cuda", learning_rate=lr)
+
+
+def _rel_err(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-12)
+
+
+@pytest.mark.parametrize("precision,tol", [("f32", 1e-5), ("bf16", 2e-2)])
+def test_policy_example_known_answers(golden_dir, precision, tol):
+    """The trained reference actor (logs/XBot_ppo/exported/policies/policy_example.pt) through the MFMA forward."""
+    G = np.load(os.path.join(golden_dir, "policy_example.npz"))
+    net = _net(705, 219, K.ACTOR_HIDDEN, K.CRITIC_HIDDEN, precision, 4096)
+    sd = {k: torch.zeros_like(v) for k, v in net.views.items()}
+    for i in (0, 2, 4, 6):
+        sd["actor.%d.weight" % i] = T(G["w_%d_weight" % i])
+        sd["actor.%d.bias" % i] = T(G["w_%d_bias" % i])
+    net.load_state_dict(sd)
+    for x, y in ((torch.zeros(1, 705), G["y_zeros"]), (torch.linspace(-1, 1, 705)[None], G["y_linspace"]),
+                 (T(G["x_rand"]), G["y_rand"])):
+        out = net.forward(0, x.cuda().contiguous())
+        torch.cuda.synchronize()
+        assert _rel_err(out.cpu().numpy(), y) <= tol, (precision, _rel_err(out.cpu().numpy(), y))
+    # the literal SURVEY.md §8c numbers
+    want0 = [0.08470258, -0.02338534, 0.00571555, 0.23484124, 0.63823998, -0.22751239, -0.11294249, -0.15007278,
+             0.20418212, 0.35353008, 0.00772867, -0.45297036]
+    out = net.forward(0, torch.zeros(1, 705, device="cuda")).cpu().numpy().ravel()
+    assert _rel_err(out, want0) <= tol
+
+
+@pytest.mark.parametrize("M", [1, 37, 128, 4096, 5000])
+def test_forward_vs_oracle_f32(M):
+    g = torch.Generator().manual_seed(M)
+    p = P.Params.random(705, 219, 12, K.ACTOR_HIDDEN, K.CRITIC_HIDDEN, g)
+    net = _net(705, 219, K.ACTOR_HIDDEN, K.CRITIC_HIDDEN, "f32", 5000)
+    net.load_state_dict(dict(zip(NAMES, p.tensors())))
+    obs = (torch.randn(M, 705, generator=g) * 2).clamp(-18, 18)
+    priv = (torch.randn(M, 219, generator=g) * 2).clamp(-18, 18)
+    mu = net.forward(0, obs.cuda())
+    v = net.forward(1, priv.cuda())
+    torch.cuda.synchronize()
+    assert _rel_err(mu.cpu(), P.mlp_forward(obs, p.actor)) <= 1e-5
+    assert _rel_err(v.cpu(), P.mlp_forward(priv, p.critic)) <= 1e-5
+
+
+def test_policy_act_vs_oracle():
+    g = torch.Generator().manual_seed(1)
+    M = 300
+    p = P.Params.random(705, 219, 12, K.ACTOR_HIDDEN, K.CRITIC_HIDDEN, g)
+    p.std = torch.rand(12, generator=g) + 0.5
+    net = _net(705, 219, K.ACTOR_HIDDEN, K.CRITIC_HIDDEN, "f32", M)
+    net.load_state_dict(dict(zip(NAMES, p.tensors())))
+    obs, priv, z = torch.randn(M, 705, generator=g), torch.randn(M, 219, generator=g), torch.randn(M, 12, generator=g)
+    out = net.act(obs.cuda(), priv.cuda(), z=z.cuda())
+    torch.cuda.synchronize()
+    a, v, lp, mu, sg = P.policy_act(p, obs, priv, z)
+    assert _rel_err(out["actions"].cpu(), a) <= 1e-5 and _rel_err(out["values"].cpu(), v) <= 1e-5
+    assert _rel_err(out["mu"].cpu(), mu) <= 1e-5 and torch.equal(out["sigma"].cpu(), sg)
+    np.testing.assert_allclose(out["logp"].cpu().numpy(), lp.numpy(), rtol=1e-5, atol=1e-4)
+    # internal Philox sampling: right moments, reproducible for the same (seed, step), different across steps
+    step = torch.zeros(1, dtype=torch.int64, device="cuda")
+    o1 = net.act(obs.cuda(), priv.cuda(), seed=9, step_counter=step)["actions"].clone()
+    o2 = net.act(obs.cuda(), priv.cuda(), seed=9, step_counter=step)["actions"].clone()
+    step += 1
+    o3 = net.act(obs.cuda(), priv.cuda(), seed=9, step_counter=step)["actions"].clone()
+    torch.cuda.synchronize()
+    assert torch.equal(o1, o2) and not torch.equal(o1, o3)
+    zz = ((o1.cpu() - mu) / sg).flatten()
+    assert abs(float(zz.mean())) < 0.08 and abs(float(zz.std()) - 1.0) < 0.08
+
+
+def _run_iteration(G, precision):
+    """Replays tests/golden/ppo_update.npz (recorded from the reference's PPO) through the HIP path."""
+    from hgym import make_ppo_config, make_batch, _lib as L
+    import ctypes as C
+    Tn, N = G["obs"].shape[:2]
+    ah, ch = [int(x) for x in G["actor_hidden"]], [int(x) for x in G["critic_hidden"]]
+    net = _net(705, 219, ah, ch, precision, Tn * N, lr=1e-3)
+    net.load_state_dict({k: T(G["p0_" + k.replace(".", "_")]) for k in NAMES})
+    dev = "cuda"
+    st = dict(obs=T(G["obs"]).to(dev).contiguous(), priv=T(G["priv"]).to(dev).contiguous())
+    for k, shape in (("actions", (Tn, N, 12)), ("mu", (Tn, N, 12)), ("sigma", (Tn, N, 12)), ("values", (Tn, N, 1)),
+                     ("logp", (Tn, N)), ("rewards", (Tn, N)), ("returns", (Tn, N)), ("advantages", (Tn, N))):
+        st[k] = torch.zeros(*shape, device=dev)
+    dones = T(G["done"]).to(dev).to(torch.uint8).contiguous()
+    s = net.stream()
+    for t in range(Tn):
+        out = dict(actions=st["actions"][t], mu=st["mu"][t], sigma=st["sigma"][t], logp=st["logp"][t], values=st["values"][t])
+        net.act(st["obs"][t], st["priv"][t], z=T(G["z"][t]).to(dev).contiguous(), out=out)   # producers write the slot
+        rew = T(G["rew_in"][t]).to(dev).contiguous()
+        to = T(G["time_outs"][t]).to(dev).to(torch.uint8).contiguous()
+        dslot = torch.zeros(N, dtype=torch.uint8, device=dev)
+        L.check(L.lib.hgym_store_step(N, L.fptr(rew), L.fptr(st["values"][t]), L.u8ptr(to), L.u8ptr(dones[t]), 0.994,
+                                      L.fptr(st["rewards"][t]), L.u8ptr(dslot), s))
+    last_v = net.forward(1, T(G["last_priv"]).to(dev).contiguous()).view(N).contiguous()
+    stats = torch.zeros(3, dtype=torch.float64, device=dev)
+    vals2d = st["values"].view(Tn, N)
+    L.check(L.lib.hgym_gae(Tn, N, L.fptr(st["rewards"]), L.fptr(vals2d), L.u8ptr(dones), L.fptr(last_v), 0.994, 0.9,
+                           L.fptr(st["returns"]), L.fptr(st["advantages"]), L.f64ptr(stats), s))
+    L.check(L.lib.hgym_adv_normalize(Tn * N, L.fptr(st["advantages"]), L.f64ptr(stats), s))
+    torch.cuda.synchronize()
+    res = dict(net=net, st=st)
+    ppo = make_ppo_config()
+    perm = T(G["perm"]).to(dev)
+    mb = perm.numel() // 4
+    flat = {k: st[k].flatten(0, 1) if st[k].dim() > 2 else st[k].flatten() for k in st}
+    lrs, g0 = [], None
+    for epoch in range(2):
+        for i in range(4):
+            idx = perm[i * mb:(i + 1) * mb].contiguous()
+            b = make_batch(flat["obs"], flat["priv"], flat["actions"], flat["values"].flatten(), flat["advantages"],
+                           flat["returns"], flat["logp"], flat["mu"], flat["sigma"], idx)
+            net.ppo_grad(ppo, b)
+            net.ppo_apply(ppo)
+            torch.cuda.synchronize()
+            lrs.append(float(net.opt_state[0]))
+            if g0 is None:
+                g0 = {k: v.clone().cpu() for k, v in net.grad_views().items()}
+    res.update(lrs=lrs, g0=g0, opt=net.opt_state.cpu().clone())
+    return res
+
+
+def test_ppo_iteration_matches_reference_f32(golden_dir):
+    G = np.load(os.path.join(golden_dir, "ppo_update.npz"))
+    r = _run_iteration(G, "f32")
+    st = r["st"]
+    for k, ref, tol in (("actions", G["actions"], 1e-5), ("values", G["values"], 1e-5), ("mu", G["mu"], 1e-5),
+                        ("rewards", G["st_rewards"].squeeze(-1), 1e-5), ("returns", G["st_returns"].squeeze(-1), 1e-5),
+                        ("advantages", G["st_advantages"].squeeze(-1), 1e-4)):
+        assert _rel_err(st[k].cpu().numpy(), ref) <= tol, (k, _rel_err(st[k].cpu().numpy(), ref))
+    np.testing.assert_allclose(st["logp"].cpu().numpy(), G["logp"], rtol=1e-5, atol=1e-4)
+    # every adaptive-KL learning-rate decision identical to the reference's
+    np.testing.assert_allclose(r["lrs"], G["lrs"], rtol=1e-12)
+    # clipped gradients of the first minibatch vs the reference's autograd
+    for k in NAMES:
+        ref = G["g0_" + k.replace(".", "_")]
+        assert _rel_err(r["g0"][k].numpy(), ref) <= 5e-5, (k, _rel_err(r["g0"][k].numpy(), ref))
+    # parameters after the 8 Adam steps
+    for k in NAMES:
+        ref = G["pF_" + k.replace(".", "_")]
+        np.testing.assert_allclose(r["net"].views[k].cpu().numpy(), ref, rtol=2e-4, atol=5e-6, err_msg=k)
+    opt = r["opt"]
+    np.testing.assert_allclose(float(opt[4] / opt[7]), float(G["mean_value_loss"]), rtol=1e-4)
+    np.testing.assert_allclose(float(opt[3] / opt[7]), float(G["mean_surrogate_loss"]), rtol=1e-3, atol=1e-6)
+    assert int(opt[1]) == 8 and int(opt[7]) == 8
+
+
+def test_ppo_iteration_bf16_close_to_reference(golden_dir):
+    """bf16 MFMA path: reported separately with the 1e-2 class tolerance (gradient direction + parameter drift)."""
+    G = np.load(os.path.join(golden_dir, "ppo_update.npz"))
+    r = _run_iteration(G, "bf16")
+    assert _rel_err(r["st"]["values"].cpu().numpy(), G["values"]) <= 2e-2
+    assert _rel_err(r["st"]["mu"].cpu().numpy(), G["mu"]) <= 2e-2
+    num = den_a = den_b = 0.0
+    for k in NAMES:
+        a, b = r["g0"][k].double().flatten(), T(G["g0_" + k.replace(".", "_")]).double().flatten()
+        num += float(a @ b); den_a += float(a @ a); den_b += float(b @ b)
+    cos = num / (den_a ** 0.5 * den_b ** 0.5)
+    assert cos > 0.995, cos
+    assert r["lrs"][0] == G["lrs"][0]
+
+
+def test_grad_vs_oracle_full_width():
+    """Full XBot-L layer widths, ragged batch (not a tile multiple), fp32: un-clipped gradient vs the oracle."""
+    from hgym import make_ppo_config, make_batch
+    g = torch.Generator().manual_seed(3)
+    S, B = 700, 333
+    p = P.Params.random(705, 219, 12, K.ACTOR_HIDDEN, K.CRITIC_HIDDEN, g)
+    p.std = torch.rand(12, generator=g) * 0.5 + 0.75
+    net = _net(705, 219, K.ACTOR_HIDDEN, K.CRITIC_HIDDEN, "f32", 512)
+    net.load_state_dict(dict(zip(NAMES, p.tensors())))
+    obs, priv = torch.randn(S, 705, generator=g), torch.randn(S, 219, generator=g)
+    act, mu_o = torch.randn(S, 12, generator=g), torch.randn(S, 12, generator=g) * 0.3
+    sg_o = torch.rand(S, 12, generator=g) * 0.5 + 0.75
+    val, adv, ret = torch.randn(S, generator=g), torch.randn(S, generator=g), torch.randn(S, generator=g)
+    with torch.no_grad():
+        mu_now = P.mlp_forward(obs, p.actor)
+    lp_o = P.gaussian_log_prob(act, mu_now, mu_now * 0 + p.std) + torch.randn(S, generator=g) * 0.3
+    idx = torch.randperm(S, generator=g)[:B].contiguous()
+    out = P.ppo_loss_and_grads(p, obs[idx], priv[idx], act[idx], val[idx], adv[idx], ret[idx], lp_o[idx], mu_o[idx], sg_o[idx])
+    c = lambda t: t.cuda().contiguous()
+    keep = [c(obs), c(priv), c(act), c(val), c(adv), c(ret), c(lp_o), c(mu_o), c(sg_o), c(idx)]
+    net.ppo_grad(make_ppo_config(), make_batch(*keep))
+    torch.cuda.synchronize()
+    gv = net.grad_views()
+    for k, ref in zip(NAMES, out["grads"].tensors()):
+        assert _rel_err(gv[k].cpu().numpy(), ref.numpy()) <= 5e-5, (k, _rel_err(gv[k].cpu().numpy(), ref.numpy()))
+    opt = net.opt_state.cpu()
+    np.testing.assert_allclose(float(opt[8]), float(out["kl"]), rtol=1e-4)
+    np.testing.assert_allclose(float(opt[4]), float(out["value_loss"]), rtol=1e-4)
+    np.testing.assert_allclose(float(opt[3]), float(out["surrogate"]), rtol=1e-4, atol=1e-6)
+
+
+def test_update_full_size_properties():
+    """BASELINE size (B = 61 440 samples, XBot-L widths), bf16 fast path vs fp32 path on the same inputs: the two
+    gradients agree to bf16 accuracy, are finite, and an Adam step moves the parameters."""
+    from hgym import make_ppo_config, make_batch
+    g = torch.Generator().manual_seed(11)
+    S = B = 61440
+    p = P.Params.random(705, 219, 12, K.ACTOR_HIDDEN, K.CRITIC_HIDDEN, g)
+    dev = "cuda"
+    obs, priv = torch.randn(S, 705, device=dev), torch.randn(S, 219, device=dev)
+    act, mu_o = torch.randn(S, 12, device=dev), torch.randn(S, 12, device=dev) * 0.3
+    sg_o = torch.ones(S, 12, device=dev)
+    val, adv, ret = torch.randn(S, device=dev), torch.randn(S, device=dev), torch.randn(S, device=dev)
+    lp_o = -12.0 + torch.randn(S, device=dev)
+    idx = torch.randperm(S, device=dev).contiguous()
+    grads = {}
+    for prec in ("f32", "bf16"):
+        net = _net(705, 219, K.ACTOR_HIDDEN, K.CRITIC_HIDDEN, prec, B)
+        net.load_state_dict(dict(zip(NAMES, p.tensors())))
+        net.ppo_grad(make_ppo_config(), make_batch(obs, priv, act, val, adv, ret, lp_o, mu_o, sg_o, idx))
+        torch.cuda.synchronize()
+        grads[prec] = net.grads.clone()
+        assert torch.isfinite(net.grads).all()
+        before = net.params.clone()
+        net.ppo_apply(make_ppo_config())
+        torch.cuda.synchronize()
+        assert not torch.equal(before, net.params) and torch.isfinite(net.params).all()
+        del net
+    a, b = grads["f32"].double(), grads["bf16"].double()
+    cos = float(a @ b) / float(a.norm() * b.norm())
+    assert cos > 0.99, cos
