@@ -1,4 +1,6 @@
 // hgym_capi.hip -- library-level entry points (version, error string, device probe).
+#include <vector>
+
 #include "hgym_common.hpp"
 
 namespace hgym {
@@ -7,6 +9,32 @@ char* last_error_buf() {
     return buf;
 }
 int device_cus();
+
+namespace {
+struct ProfRec {
+    hipEvent_t a, b;
+    double work;
+};
+bool g_prof = false;
+std::vector<ProfRec> g_rec[HGYM_PROF_CLASSES];
+hipEvent_t g_open[HGYM_PROF_CLASSES];
+}  // namespace
+
+bool prof_on() { return g_prof; }
+void prof_begin(int cls, hipStream_t s) {
+    if (!g_prof) return;
+    (void)hipEventCreate(&g_open[cls]);
+    (void)hipEventRecord(g_open[cls], s);
+}
+void prof_end(int cls, hipStream_t s, double work) {
+    if (!g_prof) return;
+    ProfRec r;
+    r.a = g_open[cls];
+    (void)hipEventCreate(&r.b);
+    (void)hipEventRecord(r.b, s);
+    r.work = work;
+    g_rec[cls].push_back(r);
+}
 }  // namespace hgym
 
 extern "C" {
@@ -19,6 +47,33 @@ int64_t hgym_sizeof(const char* name) {
     HG_SZ(HgymEnvNoise); HG_SZ(HgymNetConfig); HG_SZ(HgymPPOConfig); HG_SZ(HgymNet); HG_SZ(HgymBatch);
 #undef HG_SZ
     return -1;
+}
+int32_t hgym_prof_enable(int32_t on) {
+    for (int c = 0; c < HGYM_PROF_CLASSES; ++c) {
+        for (auto& r : hgym::g_rec[c]) {
+            (void)hipEventDestroy(r.a);
+            (void)hipEventDestroy(r.b);
+        }
+        hgym::g_rec[c].clear();
+    }
+    hgym::g_prof = on != 0;
+    return HGYM_OK;
+}
+int32_t hgym_prof_summary(int32_t cls, int64_t* launches, double* total_ms, double* work) {
+    using namespace hgym;
+    HG_REQUIRE(cls >= 0 && cls < HGYM_PROF_CLASSES && launches && total_ms && work, HGYM_E_BADARG, "bad profile class / null output");
+    *launches = 0;
+    *total_ms = 0.0;
+    *work = 0.0;
+    for (auto& r : g_rec[cls]) {
+        if (hipEventSynchronize(r.b) != hipSuccess) HG_FAIL(HGYM_E_LAUNCH, "event sync failed");
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, r.a, r.b);
+        *total_ms += ms;
+        *work += r.work;
+        *launches += 1;
+    }
+    return HGYM_OK;
 }
 int32_t hgym_device_cus(void) {
     int n = 0;

@@ -31,6 +31,12 @@ char* last_error_buf();  // thread-local, defined in hgym_capi.hip
         if (e_ != hipSuccess) HG_FAIL(HGYM_E_LAUNCH, "%s: %s", what, hipGetErrorString(e_));     \
     } while (0)
 
+// ---------------------------------------------------------------------------------------------- profiling hooks
+// (hgym_capi.hip) begin/end bracket one launch of a profiled kernel class with HIP events when enabled.
+bool prof_on();
+void prof_begin(int cls, hipStream_t s);
+void prof_end(int cls, hipStream_t s, double work);
+
 static inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 static inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
 

@@ -111,10 +111,15 @@ static int32_t launch_step(const HgymEnvConfig* cfg, const HgymSimTensors* sim, 
     A.envs_per_block = pick_envs_per_block(cfg->num_envs);
     const int blocks = ceil_div(cfg->num_envs, A.envs_per_block);
     const size_t lds = step_smem_bytes(A.envs_per_block);
+    prof_begin(HGYM_PROF_ENV_STEP, s);
     if (cfg->frame_stack == 15 && cfg->c_frame_stack == 3)
         hipLaunchKernelGGL((env_step_kernel<15, 3>), dim3(blocks), dim3(256), lds, s, A);
     else
         hipLaunchKernelGGL((env_step_kernel<0, 0>), dim3(blocks), dim3(256), lds, s, A);
+    {   // algorithmic bytes per env-step, SURVEY.md §8d: 4*[245 + (H-1)*47 + (Hc-1)*73 + H*47 + Hc*73] + 6
+        const double H = cfg->frame_stack, HC = cfg->c_frame_stack;
+        prof_end(HGYM_PROF_ENV_STEP, s, (double)cfg->num_envs * (4.0 * (245 + (H - 1) * 47 + (HC - 1) * 73 + H * 47 + HC * 73) + 6));
+    }
     HG_CHECK_LAUNCH("env_step_kernel");
     hipLaunchKernelGGL(env_finalize_kernel, dim3(1), dim3(256), 0, s, A);
     HG_CHECK_LAUNCH("env_finalize_kernel");

@@ -158,8 +158,10 @@ int32_t hgym_gae(int32_t T, int32_t n, const float* rewards, const float* values
     HG_REQUIRE(T > 0 && n > 0, HGYM_E_SHAPE, "T=%d n=%d", T, n);
     HG_REQUIRE(rewards && values && dones && last_values && returns && advantages && stats, HGYM_E_BADARG, "null pointer");
     hipLaunchKernelGGL(zero_stats_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, stats);
+    prof_begin(HGYM_PROF_GAE, (hipStream_t)stream);
     hipLaunchKernelGGL(gae_kernel, dim3(ceil_div(n, GAE_ENVS)), dim3(256), 0, (hipStream_t)stream, T, n, rewards, values, dones,
                        last_values, gamma, lam, returns, advantages, stats);
+    prof_end(HGYM_PROF_GAE, (hipStream_t)stream, (double)T * n * 17.0);   // r,V f32 + done u8 read, ret, adv f32 written
     HG_CHECK_LAUNCH("gae_kernel");
     return HGYM_OK;
 }

@@ -414,10 +414,12 @@ int32_t launch_gemm(const GemmArgs& g0, int splits, hipStream_t s) {
     const int per = ceil_div(stages, splits);
     splits = ceil_div(stages, per);
     g.k_chunk = per * SE;
+    prof_begin(HGYM_PROF_GEMM, s);
     if (g.N <= 16) launch_cfg<T, 128, 16, 4, 1>(g, splits, s);
     else if (g.M <= 16) launch_cfg<T, 16, 128, 1, 4>(g, splits, s);
     else if ((int64_t)ceil_div(g.M, 128) * ceil_div(g.N, 128) * splits >= 192) launch_cfg<T, 128, 128, 2, 2>(g, splits, s);
     else launch_cfg<T, 64, 64, 2, 2>(g, splits, s);
+    prof_end(HGYM_PROF_GEMM, s, 2.0 * (double)g.M * (double)g.N * (double)g.K);   // padded K: the flops the MFMAs execute
     HG_CHECK_LAUNCH("gemm_nt_kernel");
     return splits;
 }
@@ -605,7 +607,9 @@ struct NetRunner {
         a.dvalT = at<T>(lc.dYT);
         a.Bp = Bp;
         a.partials = at<float>(w.partials);
+        prof_begin(HGYM_PROF_LOSS, s);
         hipLaunchKernelGGL((ppo_loss_kernel<T>), dim3(nblocks), dim3(256), 0, s, a);
+        prof_end(HGYM_PROF_LOSS, s, (double)B * (4.0 * (5 * A + 6) + (double)sizeof(T) * (2 * A + 2)));
         HG_CHECK_LAUNCH("ppo_loss_kernel");
         hipLaunchKernelGGL(ppo_scalars_kernel, dim3(1), dim3(256), 0, s, nblocks, B, A, at<float>(w.partials), net.grads, net.opt_state);
         HG_CHECK_LAUNCH("ppo_scalars_kernel");

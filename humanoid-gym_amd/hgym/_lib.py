@@ -139,7 +139,18 @@ SYMBOLS = {
                                     c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, C.c_void_p]),
     "hgym_ppo_grad": (C.c_int32, [_P(NetConfig), _P(PPOConfig), _P(Net), _P(Batch), C.c_void_p]),
     "hgym_ppo_apply": (C.c_int32, [_P(NetConfig), _P(PPOConfig), _P(Net), C.c_void_p]),
+    "hgym_prof_enable": (C.c_int32, [C.c_int32]),
+    "hgym_prof_summary": (C.c_int32, [C.c_int32, _P(C.c_int64), _P(C.c_double), _P(C.c_double)]),
 }
+PROF_GEMM, PROF_ENV_STEP, PROF_GAE, PROF_LOSS = 0, 1, 2, 3
+
+
+def prof_summary(cls):
+    n, ms, work = C.c_int64(), C.c_double(), C.c_double()
+    rc = lib.hgym_prof_summary(cls, C.byref(n), C.byref(ms), C.byref(work))
+    if rc != 0:
+        raise HgymError("hgym_prof_summary failed: %s" % lib.hgym_last_error().decode())
+    return n.value, ms.value, work.value
 
 
 class HgymError(RuntimeError):

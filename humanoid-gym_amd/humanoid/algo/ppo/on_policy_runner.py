@@ -1,0 +1,210 @@
+"""OnPolicyRunner with the reference's interface (algo/ppo/on_policy_runner.py:45-307): rollout / learn loop,
+checkpoint save / load (same dict keys), inference-policy getters, console + optional TensorBoard logging.
+
+The rollout loop issues, per vec-step, one policy launch group, one fused env launch and one store launch; the
+env writes its observations straight into the next rollout-storage slot.  Episode book-keeping stays on the
+device and is read back once per iteration (the reference syncs the host every step, :146-152)."""
+import os
+import statistics
+import time
+from collections import deque
+from datetime import datetime
+
+import torch
+
+from .ppo import PPO
+from .actor_critic import ActorCritic
+from humanoid.algo.vec_env import VecEnv
+
+try:  # optional: logging back-ends are not part of the hot path
+    from torch.utils.tensorboard import SummaryWriter
+except Exception:  # pragma: no cover
+    SummaryWriter = None
+try:
+    import wandb
+except Exception:  # pragma: no cover
+    wandb = None
+
+
+class OnPolicyRunner:
+    def __init__(self, env: VecEnv, train_cfg, log_dir=None, device="cpu"):
+        self.cfg = train_cfg["runner"]
+        self.alg_cfg = train_cfg["algorithm"]
+        self.policy_cfg = train_cfg["policy"]
+        self.all_cfg = train_cfg
+        self.wandb_run_name = (datetime.now().strftime("%b%d_%H-%M-%S") + "_" + train_cfg["runner"]["experiment_name"] + "_"
+                               + train_cfg["runner"]["run_name"])
+        self.device = device
+        self.env = env
+        num_critic_obs = self.env.num_privileged_obs if self.env.num_privileged_obs is not None else self.env.num_obs
+        actor_critic_class = eval(self.cfg["policy_class_name"])  # ActorCritic
+        actor_critic = actor_critic_class(self.env.num_obs, num_critic_obs, self.env.num_actions, **self.policy_cfg).to(self.device)
+        alg_class = eval(self.cfg["algorithm_class_name"])  # PPO
+        self.alg = alg_class(actor_critic, device=self.device, **self.alg_cfg)
+        self.num_steps_per_env = self.cfg["num_steps_per_env"]
+        self.save_interval = self.cfg["save_interval"]
+        self.alg.init_storage(self.env.num_envs, self.num_steps_per_env, [self.env.num_obs], [self.env.num_privileged_obs],
+                              [self.env.num_actions])
+        self.log_dir = log_dir
+        self.writer = None
+        self.tot_timesteps = 0
+        self.tot_time = 0
+        self.current_learning_iteration = 0
+        self.last_collection_time = self.last_learn_time = 0.0
+        _, _ = self.env.reset()
+
+    # ------------------------------------------------------------------
+    def _rollout_slots(self):
+        st = self.alg.storage
+        return getattr(st, "_obs_all", None), getattr(st, "_priv_all", None)
+
+    def learn(self, num_learning_iterations, init_at_random_ep_len=False):
+        if self.log_dir is not None and self.writer is None:
+            if wandb is not None and hasattr(wandb, "init"):
+                try:
+                    wandb.init(project="XBot", sync_tensorboard=True, name=self.wandb_run_name, config=self.all_cfg)
+                except Exception:
+                    pass
+            if SummaryWriter is not None:
+                self.writer = SummaryWriter(log_dir=self.log_dir, flush_secs=10)
+            os.makedirs(self.log_dir, exist_ok=True)
+        if init_at_random_ep_len:
+            self.env.episode_length_buf = torch.randint_like(self.env.episode_length_buf, high=int(self.env.max_episode_length))
+        env, alg = self.env, self.alg
+        obs = env.get_observations()
+        privileged_obs = env.get_privileged_observations()
+        critic_obs = privileged_obs if privileged_obs is not None else obs
+        obs, critic_obs = obs.to(self.device), critic_obs.to(self.device)
+        obs_all, priv_all = self._rollout_slots()
+        zero_copy = obs_all is not None and priv_all is not None and hasattr(env, "bind_outputs") and privileged_obs is not None
+        if zero_copy:
+            obs_all[0].copy_(obs)
+            priv_all[0].copy_(critic_obs)
+            obs, critic_obs = obs_all[0], priv_all[0]
+        alg.actor_critic.train()
+
+        ep_infos = []
+        rewbuffer, lenbuffer = deque(maxlen=100), deque(maxlen=100)
+        N = env.num_envs
+        cur_reward_sum = torch.zeros(N, dtype=torch.float, device=self.device)
+        cur_episode_length = torch.zeros(N, dtype=torch.float, device=self.device)
+        done_stats = torch.zeros(3, dtype=torch.float, device=self.device)     # sum of returns, sum of lengths, episodes
+
+        tot_iter = self.current_learning_iteration + num_learning_iterations
+        for it in range(self.current_learning_iteration, tot_iter):
+            start = time.time()
+            with torch.inference_mode():
+                for i in range(self.num_steps_per_env):
+                    actions = alg.act(obs, critic_obs)
+                    if zero_copy:
+                        env.bind_outputs(obs_all[i + 1], priv_all[i + 1])
+                    obs, privileged_obs, rewards, dones, infos = env.step(actions)
+                    critic_obs = privileged_obs if privileged_obs is not None else obs
+                    alg.process_env_step(rewards, dones, infos)
+                    if self.log_dir is not None:
+                        if "episode" in infos:
+                            ep_infos.append({k: v.clone() for k, v in infos["episode"].items()})
+                        cur_reward_sum += rewards
+                        cur_episode_length += 1
+                        d = dones.to(torch.float)
+                        done_stats[0] += (cur_reward_sum * d).sum()
+                        done_stats[1] += (cur_episode_length * d).sum()
+                        done_stats[2] += d.sum()
+                        cur_reward_sum *= 1.0 - d
+                        cur_episode_length *= 1.0 - d
+                if str(self.device).startswith("cuda"):
+                    torch.cuda.synchronize()
+                stop = time.time()
+                collection_time = stop - start
+                start = stop
+                alg.compute_returns(critic_obs)
+            mean_value_loss, mean_surrogate_loss = alg.update()
+            if zero_copy:                       # storage.clear() rotated slot T into slot 0
+                obs, critic_obs = obs_all[0], priv_all[0]
+            stop = time.time()
+            learn_time = stop - start
+            self.last_collection_time, self.last_learn_time = collection_time, learn_time
+            if self.log_dir is not None:
+                s = done_stats.cpu()
+                if float(s[2]) > 0:
+                    rewbuffer.append(float(s[0] / s[2]))
+                    lenbuffer.append(float(s[1] / s[2]))
+                done_stats.zero_()
+                self.log(locals())
+                if it % self.save_interval == 0:
+                    self.save(os.path.join(self.log_dir, "model_{}.pt".format(it)))
+            ep_infos.clear()
+        if zero_copy:
+            env.bind_outputs(None, None)
+        self.current_learning_iteration += num_learning_iterations
+        if self.log_dir is not None:
+            self.save(os.path.join(self.log_dir, "model_{}.pt".format(self.current_learning_iteration)))
+
+    # ------------------------------------------------------------------
+    def log(self, locs, width=80, pad=35):
+        self.tot_timesteps += self.num_steps_per_env * self.env.num_envs
+        iteration_time = locs["collection_time"] + locs["learn_time"]
+        self.tot_time += iteration_time
+        scal = (lambda *a: self.writer.add_scalar(*a)) if self.writer is not None else (lambda *a: None)
+        ep_string = ""
+        if locs["ep_infos"]:
+            for key in locs["ep_infos"][0]:
+                vals = torch.stack([torch.as_tensor(e[key], device=self.device).float().reshape(()) for e in locs["ep_infos"]])
+                value = float(vals.mean())
+                scal("Episode/" + key, value, locs["it"])
+                ep_string += f"""{f'Mean episode {key}:':>{pad}} {value:.4f}\n"""
+        mean_std = float(self.alg.actor_critic.std.mean())
+        fps = int(self.num_steps_per_env * self.env.num_envs / iteration_time)
+        scal("Loss/value_function", locs["mean_value_loss"], locs["it"])
+        scal("Loss/surrogate", locs["mean_surrogate_loss"], locs["it"])
+        scal("Loss/learning_rate", self.alg.learning_rate, locs["it"])
+        scal("Policy/mean_noise_std", mean_std, locs["it"])
+        scal("Perf/total_fps", fps, locs["it"])
+        scal("Perf/collection time", locs["collection_time"], locs["it"])
+        scal("Perf/learning_time", locs["learn_time"], locs["it"])
+        have_eps = len(locs["rewbuffer"]) > 0
+        if have_eps:
+            scal("Train/mean_reward", statistics.mean(locs["rewbuffer"]), locs["it"])
+            scal("Train/mean_episode_length", statistics.mean(locs["lenbuffer"]), locs["it"])
+            scal("Train/mean_reward/time", statistics.mean(locs["rewbuffer"]), self.tot_time)
+            scal("Train/mean_episode_length/time", statistics.mean(locs["lenbuffer"]), self.tot_time)
+        head = f" \033[1m Learning iteration {locs['it']}/{self.current_learning_iteration + locs['num_learning_iterations']} \033[0m "
+        out = (f"""{'#' * width}\n{head.center(width, ' ')}\n\n"""
+               f"""{'Computation:':>{pad}} {fps:.0f} steps/s (collection: {locs['collection_time']:.3f}s, learning {locs['learn_time']:.3f}s)\n"""
+               f"""{'Value function loss:':>{pad}} {locs['mean_value_loss']:.4f}\n"""
+               f"""{'Surrogate loss:':>{pad}} {locs['mean_surrogate_loss']:.4f}\n"""
+               f"""{'Mean action noise std:':>{pad}} {mean_std:.2f}\n""")
+        if have_eps:
+            out += (f"""{'Mean reward:':>{pad}} {statistics.mean(locs['rewbuffer']):.2f}\n"""
+                    f"""{'Mean episode length:':>{pad}} {statistics.mean(locs['lenbuffer']):.2f}\n""")
+        out += ep_string
+        done = locs["it"] + 1 - self.current_learning_iteration
+        eta = self.tot_time / max(done, 1) * (locs["num_learning_iterations"] - done)
+        out += (f"""{'-' * width}\n{'Total timesteps:':>{pad}} {self.tot_timesteps}\n"""
+                f"""{'Iteration time:':>{pad}} {iteration_time:.2f}s\n{'Total time:':>{pad}} {self.tot_time:.2f}s\n"""
+                f"""{'ETA:':>{pad}} {eta:.1f}s\n""")
+        print(out)
+
+    def save(self, path, infos=None):
+        torch.save({"model_state_dict": self.alg.actor_critic.state_dict(),
+                    "optimizer_state_dict": self.alg.optimizer.state_dict(),
+                    "iter": self.current_learning_iteration, "infos": infos}, path)
+
+    def load(self, path, load_optimizer=True):
+        loaded = torch.load(path, map_location=self.device)
+        self.alg.actor_critic.load_state_dict(loaded["model_state_dict"])
+        if load_optimizer:
+            self.alg.optimizer.load_state_dict(loaded["optimizer_state_dict"])
+        self.current_learning_iteration = loaded["iter"]
+        return loaded["infos"]
+
+    def get_inference_policy(self, device=None):
+        self.alg.actor_critic.eval()
+        if device is not None and str(device) != str(self.device):
+            import copy
+            return copy.deepcopy(self.alg.actor_critic.actor).to(device)
+        return self.alg.actor_critic.act_inference
+
+    def get_inference_critic(self, device=None):
+        self.alg.actor_critic.eval()
+        return self.alg.actor_critic.evaluate

@@ -1,0 +1,190 @@
+"""PPO with the reference's interface (algo/ppo/ppo.py:38-184) on the MI355X hot path.
+
+act() = one hgym_policy_act call whose outputs land directly in the rollout-storage slot; process_env_step() =
+hgym_store_step (time-out bootstrap) ; compute_returns() = wavefront-scan GAE ; update() = for every minibatch
+hgym_ppo_grad (gather + forward + KL + loss + hand-written backward, all on the device, no host sync) ->
+[RCCL all-reduce of the flat gradient + KL when torch.distributed is initialised] -> hgym_ppo_apply (adaptive-KL
+learning rate, grad-norm clip, Adam, operand-shadow refresh).  The host reads the loss sums back once per update.
+"""
+import os
+
+import torch
+import torch.nn as nn  # noqa: F401  (kept importable like the reference module)
+
+from .actor_critic import ActorCritic
+from .rollout_storage import RolloutStorage
+from . import dist_utils
+
+
+class _DeviceAdam:
+    """What `alg.optimizer` exposes to OnPolicyRunner.save/load: torch.optim.Adam-shaped state dicts backed by the
+    flat exp_avg / exp_avg_sq vectors the HIP Adam kernel updates."""
+
+    def __init__(self, ppo):
+        self._ppo = ppo
+
+    @property
+    def param_groups(self):
+        return [dict(lr=self._ppo.learning_rate, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False)]
+
+    def state_dict(self):
+        net = self._ppo.net
+        state = {}
+        if net is not None:
+            step = float(net.opt_state[1])
+            base = net.params.data_ptr()
+            for i, (name, v) in enumerate(net.views.items()):
+                o = (v.data_ptr() - base) // 4
+                state[i] = dict(step=torch.tensor(step), exp_avg=net.adam_m[o:o + v.numel()].view_as(v).clone(),
+                                exp_avg_sq=net.adam_v[o:o + v.numel()].view_as(v).clone())
+        n = len(state)
+        return dict(state=state, param_groups=[dict(self.param_groups[0], params=list(range(n)))])
+
+    def load_state_dict(self, sd):
+        net = self._ppo.net
+        base = net.params.data_ptr()
+        for i, (name, v) in enumerate(net.views.items()):
+            if i in sd["state"]:
+                o = (v.data_ptr() - base) // 4
+                net.adam_m[o:o + v.numel()].copy_(sd["state"][i]["exp_avg"].flatten())
+                net.adam_v[o:o + v.numel()].copy_(sd["state"][i]["exp_avg_sq"].flatten())
+                net.opt_state[1] = float(sd["state"][i]["step"])
+        if sd.get("param_groups"):
+            self._ppo.learning_rate = sd["param_groups"][0]["lr"]
+
+    def zero_grad(self):
+        if self._ppo.net is not None:
+            self._ppo.net.grads.zero_()
+
+
+class PPO:
+    actor_critic: ActorCritic
+    # compute precision of the dense layers: "bf16" (MFMA fast path, BASELINE config) or "f32" (parity mode)
+    precision = os.environ.get("HGYM_PRECISION", "bf16")
+
+    def __init__(self, actor_critic, num_learning_epochs=1, num_mini_batches=1, clip_param=0.2, gamma=0.998, lam=0.95,
+                 value_loss_coef=1.0, entropy_coef=0.0, learning_rate=1e-3, max_grad_norm=1.0, use_clipped_value_loss=True,
+                 schedule="fixed", desired_kl=0.01, device="cpu"):
+        if not (str(device).startswith("cuda") and torch.cuda.is_available()):
+            raise RuntimeError("PPO runs on the MI355X hot path only (device=%r); there is no CPU training path" % (device,))
+        if not use_clipped_value_loss:
+            raise NotImplementedError("the loss kernel implements the clipped value loss (reference default)")
+        self.device = device
+        self.desired_kl, self.schedule = desired_kl, schedule
+        self._lr0 = learning_rate
+        self.actor_critic = actor_critic
+        self.actor_critic.to(self.device)
+        self.storage = None
+        self.net = None
+        self.optimizer = _DeviceAdam(self)
+        self.transition = RolloutStorage.Transition()
+        self.clip_param = clip_param
+        self.num_learning_epochs, self.num_mini_batches = num_learning_epochs, num_mini_batches
+        self.value_loss_coef, self.entropy_coef = value_loss_coef, entropy_coef
+        self.gamma, self.lam = gamma, lam
+        self.max_grad_norm = max_grad_norm
+        self.use_clipped_value_loss = use_clipped_value_loss
+        self._world = 1
+        self._rank = 0
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            self._world, self._rank = torch.distributed.get_world_size(), torch.distributed.get_rank()
+
+    # ------------------------------------------------------------------
+    @property
+    def learning_rate(self):
+        return float(self.net.opt_state[0]) if self.net is not None else self._lr0
+
+    @learning_rate.setter
+    def learning_rate(self, v):
+        self._lr0 = v
+        if self.net is not None:
+            self.net.opt_state[0] = v
+
+    def init_storage(self, num_envs, num_transitions_per_env, actor_obs_shape, critic_obs_shape, action_shape):
+        import hgym
+        self.storage = RolloutStorage(num_envs, num_transitions_per_env, actor_obs_shape, critic_obs_shape, action_shape, self.device)
+        ac = self.actor_critic
+        mb = (num_envs * num_transitions_per_env) // self.num_mini_batches
+        cfg = hgym.make_net_config(ac.num_actor_obs, ac.num_critic_obs, ac.num_actions, ac.actor_hidden_dims, ac.critic_hidden_dims,
+                                   self.precision, max(mb, num_envs))
+        self.net = hgym.NetBuffers(cfg, self.device, learning_rate=self._lr0)
+        dist_utils.broadcast_parameters(ac.parameters())   # identical initial parameters on every rank
+        ac.bind(self.net)
+        self._ppo_cfg = hgym.make_ppo_config(self.clip_param, self.value_loss_coef, self.entropy_coef, self.max_grad_norm,
+                                             self.desired_kl if self.desired_kl is not None else 0.0,
+                                             adaptive=(self.desired_kl is not None and self.schedule == "adaptive"),
+                                             world_size=self._world)
+        self._sample_step = torch.zeros(1, dtype=torch.int64, device=self.device)
+        ac._sample_step = self._sample_step
+        ac._sample_seed = 0x5EED + 7919 * self._rank
+        self._hgym = hgym
+        # flat gradient + one trailing slot for the minibatch KL: ONE collective per minibatch
+        self._grad_ext = torch.zeros(self.net.P + 1, device=self.device)
+
+    def test_mode(self):
+        self.actor_critic.eval()
+
+    def train_mode(self):
+        self.actor_critic.train()
+
+    # ------------------------------------------------------------------ rollout
+    def act(self, obs, critic_obs):
+        st, s = self.storage, self.storage.step
+        out = None
+        if s < st.num_transitions_per_env:     # write straight into the storage slot (no add_transitions copies)
+            out = dict(actions=st.actions[s], mu=st.mu[s], sigma=st.sigma[s], logp=st.actions_log_prob[s].view(-1), values=st.values[s])
+        t = self.transition
+        t.actions = self.actor_critic.act(obs, critic_obs, out=out)
+        last = self.actor_critic._last
+        t.values, t.actions_log_prob = last["values"], last["logp"]
+        t.action_mean, t.action_sigma = last["mu"], last["sigma"]
+        t.observations, t.critic_observations = obs, critic_obs
+        self._sample_step += 1
+        return t.actions
+
+    def process_env_step(self, rewards, dones, infos):
+        import ctypes as C
+        L = self._hgym._lib
+        st, s = self.storage, self.storage.step
+        if s >= st.num_transitions_per_env:
+            raise AssertionError("Rollout buffer overflow")
+        to = infos.get("time_outs") if isinstance(infos, dict) else None
+        d8 = dones if dones.dtype == torch.uint8 else dones.view(torch.uint8) if dones.dtype == torch.bool else dones.to(torch.uint8)
+        t8 = None if to is None else (to.view(torch.uint8) if to.dtype == torch.bool else to.to(torch.uint8))
+        L.check(L.lib.hgym_store_step(st.num_envs, L.fptr(rewards), L.fptr(self.transition.values), L.u8ptr(t8), L.u8ptr(d8),
+                                      self.gamma, L.fptr(st.rewards[s]), L.u8ptr(st.dones[s]),
+                                      C.c_void_p(torch.cuda.current_stream().cuda_stream)), "hgym_store_step")
+        self.transition.rewards = st.rewards[s].view(-1)
+        self.transition.dones = st.dones[s].view(-1)
+        st.add_transitions(self.transition)
+        self.transition.clear()
+        self.actor_critic.reset(dones)
+
+    def compute_returns(self, last_critic_obs):
+        last_values = self.actor_critic.evaluate(last_critic_obs)
+        self.storage.compute_returns(last_values, self.gamma, self.lam, stats_hook=dist_utils.allreduce_adv_stats)
+
+    # ------------------------------------------------------------------ update
+    def update(self):
+        hgym, net, st = self._hgym, self.net, self.storage
+        T, N = st.num_transitions_per_env, st.num_envs
+        batch = T * N
+        mb = batch // self.num_mini_batches
+        perm = torch.randperm(self.num_mini_batches * mb, device=self.device)     # one permutation for every epoch
+        fl = lambda t: t.flatten(0, 1)
+        obs = fl(st.observations)
+        priv = fl(st.privileged_observations) if st.privileged_observations is not None else obs
+        cols = (obs, priv, fl(st.actions), st.values.view(-1), st.advantages.view(-1), st.returns.view(-1),
+                st.actions_log_prob.view(-1), fl(st.mu), fl(st.sigma))
+        net.opt_state[2:6] = 0.0
+        net.opt_state[7] = 0.0
+        for _ in range(self.num_learning_epochs):
+            for i in range(self.num_mini_batches):
+                idx = perm[i * mb:(i + 1) * mb]
+                net.ppo_grad(self._ppo_cfg, hgym.make_batch(*cols, idx))
+                dist_utils.average_grads_and_kl(net.grads, net.opt_state, self._grad_ext)
+                net.ppo_apply(self._ppo_cfg)
+        o = net.opt_state.cpu()                # the one host read-back of the update
+        n = max(float(o[7]), 1.0)
+        st.clear()
+        return float(o[4]) / n, float(o[3]) / n

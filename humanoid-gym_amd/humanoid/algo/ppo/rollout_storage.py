@@ -1,0 +1,116 @@
+"""Time-major rollout buffer with the reference's fields and methods (algo/ppo/rollout_storage.py:36-182).
+
+Observation buffers carry ONE extra time slot: the env writes the observations of step t+1 directly into slot
+t+1 (LeggedRobot.bind_outputs), so nothing is copied per step; slot T holds the bootstrap observation and is
+rotated to slot 0 when the buffer is cleared.  `observations` / `privileged_observations` are the (T, N, .) views.
+GAE and advantage normalisation run in libhgym_hip.so (wavefront scan)."""
+import ctypes as C
+
+import torch
+
+
+class RolloutStorage:
+    class Transition:
+        def __init__(self):
+            self.observations = None
+            self.critic_observations = None
+            self.actions = None
+            self.rewards = None
+            self.dones = None
+            self.values = None
+            self.actions_log_prob = None
+            self.action_mean = None
+            self.action_sigma = None
+            self.hidden_states = None
+
+        def clear(self):
+            self.__init__()
+
+    def __init__(self, num_envs, num_transitions_per_env, obs_shape, privileged_obs_shape, actions_shape, device="cpu"):
+        self.device = device
+        self.obs_shape, self.privileged_obs_shape, self.actions_shape = obs_shape, privileged_obs_shape, actions_shape
+        T, N = num_transitions_per_env, num_envs
+        z = lambda *s, dtype=torch.float32: torch.zeros(*s, dtype=dtype, device=self.device)
+        self._obs_all = z(T + 1, N, *obs_shape)
+        self.observations = self._obs_all[:T]
+        if privileged_obs_shape[0] is not None:
+            self._priv_all = z(T + 1, N, *privileged_obs_shape)
+            self.privileged_observations = self._priv_all[:T]
+        else:
+            self._priv_all = None
+            self.privileged_observations = None
+        self.rewards = z(T, N, 1)
+        self.actions = z(T, N, *actions_shape)
+        self.dones = z(T, N, 1, dtype=torch.uint8)
+        self.actions_log_prob = z(T, N, 1)
+        self.values = z(T, N, 1)
+        self.returns = z(T, N, 1)
+        self.advantages = z(T, N, 1)
+        self.mu = z(T, N, *actions_shape)
+        self.sigma = z(T, N, *actions_shape)
+        self.num_transitions_per_env, self.num_envs = T, N
+        self.saved_hidden_states_a = self.saved_hidden_states_c = None
+        self._stats = z(3, dtype=torch.float64)
+        self.step = 0
+
+    # ------------------------------------------------------------------
+    def _same(self, a, b):
+        return a.data_ptr() == b.data_ptr() and a.shape == b.shape
+
+    def add_transitions(self, transition):
+        if self.step >= self.num_transitions_per_env:
+            raise AssertionError("Rollout buffer overflow")
+        s = self.step
+        pairs = [(self.observations[s], transition.observations), (self.actions[s], transition.actions),
+                 (self.rewards[s], transition.rewards.view(-1, 1)), (self.dones[s], transition.dones.view(-1, 1)),
+                 (self.values[s], transition.values), (self.actions_log_prob[s], transition.actions_log_prob.view(-1, 1)),
+                 (self.mu[s], transition.action_mean), (self.sigma[s], transition.action_sigma)]
+        if self.privileged_observations is not None:
+            pairs.append((self.privileged_observations[s], transition.critic_observations))
+        for dst, src in pairs:
+            if not self._same(dst, src):          # producers that already wrote the slot are not copied again
+                dst.copy_(src)
+        self.step += 1
+
+    def clear(self):
+        self._obs_all[0].copy_(self._obs_all[self.num_transitions_per_env])
+        if self._priv_all is not None:
+            self._priv_all[0].copy_(self._priv_all[self.num_transitions_per_env])
+        self.step = 0
+
+    def compute_returns(self, last_values, gamma, lam, stats_hook=None):
+        from hgym import _lib as L
+        T, N = self.num_transitions_per_env, self.num_envs
+        if not self.rewards.is_cuda:
+            raise RuntimeError("RolloutStorage.compute_returns runs on the HIP path only (storage is on %s)" % self.device)
+        s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        lv = last_values.reshape(N).contiguous()
+        L.check(L.lib.hgym_gae(T, N, L.fptr(self.rewards), L.fptr(self.values), L.u8ptr(self.dones), L.fptr(lv), gamma, lam,
+                               L.fptr(self.returns), L.fptr(self.advantages), L.f64ptr(self._stats), s), "hgym_gae")
+        if stats_hook is not None:
+            stats_hook(self._stats)               # multi-GPU: all-reduce (sum, sumsq, count) for a global normalisation
+        L.check(L.lib.hgym_adv_normalize(T * N, L.fptr(self.advantages), L.f64ptr(self._stats), s), "hgym_adv_normalize")
+
+    def get_statistics(self):
+        done = self.dones.clone()
+        done[-1] = 1
+        flat = done.permute(1, 0, 2).reshape(-1, 1)
+        idx = torch.cat((flat.new_tensor([-1], dtype=torch.int64), flat.nonzero(as_tuple=False)[:, 0]))
+        return (idx[1:] - idx[:-1]).float().mean(), self.rewards.mean()
+
+    def mini_batch_generator(self, num_mini_batches, num_epochs=8):
+        """API-compatible generator (gathers with torch); the native PPO.update does not use it -- it hands the
+        index slices to hgym_ppo_grad, which fuses the gather into the operand packing."""
+        batch = self.num_envs * self.num_transitions_per_env
+        mb = batch // num_mini_batches
+        indices = torch.randperm(num_mini_batches * mb, requires_grad=False, device=self.device)
+        fl = lambda t: t.flatten(0, 1)
+        obs = fl(self.observations)
+        cobs = fl(self.privileged_observations) if self.privileged_observations is not None else obs
+        cols = [fl(self.actions), fl(self.values), fl(self.advantages), fl(self.returns), fl(self.actions_log_prob), fl(self.mu),
+                fl(self.sigma)]
+        for _ in range(num_epochs):
+            for i in range(num_mini_batches):
+                idx = indices[i * mb:(i + 1) * mb]
+                a, v, adv, ret, lp, mu, sg = (c[idx] for c in cols)
+                yield obs[idx], cobs[idx], a, v, adv, ret, lp, mu, sg, (None, None), None

@@ -1,0 +1,308 @@
+"""LeggedRobot VecEnv on the MI355X hot path.
+
+Same constructor, attributes and step/reset contract as the reference class (envs/base/legged_robot.py:57-235),
+but the body of `step` is ONE fused HIP launch (`hgym_env_step_synth`: action processing, synthetic physics,
+post-physics pipeline, rewards, mask-driven resets, observation stacking) plus a one-workgroup finaliser, on
+env-major SoA buffers owned by this object.  PhysX is replaced by the synthetic backend of SURVEY.md §8d; an
+external simulator can instead write the four sim tensors and call `post_physics_step()`.
+
+There is no CPU implementation behind this class: without libhgym_hip.so and a gfx950 device it raises.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from humanoid.envs.base.base_task import BaseTask
+from humanoid.utils.helpers import class_to_dict
+from .legged_robot_config import LeggedRobotCfg
+
+# reward terms the fused kernel implements, in the alphabetical order class_to_dict imposes
+KERNEL_REWARD_TERMS = [
+    "action_smoothness", "base_acc", "base_height", "collision", "default_joint_pos", "dof_acc", "dof_vel", "feet_air_time",
+    "feet_clearance", "feet_contact_forces", "feet_contact_number", "feet_distance", "foot_slip", "joint_pos", "knee_distance",
+    "low_speed", "orientation", "torques", "track_vel_hard", "tracking_ang_vel", "tracking_lin_vel", "vel_mismatch_exp"]
+
+DOF_NAMES = ["%s_%s_joint" % (s, j) for s in ("left", "right")
+             for j in ("leg_roll", "leg_yaw", "leg_pitch", "knee", "ankle_pitch", "ankle_roll")]
+DOF_EFFORT = [100.0, 100.0, 250.0, 250.0, 100.0, 100.0] * 2          # urdf/XBot-L.urdf <limit effort=...>
+DOF_LOWER = [-0.44, -1.05, -1.57, -1.05, -0.70, -0.44, -1.57, -1.05, -1.31, -1.10, -0.87, -0.44]
+DOF_UPPER = [1.57, 1.05, 1.31, 1.10, 0.87, 0.44, 0.44, 1.05, 1.57, 1.05, 0.70, 0.44]
+NOMINAL_BASE_MASS = 15.0   # synthetic backend: base link + collapsed upper body (URDF base_link alone is 9.96 kg)
+
+
+class LeggedRobot(BaseTask):
+    def __init__(self, cfg: LeggedRobotCfg, sim_params, physics_engine, sim_device, headless):
+        self.cfg = cfg
+        self.sim_params = sim_params
+        self.height_samples = None
+        self.debug_viz = False
+        self.init_done = False
+        self._parse_cfg(self.cfg)
+        super().__init__(self.cfg, sim_params, physics_engine, sim_device, headless)
+        self._init_buffers()
+        self._prepare_reward_function()
+        self.init_done = True
+
+    # ------------------------------------------------------------------ configuration
+    def _parse_cfg(self, cfg):
+        self.dt = self.cfg.control.decimation * self.sim_params.dt
+        self.obs_scales = self.cfg.normalization.obs_scales
+        self.reward_scales = class_to_dict(self.cfg.rewards.scales)
+        self.command_ranges = class_to_dict(self.cfg.commands.ranges)
+        if self.cfg.terrain.mesh_type not in ["heightfield", "trimesh"]:
+            self.cfg.terrain.curriculum = False
+        self.max_episode_length_s = self.cfg.env.episode_length_s
+        self.max_episode_length = np.ceil(self.max_episode_length_s / self.dt)
+        self.cfg.domain_rand.push_interval = np.ceil(self.cfg.domain_rand.push_interval_s / self.dt)
+
+    def _native_config(self):
+        """XBotLCfg -> HgymEnvConfig.  Scalars are combined in python double arithmetic and rounded to fp32 last,
+        exactly where the reference's tensors round them."""
+        from hgym import _lib as L, default_env_config
+        cfg = self.cfg
+        for need in ("frame_stack", "c_frame_stack", "num_single_obs", "single_num_privileged_obs"):
+            if not hasattr(cfg.env, need):
+                raise NotImplementedError("the MI355X hot path implements the XBot-L observation layout (cfg.env.%s missing)" % need)
+        if cfg.env.num_single_obs != L.OBS_FRAME or cfg.env.single_num_privileged_obs != L.PRIV_FRAME:
+            raise NotImplementedError("observation frame sizes other than 47/73 are not built")
+        if cfg.terrain.measure_heights or cfg.terrain.mesh_type in ("heightfield", "trimesh"):
+            raise NotImplementedError("terrain height measurements are outside the hot path (SURVEY.md §8f item 3)")
+        if not cfg.commands.heading_command or cfg.commands.curriculum:
+            raise NotImplementedError("only heading_command=True without command curriculum is built")
+        if getattr(cfg.env, "use_ref_actions", False):
+            raise NotImplementedError("use_ref_actions is not built (SURVEY.md §8f item 3)")
+        c = default_env_config(self.num_envs, seed=getattr(cfg, "seed", 5), frame_stack=cfg.env.frame_stack,
+                               c_frame_stack=cfg.env.c_frame_stack)
+        c.decimation = cfg.control.decimation
+        c.sim_dt = self.sim_params.dt
+        c.dt = self.dt
+        c.max_episode_length = int(self.max_episode_length)
+        c.resample_steps = int(cfg.commands.resampling_time / self.dt)
+        c.push_interval = int(cfg.domain_rand.push_interval)
+        c.push_robots = int(bool(cfg.domain_rand.push_robots))
+        c.add_noise = int(bool(cfg.noise.add_noise))
+        c.clip_actions = cfg.normalization.clip_actions
+        c.clip_obs = cfg.normalization.clip_observations
+        c.action_scale = cfg.control.action_scale
+        c.action_delay = getattr(cfg.domain_rand, "action_delay", 0.0)
+        c.action_noise = getattr(cfg.domain_rand, "action_noise", 0.0)
+        c.noise_level = cfg.noise.noise_level
+        ns_, os_ = cfg.noise.noise_scales, cfg.normalization.obs_scales
+        vec = [0.0] * 5 + [ns_.dof_pos * os_.dof_pos] * 12 + [ns_.dof_vel * os_.dof_vel] * 12 + [0.0] * 12 + \
+              [ns_.ang_vel * os_.ang_vel] * 3 + [ns_.quat * os_.quat] * 3
+        for k, v in enumerate(vec):
+            c.obs_noise[k] = v
+        c.scale_lin_vel, c.scale_ang_vel, c.scale_dof_pos = os_.lin_vel, os_.ang_vel, os_.dof_pos
+        c.scale_dof_vel, c.scale_quat = os_.dof_vel, os_.quat
+        r = self.command_ranges
+        c.cmd_x_lo, c.cmd_x_span = r["lin_vel_x"][0], r["lin_vel_x"][1] - r["lin_vel_x"][0]
+        c.cmd_y_lo, c.cmd_y_span = r["lin_vel_y"][0], r["lin_vel_y"][1] - r["lin_vel_y"][0]
+        c.cmd_h_lo, c.cmd_h_span = r["heading"][0], r["heading"][1] - r["heading"][0]
+        pv, pa = cfg.domain_rand.max_push_vel_xy, getattr(cfg.domain_rand, "max_push_ang_vel", 0.0)
+        c.push_vel_lo, c.push_vel_span, c.push_ang_lo, c.push_ang_span = -pv, pv - (-pv), -pa, pa - (-pa)
+        for j, name in enumerate(self.dof_names):
+            c.default_dof_pos[j] = cfg.init_state.default_joint_angles[name]
+            kp = kd = 0.0
+            for key in cfg.control.stiffness:
+                if key in name:
+                    kp, kd = cfg.control.stiffness[key], cfg.control.damping[key]
+            c.p_gains[j], c.d_gains[j] = kp, kd
+            c.torque_limits[j] = float(np.float32(DOF_EFFORT[j]) * np.float32(cfg.safety.torque_limit))
+            c.dof_lower[j], c.dof_upper[j] = DOF_LOWER[j], DOF_UPPER[j]
+        st = cfg.init_state
+        for i, v in enumerate(st.pos + st.rot + st.lin_vel + st.ang_vel):
+            c.base_init_state[i] = v
+        c.base_body, c.feet_bodies[0], c.feet_bodies[1] = 0, 6, 12
+        c.knee_bodies[0], c.knee_bodies[1] = 4, 10
+        rw = cfg.rewards
+        c.only_positive_rewards = int(bool(rw.only_positive_rewards))
+        c.base_height_target, c.min_dist, c.max_dist = rw.base_height_target, rw.min_dist, rw.max_dist
+        c.target_joint_pos_scale, c.target_feet_height = rw.target_joint_pos_scale, rw.target_feet_height
+        c.cycle_time, c.tracking_sigma, c.max_contact_force = rw.cycle_time, rw.tracking_sigma, rw.max_contact_force
+        c.episode_length_s = self.max_episode_length_s
+        return c
+
+    # ------------------------------------------------------------------ construction
+    def create_sim(self):
+        """Where the reference builds the PhysX scene (legged_robot.py:588-708): allocate the device buffers,
+        draw the per-env friction / base-mass randomisation, lay the envs out on the plane grid."""
+        import hgym
+        if not (str(self.device).startswith("cuda") and torch.cuda.is_available()):
+            raise RuntimeError("LeggedRobot needs a gfx950 device (sim_device=%r); there is no CPU path" % (self.device,))
+        self.up_axis_idx = 2
+        self.num_dof = self.num_dofs = 12
+        self.num_bodies = 13
+        self.dof_names = list(DOF_NAMES)
+        self._hgym = hgym
+        self._L = hgym._lib
+        self.cfg.seed = getattr(self.cfg, "seed", 5)
+        self._ncfg = None
+        self.custom_origins = False
+        self.feet_indices = torch.tensor([6, 12], dtype=torch.long, device=self.device)
+        self.knee_indices = torch.tensor([4, 10], dtype=torch.long, device=self.device)
+        self.penalised_contact_indices = torch.tensor([0], dtype=torch.long, device=self.device)
+        self.termination_contact_indices = torch.tensor([0], dtype=torch.long, device=self.device)
+
+    def _init_buffers(self):
+        L = self._L
+        self._ncfg = self._native_config()
+        b = self._buf = self._hgym.EnvBuffers(self._ncfg, self.device)
+        N = self.num_envs
+        dr = self.cfg.domain_rand
+        if dr.randomize_friction:                         # legged_robot.py:257-269 (256 buckets)
+            buckets = (dr.friction_range[1] - dr.friction_range[0]) * torch.rand(256, 1) + dr.friction_range[0]
+            b.f["friction"].copy_(buckets[torch.randint(0, 256, (N,))].view(1, N))
+        mass = torch.full((N,), NOMINAL_BASE_MASS)
+        if dr.randomize_base_mass:                        # legged_robot.py:296-302
+            mass += torch.from_numpy(np.random.uniform(dr.added_mass_range[0], dr.added_mass_range[1], N)).float()
+        b.f["body_mass"].copy_(mass.view(1, N))
+        # two output sets: consecutive steps never overwrite the tensors handed out by the previous step, so an
+        # algorithm that keeps references for one step (reference ppo.py:99-100) stays correct
+        z = lambda *s: torch.zeros(*s, device=self.device)
+        self._outs = [(b.obs, b.priv_obs), (z(N, self.num_obs), z(N, self.num_privileged_obs))]
+        self._flip = 0
+        self._bound_out = None
+        self._sim_s, self._st_s = b.sim_struct(), b.state_struct()
+        self._noise_none = b.noise_struct()
+        self.common_step_counter_buf = b.counters
+        # views with the reference's names and shapes
+        self.root_states = b.root_view()
+        self.dof_pos, self.dof_vel = b.dof_pos_view(), b.dof_vel_view()
+        self.base_quat = self.root_states[:, 3:7]
+        self.contact_forces, self.rigid_state = b.contact_view(), b.rigid_view()
+        for name in ("commands", "actions", "last_actions", "last_last_actions", "last_dof_vel", "last_root_vel", "torques",
+                     "feet_air_time", "feet_height", "last_feet_z", "ref_dof_pos", "base_lin_vel", "base_ang_vel",
+                     "projected_gravity", "env_origins"):
+            setattr(self, name, b.view(name))
+        self.base_euler_xyz = b.view("base_euler")
+        self.rand_push_force, self.rand_push_torque = b.view("push_force"), b.view("push_torque")
+        self.env_frictions, self.body_mass = b.view("friction"), b.view("body_mass")
+        self.last_contacts = b.view("last_contacts")
+        self.rew_buf, self.time_out_buf = b.rew, b.time_out
+        self._reset_buf = b.reset
+        self.obs_buf, self.privileged_obs_buf = self._outs[0]
+        c = self._ncfg
+        dev = self.device
+        self.default_dof_pos = torch.tensor(list(c.default_dof_pos), device=dev).unsqueeze(0)
+        self.default_joint_pd_target = self.default_dof_pos.clone()
+        self.p_gains = torch.tensor(list(c.p_gains), device=dev).expand(N, 12)
+        self.d_gains = torch.tensor(list(c.d_gains), device=dev).expand(N, 12)
+        self.torque_limits = torch.tensor(list(c.torque_limits), device=dev)
+        self.base_init_state = torch.tensor(list(c.base_init_state), device=dev)
+        self.noise_scale_vec = torch.tensor(list(c.obs_noise), device=dev)
+        self.commands_scale = torch.tensor([c.scale_lin_vel, c.scale_lin_vel, c.scale_ang_vel], device=dev)
+        self.gravity_vec = torch.tensor([0.0, 0.0, -1.0], device=dev).repeat(N, 1)
+        self.forward_vec = torch.tensor([1.0, 0.0, 0.0], device=dev).repeat(N, 1)
+        self.extras = {}
+        self._refresh_extras()
+
+    def _prepare_reward_function(self):
+        """legged_robot.py:518-541: drop zero scales, multiply by dt once; the survivors must be the kernel's terms."""
+        for key in list(self.reward_scales.keys()):
+            if self.reward_scales[key] == 0:
+                self.reward_scales.pop(key)
+            else:
+                self.reward_scales[key] *= self.dt
+        unknown = [k for k in self.reward_scales if k not in KERNEL_REWARD_TERMS]
+        if unknown:
+            raise NotImplementedError("reward terms not built into the fused env kernel: %s" % unknown)
+        self.reward_names = [k for k in self.reward_scales]
+        for k, name in enumerate(KERNEL_REWARD_TERMS):
+            self._ncfg.reward_scales[k] = self.reward_scales.get(name, 0.0)
+        sums = self._buf.f["episode_sums"]
+        self.episode_sums = {name: sums[KERNEL_REWARD_TERMS.index(name)] for name in self.reward_names}
+
+    # ------------------------------------------------------------------ runner-visible buffers
+    @property
+    def episode_length_buf(self):
+        return self._buf.episode_length
+
+    @episode_length_buf.setter
+    def episode_length_buf(self, value):      # the runner REBINDS this attribute (on_policy_runner.py:104-106)
+        self._buf.episode_length.copy_(value)
+
+    @property
+    def reset_buf(self):
+        return self._reset_buf
+
+    @reset_buf.setter
+    def reset_buf(self, value):
+        self._reset_buf.copy_(value.to(torch.bool))
+
+    @property
+    def common_step_counter(self):
+        return int(self._buf.counters[0])
+
+    @common_step_counter.setter
+    def common_step_counter(self, v):
+        self._buf.counters[0] = int(v)
+
+    def _refresh_extras(self):
+        b = self._buf
+        self.extras["episode"] = {"rew_" + n: b.extras_episode[KERNEL_REWARD_TERMS.index(n)] for n in self.reward_names} \
+            if hasattr(self, "reward_names") else {}
+        if self.cfg.env.send_timeouts:
+            self.extras["time_outs"] = b.extras_time_outs
+
+    def bind_outputs(self, obs, priv):
+        """Native extension: make the next step write its observations straight into caller memory
+        (the rollout storage slot), removing the add_transitions copy.  Pass None to go back."""
+        self._bound_out = None if obs is None else (obs, priv)
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def _next_out(self):
+        if self._bound_out is not None:
+            obs, priv = self._bound_out
+        else:
+            self._flip ^= 1
+            obs, priv = self._outs[self._flip]
+        return obs, priv, self._buf.out_struct(obs, priv)
+
+    # ------------------------------------------------------------------ VecEnv API
+    def step(self, actions):
+        """legged_robot.py:84-109.  Returns (obs, privileged_obs, rewards, dones, extras)."""
+        L = self._L
+        a = actions.to(self.device, torch.float32)
+        if not a.is_contiguous():
+            a = a.contiguous()
+        obs, priv, out = self._next_out()
+        L.check(L.lib.hgym_env_step_synth(C.byref(self._ncfg), C.byref(self._sim_s), C.byref(self._st_s), C.byref(out),
+                                          L.fptr(a), self._stream()), "hgym_env_step_synth")
+        self.obs_buf, self.privileged_obs_buf = obs, priv
+        return self.obs_buf, self.privileged_obs_buf, self.rew_buf, self.reset_buf, self.extras
+
+    def post_physics_step(self):
+        """For an external simulator that has written root_states / dof / contact / rigid tensors itself."""
+        L = self._L
+        obs, priv, out = self._next_out()
+        L.check(L.lib.hgym_post_physics(C.byref(self._ncfg), C.byref(self._sim_s), C.byref(self._st_s), C.byref(out),
+                                        C.byref(self._noise_none), self._stream()), "hgym_post_physics")
+        self.obs_buf, self.privileged_obs_buf = obs, priv
+
+    def reset_idx(self, env_ids):
+        """Only the all-envs form exists on the device (per-env resets are mask-driven inside the step kernel)."""
+        if len(env_ids) == 0:
+            return
+        if len(env_ids) != self.num_envs:
+            raise NotImplementedError("partial reset_idx from the host is not part of the hot path; resets are mask-driven on the device")
+        L = self._L
+        out = self._buf.out_struct(self.obs_buf, self.privileged_obs_buf)
+        L.check(L.lib.hgym_env_reset_all(C.byref(self._ncfg), C.byref(self._sim_s), C.byref(self._st_s), C.byref(out),
+                                         C.byref(self._noise_none), self._stream()), "hgym_env_reset_all")
+
+    def reset(self):
+        """legged_robot.py:112-117: reset every env, then one zero-action step."""
+        self.reset_idx(torch.arange(self.num_envs, device=self.device))
+        obs, privileged_obs, _, _, _ = self.step(torch.zeros(self.num_envs, self.num_actions, device=self.device))
+        return obs, privileged_obs
+
+    def _prime(self):
+        """XBotLFreeEnv.__init__ tail (humanoid_env.py:78-81)."""
+        L = self._L
+        out = self._buf.out_struct(self.obs_buf, self.privileged_obs_buf)
+        L.check(L.lib.hgym_env_prime(C.byref(self._ncfg), C.byref(self._sim_s), C.byref(self._st_s), C.byref(out),
+                                     C.byref(self._noise_none), self._stream()), "hgym_env_prime")

@@ -305,6 +305,16 @@ int32_t hgym_ppo_grad(const HgymNetConfig* cfg, const HgymPPOConfig* ppo, const 
  * world_size > 1), refreshes the compute-precision shadows, bumps opt_state. */
 int32_t hgym_ppo_apply(const HgymNetConfig* cfg, const HgymPPOConfig* ppo, const HgymNet* net, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Measurement hooks (bench.py's roofline leg).  When enabled, every launch of a profiled kernel class is
+ * bracketed by a pair of HIP events recorded on the launch stream; the summary synchronises those events and
+ * returns launches, summed duration and summed ALGORITHMIC work (flops for the GEMM class, bytes for the
+ * HBM-bound classes; DESIGN.md states the per-unit figures).  Off by default; not capturable in a hipGraph.
+ * ---------------------------------------------------------------------------------------------- */
+enum { HGYM_PROF_GEMM = 0, HGYM_PROF_ENV_STEP = 1, HGYM_PROF_GAE = 2, HGYM_PROF_LOSS = 3, HGYM_PROF_CLASSES = 4 };
+int32_t hgym_prof_enable(int32_t on);  /* 1: start collecting (clears previous events), 0: stop */
+int32_t hgym_prof_summary(int32_t cls, int64_t* launches, double* total_ms, double* work);
+
 #ifdef __cplusplus
 }
 #endif

@@ -61,6 +61,9 @@ def gen_constants(R):
     d["state_dict_keys"] = list(ac.state_dict().keys())
     d["train_cfg_keys"] = sorted(R.class_to_dict(ppo).keys())
     json.dump(d, open(os.path.join(HERE, "constants.json"), "w"), indent=1)
+    # full flattened configs (what task_registry hands the runner): the new repo's config classes must equal these
+    json.dump(dict(env=R.class_to_dict(R.XBotLCfg()), train=R.class_to_dict(R.XBotLCfgPPO())),
+              open(os.path.join(HERE, "config_dump.json"), "w"), indent=1, sort_keys=True)
     print("constants.json", d["param_counts"])
 
 
@@ -344,7 +347,8 @@ def gen_ppo_update(R, N=24, T=8, seed=3):
 if __name__ == "__main__":
     R = H.load_reference()
     gen_constants(R)
-    gen_gae(R)
-    gen_policy_example()
-    gen_env_trace(R)
-    gen_ppo_update(R)
+    if "--constants-only" not in sys.argv:
+        gen_gae(R)
+        gen_policy_example()
+        gen_env_trace(R)
+        gen_ppo_update(R)
