@@ -213,6 +213,7 @@ class LeggedRobot(BaseTask):
             self._ncfg.reward_scales[k] = self.reward_scales.get(name, 0.0)
         sums = self._buf.f["episode_sums"]
         self.episode_sums = {name: sums[KERNEL_REWARD_TERMS.index(name)] for name in self.reward_names}
+        self._refresh_extras()
 
     # ------------------------------------------------------------------ runner-visible buffers
     @property

@@ -7,7 +7,7 @@ timeout 600 python bench.py --steps 5 --warmup 2 > gpurun_out/run3_bench.txt 2>&
 echo "bench exit $?" >> gpurun_out/run3_bench.txt
 tail -5 gpurun_out/run3_bench.txt
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof3 -o r3 -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > $GRAFT_REPO_ROOT/gpurun_out/run3_rocprof.txt 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof3 -o r3 -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > $GRAFT_REPO_ROOT/gpurun_out/run3_rocprof.txt 2>&1
 echo "rocprof exit $?" >> $GRAFT_REPO_ROOT/gpurun_out/run3_rocprof.txt
 cd $GRAFT_REPO_ROOT
 ls -R gpurun_out/prof3 | head -20
