@@ -115,6 +115,17 @@ HG_HD float normal_at(const RngKey& k, uint32_t env, uint32_t base, int i) {
     return (i & 1) ? z1 : z0;
 }
 
+// 4*CALLS standard normals from CALLS Philox evaluations starting at slot `base`; element i equals normal_at(.., i)
+template <int CALLS>
+HG_HD void normals_block(const RngKey& k, uint32_t env, uint32_t base, float* out) {
+#pragma unroll
+    for (int c = 0; c < CALLS; ++c) {
+        const U4 r = rng4(k, env, base + (uint32_t)c);
+        box_muller(r.x, r.y, out[4 * c + 0], out[4 * c + 1]);
+        box_muller(r.z, r.w, out[4 * c + 2], out[4 * c + 3]);
+    }
+}
+
 HG_HD float uniform_at(const RngKey& k, uint32_t env, uint32_t base, int i) {
     const U4 r = rng4(k, env, base + (uint32_t)(i >> 2));
     const int j = i & 3;

@@ -17,14 +17,17 @@
 
 namespace hgym {
 
-template <int H_T, int HC_T>
+template <int H_T, int HC_T, int E_T>
 __global__ __launch_bounds__(256) void env_step_kernel(const EnvArgs A) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int64_t csc0 = A.st.counters[0];
     const int64_t ring_step = A.st.counters[2];
-    env_step_phase_a(A, blockIdx.x, threadIdx.x, smem, csc0);
+    env_stage_in<E_T>(A, blockIdx.x, threadIdx.x, blockDim.x, smem);
     __syncthreads();
-    env_step_phase_b<H_T, HC_T>(A, blockIdx.x, threadIdx.x, blockDim.x, smem, csc0, ring_step);
+    env_step_phase_a<E_T>(A, blockIdx.x, threadIdx.x, smem, csc0);
+    __syncthreads();
+    env_stage_out<E_T>(A, blockIdx.x, threadIdx.x, blockDim.x, smem);
+    env_step_phase_b<H_T, HC_T, E_T>(A, blockIdx.x, threadIdx.x, blockDim.x, smem, csc0, ring_step);
 }
 
 __global__ __launch_bounds__(256) void env_finalize_kernel(const EnvArgs A) {
@@ -71,12 +74,10 @@ int device_cus() {
 }
 
 static int pick_envs_per_block(int N) {
+    // one workgroup per CU up to 4096 envs (E = 16), then wider slices; multiples of 4 keep every slice of the
+    // row-major outputs 16-byte aligned
     const int cus = device_cus() > 0 ? device_cus() : 256;
-    int E = N / (2 * cus);           // aim for ~2 workgroups per CU so phase A of one hides under phase B of another
-    E = (E / 4) * 4;                 // slices start on 16-byte boundaries of the row-major outputs
-    if (E < 4) E = 4;
-    if (E > 64) E = 64;
-    return E;
+    return (N <= 16 * cus * 2) ? 16 : 32;
 }
 
 static int32_t check_common(const HgymEnvConfig* cfg, const HgymSimTensors* sim, const HgymEnvState* st) {
@@ -109,13 +110,17 @@ static int32_t launch_step(const HgymEnvConfig* cfg, const HgymSimTensors* sim, 
     A.mode = mode;
     A.fused = fused;
     A.envs_per_block = pick_envs_per_block(cfg->num_envs);
+    set_body_offsets(A);
     const int blocks = ceil_div(cfg->num_envs, A.envs_per_block);
     const size_t lds = step_smem_bytes(A.envs_per_block);
     prof_begin(HGYM_PROF_ENV_STEP, s);
-    if (cfg->frame_stack == 15 && cfg->c_frame_stack == 3)
-        hipLaunchKernelGGL((env_step_kernel<15, 3>), dim3(blocks), dim3(256), lds, s, A);
+    const bool std_stack = cfg->frame_stack == 15 && cfg->c_frame_stack == 3;
+    if (std_stack && A.envs_per_block == 16)
+        hipLaunchKernelGGL((env_step_kernel<15, 3, 16>), dim3(blocks), dim3(256), lds, s, A);
+    else if (std_stack && A.envs_per_block == 32)
+        hipLaunchKernelGGL((env_step_kernel<15, 3, 32>), dim3(blocks), dim3(256), lds, s, A);
     else
-        hipLaunchKernelGGL((env_step_kernel<0, 0>), dim3(blocks), dim3(256), lds, s, A);
+        hipLaunchKernelGGL((env_step_kernel<0, 0, 0>), dim3(blocks), dim3(256), lds, s, A);
     {   // algorithmic bytes per env-step, SURVEY.md §8d: 4*[245 + (H-1)*47 + (Hc-1)*73 + H*47 + Hc*73] + 6
         const double H = cfg->frame_stack, HC = cfg->c_frame_stack;
         prof_end(HGYM_PROF_ENV_STEP, s, (double)cfg->num_envs * (4.0 * (245 + (H - 1) * 47 + (HC - 1) * 73 + H * 47 + HC * 73) + 6));
@@ -235,6 +240,7 @@ static int32_t launch_simple(void (*kern)(const EnvArgs), const char* name, cons
     A.st = *st;
     if (noise) A.noise = *noise;
     A.actions_in = actions_in;
+    set_body_offsets(A);
     hipLaunchKernelGGL(kern, dim3(ceil_div(cfg->num_envs, 256)), dim3(256), 0, (hipStream_t)stream, A);
     HG_CHECK_LAUNCH(name);
     return HGYM_OK;

@@ -28,7 +28,21 @@ struct EnvArgs {
     int mode;
     int fused;                // 1: pre_physics + synthetic physics run inside the step kernel
     int envs_per_block;
+    int env_base;             // global id of env index 0 of the state arrays (0, or the block's first env for an LDS shadow)
+    int contact_comp[3];      // component offset of the xyz triple of {base, foot L, foot R} in sim.contact
+    int rigid_comp[4];        // component offset of the 13-vector of {foot L, foot R, knee L, knee R} in sim.rigid
 };
+
+HG_HD void set_body_offsets(EnvArgs& A) {   // full Isaac-Gym-shaped tensors: body-major components
+    A.env_base = 0;
+    A.contact_comp[0] = A.cfg.base_body * 3;
+    A.contact_comp[1] = A.cfg.feet_bodies[0] * 3;
+    A.contact_comp[2] = A.cfg.feet_bodies[1] * 3;
+    A.rigid_comp[0] = A.cfg.feet_bodies[0] * 13;
+    A.rigid_comp[1] = A.cfg.feet_bodies[1] * 13;
+    A.rigid_comp[2] = A.cfg.knee_bodies[0] * 13;
+    A.rigid_comp[3] = A.cfg.knee_bodies[1] * 13;
+}
 
 HG_HD float sget(const HgymStrided& s, int env, int comp) { return s.base[(int64_t)env * s.env_stride + (int64_t)comp * s.comp_stride]; }
 HG_HD void sset(const HgymStrided& s, int env, int comp, float v) { s.base[(int64_t)env * s.env_stride + (int64_t)comp * s.comp_stride] = v; }
@@ -101,11 +115,12 @@ HG_HD void euler_xyz_wrapped(const float q[4], float e[3]) {
 }
 
 // ------------------------------------------------------------------------------------------------ noise
-HG_HD float nz_uniform(const float* tab, int width, int col, const RngKey& k, int e, uint32_t slot, int i) {
-    return tab ? tab[(int64_t)e * width + col] : uniform_at(k, (uint32_t)e, slot, i);
+// `e` indexes the (possibly LDS-shadowed) table row, `ge` is the global env id that keys the Philox stream
+HG_HD float nz_uniform(const float* tab, int width, int col, const RngKey& k, int e, int ge, uint32_t slot, int i) {
+    return tab ? tab[(int64_t)e * width + col] : uniform_at(k, (uint32_t)ge, slot, i);
 }
-HG_HD float nz_normal(const float* tab, int width, int col, const RngKey& k, int e, uint32_t slot, int i) {
-    return tab ? tab[(int64_t)e * width + col] : normal_at(k, (uint32_t)e, slot, i);
+HG_HD float nz_normal(const float* tab, int width, int col, const RngKey& k, int e, int ge, uint32_t slot, int i) {
+    return tab ? tab[(int64_t)e * width + col] : normal_at(k, (uint32_t)ge, slot, i);
 }
 
 // ------------------------------------------------------------------------------------------------ gait clock
@@ -122,13 +137,16 @@ HG_HD void stance_from_sin(float s, float st[2]) {
 // humanoid_env.py:189-197 + legged_robot.py:90-91
 HG_HD void pre_physics_env(const EnvArgs& A, const RngKey& rk, int e, int N) {
     const HgymEnvConfig& c = A.cfg;
-    const float u = nz_uniform(A.noise.u_delay, 1, 0, rk, e, SLOT_DELAY_CMD, 0);
+    const int ge = A.env_base + e;
+    const float u = nz_uniform(A.noise.u_delay, 1, 0, rk, e, ge, SLOT_DELAY_CMD, 0);
     const float delay = u * c.action_delay;
+    float zn[12];
+    if (!A.noise.z_act) normals_block<3>(rk, (uint32_t)ge, SLOT_ACT, zn);
 #pragma unroll
     for (int j = 0; j < 12; ++j) {
         float a = clampf(A.actions_in[(int64_t)e * 12 + j], -c.clip_actions, c.clip_actions);
         a = (1.0f - delay) * a + delay * FG(A.st.actions, j);
-        const float z = nz_normal(A.noise.z_act, 12, j, rk, e, SLOT_ACT, j);
+        const float z = A.noise.z_act ? A.noise.z_act[(int64_t)e * 12 + j] : zn[j];
         a = a + c.action_noise * z * a;
         FG(A.st.actions, j) = clampf(a, -c.clip_actions, c.clip_actions);
     }
@@ -152,7 +170,7 @@ HG_HD void pd_torques_env(const EnvArgs& A, int e, int N) {
 // tensors drawn from Philox.  This is the benchmark backend only -- it has no reference counterpart.
 HG_HD void synth_physics_env(const EnvArgs& A, const RngKey& rk, int e, int N) {
     const HgymEnvConfig& c = A.cfg;
-    const uint32_t ue = (uint32_t)e;
+    const uint32_t ue = (uint32_t)(A.env_base + e);
 #pragma unroll
     for (int j = 0; j < 12; ++j) {
         float q = sget(A.sim.dof_pos, e, j), qd = sget(A.sim.dof_vel, e, j);
@@ -173,8 +191,7 @@ HG_HD void synth_physics_env(const EnvArgs& A, const RngKey& rk, int e, int N) {
     // root: mean-reverting orientation walk, small height jitter, gaussian velocities
     const U4 r0 = rng4(rk, ue, SLOT_PHYS + 0);
     float n[12];
-#pragma unroll
-    for (int i = 0; i < 12; ++i) n[i] = normal_at(rk, ue, SLOT_PHYS + 1, i);
+    normals_block<3>(rk, ue, SLOT_PHYS + 1, n);
     float qx = 0.9f * sget(A.sim.root, e, 3) + 0.05f * n[0];
     float qy = 0.9f * sget(A.sim.root, e, 4) + 0.05f * n[1];
     float qz = 0.9f * sget(A.sim.root, e, 5) + 0.05f * n[2];
@@ -197,21 +214,20 @@ HG_HD void synth_physics_env(const EnvArgs& A, const RngKey& rk, int e, int N) {
 #pragma unroll
     for (int f = 0; f < 2; ++f) {
         const float on = (stance[f] > 0.5f || ug[f] > 0.4f) ? 1.0f : 0.0f;
-        sset(A.sim.contact, e, c.feet_bodies[f] * 3 + 2, 600.0f * uf[f] * on);
+        sset(A.sim.contact, e, A.contact_comp[1 + f] + 2, 600.0f * uf[f] * on);
     }
     const float hit = (u01(r0.y) < 0.002f) ? 2.0f : 0.0f;
-    sset(A.sim.contact, e, c.base_body * 3 + 0, hit * n[9]);
-    sset(A.sim.contact, e, c.base_body * 3 + 1, hit * n[10]);
-    sset(A.sim.contact, e, c.base_body * 3 + 2, hit * n[11]);
+    sset(A.sim.contact, e, A.contact_comp[0] + 0, hit * n[9]);
+    sset(A.sim.contact, e, A.contact_comp[0] + 1, hit * n[10]);
+    sset(A.sim.contact, e, A.contact_comp[0] + 2, hit * n[11]);
     // rigid bodies: only the entries the rewards read (feet x,y,z,vx,vy ; knees x,y)
     float m[12];
-#pragma unroll
-    for (int i = 0; i < 12; ++i) m[i] = normal_at(rk, ue, SLOT_PHYS + 5, i);
+    normals_block<3>(rk, ue, SLOT_PHYS + 5, m);
     const U4 r2 = rng4(rk, ue, SLOT_PHYS + 8);
     const float uz[2] = {u01(r2.x), u01(r2.y)};
 #pragma unroll
     for (int f = 0; f < 2; ++f) {
-        const int fb = c.feet_bodies[f] * 13, kb = c.knee_bodies[f] * 13;
+        const int fb = A.rigid_comp[f], kb = A.rigid_comp[2 + f];
         const float side = f == 0 ? 0.15f : -0.15f;
         sset(A.sim.rigid, e, fb + 0, 0.2f * m[f * 6 + 0]);
         sset(A.sim.rigid, e, fb + 1, side + 0.05f * m[f * 6 + 1]);
@@ -256,6 +272,7 @@ HG_HD StepFlags post_physics_env(const EnvArgs& A, const RngKey& rk, int64_t csc
     const HgymEnvConfig& c = A.cfg;
     const HgymEnvState& S = A.st;
     const int mode = A.mode;
+    const int ge = A.env_base + e;
     StepFlags fl;
     fl.reset = 0;
 
@@ -277,7 +294,7 @@ HG_HD StepFlags post_physics_env(const EnvArgs& A, const RngKey& rk, int64_t csc
     float fz[2], contact[2];
 #pragma unroll
     for (int f = 0; f < 2; ++f) {
-        fz[f] = sget(A.sim.contact, e, c.feet_bodies[f] * 3 + 2);
+        fz[f] = sget(A.sim.contact, e, A.contact_comp[1 + f] + 2);
         contact[f] = fz[f] > 5.0f ? 1.0f : 0.0f;
     }
     int reset = 0, time_out = 0;
@@ -293,9 +310,9 @@ HG_HD StepFlags post_physics_env(const EnvArgs& A, const RngKey& rk, int64_t csc
         euler_xyz_wrapped(root + 3, eul);
         // _post_physics_step_callback :304-320
         if (ep % c.resample_steps == 0) {
-            const float u[3] = {nz_uniform(A.noise.u_cmd, 6, 0, rk, e, SLOT_DELAY_CMD, 1),
-                                nz_uniform(A.noise.u_cmd, 6, 1, rk, e, SLOT_DELAY_CMD, 2),
-                                nz_uniform(A.noise.u_cmd, 6, 2, rk, e, SLOT_DELAY_CMD, 3)};
+            const float u[3] = {nz_uniform(A.noise.u_cmd, 6, 0, rk, e, ge, SLOT_DELAY_CMD, 1),
+                                nz_uniform(A.noise.u_cmd, 6, 1, rk, e, ge, SLOT_DELAY_CMD, 2),
+                                nz_uniform(A.noise.u_cmd, 6, 2, rk, e, ge, SLOT_DELAY_CMD, 3)};
             resample_commands(c, cmd, u);
         }
         {
@@ -306,15 +323,15 @@ HG_HD StepFlags post_physics_env(const EnvArgs& A, const RngKey& rk, int64_t csc
             cmd[2] = clampf(0.5f * wrap_like_reference(cmd[3] - heading), -1.0f, 1.0f);
         }
         if (c.push_robots && (csc % c.push_interval == 0)) {          // humanoid_env.py:83-98
-            const float px = c.push_vel_span * nz_uniform(A.noise.u_push, 5, 0, rk, e, SLOT_PUSH, 0) + c.push_vel_lo;
-            const float py = c.push_vel_span * nz_uniform(A.noise.u_push, 5, 1, rk, e, SLOT_PUSH, 1) + c.push_vel_lo;
+            const float px = c.push_vel_span * nz_uniform(A.noise.u_push, 5, 0, rk, e, ge, SLOT_PUSH, 0) + c.push_vel_lo;
+            const float py = c.push_vel_span * nz_uniform(A.noise.u_push, 5, 1, rk, e, ge, SLOT_PUSH, 1) + c.push_vel_lo;
             FG(S.push_force, 0) = px;
             FG(S.push_force, 1) = py;
             root[7] = px;
             root[8] = py;
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                const float t = c.push_ang_span * nz_uniform(A.noise.u_push, 5, 2 + i, rk, e, SLOT_PUSH, 2 + i) + c.push_ang_lo;
+                const float t = c.push_ang_span * nz_uniform(A.noise.u_push, 5, 2 + i, rk, e, ge, SLOT_PUSH, 2 + i) + c.push_ang_lo;
                 FG(S.push_torque, i) = t;
                 root[10 + i] = t;
             }
@@ -326,9 +343,9 @@ HG_HD StepFlags post_physics_env(const EnvArgs& A, const RngKey& rk, int64_t csc
         }
         // check_termination :156-161
         {
-            const float bx = sget(A.sim.contact, e, c.base_body * 3 + 0);
-            const float by = sget(A.sim.contact, e, c.base_body * 3 + 1);
-            const float bz = sget(A.sim.contact, e, c.base_body * 3 + 2);
+            const float bx = sget(A.sim.contact, e, A.contact_comp[0] + 0);
+            const float by = sget(A.sim.contact, e, A.contact_comp[0] + 1);
+            const float bz = sget(A.sim.contact, e, A.contact_comp[0] + 2);
             const float bn = sqrtf(bx * bx + by * by + bz * bz);
             time_out = ep > (int64_t)c.max_episode_length;
             reset = (bn > 1.0f) || time_out;
@@ -340,7 +357,7 @@ HG_HD StepFlags post_physics_env(const EnvArgs& A, const RngKey& rk, int64_t csc
             float fpos[2][3], fvxy[2][2], kxy[2][2], fxyz[2][3];
 #pragma unroll
             for (int f = 0; f < 2; ++f) {
-                const int fb = c.feet_bodies[f] * 13, kb = c.knee_bodies[f] * 13;
+                const int fb = A.rigid_comp[f], kb = A.rigid_comp[2 + f];
                 fpos[f][0] = sget(A.sim.rigid, e, fb + 0);
                 fpos[f][1] = sget(A.sim.rigid, e, fb + 1);
                 fpos[f][2] = sget(A.sim.rigid, e, fb + 2);
@@ -348,8 +365,8 @@ HG_HD StepFlags post_physics_env(const EnvArgs& A, const RngKey& rk, int64_t csc
                 fvxy[f][1] = sget(A.sim.rigid, e, fb + 8);
                 kxy[f][0] = sget(A.sim.rigid, e, kb + 0);
                 kxy[f][1] = sget(A.sim.rigid, e, kb + 1);
-                fxyz[f][0] = sget(A.sim.contact, e, c.feet_bodies[f] * 3 + 0);
-                fxyz[f][1] = sget(A.sim.contact, e, c.feet_bodies[f] * 3 + 1);
+                fxyz[f][0] = sget(A.sim.contact, e, A.contact_comp[1 + f] + 0);
+                fxyz[f][1] = sget(A.sim.contact, e, A.contact_comp[1 + f] + 1);
                 fxyz[f][2] = fz[f];
             }
             float term[HGYM_NUM_REWARDS];
@@ -528,7 +545,7 @@ HG_HD StepFlags post_physics_env(const EnvArgs& A, const RngKey& rk, int64_t csc
         fl.reset = 1;
 #pragma unroll
         for (int j = 0; j < 12; ++j) {
-            q[j] = c.default_dof_pos[j] + (c.dof_reset_span * nz_uniform(A.noise.u_dof, 12, j, rk, e, SLOT_DOF, j) + c.dof_reset_lo);
+            q[j] = c.default_dof_pos[j] + (c.dof_reset_span * nz_uniform(A.noise.u_dof, 12, j, rk, e, ge, SLOT_DOF, j) + c.dof_reset_lo);
             qd[j] = 0.0f;
             sset(A.sim.dof_pos, e, j, q[j]);
             sset(A.sim.dof_vel, e, j, 0.0f);
@@ -544,9 +561,9 @@ HG_HD StepFlags post_physics_env(const EnvArgs& A, const RngKey& rk, int64_t csc
 #pragma unroll
         for (int i = 0; i < 13; ++i) sset(A.sim.root, e, i, root[i]);
         {
-            const float u[3] = {nz_uniform(A.noise.u_cmd, 6, 3, rk, e, SLOT_CMD_RESET, 0),
-                                nz_uniform(A.noise.u_cmd, 6, 4, rk, e, SLOT_CMD_RESET, 1),
-                                nz_uniform(A.noise.u_cmd, 6, 5, rk, e, SLOT_CMD_RESET, 2)};
+            const float u[3] = {nz_uniform(A.noise.u_cmd, 6, 3, rk, e, ge, SLOT_CMD_RESET, 0),
+                                nz_uniform(A.noise.u_cmd, 6, 4, rk, e, ge, SLOT_CMD_RESET, 1),
+                                nz_uniform(A.noise.u_cmd, 6, 5, rk, e, ge, SLOT_CMD_RESET, 2)};
             resample_commands(c, cmd, u);
         }
         FG(S.feet_air_time, 0) = 0.0f;
@@ -660,7 +677,7 @@ HG_HD float stack_element(const EnvArgs& A, const RngKey& rk, float* ring, const
     if (j == H - 1) {
         v = clean[k];
         if (kNoisy && A.cfg.add_noise && A.cfg.obs_noise[k] != 0.0f) {
-            const float z = nz_normal(A.noise.z_obs, HGYM_OBS_FRAME, k, rk, e, SLOT_OBS, k);
+            const float z = nz_normal(A.noise.z_obs, HGYM_OBS_FRAME, k, rk, e, e, SLOT_OBS, k);
             v = v + z * A.cfg.obs_noise[k] * A.cfg.noise_level;
         } else if (kNoisy && A.cfg.add_noise) {
             v = v + 0.0f;   // clean + z*0*level in the reference; keeps -0.0 + 0.0 = +0.0 identical
@@ -681,8 +698,14 @@ HG_HD float stack_element(const EnvArgs& A, const RngKey& rk, float* ring, const
 }
 
 // ------------------------------------------------------------------------------------------------ workgroup phases
-// The step kernel is phase A (one lane per env) -> barrier -> phase B (all lanes).  Both phases are plain
-// functions of (block, thread) so that tests/hostcheck can run the identical code on the host.
+// The step kernel runs, per workgroup of E envs:
+//   stage-in   all lanes: every per-env input (state, the needed sim components, actions, noise rows) is copied
+//              into LDS with coalesced loads -- ONE global-memory round trip instead of ~250 dependent ones;
+//   phase A    one lane per env: the per-env arithmetic above, executed against an LDS "shadow" of EnvArgs
+//              (same code, pointers re-aimed at LDS, component stride E instead of N);
+//   stage-out  all lanes: modified state / sim components / step outputs written back, coalesced;
+//   phase B    all lanes: history stacking (stack_element) straight to the row-major outputs.
+// Every phase is a plain function of (block, thread) so tests/hostcheck runs the identical code on the host.
 HG_HD RngKey make_rng_key(const EnvArgs& A, int64_t csc0) {
     RngKey rk;
     rk.k0 = (uint32_t)A.cfg.seed;
@@ -692,44 +715,211 @@ HG_HD RngKey make_rng_key(const EnvArgs& A, int64_t csc0) {
     return rk;
 }
 
-struct BlockSmem {
-    float* frame;   // [E][47]
-    float* priv;    // [E][73]
-    int* reset;     // [E]
-};
-HG_HD BlockSmem carve_smem(float* smem, int E) {
-    BlockSmem b;
-    b.frame = smem;
-    b.priv = smem + E * HGYM_OBS_FRAME;
-    b.reset = (int*)(b.priv + E * HGYM_PRIV_FRAME);
-    return b;
+// components of every [C][N] state field, in HgymEnvState order (commands ... env_origins)
+constexpr int kNumStateFields = 22;
+HG_HD int state_field_comps(int f) {
+    constexpr int c[kNumStateFields] = {4, 12, 12, 12, 12, 6, 12, 2, 2, 2, 2, 12, 3, 3, HGYM_NUM_REWARDS, 3, 3, 3, 3, 1, 1, 3};
+    return c[f];
 }
-inline size_t step_smem_bytes(int E) { return (size_t)E * (HGYM_OBS_FRAME + HGYM_PRIV_FRAME + 1) * sizeof(float); }
+constexpr int kStateComps = 4 + 12 * 6 + 6 + 2 * 4 + 3 * 2 + HGYM_NUM_REWARDS + 3 * 4 + 1 + 1 + 3;   // 136
+constexpr int kFirstConstField = 19;    // friction, body_mass, env_origins are read-only
+HG_HD float** state_field_ptr(HgymEnvState& S, int f) { return (&S.commands) + f; }
+HG_HD float* const* state_field_ptr(const HgymEnvState& S, int f) { return (&S.commands) + f; }
 
+// LDS carve (float offsets) for a block of E envs
+struct LdsMap {
+    int state, root, dof_pos, dof_vel, contact, rigid, actions_in, u_delay, z_act, u_cmd, u_dof, u_push, frame, priv, rew, ep_len,
+        flags, reset_i, total;
+};
+HG_HD LdsMap lds_map(int E) {
+    LdsMap m;
+    int o = 0;
+    m.state = o;      o += kStateComps * E;
+    m.root = o;       o += 13 * E;
+    m.dof_pos = o;    o += 12 * E;
+    m.dof_vel = o;    o += 12 * E;
+    m.contact = o;    o += 9 * E;
+    m.rigid = o;      o += 52 * E;
+    m.actions_in = o; o += 12 * E;
+    m.u_delay = o;    o += E;
+    m.z_act = o;      o += 12 * E;
+    m.u_cmd = o;      o += 6 * E;
+    m.u_dof = o;      o += 12 * E;
+    m.u_push = o;     o += 5 * E;
+    m.frame = o;      o += HGYM_OBS_FRAME * E;
+    m.priv = o;       o += HGYM_PRIV_FRAME * E;
+    m.rew = o;        o += E;
+    o = (o + 1) & ~1;
+    m.ep_len = o;     o += 2 * E;          // int64[E]
+    m.flags = o;      o += (2 * E + 3) / 4;  // uint8 reset[E], time_out[E]
+    m.reset_i = o;    o += E;              // int[E]: "history must be cleared" flags for phase B
+    m.total = o;
+    return m;
+}
+inline size_t step_smem_bytes(int E) { return (size_t)lds_map(E).total * sizeof(float); }
+
+constexpr int kFootRigidComps[5] = {0, 1, 2, 7, 8};
+constexpr int kKneeRigidComps[2] = {0, 1};
+
+// The LDS shadow of EnvArgs for block `block`: same configuration, pointers into smem, component stride E.
+HG_HD EnvArgs make_shadow(const EnvArgs& A, float* smem, int block, int E) {
+    const LdsMap m = lds_map(E);
+    EnvArgs S = A;
+    S.env_base = block * E;
+    int o = m.state;
+    for (int f = 0; f < kNumStateFields; ++f) {
+        *state_field_ptr(S.st, f) = smem + o;
+        o += state_field_comps(f) * E;
+    }
+    S.st.episode_length = reinterpret_cast<int64_t*>(smem + m.ep_len);
+    S.sim.root = HgymStrided{smem + m.root, 1, E};
+    S.sim.dof_pos = HgymStrided{smem + m.dof_pos, 1, E};
+    S.sim.dof_vel = HgymStrided{smem + m.dof_vel, 1, E};
+    S.sim.contact = HgymStrided{smem + m.contact, 1, E};
+    S.sim.rigid = HgymStrided{smem + m.rigid, 1, E};
+    S.contact_comp[0] = 0; S.contact_comp[1] = 3; S.contact_comp[2] = 6;
+    S.rigid_comp[0] = 0; S.rigid_comp[1] = 13; S.rigid_comp[2] = 26; S.rigid_comp[3] = 39;
+    if (A.actions_in) S.actions_in = smem + m.actions_in;
+    if (A.noise.u_delay) S.noise.u_delay = smem + m.u_delay;
+    if (A.noise.z_act) S.noise.z_act = smem + m.z_act;
+    if (A.noise.u_cmd) S.noise.u_cmd = smem + m.u_cmd;
+    if (A.noise.u_dof) S.noise.u_dof = smem + m.u_dof;
+    if (A.noise.u_push) S.noise.u_push = smem + m.u_push;
+    S.out.rew = smem + m.rew;
+    S.out.reset = reinterpret_cast<uint8_t*>(smem + m.flags);
+    S.out.time_out = S.out.reset + E;
+    return S;
+}
+
+HG_HD void copy_rows_in(const float* g, float* l, int width, int e0, int nE, int t, int nthreads) {   // (N,width) row-major table
+    if (!g) return;
+    const float* src = g + (int64_t)e0 * width;
+    for (int i = t; i < nE * width; i += nthreads) l[i] = src[i];
+}
+
+template <int E_T>
+HG_HD void env_stage_in(const EnvArgs& A, int block, int t, int nthreads, float* smem) {
+    const int E = E_T > 0 ? E_T : A.envs_per_block;
+    const int N = A.cfg.num_envs, e0 = block * E;
+    const int nE = (E < N - e0) ? E : (N - e0);
+    const LdsMap m = lds_map(E);
+    int o = m.state;
+    for (int f = 0; f < kNumStateFields; ++f) {
+        const int nc = state_field_comps(f);
+        const float* g = *state_field_ptr(A.st, f);
+        for (int i = t; i < nc * E; i += nthreads) {
+            const int c = i / E, le = i - c * E;
+            smem[o + i] = (le < nE) ? g[(int64_t)c * N + e0 + le] : 0.0f;
+        }
+        o += nc * E;
+    }
+    {   // sim tensors through their strides; only the components the step reads
+        const HgymStrided* sv[3] = {&A.sim.root, &A.sim.dof_pos, &A.sim.dof_vel};
+        const int nc[3] = {13, 12, 12};
+        const int off[3] = {m.root, m.dof_pos, m.dof_vel};
+        for (int k = 0; k < 3; ++k)
+            for (int i = t; i < nc[k] * E; i += nthreads) {
+                const int c = i / E, le = i - c * E;
+                smem[off[k] + i] = (le < nE) ? sget(*sv[k], e0 + le, c) : 0.0f;
+            }
+        for (int i = t; i < 9 * E; i += nthreads) {
+            const int c = i / E, le = i - c * E;
+            smem[m.contact + i] = (le < nE) ? sget(A.sim.contact, e0 + le, A.contact_comp[c / 3] + c % 3) : 0.0f;
+        }
+        for (int i = t; i < 14 * E; i += nthreads) {   // feet {x,y,z,vx,vy}, knees {x,y}
+            const int q = i / E, le = i - q * E;
+            const int body = q < 10 ? q / 5 : 2 + (q - 10) / 2;
+            const int comp = q < 10 ? kFootRigidComps[q % 5] : kKneeRigidComps[(q - 10) % 2];
+            smem[m.rigid + (body * 13 + comp) * E + le] = (le < nE) ? sget(A.sim.rigid, e0 + le, A.rigid_comp[body] + comp) : 0.0f;
+        }
+    }
+    for (int i = t; i < nE; i += nthreads) reinterpret_cast<int64_t*>(smem + m.ep_len)[i] = A.st.episode_length[e0 + i];
+    copy_rows_in(A.actions_in, smem + m.actions_in, 12, e0, nE, t, nthreads);
+    copy_rows_in(A.noise.u_delay, smem + m.u_delay, 1, e0, nE, t, nthreads);
+    copy_rows_in(A.noise.z_act, smem + m.z_act, 12, e0, nE, t, nthreads);
+    copy_rows_in(A.noise.u_cmd, smem + m.u_cmd, 6, e0, nE, t, nthreads);
+    copy_rows_in(A.noise.u_dof, smem + m.u_dof, 12, e0, nE, t, nthreads);
+    copy_rows_in(A.noise.u_push, smem + m.u_push, 5, e0, nE, t, nthreads);
+}
+
+template <int E_T>
 HG_HD void env_step_phase_a(const EnvArgs& A, int block, int t, float* smem, int64_t csc0) {
-    const int N = A.cfg.num_envs, E = A.envs_per_block;
-    const int e0 = block * E;
+    const int E = E_T > 0 ? E_T : A.envs_per_block;
+    const int N = A.cfg.num_envs, e0 = block * E;
     const int nE = (E < N - e0) ? E : (N - e0);
     if (t >= nE) return;
-    const BlockSmem sm = carve_smem(smem, E);
+    const LdsMap m = lds_map(E);
+    const EnvArgs S = make_shadow(A, smem, block, E);
     const RngKey rk = make_rng_key(A, csc0);
-    const int e = e0 + t;
     if (A.mode == MODE_STEP && A.fused) {
-        pre_physics_env(A, rk, e, N);
-        synth_physics_env(A, rk, e, N);
+        pre_physics_env(S, rk, t, E);
+        synth_physics_env(S, rk, t, E);
     }
-    const StepFlags fl = post_physics_env(A, rk, csc0 + 1, e, N, sm.frame + t * HGYM_OBS_FRAME, sm.priv + t * HGYM_PRIV_FRAME);
-    sm.reset[t] = fl.reset;
+    const StepFlags fl = post_physics_env(S, rk, csc0 + 1, t, E, smem + m.frame + t * HGYM_OBS_FRAME, smem + m.priv + t * HGYM_PRIV_FRAME);
+    reinterpret_cast<int*>(smem + m.reset_i)[t] = fl.reset;
 }
 
-template <int H_T, int HC_T>
+template <int E_T>
+HG_HD void env_stage_out(const EnvArgs& A, int block, int t, int nthreads, float* smem) {
+    const int E = E_T > 0 ? E_T : A.envs_per_block;
+    const int N = A.cfg.num_envs, e0 = block * E;
+    const int nE = (E < N - e0) ? E : (N - e0);
+    const LdsMap m = lds_map(E);
+    int o = m.state;
+    for (int f = 0; f < kFirstConstField; ++f) {
+        const int nc = state_field_comps(f);
+        float* g = *state_field_ptr(A.st, f);
+        for (int i = t; i < nc * E; i += nthreads) {
+            const int c = i / E, le = i - c * E;
+            if (le < nE) g[(int64_t)c * N + e0 + le] = smem[o + i];
+        }
+        o += nc * E;
+    }
+    {
+        const HgymStrided* sv[3] = {&A.sim.root, &A.sim.dof_pos, &A.sim.dof_vel};
+        const int nc[3] = {13, 12, 12};
+        const int off[3] = {m.root, m.dof_pos, m.dof_vel};
+        for (int k = 0; k < 3; ++k)
+            for (int i = t; i < nc[k] * E; i += nthreads) {
+                const int c = i / E, le = i - c * E;
+                if (le < nE) sset(*sv[k], e0 + le, c, smem[off[k] + i]);
+            }
+        if (A.mode == MODE_STEP && A.fused) {   // the synthetic physics wrote contacts and rigid-body entries
+            for (int i = t; i < 9 * E; i += nthreads) {
+                const int c = i / E, le = i - c * E;
+                if (le < nE) sset(A.sim.contact, e0 + le, A.contact_comp[c / 3] + c % 3, smem[m.contact + i]);
+            }
+            for (int i = t; i < 14 * E; i += nthreads) {
+                const int q = i / E, le = i - q * E;
+                const int body = q < 10 ? q / 5 : 2 + (q - 10) / 2;
+                const int comp = q < 10 ? kFootRigidComps[q % 5] : kKneeRigidComps[(q - 10) % 2];
+                if (le < nE) sset(A.sim.rigid, e0 + le, A.rigid_comp[body] + comp, smem[m.rigid + (body * 13 + comp) * E + le]);
+            }
+        }
+    }
+    const uint8_t* fl = reinterpret_cast<const uint8_t*>(smem + m.flags);
+    for (int i = t; i < nE; i += nthreads) {
+        A.st.episode_length[e0 + i] = reinterpret_cast<const int64_t*>(smem + m.ep_len)[i];
+        A.out.reset[e0 + i] = fl[i];
+        if (A.mode == MODE_STEP) {
+            A.out.rew[e0 + i] = smem[m.rew + i];
+            A.out.time_out[e0 + i] = fl[E + i];
+        }
+    }
+}
+
+template <int H_T, int HC_T, int E_T>
 HG_HD void env_step_phase_b(const EnvArgs& A, int block, int t, int nthreads, float* smem, int64_t csc0, int64_t ring_step) {
-    const int N = A.cfg.num_envs, E = A.envs_per_block;
+    const int E = E_T > 0 ? E_T : A.envs_per_block;
+    const int N = A.cfg.num_envs;
     const int H = H_T > 0 ? H_T : A.cfg.frame_stack;
     const int HC = HC_T > 0 ? HC_T : A.cfg.c_frame_stack;
     const int e0 = block * E;
     const int nE = (E < N - e0) ? E : (N - e0);
-    const BlockSmem sm = carve_smem(smem, E);
+    const LdsMap m = lds_map(E);
+    const float* s_frame = smem + m.frame;
+    const float* s_priv = smem + m.priv;
+    const int* s_reset = reinterpret_cast<const int*>(smem + m.reset_i);
     const RngKey rk = make_rng_key(A, csc0);
     if (A.mode == MODE_RESET_ALL) {   // reset_idx(all) without compute_observations: just clear the history
         const int64_t no = (int64_t)nE * H * HGYM_OBS_FRAME, np = (int64_t)nE * HC * HGYM_PRIV_FRAME;
@@ -749,8 +939,8 @@ HG_HD void env_step_phase_b(const EnvArgs& A, int block, int t, int nthreads, fl
             const int rem = i - le * row;
             const int j = rem / HGYM_OBS_FRAME;
             const int k = rem - j * HGYM_OBS_FRAME;
-            dst[i] = stack_element<true>(A, rk, A.st.obs_ring, sm.frame + le * HGYM_OBS_FRAME, e0 + le, H, HGYM_OBS_FRAME,
-                                         slot_new, j, k, sm.reset[le] != 0);
+            dst[i] = stack_element<true>(A, rk, A.st.obs_ring, s_frame + le * HGYM_OBS_FRAME, e0 + le, H, HGYM_OBS_FRAME,
+                                         slot_new, j, k, s_reset[le] != 0);
         }
     }
     {   // privileged observations: (N, HC*73)
@@ -763,8 +953,8 @@ HG_HD void env_step_phase_b(const EnvArgs& A, int block, int t, int nthreads, fl
             const int rem = i - le * row;
             const int j = rem / HGYM_PRIV_FRAME;
             const int k = rem - j * HGYM_PRIV_FRAME;
-            dst[i] = stack_element<false>(A, rk, A.st.priv_ring, sm.priv + le * HGYM_PRIV_FRAME, e0 + le, HC, HGYM_PRIV_FRAME,
-                                          slot_new, j, k, sm.reset[le] != 0);
+            dst[i] = stack_element<false>(A, rk, A.st.priv_ring, s_priv + le * HGYM_PRIV_FRAME, e0 + le, HC, HGYM_PRIV_FRAME,
+                                          slot_new, j, k, s_reset[le] != 0);
         }
     }
 }

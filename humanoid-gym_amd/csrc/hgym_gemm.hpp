@@ -59,6 +59,7 @@ struct GemmArgs {
     const void* aux;    // optional [M][ldaux] operand-type matrix y = elu(z): output is multiplied by elu'(z) = y>0 ? 1 : y+1
     int64_t ldaux;
     int k_chunk;        // K range per split (multiple of stage_elems); K itself when not split
+    int gx, gy, gz;     // logical grid (N tiles, M tiles, K splits); the launch is 1-D, see the XCD mapping in the kernel
 };
 
 HG_HD float elu_f(float z) { return z > 0.0f ? z : (expf(z) - 1.0f); }
@@ -99,8 +100,17 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(const Ge
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const int kbeg = blockIdx.z * g.k_chunk;
+    // XCD-aware block mapping.  Workgroups are dealt round-robin to the 8 XCDs (block b -> XCD b % 8), each with a
+    // private L2.  All N-tiles of one (M-tile, K-split) pair share the same A panel, so they are given consecutive
+    // slots of ONE XCD: the panel is fetched from HBM once and re-read from that XCD's L2, instead of once per
+    // N-tile through the fabric.  (Placement is a speed matter only; nothing depends on it for correctness.)
+    const int lin = blockIdx.x;
+    const int slot = lin >> 3;
+    const int pair = (slot / g.gx) * 8 + (lin & 7);
+    if (pair >= g.gy * g.gz) return;
+    const int bx = slot % g.gx, by = pair % g.gy, bz = pair / g.gy;
+    const int m0 = by * BM, n0 = bx * BN;
+    const int kbeg = bz * g.k_chunk;
     const int kend = min(g.K, kbeg + g.k_chunk);
     const int nst = (kend - kbeg) / SE;
 
@@ -164,7 +174,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(const Ge
 #undef HG_WRITE_STAGE
 
     // epilogue: lane holds, for output row m = ... + (lane & 15), the 4 consecutive columns n = ... + 4*(lane>>4) + r
-    float* Cf = g.Cf ? g.Cf + (int64_t)blockIdx.z * g.slab_stride : nullptr;
+    float* Cf = g.Cf ? g.Cf + (int64_t)bz * g.slab_stride : nullptr;
     T* Ct = (T*)g.Ct;
     const T* aux = (const T*)g.aux;
 #pragma unroll

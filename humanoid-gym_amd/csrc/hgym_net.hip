@@ -36,6 +36,7 @@ struct WsLayout {
     int SE;                  // stage elements (contraction padding unit)
     int64_t maxM, Mp;        // max batch and its contraction padding (row stride of every transposed buffer)
     int64_t P;               // total parameters
+    int64_t Ps;              // slab stride (P rounded up so every slab starts 256-byte aligned)
     NetLayout net[2];        // 0 actor, 1 critic
     int splits;
     int64_t slabs;           // [splits][P] fp32
@@ -95,8 +96,9 @@ static int32_t ws_layout(const HgymNetConfig* c, WsLayout* w) {
         n.out_f32 = take(w->maxM * (int64_t)dims[n.L] * 4);
     }
     w->P = poff;
+    w->Ps = round_up(poff, 64);
     w->splits = MAX_SPLITS;
-    w->slabs = take((int64_t)w->splits * w->P * 4);
+    w->slabs = take((int64_t)w->splits * w->Ps * 4);
     w->partials = take((int64_t)MAX_LOSS_BLOCKS * 16 * 4);
     w->total_bytes = off;
     return HGYM_OK;
@@ -133,18 +135,30 @@ __global__ __launch_bounds__(256) void transpose_kernel(int M, int Mp, int C, co
     }
 }
 
-// out[r] = sum_m in[r][m], one workgroup per row (bias gradients from dY^T)
+// out[r] += sum_m in[r][m] (bias gradients from dY^T).  grid = (column chunks, rows); every lane issues four
+// independent 16-byte loads, one fp32 atomic per workgroup.  `out` must be zero on entry.
 template <typename T>
-__global__ __launch_bounds__(256) void rowsum_kernel(int M, const T* __restrict__ in, int64_t ld_in, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void rowsum_kernel(int Mp, const T* __restrict__ in, int64_t ld_in, float* __restrict__ out) {
+    constexpr int V = 16 / sizeof(T);
     __shared__ float red[4];
-    const T* row = in + (int64_t)blockIdx.x * ld_in;
+    const T* row = in + (int64_t)blockIdx.y * ld_in;
+    const int base = blockIdx.x * (256 * 4 * V);
     float s = 0.0f;
-    for (int m = threadIdx.x; m < M; m += blockDim.x) s += to_f32<T>(row[m]);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int m = base + (u * 256 + threadIdx.x) * V;
+        if (m < Mp) {   // Mp is a multiple of V and the pad columns are zero
+            const u32x4 raw = *reinterpret_cast<const u32x4*>(row + m);
+            const T* e = reinterpret_cast<const T*>(&raw);
+#pragma unroll
+            for (int k = 0; k < V; ++k) s += to_f32<T>(e[k]);
+        }
+    }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) out[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+    if (threadIdx.x == 0) atomicAdd(&out[blockIdx.y], red[0] + red[1] + red[2] + red[3]);
 }
 
 // PPO.act epilogue (actor_critic.py:111-120): a = mu + sigma*z, logp = sum log N(a; mu, sigma); sigma = std.
@@ -160,10 +174,12 @@ __global__ __launch_bounds__(256) void act_sample_kernel(int M, int A, const flo
         rk.s1 = (uint32_t)(s >> 32);
     }
     float lp = 0.0f;
+    float zn[16];
+    if (!z) normals_block<4>(rk, (uint32_t)m, SLOT_POLICY, zn);
     for (int j = 0; j < A; ++j) {
         const float mj = mu[(int64_t)m * A + j];
         const float sg = mj * 0.0f + std_[j];            // actor_critic.py:113 (propagates NaN like the reference)
-        const float zz = z ? z[(int64_t)m * A + j] : normal_at(rk, (uint32_t)m, SLOT_POLICY, j);
+        const float zz = z ? z[(int64_t)m * A + j] : zn[j];
         const float a = mj + sg * zz;
         actions[(int64_t)m * A + j] = a;
         sigma[(int64_t)m * A + j] = sg;
@@ -311,10 +327,23 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const SegTable tab, i
     const Segment& sg = tab.s[blockIdx.y];
     if (sg.splits == 0) return;
     const int64_t n = (int64_t)sg.rows * sg.cols;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        float s = 0.0f;
-        for (int z = 0; z < sg.splits; ++z) s += slabs[(int64_t)z * P + sg.off + i];
-        grads[sg.off + i] = s;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    if (((sg.off | n) & 3) == 0 && (P & 3) == 0 && (((uintptr_t)grads) & 15) == 0) {   // 16-byte path (P = slab stride)
+        const int64_t n4 = n >> 2;
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int z = 0; z < sg.splits; ++z) {
+                const float4 v = *reinterpret_cast<const float4*>(slabs + (int64_t)z * P + sg.off + 4 * i);
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+            *reinterpret_cast<float4*>(grads + sg.off + 4 * i) = acc;
+        }
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+            float s = 0.0f;
+            for (int z = 0; z < sg.splits; ++z) s += slabs[(int64_t)z * P + sg.off + i];
+            grads[sg.off + i] = s;
+        }
     }
 }
 
@@ -397,9 +426,13 @@ __global__ __launch_bounds__(256) void sync_shadow_kernel(const SegTable tab, co
 
 // ------------------------------------------------------------------------------------------------ GEMM dispatch
 template <typename T, int BM, int BN, int WMs, int WNs>
-static void launch_cfg(const GemmArgs& g, int splits, hipStream_t s) {
-    dim3 grid(ceil_div(g.N, BN), ceil_div(g.M, BM), splits);
-    hipLaunchKernelGGL((gemm_nt_kernel<T, BM, BN, WMs, WNs>), grid, dim3(WMs * WNs * 64), 0, s, g);
+static void launch_cfg(const GemmArgs& g0, int splits, hipStream_t s) {
+    GemmArgs g = g0;
+    g.gx = ceil_div(g.N, BN);
+    g.gy = ceil_div(g.M, BM);
+    g.gz = splits;
+    const int blocks = g.gx * (int)round_up((int64_t)g.gy * g.gz, 8);   // 1-D launch, XCD-aware mapping in the kernel
+    hipLaunchKernelGGL((gemm_nt_kernel<T, BM, BN, WMs, WNs>), dim3(blocks), dim3(WMs * WNs * 64), 0, s, g);
 }
 
 template <typename T>
@@ -539,12 +572,13 @@ struct NetRunner {
                 g.K = Mp;
                 g.Cf = at<float>(w.slabs) + y.w_off;
                 g.ldcf = y.K;
-                g.slab_stride = w.P;
+                g.slab_stride = w.Ps;
                 const int want = split_count(y);
                 const int32_t got = launch_gemm<T>(g, want, s);
                 if (got < 0) return got;
                 HG_REQUIRE(got == want, HGYM_E_LAUNCH, "split-K mismatch %d vs %d", got, want);
-                hipLaunchKernelGGL((rowsum_kernel<T>), dim3(y.N), dim3(256), 0, s, M, at<T>(y.dYT), w.Mp, net.grads + y.b_off);
+                hipLaunchKernelGGL((rowsum_kernel<T>), dim3(ceil_div(Mp, 256 * 4 * (16 / (int)sizeof(T))), y.N), dim3(256), 0, s, Mp,
+                                   at<T>(y.dYT), w.Mp, net.grads + y.b_off);
                 HG_CHECK_LAUNCH("rowsum_kernel");
             }
             if (l > 0) {   // dX = (dY * W) .* elu'(X_l)  -> dY of layer l-1
@@ -579,6 +613,7 @@ struct NetRunner {
         HG_REQUIRE(B > 0 && B <= w.maxM, HGYM_E_SHAPE, "minibatch %d exceeds max_batch %lld", B, (long long)w.maxM);
         float* mu = at<float>(w.net[0].out_f32);
         float* val = at<float>(w.net[1].out_f32);
+        if (hipMemsetAsync(net.grads, 0, (size_t)w.P * sizeof(float), s) != hipSuccess) HG_FAIL(HGYM_E_LAUNCH, "memset of grads failed");
         int32_t rc = forward(0, B, b.obs, cfg.num_obs, b.idx, mu, A, true);
         if (rc) return rc;
         rc = forward(1, B, b.priv, cfg.num_priv, b.idx, val, 1, true);
@@ -619,7 +654,7 @@ struct NetRunner {
         rc = backward(1, B);
         if (rc) return rc;
         const SegTable tab = segments(true);
-        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(64, tab.n), dim3(256), 0, s, tab, w.P, at<float>(w.slabs), net.grads);
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(96, tab.n), dim3(256), 0, s, tab, w.Ps, at<float>(w.slabs), net.grads);
         HG_CHECK_LAUNCH("reduce_slabs_kernel");
         return HGYM_OK;
     }

@@ -29,6 +29,7 @@ static EnvArgs make_args(const HgymEnvConfig* cfg, const HgymSimTensors* sim, co
     A.mode = mode;
     A.fused = fused;
     A.envs_per_block = epb;
+    set_body_offsets(A);
     return A;
 }
 
@@ -42,10 +43,12 @@ int hc_env_step(const HgymEnvConfig* cfg, const HgymSimTensors* sim, const HgymE
     const int64_t csc0 = st->counters[0], ring = st->counters[2];
     std::vector<float> smem(step_smem_bytes(epb) / sizeof(float));
     for (int b = 0; b < blocks; ++b) {
-        for (int t = 0; t < nthreads; ++t) env_step_phase_a(A, b, t, smem.data(), csc0);
+        for (int t = 0; t < nthreads; ++t) env_stage_in<0>(A, b, t, nthreads, smem.data());
+        for (int t = 0; t < nthreads; ++t) env_step_phase_a<0>(A, b, t, smem.data(), csc0);
+        for (int t = 0; t < nthreads; ++t) env_stage_out<0>(A, b, t, nthreads, smem.data());
         for (int t = 0; t < nthreads; ++t) {
-            if (cfg->frame_stack == 15 && cfg->c_frame_stack == 3) env_step_phase_b<15, 3>(A, b, t, nthreads, smem.data(), csc0, ring);
-            else env_step_phase_b<0, 0>(A, b, t, nthreads, smem.data(), csc0, ring);
+            if (cfg->frame_stack == 15 && cfg->c_frame_stack == 3) env_step_phase_b<15, 3, 0>(A, b, t, nthreads, smem.data(), csc0, ring);
+            else env_step_phase_b<0, 0, 0>(A, b, t, nthreads, smem.data(), csc0, ring);
         }
     }
     for (int t = 0; t < nthreads; ++t) env_finalize_part1(A, t, nthreads);
