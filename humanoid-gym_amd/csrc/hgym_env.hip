@@ -13,6 +13,8 @@
 // HBM traffic per env-step is the algorithmic minimum of SURVEY.md §8d: read 14x47+2x73 old frames,
 // write 15x47+3x73 stacked outputs + 47+73 ring frames, ~250 floats of sim input / env state.
 // The kernel is bandwidth/latency bound; no MFMA here by design.
+#include <stdlib.h>
+
 #include "hgym_env_math.hpp"
 
 namespace hgym {
@@ -22,12 +24,12 @@ __global__ __launch_bounds__(256) void env_step_kernel(const EnvArgs A) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int64_t csc0 = A.st.counters[0];
     const int64_t ring_step = A.st.counters[2];
-    env_stage_in<E_T>(A, blockIdx.x, threadIdx.x, blockDim.x, smem);
+    if (!(A.ablate & 1)) env_stage_in<E_T>(A, blockIdx.x, threadIdx.x, blockDim.x, smem);
     __syncthreads();
-    env_step_phase_a<E_T>(A, blockIdx.x, threadIdx.x, smem, csc0);
+    if (!(A.ablate & 2)) env_step_phase_a<E_T>(A, blockIdx.x, threadIdx.x, smem, csc0);
     __syncthreads();
-    env_stage_out<E_T>(A, blockIdx.x, threadIdx.x, blockDim.x, smem);
-    env_step_phase_b<H_T, HC_T, E_T>(A, blockIdx.x, threadIdx.x, blockDim.x, smem, csc0, ring_step);
+    if (!(A.ablate & 4)) env_stage_out<E_T>(A, blockIdx.x, threadIdx.x, blockDim.x, smem);
+    if (!(A.ablate & 8)) env_step_phase_b<H_T, HC_T, E_T>(A, blockIdx.x, threadIdx.x, blockDim.x, smem, csc0, ring_step);
 }
 
 __global__ __launch_bounds__(256) void env_finalize_kernel(const EnvArgs A) {
@@ -110,6 +112,10 @@ static int32_t launch_step(const HgymEnvConfig* cfg, const HgymSimTensors* sim, 
     A.mode = mode;
     A.fused = fused;
     A.envs_per_block = pick_envs_per_block(cfg->num_envs);
+    static const int ablate = getenv("HGYM_ENV_ABLATE") ? atoi(getenv("HGYM_ENV_ABLATE")) : 0;   // profiling experiments only
+    static const int epb = getenv("HGYM_ENV_EPB") ? atoi(getenv("HGYM_ENV_EPB")) : 0;
+    A.ablate = ablate;
+    if (epb == 16 || epb == 32) A.envs_per_block = epb;
     set_body_offsets(A);
     const int blocks = ceil_div(cfg->num_envs, A.envs_per_block);
     const size_t lds = step_smem_bytes(A.envs_per_block);

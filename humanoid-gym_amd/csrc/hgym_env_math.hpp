@@ -28,6 +28,8 @@ struct EnvArgs {
     int mode;
     int fused;                // 1: pre_physics + synthetic physics run inside the step kernel
     int envs_per_block;
+    int ablate;               // debug/profiling only: bit0 skip stage-in, bit1 skip phase A, bit2 skip stage-out, bit3 skip phase B,
+                              // bit4 skip pre_physics+synthetic physics, bit5 skip the per-env post-physics arithmetic
     int env_base;             // global id of env index 0 of the state arrays (0, or the block's first env for an LDS shadow)
     int contact_comp[3];      // component offset of the xyz triple of {base, foot L, foot R} in sim.contact
     int rigid_comp[4];        // component offset of the 13-vector of {foot L, foot R, knee L, knee R} in sim.rigid
@@ -669,32 +671,62 @@ HG_HD StepFlags post_physics_env(const EnvArgs& A, const RngKey& rk, int64_t csc
 // rows are oldest -> newest; the newest frame gets its noise here and is pushed into the ring.
 //   ring      [N][H][F] unclipped frames, newest at slot `slot_new`
 //   clean     this env's clean new frame (LDS), F floats
+// Two uniform passes per output tensor: (1) the newest frame (noise, ring push), (2) the H-1 older frames, a pure
+// shifted copy in which every lane issues kStackBatch independent, UNCONDITIONAL ring loads before its first store
+// (the output and the ring may alias as far as the compiler knows, so a load behind a store would serialise).
+constexpr int kStackBatch = 8;
+
 template <bool kNoisy>
-HG_HD float stack_element(const EnvArgs& A, const RngKey& rk, float* ring, const float* clean, int e, int H, int F,
-                          int slot_new, int j, int k, bool reset) {
-    const int64_t row = ((int64_t)e * H) * F;
-    float v;
-    if (j == H - 1) {
-        v = clean[k];
-        if (kNoisy && A.cfg.add_noise && A.cfg.obs_noise[k] != 0.0f) {
-            const float z = nz_normal(A.noise.z_obs, HGYM_OBS_FRAME, k, rk, e, e, SLOT_OBS, k);
-            v = v + z * A.cfg.obs_noise[k] * A.cfg.noise_level;
-        } else if (kNoisy && A.cfg.add_noise) {
-            v = v + 0.0f;   // clean + z*0*level in the reference; keeps -0.0 + 0.0 = +0.0 identical
+HG_HD void stack_rows(const EnvArgs& A, const RngKey& rk, float* ring, const float* clean_all, const int* s_reset, float* dst, int e0,
+                      int nE, int H, int F, int slot_new, int t, int nthreads) {
+    const int row = H * F;
+    const float lim = A.cfg.clip_obs;
+    // pass 1: newest frame
+    for (int i = t; i < nE * F; i += nthreads) {
+        const int le = i / F, k = i - le * F;
+        const int e = e0 + le;
+        float v = clean_all[i];
+        if (kNoisy && A.cfg.add_noise) {
+            if (A.cfg.obs_noise[k] != 0.0f) {
+                const float z = nz_normal(A.noise.z_obs, HGYM_OBS_FRAME, k, rk, e, e, SLOT_OBS, k);
+                v = v + z * A.cfg.obs_noise[k] * A.cfg.noise_level;
+            } else {
+                v = v + 0.0f;   // clean + z*0*level in the reference
+            }
         }
-        ring[row + (int64_t)slot_new * F + k] = v;
-    } else {
-        int slot = slot_new + 1 + j;
-        if (slot >= H) slot -= H;
-        float* p = ring + row + (int64_t)slot * F + k;
-        if (reset) {
-            *p = 0.0f;
-            v = 0.0f;
-        } else {
-            v = *p;
+        ring[((int64_t)e * H + slot_new) * F + k] = v;
+        dst[(int64_t)le * row + (H - 1) * F + k] = clampf(v, -lim, lim);
+    }
+    // pass 2: older frames, oldest -> newest
+    const int hrow = (H - 1) * F;
+    const int total = nE * hrow;
+    for (int base = t; base < total; base += nthreads * kStackBatch) {
+        float* p[kStackBatch];
+        float old[kStackBatch];
+        int di[kStackBatch];
+        bool rs[kStackBatch];
+#pragma unroll
+        for (int u = 0; u < kStackBatch; ++u) {
+            int i = base + u * nthreads;
+            i = i < total ? i : total - 1;             // clamp: surplus lanes redo the last element (same value)
+            const int le = i / hrow;
+            const int rem = i - le * hrow;
+            const int j = rem / F;
+            const int k = rem - j * F;
+            int slot = slot_new + 1 + j;
+            if (slot >= H) slot -= H;
+            p[u] = ring + ((int64_t)(e0 + le) * H + slot) * F + k;
+            di[u] = le * row + rem;
+            rs[u] = s_reset[le] != 0;
+        }
+#pragma unroll
+        for (int u = 0; u < kStackBatch; ++u) old[u] = *p[u];
+#pragma unroll
+        for (int u = 0; u < kStackBatch; ++u) {
+            if (rs[u]) *p[u] = 0.0f;
+            dst[di[u]] = rs[u] ? 0.0f : clampf(old[u], -lim, lim);
         }
     }
-    return clampf(v, -A.cfg.clip_obs, A.cfg.clip_obs);
 }
 
 // ------------------------------------------------------------------------------------------------ workgroup phases
@@ -851,11 +883,14 @@ HG_HD void env_step_phase_a(const EnvArgs& A, int block, int t, float* smem, int
     const LdsMap m = lds_map(E);
     const EnvArgs S = make_shadow(A, smem, block, E);
     const RngKey rk = make_rng_key(A, csc0);
-    if (A.mode == MODE_STEP && A.fused) {
+    if (A.mode == MODE_STEP && A.fused && !(A.ablate & 16)) {
         pre_physics_env(S, rk, t, E);
         synth_physics_env(S, rk, t, E);
     }
-    const StepFlags fl = post_physics_env(S, rk, csc0 + 1, t, E, smem + m.frame + t * HGYM_OBS_FRAME, smem + m.priv + t * HGYM_PRIV_FRAME);
+    StepFlags fl;
+    fl.reset = 0;
+    if (!(A.ablate & 32))
+        fl = post_physics_env(S, rk, csc0 + 1, t, E, smem + m.frame + t * HGYM_OBS_FRAME, smem + m.priv + t * HGYM_PRIV_FRAME);
     reinterpret_cast<int*>(smem + m.reset_i)[t] = fl.reset;
 }
 
@@ -929,34 +964,11 @@ HG_HD void env_step_phase_b(const EnvArgs& A, int block, int t, int nthreads, fl
         for (int64_t i = t; i < np; i += nthreads) rp[i] = 0.0f;
         return;
     }
-    {   // actor observations: (N, H*47)
-        const int row = H * HGYM_OBS_FRAME;
-        const int total = nE * row;
-        const int slot_new = (int)(ring_step % H);
-        float* dst = A.out.obs + (int64_t)e0 * row;
-        for (int i = t; i < total; i += nthreads) {
-            const int le = i / row;
-            const int rem = i - le * row;
-            const int j = rem / HGYM_OBS_FRAME;
-            const int k = rem - j * HGYM_OBS_FRAME;
-            dst[i] = stack_element<true>(A, rk, A.st.obs_ring, s_frame + le * HGYM_OBS_FRAME, e0 + le, H, HGYM_OBS_FRAME,
-                                         slot_new, j, k, s_reset[le] != 0);
-        }
-    }
-    {   // privileged observations: (N, HC*73)
-        const int row = HC * HGYM_PRIV_FRAME;
-        const int total = nE * row;
-        const int slot_new = (int)(ring_step % HC);
-        float* dst = A.out.priv_obs + (int64_t)e0 * row;
-        for (int i = t; i < total; i += nthreads) {
-            const int le = i / row;
-            const int rem = i - le * row;
-            const int j = rem / HGYM_PRIV_FRAME;
-            const int k = rem - j * HGYM_PRIV_FRAME;
-            dst[i] = stack_element<false>(A, rk, A.st.priv_ring, s_priv + le * HGYM_PRIV_FRAME, e0 + le, HC, HGYM_PRIV_FRAME,
-                                          slot_new, j, k, s_reset[le] != 0);
-        }
-    }
+    // actor observations (N, H*47) and privileged observations (N, HC*73): one contiguous run per workgroup
+    stack_rows<true>(A, rk, A.st.obs_ring, s_frame, s_reset, A.out.obs + (int64_t)e0 * H * HGYM_OBS_FRAME, e0, nE, H, HGYM_OBS_FRAME,
+                     (int)(ring_step % H), t, nthreads);
+    stack_rows<false>(A, rk, A.st.priv_ring, s_priv, s_reset, A.out.priv_obs + (int64_t)e0 * HC * HGYM_PRIV_FRAME, e0, nE, HC,
+                      HGYM_PRIV_FRAME, (int)(ring_step % HC), t, nthreads);
 }
 
 // Step finaliser: the cross-env pieces of reset_idx (legged_robot.py:199-210) -- means of the episode sums

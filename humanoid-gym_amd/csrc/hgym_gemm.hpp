@@ -59,7 +59,6 @@ struct GemmArgs {
     const void* aux;    // optional [M][ldaux] operand-type matrix y = elu(z): output is multiplied by elu'(z) = y>0 ? 1 : y+1
     int64_t ldaux;
     int k_chunk;        // K range per split (multiple of stage_elems); K itself when not split
-    int gx, gy, gz;     // logical grid (N tiles, M tiles, K splits); the launch is 1-D, see the XCD mapping in the kernel
 };
 
 HG_HD float elu_f(float z) { return z > 0.0f ? z : (expf(z) - 1.0f); }
@@ -96,19 +95,14 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(const Ge
     constexpr int SE = FRAGK * KSTAGE;
     static_assert(WTM % 16 == 0 && WTN % 16 == 0, "wave tile must be a multiple of the 16x16 MFMA tile");
 
-    __shared__ u32x4 lds[2 * F * 64];
+    extern __shared__ __attribute__((aligned(16))) u32x4 lds[];   // 2 stages x F fragments x 1 KiB
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-    // XCD-aware block mapping.  Workgroups are dealt round-robin to the 8 XCDs (block b -> XCD b % 8), each with a
-    // private L2.  All N-tiles of one (M-tile, K-split) pair share the same A panel, so they are given consecutive
-    // slots of ONE XCD: the panel is fetched from HBM once and re-read from that XCD's L2, instead of once per
-    // N-tile through the fabric.  (Placement is a speed matter only; nothing depends on it for correctness.)
-    const int lin = blockIdx.x;
-    const int slot = lin >> 3;
-    const int pair = (slot / g.gx) * 8 + (lin & 7);
-    if (pair >= g.gy * g.gz) return;
-    const int bx = slot % g.gx, by = pair % g.gy, bz = pair / g.gy;
+    // Block order: N-tiles fastest.  (An XCD-affine remap that put all N-tiles of one M-tile on the same XCD was
+    // measured on MI355X: neutral at M = 61 440 and 2.5x slower at M = 4096 -- same-line L2 contention -- so the plain
+    // order stays; the operand panels of these skinny layers are served by L2 / Infinity Cache either way.)
+    const int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
     const int m0 = by * BM, n0 = bx * BN;
     const int kbeg = bz * g.k_chunk;
     const int kend = min(g.K, kbeg + g.k_chunk);
@@ -173,10 +167,49 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(const Ge
 #undef HG_LOAD_STAGE
 #undef HG_WRITE_STAGE
 
-    // epilogue: lane holds, for output row m = ... + (lane & 15), the 4 consecutive columns n = ... + 4*(lane>>4) + r
-    float* Cf = g.Cf ? g.Cf + (int64_t)bz * g.slab_stride : nullptr;
-    T* Ct = (T*)g.Ct;
-    const T* aux = (const T*)g.aux;
+    // Epilogue.  Lane holds, for output row m = ... + (lane & 15), the 4 consecutive columns n = ... + 4*(lane>>4) + r.
+    // Every load the epilogue needs (bias, the ELU' operand) is issued BEFORE the first store: the outputs may alias
+    // the inputs as far as the compiler can tell, so a load placed after a store would wait for a full memory round
+    // trip per fragment (measured: that serialisation was half of the kernel's time).
+    float* __restrict__ Cf = g.Cf ? g.Cf + (int64_t)bz * g.slab_stride : nullptr;
+    T* __restrict__ Ct = (T*)g.Ct;
+    const T* __restrict__ aux = (const T*)g.aux;
+    struct alignas(4 * sizeof(T)) Pack { T e[4]; };
+    float bias_r[TN][4];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int nb = n0 + wn * WTN + j * 16 + 4 * lchunk;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bias_r[j][r] = (g.bias && nb + r < g.N) ? g.bias[nb + r] : 0.0f;
+    }
+    const bool vec_t = (g.ldct & 3) == 0, vec_f = (g.ldcf & 3) == 0, vec_a = (g.ldaux & 3) == 0;
+    if (aux) {
+        Pack ax[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = min(m0 + wm * WTM + i * 16 + lrow, g.M - 1);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int nb = n0 + wn * WTN + j * 16 + 4 * lchunk;
+                const T* p = aux + (int64_t)m * g.ldaux + nb;
+                if (nb + 3 < g.N && vec_a) {
+                    ax[i][j] = *reinterpret_cast<const Pack*>(p);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ax[i][j].e[r] = (nb + r < g.N) ? p[r] : from_f32<T>(0.0f);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float y = to_f32<T>(ax[i][j].e[r]);
+                    acc[i][j][r] *= (y > 0.0f) ? 1.0f : (y + 1.0f);   // elu'(z) from y = elu(z)
+                }
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int m = m0 + wm * WTM + i * 16 + lrow;
@@ -185,22 +218,16 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(const Ge
         for (int j = 0; j < TN; ++j) {
             const int nb = n0 + wn * WTN + j * 16 + 4 * lchunk;
             if (nb >= g.N) continue;
-            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-            const bool full = nb + 3 < g.N;
+            float v[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                if (nb + r < g.N) {
-                    if (g.bias) v[r] += g.bias[nb + r];
-                    if (g.act == ACT_ELU) v[r] = elu_f(v[r]);
-                    if (aux) {
-                        const float y = to_f32<T>(aux[(int64_t)m * g.ldaux + nb + r]);
-                        v[r] *= (y > 0.0f) ? 1.0f : (y + 1.0f);
-                    }
-                }
+                v[r] = acc[i][j][r] + bias_r[j][r];
+                if (g.act == ACT_ELU) v[r] = elu_f(v[r]);
             }
+            const bool full = nb + 3 < g.N;
             if (Cf) {
                 float* p = Cf + (int64_t)m * g.ldcf + nb;
-                if (full && (g.ldcf & 3) == 0) {
+                if (full && vec_f) {
                     *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
                 } else {
 #pragma unroll
@@ -210,8 +237,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(const Ge
             }
             if (Ct) {
                 T* p = Ct + (int64_t)m * g.ldct + nb;
-                if (full && (g.ldct & 3) == 0) {
-                    struct alignas(4 * sizeof(T)) Pack { T e[4]; } pk;
+                if (full && vec_t) {
+                    Pack pk;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) pk.e[r] = from_f32<T>(v[r]);
                     *reinterpret_cast<Pack*>(p) = pk;

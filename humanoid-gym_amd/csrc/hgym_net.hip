@@ -12,6 +12,8 @@
 //   split-K slabs             [splits][P] fp32, loss partial sums, scalar outputs
 // Pad rows/columns are never written with non-zero data, so zero-fill at allocation keeps every padded
 // contraction exact.
+#include <stdlib.h>
+
 #include "hgym_gemm.hpp"
 
 namespace hgym {
@@ -176,7 +178,9 @@ __global__ __launch_bounds__(256) void act_sample_kernel(int M, int A, const flo
     float lp = 0.0f;
     float zn[16];
     if (!z) normals_block<4>(rk, (uint32_t)m, SLOT_POLICY, zn);
-    for (int j = 0; j < A; ++j) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {      // fully unrolled so zn[] stays in registers
+        if (j >= A) break;
         const float mj = mu[(int64_t)m * A + j];
         const float sg = mj * 0.0f + std_[j];            // actor_critic.py:113 (propagates NaN like the reference)
         const float zz = z ? z[(int64_t)m * A + j] : zn[j];
@@ -426,13 +430,17 @@ __global__ __launch_bounds__(256) void sync_shadow_kernel(const SegTable tab, co
 
 // ------------------------------------------------------------------------------------------------ GEMM dispatch
 template <typename T, int BM, int BN, int WMs, int WNs>
-static void launch_cfg(const GemmArgs& g0, int splits, hipStream_t s) {
-    GemmArgs g = g0;
-    g.gx = ceil_div(g.N, BN);
-    g.gy = ceil_div(g.M, BM);
-    g.gz = splits;
-    const int blocks = g.gx * (int)round_up((int64_t)g.gy * g.gz, 8);   // 1-D launch, XCD-aware mapping in the kernel
-    hipLaunchKernelGGL((gemm_nt_kernel<T, BM, BN, WMs, WNs>), dim3(blocks), dim3(WMs * WNs * 64), 0, s, g);
+static void launch_cfg(const GemmArgs& g, int splits, hipStream_t s) {
+    constexpr int F = ((BM / 16) + (BN / 16)) * KSTAGE;
+    constexpr size_t lds = (size_t)2 * F * 1024;
+    static bool attr_done = false;
+    if (!attr_done) {   // > 64 KiB of LDS needs the opt-in
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<T, BM, BN, WMs, WNs>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    dim3 grid(ceil_div(g.N, BN), ceil_div(g.M, BM), splits);
+    hipLaunchKernelGGL((gemm_nt_kernel<T, BM, BN, WMs, WNs>), grid, dim3(WMs * WNs * 64), lds, s, g);
 }
 
 template <typename T>
@@ -448,9 +456,15 @@ int32_t launch_gemm(const GemmArgs& g0, int splits, hipStream_t s) {
     splits = ceil_div(stages, per);
     g.k_chunk = per * SE;
     prof_begin(HGYM_PROF_GEMM, s);
+    static const int big = getenv("HGYM_GEMM_BIG") ? atoi(getenv("HGYM_GEMM_BIG")) : 0;   // tile experiment knob
+    const int64_t t128 = (int64_t)ceil_div(g.M, 128) * ceil_div(g.N, 128) * splits;
     if (g.N <= 16) launch_cfg<T, 128, 16, 4, 1>(g, splits, s);
     else if (g.M <= 16) launch_cfg<T, 16, 128, 1, 4>(g, splits, s);
-    else if ((int64_t)ceil_div(g.M, 128) * ceil_div(g.N, 128) * splits >= 192) launch_cfg<T, 128, 128, 2, 2>(g, splits, s);
+    else if (big == 1 && g.M >= 256 && g.N >= 128 && (int64_t)ceil_div(g.M, 256) * ceil_div(g.N, 128) * splits >= 512)
+        launch_cfg<T, 256, 128, 4, 2>(g, splits, s);
+    else if (big == 2 && g.M >= 256 && g.N >= 256 && (int64_t)ceil_div(g.M, 256) * ceil_div(g.N, 256) * splits >= 256)
+        launch_cfg<T, 256, 256, 4, 2>(g, splits, s);
+    else if (t128 >= 192) launch_cfg<T, 128, 128, 2, 2>(g, splits, s);
     else launch_cfg<T, 64, 64, 2, 2>(g, splits, s);
     prof_end(HGYM_PROF_GEMM, s, 2.0 * (double)g.M * (double)g.N * (double)g.K);   // padded K: the flops the MFMAs execute
     HG_CHECK_LAUNCH("gemm_nt_kernel");
