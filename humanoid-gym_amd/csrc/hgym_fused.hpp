@@ -1,0 +1,526 @@
+// hgym_fused.hpp -- the bf16 fast path of the actor/critic: three kernels that replace ~70 launches per minibatch.
+//
+//   mlp_fwd_kernel<BM>   gather + fp32->bf16 + Linear/ELU x3 + head (+ Gaussian sample / log-prob) for a tile of BM rows;
+//                        activations never leave the CU between layers (LDS), weights stream from L2 straight into
+//                        MFMA operand registers.  Used by the rollout (PPO.act, BM = 32) and by the update (BM = 64,
+//                        which also writes the activations the backward pass needs).
+//   mlp_bwd_kernel<BM>   dZ_l = (dZ_{l+1} * W_{l+1}) .* elu'(H_l) for l = 2, 1, 0 in one launch, same structure.
+//   dw_kernel            all eight weight-gradient products dW_l = dZ_l^T * X_l (+ bias gradients) in ONE launch:
+//                        contraction over the batch, operands DMA'd (global_load_lds) into an LDS ring and read with the
+//                        gfx950 transpose read (ds_read_b64_tr_b16), so no transposed copy of anything exists in HBM.
+//
+// Activation layout ("block layout", global and LDS alike): a (rows x cols) bf16 matrix is stored as 16x16 blocks,
+// block (mb, cb) at ((mb * CB + cb) * 512) bytes, row-major inside the block (32 B per row).  With it
+//   * an MFMA 16x16x32 operand fragment (lane l: row l&15, k-chunk l>>4) is one ds_read_b128 per lane, bank-conflict
+//     free (rows 32 B apart, chunk pairs 512 B apart);
+//   * an MFMA epilogue (lane l: row l&15, 4 consecutive columns 4*(l>>4)..) writes one 512-byte block per wave
+//     instruction, to LDS and to HBM, fully coalesced;
+//   * the transpose read of the weight-gradient kernel is lane-linear (address = block + 8 * lane).
+// Weight operand layout: "fragment-major", fragment (nb, kb) = 1 KiB in exact lane order (lane l: row nb*16 + (l&15),
+// k = kb*32 + 8*(l>>4) .. +7), so a wavefront's weight load is one contiguous 1 KiB global_load_dwordx4.
+#pragma once
+#include "hgym_gemm.hpp"
+
+namespace hgym {
+
+constexpr int FUSED_THREADS = 512;
+constexpr int FUSED_WAVES = 8;
+constexpr int FUSED_CHUNK = 128;      // input columns staged per first-layer chunk (4 k-blocks of 32)
+constexpr int FUSED_MAX_G = 6;        // n-blocks per wave in the first layer: N1 <= 8 * 6 * 16 = 768
+
+struct __attribute__((packed, aligned(4))) F4 {
+    float v[4];
+};
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+struct FusedLayer {
+    const u32x4* Wf;    // forward fragments  [NB][KB][64] x 16 B
+    const u32x4* WTf;   // backward fragments [K/16][NBB][64] x 16 B (this layer's W, transposed role)
+    const float* bias;  // [N] fp32, 4-byte aligned
+    int K, N;           // logical in / out features
+    int KB;             // forward contraction blocks of 32
+    int NB;             // forward output blocks of 16
+    int NBB;            // backward contraction blocks of 32 (N padded to 32)
+};
+
+struct FusedNet {
+    FusedLayer layer[4];
+    const float* x;     // fp32 input rows (observations), leading dimension ldx
+    int64_t ldx;
+    __bf16* X0;         // bf16 copy of the gathered input, block layout, CB = 2 * layer[0].KB   (train only)
+    __bf16* H[3];       // hidden activations, block layout, CB = layer[l].N / 16                 (train only)
+    __bf16* dZ[4];      // pre-activation gradients; dZ[3] (32 columns) is written by the loss kernel
+    float* out;         // fp32 head output (M, layer[3].N) row-major
+    int64_t ldo;
+};
+
+HG_HD int fused_lds_p(const FusedNet& n, int BM) { return BM * (n.layer[0].N > n.layer[2].N ? n.layer[0].N : n.layer[2].N) * 2; }
+HG_HD int fused_lds_q(const FusedNet& n, int BM) {
+    const int a = 2 * BM * FUSED_CHUNK * 2, b = BM * n.layer[1].N * 2;
+    return a > b ? a : b;
+}
+
+__device__ __forceinline__ u32x2 pack_bf16x4(float a, float b, float c, float d) {
+    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+    bf16x4 v = {(__bf16)a, (__bf16)b, (__bf16)c, (__bf16)d};
+    return __builtin_bit_cast(u32x2, v);
+}
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned int lo16) { return __builtin_bit_cast(float, lo16 << 16); }
+
+// acc[i][g] += W(nb0+g, kb0+t) x X(i, t) for t < nk.  w0 -> fragment (nb0, kb0); wstride = fragments between n-blocks (x64).
+// xl -> LDS block layout of the input with CBx column blocks per row block, starting at k-block 0 of this call.
+template <int G, int MB>
+__device__ __forceinline__ void mma_steps(const u32x4* __restrict__ w0, int wstride, int nk, const char* xl, int CBx, int lane,
+                                          f32x4 (&acc)[MB][G]) {
+    const int r = lane & 15, q = lane >> 4;
+    const char* xb = xl + (q >> 1) * 512 + r * 32 + (q & 1) * 16;
+    const u32x4* wl = w0 + lane;
+    u32x4 wa[G], wb[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) wa[g] = wl[(int64_t)g * wstride];
+    for (int t = 0; t < nk; t += 2) {
+        const bool two = t + 1 < nk;
+        if (two) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) wb[g] = wl[(int64_t)g * wstride + (t + 1) * 64];
+        }
+        {
+            u32x4 x[MB];
+#pragma unroll
+            for (int i = 0; i < MB; ++i) x[i] = *reinterpret_cast<const u32x4*>(xb + (i * CBx + 2 * t) * 512);
+#pragma unroll
+            for (int i = 0; i < MB; ++i)
+#pragma unroll
+                for (int g = 0; g < G; ++g) mma_frag<__bf16>(wa[g], x[i], acc[i][g]);
+        }
+        if (t + 2 < nk) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) wa[g] = wl[(int64_t)g * wstride + (t + 2) * 64];
+        }
+        if (two) {
+            u32x4 x[MB];
+#pragma unroll
+            for (int i = 0; i < MB; ++i) x[i] = *reinterpret_cast<const u32x4*>(xb + (i * CBx + 2 * (t + 1)) * 512);
+#pragma unroll
+            for (int i = 0; i < MB; ++i)
+#pragma unroll
+                for (int g = 0; g < G; ++g) mma_frag<__bf16>(wb[g], x[i], acc[i][g]);
+        }
+    }
+}
+
+// bias + ELU, bf16, -> LDS block layout (next layer's input) and, when Hg != null, the same blocks in HBM
+template <int G, int MB>
+__device__ __forceinline__ void epilogue_elu(f32x4 (&acc)[MB][G], const float* __restrict__ bias, int nb0, char* out_lds, int CBo,
+                                             __bf16* __restrict__ Hg, int64_t mbg0, int lane) {
+    const int r = lane & 15, q = lane >> 4;
+    const int loff = r * 32 + q * 8;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const F4 b = *reinterpret_cast<const F4*>(bias + (nb0 + g) * 16 + 4 * q);
+#pragma unroll
+        for (int i = 0; i < MB; ++i) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = elu_f(acc[i][g][e] + b.v[e]);
+            const u32x2 pk = pack_bf16x4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<u32x2*>(out_lds + (i * CBo + nb0 + g) * 512 + loff) = pk;
+            if (Hg) *reinterpret_cast<u32x2*>(reinterpret_cast<char*>(Hg) + ((mbg0 + i) * CBo + nb0 + g) * 512 + loff) = pk;
+        }
+    }
+}
+
+template <int G, int MB>
+__device__ __forceinline__ void zero_acc(f32x4 (&acc)[MB][G]) {
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int g = 0; g < G; ++g) acc[i][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+}
+
+// one hidden layer whose whole input is resident in LDS: waves split the n-blocks, G per pass
+template <int G, int MB>
+__device__ __forceinline__ void hidden_layer(const FusedLayer& L, const char* in_lds, int CBin, char* out_lds, __bf16* Hg, int64_t mbg0,
+                                             int wave, int lane) {
+    for (int nb0 = wave * G; nb0 < L.NB; nb0 += FUSED_WAVES * G) {
+        f32x4 acc[MB][G];
+        zero_acc<G, MB>(acc);
+        mma_steps<G, MB>(L.Wf + (int64_t)nb0 * L.KB * 64, L.KB * 64, L.KB, in_lds, CBin, lane, acc);
+        epilogue_elu<G, MB>(acc, L.bias, nb0, out_lds, L.NB, Hg, mbg0, lane);
+    }
+}
+
+struct FwdArgs {
+    FusedNet net[2];
+    int net0;                 // net index of blockIdx.y == 0
+    int M;
+    const int64_t* idx;       // optional row gather
+    int train;                // write X0 / H[] for the backward pass
+    int sample;               // actor head epilogue: Gaussian sample + log-prob (PPO.act)
+    int A;                    // num_actions
+    const float* std_;        // [A]
+    const float* z;           // optional (M, A) normals; null -> Philox(k0, k1, *step)
+    uint32_t k0, k1;
+    const int64_t* step;
+    float* actions;           // (M, A)
+    float* sigma;             // (M, A)
+    float* logp;              // (M,)
+};
+
+template <int BM, int G1>
+__device__ __forceinline__ void fwd_body(const FwdArgs& a, const FusedNet& n, bool is_actor, char* smem) {
+    constexpr int MB = BM / 16;
+    constexpr int IT = BM / 16;                       // staging items per thread per chunk (BM rows x 32 float4 / 512)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const int m0 = blockIdx.x * BM;
+    const int64_t mbg0 = m0 >> 4;
+    char* P = smem;
+    char* Q = smem + fused_lds_p(n, BM);
+    const FusedLayer& L0 = n.layer[0];
+    const FusedLayer& L1 = n.layer[1];
+    const FusedLayer& L2 = n.layer[2];
+    const FusedLayer& L3 = n.layer[3];
+    const int train = a.train;
+
+    // ---------------------------------------------------------------- layer 0: input streamed in 128-column chunks
+    {
+        const int NC = L0.KB / 4;
+        const int CB0 = 2 * L0.KB;
+        const int f4 = tid & 31;
+        const float* srow[IT];
+        int lrow[IT];
+#pragma unroll
+        for (int u = 0; u < IT; ++u) {
+            const int row = u * 16 + (tid >> 5);
+            int m = m0 + row;
+            m = m < a.M ? m : a.M - 1;
+            const int64_t src = a.idx ? a.idx[m] : (int64_t)m;
+            srow[u] = n.x + src * n.ldx;
+            lrow[u] = row;
+        }
+        F4 stg[IT];
+        auto stage_load = [&](int c) {
+            const int col = c * FUSED_CHUNK + f4 * 4;
+#pragma unroll
+            for (int u = 0; u < IT; ++u) {
+                if (col + 3 < L0.K) {
+                    stg[u] = *reinterpret_cast<const F4*>(srow[u] + col);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) stg[u].v[e] = (col + e < L0.K) ? srow[u][col + e] : 0.0f;
+                }
+            }
+        };
+        auto stage_write = [&](int c, int buf) {
+            char* dst = Q + buf * (BM * FUSED_CHUNK * 2);
+#pragma unroll
+            for (int u = 0; u < IT; ++u) {
+                const u32x2 pk = pack_bf16x4(stg[u].v[0], stg[u].v[1], stg[u].v[2], stg[u].v[3]);
+                const int inblk = (lrow[u] & 15) * 32 + (f4 & 3) * 8;
+                *reinterpret_cast<u32x2*>(dst + ((lrow[u] >> 4) * 8 + (f4 >> 2)) * 512 + inblk) = pk;
+                if (train)
+                    *reinterpret_cast<u32x2*>(reinterpret_cast<char*>(n.X0) +
+                                              ((mbg0 + (lrow[u] >> 4)) * CB0 + c * 8 + (f4 >> 2)) * 512 + inblk) = pk;
+            }
+        };
+        const int nb0 = wave * G1;
+        f32x4 acc[MB][G1];
+        zero_acc<G1, MB>(acc);
+        stage_load(0);
+        stage_write(0, 0);
+        __syncthreads();
+        for (int c = 0; c < NC; ++c) {
+            if (c + 1 < NC) stage_load(c + 1);
+            mma_steps<G1, MB>(L0.Wf + ((int64_t)nb0 * L0.KB + c * 4) * 64, L0.KB * 64, 4, Q + (c & 1) * (BM * FUSED_CHUNK * 2), 8, lane, acc);
+            if (c + 1 < NC) stage_write(c + 1, (c + 1) & 1);
+            __syncthreads();
+        }
+        epilogue_elu<G1, MB>(acc, L0.bias, nb0, P, L0.NB, train ? n.H[0] : nullptr, mbg0, lane);
+    }
+    __syncthreads();
+    // ---------------------------------------------------------------- layers 1, 2: input resident in LDS
+    if (L1.NB >= 16) hidden_layer<2, MB>(L1, P, L0.NB, Q, train ? n.H[1] : nullptr, mbg0, wave, lane);
+    else hidden_layer<1, MB>(L1, P, L0.NB, Q, train ? n.H[1] : nullptr, mbg0, wave, lane);
+    __syncthreads();
+    if (L2.NB >= 16) hidden_layer<2, MB>(L2, Q, L1.NB, P, train ? n.H[2] : nullptr, mbg0, wave, lane);
+    else hidden_layer<1, MB>(L2, Q, L1.NB, P, train ? n.H[2] : nullptr, mbg0, wave, lane);
+    __syncthreads();
+    // ---------------------------------------------------------------- head: one wave per 16-row block
+    if (wave < MB) {
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int CB3 = L2.NB;
+        const char* xb = P + (q >> 1) * 512 + r * 32 + (q & 1) * 16;
+        for (int kb = 0; kb < L3.KB; ++kb) {
+            const u32x4 w = L3.Wf[kb * 64 + lane];
+            const u32x4 x = *reinterpret_cast<const u32x4*>(xb + (wave * CB3 + 2 * kb) * 512);
+            mma_frag<__bf16>(w, x, acc);
+        }
+        const int m = m0 + wave * 16 + r;
+        const int No = L3.N;
+        float mu[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) mu[e] = acc[e] + ((4 * q + e < No) ? L3.bias[4 * q + e] : 0.0f);
+        if (m < a.M) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (4 * q + e < No) n.out[(int64_t)m * n.ldo + 4 * q + e] = mu[e];
+        }
+        if (is_actor && a.sample) {
+            const int A = a.A;
+            float zz[4];
+            if (a.z) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) zz[e] = (m < a.M && 4 * q + e < A) ? a.z[(int64_t)m * A + 4 * q + e] : 0.0f;
+            } else {
+                const int64_t s = a.step ? a.step[0] : 0;
+                const RngKey rk = {a.k0, a.k1, (uint32_t)s, (uint32_t)(s >> 32)};
+                const U4 u = rng4(rk, (uint32_t)m, SLOT_POLICY + (uint32_t)q);
+                box_muller(u.x, u.y, zz[0], zz[1]);
+                box_muller(u.z, u.w, zz[2], zz[3]);
+            }
+            float lp = 0.0f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int j = 4 * q + e;
+                if (j < A) {
+                    const float sg = mu[e] * 0.0f + a.std_[j];       // actor_critic.py:113
+                    const float act = mu[e] + sg * zz[e];
+                    const float d = act - mu[e];
+                    lp += -(d * d) / (2.0f * sg * sg) - logf(sg) - 0.9189385332046727f;
+                    if (m < a.M) {
+                        a.actions[(int64_t)m * A + j] = act;
+                        a.sigma[(int64_t)m * A + j] = sg;
+                    }
+                }
+            }
+            lp += __shfl_xor(lp, 16, 64);
+            lp += __shfl_xor(lp, 32, 64);
+            if (q == 0 && m < a.M) a.logp[m] = lp;
+        }
+    }
+}
+
+template <int BM>
+__global__ __launch_bounds__(FUSED_THREADS) void mlp_fwd_kernel(const FwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int which = a.net0 + blockIdx.y;
+    const FusedNet& n = a.net[which];
+    const int g1 = n.layer[0].NB / FUSED_WAVES;
+    if (g1 == 4) fwd_body<BM, 4>(a, n, which == 0, smem);
+    else if (g1 == 6) fwd_body<BM, 6>(a, n, which == 0, smem);
+    else if (g1 == 2) fwd_body<BM, 2>(a, n, which == 0, smem);
+}
+
+// ================================================================================================ backward (dX chain)
+struct BwdArgs {
+    FusedNet net[2];
+    int net0;
+    int M;
+};
+
+// dZ_out[m][k'] = (sum_n dZ_in[m][n] * W[n][k']) * elu'(H[m][k']): W^T fragments as the MFMA A operand.
+template <int G, int MB>
+__device__ __forceinline__ void bwd_step(const u32x4* __restrict__ WTf, int NBo, int NBBc, const char* in_lds, int CBin, char* out_lds,
+                                         __bf16* __restrict__ dZg, const __bf16* __restrict__ Hg, int64_t mbg0, int wave, int lane) {
+    const int r = lane & 15, q = lane >> 4;
+    const int loff = r * 32 + q * 8;
+    for (int nb0 = wave * G; nb0 < NBo; nb0 += FUSED_WAVES * G) {
+        u32x2 aux[MB][G];
+#pragma unroll
+        for (int i = 0; i < MB; ++i)
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+                aux[i][g] = *reinterpret_cast<const u32x2*>(reinterpret_cast<const char*>(Hg) + ((mbg0 + i) * NBo + nb0 + g) * 512 + loff);
+        f32x4 acc[MB][G];
+        zero_acc<G, MB>(acc);
+        mma_steps<G, MB>(WTf + (int64_t)nb0 * NBBc * 64, NBBc * 64, NBBc, in_lds, CBin, lane, acc);
+#pragma unroll
+        for (int i = 0; i < MB; ++i)
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const unsigned int w0 = aux[i][g][0], w1 = aux[i][g][1];
+                const float y[4] = {bf16_bits_to_f32(w0 & 0xffffu), bf16_bits_to_f32(w0 >> 16), bf16_bits_to_f32(w1 & 0xffffu),
+                                    bf16_bits_to_f32(w1 >> 16)};
+                float d[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) d[e] = acc[i][g][e] * ((y[e] > 0.0f) ? 1.0f : (y[e] + 1.0f));   // elu'(z) from y = elu(z)
+                const u32x2 pk = pack_bf16x4(d[0], d[1], d[2], d[3]);
+                if (out_lds) *reinterpret_cast<u32x2*>(out_lds + (i * NBo + nb0 + g) * 512 + loff) = pk;
+                *reinterpret_cast<u32x2*>(reinterpret_cast<char*>(dZg) + ((mbg0 + i) * NBo + nb0 + g) * 512 + loff) = pk;
+            }
+    }
+}
+
+template <int G, int MB>
+__device__ __forceinline__ void bwd_step_pick(int NBo, const u32x4* WTf, int NBBc, const char* in_lds, int CBin, char* out_lds, __bf16* dZg,
+                                              const __bf16* Hg, int64_t mbg0, int wave, int lane) {
+    bwd_step<G, MB>(WTf, NBo, NBBc, in_lds, CBin, out_lds, dZg, Hg, mbg0, wave, lane);
+}
+
+template <int BM>
+__global__ __launch_bounds__(FUSED_THREADS) void mlp_bwd_kernel(const BwdArgs a) {
+    constexpr int MB = BM / 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const FusedNet& n = a.net[a.net0 + blockIdx.y];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.x * BM;
+    const int64_t mbg0 = m0 >> 4;
+    const int N0 = n.layer[0].N, N1 = n.layer[1].N, N2 = n.layer[2].N;
+    char* R0 = smem;                    // head gradient tile: BM x 32
+    char* R1 = R0 + BM * 64;            // dZ2 tile: BM x N2
+    char* R2 = R1 + BM * N2 * 2;        // dZ1 tile: BM x N1
+    {
+        const u32x4* src = reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(n.dZ[3]) + mbg0 * 2 * 512);
+        if (tid < BM * 4) reinterpret_cast<u32x4*>(R0)[tid] = src[tid];
+    }
+    __syncthreads();
+    // l = 2: through W3 (head)
+    bwd_step<1, MB>(n.layer[3].WTf, N2 / 16, n.layer[3].NBB, R0, 2, R1, n.dZ[2], n.H[2], mbg0, wave, lane);
+    __syncthreads();
+    // l = 1: through W2
+    if (N1 / 16 >= 16) bwd_step<2, MB>(n.layer[2].WTf, N1 / 16, n.layer[2].NBB, R1, N2 / 16, R2, n.dZ[1], n.H[1], mbg0, wave, lane);
+    else bwd_step<1, MB>(n.layer[2].WTf, N1 / 16, n.layer[2].NBB, R1, N2 / 16, R2, n.dZ[1], n.H[1], mbg0, wave, lane);
+    __syncthreads();
+    // l = 0: through W1 (widest)
+    if ((N0 / 16) % 24 == 0) bwd_step<3, MB>(n.layer[1].WTf, N0 / 16, n.layer[1].NBB, R2, N1 / 16, nullptr, n.dZ[0], n.H[0], mbg0, wave, lane);
+    else if ((N0 / 16) % 16 == 0) bwd_step<2, MB>(n.layer[1].WTf, N0 / 16, n.layer[1].NBB, R2, N1 / 16, nullptr, n.dZ[0], n.H[0], mbg0, wave, lane);
+    else bwd_step<1, MB>(n.layer[1].WTf, N0 / 16, n.layer[1].NBB, R2, N1 / 16, nullptr, n.dZ[0], n.H[0], mbg0, wave, lane);
+}
+
+// ================================================================================================ weight gradients
+// dW[n][k] = sum_m Z[m][n] * X[m][k]  (Z = dZ_l, X = layer input), 128 x 128 output tiles, contraction split over blockIdx.y.
+constexpr int DW_THREADS = 256;
+constexpr int DW_STAGES = 4;
+constexpr int DW_STAGE_BYTES = 16384;     // 32 rows x (8 Z blocks + 8 X blocks) x 512 B
+constexpr int DW_MAX_PRODUCTS = 8;
+
+struct DwProduct {
+    const __bf16* Z;      // block layout, CBz column blocks per row block
+    const __bf16* X;      // block layout, CBx
+    int CBz, CBx;
+    int N, K;             // valid rows / cols of dW (row-major, leading dimension K)
+    int64_t w_off;        // offset of dW in a slab (floats)
+    int64_t b_off;        // offset of the bias gradient (column sums of Z), -1: none
+    int tiles_n, tiles_k, tile0;
+};
+
+struct DwArgs {
+    DwProduct p[DW_MAX_PRODUCTS];
+    int np;
+    int steps_total;       // row blocks of 32 over the (padded) batch
+    int steps_per_split;
+    float* slabs;
+    int64_t slab_stride;   // floats
+};
+
+__device__ __forceinline__ u32x4 tr_frag(const char* p0, const char* p1) {
+    typedef s16x4 __attribute__((address_space(3)))* lds_p;
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(const_cast<char*>(p0)));
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(const_cast<char*>(p1)));
+    struct { s16x4 a, b; } pr = {a, b};
+    return __builtin_bit_cast(u32x4, pr);
+}
+
+__global__ __launch_bounds__(DW_THREADS) void dw_kernel(const DwArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave >> 1, wj = wave & 1;
+    const int r = lane & 15, q = lane >> 4;
+    // which product / tile
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < DW_MAX_PRODUCTS; ++i)
+        if (i < a.np && (int)blockIdx.x >= a.p[i].tile0) pi = i;
+    const DwProduct& P = a.p[pi];
+    const int tl = blockIdx.x - P.tile0;
+    const int tn = tl / P.tiles_k, tk = tl - tn * P.tiles_k;
+    const int cbz0 = tn * 8, cbx0 = tk * 8;
+    const int step0 = blockIdx.y * a.steps_per_split;
+    int nsteps = a.steps_total - step0;
+    nsteps = nsteps < a.steps_per_split ? nsteps : a.steps_per_split;
+
+    // DMA assignment: wave w moves pieces 4w..4w+3 of every stage; piece p = (operand, row block, block pair)
+    const int op = wave >> 1, mbl = wave & 1;
+    const char* gsrc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int CB = op ? P.CBx : P.CBz;
+        int cb = (op ? cbx0 : cbz0) + 2 * j;
+        cb = cb + 1 < CB ? cb : CB - 2;                       // clamp surplus pairs onto valid blocks (results unused)
+        gsrc[j] = reinterpret_cast<const char*>(op ? P.X : P.Z) + ((int64_t)(2 * step0 + mbl) * CB + cb) * 512 + lane * 16;
+    }
+    const int64_t gstep = (int64_t)2 * (op ? P.CBx : P.CBz) * 512;   // bytes per 32-row step
+    auto issue = [&](int t) {
+        char* dst = smem + (t % DW_STAGES) * DW_STAGE_BYTES + wave * 4096;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc[j] + (int64_t)t * gstep),
+                                             (__attribute__((address_space(3))) void*)(dst + j * 1024), 16, 0, 0);
+    };
+
+    f32x4 acc[4][4];
+    f32x4 accb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        accb[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    const bool do_bias = (P.b_off >= 0) && tk == 0 && wi == 0;
+    const u32x4 ones = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
+
+#pragma unroll
+    for (int s = 0; s < DW_STAGES - 1; ++s)
+        if (s < nsteps) issue(s);
+    for (int t = 0; t < nsteps; ++t) {
+        if (nsteps - 1 - t >= DW_STAGES - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (DW_STAGES - 2)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (t + DW_STAGES - 1 < nsteps) issue(t + DW_STAGES - 1);
+        const char* st = smem + (t % DW_STAGES) * DW_STAGE_BYTES;
+        u32x4 xa[4], zb[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const char* px = st + 8192 + (wi * 4 + i) * 512 + lane * 8;
+            xa[i] = tr_frag(px, px + 4096);
+            const char* pz = st + (wj * 4 + i) * 512 + lane * 8;
+            zb[i] = tr_frag(pz, pz + 4096);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) mma_frag<__bf16>(xa[i], zb[j], acc[i][j]);
+        if (do_bias) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) mma_frag<__bf16>(ones, zb[j], accb[j]);
+        }
+    }
+
+    // lane holds dW[n = .. + r][k = .. + 4q + e]
+    float* __restrict__ slab = a.slabs + (int64_t)blockIdx.y * a.slab_stride;
+    float* __restrict__ out = slab + P.w_off;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int nn = (cbz0 + wj * 4 + j) * 16 + r;
+        if (nn >= P.N) continue;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int kk = (cbx0 + wi * 4 + i) * 16 + 4 * q;
+            float* p = out + (int64_t)nn * P.K + kk;
+            if (kk + 3 < P.K) {
+                F4 v = {{acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]}};
+                *reinterpret_cast<F4*>(p) = v;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (kk + e < P.K) p[e] = acc[i][j][e];
+            }
+        }
+        if (do_bias && q == 0) slab[P.b_off + nn] = accb[j][0];
+    }
+}
+
+}  // namespace hgym

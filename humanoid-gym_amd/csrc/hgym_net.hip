@@ -15,6 +15,7 @@
 #include <stdlib.h>
 
 #include "hgym_gemm.hpp"
+#include "hgym_fused.hpp"
 
 namespace hgym {
 
@@ -25,12 +26,16 @@ struct LayerLayout {
     int64_t w_off, b_off;    // offsets (floats) into the flat fp32 parameter vector
     int64_t Wp, WTp;         // byte offsets into the workspace
     int64_t X, XT, dY, dYT;  // byte offsets: layer input, its transpose, output grad, its transpose
+    // fused bf16 path (hgym_fused.hpp): fragment-major operand copies
+    int KBf, NBf, NBBf;      // forward k-blocks of 32, output blocks of 16, backward contraction blocks of 32
+    int64_t Wf, WTf;         // byte offsets
 };
 
 struct NetLayout {
     int L;
     LayerLayout layer[HGYM_MAX_LAYERS];
     int64_t out_f32;         // [maxM][N_last] fp32 output of the last layer (update path)
+    int64_t X0b, Hb[3], dZb[4];   // fused path: block-layout activations / pre-activation gradients
 };
 
 struct WsLayout {
@@ -44,9 +49,26 @@ struct WsLayout {
     int64_t slabs;           // [splits][P] fp32
     int64_t partials;        // [MAX_LOSS_BLOCKS][16] fp32
     int64_t total_bytes;
+    int fused;               // 1: bf16 fast path (three fused kernels) is usable for this configuration
+    int64_t Mpad;            // fused path: batch padded to the 64-row tile
+    int dw_splits;
 };
 
 constexpr int MAX_LOSS_BLOCKS = 1024;
+constexpr int LOSS_PARTIALS = 32;   // floats per loss workgroup: surrogate, value loss, entropy, kl, dstd[12], dbias_mu[12], dbias_v, pad
+
+static bool fused_supported(const HgymNetConfig* c) {
+    if (c->precision != HGYM_BF16 || c->actor_layers != 4 || c->critic_layers != 4) return false;
+    if (getenv("HGYM_NO_FUSED")) return false;
+    for (int which = 0; which < 2; ++which) {
+        const int32_t* d = which == 0 ? c->actor_dims : c->critic_dims;
+        const int g1 = d[1] / 128;
+        if (d[1] % 128 || !(g1 == 2 || g1 == 4 || g1 == 6)) return false;
+        if (d[2] % 128 || d[2] > 768 || d[3] % 128 || d[3] > 768) return false;
+        if (d[4] > 16) return false;
+    }
+    return true;
+}
 constexpr int MAX_SPLITS = 32;
 
 static int32_t ws_layout(const HgymNetConfig* c, WsLayout* w) {
@@ -58,13 +80,15 @@ static int32_t ws_layout(const HgymNetConfig* c, WsLayout* w) {
     HG_REQUIRE(c->actor_dims[0] == c->num_obs && c->critic_dims[0] == c->num_priv &&
                    c->actor_dims[c->actor_layers] == c->num_actions && c->critic_dims[c->critic_layers] == 1,
                HGYM_E_SHAPE, "layer dims inconsistent with num_obs/num_priv/num_actions");
-    HG_REQUIRE(c->num_actions >= 1 && c->num_actions <= 16, HGYM_E_UNSUPPORTED, "num_actions=%d (kernels hold <=16 per lane)",
+    HG_REQUIRE(c->num_actions >= 1 && c->num_actions <= 12, HGYM_E_UNSUPPORTED, "num_actions=%d (loss kernel reduces <=12 per-action sums)",
                c->num_actions);
     memset(w, 0, sizeof(*w));
     w->es = c->precision == HGYM_F32 ? 4 : 2;
     w->SE = c->precision == HGYM_F32 ? stage_elems<float>() : stage_elems<__bf16>();
     w->maxM = c->max_batch;
     w->Mp = round_up(c->max_batch, w->SE);
+    w->fused = fused_supported(c) ? 1 : 0;
+    w->Mpad = round_up(c->max_batch, 64);
     int64_t off = 0, poff = c->num_actions;  // std first (state_dict order)
     auto take = [&](int64_t bytes) {
         const int64_t o = off;
@@ -88,20 +112,37 @@ static int32_t ws_layout(const HgymNetConfig* c, WsLayout* w) {
             poff += (int64_t)y.N * y.K;
             y.b_off = poff;
             poff += y.N;
-            y.Wp = take((int64_t)y.N16 * y.Kp * w->es);
-            y.WTp = take((int64_t)y.K16 * y.Ncp * w->es);
-            y.X = take(w->maxM * y.Kp * w->es);
-            y.XT = take((int64_t)y.K16 * w->Mp * w->es);
-            y.dY = take(w->maxM * y.Ncp * w->es);
-            y.dYT = take((int64_t)y.N16 * w->Mp * w->es);
+            if (w->fused) {
+                y.KBf = (int)round_up(y.K, l == 0 ? FUSED_CHUNK : 32) / 32;
+                y.NBf = y.N16 / 16;
+                y.NBBf = (int)round_up(y.N, 32) / 32;
+                y.Wf = take((int64_t)y.NBf * y.KBf * 1024);
+                y.WTf = take((int64_t)y.K16 / 16 * y.NBBf * 1024);
+            } else {
+                y.Wp = take((int64_t)y.N16 * y.Kp * w->es);
+                y.WTp = take((int64_t)y.K16 * y.Ncp * w->es);
+                y.X = take(w->maxM * y.Kp * w->es);
+                y.XT = take((int64_t)y.K16 * w->Mp * w->es);
+                y.dY = take(w->maxM * y.Ncp * w->es);
+                y.dYT = take((int64_t)y.N16 * w->Mp * w->es);
+            }
         }
         n.out_f32 = take(w->maxM * (int64_t)dims[n.L] * 4);
+        if (w->fused) {
+            n.X0b = take(w->Mpad * (int64_t)n.layer[0].KBf * 32 * 2);
+            for (int l = 0; l < 3; ++l) {
+                n.Hb[l] = take(w->Mpad * (int64_t)n.layer[l].N * 2);
+                n.dZb[l] = take(w->Mpad * (int64_t)n.layer[l].N * 2);
+            }
+            n.dZb[3] = take(w->Mpad * 32 * 2);
+        }
     }
     w->P = poff;
     w->Ps = round_up(poff, 64);
     w->splits = MAX_SPLITS;
+    w->dw_splits = 16;
     w->slabs = take((int64_t)w->splits * w->Ps * 4);
-    w->partials = take((int64_t)MAX_LOSS_BLOCKS * 16 * 4);
+    w->partials = take((int64_t)MAX_LOSS_BLOCKS * LOSS_PARTIALS * 4);
     w->total_bytes = off;
     return HGYM_OK;
 }
@@ -202,34 +243,42 @@ struct LossArgs {
     const float* val;            // [B]    current value
     const float* std_;           // [A]
     float clip, value_coef, entropy_coef;
+    int fused;                   // 1: dmu / dval are block-layout tiles of 32 columns (hgym_fused.hpp); 0: row-major + transposes
     void* dmu;  int64_t ld_dmu;  // [B][Ncp] operand type
     void* dmuT; int64_t ld_t;    // [A16][Mp]
     void* dval; int64_t ld_dval; // [B][Ncp]
     void* dvalT;                 // [16][Mp]
     int Bp;                      // contraction padding of B for this call
-    float* partials;             // [gridDim.x][16]: surrogate, value loss, entropy, kl, dstd[12]
+    float* partials;             // [gridDim.x][32]: surrogate, value loss, entropy, kl, dstd[12], sum dmu[12], sum dval, pad
 };
 
 template <typename T>
 __global__ __launch_bounds__(256) void ppo_loss_kernel(const LossArgs a) {
-    __shared__ float red[4][16];
+    __shared__ float red[4][LOSS_PARTIALS];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int B = a.b.B, A = a.A;
     const float invB = 1.0f / (float)B;
-    float acc[16];
+    float acc[LOSS_PARTIALS];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) acc[k] = 0.0f;
+    for (int k = 0; k < LOSS_PARTIALS; ++k) acc[k] = 0.0f;
     T* dmu = (T*)a.dmu;
     T* dmuT = (T*)a.dmuT;
     T* dval = (T*)a.dval;
     T* dvalT = (T*)a.dvalT;
+    // fused layout: sample i lives in row block i>>4, row i&15 of a 2-block (32-column) tile; only block 0 is ever non-zero
+    char* fmu = (char*)a.dmu + ((int64_t)(i >> 4) * 2) * 512 + (i & 15) * 32;
+    char* fval = (char*)a.dval + ((int64_t)(i >> 4) * 2) * 512 + (i & 15) * 32;
     if (i < B) {
         const int64_t r = a.b.idx[i];
         const float adv = a.b.advantages[r], ret = a.b.returns[r], vold = a.b.values[r], lpold = a.b.logp[r];
         const float v = a.val[i];
         float lp = 0.0f, ent = 0.0f, kl = 0.0f;
         float diff[16], sg[16];
-        for (int j = 0; j < A; ++j) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            diff[j] = 0.0f;
+            sg[j] = 1.0f;
+            if (j >= A) continue;
             const float m = a.mu[(int64_t)i * A + j];
             const float s = m * 0.0f + a.std_[j];
             const float act = a.b.actions[r * A + j];
@@ -255,47 +304,82 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(const LossArgs a) {
         const float v_in = ((v - vold) >= -a.clip && (v - vold) <= a.clip) ? 1.0f : 0.0f;
         const float u1 = l1 > l2 ? 1.0f : (l1 == l2 ? 0.5f : 0.0f);
         const float d_v = a.value_coef * invB * (u1 * 2.0f * (v - ret) + (1.0f - u1) * 2.0f * (vc - ret) * v_in);
-        for (int j = 0; j < A; ++j) {
+        float gm[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            gm[j] = 0.0f;
+            if (j >= A) continue;
             const float s = sg[j], d = diff[j];
             const float g_mu = d_lp * d / (s * s);
             const float g_sg = d_lp * (d * d / (s * s * s) - 1.0f / s) - (a.entropy_coef * invB) / s;
-            dmu[(int64_t)i * a.ld_dmu + j] = from_f32<T>(g_mu);
-            dmuT[(int64_t)j * a.ld_t + i] = from_f32<T>(g_mu);
-            acc[4 + j < 16 ? 4 + j : 15] += (4 + j < 16) ? g_sg : 0.0f;
+            gm[j] = g_mu;
+            if (j < 12) {
+                acc[4 + j] = g_sg;
+                acc[16 + j] = g_mu;
+            }
+            if (!a.fused) {
+                dmu[(int64_t)i * a.ld_dmu + j] = from_f32<T>(g_mu);
+                dmuT[(int64_t)j * a.ld_t + i] = from_f32<T>(g_mu);
+            }
         }
-        dval[(int64_t)i * a.ld_dval] = from_f32<T>(d_v);
-        dvalT[i] = from_f32<T>(d_v);
+        if (a.fused) {
+            if constexpr (sizeof(T) == 2) {
+                u32x4 lo, hi;
+                const u32x2 p0 = pack_bf16x4(gm[0], gm[1], gm[2], gm[3]), p1 = pack_bf16x4(gm[4], gm[5], gm[6], gm[7]);
+                const u32x2 p2 = pack_bf16x4(gm[8], gm[9], gm[10], gm[11]), p3 = pack_bf16x4(gm[12], gm[13], gm[14], gm[15]);
+                lo = (u32x4){p0[0], p0[1], p1[0], p1[1]};
+                hi = (u32x4){p2[0], p2[1], p3[0], p3[1]};
+                reinterpret_cast<u32x4*>(fmu)[0] = lo;
+                reinterpret_cast<u32x4*>(fmu)[1] = hi;
+                const u32x2 pv = pack_bf16x4(d_v, 0.0f, 0.0f, 0.0f);
+                reinterpret_cast<u32x4*>(fval)[0] = (u32x4){pv[0], 0u, 0u, 0u};
+                reinterpret_cast<u32x4*>(fval)[1] = (u32x4){0u, 0u, 0u, 0u};
+            }
+        } else {
+            dval[(int64_t)i * a.ld_dval] = from_f32<T>(d_v);
+            dvalT[i] = from_f32<T>(d_v);
+        }
         acc[0] = surr;
         acc[1] = vl;
         acc[2] = ent;
         acc[3] = kl;
-    } else if (i < a.Bp) {   // zero the contraction padding of the transposed gradients
-        for (int j = 0; j < A; ++j) dmuT[(int64_t)j * a.ld_t + i] = from_f32<T>(0.0f);
-        dvalT[i] = from_f32<T>(0.0f);
+        acc[28] = d_v;
+    } else if (i < a.Bp) {   // zero the contraction padding of the gradients
+        if (a.fused) {
+            reinterpret_cast<u32x4*>(fmu)[0] = (u32x4){0u, 0u, 0u, 0u};
+            reinterpret_cast<u32x4*>(fmu)[1] = (u32x4){0u, 0u, 0u, 0u};
+            reinterpret_cast<u32x4*>(fval)[0] = (u32x4){0u, 0u, 0u, 0u};
+            reinterpret_cast<u32x4*>(fval)[1] = (u32x4){0u, 0u, 0u, 0u};
+        } else {
+            for (int j = 0; j < A; ++j) dmuT[(int64_t)j * a.ld_t + i] = from_f32<T>(0.0f);
+            dvalT[i] = from_f32<T>(0.0f);
+        }
     }
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
+    for (int k = 0; k < LOSS_PARTIALS; ++k) {
         float s = acc[k];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = s;
     }
     __syncthreads();
-    if (threadIdx.x < 16) a.partials[(int64_t)blockIdx.x * 16 + threadIdx.x] =
+    if (threadIdx.x < LOSS_PARTIALS) a.partials[(int64_t)blockIdx.x * LOSS_PARTIALS + threadIdx.x] =
         red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
 // opt_state: [0] lr [1] adam step [2] kl sum [3] surrogate sum [4] value-loss sum [5] entropy sum [6] grad norm
 //            [7] minibatches accumulated [8] last minibatch mean KL [9] grad sq-norm accumulator
-__global__ __launch_bounds__(256) void ppo_scalars_kernel(int nblocks, int B, int A, const float* __restrict__ partials,
-                                                          float* __restrict__ grads_std, double* __restrict__ opt) {
-    __shared__ double red[16][17];
-    const int k = threadIdx.x & 15, part = threadIdx.x >> 4;   // 16 partial sums per quantity
+// grads_bmu / grads_bv (fused path only): gradients of the two head biases = column sums of the head gradients.
+__global__ __launch_bounds__(512) void ppo_scalars_kernel(int nblocks, int B, int A, const float* __restrict__ partials,
+                                                          float* __restrict__ grads_std, float* __restrict__ grads_bmu,
+                                                          float* __restrict__ grads_bv, double* __restrict__ opt) {
+    __shared__ double red[16][LOSS_PARTIALS + 1];
+    const int k = threadIdx.x & (LOSS_PARTIALS - 1), part = threadIdx.x / LOSS_PARTIALS;   // 16 partial sums per quantity
     double s = 0.0;
-    for (int b = part; b < nblocks; b += 16) s += (double)partials[(int64_t)b * 16 + k];
+    for (int b = part; b < nblocks; b += 16) s += (double)partials[(int64_t)b * LOSS_PARTIALS + k];
     red[part][k] = s;
     __syncthreads();
-    if (threadIdx.x < 16) {
+    if (threadIdx.x < LOSS_PARTIALS) {
         double t = 0.0;
         for (int p = 0; p < 16; ++p) t += red[p][threadIdx.x];
         const int q = threadIdx.x;
@@ -307,7 +391,9 @@ __global__ __launch_bounds__(256) void ppo_scalars_kernel(int nblocks, int B, in
             opt[8] = t / B;
             opt[7] += 1.0;
         }
-        if (q >= 4 && q - 4 < A) grads_std[q - 4] = (float)t;
+        if (q >= 4 && q < 16 && q - 4 < A) grads_std[q - 4] = (float)t;
+        if (q >= 16 && q < 28 && q - 16 < A && grads_bmu) grads_bmu[q - 16] = (float)t;
+        if (q == 28 && grads_bv) grads_bv[0] = (float)t;
     }
 }
 
@@ -320,6 +406,9 @@ struct Segment {
     int64_t ldw;
     void* WTp;       // operand-precision transposed shadow [K16][ldwt] or null
     int64_t ldwt;
+    void* Wf;        // fused path: forward fragments [NB][KB][64][8] or null
+    void* WTf;       // fused path: backward fragments [K/16][NBB][64][8]
+    int KB, NBB;
 };
 struct SegTable {
     int n;
@@ -377,6 +466,19 @@ __global__ void apply_prologue_kernel(const HgymPPOConfig p, double* __restrict_
     opt[9] = 0.0;
 }
 
+// writes one master weight into every compute-precision operand copy of its layer
+template <typename T>
+__device__ __forceinline__ void write_shadows(const Segment& sg, int r, int c, float w) {
+    if (sg.Wp) {
+        ((T*)sg.Wp)[(int64_t)r * sg.ldw + c] = from_f32<T>(w);
+        if (sg.WTp) ((T*)sg.WTp)[(int64_t)c * sg.ldwt + r] = from_f32<T>(w);
+    }
+    if (sg.Wf) {   // r = n (output feature), c = k (input feature); see hgym_fused.hpp for the fragment order
+        ((T*)sg.Wf)[((((int64_t)(r >> 4) * sg.KB + (c >> 5)) * 64) + ((c & 31) >> 3) * 16 + (r & 15)) * 8 + (c & 7)] = from_f32<T>(w);
+        ((T*)sg.WTf)[((((int64_t)(c >> 4) * sg.NBB + (r >> 5)) * 64) + ((r & 31) >> 3) * 16 + (c & 15)) * 8 + (r & 7)] = from_f32<T>(w);
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void adam_kernel(const SegTable tab, const HgymPPOConfig p, float* __restrict__ params,
                                                    float* __restrict__ grads, float* __restrict__ m_, float* __restrict__ v_,
@@ -392,8 +494,6 @@ __global__ __launch_bounds__(256) void adam_kernel(const SegTable tab, const Hgy
     const double bc1 = 1.0 - pow((double)p.beta1, t), bc2 = 1.0 - pow((double)p.beta2, t);
     const float step_size = (float)(opt[0] / bc1);
     const float sqrt_bc2 = (float)sqrt(bc2);
-    T* Wp = (T*)sg.Wp;
-    T* WTp = (T*)sg.WTp;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t q = sg.off + i;
         const float g = grads[q] * coef;
@@ -405,10 +505,9 @@ __global__ __launch_bounds__(256) void adam_kernel(const SegTable tab, const Hgy
         const float denom = sqrtf(v) / sqrt_bc2 + p.adam_eps;
         const float w = params[q] + (-step_size * m) / denom;
         params[q] = w;
-        if (Wp) {
+        if (sg.Wp || sg.Wf) {
             const int r = (int)(i / sg.cols), c = (int)(i - (int64_t)r * sg.cols);
-            Wp[(int64_t)r * sg.ldw + c] = from_f32<T>(w);
-            if (WTp) WTp[(int64_t)c * sg.ldwt + r] = from_f32<T>(w);
+            write_shadows<T>(sg, r, c, w);
         }
     }
 }
@@ -416,15 +515,11 @@ __global__ __launch_bounds__(256) void adam_kernel(const SegTable tab, const Hgy
 template <typename T>
 __global__ __launch_bounds__(256) void sync_shadow_kernel(const SegTable tab, const float* __restrict__ params) {
     const Segment& sg = tab.s[blockIdx.y];
-    if (!sg.Wp) return;
-    T* Wp = (T*)sg.Wp;
-    T* WTp = (T*)sg.WTp;
+    if (!sg.Wp && !sg.Wf) return;
     const int64_t n = (int64_t)sg.rows * sg.cols;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const int r = (int)(i / sg.cols), c = (int)(i - (int64_t)r * sg.cols);
-        const float w = params[sg.off + i];
-        Wp[(int64_t)r * sg.ldw + c] = from_f32<T>(w);
-        if (WTp) WTp[(int64_t)c * sg.ldwt + r] = from_f32<T>(w);
+        write_shadows<T>(sg, r, c, params[sg.off + i]);
     }
 }
 
@@ -496,15 +591,24 @@ struct NetRunner {
                 a.off = y.w_off;
                 a.rows = y.N;
                 a.cols = y.K;
-                a.splits = with_slabs ? split_count(y) : 0;
-                a.Wp = ws + y.Wp;
-                a.ldw = y.Kp;
-                a.WTp = ws + y.WTp;
-                a.ldwt = y.Ncp;
+                if (w.fused) {
+                    a.splits = with_slabs ? w.dw_splits : 0;
+                    a.Wf = ws + y.Wf;
+                    a.WTf = ws + y.WTf;
+                    a.KB = y.KBf;
+                    a.NBB = y.NBBf;
+                } else {
+                    a.splits = with_slabs ? split_count(y) : 0;
+                    a.Wp = ws + y.Wp;
+                    a.ldw = y.Kp;
+                    a.WTp = ws + y.WTp;
+                    a.ldwt = y.Ncp;
+                }
                 Segment& b = t.s[t.n++];
                 b.off = y.b_off;
                 b.rows = y.N;
                 b.cols = 1;
+                if (w.fused && with_slabs && l < w.net[which].L - 1) b.splits = w.dw_splits;   // hidden-layer bias grads come from the slabs
             }
         return t;
     }
@@ -522,7 +626,221 @@ struct NetRunner {
         return ceil_div(stages, per);
     }
 
+    // ------------------------------------------------------------------ fused bf16 path (hgym_fused.hpp)
+    struct SampleOut {
+        const float* z; uint64_t seed; const int64_t* step; float* actions; float* sigma; float* logp;
+    };
+
+    FusedNet fused_net(int which, const float* x, int64_t ldx, float* out, int64_t ldo) const {
+        FusedNet f;
+        memset(&f, 0, sizeof(f));
+        const NetLayout& n = w.net[which];
+        for (int l = 0; l < 4; ++l) {
+            const LayerLayout& y = n.layer[l];
+            FusedLayer& d = f.layer[l];
+            d.Wf = at<u32x4>(y.Wf);
+            d.WTf = at<u32x4>(y.WTf);
+            d.bias = net.params + y.b_off;
+            d.K = y.K;
+            d.N = y.N;
+            d.KB = y.KBf;
+            d.NB = y.NBf;
+            d.NBB = y.NBBf;
+        }
+        f.x = x;
+        f.ldx = ldx;
+        f.X0 = at<__bf16>(n.X0b);
+        for (int l = 0; l < 3; ++l) f.H[l] = at<__bf16>(n.Hb[l]);
+        for (int l = 0; l < 4; ++l) f.dZ[l] = at<__bf16>(n.dZb[l]);
+        f.out = out;
+        f.ldo = ldo;
+        return f;
+    }
+
+    template <int BM>
+    int32_t launch_fwd(const FwdArgs& a, int nets) {
+        size_t lds = 0;
+        for (int i = 0; i < nets; ++i) {
+            const FusedNet& n = a.net[a.net0 + i];
+            lds = std::max(lds, (size_t)fused_lds_p(n, BM) + (size_t)fused_lds_q(n, BM));
+        }
+        static size_t attr_lds = 0;
+        if (lds > attr_lds) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fwd_kernel<BM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+                hipSuccess)
+                HG_FAIL(HGYM_E_LAUNCH, "cannot reserve %zu bytes of LDS for mlp_fwd_kernel", lds);
+            attr_lds = lds;
+        }
+        hipLaunchKernelGGL((mlp_fwd_kernel<BM>), dim3(ceil_div(a.M, BM), nets), dim3(FUSED_THREADS), lds, s, a);
+        HG_CHECK_LAUNCH("mlp_fwd_kernel");
+        return HGYM_OK;
+    }
+
+    // forward of `nets` networks starting at `first` in ONE launch; xs/outs indexed by net id
+    int32_t fused_forward(int first, int nets, int M, const float* const xs[2], const int64_t ldxs[2], const int64_t* idx, float* const outs[2],
+                          const int64_t ldos[2], bool train, const SampleOut* smp) {
+        HG_REQUIRE(M > 0 && M <= w.maxM, HGYM_E_SHAPE, "batch %d exceeds max_batch %lld", M, (long long)w.maxM);
+        FwdArgs a;
+        memset(&a, 0, sizeof(a));
+        for (int i = first; i < first + nets; ++i) a.net[i] = fused_net(i, xs[i], ldxs[i], outs[i], ldos[i]);
+        a.net0 = first;
+        a.M = M;
+        a.idx = idx;
+        a.train = train ? 1 : 0;
+        a.A = cfg.num_actions;
+        a.std_ = net.params;
+        if (smp) {
+            a.sample = 1;
+            a.z = smp->z;
+            a.k0 = (uint32_t)smp->seed;
+            a.k1 = (uint32_t)(smp->seed >> 32);
+            a.step = smp->step;
+            a.actions = smp->actions;
+            a.sigma = smp->sigma;
+            a.logp = smp->logp;
+        }
+        prof_begin(HGYM_PROF_GEMM, s);
+        const int32_t rc = (train || M >= 16384) ? launch_fwd<64>(a, nets) : launch_fwd<32>(a, nets);
+        double fl = 0.0;
+        for (int i = first; i < first + nets; ++i)
+            for (int l = 0; l < 4; ++l) fl += 2.0 * (double)M * w.net[i].layer[l].N * (w.net[i].layer[l].KBf * 32.0);
+        prof_end(HGYM_PROF_GEMM, s, fl);
+        return rc;
+    }
+
+    int32_t fused_grad(const HgymPPOConfig& ppo, const HgymBatch& b) {
+        const int B = b.B, A = cfg.num_actions;
+        float* mu = at<float>(w.net[0].out_f32);
+        float* val = at<float>(w.net[1].out_f32);
+        const float* xs[2] = {b.obs, b.priv};
+        const int64_t ldxs[2] = {cfg.num_obs, cfg.num_priv};
+        float* outs[2] = {mu, val};
+        const int64_t ldos[2] = {A, 1};
+        int32_t rc = fused_forward(0, 2, B, xs, ldxs, b.idx, outs, ldos, true, nullptr);
+        if (rc) return rc;
+        const int Bp = (int)round_up(B, 64);
+        const int nblocks = ceil_div(Bp, 256);
+        HG_REQUIRE(nblocks <= MAX_LOSS_BLOCKS, HGYM_E_UNSUPPORTED, "minibatch %d too large for the loss partial buffer", B);
+        LossArgs a;
+        memset(&a, 0, sizeof(a));
+        a.b = b;
+        a.A = A;
+        a.mu = mu;
+        a.val = val;
+        a.std_ = net.params;
+        a.clip = ppo.clip_param;
+        a.value_coef = ppo.value_loss_coef;
+        a.entropy_coef = ppo.entropy_coef;
+        a.fused = 1;
+        a.dmu = at<T>(w.net[0].dZb[3]);
+        a.dval = at<T>(w.net[1].dZb[3]);
+        a.Bp = Bp;
+        a.partials = at<float>(w.partials);
+        prof_begin(HGYM_PROF_LOSS, s);
+        hipLaunchKernelGGL((ppo_loss_kernel<T>), dim3(nblocks), dim3(256), 0, s, a);
+        prof_end(HGYM_PROF_LOSS, s, (double)B * (4.0 * (5 * A + 6) + 2.0 * 64));
+        HG_CHECK_LAUNCH("ppo_loss_kernel");
+        hipLaunchKernelGGL(ppo_scalars_kernel, dim3(1), dim3(512), 0, s, nblocks, B, A, at<float>(w.partials), net.grads,
+                           net.grads + w.net[0].layer[3].b_off, net.grads + w.net[1].layer[3].b_off, net.opt_state);
+        HG_CHECK_LAUNCH("ppo_scalars_kernel");
+        {   // dZ chain of both nets
+            BwdArgs g;
+            memset(&g, 0, sizeof(g));
+            size_t lds = 0;
+            for (int i = 0; i < 2; ++i) {
+                g.net[i] = fused_net(i, nullptr, 0, nullptr, 0);
+                lds = std::max(lds, (size_t)64 * 64 + (size_t)64 * 2 * (w.net[i].layer[2].N + w.net[i].layer[1].N));
+            }
+            g.M = B;
+            static size_t attr_lds = 0;
+            if (lds > attr_lds) {
+                if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_bwd_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)lds) != hipSuccess)
+                    HG_FAIL(HGYM_E_LAUNCH, "cannot reserve %zu bytes of LDS for mlp_bwd_kernel", lds);
+                attr_lds = lds;
+            }
+            prof_begin(HGYM_PROF_GEMM, s);
+            hipLaunchKernelGGL((mlp_bwd_kernel<64>), dim3(Bp / 64, 2), dim3(FUSED_THREADS), lds, s, g);
+            double fl = 0.0;
+            for (int i = 0; i < 2; ++i)
+                for (int l = 1; l < 4; ++l) fl += 2.0 * (double)B * w.net[i].layer[l].K * (w.net[i].layer[l].NBBf * 32.0);
+            prof_end(HGYM_PROF_GEMM, s, fl);
+            HG_CHECK_LAUNCH("mlp_bwd_kernel");
+        }
+        {   // all weight (and hidden bias) gradients: one launch, split-K slabs
+            DwArgs d;
+            memset(&d, 0, sizeof(d));
+            int tile = 0;
+            double fl = 0.0;
+            for (int i = 0; i < 2; ++i)
+                for (int l = 0; l < 4; ++l) {
+                    const NetLayout& n = w.net[i];
+                    const LayerLayout& y = n.layer[l];
+                    DwProduct& p = d.p[d.np++];
+                    p.Z = at<__bf16>(n.dZb[l]);
+                    p.CBz = l < 3 ? y.N / 16 : 2;
+                    p.X = l == 0 ? at<__bf16>(n.X0b) : at<__bf16>(n.Hb[l - 1]);
+                    p.CBx = l == 0 ? 2 * y.KBf : y.K / 16;
+                    p.N = y.N;
+                    p.K = y.K;
+                    p.w_off = y.w_off;
+                    p.b_off = l < 3 ? y.b_off : -1;
+                    p.tiles_n = ceil_div(y.N, 128);
+                    p.tiles_k = ceil_div(y.K, 128);
+                    p.tile0 = tile;
+                    tile += p.tiles_n * p.tiles_k;
+                    fl += 2.0 * (double)Bp * p.tiles_n * 128.0 * p.tiles_k * 128.0;
+                }
+            d.steps_total = Bp / 32;
+            d.steps_per_split = ceil_div(d.steps_total, w.dw_splits);
+            d.slabs = at<float>(w.slabs);
+            d.slab_stride = w.Ps;
+            static bool attr_done = false;
+            if (!attr_done) {
+                if (hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        DW_STAGES * DW_STAGE_BYTES) != hipSuccess)
+                    HG_FAIL(HGYM_E_LAUNCH, "cannot reserve LDS for dw_kernel");
+                attr_done = true;
+            }
+            prof_begin(HGYM_PROF_GEMM, s);
+            hipLaunchKernelGGL(dw_kernel, dim3(tile, w.dw_splits), dim3(DW_THREADS), DW_STAGES * DW_STAGE_BYTES, s, d);
+            prof_end(HGYM_PROF_GEMM, s, fl);
+            HG_CHECK_LAUNCH("dw_kernel");
+        }
+        const SegTable tab = segments(true);
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(96, tab.n), dim3(256), 0, s, tab, w.Ps, at<float>(w.slabs), net.grads);
+        HG_CHECK_LAUNCH("reduce_slabs_kernel");
+        return HGYM_OK;
+    }
+
+    int32_t act(int M, const float* obs, const float* priv, const float* z, uint64_t seed, const int64_t* step, float* actions, float* mu,
+                float* sigma, float* logp, float* values) {
+        if (w.fused) {
+            const float* xs[2] = {obs, priv};
+            const int64_t ldxs[2] = {cfg.num_obs, cfg.num_priv};
+            float* outs[2] = {mu, values};
+            const int64_t ldos[2] = {cfg.num_actions, 1};
+            const SampleOut smp = {z, seed, step, actions, sigma, logp};
+            return fused_forward(0, 2, M, xs, ldxs, nullptr, outs, ldos, false, &smp);
+        }
+        int32_t rc = forward(0, M, obs, cfg.num_obs, nullptr, mu, cfg.num_actions, false);
+        if (rc) return rc;
+        rc = forward(1, M, priv, cfg.num_priv, nullptr, values, 1, false);
+        if (rc) return rc;
+        hipLaunchKernelGGL(act_sample_kernel, dim3(ceil_div(M, 256)), dim3(256), 0, s, M, cfg.num_actions, mu, net.params, z, seed, step,
+                           actions, sigma, logp);
+        HG_CHECK_LAUNCH("act_sample_kernel");
+        return HGYM_OK;
+    }
+
     int32_t forward(int which, int M, const float* x, int64_t ldx, const int64_t* idx, float* y_out, int64_t ld_out, bool train) {
+        if (w.fused) {
+            const float* xs[2] = {x, x};
+            const int64_t ldxs[2] = {ldx, ldx};
+            float* outs[2] = {y_out, y_out};
+            const int64_t ldos[2] = {ld_out, ld_out};
+            return fused_forward(which, 1, M, xs, ldxs, idx, outs, ldos, train, nullptr);
+        }
         const NetLayout& n = w.net[which];
         HG_REQUIRE(M > 0 && M <= w.maxM, HGYM_E_SHAPE, "batch %d exceeds max_batch %lld", M, (long long)w.maxM);
         const LayerLayout& l0 = n.layer[0];
@@ -625,6 +943,7 @@ struct NetRunner {
     int32_t grad(const HgymPPOConfig& ppo, const HgymBatch& b) {
         const int B = b.B, A = cfg.num_actions;
         HG_REQUIRE(B > 0 && B <= w.maxM, HGYM_E_SHAPE, "minibatch %d exceeds max_batch %lld", B, (long long)w.maxM);
+        if (w.fused) return fused_grad(ppo, b);
         float* mu = at<float>(w.net[0].out_f32);
         float* val = at<float>(w.net[1].out_f32);
         if (hipMemsetAsync(net.grads, 0, (size_t)w.P * sizeof(float), s) != hipSuccess) HG_FAIL(HGYM_E_LAUNCH, "memset of grads failed");
@@ -660,7 +979,8 @@ struct NetRunner {
         hipLaunchKernelGGL((ppo_loss_kernel<T>), dim3(nblocks), dim3(256), 0, s, a);
         prof_end(HGYM_PROF_LOSS, s, (double)B * (4.0 * (5 * A + 6) + (double)sizeof(T) * (2 * A + 2)));
         HG_CHECK_LAUNCH("ppo_loss_kernel");
-        hipLaunchKernelGGL(ppo_scalars_kernel, dim3(1), dim3(256), 0, s, nblocks, B, A, at<float>(w.partials), net.grads, net.opt_state);
+        hipLaunchKernelGGL(ppo_scalars_kernel, dim3(1), dim3(512), 0, s, nblocks, B, A, at<float>(w.partials), net.grads, (float*)nullptr,
+                           (float*)nullptr, net.opt_state);
         HG_CHECK_LAUNCH("ppo_scalars_kernel");
         cur_Mp = Bp;
         rc = backward(0, B);
@@ -754,14 +1074,7 @@ int32_t hgym_policy_act(const HgymNetConfig* cfg, const HgymNet* net, int32_t M,
     int32_t rc = check_net(cfg, net, &w);
     if (rc) return rc;
     HG_REQUIRE(obs && priv && actions && mu && sigma && logp && values, HGYM_E_BADARG, "null pointer");
-    rc = hgym_mlp_forward(cfg, net, 0, M, obs, cfg->num_obs, mu, stream);
-    if (rc) return rc;
-    rc = hgym_mlp_forward(cfg, net, 1, M, priv, cfg->num_priv, values, stream);
-    if (rc) return rc;
-    hipLaunchKernelGGL(act_sample_kernel, dim3(ceil_div(M, 256)), dim3(256), 0, (hipStream_t)stream, M, cfg->num_actions, mu, net->params, z,
-                       seed, step_counter, actions, sigma, logp);
-    HG_CHECK_LAUNCH("act_sample_kernel");
-    return HGYM_OK;
+    HG_DISPATCH(cfg, net, w, stream, act(M, obs, priv, z, seed, step_counter, actions, mu, sigma, logp, values));
 }
 
 int32_t hgym_ppo_grad(const HgymNetConfig* cfg, const HgymPPOConfig* ppo, const HgymNet* net, const HgymBatch* batch, void* stream) {
