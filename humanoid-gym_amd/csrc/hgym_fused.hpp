@@ -23,10 +23,10 @@
 
 namespace hgym {
 
-constexpr int FUSED_THREADS = 512;
-constexpr int FUSED_WAVES = 8;
 constexpr int FUSED_CHUNK = 128;      // input columns staged per first-layer chunk (4 k-blocks of 32)
-constexpr int FUSED_MAX_G = 6;        // n-blocks per wave in the first layer: N1 <= 8 * 6 * 16 = 768
+// Workgroup shapes: the update uses 64-row tiles with 16 wavefronts (4 per SIMD: the weight stream comes from L2 with
+// ~1 us latency under load and only thread-level parallelism hides it); the rollout uses 32-row tiles with 8 wavefronts,
+// two workgroups per CU.
 
 struct __attribute__((packed, aligned(4))) F4 {
     float v[4];
@@ -70,42 +70,41 @@ __device__ __forceinline__ float bf16_bits_to_f32(unsigned int lo16) { return __
 
 // acc[i][g] += W(nb0+g, kb0+t) x X(i, t) for t < nk.  w0 -> fragment (nb0, kb0); wstride = fragments between n-blocks (x64).
 // xl -> LDS block layout of the input with CBx column blocks per row block, starting at k-block 0 of this call.
+// Both operand streams are software-pipelined one k-block ahead (the loads of step t+1 are in flight under the MFMAs of t).
 template <int G, int MB>
 __device__ __forceinline__ void mma_steps(const u32x4* __restrict__ w0, int wstride, int nk, const char* xl, int CBx, int lane,
                                           f32x4 (&acc)[MB][G]) {
     const int r = lane & 15, q = lane >> 4;
     const char* xb = xl + (q >> 1) * 512 + r * 32 + (q & 1) * 16;
     const u32x4* wl = w0 + lane;
-    u32x4 wa[G], wb[G];
+    u32x4 wa[G], wb[G], xa[MB], xc[MB];
 #pragma unroll
     for (int g = 0; g < G; ++g) wa[g] = wl[(int64_t)g * wstride];
+#pragma unroll
+    for (int i = 0; i < MB; ++i) xa[i] = *reinterpret_cast<const u32x4*>(xb + (i * CBx) * 512);
     for (int t = 0; t < nk; t += 2) {
         const bool two = t + 1 < nk;
         if (two) {
 #pragma unroll
             for (int g = 0; g < G; ++g) wb[g] = wl[(int64_t)g * wstride + (t + 1) * 64];
+#pragma unroll
+            for (int i = 0; i < MB; ++i) xc[i] = *reinterpret_cast<const u32x4*>(xb + (i * CBx + 2 * (t + 1)) * 512);
         }
-        {
-            u32x4 x[MB];
 #pragma unroll
-            for (int i = 0; i < MB; ++i) x[i] = *reinterpret_cast<const u32x4*>(xb + (i * CBx + 2 * t) * 512);
+        for (int i = 0; i < MB; ++i)
 #pragma unroll
-            for (int i = 0; i < MB; ++i)
-#pragma unroll
-                for (int g = 0; g < G; ++g) mma_frag<__bf16>(wa[g], x[i], acc[i][g]);
-        }
+            for (int g = 0; g < G; ++g) mma_frag<__bf16>(wa[g], xa[i], acc[i][g]);
         if (t + 2 < nk) {
 #pragma unroll
             for (int g = 0; g < G; ++g) wa[g] = wl[(int64_t)g * wstride + (t + 2) * 64];
+#pragma unroll
+            for (int i = 0; i < MB; ++i) xa[i] = *reinterpret_cast<const u32x4*>(xb + (i * CBx + 2 * (t + 2)) * 512);
         }
         if (two) {
-            u32x4 x[MB];
-#pragma unroll
-            for (int i = 0; i < MB; ++i) x[i] = *reinterpret_cast<const u32x4*>(xb + (i * CBx + 2 * (t + 1)) * 512);
 #pragma unroll
             for (int i = 0; i < MB; ++i)
 #pragma unroll
-                for (int g = 0; g < G; ++g) mma_frag<__bf16>(wb[g], x[i], acc[i][g]);
+                for (int g = 0; g < G; ++g) mma_frag<__bf16>(wb[g], xc[i], acc[i][g]);
         }
     }
 }
@@ -140,10 +139,10 @@ __device__ __forceinline__ void zero_acc(f32x4 (&acc)[MB][G]) {
 }
 
 // one hidden layer whose whole input is resident in LDS: waves split the n-blocks, G per pass
-template <int G, int MB>
+template <int G, int MB, int NW>
 __device__ __forceinline__ void hidden_layer(const FusedLayer& L, const char* in_lds, int CBin, char* out_lds, __bf16* Hg, int64_t mbg0,
                                              int wave, int lane) {
-    for (int nb0 = wave * G; nb0 < L.NB; nb0 += FUSED_WAVES * G) {
+    for (int nb0 = wave * G; nb0 < L.NB; nb0 += NW * G) {
         f32x4 acc[MB][G];
         zero_acc<G, MB>(acc);
         mma_steps<G, MB>(L.Wf + (int64_t)nb0 * L.KB * 64, L.KB * 64, L.KB, in_lds, CBin, lane, acc);
@@ -168,10 +167,11 @@ struct FwdArgs {
     float* logp;              // (M,)
 };
 
-template <int BM, int G1>
+template <int BM, int NW, int G1>
 __device__ __forceinline__ void fwd_body(const FwdArgs& a, const FusedNet& n, bool is_actor, char* smem) {
     constexpr int MB = BM / 16;
-    constexpr int IT = BM / 16;                       // staging items per thread per chunk (BM rows x 32 float4 / 512)
+    constexpr int IT = BM * 32 / (NW * 64);           // staging items per thread per chunk (BM rows x 32 float4)
+    constexpr int RPP = NW * 2;                       // rows covered per staging pass (32 lanes per row)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
     const int m0 = blockIdx.x * BM;
@@ -193,7 +193,7 @@ __device__ __forceinline__ void fwd_body(const FwdArgs& a, const FusedNet& n, bo
         int lrow[IT];
 #pragma unroll
         for (int u = 0; u < IT; ++u) {
-            const int row = u * 16 + (tid >> 5);
+            const int row = u * RPP + (tid >> 5);
             int m = m0 + row;
             m = m < a.M ? m : a.M - 1;
             const int64_t src = a.idx ? a.idx[m] : (int64_t)m;
@@ -241,11 +241,11 @@ __device__ __forceinline__ void fwd_body(const FwdArgs& a, const FusedNet& n, bo
     }
     __syncthreads();
     // ---------------------------------------------------------------- layers 1, 2: input resident in LDS
-    if (L1.NB >= 16) hidden_layer<2, MB>(L1, P, L0.NB, Q, train ? n.H[1] : nullptr, mbg0, wave, lane);
-    else hidden_layer<1, MB>(L1, P, L0.NB, Q, train ? n.H[1] : nullptr, mbg0, wave, lane);
+    if (L1.NB >= 2 * NW) hidden_layer<2, MB, NW>(L1, P, L0.NB, Q, train ? n.H[1] : nullptr, mbg0, wave, lane);
+    else hidden_layer<1, MB, NW>(L1, P, L0.NB, Q, train ? n.H[1] : nullptr, mbg0, wave, lane);
     __syncthreads();
-    if (L2.NB >= 16) hidden_layer<2, MB>(L2, Q, L1.NB, P, train ? n.H[2] : nullptr, mbg0, wave, lane);
-    else hidden_layer<1, MB>(L2, Q, L1.NB, P, train ? n.H[2] : nullptr, mbg0, wave, lane);
+    if (L2.NB >= 2 * NW) hidden_layer<2, MB, NW>(L2, Q, L1.NB, P, train ? n.H[2] : nullptr, mbg0, wave, lane);
+    else hidden_layer<1, MB, NW>(L2, Q, L1.NB, P, train ? n.H[2] : nullptr, mbg0, wave, lane);
     __syncthreads();
     // ---------------------------------------------------------------- head: one wave per 16-row block
     if (wave < MB) {
@@ -302,15 +302,16 @@ __device__ __forceinline__ void fwd_body(const FwdArgs& a, const FusedNet& n, bo
     }
 }
 
-template <int BM>
-__global__ __launch_bounds__(FUSED_THREADS) void mlp_fwd_kernel(const FwdArgs a) {
+template <int BM, int NW>
+__global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(const FwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int which = a.net0 + blockIdx.y;
     const FusedNet& n = a.net[which];
-    const int g1 = n.layer[0].NB / FUSED_WAVES;
-    if (g1 == 4) fwd_body<BM, 4>(a, n, which == 0, smem);
-    else if (g1 == 6) fwd_body<BM, 6>(a, n, which == 0, smem);
-    else if (g1 == 2) fwd_body<BM, 2>(a, n, which == 0, smem);
+    const int g1 = n.layer[0].NB / NW;     // first hidden width 256 / 512 / 768
+    constexpr int U = 16 / NW;             // n-blocks per wave per 256 columns
+    if (g1 == 2 * U) fwd_body<BM, NW, 2 * U>(a, n, which == 0, smem);
+    else if (g1 == 3 * U) fwd_body<BM, NW, 3 * U>(a, n, which == 0, smem);
+    else if (g1 == U) fwd_body<BM, NW, U>(a, n, which == 0, smem);
 }
 
 // ================================================================================================ backward (dX chain)
@@ -321,21 +322,21 @@ struct BwdArgs {
 };
 
 // dZ_out[m][k'] = (sum_n dZ_in[m][n] * W[n][k']) * elu'(H[m][k']): W^T fragments as the MFMA A operand.
-template <int G, int MB>
+template <int G, int MB, int NW>
 __device__ __forceinline__ void bwd_step(const u32x4* __restrict__ WTf, int NBo, int NBBc, const char* in_lds, int CBin, char* out_lds,
                                          __bf16* __restrict__ dZg, const __bf16* __restrict__ Hg, int64_t mbg0, int wave, int lane) {
     const int r = lane & 15, q = lane >> 4;
     const int loff = r * 32 + q * 8;
-    for (int nb0 = wave * G; nb0 < NBo; nb0 += FUSED_WAVES * G) {
-        u32x2 aux[MB][G];
+    for (int nb0 = wave * G; nb0 < NBo; nb0 += NW * G) {
+        f32x4 acc[MB][G];
+        zero_acc<G, MB>(acc);
+        mma_steps<G, MB>(WTf + (int64_t)nb0 * NBBc * 64, NBBc * 64, NBBc, in_lds, CBin, lane, acc);
+        u32x2 aux[MB][G];     // y = elu(z) of this tile (every load is issued before the first store below)
 #pragma unroll
         for (int i = 0; i < MB; ++i)
 #pragma unroll
             for (int g = 0; g < G; ++g)
                 aux[i][g] = *reinterpret_cast<const u32x2*>(reinterpret_cast<const char*>(Hg) + ((mbg0 + i) * NBo + nb0 + g) * 512 + loff);
-        f32x4 acc[MB][G];
-        zero_acc<G, MB>(acc);
-        mma_steps<G, MB>(WTf + (int64_t)nb0 * NBBc * 64, NBBc * 64, NBBc, in_lds, CBin, lane, acc);
 #pragma unroll
         for (int i = 0; i < MB; ++i)
 #pragma unroll
@@ -353,14 +354,8 @@ __device__ __forceinline__ void bwd_step(const u32x4* __restrict__ WTf, int NBo,
     }
 }
 
-template <int G, int MB>
-__device__ __forceinline__ void bwd_step_pick(int NBo, const u32x4* WTf, int NBBc, const char* in_lds, int CBin, char* out_lds, __bf16* dZg,
-                                              const __bf16* Hg, int64_t mbg0, int wave, int lane) {
-    bwd_step<G, MB>(WTf, NBo, NBBc, in_lds, CBin, out_lds, dZg, Hg, mbg0, wave, lane);
-}
-
-template <int BM>
-__global__ __launch_bounds__(FUSED_THREADS) void mlp_bwd_kernel(const BwdArgs a) {
+template <int BM, int NW>
+__global__ __launch_bounds__(NW * 64) void mlp_bwd_kernel(const BwdArgs a) {
     constexpr int MB = BM / 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const FusedNet& n = a.net[a.net0 + blockIdx.y];
@@ -377,16 +372,17 @@ __global__ __launch_bounds__(FUSED_THREADS) void mlp_bwd_kernel(const BwdArgs a)
     }
     __syncthreads();
     // l = 2: through W3 (head)
-    bwd_step<1, MB>(n.layer[3].WTf, N2 / 16, n.layer[3].NBB, R0, 2, R1, n.dZ[2], n.H[2], mbg0, wave, lane);
+    bwd_step<1, MB, NW>(n.layer[3].WTf, N2 / 16, n.layer[3].NBB, R0, 2, R1, n.dZ[2], n.H[2], mbg0, wave, lane);
     __syncthreads();
     // l = 1: through W2
-    if (N1 / 16 >= 16) bwd_step<2, MB>(n.layer[2].WTf, N1 / 16, n.layer[2].NBB, R1, N2 / 16, R2, n.dZ[1], n.H[1], mbg0, wave, lane);
-    else bwd_step<1, MB>(n.layer[2].WTf, N1 / 16, n.layer[2].NBB, R1, N2 / 16, R2, n.dZ[1], n.H[1], mbg0, wave, lane);
+    if (N1 / 16 >= 2 * NW) bwd_step<2, MB, NW>(n.layer[2].WTf, N1 / 16, n.layer[2].NBB, R1, N2 / 16, R2, n.dZ[1], n.H[1], mbg0, wave, lane);
+    else bwd_step<1, MB, NW>(n.layer[2].WTf, N1 / 16, n.layer[2].NBB, R1, N2 / 16, R2, n.dZ[1], n.H[1], mbg0, wave, lane);
     __syncthreads();
-    // l = 0: through W1 (widest)
-    if ((N0 / 16) % 24 == 0) bwd_step<3, MB>(n.layer[1].WTf, N0 / 16, n.layer[1].NBB, R2, N1 / 16, nullptr, n.dZ[0], n.H[0], mbg0, wave, lane);
-    else if ((N0 / 16) % 16 == 0) bwd_step<2, MB>(n.layer[1].WTf, N0 / 16, n.layer[1].NBB, R2, N1 / 16, nullptr, n.dZ[0], n.H[0], mbg0, wave, lane);
-    else bwd_step<1, MB>(n.layer[1].WTf, N0 / 16, n.layer[1].NBB, R2, N1 / 16, nullptr, n.dZ[0], n.H[0], mbg0, wave, lane);
+    // l = 0: through W1 (widest: 256 / 512 / 768 columns)
+    const int g0 = N0 / 16 / NW;
+    if (g0 == 3) bwd_step<3, MB, NW>(n.layer[1].WTf, N0 / 16, n.layer[1].NBB, R2, N1 / 16, nullptr, n.dZ[0], n.H[0], mbg0, wave, lane);
+    else if (g0 == 2) bwd_step<2, MB, NW>(n.layer[1].WTf, N0 / 16, n.layer[1].NBB, R2, N1 / 16, nullptr, n.dZ[0], n.H[0], mbg0, wave, lane);
+    else bwd_step<1, MB, NW>(n.layer[1].WTf, N0 / 16, n.layer[1].NBB, R2, N1 / 16, nullptr, n.dZ[0], n.H[0], mbg0, wave, lane);
 }
 
 // ================================================================================================ weight gradients
@@ -409,6 +405,8 @@ struct DwProduct {
 struct DwArgs {
     DwProduct p[DW_MAX_PRODUCTS];
     int np;
+    int total_tiles;
+    int splits;
     int steps_total;       // row blocks of 32 over the (padded) batch
     int steps_per_split;
     float* slabs;
@@ -428,16 +426,24 @@ __global__ __launch_bounds__(DW_THREADS) void dw_kernel(const DwArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wi = wave >> 1, wj = wave & 1;
     const int r = lane & 15, q = lane >> 4;
-    // which product / tile
+    // Block -> (tile, split).  Workgroups are dealt round-robin to the 8 XCDs (block b -> XCD b % 8), each with a private
+    // 4 MiB L2.  All tiles of one split stream the SAME batch rows, so a split is pinned to one XCD: its ~62 tiles run there
+    // concurrently, in near lock-step, and every operand block is fetched from HBM once and re-read from that L2 by the other
+    // tiles.  (Placement is a speed matter only; nothing depends on it for correctness.)
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, slot = bid >> 3;
+    const int split = xcd + 8 * (slot / a.total_tiles);
+    const int tile = slot % a.total_tiles;
+    if (split >= a.splits) return;
     int pi = 0;
 #pragma unroll
     for (int i = 1; i < DW_MAX_PRODUCTS; ++i)
-        if (i < a.np && (int)blockIdx.x >= a.p[i].tile0) pi = i;
+        if (i < a.np && tile >= a.p[i].tile0) pi = i;
     const DwProduct& P = a.p[pi];
-    const int tl = blockIdx.x - P.tile0;
+    const int tl = tile - P.tile0;
     const int tn = tl / P.tiles_k, tk = tl - tn * P.tiles_k;
     const int cbz0 = tn * 8, cbx0 = tk * 8;
-    const int step0 = blockIdx.y * a.steps_per_split;
+    const int step0 = split * a.steps_per_split;
     int nsteps = a.steps_total - step0;
     nsteps = nsteps < a.steps_per_split ? nsteps : a.steps_per_split;
 
@@ -500,7 +506,7 @@ __global__ __launch_bounds__(DW_THREADS) void dw_kernel(const DwArgs a) {
     }
 
     // lane holds dW[n = .. + r][k = .. + 4q + e]
-    float* __restrict__ slab = a.slabs + (int64_t)blockIdx.y * a.slab_stride;
+    float* __restrict__ slab = a.slabs + (int64_t)split * a.slab_stride;
     float* __restrict__ out = slab + P.w_off;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {

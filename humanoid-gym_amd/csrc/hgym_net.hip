@@ -140,7 +140,7 @@ static int32_t ws_layout(const HgymNetConfig* c, WsLayout* w) {
     w->P = poff;
     w->Ps = round_up(poff, 64);
     w->splits = MAX_SPLITS;
-    w->dw_splits = 16;
+    w->dw_splits = getenv("HGYM_DW_SPLITS") ? atoi(getenv("HGYM_DW_SPLITS")) : 8;
     w->slabs = take((int64_t)w->splits * w->Ps * 4);
     w->partials = take((int64_t)MAX_LOSS_BLOCKS * LOSS_PARTIALS * 4);
     w->total_bytes = off;
@@ -657,7 +657,7 @@ struct NetRunner {
         return f;
     }
 
-    template <int BM>
+    template <int BM, int NW>
     int32_t launch_fwd(const FwdArgs& a, int nets) {
         size_t lds = 0;
         for (int i = 0; i < nets; ++i) {
@@ -666,12 +666,12 @@ struct NetRunner {
         }
         static size_t attr_lds = 0;
         if (lds > attr_lds) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fwd_kernel<BM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fwd_kernel<BM, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
                 hipSuccess)
                 HG_FAIL(HGYM_E_LAUNCH, "cannot reserve %zu bytes of LDS for mlp_fwd_kernel", lds);
             attr_lds = lds;
         }
-        hipLaunchKernelGGL((mlp_fwd_kernel<BM>), dim3(ceil_div(a.M, BM), nets), dim3(FUSED_THREADS), lds, s, a);
+        hipLaunchKernelGGL((mlp_fwd_kernel<BM, NW>), dim3(ceil_div(a.M, BM), nets), dim3(NW * 64), lds, s, a);
         HG_CHECK_LAUNCH("mlp_fwd_kernel");
         return HGYM_OK;
     }
@@ -699,12 +699,12 @@ struct NetRunner {
             a.sigma = smp->sigma;
             a.logp = smp->logp;
         }
-        prof_begin(HGYM_PROF_GEMM, s);
-        const int32_t rc = (train || M >= 16384) ? launch_fwd<64>(a, nets) : launch_fwd<32>(a, nets);
+        prof_begin(HGYM_PROF_MLP_FWD, s);
+        const int32_t rc = (train || M >= 16384) ? launch_fwd<64, 16>(a, nets) : launch_fwd<32, 8>(a, nets);
         double fl = 0.0;
         for (int i = first; i < first + nets; ++i)
             for (int l = 0; l < 4; ++l) fl += 2.0 * (double)M * w.net[i].layer[l].N * (w.net[i].layer[l].KBf * 32.0);
-        prof_end(HGYM_PROF_GEMM, s, fl);
+        prof_end(HGYM_PROF_MLP_FWD, s, fl);
         return rc;
     }
 
@@ -754,17 +754,17 @@ struct NetRunner {
             g.M = B;
             static size_t attr_lds = 0;
             if (lds > attr_lds) {
-                if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_bwd_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_bwd_kernel<64, 16>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)lds) != hipSuccess)
                     HG_FAIL(HGYM_E_LAUNCH, "cannot reserve %zu bytes of LDS for mlp_bwd_kernel", lds);
                 attr_lds = lds;
             }
-            prof_begin(HGYM_PROF_GEMM, s);
-            hipLaunchKernelGGL((mlp_bwd_kernel<64>), dim3(Bp / 64, 2), dim3(FUSED_THREADS), lds, s, g);
+            prof_begin(HGYM_PROF_MLP_BWD, s);
+            hipLaunchKernelGGL((mlp_bwd_kernel<64, 16>), dim3(Bp / 64, 2), dim3(1024), lds, s, g);
             double fl = 0.0;
             for (int i = 0; i < 2; ++i)
                 for (int l = 1; l < 4; ++l) fl += 2.0 * (double)B * w.net[i].layer[l].K * (w.net[i].layer[l].NBBf * 32.0);
-            prof_end(HGYM_PROF_GEMM, s, fl);
+            prof_end(HGYM_PROF_MLP_BWD, s, fl);
             HG_CHECK_LAUNCH("mlp_bwd_kernel");
         }
         {   // all weight (and hidden bias) gradients: one launch, split-K slabs
@@ -791,6 +791,8 @@ struct NetRunner {
                     tile += p.tiles_n * p.tiles_k;
                     fl += 2.0 * (double)Bp * p.tiles_n * 128.0 * p.tiles_k * 128.0;
                 }
+            d.total_tiles = tile;
+            d.splits = w.dw_splits;
             d.steps_total = Bp / 32;
             d.steps_per_split = ceil_div(d.steps_total, w.dw_splits);
             d.slabs = at<float>(w.slabs);
@@ -802,13 +804,15 @@ struct NetRunner {
                     HG_FAIL(HGYM_E_LAUNCH, "cannot reserve LDS for dw_kernel");
                 attr_done = true;
             }
-            prof_begin(HGYM_PROF_GEMM, s);
-            hipLaunchKernelGGL(dw_kernel, dim3(tile, w.dw_splits), dim3(DW_THREADS), DW_STAGES * DW_STAGE_BYTES, s, d);
-            prof_end(HGYM_PROF_GEMM, s, fl);
+            prof_begin(HGYM_PROF_DW, s);
+            hipLaunchKernelGGL(dw_kernel, dim3(tile * (int)round_up(w.dw_splits, 8)), dim3(DW_THREADS), DW_STAGES * DW_STAGE_BYTES, s, d);
+            prof_end(HGYM_PROF_DW, s, fl);
             HG_CHECK_LAUNCH("dw_kernel");
         }
         const SegTable tab = segments(true);
+        prof_begin(HGYM_PROF_REDUCE, s);
         hipLaunchKernelGGL(reduce_slabs_kernel, dim3(96, tab.n), dim3(256), 0, s, tab, w.Ps, at<float>(w.slabs), net.grads);
+        prof_end(HGYM_PROF_REDUCE, s, (double)w.P * 4.0 * (w.dw_splits + 1));
         HG_CHECK_LAUNCH("reduce_slabs_kernel");
         return HGYM_OK;
     }
@@ -994,11 +998,13 @@ struct NetRunner {
     }
 
     int32_t apply(const HgymPPOConfig& ppo) {
+        prof_begin(HGYM_PROF_APPLY, s);
         hipLaunchKernelGGL(apply_prologue_kernel, dim3(1), dim3(64), 0, s, ppo, net.opt_state);
         hipLaunchKernelGGL(sqnorm_kernel, dim3(256), dim3(256), 0, s, w.P, net.grads, net.opt_state);
         const SegTable tab = segments(false);
         hipLaunchKernelGGL((adam_kernel<T>), dim3(64, tab.n), dim3(256), 0, s, tab, ppo, net.params, net.grads, net.adam_m, net.adam_v,
                            net.opt_state);
+        prof_end(HGYM_PROF_APPLY, s, (double)w.P * 36.0);
         HG_CHECK_LAUNCH("adam_kernel");
         return HGYM_OK;
     }

@@ -51,6 +51,8 @@ class OnPolicyRunner:
         self.tot_time = 0
         self.current_learning_iteration = 0
         self.last_collection_time = self.last_learn_time = 0.0
+        self._graph = None           # captured rollout (HIP graph) and the tensors it owns
+        self._graph_warm = False
         _, _ = self.env.reset()
 
     # ------------------------------------------------------------------
@@ -90,28 +92,61 @@ class OnPolicyRunner:
         cur_episode_length = torch.zeros(N, dtype=torch.float, device=self.device)
         done_stats = torch.zeros(3, dtype=torch.float, device=self.device)     # sum of returns, sum of lengths, episodes
 
+        # One rollout = num_steps_per_env x {act, env.step, process_env_step}: a few hundred small launches whose host
+        # side (Python + ctypes) costs more than the kernels.  Every buffer the step touches has a fixed address (the env
+        # writes into the storage slots, all counters live on the device), so after one eager warm-up iteration the whole
+        # rollout is captured into a HIP graph and replayed with a single launch per iteration (HGYM_GRAPH=0 disables).
+        use_graph = (zero_copy and str(self.device).startswith("cuda") and os.environ.get("HGYM_GRAPH", "1") != "0"
+                     and hasattr(torch.cuda, "CUDAGraph"))
+        log_on = self.log_dir is not None
+
+        def rollout(obs, critic_obs):
+            for i in range(self.num_steps_per_env):
+                actions = alg.act(obs, critic_obs)
+                if zero_copy:
+                    env.bind_outputs(obs_all[i + 1], priv_all[i + 1])
+                obs, privileged_obs, rewards, dones, infos = env.step(actions)
+                critic_obs = privileged_obs if privileged_obs is not None else obs
+                alg.process_env_step(rewards, dones, infos)
+                if log_on:
+                    if "episode" in infos:
+                        ep_infos.append({k: v.clone() for k, v in infos["episode"].items()})
+                    cur_reward_sum.add_(rewards)
+                    cur_episode_length.add_(1)
+                    d = dones.to(torch.float)
+                    done_stats[0] += (cur_reward_sum * d).sum()
+                    done_stats[1] += (cur_episode_length * d).sum()
+                    done_stats[2] += d.sum()
+                    cur_reward_sum.mul_(1.0 - d)
+                    cur_episode_length.mul_(1.0 - d)
+            return obs, critic_obs
+
         tot_iter = self.current_learning_iteration + num_learning_iterations
         for it in range(self.current_learning_iteration, tot_iter):
             start = time.time()
             with torch.inference_mode():
-                for i in range(self.num_steps_per_env):
-                    actions = alg.act(obs, critic_obs)
-                    if zero_copy:
-                        env.bind_outputs(obs_all[i + 1], priv_all[i + 1])
-                    obs, privileged_obs, rewards, dones, infos = env.step(actions)
-                    critic_obs = privileged_obs if privileged_obs is not None else obs
-                    alg.process_env_step(rewards, dones, infos)
-                    if self.log_dir is not None:
-                        if "episode" in infos:
-                            ep_infos.append({k: v.clone() for k, v in infos["episode"].items()})
-                        cur_reward_sum += rewards
-                        cur_episode_length += 1
-                        d = dones.to(torch.float)
-                        done_stats[0] += (cur_reward_sum * d).sum()
-                        done_stats[1] += (cur_episode_length * d).sum()
-                        done_stats[2] += d.sum()
-                        cur_reward_sum *= 1.0 - d
-                        cur_episode_length *= 1.0 - d
+                g = self._graph
+                if use_graph and g is not None and g["key"] == (id(env), id(alg.storage), log_on):
+                    g["graph"].replay()
+                    alg.storage.step = self.num_steps_per_env
+                    obs, critic_obs = g["out"]
+                    ep_infos = g["ep_infos"]
+                    cur_reward_sum, cur_episode_length, done_stats = g["stats"]
+                elif use_graph and self._graph_warm:
+                    graph = torch.cuda.CUDAGraph()
+                    ep_infos = []
+                    torch.cuda.synchronize()
+                    with torch.cuda.graph(graph):
+                        out = rollout(obs_all[0], priv_all[0])
+                    self._graph = dict(graph=graph, out=out, ep_infos=ep_infos, key=(id(env), id(alg.storage), log_on),
+                                       stats=(cur_reward_sum, cur_episode_length, done_stats))
+                    alg.storage.step = 0
+                    graph.replay()                  # capture does not execute: run the captured rollout once
+                    alg.storage.step = self.num_steps_per_env
+                    obs, critic_obs = out
+                else:
+                    obs, critic_obs = rollout(obs, critic_obs)
+                    self._graph_warm = True
                 if str(self.device).startswith("cuda"):
                     torch.cuda.synchronize()
                 stop = time.time()
@@ -133,7 +168,8 @@ class OnPolicyRunner:
                 self.log(locals())
                 if it % self.save_interval == 0:
                     self.save(os.path.join(self.log_dir, "model_{}.pt".format(it)))
-            ep_infos.clear()
+            if self._graph is None or ep_infos is not self._graph["ep_infos"]:
+                ep_infos.clear()
         if zero_copy:
             env.bind_outputs(None, None)
         self.current_learning_iteration += num_learning_iterations

@@ -1,0 +1,60 @@
+"""GPU micro-benchmark of the PPO minibatch (B = 61 440) and the rollout policy step (M = 4096) through the C-ABI,
+with a calibration line (torch bf16 matmul + device copy) so runs on different boxes / clock states can be compared."""
+import os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "humanoid-gym_amd"))
+import torch
+from hgym import NetBuffers, make_net_config, make_ppo_config, make_batch, _lib as L
+
+dev = "cuda"
+def timeit(fn, reps=20, warm=3):
+    for _ in range(warm): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / reps
+
+a = torch.randn(8192, 8192, device=dev, dtype=torch.bfloat16); b = torch.randn(8192, 8192, device=dev, dtype=torch.bfloat16)
+us = timeit(lambda: a @ b, 10)
+src = torch.empty(1 << 28, device=dev, dtype=torch.uint8); dst = torch.empty_like(src)
+uc = timeit(lambda: dst.copy_(src), 10)
+print("calib: matmul8192 bf16 %.0f us (%.0f TF/s)  copy256MB %.0f us (%.2f TB/s r+w)" % (us, 2 * 8192**3 / us / 1e6, uc, 2 * (1 << 28) / uc / 1e6))
+
+S = B = 61440
+cfg = make_net_config(705, 219, 12, [512, 256, 128], [768, 256, 128], "bf16", B)
+net = NetBuffers(cfg, dev, learning_rate=1e-5)
+g = torch.Generator(device=dev).manual_seed(0)
+for k, v in net.views.items():
+    v.copy_(torch.randn(v.shape, device=dev, generator=g) * (0.05 if v.dim() > 1 else 0.01))
+net.views["std"].fill_(1.0)
+net.sync_shadow()
+obs, priv = torch.randn(S, 705, device=dev), torch.randn(S, 219, device=dev)
+act, mu_o = torch.randn(S, 12, device=dev), torch.randn(S, 12, device=dev) * 0.3
+sg_o = torch.ones(S, 12, device=dev)
+val, adv, ret = torch.randn(S, device=dev), torch.randn(S, device=dev), torch.randn(S, device=dev)
+lp_o = -12.0 + torch.randn(S, device=dev)
+idx = torch.randperm(S, device=dev).contiguous()
+ppo = make_ppo_config()
+batch = make_batch(obs, priv, act, val, adv, ret, lp_o, mu_o, sg_o, idx)
+names = {0: "gemm(all)", 3: "loss", 4: "mlp_fwd", 5: "mlp_bwd", 6: "dw", 7: "reduce", 8: "apply"}
+def step():
+    net.ppo_grad(ppo, batch); net.ppo_apply(ppo)
+t = timeit(step, 20)
+print("minibatch grad+apply: %.1f us" % t)
+L.lib.hgym_prof_enable(1)
+for _ in range(10): step()
+torch.cuda.synchronize()
+for c, nm in names.items():
+    try:
+        n, ms, work = L.prof_summary(c)
+    except Exception:
+        continue
+    if n: print("  %-10s launches %3d avg %8.1f us  work/s %.1f T" % (nm, n, ms / n * 1e3, work / (ms * 1e-3) / 1e12 if ms > 0 else 0))
+L.lib.hgym_prof_enable(0)
+M = 4096
+o4, p4 = torch.randn(M, 705, device=dev), torch.randn(M, 219, device=dev)
+step_c = torch.zeros(1, dtype=torch.int64, device=dev)
+out = net.act(o4, p4, seed=1, step_counter=step_c)
+t = timeit(lambda: net.act(o4, p4, seed=1, step_counter=step_c, out=out), 50)
+print("policy_act M=4096: %.1f us" % t)
