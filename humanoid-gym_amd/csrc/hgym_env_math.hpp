@@ -30,6 +30,7 @@ struct EnvArgs {
     int envs_per_block;
     int ablate;               // debug/profiling only: bit0 skip stage-in, bit1 skip phase A, bit2 skip stage-out, bit3 skip phase B,
                               // bit4 skip pre_physics+synthetic physics, bit5 skip the per-env post-physics arithmetic
+    int state_contig;         // 1: the 22 [C][N] state fields are adjacent in memory, in HgymEnvState order
     int env_base;             // global id of env index 0 of the state arrays (0, or the block's first env for an LDS shadow)
     int contact_comp[3];      // component offset of the xyz triple of {base, foot L, foot R} in sim.contact
     int rigid_comp[4];        // component offset of the 13-vector of {foot L, foot R, knee L, knee R} in sim.rigid
@@ -136,22 +137,25 @@ HG_HD void stance_from_sin(float s, float st[2]) {
 }
 
 // ------------------------------------------------------------------------------------------------ E1/E2
-// humanoid_env.py:189-197 + legged_robot.py:90-91
+// humanoid_env.py:189-197 + legged_robot.py:90-91, one joint: u = delay draw, z = action-noise normal
+HG_HD float filter_action(const HgymEnvConfig& c, float a_in, float a_prev, float u, float z) {
+    const float delay = u * c.action_delay;
+    float a = clampf(a_in, -c.clip_actions, c.clip_actions);
+    a = (1.0f - delay) * a + delay * a_prev;
+    a = a + c.action_noise * z * a;
+    return clampf(a, -c.clip_actions, c.clip_actions);
+}
+HG_HD void pre_physics_joint(const EnvArgs& A, int e, int N, int j, float u, float z) {
+    FG(A.st.actions, j) = filter_action(A.cfg, A.actions_in[(int64_t)e * 12 + j], FG(A.st.actions, j), u, z);
+}
+
 HG_HD void pre_physics_env(const EnvArgs& A, const RngKey& rk, int e, int N) {
-    const HgymEnvConfig& c = A.cfg;
     const int ge = A.env_base + e;
     const float u = nz_uniform(A.noise.u_delay, 1, 0, rk, e, ge, SLOT_DELAY_CMD, 0);
-    const float delay = u * c.action_delay;
     float zn[12];
     if (!A.noise.z_act) normals_block<3>(rk, (uint32_t)ge, SLOT_ACT, zn);
 #pragma unroll
-    for (int j = 0; j < 12; ++j) {
-        float a = clampf(A.actions_in[(int64_t)e * 12 + j], -c.clip_actions, c.clip_actions);
-        a = (1.0f - delay) * a + delay * FG(A.st.actions, j);
-        const float z = A.noise.z_act ? A.noise.z_act[(int64_t)e * 12 + j] : zn[j];
-        a = a + c.action_noise * z * a;
-        FG(A.st.actions, j) = clampf(a, -c.clip_actions, c.clip_actions);
-    }
+    for (int j = 0; j < 12; ++j) pre_physics_joint(A, e, N, j, u, A.noise.z_act ? A.noise.z_act[(int64_t)e * 12 + j] : zn[j]);
 }
 
 // legged_robot.py:340-356
@@ -170,30 +174,52 @@ HG_HD void pd_torques_env(const EnvArgs& A, int e, int N) {
 // Stands where PhysX is (legged_robot.py:94-101,124-126).  SURVEY.md §8d: unit-inertia joints under the PD
 // torque, `decimation` semi-implicit Euler substeps with URDF joint limits; root / contact / rigid-body
 // tensors drawn from Philox.  This is the benchmark backend only -- it has no reference counterpart.
-HG_HD void synth_physics_env(const EnvArgs& A, const RngKey& rk, int e, int N) {
-    const HgymEnvConfig& c = A.cfg;
-    const uint32_t ue = (uint32_t)(A.env_base + e);
-#pragma unroll
-    for (int j = 0; j < 12; ++j) {
-        float q = sget(A.sim.dof_pos, e, j), qd = sget(A.sim.dof_vel, e, j);
-        const float a = FG(A.st.actions, j);
-        float t = 0.0f;
-        for (int s = 0; s < c.decimation; ++s) {
-            t = pd_torque(c, j, a, q, qd);
-            qd = qd + c.sim_dt * t;
-            q = q + c.sim_dt * qd;
-            if (q < c.dof_lower[j]) { q = c.dof_lower[j]; qd = 0.0f; }
-            if (q > c.dof_upper[j]) { q = c.dof_upper[j]; qd = 0.0f; }
-        }
-        // the reference evaluates the torque before each substep; the last evaluation is what rewards see
-        FG(A.st.torques, j) = t;
-        sset(A.sim.dof_pos, e, j, q);
-        sset(A.sim.dof_vel, e, j, qd);
+// Split in three so the step kernel can spread it over lanes: the random draws (one Philox call per work item),
+// the joint integration (one (env, joint) pair per lane) and the per-env remainder.
+constexpr int kPhysDraws = 36;   // r0: 4 uniforms | n: 12 normals | r1: 4 uniforms | m: 12 normals | r2: 4 uniforms
+constexpr int kPhysCalls = 9;    // Philox calls SLOT_PHYS + 0 .. 8
+
+// draws of call c (0..8) -> tab[4c .. 4c+3]
+HG_HD void phys_draw_call(const RngKey& rk, uint32_t ue, int c, float* tab) {
+    const U4 r = rng4(rk, ue, SLOT_PHYS + (uint32_t)c);
+    const bool normal = (c >= 1 && c <= 3) || (c >= 5 && c <= 7);
+    if (normal) {
+        box_muller(r.x, r.y, tab[4 * c + 0], tab[4 * c + 1]);
+        box_muller(r.z, r.w, tab[4 * c + 2], tab[4 * c + 3]);
+    } else {
+        tab[4 * c + 0] = u01(r.x);
+        tab[4 * c + 1] = u01(r.y);
+        tab[4 * c + 2] = u01(r.z);
+        tab[4 * c + 3] = u01(r.w);
     }
+}
+
+// `decimation` PD + semi-implicit Euler substeps of one unit-inertia joint; t = the last torque evaluation
+HG_HD void integrate_joint(const HgymEnvConfig& c, int j, float a, float& q, float& qd, float& t) {
+    t = 0.0f;
+    for (int s = 0; s < c.decimation; ++s) {
+        t = pd_torque(c, j, a, q, qd);
+        qd = qd + c.sim_dt * t;
+        q = q + c.sim_dt * qd;
+        if (q < c.dof_lower[j]) { q = c.dof_lower[j]; qd = 0.0f; }
+        if (q > c.dof_upper[j]) { q = c.dof_upper[j]; qd = 0.0f; }
+    }
+}
+HG_HD void synth_joint(const EnvArgs& A, int e, int N, int j) {
+    float q = sget(A.sim.dof_pos, e, j), qd = sget(A.sim.dof_vel, e, j), t;
+    integrate_joint(A.cfg, j, FG(A.st.actions, j), q, qd, t);
+    // the reference evaluates the torque before each substep; the last evaluation is what rewards see
+    FG(A.st.torques, j) = t;
+    sset(A.sim.dof_pos, e, j, q);
+    sset(A.sim.dof_vel, e, j, qd);
+}
+
+// tab: this env's kPhysDraws draws
+HG_HD void synth_rest_env(const EnvArgs& A, const float* tab, int e, int N) {
+    const HgymEnvConfig& c = A.cfg;
+    const float* n = tab + 4;
+    const float* m = tab + 20;
     // root: mean-reverting orientation walk, small height jitter, gaussian velocities
-    const U4 r0 = rng4(rk, ue, SLOT_PHYS + 0);
-    float n[12];
-    normals_block<3>(rk, ue, SLOT_PHYS + 1, n);
     float qx = 0.9f * sget(A.sim.root, e, 3) + 0.05f * n[0];
     float qy = 0.9f * sget(A.sim.root, e, 4) + 0.05f * n[1];
     float qz = 0.9f * sget(A.sim.root, e, 5) + 0.05f * n[2];
@@ -202,31 +228,27 @@ HG_HD void synth_physics_env(const EnvArgs& A, const RngKey& rk, int e, int N) {
     sset(A.sim.root, e, 4, qy * inv);
     sset(A.sim.root, e, 5, qz * inv);
     sset(A.sim.root, e, 6, inv);
-    sset(A.sim.root, e, 2, 0.9f + 0.02f * (2.0f * u01(r0.x) - 1.0f));
+    sset(A.sim.root, e, 2, 0.9f + 0.02f * (2.0f * tab[0] - 1.0f));
 #pragma unroll
     for (int i = 0; i < 6; ++i) sset(A.sim.root, e, 7 + i, 0.3f * n[3 + i]);
     // contacts: feet load follows the gait clock, rare base-link hits end episodes (~ every 500 steps)
     const float s = sinf(kTwoPi * gait_phase(c, A.st.episode_length[e] + 1));
     float stance[2];
     stance_from_sin(s, stance);
-    const U4 r1 = rng4(rk, ue, SLOT_PHYS + 4);
-    const float uf[2] = {u01(r1.x), u01(r1.y)};
-    const float ug[2] = {u01(r1.z), u01(r1.w)};
+    const float uf[2] = {tab[16], tab[17]};
+    const float ug[2] = {tab[18], tab[19]};
     // (all other contact entries stay at their initial zero)
 #pragma unroll
     for (int f = 0; f < 2; ++f) {
         const float on = (stance[f] > 0.5f || ug[f] > 0.4f) ? 1.0f : 0.0f;
         sset(A.sim.contact, e, A.contact_comp[1 + f] + 2, 600.0f * uf[f] * on);
     }
-    const float hit = (u01(r0.y) < 0.002f) ? 2.0f : 0.0f;
+    const float hit = (tab[1] < 0.002f) ? 2.0f : 0.0f;
     sset(A.sim.contact, e, A.contact_comp[0] + 0, hit * n[9]);
     sset(A.sim.contact, e, A.contact_comp[0] + 1, hit * n[10]);
     sset(A.sim.contact, e, A.contact_comp[0] + 2, hit * n[11]);
     // rigid bodies: only the entries the rewards read (feet x,y,z,vx,vy ; knees x,y)
-    float m[12];
-    normals_block<3>(rk, ue, SLOT_PHYS + 5, m);
-    const U4 r2 = rng4(rk, ue, SLOT_PHYS + 8);
-    const float uz[2] = {u01(r2.x), u01(r2.y)};
+    const float uz[2] = {tab[32], tab[33]};
 #pragma unroll
     for (int f = 0; f < 2; ++f) {
         const int fb = A.rigid_comp[f], kb = A.rigid_comp[2 + f];
@@ -239,6 +261,15 @@ HG_HD void synth_physics_env(const EnvArgs& A, const RngKey& rk, int e, int N) {
         sset(A.sim.rigid, e, kb + 0, 0.2f * m[f * 6 + 4]);
         sset(A.sim.rigid, e, kb + 1, 0.8f * side + 0.05f * m[f * 6 + 5]);
     }
+}
+
+HG_HD void synth_physics_env(const EnvArgs& A, const RngKey& rk, int e, int N) {
+#pragma unroll
+    for (int j = 0; j < 12; ++j) synth_joint(A, e, N, j);
+    float tab[kPhysDraws];
+#pragma unroll
+    for (int c = 0; c < kPhysCalls; ++c) phys_draw_call(rk, (uint32_t)(A.env_base + e), c, tab);
+    synth_rest_env(A, tab, e, N);
 }
 
 // ------------------------------------------------------------------------------------------------ commands
@@ -666,77 +697,19 @@ HG_HD StepFlags post_physics_env(const EnvArgs& A, const RngKey& rk, int64_t csc
     return fl;
 }
 
-// ------------------------------------------------------------------------------------------------ phase B
-// One element of the stacked, clipped observation (humanoid_env.py:250-262, legged_robot.py:105-108):
-// rows are oldest -> newest; the newest frame gets its noise here and is pushed into the ring.
-//   ring      [N][H][F] unclipped frames, newest at slot `slot_new`
-//   clean     this env's clean new frame (LDS), F floats
-// Two uniform passes per output tensor: (1) the newest frame (noise, ring push), (2) the H-1 older frames, a pure
-// shifted copy in which every lane issues kStackBatch independent, UNCONDITIONAL ring loads before its first store
-// (the output and the ring may alias as far as the compiler knows, so a load behind a store would serialise).
-constexpr int kStackBatch = 8;
-
-template <bool kNoisy>
-HG_HD void stack_rows(const EnvArgs& A, const RngKey& rk, float* ring, const float* clean_all, const int* s_reset, float* dst, int e0,
-                      int nE, int H, int F, int slot_new, int t, int nthreads) {
-    const int row = H * F;
-    const float lim = A.cfg.clip_obs;
-    // pass 1: newest frame
-    for (int i = t; i < nE * F; i += nthreads) {
-        const int le = i / F, k = i - le * F;
-        const int e = e0 + le;
-        float v = clean_all[i];
-        if (kNoisy && A.cfg.add_noise) {
-            if (A.cfg.obs_noise[k] != 0.0f) {
-                const float z = nz_normal(A.noise.z_obs, HGYM_OBS_FRAME, k, rk, e, e, SLOT_OBS, k);
-                v = v + z * A.cfg.obs_noise[k] * A.cfg.noise_level;
-            } else {
-                v = v + 0.0f;   // clean + z*0*level in the reference
-            }
-        }
-        ring[((int64_t)e * H + slot_new) * F + k] = v;
-        dst[(int64_t)le * row + (H - 1) * F + k] = clampf(v, -lim, lim);
-    }
-    // pass 2: older frames, oldest -> newest
-    const int hrow = (H - 1) * F;
-    const int total = nE * hrow;
-    for (int base = t; base < total; base += nthreads * kStackBatch) {
-        float* p[kStackBatch];
-        float old[kStackBatch];
-        int di[kStackBatch];
-        bool rs[kStackBatch];
-#pragma unroll
-        for (int u = 0; u < kStackBatch; ++u) {
-            int i = base + u * nthreads;
-            i = i < total ? i : total - 1;             // clamp: surplus lanes redo the last element (same value)
-            const int le = i / hrow;
-            const int rem = i - le * hrow;
-            const int j = rem / F;
-            const int k = rem - j * F;
-            int slot = slot_new + 1 + j;
-            if (slot >= H) slot -= H;
-            p[u] = ring + ((int64_t)(e0 + le) * H + slot) * F + k;
-            di[u] = le * row + rem;
-            rs[u] = s_reset[le] != 0;
-        }
-#pragma unroll
-        for (int u = 0; u < kStackBatch; ++u) old[u] = *p[u];
-#pragma unroll
-        for (int u = 0; u < kStackBatch; ++u) {
-            if (rs[u]) *p[u] = 0.0f;
-            dst[di[u]] = rs[u] ? 0.0f : clampf(old[u], -lim, lim);
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------------ workgroup phases
-// The step kernel runs, per workgroup of E envs:
-//   stage-in   all lanes: every per-env input (state, the needed sim components, actions, noise rows) is copied
-//              into LDS with coalesced loads -- ONE global-memory round trip instead of ~250 dependent ones;
-//   phase A    one lane per env: the per-env arithmetic above, executed against an LDS "shadow" of EnvArgs
-//              (same code, pointers re-aimed at LDS, component stride E instead of N);
+// The step kernel runs, per workgroup of E envs (256 lanes):
+//   stage-in   all lanes: every per-env input (state, the needed sim components, actions, noise rows) is copied into
+//              LDS with coalesced 16-byte loads -- ONE global-memory round trip instead of ~250 dependent ones;
+//   draws      all lanes: every random number the step may consume that was not supplied as a table is produced here,
+//              one Philox call per work item, into the same LDS tables the parity mode fills from HBM -- the arithmetic
+//              phases below never run a Philox round;
+//   joints     one lane per (env, joint): action filter + the synthetic joint integration (fused backend only);
+//   per-env    one lane per env: everything that is a scalar chain per env (quaternions, commands, termination, the 22
+//              reward terms, reset, clean observation frames), executed against an LDS "shadow" of EnvArgs (same code,
+//              pointers re-aimed at LDS, component stride E instead of N);
 //   stage-out  all lanes: modified state / sim components / step outputs written back, coalesced;
-//   phase B    all lanes: history stacking (stack_element) straight to the row-major outputs.
+//   stacking   all lanes: observation history -> the row-major outputs, 16 bytes per lane.
 // Every phase is a plain function of (block, thread) so tests/hostcheck runs the identical code on the host.
 HG_HD RngKey make_rng_key(const EnvArgs& A, int64_t csc0) {
     RngKey rk;
@@ -747,6 +720,10 @@ HG_HD RngKey make_rng_key(const EnvArgs& A, int64_t csc0) {
     return rk;
 }
 
+struct __attribute__((packed, aligned(4))) EnvF4 {
+    float v[4];
+};
+
 // components of every [C][N] state field, in HgymEnvState order (commands ... env_origins)
 constexpr int kNumStateFields = 22;
 HG_HD int state_field_comps(int f) {
@@ -755,13 +732,25 @@ HG_HD int state_field_comps(int f) {
 }
 constexpr int kStateComps = 4 + 12 * 6 + 6 + 2 * 4 + 3 * 2 + HGYM_NUM_REWARDS + 3 * 4 + 1 + 1 + 3;   // 136
 constexpr int kFirstConstField = 19;    // friction, body_mass, env_origins are read-only
+constexpr int kMutableComps = kStateComps - 5;
 HG_HD float** state_field_ptr(HgymEnvState& S, int f) { return (&S.commands) + f; }
 HG_HD float* const* state_field_ptr(const HgymEnvState& S, int f) { return (&S.commands) + f; }
+// flat state component index (0..135) -> its [N] row in HBM
+HG_HD float* state_comp_row(const EnvArgs& A, int comp, int N) {
+    const HgymEnvState& S = A.st;
+    if (A.state_contig) return S.commands + (int64_t)comp * N;   // one [136][N] allocation (hgym.EnvBuffers)
+    int f = 0;
+    while (comp >= state_field_comps(f)) {
+        comp -= state_field_comps(f);
+        ++f;
+    }
+    return *state_field_ptr(S, f) + (int64_t)comp * N;
+}
 
 // LDS carve (float offsets) for a block of E envs
 struct LdsMap {
-    int state, root, dof_pos, dof_vel, contact, rigid, actions_in, u_delay, z_act, u_cmd, u_dof, u_push, frame, priv, rew, ep_len,
-        flags, reset_i, total;
+    int state, root, dof_pos, dof_vel, contact, rigid, actions_in, u_delay, z_act, u_cmd, u_dof, u_push, z_obs, phys, frame, priv, rew,
+        noise_vec, ep_len, flags, reset_i, total;
 };
 HG_HD LdsMap lds_map(int E) {
     LdsMap m;
@@ -775,16 +764,19 @@ HG_HD LdsMap lds_map(int E) {
     m.actions_in = o; o += 12 * E;
     m.u_delay = o;    o += E;
     m.z_act = o;      o += 12 * E;
-    m.u_cmd = o;      o += 6 * E;
+    m.u_cmd = o;      o += 8 * E;            // 6 used (row width 6), sized for whole Philox calls
     m.u_dof = o;      o += 12 * E;
-    m.u_push = o;     o += 5 * E;
+    m.u_push = o;     o += 8 * E;            // 5 used (row width 5)
+    m.z_obs = o;      o += 48 * E;           // 47 used (row width 47)
+    m.phys = o;       o += kPhysDraws * E;
     m.frame = o;      o += HGYM_OBS_FRAME * E;
     m.priv = o;       o += HGYM_PRIV_FRAME * E;
     m.rew = o;        o += E;
+    m.noise_vec = o;  o += 48;             // obs_noise[47] (a lane-varying index must not go through the kernel argument)
     o = (o + 1) & ~1;
     m.ep_len = o;     o += 2 * E;          // int64[E]
     m.flags = o;      o += (2 * E + 3) / 4;  // uint8 reset[E], time_out[E]
-    m.reset_i = o;    o += E;              // int[E]: "history must be cleared" flags for phase B
+    m.reset_i = o;    o += E;              // int[E]: "history must be cleared" flags for the stacking phase
     m.total = o;
     return m;
 }
@@ -794,6 +786,7 @@ constexpr int kFootRigidComps[5] = {0, 1, 2, 7, 8};
 constexpr int kKneeRigidComps[2] = {0, 1};
 
 // The LDS shadow of EnvArgs for block `block`: same configuration, pointers into smem, component stride E.
+// Every noise table points into LDS: it was either staged from the caller's table or filled by env_fill_draws.
 HG_HD EnvArgs make_shadow(const EnvArgs& A, float* smem, int block, int E) {
     const LdsMap m = lds_map(E);
     EnvArgs S = A;
@@ -812,11 +805,12 @@ HG_HD EnvArgs make_shadow(const EnvArgs& A, float* smem, int block, int E) {
     S.contact_comp[0] = 0; S.contact_comp[1] = 3; S.contact_comp[2] = 6;
     S.rigid_comp[0] = 0; S.rigid_comp[1] = 13; S.rigid_comp[2] = 26; S.rigid_comp[3] = 39;
     if (A.actions_in) S.actions_in = smem + m.actions_in;
-    if (A.noise.u_delay) S.noise.u_delay = smem + m.u_delay;
-    if (A.noise.z_act) S.noise.z_act = smem + m.z_act;
-    if (A.noise.u_cmd) S.noise.u_cmd = smem + m.u_cmd;
-    if (A.noise.u_dof) S.noise.u_dof = smem + m.u_dof;
-    if (A.noise.u_push) S.noise.u_push = smem + m.u_push;
+    S.noise.u_delay = smem + m.u_delay;
+    S.noise.z_act = smem + m.z_act;
+    S.noise.u_cmd = smem + m.u_cmd;
+    S.noise.u_dof = smem + m.u_dof;
+    S.noise.u_push = smem + m.u_push;
+    S.noise.z_obs = smem + m.z_obs;
     S.out.rew = smem + m.rew;
     S.out.reset = reinterpret_cast<uint8_t*>(smem + m.flags);
     S.out.time_out = S.out.reset + E;
@@ -829,49 +823,235 @@ HG_HD void copy_rows_in(const float* g, float* l, int width, int e0, int nE, int
     for (int i = t; i < nE * width; i += nthreads) l[i] = src[i];
 }
 
+// [C][N] rows <-> [C][E] LDS rows, 4 envs (16 bytes) per lane; the partial last block goes element-wise
+template <bool kIn>
+HG_HD void copy_comp_rows(float* const* rows_unused, const EnvArgs& A, int first_comp, int ncomp, float* l, int E, int e0, int nE, int N,
+                          int t, int nthreads) {
+    (void)rows_unused;
+    if (nE == E && (E & 3) == 0) {
+        const int qpr = E >> 2;
+        for (int i = t; i < ncomp * qpr; i += nthreads) {
+            const int c = i / qpr, qd = i - c * qpr;
+            float* g = state_comp_row(A, first_comp + c, N) + e0 + 4 * qd;
+            EnvF4* lp = reinterpret_cast<EnvF4*>(l + c * E + 4 * qd);
+            if (kIn) *lp = *reinterpret_cast<const EnvF4*>(g);
+            else *reinterpret_cast<EnvF4*>(g) = *lp;
+        }
+    } else {
+        for (int i = t; i < ncomp * E; i += nthreads) {
+            const int c = i / E, le = i - c * E;
+            float* g = state_comp_row(A, first_comp + c, N) + e0 + le;
+            if (kIn) l[i] = (le < nE) ? *g : 0.0f;
+            else if (le < nE) *g = l[i];
+        }
+    }
+}
+
+// one strided sim tensor (ncomp components listed by comp_of(k)) <-> LDS [k][E]
+template <bool kIn, typename CompOf>
+HG_HD void copy_sim_rows(const HgymStrided& sv, int ncomp, CompOf comp_of, float* l, int lstride_comp_of_unused, int E, int e0, int nE, int t,
+                         int nthreads) {
+    (void)lstride_comp_of_unused;
+    if (sv.env_stride == 1 && nE == E && (E & 3) == 0) {
+        const int qpr = E >> 2;
+        for (int i = t; i < ncomp * qpr; i += nthreads) {
+            const int k = i / qpr, qd = i - k * qpr;
+            float* g = sv.base + (int64_t)comp_of(k).x * sv.comp_stride + e0 + 4 * qd;
+            EnvF4* lp = reinterpret_cast<EnvF4*>(l + comp_of(k).y * E + 4 * qd);
+            if (kIn) *lp = *reinterpret_cast<const EnvF4*>(g);
+            else *reinterpret_cast<EnvF4*>(g) = *lp;
+        }
+    } else {
+        for (int i = t; i < ncomp * E; i += nthreads) {
+            const int k = i / E, le = i - k * E;
+            if (kIn) l[comp_of(k).y * E + le] = (le < nE) ? sget(sv, e0 + le, comp_of(k).x) : 0.0f;
+            else if (le < nE) sset(sv, e0 + le, comp_of(k).x, l[comp_of(k).y * E + le]);
+        }
+    }
+}
+struct CompPair {
+    int x, y;   // component in the sim tensor, row in the LDS image
+};
+
+template <bool kIn>
+HG_HD void stage_sim(const EnvArgs& A, const LdsMap& m, float* smem, int E, int e0, int nE, int t, int nthreads, bool contact_rigid) {
+    auto ident = [](int k) { return CompPair{k, k}; };
+    copy_sim_rows<kIn>(A.sim.root, 13, ident, smem + m.root, 0, E, e0, nE, t, nthreads);
+    copy_sim_rows<kIn>(A.sim.dof_pos, 12, ident, smem + m.dof_pos, 0, E, e0, nE, t, nthreads);
+    copy_sim_rows<kIn>(A.sim.dof_vel, 12, ident, smem + m.dof_vel, 0, E, e0, nE, t, nthreads);
+    if (!contact_rigid) return;
+    const int cc0 = A.contact_comp[0], cc1 = A.contact_comp[1], cc2 = A.contact_comp[2];
+    auto cmap = [=](int k) { return CompPair{(k < 3 ? cc0 : (k < 6 ? cc1 : cc2)) + k % 3, k}; };
+    copy_sim_rows<kIn>(A.sim.contact, 9, cmap, smem + m.contact, 0, E, e0, nE, t, nthreads);
+    const int r0 = A.rigid_comp[0], r1 = A.rigid_comp[1], r2 = A.rigid_comp[2], r3 = A.rigid_comp[3];
+    auto rmap = [=](int k) {   // feet {x,y,z,vx,vy}, knees {x,y}
+        const int body = k < 10 ? k / 5 : 2 + (k - 10) / 2;
+        const int comp = k < 10 ? kFootRigidComps[k % 5] : kKneeRigidComps[(k - 10) % 2];
+        const int base = body == 0 ? r0 : (body == 1 ? r1 : (body == 2 ? r2 : r3));
+        return CompPair{base + comp, body * 13 + comp};
+    };
+    copy_sim_rows<kIn>(A.sim.rigid, 14, rmap, smem + m.rigid, 0, E, e0, nE, t, nthreads);
+}
+
+// Fast stage-in (contiguous state, SoA sim tensors, full block, 256 lanes): every tensor is a list of 16-byte items
+// (4 envs of one component row).  Each lane issues one UNCONDITIONAL load per tensor (index clamped into range, surplus
+// lanes re-read the last item) plus its share of the state rows, all before its first LDS write: the stage costs one
+// memory round trip instead of one per field.  Every base pointer is a fixed struct member -- a lane-varying choice
+// between tensors would make the compiler index the kernel argument dynamically and spill it to scratch.
 template <int E_T>
 HG_HD void env_stage_in(const EnvArgs& A, int block, int t, int nthreads, float* smem) {
     const int E = E_T > 0 ? E_T : A.envs_per_block;
     const int N = A.cfg.num_envs, e0 = block * E;
     const int nE = (E < N - e0) ? E : (N - e0);
     const LdsMap m = lds_map(E);
-    int o = m.state;
-    for (int f = 0; f < kNumStateFields; ++f) {
-        const int nc = state_field_comps(f);
-        const float* g = *state_field_ptr(A.st, f);
-        for (int i = t; i < nc * E; i += nthreads) {
-            const int c = i / E, le = i - c * E;
-            smem[o + i] = (le < nE) ? g[(int64_t)c * N + e0 + le] : 0.0f;
+    constexpr int EE = E_T > 0 ? E_T : 4;
+    constexpr int Q = EE / 4;                                 // 16-byte items per component row
+    const bool fast = E_T > 0 && (E_T & 3) == 0 && 14 * Q <= 256 && nthreads == 256 && nE == E && A.state_contig &&
+                      A.sim.root.env_stride == 1 && A.sim.dof_pos.env_stride == 1 && A.sim.dof_vel.env_stride == 1 &&
+                      A.sim.contact.env_stride == 1 && A.sim.rigid.env_stride == 1;
+    if (fast) {
+        constexpr int NS = (kStateComps * Q + 255) / 256;
+        auto cl = [](int i, int n) { return i < n ? i : n - 1; };
+        EnvF4 rs[NS], r_root, r_dp, r_dv, r_ct, r_rg, r_act, r_ep;
+#pragma unroll
+        for (int u = 0; u < NS; ++u) {
+            const int i = cl(t + u * 256, kStateComps * Q);
+            rs[u] = *reinterpret_cast<const EnvF4*>(A.st.commands + (int64_t)(i / Q) * N + e0 + 4 * (i % Q));
         }
-        o += nc * E;
+        const int i13 = cl(t, 13 * Q), i12 = cl(t, 12 * Q), i9 = cl(t, 9 * Q), i14 = cl(t, 14 * Q);
+        r_root = *reinterpret_cast<const EnvF4*>(A.sim.root.base + (int64_t)(i13 / Q) * A.sim.root.comp_stride + e0 + 4 * (i13 % Q));
+        r_dp = *reinterpret_cast<const EnvF4*>(A.sim.dof_pos.base + (int64_t)(i12 / Q) * A.sim.dof_pos.comp_stride + e0 + 4 * (i12 % Q));
+        r_dv = *reinterpret_cast<const EnvF4*>(A.sim.dof_vel.base + (int64_t)(i12 / Q) * A.sim.dof_vel.comp_stride + e0 + 4 * (i12 % Q));
+        const int cc0 = A.contact_comp[0], cc1 = A.contact_comp[1], cc2 = A.contact_comp[2];
+        const int k9 = i9 / Q;
+        const int ccomp = (k9 < 3 ? cc0 : (k9 < 6 ? cc1 : cc2)) + k9 % 3;
+        r_ct = *reinterpret_cast<const EnvF4*>(A.sim.contact.base + (int64_t)ccomp * A.sim.contact.comp_stride + e0 + 4 * (i9 % Q));
+        const int rc0 = A.rigid_comp[0], rc1 = A.rigid_comp[1], rc2 = A.rigid_comp[2], rc3 = A.rigid_comp[3];
+        const int k14 = i14 / Q;                              // feet {x,y,z,vx,vy}, knees {x,y}
+        const int body = k14 < 10 ? k14 / 5 : 2 + (k14 - 10) / 2;
+        const int c5 = k14 % 5;
+        const int rcomp = k14 < 10 ? (c5 < 3 ? c5 : c5 + 4) : (k14 - 10) % 2;
+        const int rbase = body == 0 ? rc0 : (body == 1 ? rc1 : (body == 2 ? rc2 : rc3));
+        r_rg = *reinterpret_cast<const EnvF4*>(A.sim.rigid.base + (int64_t)(rbase + rcomp) * A.sim.rigid.comp_stride + e0 + 4 * (i14 % Q));
+        const int ia = cl(t, 3 * EE), ie = cl(t, EE / 2);
+        if (A.actions_in) r_act = *reinterpret_cast<const EnvF4*>(A.actions_in + (int64_t)e0 * 12 + 4 * ia);
+        r_ep = *reinterpret_cast<const EnvF4*>(reinterpret_cast<const float*>(A.st.episode_length + e0) + 4 * ie);
+#pragma unroll
+        for (int u = 0; u < NS; ++u) {
+            const int i = t + u * 256;
+            if (i < kStateComps * Q) *reinterpret_cast<EnvF4*>(smem + m.state + (i / Q) * E + 4 * (i % Q)) = rs[u];
+        }
+        if (t < 13 * Q) *reinterpret_cast<EnvF4*>(smem + m.root + (i13 / Q) * E + 4 * (i13 % Q)) = r_root;
+        if (t < 12 * Q) {
+            *reinterpret_cast<EnvF4*>(smem + m.dof_pos + (i12 / Q) * E + 4 * (i12 % Q)) = r_dp;
+            *reinterpret_cast<EnvF4*>(smem + m.dof_vel + (i12 / Q) * E + 4 * (i12 % Q)) = r_dv;
+        }
+        if (t < 9 * Q) *reinterpret_cast<EnvF4*>(smem + m.contact + k9 * E + 4 * (i9 % Q)) = r_ct;
+        if (t < 14 * Q) *reinterpret_cast<EnvF4*>(smem + m.rigid + (body * 13 + rcomp) * E + 4 * (i14 % Q)) = r_rg;
+        if (A.actions_in && t < 3 * EE) *reinterpret_cast<EnvF4*>(smem + m.actions_in + 4 * ia) = r_act;
+        if (t < EE / 2) *reinterpret_cast<EnvF4*>(smem + m.ep_len + 4 * ie) = r_ep;
+    } else {
+        copy_comp_rows<true>(nullptr, A, 0, kStateComps, smem + m.state, E, e0, nE, N, t, nthreads);
+        stage_sim<true>(A, m, smem, E, e0, nE, t, nthreads, true);
+        for (int i = t; i < nE; i += nthreads) reinterpret_cast<int64_t*>(smem + m.ep_len)[i] = A.st.episode_length[e0 + i];
+        copy_rows_in(A.actions_in, smem + m.actions_in, 12, e0, nE, t, nthreads);
     }
-    {   // sim tensors through their strides; only the components the step reads
-        const HgymStrided* sv[3] = {&A.sim.root, &A.sim.dof_pos, &A.sim.dof_vel};
-        const int nc[3] = {13, 12, 12};
-        const int off[3] = {m.root, m.dof_pos, m.dof_vel};
-        for (int k = 0; k < 3; ++k)
-            for (int i = t; i < nc[k] * E; i += nthreads) {
-                const int c = i / E, le = i - c * E;
-                smem[off[k] + i] = (le < nE) ? sget(*sv[k], e0 + le, c) : 0.0f;
-            }
-        for (int i = t; i < 9 * E; i += nthreads) {
-            const int c = i / E, le = i - c * E;
-            smem[m.contact + i] = (le < nE) ? sget(A.sim.contact, e0 + le, A.contact_comp[c / 3] + c % 3) : 0.0f;
-        }
-        for (int i = t; i < 14 * E; i += nthreads) {   // feet {x,y,z,vx,vy}, knees {x,y}
-            const int q = i / E, le = i - q * E;
-            const int body = q < 10 ? q / 5 : 2 + (q - 10) / 2;
-            const int comp = q < 10 ? kFootRigidComps[q % 5] : kKneeRigidComps[(q - 10) % 2];
-            smem[m.rigid + (body * 13 + comp) * E + le] = (le < nE) ? sget(A.sim.rigid, e0 + le, A.rigid_comp[body] + comp) : 0.0f;
-        }
-    }
-    for (int i = t; i < nE; i += nthreads) reinterpret_cast<int64_t*>(smem + m.ep_len)[i] = A.st.episode_length[e0 + i];
-    copy_rows_in(A.actions_in, smem + m.actions_in, 12, e0, nE, t, nthreads);
     copy_rows_in(A.noise.u_delay, smem + m.u_delay, 1, e0, nE, t, nthreads);
     copy_rows_in(A.noise.z_act, smem + m.z_act, 12, e0, nE, t, nthreads);
     copy_rows_in(A.noise.u_cmd, smem + m.u_cmd, 6, e0, nE, t, nthreads);
     copy_rows_in(A.noise.u_dof, smem + m.u_dof, 12, e0, nE, t, nthreads);
     copy_rows_in(A.noise.u_push, smem + m.u_push, 5, e0, nE, t, nthreads);
+    copy_rows_in(A.noise.z_obs, smem + m.z_obs, HGYM_OBS_FRAME, e0, nE, t, nthreads);
+    for (int i = t; i < HGYM_OBS_FRAME; i += nthreads) smem[m.noise_vec + i] = A.cfg.obs_noise[i];
+}
+
+// Random draws not supplied by the caller, one Philox call per work item, into the LDS tables (row-major per env,
+// same widths as the caller's tables).  Values are exactly uniform_at / normal_at of hgym_common.hpp.
+// Work item = (call c, env): consecutive lanes take consecutive envs of the SAME call, and every call runs the same
+// instruction stream (Philox, then uniforms or a Box-Muller pair), so a wavefront never serialises over call kinds.
+constexpr int kDrawCalls = 1 + 1 + 3 + 3 + 2 + 12 + kPhysCalls;   // delay+cmd | cmd reset | act | dof | push | obs | phys
+struct DrawCall {
+    uint32_t slot;   // Philox counter word
+    int normal;      // 1: two Box-Muller pairs, 0: four uniforms
+    int active;      // 0: every output of this call was supplied by the caller (or is not needed in this mode)
+};
+HG_HD DrawCall draw_call(const EnvArgs& A, int c, bool phys) {
+    DrawCall d;
+    if (c == 0) d = DrawCall{SLOT_DELAY_CMD, 0, !(A.noise.u_delay && A.noise.u_cmd)};
+    else if (c == 1) d = DrawCall{SLOT_CMD_RESET, 0, !A.noise.u_cmd};
+    else if (c < 5) d = DrawCall{SLOT_ACT + (uint32_t)(c - 2), 1, !A.noise.z_act && A.actions_in != nullptr};
+    else if (c < 8) d = DrawCall{SLOT_DOF + (uint32_t)(c - 5), 0, !A.noise.u_dof};
+    else if (c < 10) d = DrawCall{SLOT_PUSH + (uint32_t)(c - 8), 0, !A.noise.u_push};
+    else if (c < 22) d = DrawCall{SLOT_OBS + (uint32_t)(c - 10), 1, !A.noise.z_obs && A.cfg.add_noise && A.mode != MODE_RESET_ALL};
+    else {
+        const int p = c - 22;
+        d = DrawCall{SLOT_PHYS + (uint32_t)p, (p >= 1 && p <= 3) || (p >= 5 && p <= 7), phys};
+    }
+    return d;
+}
+// LDS float index of output k (0..3) of call c for local env le, or -1 if that output has no consumer
+HG_HD int draw_dest(const EnvArgs& A, const LdsMap& m, int c, int le, int k) {
+    if (c == 0) return k == 0 ? (A.noise.u_delay ? -1 : m.u_delay + le) : (A.noise.u_cmd ? -1 : m.u_cmd + le * 6 + k - 1);
+    if (c == 1) return k < 3 ? m.u_cmd + le * 6 + 3 + k : -1;
+    if (c < 5) return m.z_act + le * 12 + 4 * (c - 2) + k;
+    if (c < 8) return m.u_dof + le * 12 + 4 * (c - 5) + k;
+    if (c < 10) return (4 * (c - 8) + k < 5) ? m.u_push + le * 5 + 4 * (c - 8) + k : -1;
+    if (c < 22) return (4 * (c - 10) + k < HGYM_OBS_FRAME) ? m.z_obs + le * HGYM_OBS_FRAME + 4 * (c - 10) + k : -1;
+    return m.phys + le * kPhysDraws + 4 * (c - 22) + k;
+}
+
+template <int E_T>
+HG_HD void env_fill_draws(const EnvArgs& A, int block, int t, int nthreads, float* smem, int64_t csc0) {
+    const int E = E_T > 0 ? E_T : A.envs_per_block;
+    const int N = A.cfg.num_envs, e0 = block * E;
+    const int nE = (E < N - e0) ? E : (N - e0);
+    const LdsMap m = lds_map(E);
+    const RngKey rk = make_rng_key(A, csc0);
+    const bool phys = A.mode == MODE_STEP && A.fused;
+    for (int i = t; i < E * kDrawCalls; i += nthreads) {
+        const int c = i / E, le = i - c * E;
+        const DrawCall d = draw_call(A, c, phys);
+        if (!d.active || le >= nE) continue;
+        const U4 r = rng4(rk, (uint32_t)(e0 + le), d.slot);
+        float v[4];
+        if (d.normal) {
+            box_muller(r.x, r.y, v[0], v[1]);
+            box_muller(r.z, r.w, v[2], v[3]);
+        } else {
+            v[0] = u01(r.x); v[1] = u01(r.y); v[2] = u01(r.z); v[3] = u01(r.w);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int dst = draw_dest(A, m, c, le, k);
+            if (dst >= 0) smem[dst] = v[k];
+        }
+    }
+}
+
+// action filter + synthetic joint integration, one (env, joint) pair per lane (fused backend only)
+constexpr int kStateOffActions = 4;     // component offsets of state fields inside the [136][E] LDS image
+constexpr int kStateOffTorques = 4 + 12 * 4 + 6;
+template <int E_T>
+HG_HD void env_step_joints(const EnvArgs& A, int block, int t, int nthreads, float* smem) {
+    const int E = E_T > 0 ? E_T : A.envs_per_block;
+    const int N = A.cfg.num_envs, e0 = block * E;
+    const int nE = (E < N - e0) ? E : (N - e0);
+    if (!(A.mode == MODE_STEP && A.fused) || (A.ablate & 16)) return;
+    const LdsMap m = lds_map(E);
+    // works on the LDS image directly (no shadow struct): the per-joint constants are indexed by a lane-varying j and
+    // must be read from the kernel argument itself, not from a per-lane copy of it
+    for (int i = t; i < 12 * E; i += nthreads) {
+        const int j = i / E, le = i - j * E;
+        if (le >= nE) continue;
+        float* act = smem + m.state + (kStateOffActions + j) * E + le;
+        const float a = filter_action(A.cfg, smem[m.actions_in + le * 12 + j], *act, smem[m.u_delay + le], smem[m.z_act + le * 12 + j]);
+        *act = a;
+        float q = smem[m.dof_pos + j * E + le], qd = smem[m.dof_vel + j * E + le], tq;
+        integrate_joint(A.cfg, j, a, q, qd, tq);
+        smem[m.state + (kStateOffTorques + j) * E + le] = tq;
+        smem[m.dof_pos + j * E + le] = q;
+        smem[m.dof_vel + j * E + le] = qd;
+    }
 }
 
 template <int E_T>
@@ -883,10 +1063,7 @@ HG_HD void env_step_phase_a(const EnvArgs& A, int block, int t, float* smem, int
     const LdsMap m = lds_map(E);
     const EnvArgs S = make_shadow(A, smem, block, E);
     const RngKey rk = make_rng_key(A, csc0);
-    if (A.mode == MODE_STEP && A.fused && !(A.ablate & 16)) {
-        pre_physics_env(S, rk, t, E);
-        synth_physics_env(S, rk, t, E);
-    }
+    if (A.mode == MODE_STEP && A.fused && !(A.ablate & 16)) synth_rest_env(S, smem + m.phys + t * kPhysDraws, t, E);
     StepFlags fl;
     fl.reset = 0;
     if (!(A.ablate & 32))
@@ -900,38 +1077,8 @@ HG_HD void env_stage_out(const EnvArgs& A, int block, int t, int nthreads, float
     const int N = A.cfg.num_envs, e0 = block * E;
     const int nE = (E < N - e0) ? E : (N - e0);
     const LdsMap m = lds_map(E);
-    int o = m.state;
-    for (int f = 0; f < kFirstConstField; ++f) {
-        const int nc = state_field_comps(f);
-        float* g = *state_field_ptr(A.st, f);
-        for (int i = t; i < nc * E; i += nthreads) {
-            const int c = i / E, le = i - c * E;
-            if (le < nE) g[(int64_t)c * N + e0 + le] = smem[o + i];
-        }
-        o += nc * E;
-    }
-    {
-        const HgymStrided* sv[3] = {&A.sim.root, &A.sim.dof_pos, &A.sim.dof_vel};
-        const int nc[3] = {13, 12, 12};
-        const int off[3] = {m.root, m.dof_pos, m.dof_vel};
-        for (int k = 0; k < 3; ++k)
-            for (int i = t; i < nc[k] * E; i += nthreads) {
-                const int c = i / E, le = i - c * E;
-                if (le < nE) sset(*sv[k], e0 + le, c, smem[off[k] + i]);
-            }
-        if (A.mode == MODE_STEP && A.fused) {   // the synthetic physics wrote contacts and rigid-body entries
-            for (int i = t; i < 9 * E; i += nthreads) {
-                const int c = i / E, le = i - c * E;
-                if (le < nE) sset(A.sim.contact, e0 + le, A.contact_comp[c / 3] + c % 3, smem[m.contact + i]);
-            }
-            for (int i = t; i < 14 * E; i += nthreads) {
-                const int q = i / E, le = i - q * E;
-                const int body = q < 10 ? q / 5 : 2 + (q - 10) / 2;
-                const int comp = q < 10 ? kFootRigidComps[q % 5] : kKneeRigidComps[(q - 10) % 2];
-                if (le < nE) sset(A.sim.rigid, e0 + le, A.rigid_comp[body] + comp, smem[m.rigid + (body * 13 + comp) * E + le]);
-            }
-        }
-    }
+    copy_comp_rows<false>(nullptr, A, 0, kMutableComps, smem + m.state, E, e0, nE, N, t, nthreads);
+    stage_sim<false>(A, m, smem, E, e0, nE, t, nthreads, A.mode == MODE_STEP && A.fused);   // the synthetic physics wrote contacts / rigid bodies
     const uint8_t* fl = reinterpret_cast<const uint8_t*>(smem + m.flags);
     for (int i = t; i < nE; i += nthreads) {
         A.st.episode_length[e0 + i] = reinterpret_cast<const int64_t*>(smem + m.ep_len)[i];
@@ -943,32 +1090,217 @@ HG_HD void env_stage_out(const EnvArgs& A, int block, int t, int nthreads, float
     }
 }
 
+// ------------------------------------------------------------------------------------------------ history stacking
+// Stacked, clipped observation rows (humanoid_env.py:250-262, legged_robot.py:105-108), oldest -> newest.
+//   ring      [N][H][F] unclipped frames, the newest goes to slot `slot_new`
+//   clean     the block's clean new frames (LDS, F floats per env); z the block's noise normals (LDS) or null
+// Pass 1 adds the noise to the newest frame and pushes it into the ring.  Pass 2 copies the H-1 older frames: in ring
+// order they are ONE circular run of (H-1)*F floats starting at slot_new+1, so each lane moves 16 bytes (the rows are
+// only 4-byte aligned; gfx950 global accesses need no more) and issues kStackBatch independent loads before its first store.
+struct StackGeom {
+    int E, N, H, HC, e0, nE;
+};
 template <int H_T, int HC_T, int E_T>
-HG_HD void env_step_phase_b(const EnvArgs& A, int block, int t, int nthreads, float* smem, int64_t csc0, int64_t ring_step) {
-    const int E = E_T > 0 ? E_T : A.envs_per_block;
-    const int N = A.cfg.num_envs;
-    const int H = H_T > 0 ? H_T : A.cfg.frame_stack;
-    const int HC = HC_T > 0 ? HC_T : A.cfg.c_frame_stack;
-    const int e0 = block * E;
-    const int nE = (E < N - e0) ? E : (N - e0);
-    const LdsMap m = lds_map(E);
-    const float* s_frame = smem + m.frame;
-    const float* s_priv = smem + m.priv;
+HG_HD StackGeom stack_geom(const EnvArgs& A, int block) {
+    StackGeom g;
+    g.E = E_T > 0 ? E_T : A.envs_per_block;
+    g.N = A.cfg.num_envs;
+    g.H = H_T > 0 ? H_T : A.cfg.frame_stack;
+    g.HC = HC_T > 0 ? HC_T : A.cfg.c_frame_stack;
+    g.e0 = block * g.E;
+    g.nE = (g.E < g.N - g.e0) ? g.E : (g.N - g.e0);
+    return g;
+}
+
+constexpr int kStackBatch = 6;
+
+// Pass "old": the H-1 older frames, oldest -> newest, copied + clipped unconditionally.  It depends on nothing this
+// step computes, so the kernel runs it on the otherwise idle wavefronts WHILE the per-env scalar phase runs; envs that
+// turn out to reset are fixed up afterwards (stack_reset_fix).
+HG_HD void stack_old(const EnvArgs& A, const float* __restrict__ ring, float* __restrict__ dst, int e0, int nE, int H, int F, int slot_new,
+                     int t, int nthreads) {
+    const int row = H * F;
+    const float lim = A.cfg.clip_obs;
+    const int hrow = (H - 1) * F;
+    if (hrow == 0) return;
+    const int ipr = (hrow + 3) >> 2;              // 16-byte items per env row
+    const int total = nE * ipr;
+    const int start = (slot_new + 1) * F;         // first (oldest) element of the circular run
+    for (int base = t; base < total; base += nthreads * kStackBatch) {
+        float v[kStackBatch][4];
+#pragma unroll
+        for (int u = 0; u < kStackBatch; ++u) {
+            const int i = base + u * nthreads;
+            if (i >= total) continue;
+            const int le = i / ipr, d0 = (i - le * ipr) << 2;
+            const int n = hrow - d0 < 4 ? hrow - d0 : 4;
+            int s0 = start + d0;
+            if (s0 >= row) s0 -= row;
+            const float* src = ring + (int64_t)(e0 + le) * row;
+            if (n == 4 && s0 + 3 < row) {
+                const EnvF4 q = *reinterpret_cast<const EnvF4*>(src + s0);
+                v[u][0] = q.v[0]; v[u][1] = q.v[1]; v[u][2] = q.v[2]; v[u][3] = q.v[3];
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    int sk = s0 + k;
+                    if (sk >= row) sk -= row;
+                    v[u][k] = k < n ? src[sk] : 0.0f;
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kStackBatch; ++u) {
+            const int i = base + u * nthreads;
+            if (i >= total) continue;
+            const int le = i / ipr, d0 = (i - le * ipr) << 2;
+            const int n = hrow - d0 < 4 ? hrow - d0 : 4;
+            float* dp = dst + (int64_t)le * row + d0;
+            if (n == 4) {
+                const EnvF4 q = {{clampf(v[u][0], -lim, lim), clampf(v[u][1], -lim, lim), clampf(v[u][2], -lim, lim), clampf(v[u][3], -lim, lim)}};
+                *reinterpret_cast<EnvF4*>(dp) = q;
+            } else {
+                for (int k = 0; k < n; ++k) dp[k] = clampf(v[u][k], -lim, lim);
+            }
+        }
+    }
+}
+
+// Pass "new": the newest frame gets its noise, is pushed into the ring slot and written (clipped) as the last row.
+template <bool kNoisy>
+HG_HD void stack_new(const EnvArgs& A, float* __restrict__ ring, const float* clean_all, const float* z_all, const float* noise_vec,
+                     float* __restrict__ dst, int e0, int nE, int H, int F, int slot_new, int t, int nthreads) {
+    const int row = H * F;
+    const float lim = A.cfg.clip_obs;
+    for (int i = t; i < nE * F; i += nthreads) {
+        const int le = i / F, k = i - le * F;
+        const int e = e0 + le;
+        float v = clean_all[i];
+        if (kNoisy && A.cfg.add_noise) {
+            const float ns = noise_vec[k];
+            if (ns != 0.0f) v = v + z_all[i] * ns * A.cfg.noise_level;
+            else v = v + 0.0f;   // clean + z*0*level in the reference
+        }
+        ring[((int64_t)e * H + slot_new) * F + k] = v;
+        dst[(int64_t)le * row + (H - 1) * F + k] = clampf(v, -lim, lim);
+    }
+}
+
+// Envs that reset this step: their history is cleared (humanoid_env.py:264-269) -- older frames of the output row and
+// of the ring become zero.  Rare (a handful of envs per step), so a plain element loop per flagged env.
+HG_HD void stack_reset_fix(float* __restrict__ ring, const int* s_reset, float* __restrict__ dst, int e0, int nE, int H, int F, int slot_new,
+                           int t, int nthreads, bool zero_dst) {
+    const int row = H * F, hrow = (H - 1) * F;
+    const int start = (slot_new + 1) * F;
+    for (int le = 0; le < nE; ++le) {
+        if (!s_reset[le]) continue;
+        float* rp = ring + (int64_t)(e0 + le) * row;
+        float* dp = dst + (int64_t)le * row;
+        for (int i = t; i < hrow; i += nthreads) {
+            int sk = start + i;
+            if (sk >= row) sk -= row;
+            rp[sk] = 0.0f;
+            if (zero_dst) dp[i] = 0.0f;
+        }
+    }
+}
+
+// Register-prefetched form of the older-frames copy for the compiled-in geometry: every lane issues ALL of its history
+// loads at kernel entry, back to back, together with the state staging loads -- one memory round trip for the whole
+// step -- and stores them, clipped and reset-aware, after the per-env phase.
+// The H-1 older frames are, in ring order, two straight segments: A = [(slot+1)*F, H*F) and B = [0, slot*F).  Each is cut
+// into 16-byte items; the last item of a segment is shifted back to END at the segment end (it overlaps its neighbour and
+// rewrites identical values), so every item is one unconditional unaligned 16-byte load and one 16-byte store: no
+// branches, nothing for the compiler to serialise.  Surplus item slots repeat the last item.
+template <int H, int F>
+struct HistGeom {
+    static constexpr int kRow = H * F;
+    static constexpr int kSlots = ((H - 1) * F + 3) / 4 + 1;    // item slots per env row (covers any split into A and B)
+};
+template <int H, int F, int E, int NT>
+HG_HD constexpr int hist_ni() { return H > 1 ? (E * HistGeom<H, F>::kSlots + NT - 1) / NT : 0; }
+
+// item slot j of an env row -> (ring offset, row offset); slot_new = ring slot that receives the newest frame
+template <int H, int F>
+HG_HD void hist_slot(int slot_new, int j, int& src_off, int& dst_off) {
+    const int LA = (H - 1 - slot_new) * F, LB = slot_new * F;
+    const int nA = (LA + 3) >> 2, nB = (LB + 3) >> 2;
+    j = j < nA + nB - 1 ? j : nA + nB - 1;                       // surplus slots repeat the last item
+    const bool inA = j < nA;
+    const int k = inA ? j : j - nA;
+    const int L = inA ? LA : LB;
+    int o = 4 * k;
+    o = o < L - 4 ? o : L - 4;                                   // last item of a segment ends at the segment end
+    src_off = inA ? (slot_new + 1) * F + o : o;
+    dst_off = inA ? o : LA + o;
+}
+template <int H, int F, int NI>
+HG_HD void hist_load(const float* __restrict__ ring, int e0, int nE, int slot_new, int t, int nthreads, float (&v)[NI > 0 ? NI : 1][4]) {
+    constexpr int S = HistGeom<H, F>::kSlots, ROW = HistGeom<H, F>::kRow;
+#pragma unroll
+    for (int u = 0; u < NI; ++u) {
+        int i = t + u * nthreads;
+        i = i < nE * S ? i : nE * S - 1;
+        const int le = i / S;
+        int so, d_o;
+        hist_slot<H, F>(slot_new, i - le * S, so, d_o);
+        const EnvF4 q = *reinterpret_cast<const EnvF4*>(ring + (int64_t)(e0 + le) * ROW + so);
+        v[u][0] = q.v[0]; v[u][1] = q.v[1]; v[u][2] = q.v[2]; v[u][3] = q.v[3];
+    }
+}
+template <int H, int F, int NI>
+HG_HD void hist_store(float* __restrict__ dst, int e0, int nE, int slot_new, int t, int nthreads, const int* s_reset, float lim,
+                      const float (&v)[NI > 0 ? NI : 1][4]) {
+    constexpr int S = HistGeom<H, F>::kSlots, ROW = HistGeom<H, F>::kRow;
+#pragma unroll
+    for (int u = 0; u < NI; ++u) {
+        int i = t + u * nthreads;
+        i = i < nE * S ? i : nE * S - 1;
+        const int le = i / S;
+        int so, d_o;
+        hist_slot<H, F>(slot_new, i - le * S, so, d_o);
+        const bool rs = s_reset[le] != 0;
+        EnvF4 q;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) q.v[k] = rs ? 0.0f : clampf(v[u][k], -lim, lim);
+        *reinterpret_cast<EnvF4*>(dst + (int64_t)(e0 + le) * ROW + d_o) = q;
+    }
+}
+
+// older frames of both outputs; (t, nthreads) may be any subset of the workgroup's lanes
+template <int H_T, int HC_T, int E_T>
+HG_HD void env_step_stack_old(const EnvArgs& A, int block, int t, int nthreads, int64_t ring_step) {
+    if (A.mode == MODE_RESET_ALL) return;
+    const StackGeom g = stack_geom<H_T, HC_T, E_T>(A, block);
+    stack_old(A, A.st.obs_ring, A.out.obs + (int64_t)g.e0 * g.H * HGYM_OBS_FRAME, g.e0, g.nE, g.H, HGYM_OBS_FRAME, (int)(ring_step % g.H), t,
+              nthreads);
+    stack_old(A, A.st.priv_ring, A.out.priv_obs + (int64_t)g.e0 * g.HC * HGYM_PRIV_FRAME, g.e0, g.nE, g.HC, HGYM_PRIV_FRAME,
+              (int)(ring_step % g.HC), t, nthreads);
+}
+
+template <int H_T, int HC_T, int E_T>
+HG_HD void env_step_phase_b(const EnvArgs& A, int block, int t, int nthreads, float* smem, int64_t csc0, int64_t ring_step,
+                            bool old_rows_final = false) {
+    const StackGeom g = stack_geom<H_T, HC_T, E_T>(A, block);
+    const int H = g.H, HC = g.HC, e0 = g.e0, nE = g.nE;
+    const LdsMap m = lds_map(g.E);
     const int* s_reset = reinterpret_cast<const int*>(smem + m.reset_i);
-    const RngKey rk = make_rng_key(A, csc0);
+    (void)csc0;
+    float* ro = A.st.obs_ring + (int64_t)e0 * H * HGYM_OBS_FRAME;
+    float* rp = A.st.priv_ring + (int64_t)e0 * HC * HGYM_PRIV_FRAME;
     if (A.mode == MODE_RESET_ALL) {   // reset_idx(all) without compute_observations: just clear the history
         const int64_t no = (int64_t)nE * H * HGYM_OBS_FRAME, np = (int64_t)nE * HC * HGYM_PRIV_FRAME;
-        float* ro = A.st.obs_ring + (int64_t)e0 * H * HGYM_OBS_FRAME;
-        float* rp = A.st.priv_ring + (int64_t)e0 * HC * HGYM_PRIV_FRAME;
         for (int64_t i = t; i < no; i += nthreads) ro[i] = 0.0f;
         for (int64_t i = t; i < np; i += nthreads) rp[i] = 0.0f;
         return;
     }
-    // actor observations (N, H*47) and privileged observations (N, HC*73): one contiguous run per workgroup
-    stack_rows<true>(A, rk, A.st.obs_ring, s_frame, s_reset, A.out.obs + (int64_t)e0 * H * HGYM_OBS_FRAME, e0, nE, H, HGYM_OBS_FRAME,
-                     (int)(ring_step % H), t, nthreads);
-    stack_rows<false>(A, rk, A.st.priv_ring, s_priv, s_reset, A.out.priv_obs + (int64_t)e0 * HC * HGYM_PRIV_FRAME, e0, nE, HC,
-                      HGYM_PRIV_FRAME, (int)(ring_step % HC), t, nthreads);
+    float* dobs = A.out.obs + (int64_t)e0 * H * HGYM_OBS_FRAME;
+    float* dpriv = A.out.priv_obs + (int64_t)e0 * HC * HGYM_PRIV_FRAME;
+    stack_new<true>(A, A.st.obs_ring, smem + m.frame, smem + m.z_obs, smem + m.noise_vec, dobs, e0, nE, H, HGYM_OBS_FRAME,
+                    (int)(ring_step % H), t, nthreads);
+    stack_new<false>(A, A.st.priv_ring, smem + m.priv, nullptr, nullptr, dpriv, e0, nE, HC, HGYM_PRIV_FRAME, (int)(ring_step % HC), t, nthreads);
+    stack_reset_fix(A.st.obs_ring, s_reset, dobs, e0, nE, H, HGYM_OBS_FRAME, (int)(ring_step % H), t, nthreads, !old_rows_final);
+    stack_reset_fix(A.st.priv_ring, s_reset, dpriv, e0, nE, HC, HGYM_PRIV_FRAME, (int)(ring_step % HC), t, nthreads, !old_rows_final);
 }
 
 // Step finaliser: the cross-env pieces of reset_idx (legged_robot.py:199-210) -- means of the episode sums

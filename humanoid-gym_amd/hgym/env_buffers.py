@@ -44,7 +44,13 @@ class EnvBuffers:
         H, HC = int(cfg.frame_stack), int(cfg.c_frame_stack)
         dev = self.device
         z = lambda *s, dtype=torch.float32: torch.zeros(*s, dtype=dtype, device=dev)
-        self.f = {name: z(c, N) for name, c in L.ENV_STATE_FIELDS}
+        # one [136][N] allocation, fields adjacent in HgymEnvState order (lets the step kernel stage the state with
+        # plain 16-byte row copies; separately allocated fields also work, through the per-field pointers)
+        self._state = z(sum(c for _, c in L.ENV_STATE_FIELDS), N)
+        self.f, off = {}, 0
+        for name, c in L.ENV_STATE_FIELDS:
+            self.f[name] = self._state[off:off + c]
+            off += c
         self.episode_length = z(N, dtype=torch.int64)
         self.counters = z(4, dtype=torch.int64)
         self.obs_ring = z(N, H, L.OBS_FRAME)

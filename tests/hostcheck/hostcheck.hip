@@ -44,7 +44,13 @@ int hc_env_step(const HgymEnvConfig* cfg, const HgymSimTensors* sim, const HgymE
     std::vector<float> smem(step_smem_bytes(epb) / sizeof(float));
     for (int b = 0; b < blocks; ++b) {
         for (int t = 0; t < nthreads; ++t) env_stage_in<0>(A, b, t, nthreads, smem.data());
+        for (int t = 0; t < nthreads; ++t) env_fill_draws<0>(A, b, t, nthreads, smem.data(), csc0);
+        for (int t = 0; t < nthreads; ++t) env_step_joints<0>(A, b, t, nthreads, smem.data());
         for (int t = 0; t < nthreads; ++t) env_step_phase_a<0>(A, b, t, smem.data(), csc0);
+        for (int t = 0; t < nthreads; ++t) {   // the device runs this on its idle wavefronts, concurrently with phase A
+            if (cfg->frame_stack == 15 && cfg->c_frame_stack == 3) env_step_stack_old<15, 3, 0>(A, b, t, nthreads, ring);
+            else env_step_stack_old<0, 0, 0>(A, b, t, nthreads, ring);
+        }
         for (int t = 0; t < nthreads; ++t) env_stage_out<0>(A, b, t, nthreads, smem.data());
         for (int t = 0; t < nthreads; ++t) {
             if (cfg->frame_stack == 15 && cfg->c_frame_stack == 3) env_step_phase_b<15, 3, 0>(A, b, t, nthreads, smem.data(), csc0, ring);
