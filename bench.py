@@ -149,22 +149,39 @@ def main():
 
     roofline = None
     if rank == 0 and not args.no_roofline:
+        # live per-kernel timing with HIP events on the launch stream (hgym_prof_*).  Events cannot be recorded inside a
+        # replayed HIP graph, so these two iterations run the rollout eagerly (same kernels, same launch order).
+        os.environ["HGYM_GRAPH"] = "0"
         L.lib.hgym_prof_enable(1)
         runner.learn(num_learning_iterations=2, init_at_random_ep_len=False)
         torch.cuda.synchronize()
-        n_g, ms_g, fl = L.prof_summary(L.PROF_GEMM)
-        n_e, ms_e, by = L.prof_summary(L.PROF_ENV_STEP)
+        iter_ms = elapsed / args.steps * 1e3
+        mfma_peak = MFMA_BF16_PEAK_TFLOPS if args.precision == "bf16" else 157.3
+        classes = [  # (class id, kernel, bound, unit of `work`)
+            (L.PROF_ENV_STEP, "env_step_kernel", "hbm"), (L.PROF_MLP_FWD, "mlp_fwd_kernel", "mfma"),
+            (L.PROF_MLP_BWD, "mlp_bwd_kernel", "mfma"), (L.PROF_DW, "dw_kernel", "mfma"), (L.PROF_GEMM, "gemm_nt_kernel", "mfma"),
+            (L.PROF_LOSS, "ppo_loss_kernel", "hbm"), (L.PROF_REDUCE, "reduce_slabs_kernel", "hbm"),
+            (L.PROF_APPLY, "sqnorm+adam_kernel", "hbm"), (L.PROF_GAE, "gae_kernel", "hbm")]
+        traffic = {}
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")     # HBM bytes per launch from rocprofv3 --pmc passes
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get("kernels", {})
+        ks = []
+        for cid, name, bound in classes:
+            n, ms, work = L.prof_summary(cid)
+            if n == 0 or ms <= 0:
+                continue
+            peak, unit, scale = (HBM_PEAK_GBS, "GB/s", 1e9) if bound == "hbm" else (mfma_peak, "TFLOP/s", 1e12)
+            ach = work / (ms * 1e-3) / scale
+            ks.append(dict(kernel=name, bound=bound, launches_per_iter=n // 2, avg_launch_us=ms / n * 1e3, achieved=ach, peak=peak, unit=unit,
+                           frac=ach / peak, share_of_iteration=ms / 2 / iter_ms, traffic=traffic.get(name)))
         L.lib.hgym_prof_enable(0)
-        gemm = dict(bound="mfma", kernel="gemm_nt_kernel", launches=n_g, avg_us=ms_g / max(n_g, 1) * 1e3,
-                    achieved=fl / (ms_g * 1e-3) / 1e12 if ms_g > 0 else 0.0, peak=MFMA_BF16_PEAK_TFLOPS if args.precision == "bf16" else 157.3,
-                    unit="TFLOP/s", share_of_iteration=ms_g / 2 / (elapsed / args.steps * 1e3))
-        envk = dict(bound="hbm", kernel="env_step_kernel", launches=n_e, avg_us=ms_e / max(n_e, 1) * 1e3,
-                    achieved=by / (ms_e * 1e-3) / 1e9 if ms_e > 0 else 0.0, peak=HBM_PEAK_GBS, unit="GB/s",
-                    share_of_iteration=ms_e / 2 / (elapsed / args.steps * 1e3))
-        dom, other = (gemm, envk) if ms_g >= ms_e else (envk, gemm)
-        roofline = dict(bound=dom["bound"], achieved=dom["achieved"], peak=dom["peak"], unit=dom["unit"],
-                        frac=dom["achieved"] / dom["peak"], traffic=None, kernel=dom["kernel"], launches_per_iter=dom["launches"] // 2,
-                        avg_launch_us=dom["avg_us"], share_of_iteration=dom["share_of_iteration"], second=other)
+        os.environ["HGYM_GRAPH"] = "1"
+        ks.sort(key=lambda k: -k["share_of_iteration"])
+        dom = ks[0]
+        roofline = dict(bound=dom["bound"], achieved=dom["achieved"], peak=dom["peak"], unit=dom["unit"], frac=dom["frac"],
+                        traffic=dom["traffic"], kernel=dom["kernel"], launches_per_iter=dom["launches_per_iter"],
+                        avg_launch_us=dom["avg_launch_us"], share_of_iteration=dom["share_of_iteration"], kernels=ks[1:])
 
     if dist is not None:
         dist.barrier()

@@ -82,6 +82,8 @@ __device__ __forceinline__ void mma_steps(const u32x4* __restrict__ w0, int wstr
     for (int g = 0; g < G; ++g) wa[g] = wl[(int64_t)g * wstride];
 #pragma unroll
     for (int i = 0; i < MB; ++i) xa[i] = *reinterpret_cast<const u32x4*>(xb + (i * CBx) * 512);
+    // sched_barrier pins the order "issue the loads of the next k-block, then the MFMAs of this one": left alone, the
+    // scheduler sinks every load to just before its first use (fewer live registers) and the loop serialises on memory.
     for (int t = 0; t < nk; t += 2) {
         const bool two = t + 1 < nk;
         if (two) {
@@ -90,22 +92,26 @@ __device__ __forceinline__ void mma_steps(const u32x4* __restrict__ w0, int wstr
 #pragma unroll
             for (int i = 0; i < MB; ++i) xc[i] = *reinterpret_cast<const u32x4*>(xb + (i * CBx + 2 * (t + 1)) * 512);
         }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < MB; ++i)
 #pragma unroll
             for (int g = 0; g < G; ++g) mma_frag<__bf16>(wa[g], xa[i], acc[i][g]);
+        __builtin_amdgcn_sched_barrier(0);
         if (t + 2 < nk) {
 #pragma unroll
             for (int g = 0; g < G; ++g) wa[g] = wl[(int64_t)g * wstride + (t + 2) * 64];
 #pragma unroll
             for (int i = 0; i < MB; ++i) xa[i] = *reinterpret_cast<const u32x4*>(xb + (i * CBx + 2 * (t + 2)) * 512);
         }
+        __builtin_amdgcn_sched_barrier(0);
         if (two) {
 #pragma unroll
             for (int i = 0; i < MB; ++i)
 #pragma unroll
                 for (int g = 0; g < G; ++g) mma_frag<__bf16>(wb[g], xc[i], acc[i][g]);
         }
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -201,15 +207,20 @@ __device__ __forceinline__ void fwd_body(const FwdArgs& a, const FusedNet& n, bo
             lrow[u] = row;
         }
         F4 stg[IT];
+        // one unconditional 16-byte load per item: the address is clamped to the last full vector of the row and the
+        // (at most one per row) straddling item is re-aligned / zero-filled with selects -- no branch around a load
         auto stage_load = [&](int c) {
             const int col = c * FUSED_CHUNK + f4 * 4;
+            const int cc = col < L0.K - 4 ? col : L0.K - 4;
+            const int sh = col - cc;                       // 0 for full items, 1..3 for the straddling one, >= 4: all padding
 #pragma unroll
             for (int u = 0; u < IT; ++u) {
-                if (col + 3 < L0.K) {
-                    stg[u] = *reinterpret_cast<const F4*>(srow[u] + col);
-                } else {
+                const F4 q = *reinterpret_cast<const F4*>(srow[u] + cc);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) stg[u].v[e] = (col + e < L0.K) ? srow[u][col + e] : 0.0f;
+                for (int e = 0; e < 4; ++e) {
+                    const int k = e + sh;
+                    const float v = k == 0 ? q.v[0] : (k == 1 ? q.v[1] : (k == 2 ? q.v[2] : q.v[3]));
+                    stg[u].v[e] = k < 4 ? v : 0.0f;
                 }
             }
         };

@@ -703,7 +703,7 @@ struct NetRunner {
         const int32_t rc = (train || M >= 16384) ? launch_fwd<64, 16>(a, nets) : launch_fwd<32, 8>(a, nets);
         double fl = 0.0;
         for (int i = first; i < first + nets; ++i)
-            for (int l = 0; l < 4; ++l) fl += 2.0 * (double)M * w.net[i].layer[l].N * (w.net[i].layer[l].KBf * 32.0);
+            for (int l = 0; l < 4; ++l) fl += 2.0 * (double)M * w.net[i].layer[l].N * w.net[i].layer[l].K;   // algorithmic (unpadded) flops
         prof_end(HGYM_PROF_MLP_FWD, s, fl);
         return rc;
     }
@@ -763,7 +763,7 @@ struct NetRunner {
             hipLaunchKernelGGL((mlp_bwd_kernel<64, 16>), dim3(Bp / 64, 2), dim3(1024), lds, s, g);
             double fl = 0.0;
             for (int i = 0; i < 2; ++i)
-                for (int l = 1; l < 4; ++l) fl += 2.0 * (double)B * w.net[i].layer[l].K * (w.net[i].layer[l].NBBf * 32.0);
+                for (int l = 1; l < 4; ++l) fl += 2.0 * (double)B * w.net[i].layer[l].K * w.net[i].layer[l].N;
             prof_end(HGYM_PROF_MLP_BWD, s, fl);
             HG_CHECK_LAUNCH("mlp_bwd_kernel");
         }
@@ -789,7 +789,7 @@ struct NetRunner {
                     p.tiles_k = ceil_div(y.K, 128);
                     p.tile0 = tile;
                     tile += p.tiles_n * p.tiles_k;
-                    fl += 2.0 * (double)Bp * p.tiles_n * 128.0 * p.tiles_k * 128.0;
+                    fl += 2.0 * (double)B * y.N * y.K;
                 }
             d.total_tiles = tile;
             d.splits = w.dw_splits;
