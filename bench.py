@@ -159,6 +159,7 @@ def main():
         mfma_peak = MFMA_BF16_PEAK_TFLOPS if args.precision == "bf16" else 157.3
         classes = [  # (class id, kernel, bound, unit of `work`)
             (L.PROF_ENV_STEP, "env_step_kernel", "hbm"), (L.PROF_MLP_FWD, "mlp_fwd_kernel", "mfma"),
+            (L.PROF_POLICY, "mlp_fwd_kernel<32>", "mfma"),
             (L.PROF_MLP_BWD, "mlp_bwd_kernel", "mfma"), (L.PROF_DW, "dw_kernel", "mfma"), (L.PROF_GEMM, "gemm_nt_kernel", "mfma"),
             (L.PROF_LOSS, "ppo_loss_kernel", "hbm"), (L.PROF_REDUCE, "reduce_slabs_kernel", "hbm"),
             (L.PROF_APPLY, "sqnorm+adam_kernel", "hbm"), (L.PROF_GAE, "gae_kernel", "hbm")]

@@ -699,12 +699,13 @@ struct NetRunner {
             a.sigma = smp->sigma;
             a.logp = smp->logp;
         }
-        prof_begin(HGYM_PROF_MLP_FWD, s);
+        const int pcls = train ? HGYM_PROF_MLP_FWD : HGYM_PROF_POLICY;
+        prof_begin(pcls, s);
         const int32_t rc = (train || M >= 16384) ? launch_fwd<64, 16>(a, nets) : launch_fwd<32, 8>(a, nets);
         double fl = 0.0;
         for (int i = first; i < first + nets; ++i)
             for (int l = 0; l < 4; ++l) fl += 2.0 * (double)M * w.net[i].layer[l].N * w.net[i].layer[l].K;   // algorithmic (unpadded) flops
-        prof_end(HGYM_PROF_MLP_FWD, s, fl);
+        prof_end(pcls, s, fl);
         return rc;
     }
 

@@ -142,7 +142,7 @@ SYMBOLS = {
     "hgym_prof_enable": (C.c_int32, [C.c_int32]),
     "hgym_prof_summary": (C.c_int32, [C.c_int32, _P(C.c_int64), _P(C.c_double), _P(C.c_double)]),
 }
-PROF_GEMM, PROF_ENV_STEP, PROF_GAE, PROF_LOSS, PROF_MLP_FWD, PROF_MLP_BWD, PROF_DW, PROF_REDUCE, PROF_APPLY = range(9)
+PROF_GEMM, PROF_ENV_STEP, PROF_GAE, PROF_LOSS, PROF_MLP_FWD, PROF_MLP_BWD, PROF_DW, PROF_REDUCE, PROF_APPLY, PROF_POLICY = range(10)
 
 
 def prof_summary(cls):

@@ -314,12 +314,13 @@ int32_t hgym_ppo_apply(const HgymNetConfig* cfg, const HgymPPOConfig* ppo, const
 enum {
     HGYM_PROF_GEMM = 0,      /* generic MFMA GEMM launches (fp32 parity path / unsupported layer shapes) */
     HGYM_PROF_ENV_STEP = 1, HGYM_PROF_GAE = 2, HGYM_PROF_LOSS = 3,
-    HGYM_PROF_MLP_FWD = 4,   /* fused forward (rollout and update) */
+    HGYM_PROF_MLP_FWD = 4,   /* fused forward, update (64-row tiles, writes the activations) */
     HGYM_PROF_MLP_BWD = 5,   /* fused dZ chain */
     HGYM_PROF_DW = 6,        /* all weight-gradient products */
     HGYM_PROF_REDUCE = 7,    /* split-K slab reduction */
     HGYM_PROF_APPLY = 8,     /* grad-norm + clip + Adam */
-    HGYM_PROF_CLASSES = 9
+    HGYM_PROF_POLICY = 9,    /* fused forward, rollout / inference (32-row tiles, sampling epilogue) */
+    HGYM_PROF_CLASSES = 10
 };
 int32_t hgym_prof_enable(int32_t on);  /* 1: start collecting (clears previous events), 0: stop */
 int32_t hgym_prof_summary(int32_t cls, int64_t* launches, double* total_ms, double* work);

@@ -37,7 +37,7 @@ lp_o = -12.0 + torch.randn(S, device=dev)
 idx = torch.randperm(S, device=dev).contiguous()
 ppo = make_ppo_config()
 batch = make_batch(obs, priv, act, val, adv, ret, lp_o, mu_o, sg_o, idx)
-names = {0: "gemm(all)", 3: "loss", 4: "mlp_fwd", 5: "mlp_bwd", 6: "dw", 7: "reduce", 8: "apply"}
+names = {0: "gemm(all)", 3: "loss", 4: "mlp_fwd", 5: "mlp_bwd", 6: "dw", 7: "reduce", 8: "apply", 9: "policy"}
 def step():
     net.ppo_grad(ppo, batch); net.ppo_apply(ppo)
 t = timeit(step, 20)
