@@ -20,6 +20,10 @@ std::vector<ProfRec> g_rec[HGYM_PROF_CLASSES];
 hipEvent_t g_open[HGYM_PROF_CLASSES];
 }  // namespace
 
+long long* g_phase_buf = nullptr;
+int64_t g_phase_slots = 0;
+// phase-timestamp buffer for a grid of `blocks` workgroups (8 slots each), or null when none is set / it is too small
+long long* phase_buffer(int64_t blocks) { return blocks * 8 <= g_phase_slots ? g_phase_buf : nullptr; }
 bool prof_on() { return g_prof; }
 void prof_begin(int cls, hipStream_t s) {
     if (!g_prof) return;
@@ -57,6 +61,11 @@ int32_t hgym_prof_enable(int32_t on) {
         hgym::g_rec[c].clear();
     }
     hgym::g_prof = on != 0;
+    return HGYM_OK;
+}
+int32_t hgym_prof_phase_buffer(void* dev, int64_t slots) {
+    hgym::g_phase_buf = (long long*)dev;
+    hgym::g_phase_slots = dev ? slots : 0;
     return HGYM_OK;
 }
 int32_t hgym_prof_summary(int32_t cls, int64_t* launches, double* total_ms, double* work) {

@@ -68,48 +68,190 @@ __device__ __forceinline__ u32x2 pack_bf16x4(float a, float b, float c, float d)
 }
 __device__ __forceinline__ float bf16_bits_to_f32(unsigned int lo16) { return __builtin_bit_cast(float, lo16 << 16); }
 
-// acc[i][g] += W(nb0+g, kb0+t) x X(i, t) for t < nk.  w0 -> fragment (nb0, kb0); wstride = fragments between n-blocks (x64).
-// xl -> LDS block layout of the input with CBx column blocks per row block, starting at k-block 0 of this call.
-// Both operand streams are software-pipelined one k-block ahead (the loads of step t+1 are in flight under the MFMAs of t).
-template <int G, int MB>
-__device__ __forceinline__ void mma_steps(const u32x4* __restrict__ w0, int wstride, int nk, const char* xl, int CBx, int lane,
-                                          f32x4 (&acc)[MB][G]) {
+// ---- weight stream ------------------------------------------------------------------------------------------------------
+// The weight fragments of one output strip (G n-blocks) stream from L2 into a register ring of D k-steps per wavefront:
+// slot t % D holds k-step t, and the slot is re-loaded with k-step t + D as soon as its MFMAs have been issued, so D - 1
+// k-steps of loads (D * G KiB per wavefront) are in flight under the MFMAs of one.  L2 latency under load is ~1 us and the
+// MFMAs of a k-step take ~0.1 us: a ring primed ONE layer (or one strip) ahead -- before the epilogue and the barrier of the
+// previous one -- never starts cold.  D = 4 for the 8-wave rollout tiles (2 waves per SIMD, 256 VGPRs each), D = 2 for the
+// 16-wave update tiles (4 waves per SIMD hide the rest).
+template <int G, int D>
+struct WRing {
+    u32x4 w[D][G];
+};
+
+// issue the loads of k-steps [0, min(D, nk)) of the stream whose fragment (g, t) is wl[g * wstride + t * 64]  (wl = w0 + lane)
+// (G <= GR: a ring declared for the widest strip also serves the narrower ones; the unused slots are never allocated)
+template <int G, int D, int GR>
+__device__ __forceinline__ void wring_prime(WRing<GR, D>& R, const u32x4* __restrict__ wl, int wstride, int nk) {
+    static_assert(G <= GR, "ring too narrow");
+    // unconditional (a stream shorter than the ring re-loads its last k-step): the number of loads in flight stays a
+    // compile-time constant, which is what lets the compiler's s_waitcnt placement be exact instead of draining the ring
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        const int t = d < nk ? d : nk - 1;
+#pragma unroll
+        for (int g = 0; g < G; ++g) R.w[d][g] = wl[(int64_t)g * wstride + t * 64];
+    }
+}
+
+// acc[i][g] += W(g, t0 + t) x X(i, t) for t < n, on a ring that holds k-steps t0 .. t0 + D - 1 (t0 % D == 0); refills the
+// ring up to k-step nk_total.  xl -> LDS block layout (CBx column blocks per row block) of k-block t0.  The x fragments
+// are double-buffered one k-step ahead (LDS latency only).
+template <int G, int MB, int D, int XBP = -1, int GR>
+__device__ __forceinline__ void mma_ring(WRing<GR, D>& R, const u32x4* __restrict__ wl, int wstride, int t0, int n, int nk_total,
+                                         const char* xl, int CBx, int lane, f32x4 (&acc)[MB][G]) {
+    static_assert(D % 2 == 0, "x double buffer follows the parity of the ring slot");
+    // x fragments one k-step ahead only where registers allow (tiles of <= 2 row blocks; the 4-row-block update tiles run
+    // 4 waves per SIMD, which covers the LDS latency) unless the caller says otherwise
+    constexpr bool XB = XBP < 0 ? (MB <= 2) : (XBP != 0);
     const int r = lane & 15, q = lane >> 4;
     const char* xb = xl + (q >> 1) * 512 + r * 32 + (q & 1) * 16;
-    const u32x4* wl = w0 + lane;
-    u32x4 wa[G], wb[G], xa[MB], xc[MB];
+    u32x4 xa[MB], xc[XB ? MB : 1];
+    if (XB) {
 #pragma unroll
-    for (int g = 0; g < G; ++g) wa[g] = wl[(int64_t)g * wstride];
+        for (int i = 0; i < MB; ++i) xa[i] = *reinterpret_cast<const u32x4*>(xb + (i * CBx) * 512);
+    }
+    // sched_barrier pins the order "x of the next k-step, MFMAs of this one, refill of this slot": left alone, the scheduler
+    // sinks every load to just before its first use (fewer live registers) and the loop serialises on memory.
+    for (int tt = 0; tt < n; tt += D) {
 #pragma unroll
-    for (int i = 0; i < MB; ++i) xa[i] = *reinterpret_cast<const u32x4*>(xb + (i * CBx) * 512);
-    // sched_barrier pins the order "issue the loads of the next k-block, then the MFMAs of this one": left alone, the
-    // scheduler sinks every load to just before its first use (fewer live registers) and the loop serialises on memory.
-    for (int t = 0; t < nk; t += 2) {
-        const bool two = t + 1 < nk;
-        if (two) {
+        for (int d = 0; d < D; ++d) {
+            const int t = tt + d;
+            if (t < n) {
+                if (XB) {
+                    if (t + 1 < n) {
 #pragma unroll
-            for (int g = 0; g < G; ++g) wb[g] = wl[(int64_t)g * wstride + (t + 1) * 64];
+                        for (int i = 0; i < MB; ++i) {
+                            const u32x4 v = *reinterpret_cast<const u32x4*>(xb + (i * CBx + 2 * (t + 1)) * 512);
+                            if (d & 1) xa[i] = v; else xc[i] = v;
+                        }
+                    }
+                } else {
 #pragma unroll
-            for (int i = 0; i < MB; ++i) xc[i] = *reinterpret_cast<const u32x4*>(xb + (i * CBx + 2 * (t + 1)) * 512);
+                    for (int i = 0; i < MB; ++i) xa[i] = *reinterpret_cast<const u32x4*>(xb + (i * CBx + 2 * t) * 512);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < MB; ++i)
+#pragma unroll
+                    for (int g = 0; g < G; ++g) mma_frag<__bf16>(R.w[d][g], (XB && (d & 1)) ? xc[i] : xa[i], acc[i][g]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (t0 + t + D < nk_total) {
+#pragma unroll
+                    for (int g = 0; g < G; ++g) R.w[d][g] = wl[(int64_t)g * wstride + (t0 + t + D) * 64];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+}
+
+// The two branch-free forms of the above.  Every k-step of the steady state issues the same loads in the same order, so the
+// vmcnt the compiler derives for "slot d is ready" is the exact (D - 1) * G (+ whatever else is in flight); conditions
+// around the refills (as in mma_ring) make its path-merging analysis assume the worst and drain the ring every revolution.
+//
+// mma_stream: a whole stream of nk k-steps (nk % D == 0, nk >= D) whose input is resident in LDS; ring primed with 0..D-1.
+template <int G, int MB, int D, int XBP = -1, int GR>
+__device__ __forceinline__ void mma_stream(WRing<GR, D>& R, const u32x4* __restrict__ wl, int wstride, int nk, const char* xl, int CBx,
+                                           int lane, f32x4 (&acc)[MB][G]) {
+    static_assert(D % 2 == 0, "x double buffer follows the parity of the ring slot");
+    constexpr bool XB = XBP < 0 ? (MB <= 2) : (XBP != 0);
+    const int r = lane & 15, q = lane >> 4;
+    const char* xb = xl + (q >> 1) * 512 + r * 32 + (q & 1) * 16;
+    u32x4 xa[MB], xc[XB ? MB : 1];
+    if (XB) {
+#pragma unroll
+        for (int i = 0; i < MB; ++i) xa[i] = *reinterpret_cast<const u32x4*>(xb + (i * CBx) * 512);
+    }
+    int tt = 0;
+    for (; tt + D < nk; tt += D) {          // steady state: refill every slot
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const int t = tt + d;
+            if (XB) {
+#pragma unroll
+                for (int i = 0; i < MB; ++i) {
+                    const u32x4 v = *reinterpret_cast<const u32x4*>(xb + (i * CBx + 2 * (t + 1)) * 512);
+                    if (d & 1) xa[i] = v; else xc[i] = v;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < MB; ++i) xa[i] = *reinterpret_cast<const u32x4*>(xb + (i * CBx + 2 * t) * 512);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < MB; ++i)
+#pragma unroll
+                for (int g = 0; g < G; ++g) mma_frag<__bf16>(R.w[d][g], (XB && (d & 1)) ? xc[i] : xa[i], acc[i][g]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int g = 0; g < G; ++g) R.w[d][g] = wl[(int64_t)g * wstride + (t + D) * 64];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < D; ++d) {           // last revolution: no refills
+        const int t = tt + d;
+        if (XB) {
+            if (d + 1 < D) {
+#pragma unroll
+                for (int i = 0; i < MB; ++i) {
+                    const u32x4 v = *reinterpret_cast<const u32x4*>(xb + (i * CBx + 2 * (t + 1)) * 512);
+                    if (d & 1) xa[i] = v; else xc[i] = v;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < MB; ++i) xa[i] = *reinterpret_cast<const u32x4*>(xb + (i * CBx + 2 * t) * 512);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < MB; ++i)
 #pragma unroll
-            for (int g = 0; g < G; ++g) mma_frag<__bf16>(wa[g], xa[i], acc[i][g]);
+            for (int g = 0; g < G; ++g) mma_frag<__bf16>(R.w[d][g], (XB && (d & 1)) ? xc[i] : xa[i], acc[i][g]);
         __builtin_amdgcn_sched_barrier(0);
-        if (t + 2 < nk) {
+    }
+}
+
+// mma_chunk: the 4 k-steps t0 .. t0 + 3 (t0 % 4 == 0, D divides 4) of a stream whose input arrives in 4-k-block LDS chunks
+// (first layer).  LAST: this is the final chunk, nothing beyond k-step t0 + 3 exists.
+template <int G, int MB, int D, bool LAST, int GR>
+__device__ __forceinline__ void mma_chunk(WRing<GR, D>& R, const u32x4* __restrict__ wl, int wstride, int t0, const char* xl, int CBx,
+                                          int lane, f32x4 (&acc)[MB][G]) {
+    static_assert(D == 2 || D == 4, "ring depth must divide the chunk");
+    constexpr bool XB = MB <= 2;
+    const int r = lane & 15, q = lane >> 4;
+    const char* xb = xl + (q >> 1) * 512 + r * 32 + (q & 1) * 16;
+    u32x4 xa[MB], xc[XB ? MB : 1];
+    if (XB) {
 #pragma unroll
-            for (int g = 0; g < G; ++g) wa[g] = wl[(int64_t)g * wstride + (t + 2) * 64];
+        for (int i = 0; i < MB; ++i) xa[i] = *reinterpret_cast<const u32x4*>(xb + (i * CBx) * 512);
+    }
 #pragma unroll
-            for (int i = 0; i < MB; ++i) xa[i] = *reinterpret_cast<const u32x4*>(xb + (i * CBx + 2 * (t + 2)) * 512);
+    for (int s4 = 0; s4 < 4; ++s4) {
+        const int d = s4 % D;
+        if (XB) {
+            if (s4 + 1 < 4) {
+#pragma unroll
+                for (int i = 0; i < MB; ++i) {
+                    const u32x4 v = *reinterpret_cast<const u32x4*>(xb + (i * CBx + 2 * (s4 + 1)) * 512);
+                    if (s4 & 1) xa[i] = v; else xc[i] = v;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < MB; ++i) xa[i] = *reinterpret_cast<const u32x4*>(xb + (i * CBx + 2 * s4) * 512);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (two) {
 #pragma unroll
-            for (int i = 0; i < MB; ++i)
+        for (int i = 0; i < MB; ++i)
 #pragma unroll
-                for (int g = 0; g < G; ++g) mma_frag<__bf16>(wb[g], xc[i], acc[i][g]);
+            for (int g = 0; g < G; ++g) mma_frag<__bf16>(R.w[d][g], (XB && (s4 & 1)) ? xc[i] : xa[i], acc[i][g]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!LAST || s4 + D < 4) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) R.w[d][g] = wl[(int64_t)g * wstride + (t0 + s4 + D) * 64];
         }
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -144,19 +286,42 @@ __device__ __forceinline__ void zero_acc(f32x4 (&acc)[MB][G]) {
         for (int g = 0; g < G; ++g) acc[i][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
 }
 
-// one hidden layer whose whole input is resident in LDS: waves split the n-blocks, G per pass
-template <int G, int MB, int NW>
-__device__ __forceinline__ void hidden_layer(const FusedLayer& L, const char* in_lds, int CBin, char* out_lds, __bf16* Hg, int64_t mbg0,
-                                             int wave, int lane) {
+// one hidden layer whose whole input is resident in LDS: waves split the n-blocks, G per strip.  R holds the primed stream
+// of this wave's first strip (hidden_prime).  With AHEAD (8-wave tiles: registers to spare) `prime_next` is called before the
+// epilogue of the last strip, so the following layer's stream is in flight across the epilogue and the barrier; without it
+// the caller primes after the barrier.
+template <int G, int D, int GR>
+__device__ __forceinline__ void hidden_prime(WRing<GR, D>& R, const FusedLayer& L, int wave, int lane) {
+    const int nb0 = wave * G;
+    if (nb0 < L.NB) wring_prime<G, D>(R, L.Wf + (int64_t)nb0 * L.KB * 64 + lane, L.KB * 64, L.KB);
+}
+
+template <int G, int MB, int NW, int D, bool AHEAD, int GR, class Next>
+__device__ __forceinline__ void hidden_layer(WRing<GR, D>& R, const FusedLayer& L, const char* in_lds, int CBin, char* out_lds, __bf16* Hg,
+                                             int64_t mbg0, int wave, int lane, Next prime_next) {
+    bool primed = false;
     for (int nb0 = wave * G; nb0 < L.NB; nb0 += NW * G) {
         f32x4 acc[MB][G];
         zero_acc<G, MB>(acc);
-        mma_steps<G, MB>(L.Wf + (int64_t)nb0 * L.KB * 64, L.KB * 64, L.KB, in_lds, CBin, lane, acc);
+        const u32x4* wl = L.Wf + (int64_t)nb0 * L.KB * 64 + lane;
+        if (L.KB % D == 0) mma_stream<G, MB, D>(R, wl, L.KB * 64, L.KB, in_lds, CBin, lane, acc);
+        else mma_ring<G, MB, D>(R, wl, L.KB * 64, 0, L.KB, L.KB, in_lds, CBin, lane, acc);
+        const int nxt = nb0 + NW * G;
+        if (nxt < L.NB) wring_prime<G, D>(R, L.Wf + (int64_t)nxt * L.KB * 64 + lane, L.KB * 64, L.KB);
+        else if (AHEAD) { prime_next(); primed = true; }
         epilogue_elu<G, MB>(acc, L.bias, nb0, out_lds, L.NB, Hg, mbg0, lane);
     }
+    if (AHEAD && !primed) prime_next();       // waves without a strip in this layer
+}
+
+// optional phase timestamps (hgym_prof_phase_buffer): thread 0 of every workgroup writes the 100 MHz wall clock at phase
+// boundaries into dbg[(blockIdx.y * gridDim.x + blockIdx.x) * 8 + slot]
+__device__ __forceinline__ void phase_stamp(long long* dbg, int slot) {
+    if (dbg && threadIdx.x == 0) dbg[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + slot] = (long long)__builtin_amdgcn_s_memrealtime();
 }
 
 struct FwdArgs {
+    long long* dbg;
     FusedNet net[2];
     int net0;                 // net index of blockIdx.y == 0
     int M;
@@ -173,7 +338,7 @@ struct FwdArgs {
     float* logp;              // (M,)
 };
 
-template <int BM, int NW, int G1>
+template <int BM, int NW, int D, int G1>
 __device__ __forceinline__ void fwd_body(const FwdArgs& a, const FusedNet& n, bool is_actor, char* smem) {
     constexpr int MB = BM / 16;
     constexpr int IT = BM * 32 / (NW * 64);           // staging items per thread per chunk (BM rows x 32 float4)
@@ -189,6 +354,10 @@ __device__ __forceinline__ void fwd_body(const FwdArgs& a, const FusedNet& n, bo
     const FusedLayer& L2 = n.layer[2];
     const FusedLayer& L3 = n.layer[3];
     const int train = a.train;
+    constexpr bool AHEAD = NW <= 8;
+    constexpr int GH = NW <= 8 ? 2 : 1;   // n-blocks per strip in the hidden layers (widths are multiples of 128 = 8 n-blocks)
+    WRing<GH, D> r1, r2;             // weight streams of the two hidden layers
+    auto prime1 = [&]() { hidden_prime<GH, D>(r1, L1, wave, lane); };
 
     // ---------------------------------------------------------------- layer 0: input streamed in 128-column chunks
     {
@@ -207,28 +376,35 @@ __device__ __forceinline__ void fwd_body(const FwdArgs& a, const FusedNet& n, bo
             lrow[u] = row;
         }
         F4 stg[IT];
-        // one unconditional 16-byte load per item: the address is clamped to the last full vector of the row and the
-        // (at most one per row) straddling item is re-aligned / zero-filled with selects -- no branch around a load
+        // one unconditional 16-byte load per item: the address is clamped to the last full vector of the row.  stage_load
+        // ONLY issues the loads (nothing here may consume them: the data must stay in flight under the MFMAs of the current
+        // chunk); stage_write re-aligns / zero-fills the (at most one per row) straddling item with selects, converts and
+        // stores to LDS.
         auto stage_load = [&](int c) {
+            const int col = c * FUSED_CHUNK + f4 * 4;
+            const int cc = col < L0.K - 4 ? col : L0.K - 4;
+#pragma unroll
+            for (int u = 0; u < IT; ++u) stg[u] = *reinterpret_cast<const F4*>(srow[u] + cc);
+        };
+        auto stage_write = [&](int c, int buf) {
+            char* dst = Q + buf * (BM * FUSED_CHUNK * 2);
             const int col = c * FUSED_CHUNK + f4 * 4;
             const int cc = col < L0.K - 4 ? col : L0.K - 4;
             const int sh = col - cc;                       // 0 for full items, 1..3 for the straddling one, >= 4: all padding
 #pragma unroll
             for (int u = 0; u < IT; ++u) {
-                const F4 q = *reinterpret_cast<const F4*>(srow[u] + cc);
+                float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int k = e + sh;
-                    const float v = k == 0 ? q.v[0] : (k == 1 ? q.v[1] : (k == 2 ? q.v[2] : q.v[3]));
-                    stg[u].v[e] = k < 4 ? v : 0.0f;
+                    float r = 0.0f;
+                    r = k == 0 ? stg[u].v[0] : r;
+                    r = k == 1 ? stg[u].v[1] : r;
+                    r = k == 2 ? stg[u].v[2] : r;
+                    r = k == 3 ? stg[u].v[3] : r;
+                    v[e] = r;
                 }
-            }
-        };
-        auto stage_write = [&](int c, int buf) {
-            char* dst = Q + buf * (BM * FUSED_CHUNK * 2);
-#pragma unroll
-            for (int u = 0; u < IT; ++u) {
-                const u32x2 pk = pack_bf16x4(stg[u].v[0], stg[u].v[1], stg[u].v[2], stg[u].v[3]);
+                const u32x2 pk = pack_bf16x4(v[0], v[1], v[2], v[3]);
                 const int inblk = (lrow[u] & 15) * 32 + (f4 & 3) * 8;
                 *reinterpret_cast<u32x2*>(dst + ((lrow[u] >> 4) * 8 + (f4 >> 2)) * 512 + inblk) = pk;
                 if (train)
@@ -239,35 +415,51 @@ __device__ __forceinline__ void fwd_body(const FwdArgs& a, const FusedNet& n, bo
         const int nb0 = wave * G1;
         f32x4 acc[MB][G1];
         zero_acc<G1, MB>(acc);
+        WRing<G1, D> r0;
+        const u32x4* wl0 = L0.Wf + (int64_t)nb0 * L0.KB * 64 + lane;
+        phase_stamp(a.dbg, 0);
+        wring_prime<G1, D>(r0, wl0, L0.KB * 64, L0.KB);
         stage_load(0);
         stage_write(0, 0);
         __syncthreads();
-        for (int c = 0; c < NC; ++c) {
-            if (c + 1 < NC) stage_load(c + 1);
-            mma_steps<G1, MB>(L0.Wf + ((int64_t)nb0 * L0.KB + c * 4) * 64, L0.KB * 64, 4, Q + (c & 1) * (BM * FUSED_CHUNK * 2), 8, lane, acc);
-            if (c + 1 < NC) stage_write(c + 1, (c + 1) & 1);
+        phase_stamp(a.dbg, 1);
+        // steady state: no condition inside the body (see mma_stream); the last chunk is peeled
+        for (int c = 0; c + 1 < NC; ++c) {
+            stage_load(c + 1);
+            mma_chunk<G1, MB, D, false>(r0, wl0, L0.KB * 64, c * 4, Q + (c & 1) * (BM * FUSED_CHUNK * 2), 8, lane, acc);
+            stage_write(c + 1, (c + 1) & 1);
             __syncthreads();
         }
+        mma_chunk<G1, MB, D, true>(r0, wl0, L0.KB * 64, (NC - 1) * 4, Q + ((NC - 1) & 1) * (BM * FUSED_CHUNK * 2), 8, lane, acc);
+        phase_stamp(a.dbg, 2);
+        if (AHEAD) prime1();
         epilogue_elu<G1, MB>(acc, L0.bias, nb0, P, L0.NB, train ? n.H[0] : nullptr, mbg0, lane);
     }
     __syncthreads();
+    phase_stamp(a.dbg, 3);
+    if (!AHEAD) prime1();
     // ---------------------------------------------------------------- layers 1, 2: input resident in LDS
-    if (L1.NB >= 2 * NW) hidden_layer<2, MB, NW>(L1, P, L0.NB, Q, train ? n.H[1] : nullptr, mbg0, wave, lane);
-    else hidden_layer<1, MB, NW>(L1, P, L0.NB, Q, train ? n.H[1] : nullptr, mbg0, wave, lane);
+    auto prime2 = [&]() { hidden_prime<GH, D>(r2, L2, wave, lane); };
+    hidden_layer<GH, MB, NW, D, AHEAD>(r1, L1, P, L0.NB, Q, train ? n.H[1] : nullptr, mbg0, wave, lane, prime2);
     __syncthreads();
-    if (L2.NB >= 2 * NW) hidden_layer<2, MB, NW>(L2, Q, L1.NB, P, train ? n.H[2] : nullptr, mbg0, wave, lane);
-    else hidden_layer<1, MB, NW>(L2, Q, L1.NB, P, train ? n.H[2] : nullptr, mbg0, wave, lane);
+    phase_stamp(a.dbg, 4);
+    if (!AHEAD) prime2();
+    WRing<1, 4> r3;                  // head: one 16-row block per wave, L3.KB k-steps of one fragment
+    auto prime3 = [&]() {
+        if (wave < MB) wring_prime<1, 4>(r3, L3.Wf + lane, 0, L3.KB);
+    };
+    hidden_layer<GH, MB, NW, D, AHEAD>(r2, L2, Q, L1.NB, P, train ? n.H[2] : nullptr, mbg0, wave, lane, prime3);
     __syncthreads();
+    phase_stamp(a.dbg, 5);
+    if (!AHEAD) prime3();
     // ---------------------------------------------------------------- head: one wave per 16-row block
     if (wave < MB) {
-        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+        f32x4 hacc[1][1];
+        hacc[0][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
         const int CB3 = L2.NB;
-        const char* xb = P + (q >> 1) * 512 + r * 32 + (q & 1) * 16;
-        for (int kb = 0; kb < L3.KB; ++kb) {
-            const u32x4 w = L3.Wf[kb * 64 + lane];
-            const u32x4 x = *reinterpret_cast<const u32x4*>(xb + (wave * CB3 + 2 * kb) * 512);
-            mma_frag<__bf16>(w, x, acc);
-        }
+        if (L3.KB % 4 == 0) mma_stream<1, 1, 4>(r3, L3.Wf + lane, 0, L3.KB, P + wave * CB3 * 512, CB3, lane, hacc);
+        else mma_ring<1, 1, 4>(r3, L3.Wf + lane, 0, 0, L3.KB, L3.KB, P + wave * CB3 * 512, CB3, lane, hacc);
+        const f32x4 acc = hacc[0][0];
         const int m = m0 + wave * 16 + r;
         const int No = L3.N;
         float mu[4];
@@ -311,37 +503,52 @@ __device__ __forceinline__ void fwd_body(const FwdArgs& a, const FusedNet& n, bo
             if (q == 0 && m < a.M) a.logp[m] = lp;
         }
     }
+    phase_stamp(a.dbg, 6);
 }
 
-template <int BM, int NW>
+template <int BM, int NW, int D>
 __global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(const FwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int which = a.net0 + blockIdx.y;
     const FusedNet& n = a.net[which];
     const int g1 = n.layer[0].NB / NW;     // first hidden width 256 / 512 / 768
     constexpr int U = 16 / NW;             // n-blocks per wave per 256 columns
-    if (g1 == 2 * U) fwd_body<BM, NW, 2 * U>(a, n, which == 0, smem);
-    else if (g1 == 3 * U) fwd_body<BM, NW, 3 * U>(a, n, which == 0, smem);
-    else if (g1 == U) fwd_body<BM, NW, U>(a, n, which == 0, smem);
+    if (g1 == 2 * U) fwd_body<BM, NW, D, 2 * U>(a, n, which == 0, smem);
+    else if (g1 == 3 * U) fwd_body<BM, NW, D, 3 * U>(a, n, which == 0, smem);
+    else if (g1 == U) fwd_body<BM, NW, D, U>(a, n, which == 0, smem);
 }
 
 // ================================================================================================ backward (dX chain)
 struct BwdArgs {
+    long long* dbg;
     FusedNet net[2];
     int net0;
     int M;
 };
 
 // dZ_out[m][k'] = (sum_n dZ_in[m][n] * W[n][k']) * elu'(H[m][k']): W^T fragments as the MFMA A operand.
-template <int G, int MB, int NW>
-__device__ __forceinline__ void bwd_step(const u32x4* __restrict__ WTf, int NBo, int NBBc, const char* in_lds, int CBin, char* out_lds,
-                                         __bf16* __restrict__ dZg, const __bf16* __restrict__ Hg, int64_t mbg0, int wave, int lane) {
+// R: ring primed with this wave's first strip (bwd_prime); prime_next: called before the epilogue of the last strip.
+template <int G, int D, int GR>
+__device__ __forceinline__ void bwd_prime(WRing<GR, D>& R, const u32x4* __restrict__ WTf, int NBo, int NBBc, int wave, int lane) {
+    const int nb0 = wave * G;
+    if (nb0 < NBo) wring_prime<G, D>(R, WTf + (int64_t)nb0 * NBBc * 64 + lane, NBBc * 64, NBBc);
+}
+
+template <int G, int MB, int NW, int D, bool AHEAD, int GR, class Next>
+__device__ __forceinline__ void bwd_step(WRing<GR, D>& R, const u32x4* __restrict__ WTf, int NBo, int NBBc, const char* in_lds, int CBin,
+                                         char* out_lds, __bf16* __restrict__ dZg, const __bf16* __restrict__ Hg, int64_t mbg0, int wave,
+                                         int lane, Next prime_next) {
     const int r = lane & 15, q = lane >> 4;
     const int loff = r * 32 + q * 8;
+    bool primed = false;
     for (int nb0 = wave * G; nb0 < NBo; nb0 += NW * G) {
         f32x4 acc[MB][G];
         zero_acc<G, MB>(acc);
-        mma_steps<G, MB>(WTf + (int64_t)nb0 * NBBc * 64, NBBc * 64, NBBc, in_lds, CBin, lane, acc);
+        if (NBBc % D == 0) mma_stream<G, MB, D>(R, WTf + (int64_t)nb0 * NBBc * 64 + lane, NBBc * 64, NBBc, in_lds, CBin, lane, acc);
+        else mma_ring<G, MB, D>(R, WTf + (int64_t)nb0 * NBBc * 64 + lane, NBBc * 64, 0, NBBc, NBBc, in_lds, CBin, lane, acc);
+        const int nxt = nb0 + NW * G;
+        if (nxt < NBo) wring_prime<G, D>(R, WTf + (int64_t)nxt * NBBc * 64 + lane, NBBc * 64, NBBc);
+        else if (AHEAD) { prime_next(); primed = true; }
         u32x2 aux[MB][G];     // y = elu(z) of this tile (every load is issued before the first store below)
 #pragma unroll
         for (int i = 0; i < MB; ++i)
@@ -363,13 +570,12 @@ __device__ __forceinline__ void bwd_step(const u32x4* __restrict__ WTf, int NBo,
                 *reinterpret_cast<u32x2*>(reinterpret_cast<char*>(dZg) + ((mbg0 + i) * NBo + nb0 + g) * 512 + loff) = pk;
             }
     }
+    if (AHEAD && !primed) prime_next();
 }
 
-template <int BM, int NW>
-__global__ __launch_bounds__(NW * 64) void mlp_bwd_kernel(const BwdArgs a) {
+template <int BM, int NW, int D, int G0>
+__device__ __forceinline__ void bwd_body(const BwdArgs& a, const FusedNet& n, char* smem) {
     constexpr int MB = BM / 16;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const FusedNet& n = a.net[a.net0 + blockIdx.y];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = blockIdx.x * BM;
     const int64_t mbg0 = m0 >> 4;
@@ -377,23 +583,46 @@ __global__ __launch_bounds__(NW * 64) void mlp_bwd_kernel(const BwdArgs a) {
     char* R0 = smem;                    // head gradient tile: BM x 32
     char* R1 = R0 + BM * 64;            // dZ2 tile: BM x N2
     char* R2 = R1 + BM * N2 * 2;        // dZ1 tile: BM x N1
+    constexpr bool AHEAD = NW <= 8;
+    constexpr int GH = NW <= 8 ? 2 : 1;
+    WRing<1, D> ra;
+    WRing<GH, D> rb;
+    WRing<G0, D> rc;
+    phase_stamp(a.dbg, 0);
+    bwd_prime<1, D>(ra, n.layer[3].WTf, N2 / 16, n.layer[3].NBB, wave, lane);
     {
         const u32x4* src = reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(n.dZ[3]) + mbg0 * 2 * 512);
         if (tid < BM * 4) reinterpret_cast<u32x4*>(R0)[tid] = src[tid];
     }
     __syncthreads();
+    auto prime_b = [&]() { bwd_prime<GH, D>(rb, n.layer[2].WTf, N1 / 16, n.layer[2].NBB, wave, lane); };
+    auto prime_c = [&]() { bwd_prime<G0, D>(rc, n.layer[1].WTf, N0 / 16, n.layer[1].NBB, wave, lane); };
+    auto none = [&]() {};
+    phase_stamp(a.dbg, 1);
     // l = 2: through W3 (head)
-    bwd_step<1, MB, NW>(n.layer[3].WTf, N2 / 16, n.layer[3].NBB, R0, 2, R1, n.dZ[2], n.H[2], mbg0, wave, lane);
+    bwd_step<1, MB, NW, D, AHEAD>(ra, n.layer[3].WTf, N2 / 16, n.layer[3].NBB, R0, 2, R1, n.dZ[2], n.H[2], mbg0, wave, lane, prime_b);
     __syncthreads();
+    phase_stamp(a.dbg, 2);
+    if (!AHEAD) prime_b();
     // l = 1: through W2
-    if (N1 / 16 >= 2 * NW) bwd_step<2, MB, NW>(n.layer[2].WTf, N1 / 16, n.layer[2].NBB, R1, N2 / 16, R2, n.dZ[1], n.H[1], mbg0, wave, lane);
-    else bwd_step<1, MB, NW>(n.layer[2].WTf, N1 / 16, n.layer[2].NBB, R1, N2 / 16, R2, n.dZ[1], n.H[1], mbg0, wave, lane);
+    bwd_step<GH, MB, NW, D, AHEAD>(rb, n.layer[2].WTf, N1 / 16, n.layer[2].NBB, R1, N2 / 16, R2, n.dZ[1], n.H[1], mbg0, wave, lane, prime_c);
     __syncthreads();
+    phase_stamp(a.dbg, 3);
+    if (!AHEAD) prime_c();
     // l = 0: through W1 (widest: 256 / 512 / 768 columns)
-    const int g0 = N0 / 16 / NW;
-    if (g0 == 3) bwd_step<3, MB, NW>(n.layer[1].WTf, N0 / 16, n.layer[1].NBB, R2, N1 / 16, nullptr, n.dZ[0], n.H[0], mbg0, wave, lane);
-    else if (g0 == 2) bwd_step<2, MB, NW>(n.layer[1].WTf, N0 / 16, n.layer[1].NBB, R2, N1 / 16, nullptr, n.dZ[0], n.H[0], mbg0, wave, lane);
-    else bwd_step<1, MB, NW>(n.layer[1].WTf, N0 / 16, n.layer[1].NBB, R2, N1 / 16, nullptr, n.dZ[0], n.H[0], mbg0, wave, lane);
+    bwd_step<G0, MB, NW, D, AHEAD>(rc, n.layer[1].WTf, N0 / 16, n.layer[1].NBB, R2, N1 / 16, nullptr, n.dZ[0], n.H[0], mbg0, wave, lane, none);
+    phase_stamp(a.dbg, 4);
+}
+
+template <int BM, int NW, int D>
+__global__ __launch_bounds__(NW * 64) void mlp_bwd_kernel(const BwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const FusedNet& n = a.net[a.net0 + blockIdx.y];
+    const int g0 = n.layer[0].N / 16 / NW;     // first hidden width 256 / 512 / 768
+    constexpr int U = 16 / NW;
+    if (g0 == 2 * U) bwd_body<BM, NW, D, 2 * U>(a, n, smem);
+    else if (g0 == 3 * U) bwd_body<BM, NW, D, 3 * U>(a, n, smem);
+    else if (g0 == U) bwd_body<BM, NW, D, U>(a, n, smem);
 }
 
 // ================================================================================================ weight gradients

@@ -657,7 +657,7 @@ struct NetRunner {
         return f;
     }
 
-    template <int BM, int NW>
+    template <int BM, int NW, int D>
     int32_t launch_fwd(const FwdArgs& a, int nets) {
         size_t lds = 0;
         for (int i = 0; i < nets; ++i) {
@@ -666,12 +666,14 @@ struct NetRunner {
         }
         static size_t attr_lds = 0;
         if (lds > attr_lds) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fwd_kernel<BM, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fwd_kernel<BM, NW, D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
                 hipSuccess)
                 HG_FAIL(HGYM_E_LAUNCH, "cannot reserve %zu bytes of LDS for mlp_fwd_kernel", lds);
             attr_lds = lds;
         }
-        hipLaunchKernelGGL((mlp_fwd_kernel<BM, NW>), dim3(ceil_div(a.M, BM), nets), dim3(NW * 64), lds, s, a);
+        FwdArgs b = a;
+        b.dbg = phase_buffer((int64_t)ceil_div(a.M, BM) * nets);
+        hipLaunchKernelGGL((mlp_fwd_kernel<BM, NW, D>), dim3(ceil_div(a.M, BM), nets), dim3(NW * 64), lds, s, b);
         HG_CHECK_LAUNCH("mlp_fwd_kernel");
         return HGYM_OK;
     }
@@ -701,7 +703,16 @@ struct NetRunner {
         }
         const int pcls = train ? HGYM_PROF_MLP_FWD : HGYM_PROF_POLICY;
         prof_begin(pcls, s);
-        const int32_t rc = (train || M >= 16384) ? launch_fwd<64, 16>(a, nets) : launch_fwd<32, 8>(a, nets);
+        // tile shape / weight-ring depth: 64-row tiles x 16 waves for the update (and huge rollouts), 32-row tiles x 8 waves
+        // otherwise.  HGYM_FWD_TILE / HGYM_RING are tuning overrides for experiments.
+        static const int tile_env = getenv("HGYM_FWD_TILE") ? atoi(getenv("HGYM_FWD_TILE")) : 0;
+        static const int ring_env = getenv("HGYM_RING") ? atoi(getenv("HGYM_RING")) : 0;
+        const int tile = tile_env ? tile_env : ((train || M >= 16384) ? 64 : 32);
+        int32_t rc;
+        static const int waves_env = getenv("HGYM_FWD_WAVES") ? atoi(getenv("HGYM_FWD_WAVES")) : 0;
+        if (tile == 64 && waves_env == 8) rc = launch_fwd<64, 8, 2>(a, nets);
+        else if (tile == 64) rc = launch_fwd<64, 16, 2>(a, nets);
+        else rc = ring_env == 2 ? launch_fwd<32, 8, 2>(a, nets) : launch_fwd<32, 8, 4>(a, nets);
         double fl = 0.0;
         for (int i = first; i < first + nets; ++i)
             for (int l = 0; l < 4; ++l) fl += 2.0 * (double)M * w.net[i].layer[l].N * w.net[i].layer[l].K;   // algorithmic (unpadded) flops
@@ -753,15 +764,16 @@ struct NetRunner {
                 lds = std::max(lds, (size_t)64 * 64 + (size_t)64 * 2 * (w.net[i].layer[2].N + w.net[i].layer[1].N));
             }
             g.M = B;
+            g.dbg = phase_buffer((int64_t)(Bp / 64) * 2);
             static size_t attr_lds = 0;
             if (lds > attr_lds) {
-                if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_bwd_kernel<64, 16>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_bwd_kernel<64, 16, 2>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)lds) != hipSuccess)
                     HG_FAIL(HGYM_E_LAUNCH, "cannot reserve %zu bytes of LDS for mlp_bwd_kernel", lds);
                 attr_lds = lds;
             }
             prof_begin(HGYM_PROF_MLP_BWD, s);
-            hipLaunchKernelGGL((mlp_bwd_kernel<64, 16>), dim3(Bp / 64, 2), dim3(1024), lds, s, g);
+            hipLaunchKernelGGL((mlp_bwd_kernel<64, 16, 2>), dim3(Bp / 64, 2), dim3(1024), lds, s, g);
             double fl = 0.0;
             for (int i = 0; i < 2; ++i)
                 for (int l = 1; l < 4; ++l) fl += 2.0 * (double)B * w.net[i].layer[l].K * w.net[i].layer[l].N;

@@ -140,6 +140,7 @@ SYMBOLS = {
     "hgym_ppo_grad": (C.c_int32, [_P(NetConfig), _P(PPOConfig), _P(Net), _P(Batch), C.c_void_p]),
     "hgym_ppo_apply": (C.c_int32, [_P(NetConfig), _P(PPOConfig), _P(Net), C.c_void_p]),
     "hgym_prof_enable": (C.c_int32, [C.c_int32]),
+    "hgym_prof_phase_buffer": (C.c_int32, [C.c_void_p, C.c_int64]),
     "hgym_prof_summary": (C.c_int32, [C.c_int32, _P(C.c_int64), _P(C.c_double), _P(C.c_double)]),
 }
 PROF_GEMM, PROF_ENV_STEP, PROF_GAE, PROF_LOSS, PROF_MLP_FWD, PROF_MLP_BWD, PROF_DW, PROF_REDUCE, PROF_APPLY, PROF_POLICY = range(10)

@@ -324,6 +324,10 @@ enum {
 };
 int32_t hgym_prof_enable(int32_t on);  /* 1: start collecting (clears previous events), 0: stop */
 int32_t hgym_prof_summary(int32_t cls, int64_t* launches, double* total_ms, double* work);
+/* Kernel-internal phase clock for tuning the fused MLP kernels: while a caller-owned device buffer of `slots` int64 is
+ * set, thread 0 of workgroup b of every mlp_fwd / mlp_bwd launch writes the 100 MHz wall clock at up to 8 phase
+ * boundaries into dev[b*8 + phase] (launches with more than slots/8 workgroups are not instrumented).  NULL: off. */
+int32_t hgym_prof_phase_buffer(void* dev, int64_t slots);
 
 #ifdef __cplusplus
 }

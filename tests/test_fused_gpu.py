@@ -93,11 +93,12 @@ def test_fused_grad_vs_oracle_per_tensor(S, B):
     for k, ref in zip(NAMES, out["grads"].tensors()):
         a, b = gv[k].cpu().double().flatten(), ref.double().flatten()
         l2 = float((a - b).norm() / b.norm().clamp_min(1e-30))
-        # critic: pure bf16 operand rounding (measured 2e-3..1.1e-2).  actor / std: the surrogate gradient carries the factor
+        # critic: pure bf16 operand rounding (measured 2e-3..1.1e-2 on the weight matrices; the 1-element head bias is a
+        # single sum of bf16-rounded dZ over B samples and lands at up to 2.1e-2 for B=333, hence the 3e-2 bound).  actor / std: the surrogate gradient carries the factor
         # ratio = exp(logp - logp_old) and the clip indicator, both functions of mu, so the ~1e-2 bf16 error of mu moves
         # samples across the clip boundary (measured 6e-2..8e-2, identical for the fused and the generic bf16 path;
         # the fp32 path is exact to 1e-5, tests/test_net_gpu.py)
-        tol = 2e-2 if k.startswith("critic") else 0.12
+        tol = 3e-2 if k.startswith("critic") else 0.12
         assert l2 <= tol and _rel(a.numpy(), b.numpy()) <= 0.25, (k, l2, _rel(a.numpy(), b.numpy()))
         num += float(a @ b); da += float(a @ a); db += float(b @ b)
     assert num / (da ** 0.5 * db ** 0.5) > 0.995

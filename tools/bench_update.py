@@ -35,6 +35,8 @@ sg_o = torch.ones(S, 12, device=dev)
 val, adv, ret = torch.randn(S, device=dev), torch.randn(S, device=dev), torch.randn(S, device=dev)
 lp_o = -12.0 + torch.randn(S, device=dev)
 idx = torch.randperm(S, device=dev).contiguous()
+if os.environ.get('HGYM_IDX0'):
+    idx = torch.randint(0, 64, (S,), device=dev)   # every gather hits L2: isolates the input-latency share of mlp_fwd
 ppo = make_ppo_config()
 batch = make_batch(obs, priv, act, val, adv, ret, lp_o, mu_o, sg_o, idx)
 names = {0: "gemm(all)", 3: "loss", 4: "mlp_fwd", 5: "mlp_bwd", 6: "dw", 7: "reduce", 8: "apply", 9: "policy"}
@@ -58,3 +60,7 @@ step_c = torch.zeros(1, dtype=torch.int64, device=dev)
 out = net.act(o4, p4, seed=1, step_counter=step_c)
 t = timeit(lambda: net.act(o4, p4, seed=1, step_counter=step_c, out=out), 50)
 print("policy_act M=4096: %.1f us" % t)
+M = 61440
+out2 = net.act(obs, priv, seed=1, step_counter=step_c)
+t = timeit(lambda: net.act(obs, priv, seed=1, step_counter=step_c, out=out2), 20)
+print("policy_act M=61440 (64-row tiles, no activation stores, no gather): %.1f us" % t)
