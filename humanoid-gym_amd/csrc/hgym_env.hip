@@ -62,9 +62,10 @@ __global__ __launch_bounds__(256) void env_step_kernel(const EnvArgs A) {
     }
 }
 
-__global__ __launch_bounds__(256) void env_finalize_kernel(const EnvArgs A) {
+__global__ __launch_bounds__(1024) void env_finalize_kernel(const EnvArgs A) {
     env_finalize_part1(A, threadIdx.x, blockDim.x);
     __syncthreads();
+    env_finalize_store(A, threadIdx.x, blockDim.x);
     if (threadIdx.x == 0) env_finalize_part2(A);
 }
 
@@ -131,6 +132,7 @@ static int32_t launch_step(const HgymEnvConfig* cfg, const HgymSimTensors* sim, 
     HG_REQUIRE(out->obs && out->priv_obs && out->rew && out->reset && out->time_out && out->extras_time_outs && out->extras_episode,
                HGYM_E_BADARG, "null output buffer");
     HG_REQUIRE(st->obs_ring && st->priv_ring && st->episode_acc, HGYM_E_BADARG, "null ring/episode_acc");
+    HG_REQUIRE(!out->t_rewards || (out->t_values && out->t_dones), HGYM_E_BADARG, "transition sink needs t_values and t_dones");
     EnvArgs A;
     memset(&A, 0, sizeof(A));
     A.cfg = *cfg;
@@ -168,7 +170,7 @@ static int32_t launch_step(const HgymEnvConfig* cfg, const HgymSimTensors* sim, 
         prof_end(HGYM_PROF_ENV_STEP, s, (double)cfg->num_envs * (4.0 * (245 + (H - 1) * 47 + (HC - 1) * 73 + H * 47 + HC * 73) + 6));
     }
     HG_CHECK_LAUNCH("env_step_kernel");
-    hipLaunchKernelGGL(env_finalize_kernel, dim3(1), dim3(256), 0, s, A);
+    hipLaunchKernelGGL(env_finalize_kernel, dim3(1), dim3(cfg->num_envs > 256 ? 1024 : 256), 0, s, A);
     HG_CHECK_LAUNCH("env_finalize_kernel");
     return HGYM_OK;
 }

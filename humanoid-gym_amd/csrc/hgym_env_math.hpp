@@ -1317,7 +1317,19 @@ HG_HD void env_finalize_part1(const EnvArgs& A, int t, int nthreads) {
         for (int i = t; i < N; i += nthreads) A.out.extras_time_outs[i] = A.out.time_out[i];
     }
 }
+// optional transition sink (HgymEnvOut::t_*): PPO.process_env_step for the scalar columns, hgym_store_step's arithmetic.
+// Thread t touches exactly the elements it refreshed in part 1.
+HG_HD void env_finalize_store(const EnvArgs& A, int t, int nthreads) {
+    if (!A.out.t_rewards) return;
+    const int N = A.cfg.num_envs;
+    for (int i = t; i < N; i += nthreads) {
+        const float to = (float)(A.out.extras_time_outs[i] != 0);
+        A.out.t_rewards[i] = A.out.rew[i] + A.out.t_gamma * (A.out.t_values[i] * to);
+        A.out.t_dones[i] = A.out.reset[i] != 0;
+    }
+}
 HG_HD void env_finalize_part2(const EnvArgs& A) {
+    if (A.out.t_rewards && A.out.t_step) A.out.t_step[0] += 1;
     A.st.counters[1] = 0;
     if (A.mode == MODE_STEP) A.st.counters[0] += 1;
     if (A.mode != MODE_RESET_ALL) A.st.counters[2] += 1;

@@ -75,7 +75,9 @@ class EnvState(C.Structure):
 
 class EnvOut(C.Structure):
     _fields_ = [("obs", c_float_p), ("priv_obs", c_float_p), ("rew", c_float_p), ("reset", c_u8_p), ("time_out", c_u8_p),
-                ("extras_time_outs", c_u8_p), ("extras_episode", c_float_p)]
+                ("extras_time_outs", c_u8_p), ("extras_episode", c_float_p),
+                ("t_values", c_float_p), ("t_rewards", c_float_p), ("t_dones", c_u8_p), ("t_step", c_i64_p),
+                ("t_gamma", C.c_float)]
 
 
 class EnvNoise(C.Structure):

@@ -100,14 +100,23 @@ class OnPolicyRunner:
                      and hasattr(torch.cuda, "CUDAGraph"))
         log_on = self.log_dir is not None
 
+        # with zero_copy the env's step finaliser also stores the scalar columns of the transition (bind_transition)
+        sink_ok = (zero_copy and hasattr(env, "bind_transition") and hasattr(alg, "transition_sink")
+                   and getattr(env.cfg.env, "send_timeouts", False) and os.environ.get("HGYM_ENV_SINK", "1") != "0")
+
+        if sink_ok:
+            alg.env_stores_transitions = True
+
         def rollout(obs, critic_obs):
             for i in range(self.num_steps_per_env):
                 actions = alg.act(obs, critic_obs)
                 if zero_copy:
                     env.bind_outputs(obs_all[i + 1], priv_all[i + 1])
+                if sink_ok:
+                    env.bind_transition(alg.transition_sink())
                 obs, privileged_obs, rewards, dones, infos = env.step(actions)
                 critic_obs = privileged_obs if privileged_obs is not None else obs
-                alg.process_env_step(rewards, dones, infos)
+                alg.process_env_step(rewards, dones, infos, **({"stored": True} if sink_ok else {}))
                 if log_on:
                     if "episode" in infos:
                         ep_infos.append({k: v.clone() for k, v in infos["episode"].items()})
@@ -172,6 +181,9 @@ class OnPolicyRunner:
                 ep_infos.clear()
         if zero_copy:
             env.bind_outputs(None, None)
+        if sink_ok:
+            env.bind_transition(None)
+            alg.env_stores_transitions = False
         self.current_learning_iteration += num_learning_iterations
         if self.log_dir is not None:
             self.save(os.path.join(self.log_dir, "model_{}.pt".format(self.current_learning_iteration)))

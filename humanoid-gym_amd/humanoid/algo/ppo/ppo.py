@@ -84,6 +84,8 @@ class PPO:
         self.gamma, self.lam = gamma, lam
         self.max_grad_norm = max_grad_norm
         self.use_clipped_value_loss = use_clipped_value_loss
+        # True while a runner has the env store the scalar columns and bump the sampling step itself (transition_sink)
+        self.env_stores_transitions = False
         self._world = 1
         self._rank = 0
         if torch.distributed.is_available() and torch.distributed.is_initialized():
@@ -139,21 +141,31 @@ class PPO:
         t.values, t.actions_log_prob = last["values"], last["logp"]
         t.action_mean, t.action_sigma = last["mu"], last["sigma"]
         t.observations, t.critic_observations = obs, critic_obs
-        self._sample_step += 1
+        if not self.env_stores_transitions:
+            self._sample_step += 1
         return t.actions
 
-    def process_env_step(self, rewards, dones, infos):
+    def transition_sink(self):
+        """The scalar columns of the storage slot act() has just filled, for an env that can store them itself
+        (LeggedRobot.bind_transition); the caller sets `env_stores_transitions` for the duration and follows env.step
+        with process_env_step(..., stored=True)."""
+        st, s = self.storage, self.storage.step
+        return dict(values=st.values[s], rewards=st.rewards[s], dones=st.dones[s], step=self._sample_step, gamma=self.gamma)
+
+    def process_env_step(self, rewards, dones, infos, stored=False):
+        """`stored=True`: the env already wrote this step's rewards / dones slot (transition_sink)."""
         import ctypes as C
         L = self._hgym._lib
         st, s = self.storage, self.storage.step
         if s >= st.num_transitions_per_env:
             raise AssertionError("Rollout buffer overflow")
-        to = infos.get("time_outs") if isinstance(infos, dict) else None
-        d8 = dones if dones.dtype == torch.uint8 else dones.view(torch.uint8) if dones.dtype == torch.bool else dones.to(torch.uint8)
-        t8 = None if to is None else (to.view(torch.uint8) if to.dtype == torch.bool else to.to(torch.uint8))
-        L.check(L.lib.hgym_store_step(st.num_envs, L.fptr(rewards), L.fptr(self.transition.values), L.u8ptr(t8), L.u8ptr(d8),
-                                      self.gamma, L.fptr(st.rewards[s]), L.u8ptr(st.dones[s]),
-                                      C.c_void_p(torch.cuda.current_stream().cuda_stream)), "hgym_store_step")
+        if not stored:
+            to = infos.get("time_outs") if isinstance(infos, dict) else None
+            d8 = dones if dones.dtype == torch.uint8 else dones.view(torch.uint8) if dones.dtype == torch.bool else dones.to(torch.uint8)
+            t8 = None if to is None else (to.view(torch.uint8) if to.dtype == torch.bool else to.to(torch.uint8))
+            L.check(L.lib.hgym_store_step(st.num_envs, L.fptr(rewards), L.fptr(self.transition.values), L.u8ptr(t8), L.u8ptr(d8),
+                                          self.gamma, L.fptr(st.rewards[s]), L.u8ptr(st.dones[s]),
+                                          C.c_void_p(torch.cuda.current_stream().cuda_stream)), "hgym_store_step")
         self.transition.rewards = st.rewards[s].view(-1)
         self.transition.dones = st.dones[s].view(-1)
         st.add_transitions(self.transition)

@@ -252,6 +252,12 @@ class LeggedRobot(BaseTask):
         (the rollout storage slot), removing the add_transitions copy.  Pass None to go back."""
         self._bound_out = None if obs is None else (obs, priv)
 
+    def bind_transition(self, sink):
+        """Native extension: `sink` = dict(values, rewards, dones, step, gamma) of caller tensors (or None).  While bound, the
+        step finaliser also stores the scalar columns of the transition (what PPO.process_env_step would launch
+        hgym_store_step for) and bumps the policy's sampling-step counter: one launch per vec-step instead of three."""
+        self._sink = sink
+
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -261,7 +267,7 @@ class LeggedRobot(BaseTask):
         else:
             self._flip ^= 1
             obs, priv = self._outs[self._flip]
-        return obs, priv, self._buf.out_struct(obs, priv)
+        return obs, priv, self._buf.out_struct(obs, priv, getattr(self, "_sink", None))
 
     # ------------------------------------------------------------------ VecEnv API
     def step(self, actions):

@@ -156,6 +156,15 @@ typedef struct HgymEnvOut {
     uint8_t* extras_time_outs; /* (N,) bool: extras["time_outs"], refreshed only on steps with >=1 reset
                                   (legged_robot.py:173-174,209-210) */
     float* extras_episode;     /* (22,) extras["episode"]["rew_<term>"], same staleness rule */
+    /* Optional transition sink (t_rewards == NULL: off).  When set, the step finaliser also does what
+     * PPO.process_env_step + RolloutStorage.add_transitions do for the scalar columns (ppo.py:103-113,
+     * rollout_storage.py:91-94; same arithmetic as hgym_store_step) from this step's rew / reset and the
+     * just-refreshed extras["time_outs"], and bumps *t_step: one launch less per vec-step. */
+    const float* t_values;     /* (N,) critic values of the transition being stored */
+    float* t_rewards;          /* (N,) storage.rewards[step]  = rew + t_gamma * (values * extras_time_outs) */
+    uint8_t* t_dones;          /* (N,) storage.dones[step]    = reset */
+    int64_t* t_step;           /* device scalar += 1 per step (the policy's sampling-step counter), or NULL */
+    float t_gamma;
 } HgymEnvOut;
 
 /* Optional externally supplied random draws (parity mode), row-major (N,k) tables indexed by env id.

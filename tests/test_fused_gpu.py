@@ -152,12 +152,15 @@ def _runner(num_envs, seed):
 def test_graph_replay_equals_eager_rollout(monkeypatch):
     """Three learning iterations with the rollout captured in a HIP graph (iteration 1 eager warm-up, 2 capture + replay,
     3 replay) and three fully eager iterations from the same seeds: rollout storage and parameters bit-identical
-    (same kernels, same device-resident counters; only the launch mechanism differs)."""
+    (same kernels, same device-resident counters; only the launch mechanism differs).  The eager leg also turns the
+    env-side transition sink off (HGYM_ENV_SINK=0: PPO.process_env_step launches hgym_store_step itself and PPO.act bumps
+    the sampling step), so the two ways of storing the scalar columns are compared bit for bit as well."""
     from humanoid.algo import PPO
     PPO.precision = "bf16"
     outs = {}
     for mode in ("1", "0"):
         monkeypatch.setenv("HGYM_GRAPH", mode)
+        monkeypatch.setenv("HGYM_ENV_SINK", mode)
         torch.manual_seed(1234)
         np.random.seed(1234)
         r = _runner(256, 77)
@@ -175,7 +178,8 @@ def test_graph_replay_equals_eager_rollout(monkeypatch):
         monkeypatch.setattr(torch, "randperm", real)
         assert (r._graph is not None) == (mode == "1")
         st = r.alg.storage
-        outs[mode] = (r.alg.net.params.clone(), st._obs_all.clone(), st.rewards.clone(), st.actions.clone(), st.values.clone())
+        outs[mode] = (r.alg.net.params.clone(), st._obs_all.clone(), st.rewards.clone(), st.actions.clone(), st.values.clone(),
+                      st.dones.clone(), st.returns.clone(), r.alg._sample_step.clone())
         del r
     for a, b in zip(outs["1"], outs["0"]):
         assert torch.equal(a, b)
