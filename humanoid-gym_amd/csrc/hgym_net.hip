@@ -372,7 +372,8 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(const LossArgs a) {
 // grads_bmu / grads_bv (fused path only): gradients of the two head biases = column sums of the head gradients.
 __global__ __launch_bounds__(512) void ppo_scalars_kernel(int nblocks, int B, int A, const float* __restrict__ partials,
                                                           float* __restrict__ grads_std, float* __restrict__ grads_bmu,
-                                                          float* __restrict__ grads_bv, double* __restrict__ opt) {
+                                                          float* __restrict__ grads_bv, float* __restrict__ kl_slot,
+                                                          double* __restrict__ opt) {
     __shared__ double red[16][LOSS_PARTIALS + 1];
     const int k = threadIdx.x & (LOSS_PARTIALS - 1), part = threadIdx.x / LOSS_PARTIALS;   // 16 partial sums per quantity
     double s = 0.0;
@@ -390,6 +391,7 @@ __global__ __launch_bounds__(512) void ppo_scalars_kernel(int nblocks, int B, in
             opt[2] += t / B;
             opt[8] = t / B;
             opt[7] += 1.0;
+            kl_slot[0] = (float)(t / B);      // grads[P]: travels with the gradient in the ranks' one all-reduce
         }
         if (q >= 4 && q < 16 && q - 4 < A) grads_std[q - 4] = (float)t;
         if (q >= 16 && q < 28 && q - 16 < A && grads_bmu) grads_bmu[q - 16] = (float)t;
@@ -440,11 +442,15 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const SegTable tab, i
     }
 }
 
-__global__ __launch_bounds__(256) void sqnorm_kernel(int64_t P, const float* __restrict__ g, double* __restrict__ opt) {
+// inv_w: 1 / world_size -- with several ranks `g` holds the all-reduced SUM and the mean is formed here and in adam_kernel
+// (fp32 product, what `grad.mul_(1 / world)` would have stored); 1.0f for one rank, which is exact.
+__global__ __launch_bounds__(256) void sqnorm_kernel(int64_t P, const float* __restrict__ g, float inv_w, double* __restrict__ opt) {
     __shared__ double red[4];
     double s = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (int64_t)gridDim.x * blockDim.x)
-        s += (double)g[i] * (double)g[i];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (int64_t)gridDim.x * blockDim.x) {
+        const float gi = g[i] * inv_w;
+        s += (double)gi * (double)gi;
+    }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
@@ -453,8 +459,9 @@ __global__ __launch_bounds__(256) void sqnorm_kernel(int64_t P, const float* __r
 }
 
 // ppo.py:140-148 (adaptive-KL learning rate, python-double arithmetic) + Adam step counter + norm accumulator reset
-__global__ void apply_prologue_kernel(const HgymPPOConfig p, double* __restrict__ opt) {
+__global__ void apply_prologue_kernel(const HgymPPOConfig p, const float* __restrict__ kl_slot, float inv_w, double* __restrict__ opt) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (p.world_size > 1) opt[8] = (double)(kl_slot[0] * inv_w);     // mean over ranks of the minibatch KL: same LR branch everywhere
     if (p.adaptive_lr) {
         const double kl = opt[8];
         double lr = opt[0];
@@ -482,7 +489,7 @@ __device__ __forceinline__ void write_shadows(const Segment& sg, int r, int c, f
 template <typename T>
 __global__ __launch_bounds__(256) void adam_kernel(const SegTable tab, const HgymPPOConfig p, float* __restrict__ params,
                                                    float* __restrict__ grads, float* __restrict__ m_, float* __restrict__ v_,
-                                                   double* __restrict__ opt) {
+                                                   float inv_w, double* __restrict__ opt) {
     const Segment& sg = tab.s[blockIdx.y];
     const int64_t n = (int64_t)sg.rows * sg.cols;
     // nn.utils.clip_grad_norm_: coef = max_norm / (total_norm + 1e-6), clamped to 1 (fp32 tensor arithmetic)
@@ -496,7 +503,7 @@ __global__ __launch_bounds__(256) void adam_kernel(const SegTable tab, const Hgy
     const float sqrt_bc2 = (float)sqrt(bc2);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t q = sg.off + i;
-        const float g = grads[q] * coef;
+        const float g = (grads[q] * inv_w) * coef;
         grads[q] = g;
         const float m = m_[q] * p.beta1 + (1.0f - p.beta1) * g;
         const float v = v_[q] * p.beta2 + (1.0f - p.beta2) * (g * g);
@@ -753,7 +760,7 @@ struct NetRunner {
         prof_end(HGYM_PROF_LOSS, s, (double)B * (4.0 * (5 * A + 6) + 2.0 * 64));
         HG_CHECK_LAUNCH("ppo_loss_kernel");
         hipLaunchKernelGGL(ppo_scalars_kernel, dim3(1), dim3(512), 0, s, nblocks, B, A, at<float>(w.partials), net.grads,
-                           net.grads + w.net[0].layer[3].b_off, net.grads + w.net[1].layer[3].b_off, net.opt_state);
+                           net.grads + w.net[0].layer[3].b_off, net.grads + w.net[1].layer[3].b_off, net.grads + w.P, net.opt_state);
         HG_CHECK_LAUNCH("ppo_scalars_kernel");
         {   // dZ chain of both nets
             BwdArgs g;
@@ -997,7 +1004,7 @@ struct NetRunner {
         prof_end(HGYM_PROF_LOSS, s, (double)B * (4.0 * (5 * A + 6) + (double)sizeof(T) * (2 * A + 2)));
         HG_CHECK_LAUNCH("ppo_loss_kernel");
         hipLaunchKernelGGL(ppo_scalars_kernel, dim3(1), dim3(512), 0, s, nblocks, B, A, at<float>(w.partials), net.grads, (float*)nullptr,
-                           (float*)nullptr, net.opt_state);
+                           (float*)nullptr, net.grads + w.P, net.opt_state);
         HG_CHECK_LAUNCH("ppo_scalars_kernel");
         cur_Mp = Bp;
         rc = backward(0, B);
@@ -1012,11 +1019,12 @@ struct NetRunner {
 
     int32_t apply(const HgymPPOConfig& ppo) {
         prof_begin(HGYM_PROF_APPLY, s);
-        hipLaunchKernelGGL(apply_prologue_kernel, dim3(1), dim3(64), 0, s, ppo, net.opt_state);
-        hipLaunchKernelGGL(sqnorm_kernel, dim3(256), dim3(256), 0, s, w.P, net.grads, net.opt_state);
+        const float inv_w = ppo.world_size > 1 ? (float)(1.0 / (double)ppo.world_size) : 1.0f;
+        hipLaunchKernelGGL(apply_prologue_kernel, dim3(1), dim3(64), 0, s, ppo, net.grads + w.P, inv_w, net.opt_state);
+        hipLaunchKernelGGL(sqnorm_kernel, dim3(256), dim3(256), 0, s, w.P, net.grads, inv_w, net.opt_state);
         const SegTable tab = segments(false);
         hipLaunchKernelGGL((adam_kernel<T>), dim3(64, tab.n), dim3(256), 0, s, tab, ppo, net.params, net.grads, net.adam_m, net.adam_v,
-                           net.opt_state);
+                           inv_w, net.opt_state);
         prof_end(HGYM_PROF_APPLY, s, (double)w.P * 36.0);
         HG_CHECK_LAUNCH("adam_kernel");
         return HGYM_OK;

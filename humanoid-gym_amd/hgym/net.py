@@ -45,7 +45,9 @@ class NetBuffers:
         if self.P <= 0 or nbytes <= 0:
             raise L.HgymError("bad net config: %s" % L.lib.hgym_last_error().decode())
         z = lambda n, dt=torch.float32: torch.zeros(n, dtype=dt, device=self.device)
-        self.params, self.grads, self.adam_m, self.adam_v = z(self.P), z(self.P), z(self.P), z(self.P)
+        self.params, self.adam_m, self.adam_v = z(self.P), z(self.P), z(self.P)
+        self.grads_ext = z(self.P + 1)          # flat gradient + the minibatch KL slot: what the ranks all-reduce, in one piece
+        self.grads = self.grads_ext[:self.P]
         self.opt_state = z(16, torch.float64)
         self.opt_state[0] = learning_rate
         self.workspace = torch.zeros(nbytes + 256, dtype=torch.uint8, device=self.device)

@@ -120,8 +120,6 @@ class PPO:
         ac._sample_step = self._sample_step
         ac._sample_seed = 0x5EED + 7919 * self._rank
         self._hgym = hgym
-        # flat gradient + one trailing slot for the minibatch KL: ONE collective per minibatch
-        self._grad_ext = torch.zeros(self.net.P + 1, device=self.device)
 
     def test_mode(self):
         self.actor_critic.eval()
@@ -194,7 +192,7 @@ class PPO:
             for i in range(self.num_mini_batches):
                 idx = perm[i * mb:(i + 1) * mb]
                 net.ppo_grad(self._ppo_cfg, hgym.make_batch(*cols, idx))
-                dist_utils.average_grads_and_kl(net.grads, net.opt_state, self._grad_ext)
+                dist_utils.sum_grads_and_kl(net.grads_ext)
                 net.ppo_apply(self._ppo_cfg)
         o = net.opt_state.cpu()                # the one host read-back of the update
         n = max(float(o[7]), 1.0)

@@ -247,7 +247,8 @@ typedef struct HgymPPOConfig {
     float beta1, beta2, adam_eps;
     double lr_min, lr_max;          /* 1e-5, 1e-2 (ppo.py:142-145) */
     int32_t adaptive_lr;            /* schedule == 'adaptive' */
-    int32_t world_size;             /* >1: gradients are averaged by the caller between grad and apply */
+    int32_t world_size;             /* >1: between hgym_ppo_grad and hgym_ppo_apply the caller all-reduces (SUM) the P+1 floats of
+                                       net->grads across ranks; apply forms the means (gradient and KL) itself */
 } HgymPPOConfig;
 
 /* Sizes (bytes) of the caller-allocated blocks, as functions of the configuration. */
@@ -266,7 +267,7 @@ int64_t hgym_net_workspace_bytes(const HgymNetConfig* net);
  * (padding rows/columns of the operand buffers rely on it). */
 typedef struct HgymNet {
     float* params;
-    float* grads;
+    float* grads;          /* hgym_net_param_count() + 1 floats: the flat gradient, then ONE slot carrying the minibatch mean KL */
     float* adam_m;
     float* adam_v;
     double* opt_state;     /* [16] */
@@ -310,8 +311,9 @@ typedef struct HgymBatch {
 int32_t hgym_ppo_grad(const HgymNetConfig* cfg, const HgymPPOConfig* ppo, const HgymNet* net,
                       const HgymBatch* batch, void* stream);
 
-/* clip_grad_norm_ + Adam.step (ppo.py:173-174) on net->grads (already averaged across ranks when
- * world_size > 1), refreshes the compute-precision shadows, bumps opt_state. */
+/* clip_grad_norm_ + Adam.step (ppo.py:173-174) on net->grads (the rank-SUM when world_size > 1: divided by
+ * world_size here, as is the KL in grads[P] before the learning-rate decision), refreshes the
+ * compute-precision shadows, bumps opt_state. */
 int32_t hgym_ppo_apply(const HgymNetConfig* cfg, const HgymPPOConfig* ppo, const HgymNet* net, void* stream);
 
 /* ------------------------------------------------------------------------------------------------

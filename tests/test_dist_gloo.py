@@ -22,11 +22,15 @@ def _worker(rank, world, port, out_dir):
     g = torch.Generator().manual_seed(100 + rank)
     P = 1000
     grads = torch.randn(P, generator=g)
-    opt = torch.zeros(16, dtype=torch.float64)
-    opt[8] = 0.01 * (rank + 1)
-    ext = torch.zeros(P + 1)
+    # [gradient | KL] exactly as hgym_ppo_grad leaves net.grads (P + 1 floats); hgym_ppo_apply then multiplies by
+    # 1 / world_size on the device (fp32 product) -- done here on the host
+    ext = torch.cat([grads, torch.tensor([0.01 * (rank + 1)])])
     g_in = grads.clone()
-    D.average_grads_and_kl(grads, opt, ext)
+    D.sum_grads_and_kl(ext)
+    inv_w = torch.tensor(1.0 / world, dtype=torch.float32)
+    grads = ext[:P] * inv_w
+    opt = torch.zeros(16, dtype=torch.float64)
+    opt[8] = float(ext[P] * inv_w)
     # advantage statistics of this rank's shard
     adv = torch.randn(60, 7, generator=g) * (1 + rank) + rank
     stats = torch.tensor([adv.double().sum(), (adv.double() ** 2).sum(), adv.numel()], dtype=torch.float64)

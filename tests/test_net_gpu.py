@@ -244,3 +244,33 @@ def test_update_full_size_properties():
     a, b = grads["f32"].double(), grads["bf16"].double()
     cos = float(a @ b) / float(a.norm() * b.norm())
     assert cos > 0.99, cos
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+def test_apply_with_world_size_forms_the_rank_mean_itself(precision):
+    """N>1 contract of hgym_ppo_apply: between grad and apply the ranks all-reduce (SUM) the P+1 floats of
+    net.grads -- [flat gradient | minibatch KL] -- and apply divides by world_size on the device.  Emulated on one GPU:
+    a net whose grads/KL slot hold world x the single-rank values, applied with world_size = world, must end bit-identical
+    to the single-rank net (x2 and x0.5 are exact in fp32), including the adaptive-KL learning-rate step."""
+    from hgym import NetBuffers, make_net_config, make_ppo_config
+    world = 2
+    nets = []
+    for w in (1, world):
+        torch.manual_seed(7)
+        cfg = make_net_config(705, 219, 12, [512, 256, 128], [768, 256, 128], precision, 512)
+        net = NetBuffers(cfg, "cuda", learning_rate=1e-3)
+        for k, v in net.views.items():
+            v.copy_(torch.randn(v.shape, device="cuda") * 0.05)
+        net.sync_shadow()
+        g = torch.randn(net.P, device="cuda") * 3.0            # norm >> max_grad_norm: the clip is active
+        net.grads.copy_(g * w)
+        net.grads_ext[net.P] = 0.004 * w                        # mean KL 0.004 < desired_kl / 2 -> lr x 1.5
+        net.opt_state[8] = 123.0 if w > 1 else 0.004            # multi-rank: the local double is NOT what decides
+        net.ppo_apply(make_ppo_config(world_size=w))
+        torch.cuda.synchronize()
+        nets.append(net)
+    a, b = nets
+    assert torch.equal(a.params, b.params) and torch.equal(a.adam_m, b.adam_m) and torch.equal(a.adam_v, b.adam_v)
+    assert float(a.opt_state[0]) == float(b.opt_state[0]) == pytest.approx(1.5e-3)
+    assert float(a.opt_state[6]) == float(b.opt_state[6])       # same pre-clip gradient norm
+    assert torch.equal(a.workspace, b.workspace)                # bf16 operand shadows follow
