@@ -134,11 +134,10 @@ def main():
     runner.learn(num_learning_iterations=max(args.warmup, 0), init_at_random_ep_len=True)
     barrier()
     t0 = time.perf_counter()
-    coll = learn = 0.0
-    for _ in range(args.steps):
-        runner.learn(num_learning_iterations=1, init_at_random_ep_len=False)
-        coll += runner.last_collection_time
-        learn += runner.last_learn_time
+    # K learning iterations, enqueued back to back (the runner reads nothing back between iterations when it does not log)
+    runner.learn(num_learning_iterations=args.steps, init_at_random_ep_len=False)
+    coll = runner.last_collection_time * args.steps      # mean per iteration over this call, HIP events on the launch stream
+    learn = runner.last_learn_time * args.steps
     barrier()
     elapsed = time.perf_counter() - t0
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)

@@ -48,6 +48,7 @@ struct WsLayout {
     int splits;
     int64_t slabs;           // [splits][P] fp32
     int64_t partials;        // [MAX_LOSS_BLOCKS][16] fp32
+    int64_t zeros;           // 4 KiB that nothing ever writes (the workspace arrives zero-filled)
     int64_t total_bytes;
     int fused;               // 1: bf16 fast path (three fused kernels) is usable for this configuration
     int64_t Mpad;            // fused path: batch padded to the 64-row tile
@@ -143,6 +144,7 @@ static int32_t ws_layout(const HgymNetConfig* c, WsLayout* w) {
     w->dw_splits = getenv("HGYM_DW_SPLITS") ? atoi(getenv("HGYM_DW_SPLITS")) : 8;
     w->slabs = take((int64_t)w->splits * w->Ps * 4);
     w->partials = take((int64_t)MAX_LOSS_BLOCKS * LOSS_PARTIALS * 4);
+    w->zeros = take(4096);
     w->total_bytes = off;
     return HGYM_OK;
 }
@@ -817,6 +819,19 @@ struct NetRunner {
             d.steps_per_split = ceil_div(d.steps_total, w.dw_splits);
             d.slabs = at<float>(w.slabs);
             d.slab_stride = w.Ps;
+            d.zeros = at<char>(w.zeros);
+            static const int dma = getenv("HGYM_DW_DMA") ? atoi(getenv("HGYM_DW_DMA")) : 0;   // 1: the LDS-DMA transport (A/B experiments)
+            if (!dma) {
+                prof_begin(HGYM_PROF_DW, s);
+                static const int rs = getenv("HGYM_DW_RS") ? atoi(getenv("HGYM_DW_RS")) : 3;
+                const dim3 grid(tile * (int)round_up(w.dw_splits, 8));
+                if (rs == 5) hipLaunchKernelGGL(dw_kernel_rs<5>, grid, dim3(DW_THREADS), 2 * DW_STAGE_BYTES, s, d);
+                else if (rs == 4) hipLaunchKernelGGL(dw_kernel_rs<4>, grid, dim3(DW_THREADS), 2 * DW_STAGE_BYTES, s, d);
+                else if (rs == 2) hipLaunchKernelGGL(dw_kernel_rs<2>, grid, dim3(DW_THREADS), 2 * DW_STAGE_BYTES, s, d);
+                else hipLaunchKernelGGL(dw_kernel_rs<3>, grid, dim3(DW_THREADS), 2 * DW_STAGE_BYTES, s, d);
+                prof_end(HGYM_PROF_DW, s, fl);
+                HG_CHECK_LAUNCH("dw_kernel_rs");
+            } else {
             static bool attr_done = false;
             if (!attr_done) {
                 if (hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -828,6 +843,7 @@ struct NetRunner {
             hipLaunchKernelGGL(dw_kernel, dim3(tile * (int)round_up(w.dw_splits, 8)), dim3(DW_THREADS), DW_STAGES * DW_STAGE_BYTES, s, d);
             prof_end(HGYM_PROF_DW, s, fl);
             HG_CHECK_LAUNCH("dw_kernel");
+            }
         }
         const SegTable tab = segments(true);
         prof_begin(HGYM_PROF_REDUCE, s);

@@ -130,12 +130,22 @@ class OnPolicyRunner:
                     cur_episode_length.mul_(1.0 - d)
             return obs, critic_obs
 
+        # Without logging nothing on the host needs the iteration's results: collection / learn time are then measured with
+        # HIP events on the launch stream and read once at the end of learn(), and the update's loss read-back is skipped,
+        # so the host enqueues iteration k+1 while the device still runs iteration k (no idle gap at the phase
+        # boundaries).  With logging the reference's per-iteration host synchronisation is kept.
+        async_iters = ((not log_on) and str(self.device).startswith("cuda") and isinstance(alg, PPO)
+                       and os.environ.get("HGYM_ASYNC", "1") != "0")
+        marks = []
         tot_iter = self.current_learning_iteration + num_learning_iterations
         for it in range(self.current_learning_iteration, tot_iter):
             start = time.time()
+            if async_iters:
+                ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+                ev[0].record()
             with torch.inference_mode():
                 g = self._graph
-                if use_graph and g is not None and g["key"] == (id(env), id(alg.storage), log_on):
+                if use_graph and g is not None and g["key"] == (id(env), id(alg.storage), log_on, sink_ok):
                     g["graph"].replay()
                     alg.storage.step = self.num_steps_per_env
                     obs, critic_obs = g["out"]
@@ -147,7 +157,7 @@ class OnPolicyRunner:
                     torch.cuda.synchronize()
                     with torch.cuda.graph(graph):
                         out = rollout(obs_all[0], priv_all[0])
-                    self._graph = dict(graph=graph, out=out, ep_infos=ep_infos, key=(id(env), id(alg.storage), log_on),
+                    self._graph = dict(graph=graph, out=out, ep_infos=ep_infos, key=(id(env), id(alg.storage), log_on, sink_ok),
                                        stats=(cur_reward_sum, cur_episode_length, done_stats))
                     alg.storage.step = 0
                     graph.replay()                  # capture does not execute: run the captured rollout once
@@ -156,18 +166,24 @@ class OnPolicyRunner:
                 else:
                     obs, critic_obs = rollout(obs, critic_obs)
                     self._graph_warm = True
-                if str(self.device).startswith("cuda"):
+                if async_iters:
+                    ev[1].record()
+                elif str(self.device).startswith("cuda"):
                     torch.cuda.synchronize()
                 stop = time.time()
                 collection_time = stop - start
                 start = stop
                 alg.compute_returns(critic_obs)
-            mean_value_loss, mean_surrogate_loss = alg.update()
+            mean_value_loss, mean_surrogate_loss = alg.update(sync=False) if async_iters else alg.update()
             if zero_copy:                       # storage.clear() rotated slot T into slot 0
                 obs, critic_obs = obs_all[0], priv_all[0]
             stop = time.time()
             learn_time = stop - start
-            self.last_collection_time, self.last_learn_time = collection_time, learn_time
+            if async_iters:
+                ev[2].record()
+                marks.append(ev)
+            else:
+                self.last_collection_time, self.last_learn_time = collection_time, learn_time
             if self.log_dir is not None:
                 s = done_stats.cpu()
                 if float(s[2]) > 0:
@@ -179,6 +195,10 @@ class OnPolicyRunner:
                     self.save(os.path.join(self.log_dir, "model_{}.pt".format(it)))
             if self._graph is None or ep_infos is not self._graph["ep_infos"]:
                 ep_infos.clear()
+        if marks:                               # mean device time per iteration of this call (HIP events, one sync)
+            torch.cuda.synchronize()
+            self.last_collection_time = sum(a.elapsed_time(b) for a, b, _ in marks) * 1e-3 / len(marks)
+            self.last_learn_time = sum(b.elapsed_time(c) for _, b, c in marks) * 1e-3 / len(marks)
         if zero_copy:
             env.bind_outputs(None, None)
         if sink_ok:

@@ -175,7 +175,10 @@ class PPO:
         self.storage.compute_returns(last_values, self.gamma, self.lam, stats_hook=dist_utils.allreduce_adv_stats)
 
     # ------------------------------------------------------------------ update
-    def update(self):
+    def update(self, sync=True):
+        """ppo.py:119-184.  Returns (mean_value_loss, mean_surrogate_loss) as floats -- the one host read-back of the
+        update.  sync=False (native extension, used by the runner when nothing is logged): no read-back, returns
+        (None, None), so the host can already enqueue the next rollout while this update runs."""
         hgym, net, st = self._hgym, self.net, self.storage
         T, N = st.num_transitions_per_env, st.num_envs
         batch = T * N
@@ -194,7 +197,9 @@ class PPO:
                 net.ppo_grad(self._ppo_cfg, hgym.make_batch(*cols, idx))
                 dist_utils.sum_grads_and_kl(net.grads_ext)
                 net.ppo_apply(self._ppo_cfg)
+        st.clear()
+        if not sync:
+            return None, None
         o = net.opt_state.cpu()                # the one host read-back of the update
         n = max(float(o[7]), 1.0)
-        st.clear()
         return float(o[4]) / n, float(o[3]) / n
