@@ -56,6 +56,8 @@ struct FusedNet {
 };
 
 HG_HD int fused_lds_p(const FusedNet& n, int BM) { return BM * (n.layer[0].N > n.layer[2].N ? n.layer[0].N : n.layer[2].N) * 2; }
+// fp32 copies of the four bias vectors (fetched at kernel entry so no epilogue waits on a cold global load) + 16 pad
+HG_HD int fused_lds_bias(const FusedNet& n) { return (n.layer[0].N + n.layer[1].N + n.layer[2].N + 16 + 16) * 4; }
 HG_HD int fused_lds_q(const FusedNet& n, int BM) {
     const int a = 2 * BM * FUSED_CHUNK * 2, b = BM * n.layer[1].N * 2;
     return a > b ? a : b;
@@ -216,11 +218,11 @@ __device__ __forceinline__ void mma_stream(WRing<GR, D>& R, const u32x4* __restr
 
 // mma_chunk: the 4 k-steps t0 .. t0 + 3 (t0 % 4 == 0, D divides 4) of a stream whose input arrives in 4-k-block LDS chunks
 // (first layer).  LAST: this is the final chunk, nothing beyond k-step t0 + 3 exists.
-template <int G, int MB, int D, bool LAST, int GR>
+template <int G, int MB, int D, bool LAST, int XBP = -1, int GR>
 __device__ __forceinline__ void mma_chunk(WRing<GR, D>& R, const u32x4* __restrict__ wl, int wstride, int t0, const char* xl, int CBx,
                                           int lane, f32x4 (&acc)[MB][G]) {
     static_assert(D == 2 || D == 4, "ring depth must divide the chunk");
-    constexpr bool XB = MB <= 2;
+    constexpr bool XB = XBP < 0 ? (MB <= 2) : (XBP != 0);
     const int r = lane & 15, q = lane >> 4;
     const char* xb = xl + (q >> 1) * 512 + r * 32 + (q & 1) * 16;
     u32x4 xa[MB], xc[XB ? MB : 1];
@@ -297,19 +299,20 @@ __device__ __forceinline__ void hidden_prime(WRing<GR, D>& R, const FusedLayer& 
 }
 
 template <int G, int MB, int NW, int D, bool AHEAD, int GR, class Next>
-__device__ __forceinline__ void hidden_layer(WRing<GR, D>& R, const FusedLayer& L, const char* in_lds, int CBin, char* out_lds, __bf16* Hg,
-                                             int64_t mbg0, int wave, int lane, Next prime_next) {
+__device__ __forceinline__ void hidden_layer(WRing<GR, D>& R, const FusedLayer& L, const float* bias, const char* in_lds, int CBin,
+                                             char* out_lds, __bf16* Hg, int64_t mbg0, int wave, int lane, Next prime_next) {
     bool primed = false;
     for (int nb0 = wave * G; nb0 < L.NB; nb0 += NW * G) {
         f32x4 acc[MB][G];
         zero_acc<G, MB>(acc);
         const u32x4* wl = L.Wf + (int64_t)nb0 * L.KB * 64 + lane;
-        if (L.KB % D == 0) mma_stream<G, MB, D>(R, wl, L.KB * 64, L.KB, in_lds, CBin, lane, acc);
-        else mma_ring<G, MB, D>(R, wl, L.KB * 64, 0, L.KB, L.KB, in_lds, CBin, lane, acc);
+        constexpr int XBF = NW <= 8 ? 1 : -1;
+        if (L.KB % D == 0) mma_stream<G, MB, D, XBF>(R, wl, L.KB * 64, L.KB, in_lds, CBin, lane, acc);
+        else mma_ring<G, MB, D, XBF>(R, wl, L.KB * 64, 0, L.KB, L.KB, in_lds, CBin, lane, acc);
         const int nxt = nb0 + NW * G;
         if (nxt < L.NB) wring_prime<G, D>(R, L.Wf + (int64_t)nxt * L.KB * 64 + lane, L.KB * 64, L.KB);
         else if (AHEAD) { prime_next(); primed = true; }
-        epilogue_elu<G, MB>(acc, L.bias, nb0, out_lds, L.NB, Hg, mbg0, lane);
+        epilogue_elu<G, MB>(acc, bias, nb0, out_lds, L.NB, Hg, mbg0, lane);
     }
     if (AHEAD && !primed) prime_next();       // waves without a strip in this layer
 }
@@ -354,7 +357,36 @@ __device__ __forceinline__ void fwd_body(const FwdArgs& a, const FusedNet& n, bo
     const FusedLayer& L2 = n.layer[2];
     const FusedLayer& L3 = n.layer[3];
     const int train = a.train;
+    // the four bias vectors -> LDS: the loads are issued here, ahead of everything else, and parked in registers; they are
+    // written to LDS next to the first input chunk, so no epilogue ever waits on a cold global load
+    float* bl = reinterpret_cast<float*>(smem + fused_lds_p(n, BM) + fused_lds_q(n, BM));
+    constexpr int BIT = (768 + 768 + 768 + 16 + NW * 64 - 1) / (NW * 64);     // fused_supported: hidden widths <= 768
+    float bv[BIT];
+    const int bn0 = L0.N, bn1 = bn0 + L1.N, bn2 = bn1 + L2.N, bn3 = bn2 + 16;
+#pragma unroll
+    for (int u = 0; u < BIT; ++u) {
+        int i = tid + u * NW * 64;
+        i = i < bn2 + L3.N ? i : bn2 + L3.N - 1;          // clamp: the pad entries re-read the last head bias (never used)
+        const float* src = i < bn0 ? L0.bias + i : (i < bn1 ? L1.bias + (i - bn0) : (i < bn2 ? L2.bias + (i - bn1) : L3.bias + (i - bn2)));
+        bv[u] = *src;
+    }
+    // sampling epilogue inputs (head waves of the actor): fetched now, used ~20 us later
+    int64_t step_pre = 0;
+    float std_pre[4] = {1.0f, 1.0f, 1.0f, 1.0f};
+    if (is_actor && a.sample && wave < BM / 16) {
+        if (!a.z && a.step) step_pre = a.step[0];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) std_pre[e] = a.std_[4 * q + e < a.A ? 4 * q + e : 0];
+    }
+    auto bias_to_lds = [&]() {
+#pragma unroll
+        for (int u = 0; u < BIT; ++u) {
+            const int i = tid + u * NW * 64;
+            if (i < bn3) bl[i] = bv[u];
+        }
+    };
     constexpr bool AHEAD = NW <= 8;
+    constexpr int XBF = NW <= 8 ? 1 : -1;  // 8-wave tiles have the registers to keep the x fragments one k-step ahead
     constexpr int GH = NW <= 8 ? 2 : 1;   // n-blocks per strip in the hidden layers (widths are multiples of 128 = 8 n-blocks)
     WRing<GH, D> r1, r2;             // weight streams of the two hidden layers
     auto prime1 = [&]() { hidden_prime<GH, D>(r1, L1, wave, lane); };
@@ -421,26 +453,27 @@ __device__ __forceinline__ void fwd_body(const FwdArgs& a, const FusedNet& n, bo
         wring_prime<G1, D>(r0, wl0, L0.KB * 64, L0.KB);
         stage_load(0);
         stage_write(0, 0);
+        bias_to_lds();
         __syncthreads();
         phase_stamp(a.dbg, 1);
         // steady state: no condition inside the body (see mma_stream); the last chunk is peeled
         for (int c = 0; c + 1 < NC; ++c) {
             stage_load(c + 1);
-            mma_chunk<G1, MB, D, false>(r0, wl0, L0.KB * 64, c * 4, Q + (c & 1) * (BM * FUSED_CHUNK * 2), 8, lane, acc);
+            mma_chunk<G1, MB, D, false, XBF>(r0, wl0, L0.KB * 64, c * 4, Q + (c & 1) * (BM * FUSED_CHUNK * 2), 8, lane, acc);
             stage_write(c + 1, (c + 1) & 1);
             __syncthreads();
         }
-        mma_chunk<G1, MB, D, true>(r0, wl0, L0.KB * 64, (NC - 1) * 4, Q + ((NC - 1) & 1) * (BM * FUSED_CHUNK * 2), 8, lane, acc);
+        mma_chunk<G1, MB, D, true, XBF>(r0, wl0, L0.KB * 64, (NC - 1) * 4, Q + ((NC - 1) & 1) * (BM * FUSED_CHUNK * 2), 8, lane, acc);
         phase_stamp(a.dbg, 2);
         if (AHEAD) prime1();
-        epilogue_elu<G1, MB>(acc, L0.bias, nb0, P, L0.NB, train ? n.H[0] : nullptr, mbg0, lane);
+        epilogue_elu<G1, MB>(acc, bl, nb0, P, L0.NB, train ? n.H[0] : nullptr, mbg0, lane);
     }
     __syncthreads();
     phase_stamp(a.dbg, 3);
     if (!AHEAD) prime1();
     // ---------------------------------------------------------------- layers 1, 2: input resident in LDS
     auto prime2 = [&]() { hidden_prime<GH, D>(r2, L2, wave, lane); };
-    hidden_layer<GH, MB, NW, D, AHEAD>(r1, L1, P, L0.NB, Q, train ? n.H[1] : nullptr, mbg0, wave, lane, prime2);
+    hidden_layer<GH, MB, NW, D, AHEAD>(r1, L1, bl + L0.N, P, L0.NB, Q, train ? n.H[1] : nullptr, mbg0, wave, lane, prime2);
     __syncthreads();
     phase_stamp(a.dbg, 4);
     if (!AHEAD) prime2();
@@ -448,7 +481,7 @@ __device__ __forceinline__ void fwd_body(const FwdArgs& a, const FusedNet& n, bo
     auto prime3 = [&]() {
         if (wave < MB) wring_prime<1, 4>(r3, L3.Wf + lane, 0, L3.KB);
     };
-    hidden_layer<GH, MB, NW, D, AHEAD>(r2, L2, Q, L1.NB, P, train ? n.H[2] : nullptr, mbg0, wave, lane, prime3);
+    hidden_layer<GH, MB, NW, D, AHEAD>(r2, L2, bl + L0.N + L1.N, Q, L1.NB, P, train ? n.H[2] : nullptr, mbg0, wave, lane, prime3);
     __syncthreads();
     phase_stamp(a.dbg, 5);
     if (!AHEAD) prime3();
@@ -464,7 +497,7 @@ __device__ __forceinline__ void fwd_body(const FwdArgs& a, const FusedNet& n, bo
         const int No = L3.N;
         float mu[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) mu[e] = acc[e] + ((4 * q + e < No) ? L3.bias[4 * q + e] : 0.0f);
+        for (int e = 0; e < 4; ++e) mu[e] = acc[e] + ((4 * q + e < No) ? bl[L0.N + L1.N + L2.N + 4 * q + e] : 0.0f);
         if (m < a.M) {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
@@ -477,7 +510,7 @@ __device__ __forceinline__ void fwd_body(const FwdArgs& a, const FusedNet& n, bo
 #pragma unroll
                 for (int e = 0; e < 4; ++e) zz[e] = (m < a.M && 4 * q + e < A) ? a.z[(int64_t)m * A + 4 * q + e] : 0.0f;
             } else {
-                const int64_t s = a.step ? a.step[0] : 0;
+                const int64_t s = step_pre;
                 const RngKey rk = {a.k0, a.k1, (uint32_t)s, (uint32_t)(s >> 32)};
                 const U4 u = rng4(rk, (uint32_t)m, SLOT_POLICY + (uint32_t)q);
                 box_muller(u.x, u.y, zz[0], zz[1]);
@@ -488,7 +521,7 @@ __device__ __forceinline__ void fwd_body(const FwdArgs& a, const FusedNet& n, bo
             for (int e = 0; e < 4; ++e) {
                 const int j = 4 * q + e;
                 if (j < A) {
-                    const float sg = mu[e] * 0.0f + a.std_[j];       // actor_critic.py:113
+                    const float sg = mu[e] * 0.0f + std_pre[e];      // actor_critic.py:113
                     const float act = mu[e] + sg * zz[e];
                     const float d = act - mu[e];
                     lp += -(d * d) / (2.0f * sg * sg) - logf(sg) - 0.9189385332046727f;

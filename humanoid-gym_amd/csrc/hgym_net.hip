@@ -671,7 +671,7 @@ struct NetRunner {
         size_t lds = 0;
         for (int i = 0; i < nets; ++i) {
             const FusedNet& n = a.net[a.net0 + i];
-            lds = std::max(lds, (size_t)fused_lds_p(n, BM) + (size_t)fused_lds_q(n, BM));
+            lds = std::max(lds, (size_t)fused_lds_p(n, BM) + (size_t)fused_lds_q(n, BM) + (size_t)fused_lds_bias(n));
         }
         static size_t attr_lds = 0;
         if (lds > attr_lds) {
@@ -719,7 +719,7 @@ struct NetRunner {
         const int tile = tile_env ? tile_env : ((train || M >= 16384) ? 64 : 32);
         int32_t rc;
         static const int waves_env = getenv("HGYM_FWD_WAVES") ? atoi(getenv("HGYM_FWD_WAVES")) : 0;
-        if (tile == 64 && waves_env == 8) rc = launch_fwd<64, 8, 2>(a, nets);
+        if (tile == 64 && waves_env == 8) rc = ring_env == 4 ? launch_fwd<64, 8, 4>(a, nets) : launch_fwd<64, 8, 2>(a, nets);
         else if (tile == 64) rc = launch_fwd<64, 16, 2>(a, nets);
         else rc = ring_env == 2 ? launch_fwd<32, 8, 2>(a, nets) : launch_fwd<32, 8, 4>(a, nets);
         double fl = 0.0;
