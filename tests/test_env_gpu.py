@@ -51,7 +51,7 @@ def test_golden_trace_gpu(hip, golden_dir):
             EC.close(b.priv_obs, G["priv_step%d" % t], "priv %d" % t)
 
 
-@pytest.mark.parametrize("N,layout,steps", [(37, "soa", 20), (256, "aos", 16), (4096, "soa", 12)])
+@pytest.mark.parametrize("N,layout,steps", [(37, "soa", 20), (256, "aos", 16), (4096, "soa", 12), (8192, "soa", 8)])
 def test_random_trace_gpu(hip, N, layout, steps):
     counts, env, o = EC.run_random_trace(hip, N, steps=steps, seed=100 + N, sim_layout=layout,
                                          check_every=1 if N < 1000 else 4)
@@ -62,13 +62,14 @@ def test_generic_frame_stack_gpu(hip):
     EC.run_random_trace(hip, 100, steps=10, seed=7, frame_stack=4, c_frame_stack=2)
 
 
-def test_fused_synthetic_step_properties(hip):
-    """Full-size fused fast path (pre_physics + synthetic physics + post_physics in one launch, internal
+@pytest.mark.parametrize("N", [4096, 8192, 5000, 16384])
+def test_fused_synthetic_step_properties(hip, N):
+    """BASELINE configs[1] (4096 envs) and configs[3] (8192 envs/GPU, stack 15), a ragged count, and 16 384 envs (the 32-env
+    workgroup shape).  Full-size fused fast path (pre_physics + synthetic physics + post_physics in one launch, internal
     Philox): size-independent properties instead of an element-wise oracle --
     obs rows are the shifted previous rows plus a new frame, masks are consistent, counters advance."""
     import ctypes as C
     from hgym import EnvBuffers, default_env_config, _lib as L
-    N = 4096
     cfg = default_env_config(N, seed=123)
     buf = EnvBuffers(cfg, "cuda")
     sim, st, out = buf.sim_struct(), buf.state_struct(), buf.out_struct()
