@@ -25,41 +25,49 @@ __global__ __launch_bounds__(256) void env_step_kernel(const EnvArgs A) {
     const int64_t csc0 = A.st.counters[0];
     const int64_t ring_step = A.st.counters[2];
     const int t = threadIdx.x;
-    // compiled-in geometry: the observation history is prefetched into registers here and stored at the end, so the
-    // whole step makes ONE round trip to memory for its inputs
+    // compiled-in geometry: wavefronts 1..3 prefetch the observation history into registers here, so the whole step makes
+    // ONE round trip to memory for its inputs, and store it (clipped) while wavefront 0 runs the per-env scalar chains
     constexpr bool kPrefetch = E_T > 0 && H_T > 1 && HC_T > 1;
+    constexpr int NTH = 192;                              // history lanes: wavefronts 1..3
     constexpr int HP = kPrefetch ? H_T : 2, HCP = kPrefetch ? HC_T : 2, EP = kPrefetch ? E_T : 4;
-    constexpr int NIO = kPrefetch ? hist_ni<HP, HGYM_OBS_FRAME, EP, 256>() : 0;
-    constexpr int NIP = kPrefetch ? hist_ni<HCP, HGYM_PRIV_FRAME, EP, 256>() : 0;
+    constexpr int NIO = kPrefetch ? hist_ni<HP, HGYM_OBS_FRAME, EP, NTH>() : 0;
+    constexpr int NIP = kPrefetch ? hist_ni<HCP, HGYM_PRIV_FRAME, EP, NTH>() : 0;
     float hist_o[NIO > 0 ? NIO : 1][4], hist_p[NIP > 0 ? NIP : 1][4];
     const StackGeom geom = stack_geom<H_T, HC_T, E_T>(A, blockIdx.x);
     const bool stack_on = A.mode != MODE_RESET_ALL && !(A.ablate & 8);
-    if (kPrefetch && stack_on) {
-        hist_load<HP, HGYM_OBS_FRAME, NIO>(A.st.obs_ring, geom.e0, geom.nE, (int)(ring_step % HP), t, 256, hist_o);
-        hist_load<HCP, HGYM_PRIV_FRAME, NIP>(A.st.priv_ring, geom.e0, geom.nE, (int)(ring_step % HCP), t, 256, hist_p);
+    if (kPrefetch && stack_on && t >= 64) {
+        hist_load<HP, HGYM_OBS_FRAME, NIO>(A.st.obs_ring, geom.e0, geom.nE, (int)(ring_step % HP), t - 64, NTH, hist_o);
+        hist_load<HCP, HGYM_PRIV_FRAME, NIP>(A.st.priv_ring, geom.e0, geom.nE, (int)(ring_step % HCP), t - 64, NTH, hist_p);
     }
     if (!(A.ablate & 1)) env_stage_in<E_T>(A, blockIdx.x, t, blockDim.x, smem);
     if (!(A.ablate & 64)) env_fill_draws<E_T>(A, blockIdx.x, t, blockDim.x, smem, csc0);
     __syncthreads();
     if (!(A.ablate & 128)) env_step_joints<E_T>(A, blockIdx.x, t, blockDim.x, smem);
     __syncthreads();
-    // wavefront 0 runs the per-env scalar chains (one lane per env); without the register prefetch the other wavefronts
-    // meanwhile move the observation history, which depends on nothing this step computes
+    // wavefront 0 runs the per-env scalar chains (one lane per env); the other wavefronts meanwhile move the older frames of
+    // the observation history, which depend on nothing this step computes (reset envs are fixed up in phase B)
     if (t < 64) {
         if (!(A.ablate & 2)) env_step_phase_a<E_T>(A, blockIdx.x, t, smem, csc0);
-    } else if (!kPrefetch && !(A.ablate & 8)) {
+    } else if (kPrefetch) {
+        if (stack_on && !(A.ablate & 256)) {
+            hist_store<HP, HGYM_OBS_FRAME, NIO>(A.out.obs, geom.e0, geom.nE, (int)(ring_step % HP), t - 64, NTH, nullptr, A.cfg.clip_obs, hist_o);
+            hist_store<HCP, HGYM_PRIV_FRAME, NIP>(A.out.priv_obs, geom.e0, geom.nE, (int)(ring_step % HCP), t - 64, NTH, nullptr, A.cfg.clip_obs,
+                                                  hist_p);
+        }
+    } else if (!(A.ablate & 8)) {
         env_step_stack_old<H_T, HC_T, E_T>(A, blockIdx.x, t - 64, blockDim.x - 64, ring_step);
     }
     __syncthreads();
-    if (!(A.ablate & 4)) env_stage_out<E_T>(A, blockIdx.x, t, blockDim.x, smem);
-    if (!(A.ablate & 8)) {
-        if (kPrefetch && stack_on) {
-            const int* s_reset = reinterpret_cast<const int*>(smem + lds_map(geom.E).reset_i);
-            hist_store<HP, HGYM_OBS_FRAME, NIO>(A.out.obs, geom.e0, geom.nE, (int)(ring_step % HP), t, 256, s_reset, A.cfg.clip_obs, hist_o);
-            hist_store<HCP, HGYM_PRIV_FRAME, NIP>(A.out.priv_obs, geom.e0, geom.nE, (int)(ring_step % HCP), t, 256, s_reset, A.cfg.clip_obs, hist_p);
+    if (kPrefetch && stack_on && (A.ablate & 256)) {      // A/B experiment: the stores after the scalar phase instead
+        if (t >= 64) {
+            hist_store<HP, HGYM_OBS_FRAME, NIO>(A.out.obs, geom.e0, geom.nE, (int)(ring_step % HP), t - 64, NTH, nullptr, A.cfg.clip_obs, hist_o);
+            hist_store<HCP, HGYM_PRIV_FRAME, NIP>(A.out.priv_obs, geom.e0, geom.nE, (int)(ring_step % HCP), t - 64, NTH, nullptr, A.cfg.clip_obs,
+                                                  hist_p);
         }
-        env_step_phase_b<H_T, HC_T, E_T>(A, blockIdx.x, t, blockDim.x, smem, csc0, ring_step, kPrefetch);
+        __syncthreads();
     }
+    if (!(A.ablate & 4)) env_stage_out<E_T>(A, blockIdx.x, t, blockDim.x, smem);
+    if (!(A.ablate & 8)) env_step_phase_b<H_T, HC_T, E_T>(A, blockIdx.x, t, blockDim.x, smem, csc0, ring_step, false);
 }
 
 __global__ __launch_bounds__(1024) void env_finalize_kernel(const EnvArgs A) {

@@ -1205,9 +1205,10 @@ HG_HD void stack_reset_fix(float* __restrict__ ring, const int* s_reset, float* 
     }
 }
 
-// Register-prefetched form of the older-frames copy for the compiled-in geometry: every lane issues ALL of its history
-// loads at kernel entry, back to back, together with the state staging loads -- one memory round trip for the whole
-// step -- and stores them, clipped and reset-aware, after the per-env phase.
+// Register-prefetched form of the older-frames copy for the compiled-in geometry: the lanes of wavefronts 1..3 issue ALL
+// of the history loads at kernel entry, back to back, together with the state staging loads -- one memory round trip for
+// the whole step -- and store them, clipped, WHILE wavefront 0 runs the per-env scalar phase; the few envs that turn out
+// to reset are fixed up afterwards (stack_reset_fix), exactly as in the unprefetched form (stack_old).
 // The H-1 older frames are, in ring order, two straight segments: A = [(slot+1)*F, H*F) and B = [0, slot*F).  Each is cut
 // into 16-byte items; the last item of a segment is shifted back to END at the segment end (it overlaps its neighbour and
 // rewrites identical values), so every item is one unconditional unaligned 16-byte load and one 16-byte store: no
@@ -1259,7 +1260,7 @@ HG_HD void hist_store(float* __restrict__ dst, int e0, int nE, int slot_new, int
         const int le = i / S;
         int so, d_o;
         hist_slot<H, F>(slot_new, i - le * S, so, d_o);
-        const bool rs = s_reset[le] != 0;
+        const bool rs = s_reset ? s_reset[le] != 0 : false;     // null: reset envs are fixed up later (stack_reset_fix)
         EnvF4 q;
 #pragma unroll
         for (int k = 0; k < 4; ++k) q.v[k] = rs ? 0.0f : clampf(v[u][k], -lim, lim);
