@@ -5,9 +5,9 @@
 //                        MFMA operand registers.  Used by the rollout (PPO.act, BM = 32) and by the update (BM = 64,
 //                        which also writes the activations the backward pass needs).
 //   mlp_bwd_kernel<BM>   dZ_l = (dZ_{l+1} * W_{l+1}) .* elu'(H_l) for l = 2, 1, 0 in one launch, same structure.
-//   dw_kernel            all eight weight-gradient products dW_l = dZ_l^T * X_l (+ bias gradients) in ONE launch:
-//                        contraction over the batch, operands DMA'd (global_load_lds) into an LDS ring and read with the
-//                        gfx950 transpose read (ds_read_b64_tr_b16), so no transposed copy of anything exists in HBM.
+//   dw_kernel_rs         all eight weight-gradient products dW_l = dZ_l^T * X_l (+ bias gradients) in ONE launch:
+//                        contraction over the batch, operands staged registers -> LDS and read with the gfx950
+//                        transpose read (ds_read_b64_tr_b16), so no transposed copy of anything exists in HBM.
 //
 // Activation layout ("block layout", global and LDS alike): a (rows x cols) bf16 matrix is stored as 16x16 blocks,
 // block (mb, cb) at ((mb * CB + cb) * 512) bytes, row-major inside the block (32 B per row).  With it
@@ -661,7 +661,6 @@ __global__ __launch_bounds__(NW * 64) void mlp_bwd_kernel(const BwdArgs a) {
 // ================================================================================================ weight gradients
 // dW[n][k] = sum_m Z[m][n] * X[m][k]  (Z = dZ_l, X = layer input), 128 x 128 output tiles, contraction split over blockIdx.y.
 constexpr int DW_THREADS = 256;
-constexpr int DW_STAGES = 4;
 constexpr int DW_STAGE_BYTES = 16384;     // 32 rows x (8 Z blocks + 8 X blocks) x 512 B
 constexpr int DW_MAX_PRODUCTS = 8;
 
@@ -695,121 +694,13 @@ __device__ __forceinline__ u32x4 tr_frag(const char* p0, const char* p1) {
     return __builtin_bit_cast(u32x4, pr);
 }
 
-__global__ __launch_bounds__(DW_THREADS) void dw_kernel(const DwArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wi = wave >> 1, wj = wave & 1;
-    const int r = lane & 15, q = lane >> 4;
-    // Block -> (tile, split).  Workgroups are dealt round-robin to the 8 XCDs (block b -> XCD b % 8), each with a private
-    // 4 MiB L2.  All tiles of one split stream the SAME batch rows, so a split is pinned to one XCD: its ~62 tiles run there
-    // concurrently, in near lock-step, and every operand block is fetched from HBM once and re-read from that L2 by the other
-    // tiles.  (Placement is a speed matter only; nothing depends on it for correctness.)
-    const int bid = blockIdx.x;
-    const int xcd = bid & 7, slot = bid >> 3;
-    const int split = xcd + 8 * (slot / a.total_tiles);
-    const int tile = slot % a.total_tiles;
-    if (split >= a.splits) return;
-    int pi = 0;
-#pragma unroll
-    for (int i = 1; i < DW_MAX_PRODUCTS; ++i)
-        if (i < a.np && tile >= a.p[i].tile0) pi = i;
-    const DwProduct& P = a.p[pi];
-    const int tl = tile - P.tile0;
-    const int tn = tl / P.tiles_k, tk = tl - tn * P.tiles_k;
-    const int cbz0 = tn * 8, cbx0 = tk * 8;
-    const int step0 = split * a.steps_per_split;
-    int nsteps = a.steps_total - step0;
-    nsteps = nsteps < a.steps_per_split ? nsteps : a.steps_per_split;
-
-    // DMA assignment: wave w moves pieces 4w..4w+3 of every stage; piece p = (operand, row block, block pair)
-    const int op = wave >> 1, mbl = wave & 1;
-    const char* gsrc[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int CB = op ? P.CBx : P.CBz;
-        int cb = (op ? cbx0 : cbz0) + 2 * j;
-        cb = cb + 1 < CB ? cb : CB - 2;                       // clamp surplus pairs onto valid blocks (results unused)
-        gsrc[j] = reinterpret_cast<const char*>(op ? P.X : P.Z) + ((int64_t)(2 * step0 + mbl) * CB + cb) * 512 + lane * 16;
-    }
-    const int64_t gstep = (int64_t)2 * (op ? P.CBx : P.CBz) * 512;   // bytes per 32-row step
-    auto issue = [&](int t) {
-        char* dst = smem + (t % DW_STAGES) * DW_STAGE_BYTES + wave * 4096;
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc[j] + (int64_t)t * gstep),
-                                             (__attribute__((address_space(3))) void*)(dst + j * 1024), 16, 0, 0);
-    };
-
-    f32x4 acc[4][4];
-    f32x4 accb[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        accb[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
-    const bool do_bias = (P.b_off >= 0) && tk == 0 && wi == 0;
-    const u32x4 ones = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
-
-#pragma unroll
-    for (int s = 0; s < DW_STAGES - 1; ++s)
-        if (s < nsteps) issue(s);
-    for (int t = 0; t < nsteps; ++t) {
-        if (nsteps - 1 - t >= DW_STAGES - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (DW_STAGES - 2)) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (t + DW_STAGES - 1 < nsteps) issue(t + DW_STAGES - 1);
-        const char* st = smem + (t % DW_STAGES) * DW_STAGE_BYTES;
-        u32x4 xa[4], zb[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const char* px = st + 8192 + (wi * 4 + i) * 512 + lane * 8;
-            xa[i] = tr_frag(px, px + 4096);
-            const char* pz = st + (wj * 4 + i) * 512 + lane * 8;
-            zb[i] = tr_frag(pz, pz + 4096);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) mma_frag<__bf16>(xa[i], zb[j], acc[i][j]);
-        if (do_bias) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) mma_frag<__bf16>(ones, zb[j], accb[j]);
-        }
-    }
-
-    // lane holds dW[n = .. + r][k = .. + 4q + e]
-    float* __restrict__ slab = a.slabs + (int64_t)split * a.slab_stride;
-    float* __restrict__ out = slab + P.w_off;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int nn = (cbz0 + wj * 4 + j) * 16 + r;
-        if (nn >= P.N) continue;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int kk = (cbx0 + wi * 4 + i) * 16 + 4 * q;
-            float* p = out + (int64_t)nn * P.K + kk;
-            if (kk + 3 < P.K) {
-                F4 v = {{acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]}};
-                *reinterpret_cast<F4*>(p) = v;
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (kk + e < P.K) p[e] = acc[i][j][e];
-            }
-        }
-        if (do_bias && q == 0) slab[P.b_off + nn] = accb[j][0];
-    }
-}
-
-// ---- register-staged variant ------------------------------------------------------------------------------------------
-// Same tiles, same LDS image, same tr-reads; only the transport differs.  A `global_load_lds` piece (1 KiB per wave) costs
-// the issuing wave 60-185 cycles (MI355X_MICROARCH.md, LDS-DMA issue cost), four pieces per 32-row step next to 20 MFMAs
-// (320 cycles): the DMA issue, not memory, set the pace (MFMA pipe 20 % busy, L2 at 7 TB/s).  Here every wave keeps
-// DW_RS stages of its four pieces in registers (global_load_dwordx4, ~16 issue cycles each), and passes one stage per step
-// to a 2-stage LDS buffer with ds_write_b128.  The steady-state loop is branch-free -- stages past the end of the split are
-// read from a page of zeros, so they add nothing -- which keeps the compiler's vmcnt exact (two younger stages in flight).
+// Operand transport: every wave keeps DW_RS stages of its four 1-KiB pieces in registers (global_load_dwordx4) and passes one
+// stage per step to a 2-stage LDS buffer with ds_write_b128; the fragments are then read with the transpose read.  (A first
+// version DMA'd the pieces straight into an LDS ring with global_load_lds: a piece costs the issuing wave 60-185 cycles
+// (MI355X_MICROARCH.md, LDS-DMA issue cost), four pieces per 32-row step next to 20 MFMAs = 320 cycles, so the DMA issue,
+// not memory, set the pace -- MFMA pipe 20 % busy, L2 at 7 TB/s, 272 us per launch against 183 us now.)  The steady-state
+// loop is branch-free -- stages past the end of the split are read from a page of zeros, so they add nothing -- which keeps
+// the compiler's vmcnt exact (two younger stages in flight).  Depths 2..5 measure the same; 3 is used.
 template <int DW_RS>
 __global__ __launch_bounds__(DW_THREADS, 2) void dw_kernel_rs(const DwArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -817,7 +708,10 @@ __global__ __launch_bounds__(DW_THREADS, 2) void dw_kernel_rs(const DwArgs a) {
     const int wi = wave >> 1, wj = wave & 1;
     const int r = lane & 15, q = lane >> 4;
     const int bid = blockIdx.x;
-    const int xcd = bid & 7, slot = bid >> 3;              // a split stays on one XCD (see dw_kernel)
+    // Block -> (tile, split).  Workgroups are dealt round-robin to the 8 XCDs (block b -> XCD b % 8), each with a private
+    // 4 MiB L2.  All tiles of one split stream the SAME batch rows, so a split is pinned to one XCD: its ~62 tiles run there
+    // concurrently and every operand block is fetched from HBM once and re-read from that L2 by the other tiles.
+    const int xcd = bid & 7, slot = bid >> 3;
     const int split = xcd + 8 * (slot / a.total_tiles);
     const int tile = slot % a.total_tiles;
     if (split >= a.splits) return;

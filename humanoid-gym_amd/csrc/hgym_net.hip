@@ -141,7 +141,7 @@ static int32_t ws_layout(const HgymNetConfig* c, WsLayout* w) {
     w->P = poff;
     w->Ps = round_up(poff, 64);
     w->splits = MAX_SPLITS;
-    w->dw_splits = getenv("HGYM_DW_SPLITS") ? atoi(getenv("HGYM_DW_SPLITS")) : 8;
+    w->dw_splits = 8;        // batch splits of the dW contraction, one per XCD (16 measured 3 % slower: twice the slab traffic)
     w->slabs = take((int64_t)w->splits * w->Ps * 4);
     w->partials = take((int64_t)MAX_LOSS_BLOCKS * LOSS_PARTIALS * 4);
     w->zeros = take(4096);
@@ -560,14 +560,9 @@ int32_t launch_gemm(const GemmArgs& g0, int splits, hipStream_t s) {
     splits = ceil_div(stages, per);
     g.k_chunk = per * SE;
     prof_begin(HGYM_PROF_GEMM, s);
-    static const int big = getenv("HGYM_GEMM_BIG") ? atoi(getenv("HGYM_GEMM_BIG")) : 0;   // tile experiment knob
     const int64_t t128 = (int64_t)ceil_div(g.M, 128) * ceil_div(g.N, 128) * splits;
     if (g.N <= 16) launch_cfg<T, 128, 16, 4, 1>(g, splits, s);
     else if (g.M <= 16) launch_cfg<T, 16, 128, 1, 4>(g, splits, s);
-    else if (big == 1 && g.M >= 256 && g.N >= 128 && (int64_t)ceil_div(g.M, 256) * ceil_div(g.N, 128) * splits >= 512)
-        launch_cfg<T, 256, 128, 4, 2>(g, splits, s);
-    else if (big == 2 && g.M >= 256 && g.N >= 256 && (int64_t)ceil_div(g.M, 256) * ceil_div(g.N, 256) * splits >= 256)
-        launch_cfg<T, 256, 256, 4, 2>(g, splits, s);
     else if (t128 >= 192) launch_cfg<T, 128, 128, 2, 2>(g, splits, s);
     else launch_cfg<T, 64, 64, 2, 2>(g, splits, s);
     prof_end(HGYM_PROF_GEMM, s, 2.0 * (double)g.M * (double)g.N * (double)g.K);   // padded K: the flops the MFMAs execute
@@ -712,16 +707,9 @@ struct NetRunner {
         }
         const int pcls = train ? HGYM_PROF_MLP_FWD : HGYM_PROF_POLICY;
         prof_begin(pcls, s);
-        // tile shape / weight-ring depth: 64-row tiles x 16 waves for the update (and huge rollouts), 32-row tiles x 8 waves
-        // otherwise.  HGYM_FWD_TILE / HGYM_RING are tuning overrides for experiments.
-        static const int tile_env = getenv("HGYM_FWD_TILE") ? atoi(getenv("HGYM_FWD_TILE")) : 0;
-        static const int ring_env = getenv("HGYM_RING") ? atoi(getenv("HGYM_RING")) : 0;
-        const int tile = tile_env ? tile_env : ((train || M >= 16384) ? 64 : 32);
-        int32_t rc;
-        static const int waves_env = getenv("HGYM_FWD_WAVES") ? atoi(getenv("HGYM_FWD_WAVES")) : 0;
-        if (tile == 64 && waves_env == 8) rc = ring_env == 4 ? launch_fwd<64, 8, 4>(a, nets) : launch_fwd<64, 8, 2>(a, nets);
-        else if (tile == 64) rc = launch_fwd<64, 16, 2>(a, nets);
-        else rc = ring_env == 2 ? launch_fwd<32, 8, 2>(a, nets) : launch_fwd<32, 8, 4>(a, nets);
+        // 64-row tiles x 16 waves (weight ring depth 2) for the update and for huge rollouts, 32-row tiles x 8 waves (depth 4)
+        // otherwise; measured alternatives (64 rows x 8 waves, 32-row tiles for the update, other depths) were equal or slower
+        const int32_t rc = (train || M >= 16384) ? launch_fwd<64, 16, 2>(a, nets) : launch_fwd<32, 8, 4>(a, nets);
         double fl = 0.0;
         for (int i = first; i < first + nets; ++i)
             for (int l = 0; l < 4; ++l) fl += 2.0 * (double)M * w.net[i].layer[l].N * w.net[i].layer[l].K;   // algorithmic (unpadded) flops
@@ -820,30 +808,10 @@ struct NetRunner {
             d.slabs = at<float>(w.slabs);
             d.slab_stride = w.Ps;
             d.zeros = at<char>(w.zeros);
-            static const int dma = getenv("HGYM_DW_DMA") ? atoi(getenv("HGYM_DW_DMA")) : 0;   // 1: the LDS-DMA transport (A/B experiments)
-            if (!dma) {
-                prof_begin(HGYM_PROF_DW, s);
-                static const int rs = getenv("HGYM_DW_RS") ? atoi(getenv("HGYM_DW_RS")) : 3;
-                const dim3 grid(tile * (int)round_up(w.dw_splits, 8));
-                if (rs == 5) hipLaunchKernelGGL(dw_kernel_rs<5>, grid, dim3(DW_THREADS), 2 * DW_STAGE_BYTES, s, d);
-                else if (rs == 4) hipLaunchKernelGGL(dw_kernel_rs<4>, grid, dim3(DW_THREADS), 2 * DW_STAGE_BYTES, s, d);
-                else if (rs == 2) hipLaunchKernelGGL(dw_kernel_rs<2>, grid, dim3(DW_THREADS), 2 * DW_STAGE_BYTES, s, d);
-                else hipLaunchKernelGGL(dw_kernel_rs<3>, grid, dim3(DW_THREADS), 2 * DW_STAGE_BYTES, s, d);
-                prof_end(HGYM_PROF_DW, s, fl);
-                HG_CHECK_LAUNCH("dw_kernel_rs");
-            } else {
-            static bool attr_done = false;
-            if (!attr_done) {
-                if (hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        DW_STAGES * DW_STAGE_BYTES) != hipSuccess)
-                    HG_FAIL(HGYM_E_LAUNCH, "cannot reserve LDS for dw_kernel");
-                attr_done = true;
-            }
             prof_begin(HGYM_PROF_DW, s);
-            hipLaunchKernelGGL(dw_kernel, dim3(tile * (int)round_up(w.dw_splits, 8)), dim3(DW_THREADS), DW_STAGES * DW_STAGE_BYTES, s, d);
+            hipLaunchKernelGGL(dw_kernel_rs<3>, dim3(tile * (int)round_up(w.dw_splits, 8)), dim3(DW_THREADS), 2 * DW_STAGE_BYTES, s, d);
             prof_end(HGYM_PROF_DW, s, fl);
-            HG_CHECK_LAUNCH("dw_kernel");
-            }
+            HG_CHECK_LAUNCH("dw_kernel_rs");
         }
         const SegTable tab = segments(true);
         prof_begin(HGYM_PROF_REDUCE, s);
