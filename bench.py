@@ -131,7 +131,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    runner.learn(num_learning_iterations=max(args.warmup, 0), init_at_random_ep_len=True)
+    # untimed warm-up: W iterations, but never fewer than 2 -- the first iteration runs the rollout eagerly, the second captures it
+    # into the HIP graph the timed iterations replay (a capture inside the timed region would not be the steady state)
+    runner.learn(num_learning_iterations=max(args.warmup, 2), init_at_random_ep_len=True)
     barrier()
     t0 = time.perf_counter()
     # K learning iterations, enqueued back to back (the runner reads nothing back between iterations when it does not log)
