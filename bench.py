@@ -149,13 +149,17 @@ def main():
     value = T * N * world * args.steps / elapsed
 
     roofline = None
-    if rank == 0 and not args.no_roofline:
+    if not args.no_roofline:
         # live per-kernel timing with HIP events on the launch stream (hgym_prof_*).  Events cannot be recorded inside a
-        # replayed HIP graph, so these two iterations run the rollout eagerly (same kernels, same launch order).
+        # replayed HIP graph, so these two iterations run the rollout eagerly (same kernels, same launch order).  EVERY rank
+        # runs them (the update contains the gradient all-reduce); only rank 0 records and reports.
         os.environ["HGYM_GRAPH"] = "0"
-        L.lib.hgym_prof_enable(1)
+        if rank == 0:
+            L.lib.hgym_prof_enable(1)
         runner.learn(num_learning_iterations=2, init_at_random_ep_len=False)
         torch.cuda.synchronize()
+        os.environ["HGYM_GRAPH"] = "1"
+    if rank == 0 and not args.no_roofline:
         iter_ms = elapsed / args.steps * 1e3
         mfma_peak = MFMA_BF16_PEAK_TFLOPS if args.precision == "bf16" else 157.3
         classes = [  # (class id, kernel, bound, unit of `work`)
@@ -178,7 +182,6 @@ def main():
             ks.append(dict(kernel=name, bound=bound, launches_per_iter=n // 2, avg_launch_us=ms / n * 1e3, achieved=ach, peak=peak, unit=unit,
                            frac=ach / peak, share_of_iteration=ms / 2 / iter_ms, traffic=traffic.get(name)))
         L.lib.hgym_prof_enable(0)
-        os.environ["HGYM_GRAPH"] = "1"
         ks.sort(key=lambda k: -k["share_of_iteration"])
         dom = ks[0]
         roofline = dict(bound=dom["bound"], achieved=dom["achieved"], peak=dom["peak"], unit=dom["unit"], frac=dom["frac"],
@@ -199,7 +202,7 @@ def main():
         }
         if roofline is not None:
             out["roofline"] = roofline
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # the CPU baseline leg belongs to the N=1 run only
             out["cpu_baseline"] = cpu_baseline(N, T)
         print(json.dumps(out))
     if dist is not None:
