@@ -155,7 +155,9 @@ class OnPolicyRunner:
                     graph = torch.cuda.CUDAGraph()
                     ep_infos = []
                     torch.cuda.synchronize()
-                    with torch.cuda.graph(graph):
+                    # thread-local capture mode: with torch.distributed initialised, the RCCL watchdog thread polls events
+                    # concurrently; only this thread's launches belong to the capture
+                    with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                         out = rollout(obs_all[0], priv_all[0])
                     self._graph = dict(graph=graph, out=out, ep_infos=ep_infos, key=(id(env), id(alg.storage), log_on, sink_ok),
                                        stats=(cur_reward_sum, cur_episode_length, done_stats))
