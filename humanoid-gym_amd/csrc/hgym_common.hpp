@@ -36,7 +36,8 @@ char* last_error_buf();  // thread-local, defined in hgym_capi.hip
 bool prof_on();
 void prof_begin(int cls, hipStream_t s);
 void prof_end(int cls, hipStream_t s, double work);
-long long* phase_buffer(int64_t blocks);   // hgym_prof_phase_buffer: null unless set and large enough
+long long* phase_buffer(int64_t blocks);
+int device_cus();                           // compute units of the current device (hgym_env.hip)   // hgym_prof_phase_buffer: null unless set and large enough
 
 static inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 static inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }

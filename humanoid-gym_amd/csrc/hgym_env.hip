@@ -115,10 +115,11 @@ int device_cus() {
 }
 
 static int pick_envs_per_block(int N) {
-    // one workgroup per CU up to 4096 envs (E = 16), then wider slices; multiples of 4 keep every slice of the
-    // row-major outputs 16-byte aligned
-    const int cus = device_cus() > 0 ? device_cus() : 256;
-    return (N <= 16 * cus * 2) ? 16 : 32;
+    // 16 envs per workgroup at every size: one workgroup per CU at 4096 envs, two co-resident ones (240 VGPRs) beyond.
+    // 32-env workgroups (HGYM_ENV_EPB=32, kept for experiments) need 256 + 69 registers, run one per CU and measured
+    // 80 us against 67 us at 16 384 envs.  Multiples of 4 keep every slice of the row-major outputs 16-byte aligned.
+    (void)N;
+    return 16;
 }
 
 static int32_t check_common(const HgymEnvConfig* cfg, const HgymSimTensors* sim, const HgymEnvState* st) {

@@ -55,7 +55,7 @@ struct WsLayout {
     int dw_splits;
 };
 
-constexpr int MAX_LOSS_BLOCKS = 1024;
+constexpr int MAX_LOSS_BLOCKS = 8192;   // 256 samples each: minibatches up to 2 M samples
 constexpr int LOSS_PARTIALS = 32;   // floats per loss workgroup: surrogate, value loss, entropy, kl, dstd[12], dbias_mu[12], dbias_v, pad
 
 static bool fused_supported(const HgymNetConfig* c) {
@@ -707,9 +707,11 @@ struct NetRunner {
         }
         const int pcls = train ? HGYM_PROF_MLP_FWD : HGYM_PROF_POLICY;
         prof_begin(pcls, s);
-        // 64-row tiles x 16 waves (weight ring depth 2) for the update and for huge rollouts, 32-row tiles x 8 waves (depth 4)
-        // otherwise; measured alternatives (64 rows x 8 waves, 32-row tiles for the update, other depths) were equal or slower
-        const int32_t rc = (train || M >= 16384) ? launch_fwd<64, 16, 2>(a, nets) : launch_fwd<32, 8, 4>(a, nets);
+        // 32-row tiles x 8 waves (weight ring depth 4) while they fit the chip in one round (one workgroup per CU: 2 * M / 32
+        // <= CUs, i.e. 4096 envs), 64-row tiles x 16 waves (depth 2) for the update and for larger rollouts; measured
+        // alternatives (64 rows x 8 waves, 32-row tiles for the update, other depths) were equal or slower
+        const int cus = device_cus() > 0 ? device_cus() : 256;
+        const int32_t rc = (train || nets * ceil_div(M, 32) > cus) ? launch_fwd<64, 16, 2>(a, nets) : launch_fwd<32, 8, 4>(a, nets);
         double fl = 0.0;
         for (int i = first; i < first + nets; ++i)
             for (int l = 0; l < 4; ++l) fl += 2.0 * (double)M * w.net[i].layer[l].N * w.net[i].layer[l].K;   // algorithmic (unpadded) flops

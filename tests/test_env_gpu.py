@@ -64,8 +64,8 @@ def test_generic_frame_stack_gpu(hip):
 
 @pytest.mark.parametrize("N", [4096, 8192, 5000, 16384])
 def test_fused_synthetic_step_properties(hip, N):
-    """BASELINE configs[1] (4096 envs) and configs[3] (8192 envs/GPU, stack 15), a ragged count, and 16 384 envs (the 32-env
-    workgroup shape).  Full-size fused fast path (pre_physics + synthetic physics + post_physics in one launch, internal
+    """BASELINE configs[1] (4096 envs) and configs[3] (8192 envs/GPU, stack 15), a ragged count, and 16 384 envs (four
+    workgroups per CU).  Full-size fused fast path (pre_physics + synthetic physics + post_physics in one launch, internal
     Philox): size-independent properties instead of an element-wise oracle --
     obs rows are the shifted previous rows plus a new frame, masks are consistent, counters advance."""
     import ctypes as C
