@@ -134,7 +134,7 @@ static int32_t check_common(const HgymEnvConfig* cfg, const HgymSimTensors* sim,
 }
 
 static int32_t launch_step(const HgymEnvConfig* cfg, const HgymSimTensors* sim, const HgymEnvState* st, const HgymEnvOut* out,
-                           const HgymEnvNoise* noise, const float* actions_in, int mode, int fused, hipStream_t s) {
+                           const HgymEnvNoise* noise, float* actions_in, int mode, int fused, hipStream_t s) {
     int32_t rc = check_common(cfg, sim, st);
     if (rc) return rc;
     HG_REQUIRE(sim && out, HGYM_E_BADARG, "null sim/out");
@@ -277,13 +277,13 @@ int32_t hgym_post_physics(const HgymEnvConfig* cfg, const HgymSimTensors* sim, c
 }
 
 int32_t hgym_env_step_synth(const HgymEnvConfig* cfg, const HgymSimTensors* sim, const HgymEnvState* st, const HgymEnvOut* out,
-                            const float* actions_in, void* stream) {
+                            float* actions_in, void* stream) {
     HG_REQUIRE(actions_in, HGYM_E_BADARG, "null actions");
     return launch_step(cfg, sim, st, out, nullptr, actions_in, MODE_STEP, 1, (hipStream_t)stream);
 }
 
 static int32_t launch_simple(void (*kern)(const EnvArgs), const char* name, const HgymEnvConfig* cfg, const HgymSimTensors* sim,
-                             const HgymEnvState* st, const HgymEnvNoise* noise, const float* actions_in, void* stream) {
+                             const HgymEnvState* st, const HgymEnvNoise* noise, float* actions_in, void* stream) {
     int32_t rc = check_common(cfg, sim, st);
     if (rc) return rc;
     EnvArgs A;
@@ -299,7 +299,7 @@ static int32_t launch_simple(void (*kern)(const EnvArgs), const char* name, cons
     return HGYM_OK;
 }
 
-int32_t hgym_pre_physics(const HgymEnvConfig* cfg, const HgymEnvState* st, const float* actions_in, const HgymEnvNoise* noise,
+int32_t hgym_pre_physics(const HgymEnvConfig* cfg, const HgymEnvState* st, float* actions_in, const HgymEnvNoise* noise,
                          void* stream) {
     HG_REQUIRE(actions_in, HGYM_E_BADARG, "null actions");
     return launch_simple(pre_physics_kernel, "pre_physics_kernel", cfg, nullptr, st, noise, actions_in, stream);

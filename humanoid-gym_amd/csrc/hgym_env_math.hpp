@@ -24,7 +24,7 @@ struct EnvArgs {
     HgymEnvState st;
     HgymEnvOut out;
     HgymEnvNoise noise;
-    const float* actions_in;  // (N,12) row-major or null
+    float* actions_in;        // (N,12) row-major or null; written only when cfg.use_ref_actions (humanoid_env.py:190-191)
     int mode;
     int fused;                // 1: pre_physics + synthetic physics run inside the step kernel
     int envs_per_block;
@@ -146,7 +146,12 @@ HG_HD float filter_action(const HgymEnvConfig& c, float a_in, float a_prev, floa
     return clampf(a, -c.clip_actions, c.clip_actions);
 }
 HG_HD void pre_physics_joint(const EnvArgs& A, int e, int N, int j, float u, float z) {
-    FG(A.st.actions, j) = filter_action(A.cfg, A.actions_in[(int64_t)e * 12 + j], FG(A.st.actions, j), u, z);
+    float a_in = A.actions_in[(int64_t)e * 12 + j];
+    if (A.cfg.use_ref_actions) {          // actions += self.ref_action (= 2 * ref_dof_pos of the last compute_observations), in place
+        a_in = a_in + 2.0f * FG(A.st.ref_dof_pos, j);
+        A.actions_in[(int64_t)e * 12 + j] = a_in;
+    }
+    FG(A.st.actions, j) = filter_action(A.cfg, a_in, FG(A.st.actions, j), u, z);
 }
 
 HG_HD void pre_physics_env(const EnvArgs& A, const RngKey& rk, int e, int N) {
@@ -1031,6 +1036,7 @@ HG_HD void env_fill_draws(const EnvArgs& A, int block, int t, int nthreads, floa
 // action filter + synthetic joint integration, one (env, joint) pair per lane (fused backend only)
 constexpr int kStateOffActions = 4;     // component offsets of state fields inside the [136][E] LDS image
 constexpr int kStateOffTorques = 4 + 12 * 4 + 6;
+constexpr int kStateOffRefPos = kStateOffTorques + 12 + 2 * 4;     // ... torques, feet_air_time, last_contacts, feet_height, last_feet_z
 template <int E_T>
 HG_HD void env_step_joints(const EnvArgs& A, int block, int t, int nthreads, float* smem) {
     const int E = E_T > 0 ? E_T : A.envs_per_block;
@@ -1044,7 +1050,12 @@ HG_HD void env_step_joints(const EnvArgs& A, int block, int t, int nthreads, flo
         const int j = i / E, le = i - j * E;
         if (le >= nE) continue;
         float* act = smem + m.state + (kStateOffActions + j) * E + le;
-        const float a = filter_action(A.cfg, smem[m.actions_in + le * 12 + j], *act, smem[m.u_delay + le], smem[m.z_act + le * 12 + j]);
+        float a_in = smem[m.actions_in + le * 12 + j];
+        if (A.cfg.use_ref_actions) {      // see pre_physics_joint; the LDS row goes back to the caller's tensor in env_stage_out
+            a_in = a_in + 2.0f * smem[m.state + (kStateOffRefPos + j) * E + le];
+            smem[m.actions_in + le * 12 + j] = a_in;
+        }
+        const float a = filter_action(A.cfg, a_in, *act, smem[m.u_delay + le], smem[m.z_act + le * 12 + j]);
         *act = a;
         float q = smem[m.dof_pos + j * E + le], qd = smem[m.dof_vel + j * E + le], tq;
         integrate_joint(A.cfg, j, a, q, qd, tq);
@@ -1079,6 +1090,8 @@ HG_HD void env_stage_out(const EnvArgs& A, int block, int t, int nthreads, float
     const LdsMap m = lds_map(E);
     copy_comp_rows<false>(nullptr, A, 0, kMutableComps, smem + m.state, E, e0, nE, N, t, nthreads);
     stage_sim<false>(A, m, smem, E, e0, nE, t, nthreads, A.mode == MODE_STEP && A.fused);   // the synthetic physics wrote contacts / rigid bodies
+    if (A.cfg.use_ref_actions && A.mode == MODE_STEP && A.fused && A.actions_in)       // the in-place `actions += ref_action`
+        for (int i = t; i < nE * 12; i += nthreads) A.actions_in[(int64_t)e0 * 12 + i] = smem[m.actions_in + i];
     const uint8_t* fl = reinterpret_cast<const uint8_t*>(smem + m.flags);
     for (int i = t; i < nE; i += nthreads) {
         A.st.episode_length[e0 + i] = reinterpret_cast<const int64_t*>(smem + m.ep_len)[i];

@@ -29,7 +29,7 @@ class EnvConfig(C.Structure):
         ("num_envs", C.c_int32), ("frame_stack", C.c_int32), ("c_frame_stack", C.c_int32), ("decimation", C.c_int32),
         ("sim_dt", C.c_float), ("dt", C.c_float),
         ("max_episode_length", C.c_int32), ("resample_steps", C.c_int32), ("push_interval", C.c_int32),
-        ("push_robots", C.c_int32), ("add_noise", C.c_int32), ("heading_command", C.c_int32),
+        ("push_robots", C.c_int32), ("add_noise", C.c_int32), ("heading_command", C.c_int32), ("use_ref_actions", C.c_int32),
         ("clip_actions", C.c_float), ("clip_obs", C.c_float), ("action_scale", C.c_float),
         ("action_delay", C.c_float), ("action_noise", C.c_float), ("noise_level", C.c_float),
         ("obs_noise", C.c_float * OBS_FRAME),

@@ -71,8 +71,6 @@ class LeggedRobot(BaseTask):
             raise NotImplementedError("terrain height measurements are outside the hot path (SURVEY.md §8f item 3)")
         if not cfg.commands.heading_command or cfg.commands.curriculum:
             raise NotImplementedError("only heading_command=True without command curriculum is built")
-        if getattr(cfg.env, "use_ref_actions", False):
-            raise NotImplementedError("use_ref_actions is not built (SURVEY.md §8f item 3)")
         c = default_env_config(self.num_envs, seed=getattr(cfg, "seed", 5), frame_stack=cfg.env.frame_stack,
                                c_frame_stack=cfg.env.c_frame_stack)
         c.decimation = cfg.control.decimation
@@ -83,6 +81,7 @@ class LeggedRobot(BaseTask):
         c.push_interval = int(cfg.domain_rand.push_interval)
         c.push_robots = int(bool(cfg.domain_rand.push_robots))
         c.add_noise = int(bool(cfg.noise.add_noise))
+        c.use_ref_actions = int(bool(getattr(cfg.env, "use_ref_actions", False)))
         c.clip_actions = cfg.normalization.clip_actions
         c.clip_obs = cfg.normalization.clip_observations
         c.action_scale = cfg.control.action_scale
@@ -279,6 +278,8 @@ class LeggedRobot(BaseTask):
         obs, priv, out = self._next_out()
         L.check(L.lib.hgym_env_step_synth(C.byref(self._ncfg), C.byref(self._sim_s), C.byref(self._st_s), C.byref(out),
                                           L.fptr(a), self._stream()), "hgym_env_step_synth")
+        if self._ncfg.use_ref_actions and a.data_ptr() != actions.data_ptr():
+            actions.copy_(a)         # the reference mutates the caller's tensor (humanoid_env.py:190-191: actions += ref_action)
         self.obs_buf, self.privileged_obs_buf = obs, priv
         return self.obs_buf, self.privileged_obs_buf, self.rew_buf, self.reset_buf, self.extras
 

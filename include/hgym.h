@@ -72,6 +72,8 @@ typedef struct HgymEnvConfig {
     int32_t push_robots;          /* 1 */
     int32_t add_noise;            /* 1 */
     int32_t heading_command;      /* 1 (only mode supported) */
+    int32_t use_ref_actions;      /* 0 for XBot-L (humanoid_config.py:49); 1: actions += 2 * ref_dof_pos, IN PLACE, before the clip
+                                     (humanoid_env.py:190-191) */
     float clip_actions, clip_obs; /* 18, 18 */
     float action_scale;           /* 0.25 */
     float action_delay, action_noise; /* 0.5, 0.02 */
@@ -188,8 +190,10 @@ int32_t hgym_env_reset_all(const HgymEnvConfig* cfg, const HgymSimTensors* sim, 
                            const HgymEnvOut* out, const HgymEnvNoise* noise, void* stream);
 
 /* XBotLFreeEnv.step head + LeggedRobot.step clip (humanoid_env.py:189-197, legged_robot.py:90-91):
- * st->actions <- clip(blend(clip(actions_in), st->actions) * (1 + noise)).  actions_in (N,12) row-major. */
-int32_t hgym_pre_physics(const HgymEnvConfig* cfg, const HgymEnvState* st, const float* actions_in,
+ * st->actions <- clip(blend(clip(actions_in), st->actions) * (1 + noise)).  actions_in (N,12) row-major; read-only
+ * unless cfg->use_ref_actions, in which case the reference pose is added to it in place first (as the reference does to
+ * the caller's tensor). */
+int32_t hgym_pre_physics(const HgymEnvConfig* cfg, const HgymEnvState* st, float* actions_in,
                          const HgymEnvNoise* noise, void* stream);
 
 /* LeggedRobot._compute_torques (legged_robot.py:340-356) on the current dof state -> st->torques. */
@@ -207,7 +211,7 @@ int32_t hgym_post_physics(const HgymEnvConfig* cfg, const HgymSimTensors* sim, c
 
 /* Fast path: pre_physics + synth_physics + post_physics in ONE launch, then the step finaliser. */
 int32_t hgym_env_step_synth(const HgymEnvConfig* cfg, const HgymSimTensors* sim, const HgymEnvState* st,
-                            const HgymEnvOut* out, const float* actions_in, void* stream);
+                            const HgymEnvOut* out, float* actions_in, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Rollout storage side (algo/ppo/rollout_storage.py, algo/ppo/ppo.py:103-117)

@@ -105,8 +105,9 @@ class XBotEnvOracle:
     """State record + the per-step functions.  All tensors are (N, k) fp32 unless noted."""
 
     def __init__(self, n, frictions=None, body_mass=None, frame_stack=C.FRAME_STACK,
-                 c_frame_stack=C.C_FRAME_STACK):
+                 c_frame_stack=C.C_FRAME_STACK, use_ref_actions=False):
         self.n = n
+        self.use_ref_actions = bool(use_ref_actions)      # cfg.env.use_ref_actions, humanoid_config.py:49 (False for XBot-L)
         self.H = frame_stack
         self.Hc = c_frame_stack
         self.sim = SimState(n)
@@ -197,7 +198,11 @@ class XBotEnvOracle:
 
     # ------------------------------------------------------------------ E1, E2 (clip), E3
     def pre_physics(self, actions_in, u_delay, z_act):
-        """humanoid_env.py:189-197 + legged_robot.py:90-91.  u_delay (N,), z_act (N,12)."""
+        """humanoid_env.py:189-197 + legged_robot.py:90-91.  u_delay (N,), z_act (N,12).
+        With use_ref_actions the reference adds ref_action = 2 * ref_dof_pos (the pose of the LAST compute_observations,
+        humanoid_env.py:142) to the caller's tensor IN PLACE before the clip (:190-191): `actions_in` is mutated here too."""
+        if self.use_ref_actions:
+            actions_in += 2 * self.ref_dof_pos
         a = torch.clip(actions_in, -C.CLIP_ACTIONS, C.CLIP_ACTIONS)
         delay = u_delay.view(-1, 1) * C.ACTION_DELAY
         a = (1 - delay) * a + delay * self.actions

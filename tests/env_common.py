@@ -121,10 +121,11 @@ def exact(a, b, what):
 class EnvUnderTest:
     """Product-side buffers + the call sequence of one vec-step in parity mode (external noise, external sim frames)."""
 
-    def __init__(self, backend, N, friction, body_mass, sim_layout="soa", frame_stack=15, c_frame_stack=3):
+    def __init__(self, backend, N, friction, body_mass, sim_layout="soa", frame_stack=15, c_frame_stack=3, use_ref_actions=False):
         from hgym import EnvBuffers, default_env_config
         self.be = backend
         self.cfg = default_env_config(N, frame_stack=frame_stack, c_frame_stack=c_frame_stack)
+        self.cfg.use_ref_actions = int(bool(use_ref_actions))
         self.buf = EnvBuffers(self.cfg, backend.device, sim_layout=sim_layout)
         self.buf.f["friction"].copy_(friction.view(1, N))
         self.buf.f["body_mass"].copy_(body_mass.view(1, N))
@@ -148,8 +149,9 @@ class EnvUnderTest:
         self.be.step_call("reset_all", self.cfg, self.sim, self.st, self.out, self._noise(u_dof=u_dof, u_cmd=u_cmd))
 
     def step(self, actions_in, frame, u_delay, z_act, u_cmd, u_dof, u_push, z_obs):
-        a = actions_in.to(self.dev).float().contiguous()
+        a = actions_in.to(self.dev).float().contiguous().clone()
         self.be.pre_physics(self.cfg, self.st, a, self._noise(u_delay=u_delay, z_act=z_act))
+        self.actions_after = a                  # the caller's tensor after the call (mutated only with use_ref_actions)
         self.be.pd_torques(self.cfg, self.sim, self.st)
         self.be.sync()
         self.buf.load_sim(*frame)
@@ -173,7 +175,9 @@ def compare_state(env, o, tag, check_obs=True):
                       ("push_force", o.push_force), ("push_torque", o.push_torque), ("episode_sums", o.episode_sums),
                       ("base_lin_vel", o.base_lin_vel), ("base_ang_vel", o.base_ang_vel),
                       ("projected_gravity", o.projected_gravity), ("base_euler", o.base_euler)]:
-        close(b.view(name), ref, tag + " " + name)
+        # torques = Kp*(0.25 a + q0 - q) - Kd*qd: terms of magnitude ~1e2 that can cancel to ~1e-1, so 1e-5 relative is taken
+        # on the scale of the terms (1 ulp of an action moves the result by ~1e-5 absolute), not of the difference
+        close(b.view(name), ref, tag + " " + name, atol=2e-5 if name == "torques" else ATOL)
     exact(b.view("last_contacts") > 0.5, o.last_contacts, tag + " last_contacts")
     close(b.rew, o.rew, tag + " rew")
     close(b.root_view(), o.sim.root, tag + " root_states (reset / push write-back)")
@@ -186,13 +190,16 @@ def compare_state(env, o, tag, check_obs=True):
         close(b.priv_obs, torch.clip(o.priv, -K.CLIP_OBS, K.CLIP_OBS), tag + " priv_obs")
 
 
-def run_random_trace(backend, N, steps, seed, sim_layout="soa", frame_stack=15, c_frame_stack=3, check_every=1):
+def run_random_trace(backend, N, steps, seed, sim_layout="soa", frame_stack=15, c_frame_stack=3, check_every=1,
+                     use_ref_actions=False):
     """Seeded random trace through product + oracle with identical inputs; returns event counts."""
     g = torch.Generator().manual_seed(seed)
     fr = 0.1 + 1.9 * torch.rand(N, 1, generator=g)
     bm = 10.0 + 10.0 * torch.rand(N, 1, generator=g)
-    o = XBotEnvOracle(N, frictions=fr, body_mass=bm, frame_stack=frame_stack, c_frame_stack=c_frame_stack)
-    env = EnvUnderTest(backend, N, fr, bm, sim_layout=sim_layout, frame_stack=frame_stack, c_frame_stack=c_frame_stack)
+    o = XBotEnvOracle(N, frictions=fr, body_mass=bm, frame_stack=frame_stack, c_frame_stack=c_frame_stack,
+                      use_ref_actions=use_ref_actions)
+    env = EnvUnderTest(backend, N, fr, bm, sim_layout=sim_layout, frame_stack=frame_stack, c_frame_stack=c_frame_stack,
+                       use_ref_actions=use_ref_actions)
     u_dof, u_cmd3, z_obs = torch.rand(N, 12, generator=g), torch.rand(N, 3, generator=g), torch.randn(N, 47, generator=g)
     o.prime(u_dof, u_cmd3, z_obs)
     env.prime(u_dof, u_cmd3, z_obs)
@@ -214,13 +221,15 @@ def run_random_trace(backend, N, steps, seed, sim_layout="soa", frame_stack=15, 
         u_delay, z_act = torch.rand(N, generator=g), torch.randn(N, 12, generator=g)
         u_cmd, u_dof = torch.rand(N, 6, generator=g), torch.rand(N, 12, generator=g)
         u_push, z_obs = torch.rand(N, 5, generator=g), torch.randn(N, 47, generator=g)
-        o.pre_physics(a_in, u_delay, z_act)
+        a_o = a_in.clone()
+        o.pre_physics(a_o, u_delay, z_act)      # mutates a_o when use_ref_actions
         o.pd_torques()
         o.sim.load(*frame)
         _, _, _, _, info = o.post_physics(u_cmd, u_dof, u_push, z_obs)
         env.step(a_in, frame, u_delay, z_act, u_cmd, u_dof, u_push, z_obs)
         if t % check_every == 0 or t == steps - 1:
             compare_state(env, o, "step %d" % t)
+            close(env.actions_after, a_o, "step %d caller's action tensor" % t)
         counts["reset"] += int(o.reset.sum())
         counts["timeout"] += int(o.time_out.sum())
         counts["push"] += int(info["pushed"])

@@ -122,12 +122,15 @@ def gen_policy_example():
 
 
 # ------------------------------------------------------------------------------------------------
-def gen_env_trace(R, N=32, S=36, seed=11):
+def gen_env_trace(R, N=32, S=36, seed=11, use_ref_actions=False, name="env_trace.npz"):
+    """use_ref_actions=True records the second trace (env_trace_refact.npz): cfg.env.use_ref_actions, humanoid_env.py:190-191
+    -- `actions += ref_action` IN PLACE on the caller's tensor, before the clip."""
     torch.manual_seed(seed)
     g = torch.Generator().manual_seed(seed)
     fr = 0.1 + 1.9 * torch.rand(N, 1, generator=g)
     bm = 15.0 + 10.0 * torch.rand(N, 1, generator=g) - 5.0
     e, cfg = H.make_ref_env(N, frictions=fr, body_mass=bm)
+    cfg.env.use_ref_actions = bool(use_ref_actions)
     ids_log = []
     orig_resample = e._resample_commands
     orig_reset_dofs = e._reset_dofs
@@ -188,7 +191,7 @@ def gen_env_trace(R, N=32, S=36, seed=11):
             H.write_sim_state(e, frames[counter["t"]])
 
     e.gym.simulate = simulate
-    keys = ["actions_in", "u_delay", "z_act", "u_cmd", "u_dof", "u_push", "z_obs", "root", "dof", "contact", "rigid",
+    keys = ["actions_in", "actions_in_after", "u_delay", "z_act", "u_cmd", "u_dof", "u_push", "z_obs", "root", "dof", "contact", "rigid",
             "frame", "priv_frame", "rew", "reset", "time_out", "commands", "ep_len", "episode_sums", "torques",
             "actions", "any_reset", "pushed", "extras_time_outs", "extras_episode", "root_after", "dof_after"]
     rec = {k: [] for k in keys}
@@ -198,8 +201,9 @@ def gen_env_trace(R, N=32, S=36, seed=11):
         a_in = torch.randn(N, 12, generator=g) * 1.5
         if t % 7 == 3:
             a_in[t % N] *= 40.0                              # exercise the +-18 clip
+        a_pass = a_in.clone()                                # the tensor the caller hands over (mutated when use_ref_actions)
         with H.recording_rng():
-            obs, priv, rew, reset, extras = e.step(a_in.clone())
+            obs, priv, rew, reset, extras = e.step(a_pass)
         log = H.RECORDER.pop_all()
         ids = ids_log[:]
         del ids_log[:]
@@ -226,7 +230,7 @@ def gen_env_trace(R, N=32, S=36, seed=11):
         z_obs = take(log, "randn_like")
         assert not log and not ids, (log, ids)
         root, dof, contact, rigid = frames[t]
-        vals = dict(actions_in=a_in, u_delay=u_delay, z_act=z_act, u_cmd=u_cmd, u_dof=u_dof, u_push=u_push, z_obs=z_obs,
+        vals = dict(actions_in=a_in, actions_in_after=a_pass, u_delay=u_delay, z_act=z_act, u_cmd=u_cmd, u_dof=u_dof, u_push=u_push, z_obs=z_obs,
                     root=root, dof=dof, contact=contact, rigid=rigid,
                     frame=e.obs_history[-1], priv_frame=e.critic_history[-1], rew=rew, reset=reset,
                     time_out=e.time_out_buf, commands=e.commands, ep_len=e.episode_length_buf,
@@ -251,12 +255,13 @@ def gen_env_trace(R, N=32, S=36, seed=11):
                final_push_torque=npy(e.rand_push_torque), final_base_lin_vel=npy(e.base_lin_vel),
                final_base_ang_vel=npy(e.base_ang_vel), final_projected_gravity=npy(e.projected_gravity),
                final_base_euler=npy(e.base_euler_xyz))
-    np.savez_compressed(os.path.join(HERE, "env_trace.npz"), **out)
+    out["use_ref_actions"] = np.array(bool(use_ref_actions))
+    np.savez_compressed(os.path.join(HERE, name), **out)
     n_reset = int(out["reset"].sum())
     n_to = int(out["time_out"].sum())
-    print("env_trace.npz N=%d S=%d resets=%d timeouts=%d pushed_steps=%s resample_rows=%d size=%.2f MB" % (
-        N, S, n_reset, n_to, np.nonzero(out["pushed"])[0].tolist(), int((out["u_cmd"][:, :, 0] != 0).sum()),
-        os.path.getsize(os.path.join(HERE, "env_trace.npz")) / 1e6))
+    print("%s N=%d S=%d resets=%d timeouts=%d pushed_steps=%s resample_rows=%d size=%.2f MB" % (
+        name, N, S, n_reset, n_to, np.nonzero(out["pushed"])[0].tolist(), int((out["u_cmd"][:, :, 0] != 0).sum()),
+        os.path.getsize(os.path.join(HERE, name)) / 1e6))
     H.RECORDER.enabled = False
 
 
@@ -351,4 +356,5 @@ if __name__ == "__main__":
         gen_gae(R)
         gen_policy_example()
         gen_env_trace(R)
+        gen_env_trace(R, N=16, S=16, seed=12, use_ref_actions=True, name="env_trace_refact.npz")
         gen_ppo_update(R)

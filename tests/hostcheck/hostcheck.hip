@@ -17,7 +17,7 @@ char* last_error_buf() {
 using namespace hgym;
 
 static EnvArgs make_args(const HgymEnvConfig* cfg, const HgymSimTensors* sim, const HgymEnvState* st, const HgymEnvOut* out,
-                         const HgymEnvNoise* noise, const float* actions_in, int mode, int fused, int epb) {
+                         const HgymEnvNoise* noise, float* actions_in, int mode, int fused, int epb) {
     EnvArgs A;
     memset(&A, 0, sizeof(A));
     A.cfg = *cfg;
@@ -36,7 +36,7 @@ static EnvArgs make_args(const HgymEnvConfig* cfg, const HgymSimTensors* sim, co
 extern "C" {
 
 int hc_env_step(const HgymEnvConfig* cfg, const HgymSimTensors* sim, const HgymEnvState* st, const HgymEnvOut* out,
-                const HgymEnvNoise* noise, const float* actions_in, int mode, int fused, int epb, int nthreads) {
+                const HgymEnvNoise* noise, float* actions_in, int mode, int fused, int epb, int nthreads) {
     const EnvArgs A = make_args(cfg, sim, st, out, noise, actions_in, mode, fused, epb);
     const int N = cfg->num_envs;
     const int blocks = (N + epb - 1) / epb;
@@ -62,7 +62,7 @@ int hc_env_step(const HgymEnvConfig* cfg, const HgymSimTensors* sim, const HgymE
     return 0;
 }
 
-int hc_pre_physics(const HgymEnvConfig* cfg, const HgymEnvState* st, const float* actions_in, const HgymEnvNoise* noise) {
+int hc_pre_physics(const HgymEnvConfig* cfg, const HgymEnvState* st, float* actions_in, const HgymEnvNoise* noise) {
     const EnvArgs A = make_args(cfg, nullptr, st, nullptr, noise, actions_in, MODE_STEP, 0, 4);
     const RngKey rk = make_rng_key(A, st->counters[0]);
     for (int e = 0; e < cfg->num_envs; ++e) pre_physics_env(A, rk, e, cfg->num_envs);

@@ -18,10 +18,12 @@ def hip():
     return EC.HipBackend()
 
 
-def test_golden_trace_gpu(hip, golden_dir):
-    G = np.load(os.path.join(golden_dir, "env_trace.npz"))
+@pytest.mark.parametrize("name", ["env_trace.npz", "env_trace_refact.npz"])
+def test_golden_trace_gpu(hip, golden_dir, name):
+    """The traces recorded from the reference's own XBotLFreeEnv.step: XBot-L defaults, and cfg.env.use_ref_actions = True."""
+    G = np.load(os.path.join(golden_dir, name))
     N = G["friction"].shape[0]
-    env = EC.EnvUnderTest(hip, N, T(G["friction"]), T(G["body_mass"]), sim_layout="aos")
+    env = EC.EnvUnderTest(hip, N, T(G["friction"]), T(G["body_mass"]), sim_layout="aos", use_ref_actions=bool(G["use_ref_actions"]))
     env.prime(T(G["prime_u_dof"]), T(G["prime_u_cmd"]), T(G["prime_z_obs"]))
     hip.sync()
     EC.close(env.buf.obs, G["prime_obs"], "prime obs")
@@ -34,6 +36,7 @@ def test_golden_trace_gpu(hip, golden_dir):
         env.step(T(G["actions_in"][t]), frame, T(G["u_delay"][t]), T(G["z_act"][t]), T(G["u_cmd"][t]), T(G["u_dof"][t]),
                  T(G["u_push"][t]), T(G["z_obs"][t]))
         b = env.buf
+        EC.close(env.actions_after, G["actions_in_after"][t], "caller's action tensor %d" % t)
         EC.exact(b.reset, G["reset"][t], "reset %d" % t)                       # bit-exact masks
         EC.exact(b.time_out, G["time_out"][t], "time_out %d" % t)
         EC.exact(b.episode_length, G["ep_len"][t], "ep_len %d" % t)
@@ -60,6 +63,12 @@ def test_random_trace_gpu(hip, N, layout, steps):
 
 def test_generic_frame_stack_gpu(hip):
     EC.run_random_trace(hip, 100, steps=10, seed=7, frame_stack=4, c_frame_stack=2)
+
+
+def test_use_ref_actions_random_trace_gpu(hip):
+    """SURVEY.md 8f item 3, cfg.env.use_ref_actions: component-wise entry points against the oracle, incl. the in-place
+    mutation of the caller's action tensor."""
+    EC.run_random_trace(hip, 300, steps=12, seed=21, use_ref_actions=True)
 
 
 @pytest.mark.parametrize("N", [4096, 8192, 5000, 16384])

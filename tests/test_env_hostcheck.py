@@ -17,11 +17,12 @@ def host():
     return EC.HostBackend(envs_per_block=8, nthreads=64)
 
 
-def test_golden_trace_host(host, golden_dir):
-    """The reference's own recorded trace (tests/golden/env_trace.npz) through the kernel source."""
-    G = np.load(os.path.join(golden_dir, "env_trace.npz"))
+@pytest.mark.parametrize("name", ["env_trace.npz", "env_trace_refact.npz"])
+def test_golden_trace_host(host, golden_dir, name):
+    """The reference's own recorded traces (XBot-L defaults; cfg.env.use_ref_actions = True) through the kernel source."""
+    G = np.load(os.path.join(golden_dir, name))
     N = G["friction"].shape[0]
-    env = EC.EnvUnderTest(host, N, T(G["friction"]), T(G["body_mass"]), sim_layout="aos")
+    env = EC.EnvUnderTest(host, N, T(G["friction"]), T(G["body_mass"]), sim_layout="aos", use_ref_actions=bool(G["use_ref_actions"]))
     env.prime(T(G["prime_u_dof"]), T(G["prime_u_cmd"]), T(G["prime_z_obs"]))
     EC.close(env.buf.obs, G["prime_obs"], "prime obs")
     EC.close(env.buf.priv_obs, G["prime_priv"], "prime priv")
@@ -33,6 +34,7 @@ def test_golden_trace_host(host, golden_dir):
         env.step(T(G["actions_in"][t]), frame, T(G["u_delay"][t]), T(G["z_act"][t]), T(G["u_cmd"][t]), T(G["u_dof"][t]),
                  T(G["u_push"][t]), T(G["z_obs"][t]))
         b = env.buf
+        EC.close(env.actions_after, G["actions_in_after"][t], "caller's action tensor %d" % t)
         EC.exact(b.reset, G["reset"][t], "reset %d" % t)
         EC.exact(b.time_out, G["time_out"][t], "time_out %d" % t)
         EC.exact(b.episode_length, G["ep_len"][t], "ep_len %d" % t)

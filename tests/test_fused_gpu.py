@@ -185,8 +185,10 @@ def test_graph_replay_equals_eager_rollout(monkeypatch):
         assert torch.equal(a, b)
 
 
-def test_single_launch_env_step_equals_componentwise_calls():
-    """hgym_env_step_synth (one launch: draws, joints, per-env phase, history) against the same step issued as
+@pytest.mark.parametrize("use_ref_actions", [0, 1])
+def test_single_launch_env_step_equals_componentwise_calls(use_ref_actions):
+    """(use_ref_actions = 1: also the in-place `actions += ref_action` on the caller's tensor)
+    hgym_env_step_synth (one launch: draws, joints, per-env phase, history) against the same step issued as
     hgym_pre_physics -> hgym_synth_physics -> hgym_post_physics (three independent kernels, internal Philox): every
     output and every piece of state bit-identical over 25 steps including resets, pushes and command resampling."""
     from hgym import EnvBuffers, default_env_config, _lib as L
@@ -194,6 +196,7 @@ def test_single_launch_env_step_equals_componentwise_calls():
     bufs = []
     for k in range(2):
         cfg = default_env_config(N, seed=99)
+        cfg.use_ref_actions = use_ref_actions
         b = EnvBuffers(cfg, "cuda")
         s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         L.check(L.lib.hgym_env_prime(C.byref(cfg), C.byref(b.sim_struct()), C.byref(b.state_struct()), C.byref(b.out_struct()),
@@ -204,18 +207,20 @@ def test_single_launch_env_step_equals_componentwise_calls():
     g = torch.Generator().manual_seed(3)
     for t in range(25):
         a = (torch.randn(N, 12, generator=g) * 3).cuda()
+        a2 = a.clone()
         cfg, b = bufs[0]
         s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         L.check(L.lib.hgym_env_step_synth(C.byref(cfg), C.byref(b.sim_struct()), C.byref(b.state_struct()), C.byref(b.out_struct()),
                                           L.fptr(a), s))
         cfg, b = bufs[1]
         nz = b.noise_struct()
-        L.check(L.lib.hgym_pre_physics(C.byref(cfg), C.byref(b.state_struct()), L.fptr(a), C.byref(nz), s))
+        L.check(L.lib.hgym_pre_physics(C.byref(cfg), C.byref(b.state_struct()), L.fptr(a2), C.byref(nz), s))
         L.check(L.lib.hgym_synth_physics(C.byref(cfg), C.byref(b.sim_struct()), C.byref(b.state_struct()), s))
         L.check(L.lib.hgym_post_physics(C.byref(cfg), C.byref(b.sim_struct()), C.byref(b.state_struct()), C.byref(b.out_struct()),
                                         C.byref(nz), s))
         torch.cuda.synchronize()
         x, y = bufs[0][1], bufs[1][1]
+        assert torch.equal(a, a2), t                       # the caller's tensor: untouched, or the same in-place update
         for name in ("obs", "priv_obs", "rew", "reset", "time_out", "episode_length", "root", "dof_pos", "dof_vel", "contact", "rigid",
                      "_state", "obs_ring", "priv_ring", "extras_time_outs", "counters"):
             assert torch.equal(getattr(x, name), getattr(y, name)), (t, name)

@@ -1,8 +1,10 @@
-"""Pins oracle/xbot_env_oracle.py against tests/golden/env_trace.npz, which was recorded by running the
-reference's own XBotLFreeEnv.step (tests/golden/gen_fixtures.py).  CPU only."""
+"""Pins oracle/xbot_env_oracle.py against tests/golden/env_trace.npz (XBot-L defaults) and env_trace_refact.npz
+(cfg.env.use_ref_actions = True), both recorded by running the reference's own XBotLFreeEnv.step
+(tests/golden/gen_fixtures.py).  CPU only."""
 import os
 
 import numpy as np
+import pytest
 import torch
 
 from oracle import xbot_constants as C
@@ -11,19 +13,23 @@ from oracle.xbot_env_oracle import XBotEnvOracle
 T = lambda a: torch.from_numpy(np.asarray(a))
 
 
-def _load(golden_dir):
-    return np.load(os.path.join(golden_dir, "env_trace.npz"))
+TRACES = ["env_trace.npz", "env_trace_refact.npz"]
+
+
+def _load(golden_dir, name="env_trace.npz"):
+    return np.load(os.path.join(golden_dir, name))
 
 
 def _prime(G):
     N = G["friction"].shape[0]
-    o = XBotEnvOracle(N, frictions=T(G["friction"]), body_mass=T(G["body_mass"]))
+    o = XBotEnvOracle(N, frictions=T(G["friction"]), body_mass=T(G["body_mass"]), use_ref_actions=bool(G["use_ref_actions"]))
     o.prime(T(G["prime_u_dof"]), T(G["prime_u_cmd"]), T(G["prime_z_obs"]))
     return o
 
 
-def test_prime_matches_reference(golden_dir):
-    G = _load(golden_dir)
+@pytest.mark.parametrize("name", TRACES)
+def test_prime_matches_reference(golden_dir, name):
+    G = _load(golden_dir, name)
     o = _prime(G)
     assert torch.equal(o.obs, T(G["prime_obs"]))
     assert torch.equal(o.priv, T(G["prime_priv"]))
@@ -31,8 +37,9 @@ def test_prime_matches_reference(golden_dir):
     assert torch.equal(o.sim.dof_pos, T(G["prime_dof_pos"]))
 
 
-def test_trace_matches_reference(golden_dir):
-    G = _load(golden_dir)
+@pytest.mark.parametrize("name", TRACES)
+def test_trace_matches_reference(golden_dir, name):
+    G = _load(golden_dir, name)
     o = _prime(G)
     o.ep_len = T(G["init_ep_len"]).clone()
     o.common_step_counter = int(G["init_common_step_counter"])
@@ -40,7 +47,9 @@ def test_trace_matches_reference(golden_dir):
     full = {int(s) for s in G["full_steps"]}
     saw = dict(reset=0, timeout=0, push=0, resample=0, stale=0)
     for t in range(S):
-        a = o.pre_physics(T(G["actions_in"][t]), T(G["u_delay"][t]), T(G["z_act"][t]))
+        a_in = T(G["actions_in"][t]).clone()
+        a = o.pre_physics(a_in, T(G["u_delay"][t]), T(G["z_act"][t]))
+        assert torch.equal(a_in, T(G["actions_in_after"][t])), t        # the caller's tensor: untouched, or += ref_action in place
         tq = o.pd_torques()
         o.sim.load(T(G["root"][t]), T(G["dof"][t]), T(G["contact"][t]), T(G["rigid"][t]))
         obs, priv, rew, reset, info = o.post_physics(T(G["u_cmd"][t]), T(G["u_dof"][t]), T(G["u_push"][t]), T(G["z_obs"][t]))
@@ -69,6 +78,8 @@ def test_trace_matches_reference(golden_dir):
         saw["stale"] += int((not info["any_reset"]) and bool(o.extras_time_outs.any()))
     # the trace must have exercised every event class
     assert saw["reset"] > 10 and saw["timeout"] >= 3 and saw["push"] == 1
+    if bool(G["use_ref_actions"]):
+        assert float(np.abs(G["actions_in_after"] - G["actions_in"]).max()) > 0.5       # the feature really was on
     for k in ("feet_air_time", "last_contacts", "feet_height", "last_feet_z", "last_actions", "last_last_actions",
               "last_dof_vel", "last_root_vel", "ref_dof_pos", "base_lin_vel", "base_ang_vel", "projected_gravity"):
         assert torch.equal(getattr(o, k), T(G["final_" + k])), k
