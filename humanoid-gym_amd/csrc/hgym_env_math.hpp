@@ -939,8 +939,11 @@ HG_HD void env_stage_in(const EnvArgs& A, int block, int t, int nthreads, float*
         const int rbase = body == 0 ? rc0 : (body == 1 ? rc1 : (body == 2 ? rc2 : rc3));
         r_rg = *reinterpret_cast<const EnvF4*>(A.sim.rigid.base + (int64_t)(rbase + rcomp) * A.sim.rigid.comp_stride + e0 + 4 * (i14 % Q));
         const int ia = cl(t, 3 * EE), ie = cl(t, EE / 2);
-        if (A.actions_in) r_act = *reinterpret_cast<const EnvF4*>(A.actions_in + (int64_t)e0 * 12 + 4 * ia);
         r_ep = *reinterpret_cast<const EnvF4*>(reinterpret_cast<const float*>(A.st.episode_length + e0) + 4 * ie);
+        // unconditional load (from the episode-length row when there are no actions): a conditionally initialised vector ends
+        // up in scratch memory, and a kernel with a private segment is dispatched differently from its neighbours
+        r_act = *reinterpret_cast<const EnvF4*>(A.actions_in ? A.actions_in + (int64_t)e0 * 12 + 4 * ia
+                                                              : reinterpret_cast<const float*>(A.st.episode_length + e0) + 4 * ie);
 #pragma unroll
         for (int u = 0; u < NS; ++u) {
             const int i = t + u * 256;
