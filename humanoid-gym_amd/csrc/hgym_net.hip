@@ -276,15 +276,42 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(const LossArgs a) {
         const float v = a.val[i];
         float lp = 0.0f, ent = 0.0f, kl = 0.0f;
         float diff[16], sg[16];
+        // the gathered rows (actions, old mu, old sigma: A floats each, at a random row r) and this sample's mu row.  For the
+        // XBot-L width (A = 12: 48-byte rows, 16-byte aligned) they are fetched as three 16-byte loads each: a 4-byte load
+        // per element costs the texture path one cache line per lane PER ELEMENT (the rows are scattered), a vector load one
+        // per lane per 4 elements -- the kernel was bound by exactly that (31 us for 61 440 samples).
+        float rowm[16], rowa[16], rowmo[16], rowso[16];
+        if (A == 12) {
+#pragma unroll
+            for (int v = 0; v < 3; ++v) {
+                const float4 qm = reinterpret_cast<const float4*>(a.mu + (int64_t)i * 12)[v];
+                const float4 qa = reinterpret_cast<const float4*>(a.b.actions + r * 12)[v];
+                const float4 qo = reinterpret_cast<const float4*>(a.b.mu + r * 12)[v];
+                const float4 qs = reinterpret_cast<const float4*>(a.b.sigma + r * 12)[v];
+                rowm[4 * v] = qm.x; rowm[4 * v + 1] = qm.y; rowm[4 * v + 2] = qm.z; rowm[4 * v + 3] = qm.w;
+                rowa[4 * v] = qa.x; rowa[4 * v + 1] = qa.y; rowa[4 * v + 2] = qa.z; rowa[4 * v + 3] = qa.w;
+                rowmo[4 * v] = qo.x; rowmo[4 * v + 1] = qo.y; rowmo[4 * v + 2] = qo.z; rowmo[4 * v + 3] = qo.w;
+                rowso[4 * v] = qs.x; rowso[4 * v + 1] = qs.y; rowso[4 * v + 2] = qs.z; rowso[4 * v + 3] = qs.w;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                if (j >= A) continue;
+                rowm[j] = a.mu[(int64_t)i * A + j];
+                rowa[j] = a.b.actions[r * A + j];
+                rowmo[j] = a.b.mu[r * A + j];
+                rowso[j] = a.b.sigma[r * A + j];
+            }
+        }
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             diff[j] = 0.0f;
             sg[j] = 1.0f;
             if (j >= A) continue;
-            const float m = a.mu[(int64_t)i * A + j];
+            const float m = rowm[j];
             const float s = m * 0.0f + a.std_[j];
-            const float act = a.b.actions[r * A + j];
-            const float mo = a.b.mu[r * A + j], so = a.b.sigma[r * A + j];
+            const float act = rowa[j];
+            const float mo = rowmo[j], so = rowso[j];
             const float d = act - m;
             diff[j] = d;
             sg[j] = s;
@@ -393,6 +420,7 @@ __global__ __launch_bounds__(512) void ppo_scalars_kernel(int nblocks, int B, in
             opt[2] += t / B;
             opt[8] = t / B;
             opt[7] += 1.0;
+            opt[9] = 0.0;                     // squared gradient norm: accumulated by reduce_slabs_kernel later in this call
             kl_slot[0] = (float)(t / B);      // grads[P]: travels with the gradient in the ranks' one all-reduce
         }
         if (q >= 4 && q < 16 && q - 4 < A) grads_std[q - 4] = (float)t;
@@ -419,13 +447,22 @@ struct SegTable {
     Segment s[2 * HGYM_MAX_LAYERS * 2 + 1];
 };
 
+// Also accumulates the squared norm of the finished gradient into opt[9] (zeroed by ppo_scalars_kernel earlier in the same
+// hgym_ppo_grad): with one rank that IS the norm clip_grad_norm_ needs, and hgym_ppo_apply skips its own pass over the
+// gradient.  (Segments whose gradient is already final -- splits == 0 -- are only read.)
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(const SegTable tab, int64_t P, const float* __restrict__ slabs,
-                                                           float* __restrict__ grads) {
+                                                           float* __restrict__ grads, double* __restrict__ opt) {
+    __shared__ double red[4];
     const Segment& sg = tab.s[blockIdx.y];
-    if (sg.splits == 0) return;
     const int64_t n = (int64_t)sg.rows * sg.cols;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    if (((sg.off | n) & 3) == 0 && (P & 3) == 0 && (((uintptr_t)grads) & 15) == 0) {   // 16-byte path (P = slab stride)
+    double sq = 0.0;
+    if (sg.splits == 0) {
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+            const float g = grads[sg.off + i];
+            sq += (double)g * (double)g;
+        }
+    } else if (((sg.off | n) & 3) == 0 && (P & 3) == 0 && (((uintptr_t)grads) & 15) == 0) {   // 16-byte path (P = slab stride)
         const int64_t n4 = n >> 2;
         for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -434,13 +471,23 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const SegTable tab, i
                 acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
             }
             *reinterpret_cast<float4*>(grads + sg.off + 4 * i) = acc;
+            sq += (double)acc.x * (double)acc.x + (double)acc.y * (double)acc.y + (double)acc.z * (double)acc.z + (double)acc.w * (double)acc.w;
         }
     } else {
         for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
             float s = 0.0f;
             for (int z = 0; z < sg.splits; ++z) s += slabs[(int64_t)z * P + sg.off + i];
             grads[sg.off + i] = s;
+            sq += (double)s * (double)s;
         }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sq += __shfl_down(sq, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sq;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double t = red[0] + red[1] + red[2] + red[3];
+        if (t != 0.0) atomicAdd(&opt[9], t);
     }
 }
 
@@ -472,7 +519,7 @@ __global__ void apply_prologue_kernel(const HgymPPOConfig p, const float* __rest
         opt[0] = lr;
     }
     opt[1] += 1.0;
-    opt[9] = 0.0;
+    if (p.world_size > 1 || !p.grad_norm_ready) opt[9] = 0.0;   // sqnorm_kernel follows (rank MEAN after an all-reduce / foreign gradients)
 }
 
 // writes one master weight into every compute-precision operand copy of its layer
@@ -817,7 +864,7 @@ struct NetRunner {
         }
         const SegTable tab = segments(true);
         prof_begin(HGYM_PROF_REDUCE, s);
-        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(96, tab.n), dim3(256), 0, s, tab, w.Ps, at<float>(w.slabs), net.grads);
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(96, tab.n), dim3(256), 0, s, tab, w.Ps, at<float>(w.slabs), net.grads, net.opt_state);
         prof_end(HGYM_PROF_REDUCE, s, (double)w.P * 4.0 * (w.dw_splits + 1));
         HG_CHECK_LAUNCH("reduce_slabs_kernel");
         return HGYM_OK;
@@ -998,7 +1045,7 @@ struct NetRunner {
         rc = backward(1, B);
         if (rc) return rc;
         const SegTable tab = segments(true);
-        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(96, tab.n), dim3(256), 0, s, tab, w.Ps, at<float>(w.slabs), net.grads);
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(96, tab.n), dim3(256), 0, s, tab, w.Ps, at<float>(w.slabs), net.grads, net.opt_state);
         HG_CHECK_LAUNCH("reduce_slabs_kernel");
         return HGYM_OK;
     }
@@ -1007,7 +1054,8 @@ struct NetRunner {
         prof_begin(HGYM_PROF_APPLY, s);
         const float inv_w = ppo.world_size > 1 ? (float)(1.0 / (double)ppo.world_size) : 1.0f;
         hipLaunchKernelGGL(apply_prologue_kernel, dim3(1), dim3(64), 0, s, ppo, net.grads + w.P, inv_w, net.opt_state);
-        hipLaunchKernelGGL(sqnorm_kernel, dim3(256), dim3(256), 0, s, w.P, net.grads, inv_w, net.opt_state);
+        if (ppo.world_size > 1 || !ppo.grad_norm_ready)        // else: reduce_slabs_kernel left the squared norm in opt[9]
+            hipLaunchKernelGGL(sqnorm_kernel, dim3(256), dim3(256), 0, s, w.P, net.grads, inv_w, net.opt_state);
         const SegTable tab = segments(false);
         hipLaunchKernelGGL((adam_kernel<T>), dim3(64, tab.n), dim3(256), 0, s, tab, ppo, net.params, net.grads, net.adam_m, net.adam_v,
                            inv_w, net.opt_state);

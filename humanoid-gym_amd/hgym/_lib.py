@@ -96,7 +96,8 @@ class PPOConfig(C.Structure):
     _fields_ = [("clip_param", C.c_float), ("value_loss_coef", C.c_float), ("entropy_coef", C.c_float),
                 ("max_grad_norm", C.c_float), ("desired_kl", C.c_float),
                 ("beta1", C.c_float), ("beta2", C.c_float), ("adam_eps", C.c_float),
-                ("lr_min", C.c_double), ("lr_max", C.c_double), ("adaptive_lr", C.c_int32), ("world_size", C.c_int32)]
+                ("lr_min", C.c_double), ("lr_max", C.c_double), ("adaptive_lr", C.c_int32), ("world_size", C.c_int32),
+                ("grad_norm_ready", C.c_int32)]
 
 
 class Net(C.Structure):

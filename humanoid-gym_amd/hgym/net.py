@@ -22,7 +22,7 @@ def make_net_config(num_obs, num_priv, num_actions, actor_hidden, critic_hidden,
 
 
 def make_ppo_config(clip_param=0.2, value_loss_coef=1.0, entropy_coef=0.001, max_grad_norm=1.0, desired_kl=0.01,
-                    adaptive=True, world_size=1):
+                    adaptive=True, world_size=1, grad_norm_ready=False):
     p = L.PPOConfig()
     p.clip_param, p.value_loss_coef, p.entropy_coef = clip_param, value_loss_coef, entropy_coef
     p.max_grad_norm, p.desired_kl = max_grad_norm, desired_kl
@@ -30,6 +30,7 @@ def make_ppo_config(clip_param=0.2, value_loss_coef=1.0, entropy_coef=0.001, max
     p.lr_min, p.lr_max = 1e-5, 1e-2
     p.adaptive_lr = 1 if adaptive else 0
     p.world_size = int(world_size)
+    p.grad_norm_ready = 1 if (grad_norm_ready and int(world_size) == 1) else 0    # see HgymPPOConfig
     return p
 
 

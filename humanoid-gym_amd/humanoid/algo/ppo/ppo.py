@@ -115,7 +115,8 @@ class PPO:
         self._ppo_cfg = hgym.make_ppo_config(self.clip_param, self.value_loss_coef, self.entropy_coef, self.max_grad_norm,
                                              self.desired_kl if self.desired_kl is not None else 0.0,
                                              adaptive=(self.desired_kl is not None and self.schedule == "adaptive"),
-                                             world_size=self._world)
+                                             world_size=self._world,
+                                             grad_norm_ready=True)   # update() applies exactly what hgym_ppo_grad produced
         self._sample_step = torch.zeros(1, dtype=torch.int64, device=self.device)
         ac._sample_step = self._sample_step
         ac._sample_seed = 0x5EED + 7919 * self._rank

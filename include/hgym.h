@@ -253,6 +253,9 @@ typedef struct HgymPPOConfig {
     int32_t adaptive_lr;            /* schedule == 'adaptive' */
     int32_t world_size;             /* >1: between hgym_ppo_grad and hgym_ppo_apply the caller all-reduces (SUM) the P+1 floats of
                                        net->grads across ranks; apply forms the means (gradient and KL) itself */
+    int32_t grad_norm_ready;        /* 1: net->grads is exactly what the preceding hgym_ppo_grad left (one rank, nothing touched it),
+                                       so its squared norm is already in opt_state[9] and apply skips its own pass over the
+                                       gradient; 0 (or world_size > 1): apply computes the norm itself */
 } HgymPPOConfig;
 
 /* Sizes (bytes) of the caller-allocated blocks, as functions of the configuration. */

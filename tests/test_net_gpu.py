@@ -274,3 +274,35 @@ def test_apply_with_world_size_forms_the_rank_mean_itself(precision):
     assert float(a.opt_state[0]) == float(b.opt_state[0]) == pytest.approx(1.5e-3)
     assert float(a.opt_state[6]) == float(b.opt_state[6])       # same pre-clip gradient norm
     assert torch.equal(a.workspace, b.workspace)                # bf16 operand shadows follow
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+def test_apply_can_reuse_the_norm_left_by_grad(precision):
+    """HgymPPOConfig.grad_norm_ready: hgym_ppo_grad leaves the squared norm of its gradient in opt_state[9] (accumulated while the
+    split-K slabs are summed); with the flag, hgym_ppo_apply skips its own pass over the gradient.  Both ways must agree: the
+    norms to double rounding (different summation order), the updated parameters to 1e-7 relative."""
+    from hgym import NetBuffers, make_net_config, make_ppo_config, make_batch
+    S = B = 1000
+    nets = []
+    for ready in (False, True):
+        torch.manual_seed(11)
+        cfg = make_net_config(705, 219, 12, [512, 256, 128], [768, 256, 128], precision, B)
+        net = NetBuffers(cfg, "cuda", learning_rate=1e-3)
+        for k, v in net.views.items():
+            v.copy_(torch.randn(v.shape, device="cuda") * (0.05 if v.dim() > 1 else 0.01))
+        net.views["std"].fill_(1.0)
+        net.sync_shadow()
+        g = torch.Generator(device="cuda").manual_seed(5)
+        r = lambda *s: torch.randn(*s, device="cuda", generator=g)
+        cols = (r(S, 705), r(S, 219), r(S, 12), r(S), r(S) * 30.0, r(S), r(S) - 12.0, r(S, 12) * 0.3, torch.ones(S, 12, device="cuda"))
+        idx = torch.randperm(S, device="cuda", generator=g).contiguous()
+        ppo = make_ppo_config(grad_norm_ready=ready)
+        assert ppo.grad_norm_ready == int(ready)
+        net.ppo_grad(ppo, make_batch(*cols, idx))
+        net.ppo_apply(ppo)
+        torch.cuda.synchronize()
+        nets.append(net)
+    a, b = nets
+    assert float(a.opt_state[6]) > 1.0                         # the clip really acted (advantages x30)
+    np.testing.assert_allclose(float(b.opt_state[6]), float(a.opt_state[6]), rtol=1e-6)
+    np.testing.assert_allclose(b.params.cpu().numpy(), a.params.cpu().numpy(), rtol=1e-7, atol=1e-9)

@@ -37,7 +37,7 @@ lp_o = -12.0 + torch.randn(S, device=dev)
 idx = torch.randperm(S, device=dev).contiguous()
 if os.environ.get('HGYM_IDX0'):
     idx = torch.randint(0, 64, (S,), device=dev)   # every gather hits L2: isolates the input-latency share of mlp_fwd
-ppo = make_ppo_config()
+ppo = make_ppo_config(grad_norm_ready=True)      # what PPO.update passes on one rank
 batch = make_batch(obs, priv, act, val, adv, ret, lp_o, mu_o, sg_o, idx)
 names = {0: "gemm(all)", 3: "loss", 4: "mlp_fwd", 5: "mlp_bwd", 6: "dw", 7: "reduce", 8: "apply", 9: "policy"}
 def step():
