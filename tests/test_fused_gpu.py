@@ -227,3 +227,23 @@ def test_single_launch_env_step_equals_componentwise_calls(use_ref_actions):
         # means over the resetting envs are accumulated with fp32 atomics (order-dependent in the last bit)
         np.testing.assert_allclose(x.extras_episode.cpu().numpy(), y.extras_episode.cpu().numpy(), rtol=1e-5, atol=1e-9)
     assert int(bufs[0][1].reset.sum()) >= 0
+
+
+def test_adam_writes_the_same_operand_copies_as_the_refresh_from_master():
+    """adam_kernel keeps the fragment-major bf16 operand copies (W and W^T images) of every weight matrix current;
+    hgym_net_sync_shadow re-derives them from the fp32 master parameters.  After clipped Adam steps on random gradients
+    the two must be byte-identical (every edge: 705, 219, 12 and 1 are not multiples of the 16/32-wide fragments)."""
+    from hgym import make_ppo_config
+    net = _net("bf16", 512)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    for k, v in net.views.items():
+        v.copy_(torch.randn(v.shape, device="cuda", generator=g) * 0.05)
+    net.sync_shadow()
+    net.grads.copy_(torch.randn(net.P, device="cuda", generator=g))
+    for _ in range(2):
+        net.ppo_apply(make_ppo_config())
+    torch.cuda.synchronize()
+    after_adam = net.workspace.clone()
+    net.sync_shadow()
+    torch.cuda.synchronize()
+    assert torch.equal(after_adam, net.workspace)
