@@ -68,6 +68,9 @@ __global__ __launch_bounds__(256) void env_step_kernel(const EnvArgs A) {
     }
     if (!(A.ablate & 4)) env_stage_out<E_T>(A, blockIdx.x, t, blockDim.x, smem);
     if (!(A.ablate & 8)) env_step_phase_b<H_T, HC_T, E_T>(A, blockIdx.x, t, blockDim.x, smem, csc0, ring_step, false);
+    // postponed finaliser (HgymEnvOut.defer_finalize): the sampling step the NEXT policy launch reads is bumped here -- no policy
+    // kernel is running now, and the finaliser will be one of that launch's workgroups
+    if (A.out.defer_finalize && blockIdx.x == 0 && t == 0 && A.out.t_rewards && A.out.t_step) A.out.t_step[0] += 1;
 }
 
 __global__ __launch_bounds__(1024) void env_finalize_kernel(const EnvArgs A) {
@@ -179,8 +182,10 @@ static int32_t launch_step(const HgymEnvConfig* cfg, const HgymSimTensors* sim, 
         prof_end(HGYM_PROF_ENV_STEP, s, (double)cfg->num_envs * (4.0 * (245 + (H - 1) * 47 + (HC - 1) * 73 + H * 47 + HC * 73) + 6));
     }
     HG_CHECK_LAUNCH("env_step_kernel");
-    hipLaunchKernelGGL(env_finalize_kernel, dim3(1), dim3(cfg->num_envs > 256 ? 1024 : 256), 0, s, A);
-    HG_CHECK_LAUNCH("env_finalize_kernel");
+    if (!out->defer_finalize) {
+        hipLaunchKernelGGL(env_finalize_kernel, dim3(1), dim3(cfg->num_envs > 256 ? 1024 : 256), 0, s, A);
+        HG_CHECK_LAUNCH("env_finalize_kernel");
+    }
     return HGYM_OK;
 }
 
@@ -280,6 +285,21 @@ int32_t hgym_env_step_synth(const HgymEnvConfig* cfg, const HgymSimTensors* sim,
                             float* actions_in, void* stream) {
     HG_REQUIRE(actions_in, HGYM_E_BADARG, "null actions");
     return launch_step(cfg, sim, st, out, nullptr, actions_in, MODE_STEP, 1, (hipStream_t)stream);
+}
+
+int32_t hgym_env_finalize(const HgymEnvConfig* cfg, const HgymEnvState* st, const HgymEnvOut* out, void* stream) {
+    HG_REQUIRE(cfg && st && out, HGYM_E_BADARG, "null cfg/state/out");
+    HG_REQUIRE(st->counters && st->episode_acc && out->time_out && out->extras_time_outs && out->extras_episode, HGYM_E_BADARG,
+               "null finaliser buffer");
+    EnvArgs A;
+    memset(&A, 0, sizeof(A));
+    A.cfg = *cfg;
+    A.st = *st;
+    A.out = *out;
+    A.mode = MODE_STEP;
+    hipLaunchKernelGGL(env_finalize_kernel, dim3(1), dim3(cfg->num_envs > 256 ? 1024 : 256), 0, (hipStream_t)stream, A);
+    HG_CHECK_LAUNCH("env_finalize_kernel");
+    return HGYM_OK;
 }
 
 static int32_t launch_simple(void (*kern)(const EnvArgs), const char* name, const HgymEnvConfig* cfg, const HgymSimTensors* sim,

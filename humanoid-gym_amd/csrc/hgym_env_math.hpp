@@ -9,6 +9,7 @@
 // Layout: state fields are [C][N] fp32 (env-major SoA): component c of env e is p[c*N + e].
 #pragma once
 #include "hgym_common.hpp"
+#include "hgym_finalize.hpp"
 
 namespace hgym {
 
@@ -1320,37 +1321,11 @@ HG_HD void env_step_phase_b(const EnvArgs& A, int block, int t, int nthreads, fl
     stack_reset_fix(A.st.priv_ring, s_reset, dpriv, e0, nE, HC, HGYM_PRIV_FRAME, (int)(ring_step % HC), t, nthreads, !old_rows_final);
 }
 
-// Step finaliser: the cross-env pieces of reset_idx (legged_robot.py:199-210) -- means of the episode sums
-// over the envs that reset, extras["time_outs"] refreshed only when >= 1 env reset (the reference's
-// stale-extras behaviour) -- then (after a barrier) the device-resident counters.
-HG_HD void env_finalize_part1(const EnvArgs& A, int t, int nthreads) {
-    const int N = A.cfg.num_envs;
-    const int64_t cnt = A.st.counters[1];
-    if (cnt > 0) {
-        if (t < HGYM_NUM_REWARDS) {
-            A.out.extras_episode[t] = A.st.episode_acc[t] / (float)cnt / A.cfg.episode_length_s;
-            A.st.episode_acc[t] = 0.0f;
-        }
-        for (int i = t; i < N; i += nthreads) A.out.extras_time_outs[i] = A.out.time_out[i];
-    }
-}
-// optional transition sink (HgymEnvOut::t_*): PPO.process_env_step for the scalar columns, hgym_store_step's arithmetic.
-// Thread t touches exactly the elements it refreshed in part 1.
-HG_HD void env_finalize_store(const EnvArgs& A, int t, int nthreads) {
-    if (!A.out.t_rewards) return;
-    const int N = A.cfg.num_envs;
-    for (int i = t; i < N; i += nthreads) {
-        const float to = (float)(A.out.extras_time_outs[i] != 0);
-        A.out.t_rewards[i] = A.out.rew[i] + A.out.t_gamma * (A.out.t_values[i] * to);
-        A.out.t_dones[i] = A.out.reset[i] != 0;
-    }
-}
-HG_HD void env_finalize_part2(const EnvArgs& A) {
-    if (A.out.t_rewards && A.out.t_step) A.out.t_step[0] += 1;
-    A.st.counters[1] = 0;
-    if (A.mode == MODE_STEP) A.st.counters[0] += 1;
-    if (A.mode != MODE_RESET_ALL) A.st.counters[2] += 1;
-}
+// Step finaliser (hgym_finalize.hpp) on an EnvArgs record.
+HG_HD FinArgs fin_of(const EnvArgs& A) { return make_fin_args(A.cfg, A.st, A.out, A.mode); }
+HG_HD void env_finalize_part1(const EnvArgs& A, int t, int nthreads) { fin_part1(fin_of(A), t, nthreads); }
+HG_HD void env_finalize_store(const EnvArgs& A, int t, int nthreads) { fin_store(fin_of(A), t, nthreads); }
+HG_HD void env_finalize_part2(const EnvArgs& A) { fin_part2(fin_of(A)); }
 
 #undef FG
 }  // namespace hgym

@@ -1,0 +1,78 @@
+// hgym_finalize.hpp -- the step finaliser: the cross-env pieces of one env step, which need every env's result.
+//   * extras["episode"][k] = mean over the envs that reset this step of their episode sums / episode_length_s, and
+//     extras["time_outs"] = this step's time_out_buf -- both refreshed ONLY when at least one env reset (the reference
+//     re-assigns them inside reset_idx: legged_robot.py:173-174, 199-210);
+//   * optionally (HgymEnvOut transition sink) PPO.process_env_step's scalar columns, hgym_store_step's arithmetic;
+//   * the device-resident step counters.
+// Shared by two hosts: env_finalize_kernel (its own launch, hgym_env.hip) and the fused-forward kernel, where the finaliser
+// of vec-step t rides as ONE extra workgroup of the policy launch of step t+1 (HgymEnvOut.defer_finalize): the kernel
+// boundary between the env step and that launch is the only synchronisation it needs, and a 5 us single-workgroup launch
+// leaves the rollout's critical path.  (Folding it into the env kernel itself with a last-workgroup-done ticket needs an
+// agent-scope release per workgroup -- an L2 write-back on every XCD -- and measured 52 us against 31.5 us.)
+#pragma once
+#include "hgym_common.hpp"
+
+namespace hgym {
+
+enum { FIN_MODE_STEP = 0, FIN_MODE_PRIME = 1, FIN_MODE_RESET_ALL = 2 };   // = MODE_* of hgym_env_math.hpp
+
+struct FinArgs {
+    int N;
+    int mode;
+    float episode_length_s;
+    int64_t* counters;       // HgymEnvState::counters
+    float* episode_acc;      // HgymEnvState::episode_acc
+    HgymEnvOut out;
+};
+
+HG_HD FinArgs make_fin_args(const HgymEnvConfig& cfg, const HgymEnvState& st, const HgymEnvOut& out, int mode) {
+    FinArgs f;
+    f.N = cfg.num_envs;
+    f.mode = mode;
+    f.episode_length_s = cfg.episode_length_s;
+    f.counters = st.counters;
+    f.episode_acc = st.episode_acc;
+    f.out = out;
+    return f;
+}
+
+HG_HD void fin_part1(const FinArgs& F, int t, int nthreads) {
+    const int64_t cnt = F.counters[1];
+    if (cnt > 0) {
+        if (t < HGYM_NUM_REWARDS) {
+            F.out.extras_episode[t] = F.episode_acc[t] / (float)cnt / F.episode_length_s;
+            F.episode_acc[t] = 0.0f;
+        }
+        for (int i = t; i < F.N; i += nthreads) F.out.extras_time_outs[i] = F.out.time_out[i];
+    }
+}
+// optional transition sink (HgymEnvOut::t_*).  Thread t touches exactly the elements it refreshed in part 1.
+HG_HD void fin_store(const FinArgs& F, int t, int nthreads) {
+#pragma clang fp contract(off)      // rew + gamma * (V * to) as three fp32 roundings, in every translation unit
+    if (!F.out.t_rewards) return;
+    for (int i = t; i < F.N; i += nthreads) {
+        const float to = (float)(F.out.extras_time_outs[i] != 0);
+        const float boot = F.out.t_values[i] * to;
+        const float gb = F.out.t_gamma * boot;
+        F.out.t_rewards[i] = F.out.rew[i] + gb;
+        F.out.t_dones[i] = F.out.reset[i] != 0;
+    }
+}
+HG_HD void fin_part2(const FinArgs& F) {
+    // with a deferred finaliser the env kernel itself bumps the policy's sampling step (the policy launch this rides in
+    // reads it at entry)
+    if (F.out.t_rewards && F.out.t_step && !F.out.defer_finalize) F.out.t_step[0] += 1;
+    F.counters[1] = 0;
+    if (F.mode == FIN_MODE_STEP) F.counters[0] += 1;
+    if (F.mode != FIN_MODE_RESET_ALL) F.counters[2] += 1;
+}
+
+// all of it, for one workgroup of `nthreads` lanes
+__device__ __forceinline__ void fin_block(const FinArgs& F, int t, int nthreads) {
+    fin_part1(F, t, nthreads);
+    __syncthreads();
+    fin_store(F, t, nthreads);
+    if (t == 0) fin_part2(F);
+}
+
+}  // namespace hgym

@@ -19,6 +19,7 @@
 // Weight operand layout: "fragment-major", fragment (nb, kb) = 1 KiB in exact lane order (lane l: row nb*16 + (l&15),
 // k = kb*32 + 8*(l>>4) .. +7), so a wavefront's weight load is one contiguous 1 KiB global_load_dwordx4.
 #pragma once
+#include "hgym_finalize.hpp"
 #include "hgym_gemm.hpp"
 
 namespace hgym {
@@ -339,6 +340,8 @@ struct FwdArgs {
     float* actions;           // (M, A)
     float* sigma;             // (M, A)
     float* logp;              // (M,)
+    int nets;                 // networks in this launch (blockIdx.y < nets)
+    FinArgs fin;              // postponed env-step finaliser riding in this launch (blockIdx.y == nets, one workgroup); fin.N == 0: none
 };
 
 template <int BM, int NW, int D, int G1>
@@ -539,9 +542,13 @@ __device__ __forceinline__ void fwd_body(const FwdArgs& a, const FusedNet& n, bo
     phase_stamp(a.dbg, 6);
 }
 
-template <int BM, int NW, int D>
+template <int BM, int NW, int D, bool FIN = false>
 __global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(const FwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (FIN && (int)blockIdx.y >= a.nets) {       // the extra grid row: the previous env step's finaliser, one workgroup
+        if (blockIdx.x == 0) fin_block(a.fin, threadIdx.x, NW * 64);
+        return;
+    }
     const int which = a.net0 + blockIdx.y;
     const FusedNet& n = a.net[which];
     const int g1 = n.layer[0].NB / NW;     // first hidden width 256 / 512 / 768

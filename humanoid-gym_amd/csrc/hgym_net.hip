@@ -150,6 +150,8 @@ static int32_t ws_layout(const HgymNetConfig* c, WsLayout* w) {
 }
 
 // ------------------------------------------------------------------------------------------------ small kernels
+__global__ __launch_bounds__(1024) void fin_only_kernel(const FinArgs f) { fin_block(f, threadIdx.x, blockDim.x); }
+
 // dst[m][k] = T(src[row(m)][k]) for k < K; row(m) = idx ? idx[m] : m.  Pad columns are left untouched (zero).
 template <typename T>
 __global__ __launch_bounds__(256) void pack_rows_kernel(int M, int K, const float* __restrict__ src, int64_t ld_src,
@@ -711,8 +713,8 @@ struct NetRunner {
         return f;
     }
 
-    template <int BM, int NW, int D>
-    int32_t launch_fwd(const FwdArgs& a, int nets) {
+    template <int BM, int NW, int D, bool FIN>
+    int32_t launch_fwd_k(const FwdArgs& a, int nets) {
         size_t lds = 0;
         for (int i = 0; i < nets; ++i) {
             const FusedNet& n = a.net[a.net0 + i];
@@ -720,21 +722,27 @@ struct NetRunner {
         }
         static size_t attr_lds = 0;
         if (lds > attr_lds) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fwd_kernel<BM, NW, D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
-                hipSuccess)
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fwd_kernel<BM, NW, D, FIN>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds) != hipSuccess)
                 HG_FAIL(HGYM_E_LAUNCH, "cannot reserve %zu bytes of LDS for mlp_fwd_kernel", lds);
             attr_lds = lds;
         }
         FwdArgs b = a;
-        b.dbg = phase_buffer((int64_t)ceil_div(a.M, BM) * nets);
-        hipLaunchKernelGGL((mlp_fwd_kernel<BM, NW, D>), dim3(ceil_div(a.M, BM), nets), dim3(NW * 64), lds, s, b);
+        b.nets = nets;
+        const int rows = nets + (FIN ? 1 : 0);          // + the finaliser's grid row (its workgroup 0 works, the rest exit)
+        b.dbg = phase_buffer((int64_t)ceil_div(a.M, BM) * rows);
+        hipLaunchKernelGGL((mlp_fwd_kernel<BM, NW, D, FIN>), dim3(ceil_div(a.M, BM), rows), dim3(NW * 64), lds, s, b);
         HG_CHECK_LAUNCH("mlp_fwd_kernel");
         return HGYM_OK;
+    }
+    template <int BM, int NW, int D>
+    int32_t launch_fwd(const FwdArgs& a, int nets) {
+        return a.fin.N > 0 ? launch_fwd_k<BM, NW, D, true>(a, nets) : launch_fwd_k<BM, NW, D, false>(a, nets);
     }
 
     // forward of `nets` networks starting at `first` in ONE launch; xs/outs indexed by net id
     int32_t fused_forward(int first, int nets, int M, const float* const xs[2], const int64_t ldxs[2], const int64_t* idx, float* const outs[2],
-                          const int64_t ldos[2], bool train, const SampleOut* smp) {
+                          const int64_t ldos[2], bool train, const SampleOut* smp, const FinArgs* fin = nullptr) {
         HG_REQUIRE(M > 0 && M <= w.maxM, HGYM_E_SHAPE, "batch %d exceeds max_batch %lld", M, (long long)w.maxM);
         FwdArgs a;
         memset(&a, 0, sizeof(a));
@@ -742,6 +750,7 @@ struct NetRunner {
         a.net0 = first;
         a.M = M;
         a.idx = idx;
+        if (fin) a.fin = *fin;
         a.train = train ? 1 : 0;
         a.A = cfg.num_actions;
         a.std_ = net.params;
@@ -874,14 +883,18 @@ struct NetRunner {
     }
 
     int32_t act(int M, const float* obs, const float* priv, const float* z, uint64_t seed, const int64_t* step, float* actions, float* mu,
-                float* sigma, float* logp, float* values) {
+                float* sigma, float* logp, float* values, const FinArgs* fin = nullptr) {
         if (w.fused) {
             const float* xs[2] = {obs, priv};
             const int64_t ldxs[2] = {cfg.num_obs, cfg.num_priv};
             float* outs[2] = {mu, values};
             const int64_t ldos[2] = {cfg.num_actions, 1};
             const SampleOut smp = {z, seed, step, actions, sigma, logp};
-            return fused_forward(0, 2, M, xs, ldxs, nullptr, outs, ldos, false, &smp);
+            return fused_forward(0, 2, M, xs, ldxs, nullptr, outs, ldos, false, &smp, fin);
+        }
+        if (fin) {     // generic path: the postponed finaliser as its own (tiny) launch
+            hipLaunchKernelGGL(fin_only_kernel, dim3(1), dim3(1024), 0, s, *fin);
+            HG_CHECK_LAUNCH("fin_only_kernel");
         }
         int32_t rc = forward(0, M, obs, cfg.num_obs, nullptr, mu, cfg.num_actions, false);
         if (rc) return rc;
@@ -1141,6 +1154,22 @@ int32_t hgym_policy_act(const HgymNetConfig* cfg, const HgymNet* net, int32_t M,
     if (rc) return rc;
     HG_REQUIRE(obs && priv && actions && mu && sigma && logp && values, HGYM_E_BADARG, "null pointer");
     HG_DISPATCH(cfg, net, w, stream, act(M, obs, priv, z, seed, step_counter, actions, mu, sigma, logp, values));
+}
+
+int32_t hgym_policy_act_fin(const HgymNetConfig* cfg, const HgymNet* net, int32_t M, const float* obs, const float* priv, const float* z,
+                            uint64_t seed, const int64_t* step_counter, float* actions, float* mu, float* sigma, float* logp,
+                            float* values, const HgymEnvConfig* env_cfg, const HgymEnvState* env_st, const HgymEnvOut* env_out,
+                            void* stream) {
+    WsLayout w;
+    int32_t rc = check_net(cfg, net, &w);
+    if (rc) return rc;
+    HG_REQUIRE(obs && priv && actions && mu && sigma && logp && values, HGYM_E_BADARG, "null pointer");
+    HG_REQUIRE(env_cfg && env_st && env_out, HGYM_E_BADARG, "null env cfg/state/out");
+    HG_REQUIRE(env_st->counters && env_st->episode_acc && env_out->time_out && env_out->extras_time_outs && env_out->extras_episode &&
+                   env_out->rew && env_out->reset, HGYM_E_BADARG, "null finaliser buffer");
+    HG_REQUIRE(env_cfg->num_envs > 0, HGYM_E_SHAPE, "num_envs=%d", env_cfg->num_envs);
+    const FinArgs fin = make_fin_args(*env_cfg, *env_st, *env_out, FIN_MODE_STEP);
+    HG_DISPATCH(cfg, net, w, stream, act(M, obs, priv, z, seed, step_counter, actions, mu, sigma, logp, values, &fin));
 }
 
 int32_t hgym_ppo_grad(const HgymNetConfig* cfg, const HgymPPOConfig* ppo, const HgymNet* net, const HgymBatch* batch, void* stream) {

@@ -77,7 +77,7 @@ class EnvOut(C.Structure):
     _fields_ = [("obs", c_float_p), ("priv_obs", c_float_p), ("rew", c_float_p), ("reset", c_u8_p), ("time_out", c_u8_p),
                 ("extras_time_outs", c_u8_p), ("extras_episode", c_float_p),
                 ("t_values", c_float_p), ("t_rewards", c_float_p), ("t_dones", c_u8_p), ("t_step", c_i64_p),
-                ("t_gamma", C.c_float)]
+                ("t_gamma", C.c_float), ("defer_finalize", C.c_int32)]
 
 
 class EnvNoise(C.Structure):
@@ -130,6 +130,7 @@ SYMBOLS = {
     "hgym_synth_physics": (C.c_int32, [_P(EnvConfig), _P(SimTensors), _P(EnvState), C.c_void_p]),
     "hgym_post_physics": (C.c_int32, [_P(EnvConfig), _P(SimTensors), _P(EnvState), _P(EnvOut), _P(EnvNoise), C.c_void_p]),
     "hgym_env_step_synth": (C.c_int32, [_P(EnvConfig), _P(SimTensors), _P(EnvState), _P(EnvOut), c_float_p, C.c_void_p]),
+    "hgym_env_finalize": (C.c_int32, [_P(EnvConfig), _P(EnvState), _P(EnvOut), C.c_void_p]),
     "hgym_store_step": (C.c_int32, [C.c_int32, c_float_p, c_float_p, c_u8_p, c_u8_p, C.c_float, c_float_p, c_u8_p, C.c_void_p]),
     "hgym_gae": (C.c_int32, [C.c_int32, C.c_int32, c_float_p, c_float_p, c_u8_p, c_float_p, C.c_float, C.c_float,
                              c_float_p, c_float_p, c_f64_p, C.c_void_p]),
@@ -140,6 +141,8 @@ SYMBOLS = {
     "hgym_mlp_forward": (C.c_int32, [_P(NetConfig), _P(Net), C.c_int32, C.c_int32, c_float_p, C.c_int64, c_float_p, C.c_void_p]),
     "hgym_policy_act": (C.c_int32, [_P(NetConfig), _P(Net), C.c_int32, c_float_p, c_float_p, c_float_p, C.c_uint64, c_i64_p,
                                     c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, C.c_void_p]),
+    "hgym_policy_act_fin": (C.c_int32, [_P(NetConfig), _P(Net), C.c_int32, c_float_p, c_float_p, c_float_p, C.c_uint64, c_i64_p,
+                                    c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, _P(EnvConfig), _P(EnvState), _P(EnvOut), C.c_void_p]),
     "hgym_ppo_grad": (C.c_int32, [_P(NetConfig), _P(PPOConfig), _P(Net), _P(Batch), C.c_void_p]),
     "hgym_ppo_apply": (C.c_int32, [_P(NetConfig), _P(PPOConfig), _P(Net), C.c_void_p]),
     "hgym_prof_enable": (C.c_int32, [C.c_int32]),

@@ -153,14 +153,16 @@ class EnvBuffers:
         st.episode_acc = L.fptr(self.episode_acc)
         return st
 
-    def out_struct(self, obs=None, priv=None, sink=None):
-        """sink: optional dict(values, rewards, dones, step, gamma) -- HgymEnvOut's transition sink (caller keeps the tensors alive)."""
+    def out_struct(self, obs=None, priv=None, sink=None, defer_finalize=False):
+        """sink: optional dict(values, rewards, dones, step, gamma) -- HgymEnvOut's transition sink (caller keeps the tensors alive).
+        defer_finalize: the env-step call does not launch the step finaliser (see HgymEnvOut.defer_finalize)."""
         o = L.EnvOut(L.fptr(self.obs if obs is None else obs), L.fptr(self.priv_obs if priv is None else priv),
                      L.fptr(self.rew), L.u8ptr(self.reset), L.u8ptr(self.time_out), L.u8ptr(self.extras_time_outs),
                      L.fptr(self.extras_episode))
         if sink is not None:
             o.t_values, o.t_rewards = L.fptr(sink["values"]), L.fptr(sink["rewards"])
             o.t_dones, o.t_step, o.t_gamma = L.u8ptr(sink["dones"]), L.i64ptr(sink.get("step")), float(sink["gamma"])
+        o.defer_finalize = 1 if defer_finalize else 0
         return o
 
     @staticmethod

@@ -98,12 +98,21 @@ class NetBuffers:
                                        self.stream()), "hgym_mlp_forward")
         return y
 
-    def act(self, obs, priv, z=None, seed=0, step_counter=None, out=None):
+    def act(self, obs, priv, z=None, seed=0, step_counter=None, out=None, env_fin=None):
+        """env_fin: optional (HgymEnvConfig, HgymEnvState, HgymEnvOut) of an env step whose finaliser was postponed
+        (HgymEnvOut.defer_finalize): it runs as one extra workgroup of this launch (hgym_policy_act_fin)."""
         M = obs.shape[0]
         A = self.cfg.num_actions
         if out is None:
             e = lambda *s: torch.empty(*s, device=self.device)
             out = dict(actions=e(M, A), mu=e(M, A), sigma=e(M, A), logp=e(M), values=e(M, 1))
+        if env_fin is not None:
+            ecfg, est, eout = env_fin
+            L.check(L.lib.hgym_policy_act_fin(C.byref(self.cfg), C.byref(self.struct), M, L.fptr(obs), L.fptr(priv), L.fptr(z), int(seed),
+                                              L.i64ptr(step_counter), L.fptr(out["actions"]), L.fptr(out["mu"]), L.fptr(out["sigma"]),
+                                              L.fptr(out["logp"]), L.fptr(out["values"]), C.byref(ecfg), C.byref(est), C.byref(eout),
+                                              self.stream()), "hgym_policy_act_fin")
+            return out
         L.check(L.lib.hgym_policy_act(C.byref(self.cfg), C.byref(self.struct), M, L.fptr(obs), L.fptr(priv), L.fptr(z), int(seed),
                                       L.i64ptr(step_counter), L.fptr(out["actions"]), L.fptr(out["mu"]), L.fptr(out["sigma"]),
                                       L.fptr(out["logp"]), L.fptr(out["values"]), self.stream()), "hgym_policy_act")

@@ -106,15 +106,22 @@ class OnPolicyRunner:
 
         if sink_ok:
             alg.env_stores_transitions = True
+        # ... and, when nothing on the host looks at the per-step extras (no logging), the finaliser of vec-step t is not
+        # launched by the env at all: it rides as one extra workgroup of the policy launch of step t+1 (2 launches per vec-step)
+        defer_ok = (sink_ok and not log_on and hasattr(env, "take_pending_finalize") and isinstance(alg, PPO)
+                    and os.environ.get("HGYM_DEFER_FIN", "1") != "0")
 
         def rollout(obs, critic_obs):
+            fin = None
             for i in range(self.num_steps_per_env):
-                actions = alg.act(obs, critic_obs)
+                actions = alg.act(obs, critic_obs, env_fin=fin) if defer_ok else alg.act(obs, critic_obs)
                 if zero_copy:
                     env.bind_outputs(obs_all[i + 1], priv_all[i + 1])
                 if sink_ok:
-                    env.bind_transition(alg.transition_sink())
+                    env.bind_transition(alg.transition_sink(), defer_finalize=True) if defer_ok else env.bind_transition(alg.transition_sink())
                 obs, privileged_obs, rewards, dones, infos = env.step(actions)
+                if defer_ok:
+                    fin = env.take_pending_finalize()
                 critic_obs = privileged_obs if privileged_obs is not None else obs
                 alg.process_env_step(rewards, dones, infos, **({"stored": True} if sink_ok else {}))
                 if log_on:
@@ -128,6 +135,8 @@ class OnPolicyRunner:
                     done_stats[2] += d.sum()
                     cur_reward_sum.mul_(1.0 - d)
                     cur_episode_length.mul_(1.0 - d)
+            if defer_ok:
+                env.run_finalize(fin)           # the last step has no following policy launch
             return obs, critic_obs
 
         # Without logging nothing on the host needs the iteration's results: collection / learn time are then measured with
@@ -145,7 +154,7 @@ class OnPolicyRunner:
                 ev[0].record()
             with torch.inference_mode():
                 g = self._graph
-                if use_graph and g is not None and g["key"] == (id(env), id(alg.storage), log_on, sink_ok):
+                if use_graph and g is not None and g["key"] == (id(env), id(alg.storage), log_on, sink_ok, defer_ok):
                     g["graph"].replay()
                     alg.storage.step = self.num_steps_per_env
                     obs, critic_obs = g["out"]
@@ -159,7 +168,7 @@ class OnPolicyRunner:
                     # concurrently; only this thread's launches belong to the capture
                     with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                         out = rollout(obs_all[0], priv_all[0])
-                    self._graph = dict(graph=graph, out=out, ep_infos=ep_infos, key=(id(env), id(alg.storage), log_on, sink_ok),
+                    self._graph = dict(graph=graph, out=out, ep_infos=ep_infos, key=(id(env), id(alg.storage), log_on, sink_ok, defer_ok),
                                        stats=(cur_reward_sum, cur_episode_length, done_stats))
                     alg.storage.step = 0
                     graph.replay()                  # capture does not execute: run the captured rollout once

@@ -129,13 +129,15 @@ class PPO:
         self.actor_critic.train()
 
     # ------------------------------------------------------------------ rollout
-    def act(self, obs, critic_obs):
+    def act(self, obs, critic_obs, env_fin=None):
+        """env_fin (native extension): a postponed env-step finaliser to run inside this policy launch
+        (LeggedRobot.take_pending_finalize)."""
         st, s = self.storage, self.storage.step
         out = None
         if s < st.num_transitions_per_env:     # write straight into the storage slot (no add_transitions copies)
             out = dict(actions=st.actions[s], mu=st.mu[s], sigma=st.sigma[s], logp=st.actions_log_prob[s].view(-1), values=st.values[s])
         t = self.transition
-        t.actions = self.actor_critic.act(obs, critic_obs, out=out)
+        t.actions = self.actor_critic.act(obs, critic_obs, out=out, env_fin=env_fin)
         last = self.actor_critic._last
         t.values, t.actions_log_prob = last["values"], last["logp"]
         t.action_mean, t.action_sigma = last["mu"], last["sigma"]

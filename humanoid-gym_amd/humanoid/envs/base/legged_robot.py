@@ -251,11 +251,24 @@ class LeggedRobot(BaseTask):
         (the rollout storage slot), removing the add_transitions copy.  Pass None to go back."""
         self._bound_out = None if obs is None else (obs, priv)
 
-    def bind_transition(self, sink):
+    def bind_transition(self, sink, defer_finalize=False):
         """Native extension: `sink` = dict(values, rewards, dones, step, gamma) of caller tensors (or None).  While bound, the
         step finaliser also stores the scalar columns of the transition (what PPO.process_env_step would launch
-        hgym_store_step for) and bumps the policy's sampling-step counter: one launch per vec-step instead of three."""
+        hgym_store_step for) and bumps the policy's sampling-step counter: one launch per vec-step instead of three.
+        defer_finalize: step() does not launch the finaliser at all; the caller collects it with take_pending_finalize() and
+        hands it to the next policy launch (PPO.act(env_fin=...)) or to run_finalize() -- before the next step()."""
         self._sink = sink
+        self._defer = bool(defer_finalize) and sink is not None
+
+    def take_pending_finalize(self):
+        p, self._pending_fin = getattr(self, "_pending_fin", None), None
+        return p
+
+    def run_finalize(self, fin):
+        """Run a postponed step finaliser on its own (the last step of a rollout has no following policy launch)."""
+        if fin is not None:
+            self._L.check(self._L.lib.hgym_env_finalize(C.byref(fin[0]), C.byref(fin[1]), C.byref(fin[2]), self._stream()),
+                          "hgym_env_finalize")
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -266,7 +279,7 @@ class LeggedRobot(BaseTask):
         else:
             self._flip ^= 1
             obs, priv = self._outs[self._flip]
-        return obs, priv, self._buf.out_struct(obs, priv, getattr(self, "_sink", None))
+        return obs, priv, self._buf.out_struct(obs, priv, getattr(self, "_sink", None), getattr(self, "_defer", False))
 
     # ------------------------------------------------------------------ VecEnv API
     def step(self, actions):
@@ -275,9 +288,13 @@ class LeggedRobot(BaseTask):
         a = actions.to(self.device, torch.float32)
         if not a.is_contiguous():
             a = a.contiguous()
+        if getattr(self, "_pending_fin", None) is not None:
+            raise RuntimeError("the previous step's finaliser was postponed (bind_transition(defer_finalize=True)) and never run")
         obs, priv, out = self._next_out()
         L.check(L.lib.hgym_env_step_synth(C.byref(self._ncfg), C.byref(self._sim_s), C.byref(self._st_s), C.byref(out),
                                           L.fptr(a), self._stream()), "hgym_env_step_synth")
+        if out.defer_finalize:
+            self._pending_fin = (self._ncfg, self._st_s, out)
         if self._ncfg.use_ref_actions and a.data_ptr() != actions.data_ptr():
             actions.copy_(a)         # the reference mutates the caller's tensor (humanoid_env.py:190-191: actions += ref_action)
         self.obs_buf, self.privileged_obs_buf = obs, priv

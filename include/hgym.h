@@ -167,6 +167,11 @@ typedef struct HgymEnvOut {
     uint8_t* t_dones;          /* (N,) storage.dones[step]    = reset */
     int64_t* t_step;           /* device scalar += 1 per step (the policy's sampling-step counter), or NULL */
     float t_gamma;
+    /* 1: the env-step entry points do NOT launch the step finaliser; the caller runs it before the next env step, either as
+     * one extra workgroup of the next policy launch (hgym_policy_act_fin) or on its own (hgym_env_finalize).  *t_step is
+     * then bumped by the env kernel itself.  Until the finaliser has run, the extras_* outputs, the transition-sink slots
+     * and the step counters are those of the previous step. */
+    int32_t defer_finalize;
 } HgymEnvOut;
 
 /* Optional externally supplied random draws (parity mode), row-major (N,k) tables indexed by env id.
@@ -212,6 +217,10 @@ int32_t hgym_post_physics(const HgymEnvConfig* cfg, const HgymSimTensors* sim, c
 /* Fast path: pre_physics + synth_physics + post_physics in ONE launch, then the step finaliser. */
 int32_t hgym_env_step_synth(const HgymEnvConfig* cfg, const HgymSimTensors* sim, const HgymEnvState* st,
                             const HgymEnvOut* out, float* actions_in, void* stream);
+
+/* The step finaliser of the last env step on its own (flushes HgymEnvOut.defer_finalize; a no-op to call twice it is NOT:
+ * the counters advance each time). */
+int32_t hgym_env_finalize(const HgymEnvConfig* cfg, const HgymEnvState* st, const HgymEnvOut* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Rollout storage side (algo/ppo/rollout_storage.py, algo/ppo/ppo.py:103-117)
@@ -296,6 +305,14 @@ int32_t hgym_mlp_forward(const HgymNetConfig* cfg, const HgymNet* net, int32_t w
 int32_t hgym_policy_act(const HgymNetConfig* cfg, const HgymNet* net, int32_t M, const float* obs,
                         const float* priv, const float* z, uint64_t seed, const int64_t* step_counter,
                         float* actions, float* mu, float* sigma, float* logp, float* values, void* stream);
+
+/* hgym_policy_act + the postponed step finaliser of the PREVIOUS env step (env_cfg / env_st / env_out as that step got them,
+ * env_out->defer_finalize = 1) as one extra workgroup of the same launch: one launch less per vec-step. */
+int32_t hgym_policy_act_fin(const HgymNetConfig* cfg, const HgymNet* net, int32_t M, const float* obs,
+                            const float* priv, const float* z, uint64_t seed, const int64_t* step_counter,
+                            float* actions, float* mu, float* sigma, float* logp, float* values,
+                            const HgymEnvConfig* env_cfg, const HgymEnvState* env_st, const HgymEnvOut* env_out,
+                            void* stream);
 
 /* One minibatch of PPO.update up to and including backward (ppo.py:128-171), device side only:
  * gathers rows `idx[0..B)` (indices into the flattened (T*N) storage, rollout_storage.py:151-182) of the
