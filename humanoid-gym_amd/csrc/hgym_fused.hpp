@@ -374,9 +374,10 @@ __device__ __forceinline__ void fwd_body(const FwdArgs& a, const FusedNet& n, bo
         bv[u] = *src;
     }
     // sampling epilogue inputs (head waves of the actor): fetched now, used ~20 us later
+    constexpr bool HOIST = NW <= 8;      // the 16-wave tiles have no registers to park them in (they spill)
     int64_t step_pre = 0;
     float std_pre[4] = {1.0f, 1.0f, 1.0f, 1.0f};
-    if (is_actor && a.sample && wave < BM / 16) {
+    if (HOIST && is_actor && a.sample && wave < BM / 16) {
         if (!a.z && a.step) step_pre = a.step[0];
 #pragma unroll
         for (int e = 0; e < 4; ++e) std_pre[e] = a.std_[4 * q + e < a.A ? 4 * q + e : 0];
@@ -513,7 +514,7 @@ __device__ __forceinline__ void fwd_body(const FwdArgs& a, const FusedNet& n, bo
 #pragma unroll
                 for (int e = 0; e < 4; ++e) zz[e] = (m < a.M && 4 * q + e < A) ? a.z[(int64_t)m * A + 4 * q + e] : 0.0f;
             } else {
-                const int64_t s = step_pre;
+                const int64_t s = HOIST ? step_pre : (a.step ? a.step[0] : 0);
                 const RngKey rk = {a.k0, a.k1, (uint32_t)s, (uint32_t)(s >> 32)};
                 const U4 u = rng4(rk, (uint32_t)m, SLOT_POLICY + (uint32_t)q);
                 box_muller(u.x, u.y, zz[0], zz[1]);
@@ -524,7 +525,7 @@ __device__ __forceinline__ void fwd_body(const FwdArgs& a, const FusedNet& n, bo
             for (int e = 0; e < 4; ++e) {
                 const int j = 4 * q + e;
                 if (j < A) {
-                    const float sg = mu[e] * 0.0f + std_pre[e];      // actor_critic.py:113
+                    const float sg = mu[e] * 0.0f + (HOIST ? std_pre[e] : a.std_[j]);      // actor_critic.py:113
                     const float act = mu[e] + sg * zz[e];
                     const float d = act - mu[e];
                     lp += -(d * d) / (2.0f * sg * sg) - logf(sg) - 0.9189385332046727f;
