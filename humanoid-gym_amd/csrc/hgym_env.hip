@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void env_step_kernel(const EnvArgs A) {
     if (t < 64) {
         if (!(A.ablate & 2)) env_step_phase_a<E_T>(A, blockIdx.x, t, smem, csc0);
     } else if (kPrefetch) {
-        if (stack_on && !(A.ablate & 256)) {
+        if (stack_on) {
             hist_store<HP, HGYM_OBS_FRAME, NIO>(A.out.obs, geom.e0, geom.nE, (int)(ring_step % HP), t - 64, NTH, nullptr, A.cfg.clip_obs, hist_o);
             hist_store<HCP, HGYM_PRIV_FRAME, NIP>(A.out.priv_obs, geom.e0, geom.nE, (int)(ring_step % HCP), t - 64, NTH, nullptr, A.cfg.clip_obs,
                                                   hist_p);
@@ -58,14 +58,6 @@ __global__ __launch_bounds__(256) void env_step_kernel(const EnvArgs A) {
         env_step_stack_old<H_T, HC_T, E_T>(A, blockIdx.x, t - 64, blockDim.x - 64, ring_step);
     }
     __syncthreads();
-    if (kPrefetch && stack_on && (A.ablate & 256)) {      // A/B experiment: the stores after the scalar phase instead
-        if (t >= 64) {
-            hist_store<HP, HGYM_OBS_FRAME, NIO>(A.out.obs, geom.e0, geom.nE, (int)(ring_step % HP), t - 64, NTH, nullptr, A.cfg.clip_obs, hist_o);
-            hist_store<HCP, HGYM_PRIV_FRAME, NIP>(A.out.priv_obs, geom.e0, geom.nE, (int)(ring_step % HCP), t - 64, NTH, nullptr, A.cfg.clip_obs,
-                                                  hist_p);
-        }
-        __syncthreads();
-    }
     if (!(A.ablate & 4)) env_stage_out<E_T>(A, blockIdx.x, t, blockDim.x, smem);
     if (!(A.ablate & 8)) env_step_phase_b<H_T, HC_T, E_T>(A, blockIdx.x, t, blockDim.x, smem, csc0, ring_step, false);
     // postponed finaliser (HgymEnvOut.defer_finalize): the sampling step the NEXT policy launch reads is bumped here -- no policy
@@ -119,8 +111,8 @@ int device_cus() {
 
 static int pick_envs_per_block(int N) {
     // 16 envs per workgroup at every size: one workgroup per CU at 4096 envs, two co-resident ones (240 VGPRs) beyond.
-    // 32-env workgroups (HGYM_ENV_EPB=32, kept for experiments) need 256 + 69 registers, run one per CU and measured
-    // 80 us against 67 us at 16 384 envs.  Multiples of 4 keep every slice of the row-major outputs 16-byte aligned.
+    // (32-env workgroups needed 256 + 69 registers, ran one per CU and measured 80 us against 67 us at 16 384 envs.)
+    // Multiples of 4 keep every slice of the row-major outputs 16-byte aligned.
     (void)N;
     return 16;
 }
@@ -157,9 +149,7 @@ static int32_t launch_step(const HgymEnvConfig* cfg, const HgymSimTensors* sim, 
     A.fused = fused;
     A.envs_per_block = pick_envs_per_block(cfg->num_envs);
     static const int ablate = getenv("HGYM_ENV_ABLATE") ? atoi(getenv("HGYM_ENV_ABLATE")) : 0;   // profiling experiments only
-    static const int epb = getenv("HGYM_ENV_EPB") ? atoi(getenv("HGYM_ENV_EPB")) : 0;
     A.ablate = ablate;
-    if (epb == 16 || epb == 32) A.envs_per_block = epb;
     set_body_offsets(A);
     {   // fast staging when the state fields are one contiguous [136][N] allocation
         bool contig = true;
@@ -173,8 +163,6 @@ static int32_t launch_step(const HgymEnvConfig* cfg, const HgymSimTensors* sim, 
     const bool std_stack = cfg->frame_stack == 15 && cfg->c_frame_stack == 3;
     if (std_stack && A.envs_per_block == 16)
         hipLaunchKernelGGL((env_step_kernel<15, 3, 16>), dim3(blocks), dim3(256), lds, s, A);
-    else if (std_stack && A.envs_per_block == 32)
-        hipLaunchKernelGGL((env_step_kernel<15, 3, 32>), dim3(blocks), dim3(256), lds, s, A);
     else
         hipLaunchKernelGGL((env_step_kernel<0, 0, 0>), dim3(blocks), dim3(256), lds, s, A);
     {   // algorithmic bytes per env-step, SURVEY.md §8d: 4*[245 + (H-1)*47 + (Hc-1)*73 + H*47 + Hc*73] + 6
