@@ -37,6 +37,8 @@ def parse():
     p.add_argument("--warmup", type=int, default=3)
     p.add_argument("--num-envs", type=int, default=4096, help="envs per GPU (weak scaling)")
     p.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
+    p.add_argument("--task", default="humanoid_ppo", choices=["humanoid_ppo", "humanoid_dwl_ppo"],
+                   help="humanoid_ppo = BASELINE configs[1] (the headline); humanoid_dwl_ppo adds the denoising head (configs[4])")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-roofline", action="store_true")
     return p.parse_args()
@@ -123,7 +125,7 @@ def main():
     from humanoid.utils import get_args
     from hgym import _lib as L
     dev = "cuda:%d" % local
-    a = get_args(["--task=humanoid_ppo", "--headless", "--num_envs", str(args.num_envs), "--sim_device", dev, "--rl_device", dev,
+    a = get_args(["--task=" + args.task, "--headless", "--num_envs", str(args.num_envs), "--sim_device", dev, "--rl_device", dev,
                   "--seed", str(5 + rank)])
     env, env_cfg = task_registry.make_env(name=a.task, args=a)
     runner, train_cfg = task_registry.make_alg_runner(env=env, name=a.task, args=a, log_root=None)
@@ -200,7 +202,8 @@ def main():
             "metric": "env-steps/s (XBot-L PPO, whole job)", "value": value, "unit": "env-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": "XBot-L PPO %d envs/GPU, synthetic physics step, T=60, 2 epochs x 4 minibatches (BASELINE configs[1])" % N,
+            "config": {"workload": "XBot-L PPO %d envs/GPU, synthetic physics step, T=60, 2 epochs x 4 minibatches (BASELINE configs[%s])"
+                                   % (N, "1" if args.task == "humanoid_ppo" else "4: + denoising head"),
                        "envs_per_gpu": N, "steps_per_env": T, "obs": env.num_obs, "privileged_obs": env.num_privileged_obs,
                        "minibatch": T * N // 4, "parallelism": "dp%d (env shards, RCCL grad all-reduce)" % world},
             "ppo_update_ms": learn / args.steps * 1e3, "collection_ms": coll / args.steps * 1e3,

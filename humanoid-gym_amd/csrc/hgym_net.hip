@@ -44,7 +44,9 @@ struct WsLayout {
     int64_t maxM, Mp;        // max batch and its contraction padding (row stride of every transposed buffer)
     int64_t P;               // total parameters
     int64_t Ps;              // slab stride (P rounded up so every slab starts 256-byte aligned)
-    NetLayout net[2];        // 0 actor, 1 critic
+    NetLayout net[3];        // 0 actor, 1 critic, 2 auxiliary head (optional, always the generic layer-by-layer layout)
+    int nnets;               // 2 or 3
+    int64_t aux_p0;          // first parameter of the auxiliary head in the flat vector (= P when absent)
     int splits;
     int64_t slabs;           // [splits][P] fp32
     int64_t partials;        // [MAX_LOSS_BLOCKS][16] fp32
@@ -96,10 +98,19 @@ static int32_t ws_layout(const HgymNetConfig* c, WsLayout* w) {
         off += round_up(bytes, 256);
         return o;
     };
-    for (int which = 0; which < 2; ++which) {
+    HG_REQUIRE(c->aux_layers >= 0 && c->aux_layers <= HGYM_MAX_LAYERS, HGYM_E_SHAPE, "aux_layers=%d", c->aux_layers);
+    if (c->aux_layers > 0)
+        HG_REQUIRE(c->aux_dims[0] == c->num_obs && c->aux_target_offset >= 0 &&
+                       c->aux_target_offset + c->aux_dims[c->aux_layers] <= c->num_priv && c->actor_layers + c->critic_layers + c->aux_layers <= 16,
+                   HGYM_E_SHAPE, "auxiliary head: input must be num_obs, targets must lie inside the privileged row");
+    w->nnets = c->aux_layers > 0 ? 3 : 2;
+    w->aux_p0 = -1;
+    for (int which = 0; which < w->nnets; ++which) {
         NetLayout& n = w->net[which];
-        n.L = which == 0 ? c->actor_layers : c->critic_layers;
-        const int32_t* dims = which == 0 ? c->actor_dims : c->critic_dims;
+        n.L = which == 0 ? c->actor_layers : (which == 1 ? c->critic_layers : c->aux_layers);
+        const int32_t* dims = which == 0 ? c->actor_dims : (which == 1 ? c->critic_dims : c->aux_dims);
+        const bool fused_net = w->fused && which < 2;
+        if (which == 2) w->aux_p0 = poff;
         for (int l = 0; l < n.L; ++l) {
             LayerLayout& y = n.layer[l];
             y.K = dims[l];
@@ -113,7 +124,7 @@ static int32_t ws_layout(const HgymNetConfig* c, WsLayout* w) {
             poff += (int64_t)y.N * y.K;
             y.b_off = poff;
             poff += y.N;
-            if (w->fused) {
+            if (fused_net) {
                 y.KBf = (int)round_up(y.K, l == 0 ? FUSED_CHUNK : 32) / 32;
                 y.NBf = y.N16 / 16;
                 y.NBBf = (int)round_up(y.N, 32) / 32;
@@ -129,7 +140,7 @@ static int32_t ws_layout(const HgymNetConfig* c, WsLayout* w) {
             }
         }
         n.out_f32 = take(w->maxM * (int64_t)dims[n.L] * 4);
-        if (w->fused) {
+        if (fused_net) {
             n.X0b = take(w->Mpad * (int64_t)n.layer[0].KBf * 32 * 2);
             for (int l = 0; l < 3; ++l) {
                 n.Hb[l] = take(w->Mpad * (int64_t)n.layer[l].N * 2);
@@ -139,6 +150,7 @@ static int32_t ws_layout(const HgymNetConfig* c, WsLayout* w) {
         }
     }
     w->P = poff;
+    if (w->aux_p0 < 0) w->aux_p0 = poff;
     w->Ps = round_up(poff, 64);
     w->splits = MAX_SPLITS;
     w->dw_splits = 8;        // batch splits of the dW contraction, one per XCD (16 measured 3 % slower: twice the slab traffic)
@@ -206,6 +218,37 @@ __global__ __launch_bounds__(256) void rowsum_kernel(int Mp, const T* __restrict
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
     if (threadIdx.x == 0) atomicAdd(&out[blockIdx.y], red[0] + red[1] + red[2] + red[3]);
+}
+
+// Auxiliary head loss: L = coef * mean_b mean_j (y[b][j] - t[b][j])^2 with t = priv[idx[b]][off + j].  Writes
+// dL/dy in operand precision, row-major (dY, leading dimension ld) and transposed (dYT [No16][Mp]) for the generic backward,
+// zero in the contraction padding rows B..Bp, and adds the (unweighted) minibatch MSE to opt[10].
+template <typename T>
+__global__ __launch_bounds__(256) void aux_mse_kernel(int B, int Bp, int No, const float* __restrict__ y, const float* __restrict__ priv,
+                                                      int64_t ldp, int off, const int64_t* __restrict__ idx, float coef,
+                                                      T* __restrict__ dY, int64_t ld, T* __restrict__ dYT, int64_t ldt,
+                                                      double* __restrict__ opt) {
+    __shared__ float red[4];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    float se = 0.0f;
+    if (i < B) {
+        const float* t = priv + idx[i] * ldp + off;
+        const float g = 2.0f * coef / ((float)B * (float)No);
+        for (int j = 0; j < No; ++j) {
+            const float d = y[(int64_t)i * No + j] - t[j];
+            se += d * d;
+            const T gv = from_f32<T>(g * d);
+            dY[(int64_t)i * ld + j] = gv;
+            dYT[(int64_t)j * ldt + i] = gv;
+        }
+    } else if (i < Bp) {
+        for (int j = 0; j < No; ++j) dYT[(int64_t)j * ldt + i] = from_f32<T>(0.0f);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) se += __shfl_down(se, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = se;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(&opt[10], (double)(red[0] + red[1] + red[2] + red[3]) / ((double)B * (double)No));
 }
 
 // PPO.act epilogue (actor_critic.py:111-120): a = mu + sigma*z, logp = sum log N(a; mu, sigma); sigma = std.
@@ -640,14 +683,15 @@ struct NetRunner {
         sd.off = 0;
         sd.rows = cfg.num_actions;
         sd.cols = 1;
-        for (int which = 0; which < 2; ++which)
+        for (int which = 0; which < w.nnets; ++which)
             for (int l = 0; l < w.net[which].L; ++l) {
                 const LayerLayout& y = w.net[which].layer[l];
+                const bool fused_net = w.fused && which < 2;      // the auxiliary head always runs layer by layer
                 Segment& a = t.s[t.n++];
                 a.off = y.w_off;
                 a.rows = y.N;
                 a.cols = y.K;
-                if (w.fused) {
+                if (fused_net) {
                     a.splits = with_slabs ? w.dw_splits : 0;
                     a.Wf = ws + y.Wf;
                     a.WTf = ws + y.WTf;
@@ -664,7 +708,7 @@ struct NetRunner {
                 b.off = y.b_off;
                 b.rows = y.N;
                 b.cols = 1;
-                if (w.fused && with_slabs && l < w.net[which].L - 1) b.splits = w.dw_splits;   // hidden-layer bias grads come from the slabs
+                if (fused_net && with_slabs && l < w.net[which].L - 1) b.splits = w.dw_splits;   // hidden-layer bias grads come from the slabs
             }
         return t;
     }
@@ -874,6 +918,10 @@ struct NetRunner {
             prof_end(HGYM_PROF_DW, s, fl);
             HG_CHECK_LAUNCH("dw_kernel_rs");
         }
+        if (w.nnets > 2) {
+            const int32_t rca = aux_grad(ppo, b);
+            if (rca) return rca;
+        }
         const SegTable tab = segments(true);
         prof_begin(HGYM_PROF_REDUCE, s);
         hipLaunchKernelGGL(reduce_slabs_kernel, dim3(96, tab.n), dim3(256), 0, s, tab, w.Ps, at<float>(w.slabs), net.grads, net.opt_state);
@@ -907,7 +955,7 @@ struct NetRunner {
     }
 
     int32_t forward(int which, int M, const float* x, int64_t ldx, const int64_t* idx, float* y_out, int64_t ld_out, bool train) {
-        if (w.fused) {
+        if (w.fused && which < 2) {
             const float* xs[2] = {x, x};
             const int64_t ldxs[2] = {ldx, ldx};
             float* outs[2] = {y_out, y_out};
@@ -1013,6 +1061,27 @@ struct NetRunner {
         return HGYM_OK;
     }
 
+    // Auxiliary (denoising) head, HgymNetConfig::aux_*: forward on the gathered observation rows, MSE against the target
+    // columns of the gathered privileged rows, backward.  Leaves its weight gradients in the split-K slabs and its bias
+    // gradients in net.grads; the caller's slab reduction finishes them together with everything else.
+    int32_t aux_grad(const HgymPPOConfig& ppo, const HgymBatch& b) {
+        const NetLayout& n = w.net[2];
+        const LayerLayout& last = n.layer[n.L - 1];
+        const int B = b.B, No = last.N;
+        float* y = at<float>(n.out_f32);
+        if (hipMemsetAsync(net.grads + w.aux_p0, 0, (size_t)(w.P - w.aux_p0) * sizeof(float), s) != hipSuccess)
+            HG_FAIL(HGYM_E_LAUNCH, "memset of the auxiliary gradients failed");
+        int32_t rc = forward(2, B, b.obs, cfg.num_obs, b.idx, y, No, true);
+        if (rc) return rc;
+        const int Bp = (int)round_up(B, w.SE);
+        hipLaunchKernelGGL((aux_mse_kernel<T>), dim3(ceil_div(Bp, 256)), dim3(256), 0, s, B, Bp, No, y, b.priv, (int64_t)cfg.num_priv,
+                           cfg.aux_target_offset, b.idx, ppo.aux_coef, at<T>(last.dY), (int64_t)last.Ncp, at<T>(last.dYT), w.Mp,
+                           net.opt_state);
+        HG_CHECK_LAUNCH("aux_mse_kernel");
+        cur_Mp = Bp;
+        return backward(2, B);
+    }
+
     int32_t grad(const HgymPPOConfig& ppo, const HgymBatch& b) {
         const int B = b.B, A = cfg.num_actions;
         HG_REQUIRE(B > 0 && B <= w.maxM, HGYM_E_SHAPE, "minibatch %d exceeds max_batch %lld", B, (long long)w.maxM);
@@ -1060,6 +1129,10 @@ struct NetRunner {
         if (rc) return rc;
         rc = backward(1, B);
         if (rc) return rc;
+        if (w.nnets > 2) {
+            rc = aux_grad(ppo, b);
+            if (rc) return rc;
+        }
         const SegTable tab = segments(true);
         hipLaunchKernelGGL(reduce_slabs_kernel, dim3(96, tab.n), dim3(256), 0, s, tab, w.Ps, at<float>(w.slabs), net.grads, net.opt_state);
         HG_CHECK_LAUNCH("reduce_slabs_kernel");
@@ -1140,9 +1213,9 @@ int32_t hgym_mlp_forward(const HgymNetConfig* cfg, const HgymNet* net, int32_t w
     WsLayout w;
     const int32_t rc = check_net(cfg, net, &w);
     if (rc) return rc;
-    HG_REQUIRE(which == 0 || which == 1, HGYM_E_BADARG, "which=%d", which);
+    HG_REQUIRE(which == 0 || which == 1 || (which == 2 && cfg->aux_layers > 0), HGYM_E_BADARG, "which=%d", which);
     HG_REQUIRE(x && y, HGYM_E_BADARG, "null x / y");
-    const int nout = which == 0 ? cfg->num_actions : 1;
+    const int nout = which == 0 ? cfg->num_actions : (which == 1 ? 1 : cfg->aux_dims[cfg->aux_layers]);
     HG_DISPATCH(cfg, net, w, stream, forward(which, M, x, ldx, nullptr, y, nout, false));
 }
 

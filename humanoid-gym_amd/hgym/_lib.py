@@ -89,7 +89,8 @@ class NetConfig(C.Structure):
     _fields_ = [("num_obs", C.c_int32), ("num_priv", C.c_int32), ("num_actions", C.c_int32),
                 ("actor_layers", C.c_int32), ("critic_layers", C.c_int32),
                 ("actor_dims", C.c_int32 * (MAX_LAYERS + 1)), ("critic_dims", C.c_int32 * (MAX_LAYERS + 1)),
-                ("precision", C.c_int32), ("max_batch", C.c_int32)]
+                ("precision", C.c_int32), ("max_batch", C.c_int32),
+                ("aux_layers", C.c_int32), ("aux_dims", C.c_int32 * (MAX_LAYERS + 1)), ("aux_target_offset", C.c_int32)]
 
 
 class PPOConfig(C.Structure):
@@ -97,7 +98,7 @@ class PPOConfig(C.Structure):
                 ("max_grad_norm", C.c_float), ("desired_kl", C.c_float),
                 ("beta1", C.c_float), ("beta2", C.c_float), ("adam_eps", C.c_float),
                 ("lr_min", C.c_double), ("lr_max", C.c_double), ("adaptive_lr", C.c_int32), ("world_size", C.c_int32),
-                ("grad_norm_ready", C.c_int32)]
+                ("aux_coef", C.c_float), ("grad_norm_ready", C.c_int32)]
 
 
 class Net(C.Structure):

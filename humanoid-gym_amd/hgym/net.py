@@ -6,7 +6,10 @@ import torch
 from . import _lib as L
 
 
-def make_net_config(num_obs, num_priv, num_actions, actor_hidden, critic_hidden, precision, max_batch):
+def make_net_config(num_obs, num_priv, num_actions, actor_hidden, critic_hidden, precision, max_batch, aux_hidden=None, aux_out=0,
+                    aux_target_offset=0):
+    """aux_hidden / aux_out / aux_target_offset: the optional auxiliary (denoising) head obs -> aux_hidden -> aux_out that regresses
+    columns [aux_target_offset, aux_target_offset + aux_out) of the privileged row (HgymNetConfig.aux_*)."""
     c = L.NetConfig()
     c.num_obs, c.num_priv, c.num_actions = int(num_obs), int(num_priv), int(num_actions)
     ad = [num_obs] + list(actor_hidden) + [num_actions]
@@ -18,11 +21,17 @@ def make_net_config(num_obs, num_priv, num_actions, actor_hidden, critic_hidden,
         c.critic_dims[i] = int(d)
     c.precision = {"f32": L.F32, "fp32": L.F32, "bf16": L.BF16}[precision] if isinstance(precision, str) else int(precision)
     c.max_batch = int(max_batch)
+    if aux_hidden is not None and aux_out > 0:
+        xd = [num_obs] + list(aux_hidden) + [int(aux_out)]
+        c.aux_layers = len(xd) - 1
+        for i, d in enumerate(xd):
+            c.aux_dims[i] = int(d)
+        c.aux_target_offset = int(aux_target_offset)
     return c
 
 
 def make_ppo_config(clip_param=0.2, value_loss_coef=1.0, entropy_coef=0.001, max_grad_norm=1.0, desired_kl=0.01,
-                    adaptive=True, world_size=1, grad_norm_ready=False):
+                    adaptive=True, world_size=1, grad_norm_ready=False, aux_coef=0.0):
     p = L.PPOConfig()
     p.clip_param, p.value_loss_coef, p.entropy_coef = clip_param, value_loss_coef, entropy_coef
     p.max_grad_norm, p.desired_kl = max_grad_norm, desired_kl
@@ -30,6 +39,7 @@ def make_ppo_config(clip_param=0.2, value_loss_coef=1.0, entropy_coef=0.001, max
     p.lr_min, p.lr_max = 1e-5, 1e-2
     p.adaptive_lr = 1 if adaptive else 0
     p.world_size = int(world_size)
+    p.aux_coef = float(aux_coef)
     p.grad_norm_ready = 1 if (grad_norm_ready and int(world_size) == 1) else 0    # see HgymPPOConfig
     return p
 
@@ -61,7 +71,10 @@ class NetBuffers:
         A = cfg.num_actions
         self.views["std"] = self.params[:A]
         off = A
-        for name, dims, n in (("actor", cfg.actor_dims, cfg.actor_layers), ("critic", cfg.critic_dims, cfg.critic_layers)):
+        nets = [("actor", cfg.actor_dims, cfg.actor_layers), ("critic", cfg.critic_dims, cfg.critic_layers)]
+        if cfg.aux_layers > 0:
+            nets.append(("denoiser", cfg.aux_dims, cfg.aux_layers))
+        for name, dims, n in nets:
             for l in range(n):
                 k, o = dims[l], dims[l + 1]
                 self.views["%s.%d.weight" % (name, 2 * l)] = self.params[off:off + o * k].view(o, k)
@@ -93,7 +106,8 @@ class NetBuffers:
 
     def forward(self, which, x):
         M = x.shape[0]
-        y = torch.empty(M, self.cfg.num_actions if which == 0 else 1, device=self.device)
+        nout = self.cfg.num_actions if which == 0 else (1 if which == 1 else self.cfg.aux_dims[self.cfg.aux_layers])
+        y = torch.empty(M, nout, device=self.device)
         L.check(L.lib.hgym_mlp_forward(C.byref(self.cfg), C.byref(self.struct), which, M, L.fptr(x), x.stride(0), L.fptr(y),
                                        self.stream()), "hgym_mlp_forward")
         return y

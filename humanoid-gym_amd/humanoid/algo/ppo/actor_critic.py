@@ -26,7 +26,12 @@ def _mlp(sizes, activation):
 
 class ActorCritic(nn.Module):
     def __init__(self, num_actor_obs, num_critic_obs, num_actions, actor_hidden_dims=[256, 256, 256],
-                 critic_hidden_dims=[256, 256, 256], init_noise_std=1.0, activation=nn.ELU(), **kwargs):
+                 critic_hidden_dims=[256, 256, 256], init_noise_std=1.0, activation=nn.ELU(), denoiser_hidden_dims=None,
+                 denoiser_targets=0, **kwargs):
+        """denoiser_hidden_dims / denoiser_targets (native extension, BASELINE configs[4]): an auxiliary head
+        obs -> denoiser_hidden_dims -> denoiser_targets that regresses the newest `denoiser_targets` columns of the
+        privileged observation (the clean single-frame privileged state) from the noisy observation history; trained jointly
+        with PPO (PPO(denoise_coef=...)).  The reference has no code for it (README.md:113); off by default."""
         if kwargs:
             print("ActorCritic.__init__ got unexpected arguments, which will be ignored: " + str(list(kwargs.keys())))
         super().__init__()
@@ -36,6 +41,10 @@ class ActorCritic(nn.Module):
         self.actor_hidden_dims, self.critic_hidden_dims = list(actor_hidden_dims), list(critic_hidden_dims)
         self.actor = _mlp([num_actor_obs] + self.actor_hidden_dims + [num_actions], activation)
         self.critic = _mlp([num_critic_obs] + self.critic_hidden_dims + [1], activation)
+        self.denoiser_hidden_dims = list(denoiser_hidden_dims) if denoiser_hidden_dims else None
+        self.denoiser_targets = int(denoiser_targets) if self.denoiser_hidden_dims else 0
+        if self.denoiser_hidden_dims:
+            self.denoiser = _mlp([num_actor_obs] + self.denoiser_hidden_dims + [self.denoiser_targets], activation)
         print(f"Actor MLP: {self.actor}")
         print(f"Critic MLP: {self.critic}")
         self.std = nn.Parameter(init_noise_std * torch.ones(num_actions))
@@ -126,3 +135,11 @@ class ActorCritic(nn.Module):
 
     def evaluate(self, critic_observations, **kwargs):
         return self._need_net().forward(1, critic_observations.contiguous())
+
+    def denoise(self, observations):
+        """The auxiliary head's estimate of the clean privileged frame from the (noisy) observation history."""
+        if not self.denoiser_hidden_dims:
+            raise RuntimeError("this ActorCritic was built without a denoiser head (denoiser_hidden_dims)")
+        if self._net is not None and observations.is_cuda:
+            return self._net.forward(2, observations.contiguous())
+        return self.denoiser(observations)

@@ -237,6 +237,8 @@ class OnPolicyRunner:
         scal("Loss/value_function", locs["mean_value_loss"], locs["it"])
         scal("Loss/surrogate", locs["mean_surrogate_loss"], locs["it"])
         scal("Loss/learning_rate", self.alg.learning_rate, locs["it"])
+        if getattr(self.alg, "denoise_coef", 0.0) and getattr(self.alg, "last_denoise_loss", None) is not None:
+            scal("Loss/denoise_mse", self.alg.last_denoise_loss, locs["it"])
         scal("Policy/mean_noise_std", mean_std, locs["it"])
         scal("Perf/total_fps", fps, locs["it"])
         scal("Perf/collection time", locs["collection_time"], locs["it"])

@@ -64,7 +64,7 @@ class PPO:
 
     def __init__(self, actor_critic, num_learning_epochs=1, num_mini_batches=1, clip_param=0.2, gamma=0.998, lam=0.95,
                  value_loss_coef=1.0, entropy_coef=0.0, learning_rate=1e-3, max_grad_norm=1.0, use_clipped_value_loss=True,
-                 schedule="fixed", desired_kl=0.01, device="cpu"):
+                 schedule="fixed", desired_kl=0.01, device="cpu", denoise_coef=0.0):
         if not (str(device).startswith("cuda") and torch.cuda.is_available()):
             raise RuntimeError("PPO runs on the MI355X hot path only (device=%r); there is no CPU training path" % (device,))
         if not use_clipped_value_loss:
@@ -84,6 +84,7 @@ class PPO:
         self.gamma, self.lam = gamma, lam
         self.max_grad_norm = max_grad_norm
         self.use_clipped_value_loss = use_clipped_value_loss
+        self.denoise_coef = float(denoise_coef)     # weight of the ActorCritic denoiser head's MSE (0: head absent / not trained)
         # True while a runner has the env store the scalar columns and bump the sampling step itself (transition_sink)
         self.env_stores_transitions = False
         self._world = 1
@@ -107,8 +108,10 @@ class PPO:
         self.storage = RolloutStorage(num_envs, num_transitions_per_env, actor_obs_shape, critic_obs_shape, action_shape, self.device)
         ac = self.actor_critic
         mb = (num_envs * num_transitions_per_env) // self.num_mini_batches
+        aux = getattr(ac, "denoiser_hidden_dims", None)
         cfg = hgym.make_net_config(ac.num_actor_obs, ac.num_critic_obs, ac.num_actions, ac.actor_hidden_dims, ac.critic_hidden_dims,
-                                   self.precision, max(mb, num_envs))
+                                   self.precision, max(mb, num_envs), aux_hidden=aux, aux_out=getattr(ac, "denoiser_targets", 0),
+                                   aux_target_offset=ac.num_critic_obs - getattr(ac, "denoiser_targets", 0))
         self.net = hgym.NetBuffers(cfg, self.device, learning_rate=self._lr0)
         dist_utils.broadcast_parameters(ac.parameters())   # identical initial parameters on every rank
         ac.bind(self.net)
@@ -116,7 +119,9 @@ class PPO:
                                              self.desired_kl if self.desired_kl is not None else 0.0,
                                              adaptive=(self.desired_kl is not None and self.schedule == "adaptive"),
                                              world_size=self._world,
-                                             grad_norm_ready=True)   # update() applies exactly what hgym_ppo_grad produced
+                                             grad_norm_ready=True,   # update() applies exactly what hgym_ppo_grad produced
+                                             aux_coef=self.denoise_coef if aux else 0.0)
+        self.last_denoise_loss = None
         self._sample_step = torch.zeros(1, dtype=torch.int64, device=self.device)
         ac._sample_step = self._sample_step
         ac._sample_seed = 0x5EED + 7919 * self._rank
@@ -194,6 +199,8 @@ class PPO:
                 st.actions_log_prob.view(-1), fl(st.mu), fl(st.sigma))
         net.opt_state[2:6] = 0.0
         net.opt_state[7] = 0.0
+        if self._ppo_cfg.aux_coef > 0.0:
+            net.opt_state[10] = 0.0
         for _ in range(self.num_learning_epochs):
             for i in range(self.num_mini_batches):
                 idx = perm[i * mb:(i + 1) * mb]
@@ -205,4 +212,5 @@ class PPO:
             return None, None
         o = net.opt_state.cpu()                # the one host read-back of the update
         n = max(float(o[7]), 1.0)
+        self.last_denoise_loss = float(o[10]) / n if self._ppo_cfg.aux_coef > 0.0 else None
         return float(o[4]) / n, float(o[3]) / n

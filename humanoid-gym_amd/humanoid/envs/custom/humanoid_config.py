@@ -54,3 +54,11 @@ class XBotLCfgPPO(_P):
                    num_mini_batches=4)
     runner = ns("runner", policy_class_name="ActorCritic", algorithm_class_name="PPO", num_steps_per_env=60, max_iterations=3001,
                 save_interval=100, experiment_name="XBot_ppo", run_name="", resume=False, load_run=-1, checkpoint=-1, resume_path=None)
+
+
+class XBotLDWLCfgPPO(XBotLCfgPPO):
+    """XBot-L PPO with the denoising auxiliary head trained jointly (BASELINE.json configs[4]; the reference only announces it,
+    README.md:113 -- hyper-parameters are this repo's: head as wide as the actor, unit loss weight, 73 = one privileged frame)."""
+    policy = ns("policy", XBotLCfgPPO.policy, denoiser_hidden_dims=[512, 256, 128], denoiser_targets=_SINGLE_PRIV)
+    algorithm = ns("algorithm", XBotLCfgPPO.algorithm, denoise_coef=1.0)
+    runner = ns("runner", XBotLCfgPPO.runner, experiment_name="XBot_dwl_ppo")

@@ -253,6 +253,14 @@ typedef struct HgymNetConfig {
     int32_t critic_dims[HGYM_MAX_LAYERS + 1];            /* 219,768,256,128,1  */
     int32_t precision;                                   /* HGYM_F32 (parity) or HGYM_BF16 (MFMA fast path) */
     int32_t max_batch;                                   /* largest M any call will use */
+    /* Optional auxiliary head trained jointly with PPO (BASELINE configs[4], SURVEY.md 8f item 4: the denoising world-model
+     * head -- NO reference code exists for it; design: DESIGN.md section 9).  An MLP obs -> aux_dims[1..] (ELU between) that
+     * regresses columns [aux_target_offset, aux_target_offset + aux_dims[aux_layers]) of the privileged observation row
+     * with a mean-squared error weighted by HgymPPOConfig.aux_coef.  aux_layers = 0: absent.  Its parameters follow the
+     * critic's in the flat vector ("denoiser.{0,2,..}.{weight,bias}"); hgym_mlp_forward(which = 2) evaluates it. */
+    int32_t aux_layers;
+    int32_t aux_dims[HGYM_MAX_LAYERS + 1];               /* aux_dims[0] = num_obs */
+    int32_t aux_target_offset;
 } HgymNetConfig;
 
 typedef struct HgymPPOConfig {
@@ -262,6 +270,7 @@ typedef struct HgymPPOConfig {
     int32_t adaptive_lr;            /* schedule == 'adaptive' */
     int32_t world_size;             /* >1: between hgym_ppo_grad and hgym_ppo_apply the caller all-reduces (SUM) the P+1 floats of
                                        net->grads across ranks; apply forms the means (gradient and KL) itself */
+    float aux_coef;                 /* weight of the auxiliary head's MSE in the total loss (0 with aux_layers = 0) */
     int32_t grad_norm_ready;        /* 1: net->grads is exactly what the preceding hgym_ppo_grad left (one rank, nothing touched it),
                                        so its squared norm is already in opt_state[9] and apply skips its own pass over the
                                        gradient; 0 (or world_size > 1): apply computes the norm itself */
@@ -278,7 +287,7 @@ int64_t hgym_net_workspace_bytes(const HgymNetConfig* net);
  * [2] sum of minibatch mean KL  [3] sum of surrogate losses  [4] sum of value losses  [5] sum of mean entropies
  * [6] gradient norm of the last step (before clipping)  [7] minibatches accumulated in [2..5]
  * [8] mean KL of the last minibatch (average it across ranks before hgym_ppo_apply when world_size > 1)
- * [9..15] internal.
+ * [9] internal  [10] sum of the auxiliary head's minibatch MSE losses  [11..15] internal.
  * workspace: hgym_net_workspace_bytes() bytes, 256-byte aligned, ZERO-FILLED once by the caller before first use
  * (padding rows/columns of the operand buffers rely on it). */
 typedef struct HgymNet {

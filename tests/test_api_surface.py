@@ -20,9 +20,10 @@ def test_import_paths_and_exports():
     assert list(inspect.signature(OnPolicyRunner.__init__).parameters)[1:] == ["env", "train_cfg", "log_dir", "device"]
     assert list(inspect.signature(RolloutStorage.__init__).parameters)[1:] == [
         "num_envs", "num_transitions_per_env", "obs_shape", "privileged_obs_shape", "actions_shape", "device"]
+    # the reference's positional/keyword order, then this repo's keyword-only-in-practice extension (denoising head weight)
     assert list(inspect.signature(PPO.__init__).parameters)[1:] == [
         "actor_critic", "num_learning_epochs", "num_mini_batches", "clip_param", "gamma", "lam", "value_loss_coef", "entropy_coef",
-        "learning_rate", "max_grad_norm", "use_clipped_value_loss", "schedule", "desired_kl", "device"]
+        "learning_rate", "max_grad_norm", "use_clipped_value_loss", "schedule", "desired_kl", "device", "denoise_coef"]
     for m in ("step", "reset", "get_observations", "get_privileged_observations"):
         assert hasattr(LeggedRobot, m)
     for m in ("act", "process_env_step", "compute_returns", "update", "init_storage", "test_mode", "train_mode"):
