@@ -69,6 +69,31 @@ def uniform(lo, hi, u):
     return (hi - lo) * u + lo
 
 
+def quat_apply_yaw(q, v):
+    """utils/math.py:39-43: rotate (N,P,3) points by the yaw part of q (N,4) -- x,y zeroed, renormalised."""
+    qy = q.clone()
+    qy[:, :2] = 0.0
+    qy = qy / qy.norm(p=2, dim=-1).clamp(min=1e-9).unsqueeze(-1)
+    n, p = v.shape[0], v.shape[1]
+    return quat_apply(qy.repeat(1, p).view(-1, 4), v.reshape(-1, 3)).view(n, p, 3)
+
+
+class TerrainSpec:
+    """What the env needs of a terrain map (utils/terrain.py) when cfg.terrain.mesh_type is heightfield / trimesh."""
+
+    def __init__(self, origins, levels, types, env_length, curriculum, height_samples=None, height_points=None,
+                 border_size=0.0, horizontal_scale=0.1, vertical_scale=0.005):
+        self.origins = origins.float()                 # (rows, cols, 3)  legged_robot.py:696
+        self.levels = levels.clone().long()            # (N,)             :693
+        self.types = types.clone().long()              # (N,)             :694
+        self.max_level = origins.shape[0]              # :695
+        self.env_length = env_length                   # Terrain.env_length
+        self.curriculum = bool(curriculum)
+        self.height_samples = height_samples           # (tot_rows, tot_cols) int16, :586
+        self.height_points = height_points             # (P, 3) base-frame sample points (z = 0), :743-759
+        self.border_size, self.hscale, self.vscale = border_size, horizontal_scale, vertical_scale
+
+
 # ----------------------------------------------------------------------------------------------
 class SimState:
     """The four sim tensors of legged_robot.py:449-457, kept separately (dof state split in pos/vel)."""
@@ -105,13 +130,19 @@ class XBotEnvOracle:
     """State record + the per-step functions.  All tensors are (N, k) fp32 unless noted."""
 
     def __init__(self, n, frictions=None, body_mass=None, frame_stack=C.FRAME_STACK,
-                 c_frame_stack=C.C_FRAME_STACK, use_ref_actions=False):
+                 c_frame_stack=C.C_FRAME_STACK, use_ref_actions=False, terrain=None, command_curriculum=False, max_curriculum=1.0):
         self.n = n
         self.use_ref_actions = bool(use_ref_actions)      # cfg.env.use_ref_actions, humanoid_config.py:49 (False for XBot-L)
+        # generic LeggedRobot options XBot-L leaves off (SURVEY.md 8f item 3)
+        self.terrain = terrain                            # TerrainSpec or None (plane)
+        self.command_curriculum = bool(command_curriculum)   # cfg.commands.curriculum, legged_robot.py:179-180,422-431
+        self.max_curriculum = max_curriculum
+        self.cmd_range_x = [C.CMD_LIN_VEL_X[0], C.CMD_LIN_VEL_X[1]]   # python doubles, moved by the command curriculum
+        self.measured_heights = None
         self.H = frame_stack
         self.Hc = c_frame_stack
         self.sim = SimState(n)
-        self.env_origins = grid_origins(n)
+        self.env_origins = grid_origins(n) if terrain is None else terrain.origins[terrain.levels, terrain.types].clone()   # :697
         self.base_init = torch.tensor(C.BASE_INIT_STATE)
         self.friction = torch.ones(n, 1) if frictions is None else frictions.clone().view(n, 1)
         self.body_mass = torch.full((n, 1), 15.0) if body_mass is None else body_mass.clone().view(n, 1)
@@ -221,7 +252,7 @@ class XBotEnvOracle:
     def _resample_commands(self, mask, u3):
         """legged_robot.py:322-336 for envs where mask; u3 (N,3) = draws for x, y, heading."""
         m = mask
-        cx = uniform(C.CMD_LIN_VEL_X[0], C.CMD_LIN_VEL_X[1], u3[:, 0])
+        cx = uniform(self.cmd_range_x[0], self.cmd_range_x[1], u3[:, 0])
         cy = uniform(C.CMD_LIN_VEL_Y[0], C.CMD_LIN_VEL_Y[1], u3[:, 1])
         ch = uniform(C.CMD_HEADING[0], C.CMD_HEADING[1], u3[:, 2])
         self.commands[:, 0] = torch.where(m, cx, self.commands[:, 0])
@@ -335,16 +366,60 @@ class XBotEnvOracle:
         return (torch.exp(-torch.abs(d_min) * 100) + torch.exp(-torch.abs(d_max) * 100)) / 2
 
     # ------------------------------------------------------------------ reset (E10)
-    def _reset_masked(self, m, u_dof, u_cmd):
-        """legged_robot.py:163-215 + humanoid_env.py:264-269 for envs where m (bool N)."""
+    # ------------------------------------------------------------------ curricula / heights
+    def _update_terrain_curriculum(self, m, r_level):
+        """legged_robot.py:400-420 for envs where m; r_level (N,) int64 = the randint_like draw in [0, max_level)."""
+        t = self.terrain
+        s = self.sim
+        distance = torch.norm(s.root[:, :2] - self.env_origins[:, :2], dim=1)
+        move_up = distance > t.env_length / 2
+        move_down = (distance < torch.norm(self.commands[:, :2], dim=1) * C.EPISODE_LENGTH_S * 0.5) * ~move_up
+        lv = t.levels + (1 * move_up - 1 * move_down)
+        lv = torch.where(lv >= t.max_level, r_level, torch.clip(lv, 0))
+        t.levels = torch.where(m, lv, t.levels)
+        self.env_origins = torch.where(m.unsqueeze(1), t.origins[t.levels, t.types], self.env_origins)
+
+    def _update_command_curriculum(self, m):
+        """legged_robot.py:422-431: widen lin_vel_x by 0.5 each way (capped) when the resetting envs tracked well."""
+        k = C.REWARD_NAMES.index("tracking_lin_vel")
+        mean_sum = self.episode_sums[m, k].mean()
+        if bool(mean_sum / float(C.MAX_EPISODE_LENGTH) > 0.8 * C.REWARD_SCALES_DT[k]):     # fp32 tensor against python doubles
+            lo = min(max(self.cmd_range_x[0] - 0.5, -self.max_curriculum), 0.0)
+            hi = min(max(self.cmd_range_x[1] + 0.5, 0.0), self.max_curriculum)
+            self.cmd_range_x = [lo, hi]
+            return True
+        return False
+
+    def _get_heights(self):
+        """legged_robot.py:761-795: min of three neighbouring height samples under each yaw-rotated sample point."""
+        t = self.terrain
+        s = self.sim
+        pts = quat_apply_yaw(s.root[:, 3:7], t.height_points.unsqueeze(0).repeat(self.n, 1, 1)) + s.root[:, :3].unsqueeze(1)
+        pts = pts + t.border_size
+        pts = (pts / t.hscale).long()
+        px = torch.clip(pts[:, :, 0].reshape(-1), 0, t.height_samples.shape[0] - 2)
+        py = torch.clip(pts[:, :, 1].reshape(-1), 0, t.height_samples.shape[1] - 2)
+        h = torch.min(torch.min(t.height_samples[px, py], t.height_samples[px + 1, py]), t.height_samples[px, py + 1])
+        return h.view(self.n, -1) * t.vscale
+
+    def _reset_masked(self, m, u_dof, u_cmd, u_xy=None, r_level=None):
+        """legged_robot.py:163-215 + humanoid_env.py:264-269 for envs where m (bool N).
+        u_xy (N,2): spawn jitter draws of custom origins (:385); r_level (N,): see _update_terrain_curriculum."""
         if not bool(m.any()):
             return False
         s = self.sim
         mc = m.unsqueeze(1)
+        if self.terrain is not None and self.terrain.curriculum:
+            self._update_terrain_curriculum(m, r_level)
+        self.curriculum_moved = False
+        if self.command_curriculum and self.common_step_counter % C.MAX_EPISODE_LENGTH == 0:
+            self.curriculum_moved = self._update_command_curriculum(m)
         s.dof_pos[:] = torch.where(mc, self.default_dof_pos + uniform(-0.1, 0.1, u_dof), s.dof_pos)
         s.dof_vel[:] = torch.where(mc, torch.zeros_like(s.dof_vel), s.dof_vel)
         init = self.base_init.unsqueeze(0).repeat(self.n, 1)
         init[:, :3] += self.env_origins
+        if self.terrain is not None:                      # custom origins: within 1 m of the tile centre (:382-385)
+            init[:, :2] += uniform(-1.0, 1.0, u_xy)
         s.root[:] = torch.where(mc, init, s.root)
         self._resample_commands(m, u_cmd)
         for name in ("last_last_actions", "actions", "last_actions", "last_dof_vel", "feet_air_time"):
@@ -394,11 +469,12 @@ class XBotEnvOracle:
         return frame_noisy, priv
 
     # ------------------------------------------------------------------ post-physics (E4-E12)
-    def post_physics(self, u_cmd, u_dof, u_push, z_obs):
+    def post_physics(self, u_cmd, u_dof, u_push, z_obs, u_xy=None, r_level=None):
         """legged_robot.py:119-151 + the clip of :105-108.
 
         u_cmd (N,6): [0:3] draws of the callback resample, [3:6] draws of the reset resample;
-        u_dof (N,12): reset joint offsets; u_push (N,5): push lin xy + ang xyz; z_obs (N,47)."""
+        u_dof (N,12): reset joint offsets; u_push (N,5): push lin xy + ang xyz; z_obs (N,47);
+        u_xy (N,2), r_level (N,): only with a terrain map (see _reset_masked)."""
         s = self.sim
         self.ep_len = self.ep_len + 1
         self.common_step_counter += 1
@@ -415,6 +491,8 @@ class XBotEnvOracle:
         ang = ang % TWO_PI                                   # utils/math.py:46-49 wrap_to_pi
         ang = ang - TWO_PI * (ang > math.pi)
         self.commands[:, 2] = torch.clip(0.5 * ang, -1.0, 1.0)
+        if self.terrain is not None and self.terrain.height_samples is not None:
+            self.measured_heights = self._get_heights()      # :316-317
         pushed = self.common_step_counter % C.PUSH_INTERVAL == 0
         if pushed:                                           # humanoid_env.py:83-98
             self.push_force[:, :2] = uniform(-C.MAX_PUSH_VEL_XY, C.MAX_PUSH_VEL_XY, u_push[:, 0:2])
@@ -436,7 +514,7 @@ class XBotEnvOracle:
             self.episode_sums[:, k] += term
             self.reward_terms[:, k] = term
         self.rew = torch.clip(self.rew, min=0.0)
-        any_reset = self._reset_masked(self.reset.clone(), u_dof, u_cmd[:, 3:6])
+        any_reset = self._reset_masked(self.reset.clone(), u_dof, u_cmd[:, 3:6], u_xy, r_level)
         frame, priv_frame = self._observe(z_obs)
         self.last_last_actions = self.last_actions.clone()
         self.last_actions = self.actions.clone()
@@ -448,7 +526,7 @@ class XBotEnvOracle:
                                                      frame=frame, priv_frame=priv_frame)
 
     # ------------------------------------------------------------------ construction tail / reset()
-    def prime(self, u_dof, u_cmd3, z_obs):
+    def prime(self, u_dof, u_cmd3, z_obs, u_xy=None, r_level=None):
         """XBotLFreeEnv.__init__ tail, humanoid_env.py:80-81: reset_idx(all) then compute_observations."""
-        self._reset_masked(torch.ones(self.n, dtype=torch.bool), u_dof, u_cmd3)
+        self._reset_masked(torch.ones(self.n, dtype=torch.bool), u_dof, u_cmd3, u_xy, r_level)
         self._observe(z_obs)

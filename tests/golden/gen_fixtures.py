@@ -10,6 +10,8 @@ Needs /root/reference (present only in the build container).  Outputs (all small
                                     actor, a data artefact not source) + its outputs on fixed inputs
   tests/golden/env_trace.npz        XBotLFreeEnv.step over a seeded synthetic sim trace: inputs, every RNG
                                     draw (scattered to full-N tables), outputs, final state
+  tests/golden/env_trace_refact.npz the same with cfg.env.use_ref_actions
+  tests/golden/env_trace_generic.npz  the same on a trimesh terrain map with terrain + command curricula and height measurements
   tests/golden/ppo_update.npz       PPO.act / process_env_step / compute_returns / update on a small net
 The oracle (oracle/*.py) is pinned against these in tests/test_oracle_golden.py; the HIP path is then
 compared against the oracle on the GPU.
@@ -122,14 +124,20 @@ def gen_policy_example():
 
 
 # ------------------------------------------------------------------------------------------------
-def gen_env_trace(R, N=32, S=36, seed=11, use_ref_actions=False, name="env_trace.npz"):
+def gen_env_trace(R, N=32, S=36, seed=11, use_ref_actions=False, name="env_trace.npz", generic=False):
     """use_ref_actions=True records the second trace (env_trace_refact.npz): cfg.env.use_ref_actions, humanoid_env.py:190-191
-    -- `actions += ref_action` IN PLACE on the caller's tensor, before the clip."""
+    -- `actions += ref_action` IN PLACE on the caller's tensor, before the clip.
+    generic=True records the third (env_trace_generic.npz): the LeggedRobot options XBot-L leaves off -- a trimesh terrain map
+    (custom origins with spawn jitter, terrain curriculum, height measurements) and the command curriculum."""
     torch.manual_seed(seed)
+    np.random.seed(seed)
     g = torch.Generator().manual_seed(seed)
     fr = 0.1 + 1.9 * torch.rand(N, 1, generator=g)
     bm = 15.0 + 10.0 * torch.rand(N, 1, generator=g) - 5.0
-    e, cfg = H.make_ref_env(N, frictions=fr, body_mass=bm)
+    if generic:
+        e, cfg = H.make_ref_env(N, frictions=fr, body_mass=bm, terrain=H.TERRAIN_OPTS, command_curriculum=True)
+    else:
+        e, cfg = H.make_ref_env(N, frictions=fr, body_mass=bm)
     cfg.env.use_ref_actions = bool(use_ref_actions)
     ids_log = []
     orig_resample = e._resample_commands
@@ -157,6 +165,8 @@ def gen_env_trace(R, N=32, S=36, seed=11, use_ref_actions=False, name="env_trace
             full[ids] = vals.view(len(ids), width)
         return full
 
+    if generic:
+        levels0, origins0 = e.terrain_levels.clone(), e.env_origins.clone()
     H.RECORDER.enabled = True
     with H.recording_rng():
         H.finish_init(e)
@@ -164,13 +174,24 @@ def gen_env_trace(R, N=32, S=36, seed=11, use_ref_actions=False, name="env_trace
     ids = ids_log[:]
     del ids_log[:]
     assert [k for k, _ in ids] == ["dof", "cmd"]
+    out = {}
+    if generic:                                             # reset_idx order: terrain curriculum, dofs, root states, commands
+        t0 = e.terrain
+        out.update(terrain_origins=npy(e.terrain_origins), terrain_types=npy(e.terrain_types), terrain_levels0=npy(levels0),
+                   height_samples=t0.heightsamples.astype(np.int16), height_points=npy(e.height_points[0]),
+                   terrain_env_length=np.array(t0.env_length), terrain_border=np.array(float(cfg.terrain.border_size)),
+                   terrain_hscale=np.array(cfg.terrain.horizontal_scale), terrain_vscale=np.array(cfg.terrain.vertical_scale),
+                   max_curriculum=np.array(cfg.commands.max_curriculum), env_origins0=npy(origins0))
+        out["prime_r_level"] = npy(take(log, "randint_like"))
     prime_u_dof = take(log, "rand_float")
+    if generic:
+        out["prime_u_xy"] = npy(take(log, "rand_float"))
     prime_u_cmd = torch.cat([take(log, "rand_float") for _ in range(3)], dim=1)
     prime_z_obs = take(log, "randn_like")
     assert not log
-    out = dict(friction=npy(fr), body_mass=npy(bm), prime_u_dof=npy(prime_u_dof), prime_u_cmd=npy(prime_u_cmd),
+    out.update(friction=npy(fr), body_mass=npy(bm), prime_u_dof=npy(prime_u_dof), prime_u_cmd=npy(prime_u_cmd),
                prime_z_obs=npy(prime_z_obs), prime_obs=npy(e.obs_buf), prime_priv=npy(e.privileged_obs_buf),
-               prime_commands=npy(e.commands), prime_dof_pos=npy(e.dof_pos))
+               prime_commands=npy(e.commands), prime_dof_pos=npy(e.dof_pos), prime_root=npy(e.root_states))
 
     # plant episode lengths so that time-outs, command resampling and pushes all fire inside S steps
     ep = torch.randint(0, 2300, (N,), generator=g)
@@ -179,11 +200,31 @@ def gen_env_trace(R, N=32, S=36, seed=11, use_ref_actions=False, name="env_trace
     ep[8] = 0
     e.episode_length_buf = ep.clone()                       # rebinding, as on_policy_runner.py:104-106 does
     e.common_step_counter = 388                             # push fires at step 12
+    if generic:
+        ep[9] = 2389                                        # a time-out at step 12 ...
+        e.episode_length_buf = ep.clone()
+        e.common_step_counter = 2388                        # ... where the command curriculum is examined (2400 % 2400 == 0)
+        k = e.reward_names.index("tracking_lin_vel")
+        e.episode_sums["tracking_lin_vel"][:] = 10.0 * torch.rand(N, generator=g) + 200.0   # "tracked well" by a wide margin: the range widens at step 12
+        out["init_episode_sums"] = npy(torch.stack([e.episode_sums[n] for n in e.reward_names], dim=1))
     out["init_ep_len"] = npy(ep)
-    out["init_common_step_counter"] = 388
+    out["init_common_step_counter"] = int(e.common_step_counter)
 
     frames = [H.synth_sim_state(g, N) for _ in range(S)]
     counter = {"n": 0, "t": 0}
+
+    def place_on_terrain(frame):
+        """Root positions relative to the env's CURRENT origin: far (promotes), near (demotes), in between."""
+        root = frame[0]
+        r = torch.rand(N, generator=g)
+        rad = torch.where(r < 0.35, 4.2 + 2.8 * torch.rand(N, generator=g),
+                          torch.where(r < 0.7, 0.3 * torch.rand(N, generator=g), 1.0 + 2.5 * torch.rand(N, generator=g)))
+        ang = 6.2831853 * torch.rand(N, generator=g)
+        root[:, 0] = e.env_origins[:, 0] + rad * torch.cos(ang)
+        root[:, 1] = e.env_origins[:, 1] + rad * torch.sin(ang)
+        root[:, 2] += e.env_origins[:, 2]
+        extra = torch.rand(N, generator=g) < 0.08            # more falls than the shared frames carry: more curriculum moves
+        frame[2].view(N, H.NUM_BODIES, 3)[extra, 0, 2] = 3.0
 
     def simulate(sim):
         counter["n"] += 1
@@ -194,6 +235,8 @@ def gen_env_trace(R, N=32, S=36, seed=11, use_ref_actions=False, name="env_trace
     keys = ["actions_in", "actions_in_after", "u_delay", "z_act", "u_cmd", "u_dof", "u_push", "z_obs", "root", "dof", "contact", "rigid",
             "frame", "priv_frame", "rew", "reset", "time_out", "commands", "ep_len", "episode_sums", "torques",
             "actions", "any_reset", "pushed", "extras_time_outs", "extras_episode", "root_after", "dof_after"]
+    if generic:
+        keys += ["u_xy", "r_level", "terrain_levels", "env_origins", "measured_heights", "cmd_range_x"]
     rec = {k: [] for k in keys}
     full_steps = [0, 5, 14, 24, S - 1]
     for t in range(S):
@@ -202,6 +245,8 @@ def gen_env_trace(R, N=32, S=36, seed=11, use_ref_actions=False, name="env_trace
         if t % 7 == 3:
             a_in[t % N] *= 40.0                              # exercise the +-18 clip
         a_pass = a_in.clone()                                # the tensor the caller hands over (mutated when use_ref_actions)
+        if generic:
+            place_on_terrain(frames[t])
         with H.recording_rng():
             obs, priv, rew, reset, extras = e.step(a_pass)
         log = H.RECORDER.pop_all()
@@ -219,11 +264,16 @@ def gen_env_trace(R, N=32, S=36, seed=11, use_ref_actions=False, name="env_trace
             u_push[:, 0:2] = take(log, "rand_float")
             u_push[:, 2:5] = take(log, "rand_float")
         u_dof = torch.zeros(N, 12)
+        u_xy, r_level = torch.zeros(N, 2), torch.zeros(N, dtype=torch.long)
         any_reset = bool(reset.any())
         if any_reset:
             kind, r_ids = ids.pop(0)
             assert kind == "dof"
+            if generic:
+                r_level[r_ids] = take(log, "randint_like")
             u_dof = scatter(r_ids, take(log, "rand_float"), 12)
+            if generic:
+                u_xy = scatter(r_ids, take(log, "rand_float"), 2)
             kind, r_ids2 = ids.pop(0)
             assert kind == "cmd" and torch.equal(r_ids, r_ids2)
             u_cmd[:, 3:6] = scatter(r_ids, torch.cat([take(log, "rand_float") for _ in range(3)], dim=1), 3)
@@ -239,6 +289,10 @@ def gen_env_trace(R, N=32, S=36, seed=11, use_ref_actions=False, name="env_trace
                     pushed=torch.tensor(bool(pushed)), extras_time_outs=extras["time_outs"],
                     extras_episode=torch.stack([extras["episode"]["rew_" + k] for k in e.reward_names]),
                     root_after=e.root_states, dof_after=e.dof_state)
+        if generic:
+            vals.update(u_xy=u_xy, r_level=r_level, terrain_levels=e.terrain_levels, env_origins=e.env_origins,
+                        measured_heights=e.measured_heights,
+                        cmd_range_x=torch.tensor([float(v) for v in e.command_ranges["lin_vel_x"]], dtype=torch.float64))
         for k in keys:
             rec[k].append(npy(vals[k]))
         if t in full_steps:
@@ -257,6 +311,10 @@ def gen_env_trace(R, N=32, S=36, seed=11, use_ref_actions=False, name="env_trace
                final_base_euler=npy(e.base_euler_xyz))
     out["use_ref_actions"] = np.array(bool(use_ref_actions))
     np.savez_compressed(os.path.join(HERE, name), **out)
+    if generic:
+        lv = np.concatenate([out["terrain_levels0"][None], out["terrain_levels"]])
+        print("terrain moves: up %d down %d; command range %s -> %s" % (
+            int((np.diff(lv, axis=0) > 0).sum()), int((np.diff(lv, axis=0) < 0).sum()), out["cmd_range_x"][0], out["cmd_range_x"][-1]))
     n_reset = int(out["reset"].sum())
     n_to = int(out["time_out"].sum())
     print("%s N=%d S=%d resets=%d timeouts=%d pushed_steps=%s resample_rows=%d size=%.2f MB" % (
@@ -351,10 +409,14 @@ def gen_ppo_update(R, N=24, T=8, seed=3):
 
 if __name__ == "__main__":
     R = H.load_reference()
+    if "--only-generic" in sys.argv:
+        gen_env_trace(R, N=32, S=20, seed=13, name="env_trace_generic.npz", generic=True)
+        sys.exit(0)
     gen_constants(R)
     if "--constants-only" not in sys.argv:
         gen_gae(R)
         gen_policy_example()
         gen_env_trace(R)
         gen_env_trace(R, N=16, S=16, seed=12, use_ref_actions=True, name="env_trace_refact.npz")
+        gen_env_trace(R, N=32, S=20, seed=13, name="env_trace_generic.npz", generic=True)
         gen_ppo_update(R)

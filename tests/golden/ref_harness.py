@@ -124,12 +124,26 @@ def load_reference():
     gt = sys.modules["isaacgym.gymtorch"]
     gt.unwrap_tensor = lambda t: t
     gt.wrap_tensor = lambda t: t
+    # isaacgym.terrain_utils (closed source, absent): this repo's restatement, loaded by path because the package name
+    # `humanoid` belongs to the reference in this interpreter
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("hgym_terrain_utils", os.path.join(
+        os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "humanoid-gym_amd", "humanoid", "utils", "terrain_utils.py"))
+    mine = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mine)
+    tz = sys.modules["isaacgym.terrain_utils"]
+    for k in dir(mine):
+        if not k.startswith("_") and k != "np":
+            setattr(tz, k, getattr(mine, k))
 
     from humanoid.envs import XBotLCfg, XBotLCfgPPO, XBotLFreeEnv  # noqa: E402
     from humanoid.algo import PPO, ActorCritic, RolloutStorage, OnPolicyRunner  # noqa: E402
     from humanoid.utils.helpers import class_to_dict  # noqa: E402
     import humanoid.envs.custom.humanoid_env as henv  # noqa: E402
 
+    import humanoid.utils.terrain as rterrain  # noqa: E402
+    _LOADED.update(dict(rterrain=rterrain))
     _LOADED.update(dict(XBotLCfg=XBotLCfg, XBotLCfgPPO=XBotLCfgPPO, XBotLFreeEnv=XBotLFreeEnv, PPO=PPO,
                         ActorCritic=ActorCritic, RolloutStorage=RolloutStorage, OnPolicyRunner=OnPolicyRunner,
                         class_to_dict=class_to_dict, henv=henv, tu=tu))
@@ -148,7 +162,7 @@ class _recording_rng:
     (`humanoid_env.py:194,196,251`)."""
 
     def __enter__(self):
-        self._rand, self._randn_like = torch.rand, torch.randn_like
+        self._rand, self._randn_like, self._randint_like = torch.rand, torch.randn_like, torch.randint_like
 
         def rand(*a, **k):
             t = self._rand(*a, **k)
@@ -162,18 +176,37 @@ class _recording_rng:
                 RECORDER.log.append(("randn_like%s" % (tuple(t.shape),), t.detach().clone()))
             return t
 
-        torch.rand, torch.randn_like = rand, randn_like
+        def randint_like(x, *a, **k):
+            t = self._randint_like(x, *a, **k)
+            if RECORDER.enabled:
+                RECORDER.log.append(("randint_like%s" % (tuple(t.shape),), t.detach().clone()))
+            return t
+
+        torch.rand, torch.randn_like, torch.randint_like = rand, randn_like, randint_like
         return self
 
     def __exit__(self, *a):
-        torch.rand, torch.randn_like = self._rand, self._randn_like
+        torch.rand, torch.randn_like, torch.randint_like = self._rand, self._randn_like, self._randint_like
 
 
-def make_ref_env(num_envs, frictions=None, body_mass=None, frame_stack=15, c_frame_stack=3):
-    """Build the reference's XBotLFreeEnv without PhysX."""
+TERRAIN_OPTS = dict(mesh_type="trimesh", curriculum=True, num_rows=4, num_cols=4, border_size=5, max_init_terrain_level=3)
+
+
+def make_ref_env(num_envs, frictions=None, body_mass=None, frame_stack=15, c_frame_stack=3, terrain=None, command_curriculum=False):
+    """Build the reference's XBotLFreeEnv without PhysX.
+
+    terrain: dict of cfg.terrain overrides (e.g. TERRAIN_OPTS) -> the reference's HumanoidTerrain map (tile generators:
+    this repo's terrain_utils), custom origins, terrain curriculum; height measurements are taken with the reference's own
+    `_get_heights` at the point of `_post_physics_step_callback` where legged_robot.py:316-317 takes them, WITHOUT setting
+    cfg.terrain.measure_heights: the XBot observation code for that flag (humanoid_env.py:246-248) concatenates the previous
+    705-wide observation into the privileged frame and cannot run with the configured observation sizes."""
     R = load_reference()
     gt = sys.modules["isaacgym.gymtorch"]
     cfg = R.XBotLCfg()
+    if terrain:
+        for k, v in terrain.items():
+            setattr(cfg.terrain, k, v)
+    cfg.commands.curriculum = bool(command_curriculum)
     cfg.env.num_envs = num_envs
     cfg.env.frame_stack = frame_stack
     cfg.env.c_frame_stack = c_frame_stack
@@ -215,12 +248,17 @@ def make_ref_env(num_envs, frictions=None, body_mass=None, frame_stack=15, c_fra
     e.privileged_obs_buf = torch.zeros(N, e.num_privileged_obs)
     e.extras = {}
     # what _create_envs (legged_robot.py:588-681) would have produced
-    e.env_origins = torch.zeros(N, 3)
-    num_cols = np.floor(np.sqrt(N))
-    num_rows = np.ceil(N / num_cols)
-    xx, yy = torch.meshgrid(torch.arange(num_rows), torch.arange(num_cols), indexing="ij")
-    e.env_origins[:, 0] = cfg.env.env_spacing * xx.flatten()[:N]
-    e.env_origins[:, 1] = cfg.env.env_spacing * yy.flatten()[:N]
+    if terrain:
+        e.terrain = R.rterrain.HumanoidTerrain(cfg.terrain, N)                    # humanoid_env.py:152-153
+        e.height_samples = torch.tensor(e.terrain.heightsamples).view(e.terrain.tot_rows, e.terrain.tot_cols)   # :586
+        e._get_env_origins()                                                      # :683-697 (draws the initial levels)
+    else:
+        e.env_origins = torch.zeros(N, 3)
+        num_cols = np.floor(np.sqrt(N))
+        num_rows = np.ceil(N / num_cols)
+        xx, yy = torch.meshgrid(torch.arange(num_rows), torch.arange(num_cols), indexing="ij")
+        e.env_origins[:, 0] = cfg.env.env_spacing * xx.flatten()[:N]
+        e.env_origins[:, 1] = cfg.env.env_spacing * yy.flatten()[:N]
     st = cfg.init_state
     e.base_init_state = torch.tensor(st.pos + st.rot + st.lin_vel + st.ang_vel, dtype=torch.float)
     e.env_frictions = torch.ones(N, 1) if frictions is None else frictions.clone().view(N, 1)
@@ -244,6 +282,15 @@ def make_ref_env(num_envs, frictions=None, body_mass=None, frame_stack=15, c_fra
     gt.wrap_tensor = lambda t: t
     e._init_buffers()
     e._prepare_reward_function()
+    if terrain:
+        e.height_points = e._init_height_points()                                 # :481-482
+        callback = e._post_physics_step_callback
+
+        def callback_with_heights():
+            callback()
+            e.measured_heights = e._get_heights()                                 # :316-317 (pushes do not move the base pose)
+
+        e._post_physics_step_callback = callback_with_heights
     e.init_done = True
     # XBotLFreeEnv.__init__, humanoid_env.py:78-81
     e.last_feet_z = 0.05

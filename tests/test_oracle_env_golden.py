@@ -103,3 +103,52 @@ def test_constants_match_reference(golden_dir):
     assert (K["learning_rate"], K["desired_kl"], K["max_grad_norm"]) == (C.LEARNING_RATE, C.DESIRED_KL, C.MAX_GRAD_NORM)
     assert K["actor_hidden_dims"] == C.ACTOR_HIDDEN and K["critic_hidden_dims"] == C.CRITIC_HIDDEN
     assert K["num_steps_per_env"] == C.NUM_STEPS_PER_ENV and K["seed"] == C.SEED
+
+
+# ------------------------------------------------------------------------------------------------
+# third trace: the generic LeggedRobot options XBot-L leaves off -- terrain map with custom origins,
+# terrain curriculum, height measurements, command curriculum
+def terrain_spec(G):
+    from oracle.xbot_env_oracle import TerrainSpec
+    return TerrainSpec(T(G["terrain_origins"]), T(G["terrain_levels0"]), T(G["terrain_types"]), float(G["terrain_env_length"]), True,
+                       height_samples=T(G["height_samples"]), height_points=T(G["height_points"]),
+                       border_size=float(G["terrain_border"]), horizontal_scale=float(G["terrain_hscale"]),
+                       vertical_scale=float(G["terrain_vscale"]))
+
+
+def test_generic_trace_matches_reference(golden_dir):
+    G = _load(golden_dir, "env_trace_generic.npz")
+    N = G["friction"].shape[0]
+    o = XBotEnvOracle(N, frictions=T(G["friction"]), body_mass=T(G["body_mass"]), terrain=terrain_spec(G), command_curriculum=True,
+                      max_curriculum=float(G["max_curriculum"]))
+    assert torch.equal(o.env_origins, T(G["env_origins0"]))
+    o.prime(T(G["prime_u_dof"]), T(G["prime_u_cmd"]), T(G["prime_z_obs"]), T(G["prime_u_xy"]), T(G["prime_r_level"]))
+    assert torch.equal(o.obs, T(G["prime_obs"])) and torch.equal(o.priv, T(G["prime_priv"]))
+    assert torch.equal(o.sim.root, T(G["prime_root"]))                  # spawn jitter applied, levels untouched by the first reset
+    assert torch.equal(o.terrain.levels, T(G["terrain_levels0"]))
+    o.ep_len = T(G["init_ep_len"]).clone()
+    o.common_step_counter = int(G["init_common_step_counter"])
+    o.episode_sums = T(G["init_episode_sums"]).clone()
+    ups = downs = redraws = 0
+    for t in range(G["rew"].shape[0]):
+        a = o.pre_physics(T(G["actions_in"][t]).clone(), T(G["u_delay"][t]), T(G["z_act"][t]))
+        o.pd_torques()
+        o.sim.load(T(G["root"][t]), T(G["dof"][t]), T(G["contact"][t]), T(G["rigid"][t]))
+        before = o.terrain.levels.clone()
+        obs, priv, rew, reset, info = o.post_physics(T(G["u_cmd"][t]), T(G["u_dof"][t]), T(G["u_push"][t]), T(G["z_obs"][t]),
+                                                     T(G["u_xy"][t]), T(G["r_level"][t]))
+        assert torch.equal(reset, T(G["reset"][t])), t
+        assert torch.equal(o.terrain.levels, T(G["terrain_levels"][t])), t
+        assert torch.equal(o.env_origins, T(G["env_origins"][t])), t
+        assert torch.equal(o.measured_heights, T(G["measured_heights"][t])), t
+        assert o.cmd_range_x == [float(v) for v in G["cmd_range_x"][t]], t
+        assert torch.equal(o.commands, T(G["commands"][t])), t
+        assert torch.equal(o.sim.root, T(G["root_after"][t])), t
+        assert torch.equal(info["frame"], T(G["frame"][t])) and torch.equal(info["priv_frame"], T(G["priv_frame"][t])), t
+        assert torch.equal(rew, T(G["rew"][t])) and torch.equal(o.episode_sums, T(G["episode_sums"][t])), t
+        d = o.terrain.levels - before
+        ups += int((d > 0).sum()); downs += int((d < 0).sum())
+        redraws += int(((before == o.terrain.max_level - 1) & reset & (o.terrain.levels == T(G["r_level"][t])) & (d <= 0)).sum())
+    assert ups >= 5 and downs >= 5                                          # both curriculum directions exercised
+    assert o.cmd_range_x == [-0.8, 1.0] and [float(v) for v in G["cmd_range_x"][0]] == [-0.3, 0.6]   # the command range widened once
+    assert float(np.abs(G["measured_heights"]).max()) > 0.01                # heights really sampled a non-flat map
