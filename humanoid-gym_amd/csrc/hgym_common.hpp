@@ -102,6 +102,7 @@ enum : uint32_t {
     SLOT_ACT = 2,         // 2..4  : 12 action-noise normals
     SLOT_DOF = 5,         // 5..7  : 12 reset joint offsets
     SLOT_PUSH = 8,        // 8..9  : 5 push draws
+    SLOT_TERRAIN = 10,    // x,y: spawn jitter of custom origins, z: terrain-level redraw
     SLOT_OBS = 16,        // 16..27: 47 observation-noise normals (pairs)
     SLOT_PHYS = 32,       // 32..47: synthetic physics
     SLOT_POLICY = 64      // 64..66: 12 policy-sampling normals

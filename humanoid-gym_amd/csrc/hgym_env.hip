@@ -19,7 +19,7 @@
 
 namespace hgym {
 
-template <int H_T, int HC_T, int E_T>
+template <int H_T, int HC_T, int E_T, bool kGeneric>
 __global__ __launch_bounds__(256) void env_step_kernel(const EnvArgs A) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int64_t csc0 = A.st.counters[0];
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void env_step_kernel(const EnvArgs A) {
     // wavefront 0 runs the per-env scalar chains (one lane per env); the other wavefronts meanwhile move the older frames of
     // the observation history, which depend on nothing this step computes (reset envs are fixed up in phase B)
     if (t < 64) {
-        if (!(A.ablate & 2)) env_step_phase_a<E_T>(A, blockIdx.x, t, smem, csc0);
+        if (!(A.ablate & 2)) env_step_phase_a<E_T, kGeneric>(A, blockIdx.x, t, smem, csc0);
     } else if (kPrefetch) {
         if (stack_on) {
             hist_store<HP, HGYM_OBS_FRAME, NIO>(A.out.obs, geom.e0, geom.nE, (int)(ring_step % HP), t - 64, NTH, nullptr, A.cfg.clip_obs, hist_o);
@@ -70,6 +70,37 @@ __global__ __launch_bounds__(1024) void env_finalize_kernel(const EnvArgs A) {
     __syncthreads();
     env_finalize_store(A, threadIdx.x, blockDim.x);
     if (threadIdx.x == 0) env_finalize_part2(A);
+}
+
+// generic options; neither kernel is launched in the XBot-L default configuration
+__global__ __launch_bounds__(256) void measure_heights_kernel(const EnvArgs A) {
+    const int P = A.cfg.num_height_points;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)A.cfg.num_envs * P) return;
+    const int e = (int)(i / P);
+    measure_height_point(A, e, (int)(i - (int64_t)e * P));
+}
+
+__global__ __launch_bounds__(1024) void command_curriculum_kernel(const EnvArgs A) {
+    __shared__ int due;
+    __shared__ float xr[2];
+    const int64_t csc0 = A.st.counters[0];
+    if (threadIdx.x == 0) {
+        due = command_curriculum_due(A, A.mode == MODE_STEP ? csc0 + 1 : csc0) ? 1 : 0;   // the finaliser has not bumped the counter yet
+        if (due) {
+            double lo, hi;
+            command_curriculum_move(A, A.st.command_range_x[0], A.st.command_range_x[1], lo, hi);
+            A.st.command_range_x[0] = lo;
+            A.st.command_range_x[1] = hi;
+            xr[0] = (float)lo;
+            xr[1] = (float)(hi - lo);
+        }
+    }
+    __syncthreads();
+    if (!due) return;
+    const RngKey rk = make_rng_key(A, csc0);
+    const int64_t ring_step = A.st.counters[2];
+    for (int e = threadIdx.x; e < A.cfg.num_envs; e += blockDim.x) command_curriculum_fix_env(A, rk, e, xr[0], xr[1], ring_step);
 }
 
 __global__ __launch_bounds__(256) void pre_physics_kernel(const EnvArgs A) {
@@ -125,7 +156,22 @@ static int32_t check_common(const HgymEnvConfig* cfg, const HgymSimTensors* sim,
     if (sim) HG_REQUIRE(sim->root.base && sim->dof_pos.base && sim->dof_vel.base && sim->contact.base && sim->rigid.base,
                         HGYM_E_BADARG, "null sim tensor");
     HG_REQUIRE(st->episode_length && st->counters && st->commands && st->actions, HGYM_E_BADARG, "null env state field");
+    if (cfg->terrain_curriculum) {
+        HG_REQUIRE(cfg->custom_origins, HGYM_E_BADARG, "terrain_curriculum needs custom_origins (a height-field / trimesh terrain)");
+        HG_REQUIRE(st->terrain_levels && st->terrain_types && st->terrain_origins && cfg->terrain_rows > 0 && cfg->terrain_cols > 0,
+                   HGYM_E_BADARG, "terrain_curriculum needs terrain_levels / terrain_types / terrain_origins and their shape");
+    }
+    if (cfg->num_height_points > 0)
+        HG_REQUIRE(st->height_samples && st->height_points && st->height_pose && st->measured_heights && cfg->height_rows > 1 &&
+                       cfg->height_cols > 1 && cfg->terrain_hscale > 0.f,
+                   HGYM_E_BADARG, "height measurements need height_samples / height_points / height_pose / measured_heights");
+    if (cfg->command_curriculum) HG_REQUIRE(st->command_range_x, HGYM_E_BADARG, "command_curriculum needs command_range_x");
     return HGYM_OK;
+}
+
+static void launch_measure_heights(const EnvArgs& A, hipStream_t s) {
+    const int64_t total = (int64_t)A.cfg.num_envs * A.cfg.num_height_points;
+    hipLaunchKernelGGL(measure_heights_kernel, dim3((unsigned)ceil_div(total, (int64_t)256)), dim3(256), 0, s, A);
 }
 
 static int32_t launch_step(const HgymEnvConfig* cfg, const HgymSimTensors* sim, const HgymEnvState* st, const HgymEnvOut* out,
@@ -145,6 +191,7 @@ static int32_t launch_step(const HgymEnvConfig* cfg, const HgymSimTensors* sim, 
     A.out = *out;
     if (noise) A.noise = *noise;
     A.actions_in = actions_in;
+    A.origins_hbm = st->env_origins;
     A.mode = mode;
     A.fused = fused;
     A.envs_per_block = pick_envs_per_block(cfg->num_envs);
@@ -161,15 +208,27 @@ static int32_t launch_step(const HgymEnvConfig* cfg, const HgymSimTensors* sim, 
     const size_t lds = step_smem_bytes(A.envs_per_block);
     prof_begin(HGYM_PROF_ENV_STEP, s);
     const bool std_stack = cfg->frame_stack == 15 && cfg->c_frame_stack == 3;
-    if (std_stack && A.envs_per_block == 16)
-        hipLaunchKernelGGL((env_step_kernel<15, 3, 16>), dim3(blocks), dim3(256), lds, s, A);
+    // the generic LeggedRobot options (HgymEnvConfig tail) have their own instantiation: off, none of their code is compiled in
+    const bool generic = cfg->custom_origins || cfg->terrain_curriculum || cfg->num_height_points > 0 || cfg->command_curriculum;
+    if (std_stack && A.envs_per_block == 16 && !generic)
+        hipLaunchKernelGGL((env_step_kernel<15, 3, 16, false>), dim3(blocks), dim3(256), lds, s, A);
+    else if (std_stack && A.envs_per_block == 16)
+        hipLaunchKernelGGL((env_step_kernel<15, 3, 16, true>), dim3(blocks), dim3(256), lds, s, A);
     else
-        hipLaunchKernelGGL((env_step_kernel<0, 0, 0>), dim3(blocks), dim3(256), lds, s, A);
+        hipLaunchKernelGGL((env_step_kernel<0, 0, 0, true>), dim3(blocks), dim3(256), lds, s, A);
     {   // algorithmic bytes per env-step, SURVEY.md §8d: 4*[245 + (H-1)*47 + (Hc-1)*73 + H*47 + Hc*73] + 6
         const double H = cfg->frame_stack, HC = cfg->c_frame_stack;
         prof_end(HGYM_PROF_ENV_STEP, s, (double)cfg->num_envs * (4.0 * (245 + (H - 1) * 47 + (HC - 1) * 73 + H * 47 + HC * 73) + 6));
     }
     HG_CHECK_LAUNCH("env_step_kernel");
+    if (cfg->num_height_points > 0 && mode == MODE_STEP) {
+        launch_measure_heights(A, s);
+        HG_CHECK_LAUNCH("measure_heights_kernel");
+    }
+    if (cfg->command_curriculum && mode != MODE_PRIME) {     // before the finaliser consumes the episode-sum accumulators
+        hipLaunchKernelGGL(command_curriculum_kernel, dim3(1), dim3(cfg->num_envs > 256 ? 1024 : 256), 0, s, A);
+        HG_CHECK_LAUNCH("command_curriculum_kernel");
+    }
     if (!out->defer_finalize) {
         hipLaunchKernelGGL(env_finalize_kernel, dim3(1), dim3(cfg->num_envs > 256 ? 1024 : 256), 0, s, A);
         HG_CHECK_LAUNCH("env_finalize_kernel");
@@ -273,6 +332,19 @@ int32_t hgym_env_step_synth(const HgymEnvConfig* cfg, const HgymSimTensors* sim,
                             float* actions_in, void* stream) {
     HG_REQUIRE(actions_in, HGYM_E_BADARG, "null actions");
     return launch_step(cfg, sim, st, out, nullptr, actions_in, MODE_STEP, 1, (hipStream_t)stream);
+}
+
+int32_t hgym_measure_heights(const HgymEnvConfig* cfg, const HgymEnvState* st, void* stream) {
+    int32_t rc = check_common(cfg, nullptr, st);
+    if (rc) return rc;
+    HG_REQUIRE(cfg->num_height_points > 0, HGYM_E_BADARG, "num_height_points is 0");
+    EnvArgs A;
+    memset(&A, 0, sizeof(A));
+    A.cfg = *cfg;
+    A.st = *st;
+    launch_measure_heights(A, (hipStream_t)stream);
+    HG_CHECK_LAUNCH("measure_heights_kernel");
+    return HGYM_OK;
 }
 
 int32_t hgym_env_finalize(const HgymEnvConfig* cfg, const HgymEnvState* st, const HgymEnvOut* out, void* stream) {

@@ -26,6 +26,7 @@ struct EnvArgs {
     HgymEnvOut out;
     HgymEnvNoise noise;
     float* actions_in;        // (N,12) row-major or null; written only when cfg.use_ref_actions (humanoid_env.py:190-191)
+    float* origins_hbm;       // st.env_origins as the caller gave it (the LDS shadow replaces st.env_origins by its staged copy)
     int mode;
     int fused;                // 1: pre_physics + synthetic physics run inside the step kernel
     int envs_per_block;
@@ -280,8 +281,20 @@ HG_HD void synth_physics_env(const EnvArgs& A, const RngKey& rk, int e, int N) {
 
 // ------------------------------------------------------------------------------------------------ commands
 // legged_robot.py:322-336 for one env; u[3] = draws for x, y, heading
-HG_HD void resample_commands(const HgymEnvConfig& c, float cmd[4], const float u[3]) {
-    cmd[0] = c.cmd_x_span * u[0] + c.cmd_x_lo;
+// lin_vel_x range: the configuration's, or (command curriculum) the live device-resident [lo, hi] python doubles
+template <bool kGeneric>
+HG_HD void cmd_x_range(const EnvArgs& A, float& lo, float& span) {
+    lo = A.cfg.cmd_x_lo;
+    span = A.cfg.cmd_x_span;
+    if (kGeneric && A.cfg.command_curriculum && A.st.command_range_x) {
+        const double l = A.st.command_range_x[0], h = A.st.command_range_x[1];
+        lo = (float)l;
+        span = (float)(h - l);      // torch_rand_float: (hi - lo) in python double, then against the fp32 tensor
+    }
+}
+
+HG_HD void resample_commands(const HgymEnvConfig& c, float x_lo, float x_span, float cmd[4], const float u[3]) {
+    cmd[0] = x_span * u[0] + x_lo;
     cmd[1] = c.cmd_y_span * u[1] + c.cmd_y_lo;
     cmd[3] = c.cmd_h_span * u[2] + c.cmd_h_lo;
     const float keep = (sqrtf(cmd[0] * cmd[0] + cmd[1] * cmd[1]) > 0.2f) ? 1.0f : 0.0f;
@@ -306,6 +319,9 @@ struct StepFlags {
 // (humanoid_env.py:272-540, alphabetical order), mask-driven reset_idx (legged_robot.py:163-215) and the
 // clean observation frames (humanoid_env.py:200-244).  frame47 / priv73 receive the UN-noised new frames
 // (LDS on the device); noise, history stacking and clipping happen in the cooperative phase.
+// kGeneric = false compiles the generic LeggedRobot options (terrain map, curricula, height measurements) OUT: the XBot-L
+// default configuration runs the instantiation that has none of their branches on its per-env latency chain.
+template <bool kGeneric>
 HG_HD StepFlags post_physics_env(const EnvArgs& A, const RngKey& rk, int64_t csc, int e, int N, float* frame47,
                                  float* priv73) {
     const HgymEnvConfig& c = A.cfg;
@@ -352,7 +368,9 @@ HG_HD StepFlags post_physics_env(const EnvArgs& A, const RngKey& rk, int64_t csc
             const float u[3] = {nz_uniform(A.noise.u_cmd, 6, 0, rk, e, ge, SLOT_DELAY_CMD, 1),
                                 nz_uniform(A.noise.u_cmd, 6, 1, rk, e, ge, SLOT_DELAY_CMD, 2),
                                 nz_uniform(A.noise.u_cmd, 6, 2, rk, e, ge, SLOT_DELAY_CMD, 3)};
-            resample_commands(c, cmd, u);
+            float x_lo, x_span;
+            cmd_x_range<kGeneric>(A, x_lo, x_span);
+            resample_commands(c, x_lo, x_span, cmd, u);
         }
         {
             const float fv[3] = {1.0f, 0.0f, 0.0f};
@@ -360,6 +378,10 @@ HG_HD StepFlags post_physics_env(const EnvArgs& A, const RngKey& rk, int64_t csc
             quat_apply(root + 3, fv, fw);
             const float heading = atan2f(fw[1], fw[0]);
             cmd[2] = clampf(0.5f * wrap_like_reference(cmd[3] - heading), -1.0f, 1.0f);
+        }
+        if (kGeneric && c.num_height_points > 0 && S.height_pose) {   // :316-317 samples the terrain HERE, on the pre-reset base pose
+#pragma unroll
+            for (int i = 0; i < 7; ++i) S.height_pose[(int64_t)ge * 7 + i] = root[i];
         }
         if (c.push_robots && (csc % c.push_interval == 0)) {          // humanoid_env.py:83-98
             const float px = c.push_vel_span * nz_uniform(A.noise.u_push, 5, 0, rk, e, ge, SLOT_PUSH, 0) + c.push_vel_lo;
@@ -593,17 +615,47 @@ HG_HD StepFlags post_physics_env(const EnvArgs& A, const RngKey& rk, int64_t csc
             FG(S.last_last_actions, j) = 0.0f;
             FG(S.last_dof_vel, j) = 0.0f;
         }
+        if (kGeneric && c.terrain_curriculum && S.terrain_levels) {
+            // _update_terrain_curriculum legged_robot.py:400-420 (runs in every reset_idx once init_done, i.e. in all three modes):
+            // on the pre-reset base position and the commands this step ends with
+            const float dx = root[0] - FG(S.env_origins, 0), dy = root[1] - FG(S.env_origins, 1);
+            const float distance = sqrtf(dx * dx + dy * dy);
+            const bool up = distance > c.terrain_env_length / 2.0f;
+            const float cn = sqrtf(cmd[0] * cmd[0] + cmd[1] * cmd[1]);
+            const bool down = (distance < cn * c.episode_length_s * 0.5f) && !up;
+            int64_t lv = S.terrain_levels[ge] + (up ? 1 : 0) - (down ? 1 : 0);
+            if (lv >= c.terrain_rows) {      // solved the last level: a random one (torch.randint_like)
+                if (A.noise.r_level) lv = A.noise.r_level[ge];
+                else {
+                    const int r = (int)(uniform_at(rk, (uint32_t)ge, SLOT_TERRAIN, 2) * (float)c.terrain_rows);
+                    lv = r < c.terrain_rows ? r : c.terrain_rows - 1;
+                }
+            } else if (lv < 0) lv = 0;
+            S.terrain_levels[ge] = lv;
+            const float* o = S.terrain_origins + ((int64_t)lv * c.terrain_cols + S.terrain_types[ge]) * 3;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                FG(S.env_origins, i) = o[i];
+                A.origins_hbm[(int64_t)i * c.num_envs + ge] = o[i];      // env_origins is a read-only field of the staged state
+            }
+        }
 #pragma unroll
         for (int i = 0; i < 13; ++i) root[i] = c.base_init_state[i];
 #pragma unroll
         for (int i = 0; i < 3; ++i) root[i] += FG(S.env_origins, i);
+        if (kGeneric && c.custom_origins) {  // xy within 1 m of the tile centre, legged_robot.py:382-385
+            root[0] += 2.0f * (A.noise.u_xy ? A.noise.u_xy[(int64_t)ge * 2 + 0] : uniform_at(rk, (uint32_t)ge, SLOT_TERRAIN, 0)) + -1.0f;
+            root[1] += 2.0f * (A.noise.u_xy ? A.noise.u_xy[(int64_t)ge * 2 + 1] : uniform_at(rk, (uint32_t)ge, SLOT_TERRAIN, 1)) + -1.0f;
+        }
 #pragma unroll
         for (int i = 0; i < 13; ++i) sset(A.sim.root, e, i, root[i]);
         {
             const float u[3] = {nz_uniform(A.noise.u_cmd, 6, 3, rk, e, ge, SLOT_CMD_RESET, 0),
                                 nz_uniform(A.noise.u_cmd, 6, 4, rk, e, ge, SLOT_CMD_RESET, 1),
                                 nz_uniform(A.noise.u_cmd, 6, 5, rk, e, ge, SLOT_CMD_RESET, 2)};
-            resample_commands(c, cmd, u);
+            float x_lo, x_span;
+            cmd_x_range<kGeneric>(A, x_lo, x_span);       // a command-curriculum move this step is applied by command_curriculum_fix
+            resample_commands(c, x_lo, x_span, cmd, u);
         }
         FG(S.feet_air_time, 0) = 0.0f;
         FG(S.feet_air_time, 1) = 0.0f;
@@ -1069,7 +1121,7 @@ HG_HD void env_step_joints(const EnvArgs& A, int block, int t, int nthreads, flo
     }
 }
 
-template <int E_T>
+template <int E_T, bool kGeneric>
 HG_HD void env_step_phase_a(const EnvArgs& A, int block, int t, float* smem, int64_t csc0) {
     const int E = E_T > 0 ? E_T : A.envs_per_block;
     const int N = A.cfg.num_envs, e0 = block * E;
@@ -1082,7 +1134,7 @@ HG_HD void env_step_phase_a(const EnvArgs& A, int block, int t, float* smem, int
     StepFlags fl;
     fl.reset = 0;
     if (!(A.ablate & 32))
-        fl = post_physics_env(S, rk, csc0 + 1, t, E, smem + m.frame + t * HGYM_OBS_FRAME, smem + m.priv + t * HGYM_PRIV_FRAME);
+        fl = post_physics_env<kGeneric>(S, rk, csc0 + 1, t, E, smem + m.frame + t * HGYM_OBS_FRAME, smem + m.priv + t * HGYM_PRIV_FRAME);
     reinterpret_cast<int*>(smem + m.reset_i)[t] = fl.reset;
 }
 
@@ -1104,6 +1156,84 @@ HG_HD void env_stage_out(const EnvArgs& A, int block, int t, int nthreads, float
             A.out.rew[e0 + i] = smem[m.rew + i];
             A.out.time_out[e0 + i] = fl[E + i];
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ generic options
+// LeggedRobot._get_heights (legged_robot.py:761-795) for sample point p of env e: the point, rotated by the yaw part of the
+// base quaternion (utils/math.py:39-43) and shifted to the base position, indexes the int16 height field; the height is the
+// minimum of the cell and its +x / +y neighbours.  Same fp32 operation order as the torch expressions.
+HG_HD void measure_height_point(const EnvArgs& A, int e, int p) {
+    const HgymEnvConfig& c = A.cfg;
+    const float* pose = A.st.height_pose + (int64_t)e * 7;
+    float q[4] = {0.0f, 0.0f, pose[5], pose[6]};
+    float n = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    n = n < 1e-9f ? 1e-9f : n;                                // isaacgym.torch_utils.normalize: x / norm.clamp(min=eps)
+    q[2] = q[2] / n;
+    q[3] = q[3] / n;
+    const float* hp = A.st.height_points + (int64_t)p * 3;
+    const float v[3] = {hp[0], hp[1], hp[2]};
+    float w[3];
+    quat_apply(q, v, w);
+    const float fx = ((w[0] + pose[0]) + c.terrain_border) / c.terrain_hscale;
+    const float fy = ((w[1] + pose[1]) + c.terrain_border) / c.terrain_hscale;
+    int64_t px = (int64_t)fx, py = (int64_t)fy;               // .long(): truncation towards zero
+    px = px < 0 ? 0 : (px > c.height_rows - 2 ? c.height_rows - 2 : px);
+    py = py < 0 ? 0 : (py > c.height_cols - 2 ? c.height_cols - 2 : py);
+    const int16_t* hs = A.st.height_samples;
+    const int16_t h1 = hs[px * c.height_cols + py], h2 = hs[(px + 1) * c.height_cols + py], h3 = hs[px * c.height_cols + py + 1];
+    int16_t h = h1 < h2 ? h1 : h2;
+    h = h < h3 ? h : h3;
+    A.st.measured_heights[(int64_t)e * c.num_height_points + p] = (float)h * c.terrain_vscale;
+}
+
+// LeggedRobot.update_command_curriculum (legged_robot.py:179-180,422-431) AFTER the step kernel and BEFORE the step finaliser.
+// The reference decides inside reset_idx, between the termination check and the command resample, from a mean over the
+// resetting envs: a cross-env dependency in the middle of the per-env chain, met on one step in max_episode_length.  The step
+// kernel therefore resamples with the range it found, and on that one step this single-workgroup pass (a) takes the decision
+// from the episode-sum accumulators the finaliser is about to consume, (b) moves the device-resident range, and (c) redoes the
+// reset envs' x / y commands from the SAME uniform draws, patching the four places the two command columns went to: the
+// state, the newest ring frames and the stacked outputs (those columns carry no observation noise, humanoid_env.py:176).
+HG_HD bool command_curriculum_due(const EnvArgs& A, int64_t csc) {
+    const HgymEnvConfig& c = A.cfg;
+    if (!c.command_curriculum || !A.st.command_range_x || A.mode == MODE_PRIME) return false;
+    if (csc % c.max_episode_length != 0) return false;
+    const int64_t cnt = A.st.counters[1];
+    if (cnt <= 0) return false;
+    constexpr int kTrack = 20;                       // "tracking_lin_vel" in the alphabetical reward order
+    const float mean_sum = A.st.episode_acc[kTrack] / (float)cnt;
+    return mean_sum / (float)c.max_episode_length > (float)(0.8 * (double)c.reward_scales[kTrack]);
+}
+
+HG_HD void command_curriculum_move(const EnvArgs& A, double lo, double hi, double& nlo, double& nhi) {
+    const double m = (double)A.cfg.max_curriculum;
+    nlo = lo - 0.5;
+    nlo = nlo < -m ? -m : (nlo > 0.0 ? 0.0 : nlo);
+    nhi = hi + 0.5;
+    nhi = nhi < 0.0 ? 0.0 : (nhi > m ? m : nhi);
+}
+
+// the redo for env e (global id); ring slots as in the stacking phase of the same step
+HG_HD void command_curriculum_fix_env(const EnvArgs& A, const RngKey& rk, int e, float x_lo, float x_span, int64_t ring_step) {
+    const HgymEnvConfig& c = A.cfg;
+    const int N = c.num_envs;
+    if (!A.out.reset[e]) return;
+    const float u[3] = {A.noise.u_cmd ? A.noise.u_cmd[(int64_t)e * 6 + 3] : uniform_at(rk, (uint32_t)e, SLOT_CMD_RESET, 0),
+                        A.noise.u_cmd ? A.noise.u_cmd[(int64_t)e * 6 + 4] : uniform_at(rk, (uint32_t)e, SLOT_CMD_RESET, 1), 0.0f};
+    float cmd[4];
+    resample_commands(c, x_lo, x_span, cmd, u);
+    A.st.commands[e] = cmd[0];
+    A.st.commands[(int64_t)N + e] = cmd[1];
+    if (A.mode != MODE_STEP) return;                 // reset_all pushes no observation
+    const int H = c.frame_stack, HC = c.c_frame_stack;
+    const float lim = c.clip_obs;
+    for (int k = 0; k < 2; ++k) {
+        const float v = cmd[k] * c.scale_lin_vel;
+        const float vc = clampf(v, -lim, lim);
+        A.st.obs_ring[((int64_t)e * H + (int)(ring_step % H)) * HGYM_OBS_FRAME + 2 + k] = v;
+        A.st.priv_ring[((int64_t)e * HC + (int)(ring_step % HC)) * HGYM_PRIV_FRAME + 2 + k] = v;
+        A.out.obs[(int64_t)e * H * HGYM_OBS_FRAME + (H - 1) * HGYM_OBS_FRAME + 2 + k] = vc;
+        A.out.priv_obs[(int64_t)e * HC * HGYM_PRIV_FRAME + (HC - 1) * HGYM_PRIV_FRAME + 2 + k] = vc;
     }
 }
 

@@ -48,6 +48,11 @@ class EnvConfig(C.Structure):
         ("target_joint_pos_scale", C.c_float), ("target_feet_height", C.c_float), ("cycle_time", C.c_float),
         ("tracking_sigma", C.c_float), ("max_contact_force", C.c_float), ("episode_length_s", C.c_float),
         ("seed", C.c_uint64),
+        # generic LeggedRobot options (all zero for XBot-L)
+        ("custom_origins", C.c_int32), ("terrain_curriculum", C.c_int32), ("terrain_rows", C.c_int32), ("terrain_cols", C.c_int32),
+        ("terrain_env_length", C.c_float), ("num_height_points", C.c_int32), ("height_rows", C.c_int32), ("height_cols", C.c_int32),
+        ("terrain_border", C.c_float), ("terrain_hscale", C.c_float), ("terrain_vscale", C.c_float),
+        ("command_curriculum", C.c_int32), ("max_curriculum", C.c_float),
     ]
 
 
@@ -70,7 +75,10 @@ ENV_STATE_FIELDS = [  # (name, components) in header order; all [C][N] fp32
 
 class EnvState(C.Structure):
     _fields_ = ([("episode_length", c_i64_p), ("counters", c_i64_p)] + [(n, c_float_p) for n, _ in ENV_STATE_FIELDS] +
-                [("obs_ring", c_float_p), ("priv_ring", c_float_p), ("episode_acc", c_float_p)])
+                [("obs_ring", c_float_p), ("priv_ring", c_float_p), ("episode_acc", c_float_p),
+                 ("terrain_levels", c_i64_p), ("terrain_types", c_i64_p), ("terrain_origins", c_float_p),
+                 ("height_samples", C.POINTER(C.c_int16)), ("height_points", c_float_p), ("height_pose", c_float_p),
+                 ("measured_heights", c_float_p), ("command_range_x", c_f64_p)])
 
 
 class EnvOut(C.Structure):
@@ -82,7 +90,7 @@ class EnvOut(C.Structure):
 
 class EnvNoise(C.Structure):
     _fields_ = [("u_delay", c_float_p), ("z_act", c_float_p), ("u_cmd", c_float_p), ("u_dof", c_float_p),
-                ("u_push", c_float_p), ("z_obs", c_float_p)]
+                ("u_push", c_float_p), ("z_obs", c_float_p), ("u_xy", c_float_p), ("r_level", c_i64_p)]
 
 
 class NetConfig(C.Structure):
@@ -132,6 +140,7 @@ SYMBOLS = {
     "hgym_post_physics": (C.c_int32, [_P(EnvConfig), _P(SimTensors), _P(EnvState), _P(EnvOut), _P(EnvNoise), C.c_void_p]),
     "hgym_env_step_synth": (C.c_int32, [_P(EnvConfig), _P(SimTensors), _P(EnvState), _P(EnvOut), c_float_p, C.c_void_p]),
     "hgym_env_finalize": (C.c_int32, [_P(EnvConfig), _P(EnvState), _P(EnvOut), C.c_void_p]),
+    "hgym_measure_heights": (C.c_int32, [_P(EnvConfig), _P(EnvState), C.c_void_p]),
     "hgym_store_step": (C.c_int32, [C.c_int32, c_float_p, c_float_p, c_u8_p, c_u8_p, C.c_float, c_float_p, c_u8_p, C.c_void_p]),
     "hgym_gae": (C.c_int32, [C.c_int32, C.c_int32, c_float_p, c_float_p, c_u8_p, c_float_p, C.c_float, C.c_float,
                              c_float_p, c_float_p, c_f64_p, C.c_void_p]),

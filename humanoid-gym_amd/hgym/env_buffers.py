@@ -85,6 +85,43 @@ class EnvBuffers:
         self.f["env_origins"].copy_(grid_origins(N).t())
         self.set_initial_root()
         self._structs = None
+        # generic LeggedRobot options (set_terrain / set_command_curriculum); absent for XBot-L
+        self.terrain_levels = self.terrain_types = self.terrain_origins = None
+        self.height_samples = self.height_points = self.height_pose = self.measured_heights = None
+        self.command_range_x = None
+
+    # ---- generic options --------------------------------------------------------
+    def set_terrain(self, origins, levels, types, env_length, curriculum, height_samples=None, height_points=None, border_size=0.0,
+                    horizontal_scale=0.1, vertical_scale=0.005):
+        """A height-field / trimesh terrain map (humanoid.utils.terrain.Terrain): tile origins (rows, cols, 3), each env's
+        level (row) and type (column); optionally the int16 height field and the (P, 3) base-frame sample points of the height
+        measurements.  Sets the env origins from it (legged_robot.py:687-697) and fills the option fields of the config."""
+        dev, cfg, N = self.device, self.cfg, self.N
+        self.terrain_origins = torch.as_tensor(origins, dtype=torch.float32).to(dev).contiguous()
+        self.terrain_levels = torch.as_tensor(levels, dtype=torch.int64).to(dev).contiguous().clone()
+        self.terrain_types = torch.as_tensor(types, dtype=torch.int64).to(dev).contiguous()
+        assert self.terrain_origins.dim() == 3 and self.terrain_levels.shape == (N,) and self.terrain_types.shape == (N,)
+        cfg.custom_origins = 1
+        cfg.terrain_curriculum = int(bool(curriculum))
+        cfg.terrain_rows, cfg.terrain_cols = int(self.terrain_origins.shape[0]), int(self.terrain_origins.shape[1])
+        cfg.terrain_env_length = float(env_length)
+        self.f["env_origins"].copy_(self.terrain_origins[self.terrain_levels, self.terrain_types].t())
+        self.set_initial_root()
+        if height_samples is not None:
+            self.height_samples = torch.as_tensor(height_samples, dtype=torch.int16).to(dev).contiguous()
+            self.height_points = torch.as_tensor(height_points, dtype=torch.float32).to(dev).contiguous()
+            P = int(self.height_points.shape[0])
+            self.height_pose = torch.zeros(N, 7, device=dev)
+            self.measured_heights = torch.zeros(N, P, device=dev)
+            cfg.num_height_points = P
+            cfg.height_rows, cfg.height_cols = int(self.height_samples.shape[0]), int(self.height_samples.shape[1])
+            cfg.terrain_border, cfg.terrain_hscale, cfg.terrain_vscale = float(border_size), float(horizontal_scale), float(vertical_scale)
+
+    def set_command_curriculum(self, lin_vel_x, max_curriculum):
+        """cfg.commands.curriculum: the lin_vel_x range becomes device-resident ([lo, hi] doubles) and widens as the policy tracks."""
+        self.command_range_x = torch.tensor([float(lin_vel_x[0]), float(lin_vel_x[1])], dtype=torch.float64, device=self.device)
+        self.cfg.command_curriculum = 1
+        self.cfg.max_curriculum = float(max_curriculum)
 
     # ---- views with the reference's shapes -------------------------------------------------------
     def view(self, name):
@@ -151,6 +188,15 @@ class EnvBuffers:
         st.obs_ring = L.fptr(self.obs_ring)
         st.priv_ring = L.fptr(self.priv_ring)
         st.episode_acc = L.fptr(self.episode_acc)
+        if self.terrain_levels is not None:
+            st.terrain_levels, st.terrain_types = L.i64ptr(self.terrain_levels), L.i64ptr(self.terrain_types)
+            st.terrain_origins = L.fptr(self.terrain_origins)
+        if self.height_samples is not None:
+            st.height_samples = C.cast(self.height_samples.data_ptr(), C.POINTER(C.c_int16))
+            st.height_points, st.height_pose = L.fptr(self.height_points), L.fptr(self.height_pose)
+            st.measured_heights = L.fptr(self.measured_heights)
+        if self.command_range_x is not None:
+            st.command_range_x = C.cast(self.command_range_x.data_ptr(), L.c_f64_p)
         return st
 
     def out_struct(self, obs=None, priv=None, sink=None, defer_finalize=False):
@@ -166,8 +212,10 @@ class EnvBuffers:
         return o
 
     @staticmethod
-    def noise_struct(u_delay=None, z_act=None, u_cmd=None, u_dof=None, u_push=None, z_obs=None):
-        """Row-major (N,k) fp32 tables (or None -> internal Philox).  The caller keeps the tensors alive."""
-        for t in (u_delay, z_act, u_cmd, u_dof, u_push, z_obs):
+    def noise_struct(u_delay=None, z_act=None, u_cmd=None, u_dof=None, u_push=None, z_obs=None, u_xy=None, r_level=None):
+        """Row-major (N,k) fp32 tables (or None -> internal Philox); r_level (N,) int64.  The caller keeps the tensors alive."""
+        for t in (u_delay, z_act, u_cmd, u_dof, u_push, z_obs, u_xy):
             assert t is None or (t.is_contiguous() and t.dtype == torch.float32)
-        return L.EnvNoise(L.fptr(u_delay), L.fptr(z_act), L.fptr(u_cmd), L.fptr(u_dof), L.fptr(u_push), L.fptr(z_obs))
+        assert r_level is None or (r_level.is_contiguous() and r_level.dtype == torch.int64)
+        return L.EnvNoise(L.fptr(u_delay), L.fptr(z_act), L.fptr(u_cmd), L.fptr(u_dof), L.fptr(u_push), L.fptr(z_obs), L.fptr(u_xy),
+                          L.i64ptr(r_level))

@@ -32,6 +32,17 @@ DOF_UPPER = [1.57, 1.05, 1.31, 1.10, 0.87, 0.44, 0.44, 1.05, 1.57, 1.05, 0.70, 0
 NOMINAL_BASE_MASS = 15.0   # synthetic backend: base link + collapsed upper body (URDF base_link alone is 9.96 kg)
 
 
+class _CommandRanges(dict):
+    """`env.command_ranges`: with cfg.commands.curriculum the lin_vel_x range lives on the device (the curriculum kernel moves
+    it, legged_robot.py:422-431); reading that key reads it back."""
+    live_x = None
+
+    def __getitem__(self, key):
+        if key == "lin_vel_x" and self.live_x is not None:
+            return [float(v) for v in self.live_x.cpu()]
+        return dict.__getitem__(self, key)
+
+
 class LeggedRobot(BaseTask):
     def __init__(self, cfg: LeggedRobotCfg, sim_params, physics_engine, sim_device, headless):
         self.cfg = cfg
@@ -50,7 +61,7 @@ class LeggedRobot(BaseTask):
         self.dt = self.cfg.control.decimation * self.sim_params.dt
         self.obs_scales = self.cfg.normalization.obs_scales
         self.reward_scales = class_to_dict(self.cfg.rewards.scales)
-        self.command_ranges = class_to_dict(self.cfg.commands.ranges)
+        self.command_ranges = _CommandRanges(class_to_dict(self.cfg.commands.ranges))
         if self.cfg.terrain.mesh_type not in ["heightfield", "trimesh"]:
             self.cfg.terrain.curriculum = False
         self.max_episode_length_s = self.cfg.env.episode_length_s
@@ -67,10 +78,12 @@ class LeggedRobot(BaseTask):
                 raise NotImplementedError("the MI355X hot path implements the XBot-L observation layout (cfg.env.%s missing)" % need)
         if cfg.env.num_single_obs != L.OBS_FRAME or cfg.env.single_num_privileged_obs != L.PRIV_FRAME:
             raise NotImplementedError("observation frame sizes other than 47/73 are not built")
-        if cfg.terrain.measure_heights or cfg.terrain.mesh_type in ("heightfield", "trimesh"):
-            raise NotImplementedError("terrain height measurements are outside the hot path (SURVEY.md §8f item 3)")
-        if not cfg.commands.heading_command or cfg.commands.curriculum:
-            raise NotImplementedError("only heading_command=True without command curriculum is built")
+        if cfg.terrain.mesh_type not in ("plane", "heightfield", "trimesh"):
+            raise ValueError("Terrain mesh type not recognised. Allowed types are [plane, heightfield, trimesh]")
+        if cfg.terrain.measure_heights and cfg.terrain.mesh_type == "plane":
+            raise NotImplementedError("measure_heights on a plane returns zeros in the reference; there is nothing to sample")
+        if not cfg.commands.heading_command:
+            raise NotImplementedError("only heading_command=True is built (XBotLCfg)")
         c = default_env_config(self.num_envs, seed=getattr(cfg, "seed", 5), frame_stack=cfg.env.frame_stack,
                                c_frame_stack=cfg.env.c_frame_stack)
         c.decimation = cfg.control.decimation
@@ -124,6 +137,46 @@ class LeggedRobot(BaseTask):
         return c
 
     # ------------------------------------------------------------------ construction
+    terrain_class = None          # set by create_sim: humanoid.utils.terrain.Terrain (XBotLFreeEnv: HumanoidTerrain)
+
+    def _build_terrain(self):
+        """mesh_type heightfield / trimesh (legged_robot.py:543-586,683-697): the procedural map, each env's terrain level
+        (row) and type (column), origins from the map.  The synthetic physics backend does not collide with the map; it
+        feeds the reset origins, the terrain curriculum and the height measurements."""
+        from humanoid.utils.terrain import Terrain
+        tc = self.cfg.terrain
+        self.terrain = (self.terrain_class or Terrain)(tc, self.num_envs)
+        self.height_samples = torch.tensor(self.terrain.heightsamples).view(self.terrain.tot_rows, self.terrain.tot_cols).to(self.device)
+        self.custom_origins = True
+        max_init_level = tc.max_init_terrain_level if tc.curriculum else tc.num_rows - 1
+        self.terrain_levels = torch.randint(0, max_init_level + 1, (self.num_envs,), device=self.device)
+        self.terrain_types = torch.div(torch.arange(self.num_envs, device=self.device), (self.num_envs / tc.num_cols),
+                                       rounding_mode="floor").to(torch.long)
+        self.max_terrain_level = tc.num_rows
+        self.terrain_origins = torch.from_numpy(self.terrain.env_origins).to(self.device).to(torch.float)
+
+    def _init_height_points(self):
+        """(num_envs, P, 3) base-frame sample grid, legged_robot.py:743-759 (the kernel keeps one (P, 3) copy)."""
+        y = torch.tensor(self.cfg.terrain.measured_points_y, device=self.device)
+        x = torch.tensor(self.cfg.terrain.measured_points_x, device=self.device)
+        grid_x, grid_y = torch.meshgrid(x, y, indexing="ij")
+        self.num_height_points = grid_x.numel()
+        points = torch.zeros(self.num_envs, self.num_height_points, 3, device=self.device)
+        points[:, :, 0] = grid_x.flatten()
+        points[:, :, 1] = grid_y.flatten()
+        return points
+
+    def _get_heights(self, env_ids=None):
+        """legged_robot.py:761-795 on the CURRENT base poses (the step itself samples before its resets; this is for callers
+        such as play scripts)."""
+        if self.cfg.terrain.mesh_type == "plane":
+            return torch.zeros(self.num_envs, getattr(self, "num_height_points", 0), device=self.device)
+        b = self._buf
+        b.height_pose.copy_(self.root_states[:, :7])
+        self._L.check(self._L.lib.hgym_measure_heights(C.byref(self._ncfg), C.byref(self._st_s), self._stream()), "hgym_measure_heights")
+        h = b.measured_heights.clone()
+        return h if env_ids is None else h[env_ids]
+
     def create_sim(self):
         """Where the reference builds the PhysX scene (legged_robot.py:588-708): allocate the device buffers,
         draw the per-env friction / base-mass randomisation, lay the envs out on the plane grid."""
@@ -139,6 +192,8 @@ class LeggedRobot(BaseTask):
         self.cfg.seed = getattr(self.cfg, "seed", 5)
         self._ncfg = None
         self.custom_origins = False
+        if self.cfg.terrain.mesh_type in ("heightfield", "trimesh"):
+            self._build_terrain()
         self.feet_indices = torch.tensor([6, 12], dtype=torch.long, device=self.device)
         self.knee_indices = torch.tensor([4, 10], dtype=torch.long, device=self.device)
         self.penalised_contact_indices = torch.tensor([0], dtype=torch.long, device=self.device)
@@ -149,6 +204,26 @@ class LeggedRobot(BaseTask):
         self._ncfg = self._native_config()
         b = self._buf = self._hgym.EnvBuffers(self._ncfg, self.device)
         N = self.num_envs
+        tc = self.cfg.terrain
+        if self.custom_origins:
+            measure = bool(tc.measure_heights)
+            if measure:
+                self.height_points = self._init_height_points()
+                if not getattr(LeggedRobot, "_warned_heights", False):
+                    LeggedRobot._warned_heights = True
+                    print("measure_heights: heights are sampled into env.measured_heights every step; the XBot-L observation layout "
+                          "is unchanged (the reference's concatenation, humanoid_env.py:246-248, does not fit its configured sizes)")
+            b.set_terrain(self.terrain_origins, self.terrain_levels, self.terrain_types, self.terrain.env_length, tc.curriculum,
+                          height_samples=self.height_samples if measure else None,
+                          height_points=self.height_points[0] if measure else None, border_size=tc.border_size,
+                          horizontal_scale=tc.horizontal_scale, vertical_scale=tc.vertical_scale)
+            self.terrain_levels = b.terrain_levels           # the kernel's copy is the live one
+            self.measured_heights = b.measured_heights if measure else 0
+        else:
+            self.measured_heights = 0
+        if self.cfg.commands.curriculum:
+            b.set_command_curriculum(self.command_ranges["lin_vel_x"], self.cfg.commands.max_curriculum)
+            self.command_ranges.live_x = b.command_range_x
         dr = self.cfg.domain_rand
         if dr.randomize_friction:                         # legged_robot.py:257-269 (256 buckets)
             buckets = (dr.friction_range[1] - dr.friction_range[0]) * torch.rand(256, 1) + dr.friction_range[0]
@@ -245,6 +320,13 @@ class LeggedRobot(BaseTask):
             if hasattr(self, "reward_names") else {}
         if self.cfg.env.send_timeouts:
             self.extras["time_outs"] = b.extras_time_outs
+        # curriculum info (legged_robot.py:203-207): live device scalars (the reference refreshes them on steps with a reset)
+        if self.cfg.terrain.mesh_type == "trimesh" and getattr(self, "custom_origins", False) and self.extras["episode"]:
+            if not hasattr(self, "_terrain_level_mean"):
+                self._terrain_level_mean = torch.zeros((), device=self.device)
+            self.extras["episode"]["terrain_level"] = self._terrain_level_mean
+        if self.cfg.commands.curriculum and b.command_range_x is not None and self.extras["episode"]:
+            self.extras["episode"]["max_command_x"] = b.command_range_x[1]
 
     def bind_outputs(self, obs, priv):
         """Native extension: make the next step write its observations straight into caller memory
@@ -297,6 +379,8 @@ class LeggedRobot(BaseTask):
             self._pending_fin = (self._ncfg, self._st_s, out)
         if self._ncfg.use_ref_actions and a.data_ptr() != actions.data_ptr():
             actions.copy_(a)         # the reference mutates the caller's tensor (humanoid_env.py:190-191: actions += ref_action)
+        if hasattr(self, "_terrain_level_mean"):
+            torch.mean(self.terrain_levels.float(), dim=0, out=self._terrain_level_mean)
         self.obs_buf, self.privileged_obs_buf = obs, priv
         return self.obs_buf, self.privileged_obs_buf, self.rew_buf, self.reset_buf, self.extras
 

@@ -8,6 +8,8 @@ from humanoid.envs.base.legged_robot_config import LeggedRobotCfg
 
 
 class XBotLFreeEnv(LeggedRobot):
+    from humanoid.utils.terrain import HumanoidTerrain as terrain_class      # humanoid_env.py:152-153
+
     def __init__(self, cfg: LeggedRobotCfg, sim_params, physics_engine, sim_device, headless):
         super().__init__(cfg, sim_params, physics_engine, sim_device, headless)
         self._prime()     # last_feet_z = 0.05, reset_idx(all), compute_observations()

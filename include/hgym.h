@@ -97,6 +97,22 @@ typedef struct HgymEnvConfig {
     float base_height_target, min_dist, max_dist, target_joint_pos_scale, target_feet_height;
     float cycle_time, tracking_sigma, max_contact_force, episode_length_s;
     uint64_t seed;                /* Philox key for internally generated noise */
+    /* ---- generic LeggedRobot options XBot-L leaves off.  All zero = plane terrain, fixed command
+     * ranges: the XBot-L default, and the configuration the headline numbers are measured on. ---- */
+    int32_t custom_origins;       /* terrain.mesh_type in {heightfield, trimesh} (legged_robot.py:687-697): a reset spawns the robot at
+                                     its tile origin + U(-1,1) m in x and y (:382-385) */
+    int32_t terrain_curriculum;   /* terrain.curriculum: on reset an env that walked more than half a tile is promoted one terrain
+                                     level, one that covered less than half its commanded distance demoted; solving the last level
+                                     redraws a random one (:176-177,400-420).  Needs custom_origins. */
+    int32_t terrain_rows, terrain_cols;   /* levels x types of HgymEnvState.terrain_origins; max_terrain_level = terrain_rows (:695) */
+    float terrain_env_length;     /* Terrain.env_length (utils/terrain.py:46) */
+    int32_t num_height_points;    /* > 0: terrain.measure_heights with that many sample points per env (:316-317,743-795) */
+    int32_t height_rows, height_cols;     /* shape of HgymEnvState.height_samples (Terrain.tot_rows, tot_cols) */
+    float terrain_border, terrain_hscale, terrain_vscale;   /* terrain.border_size / horizontal_scale / vertical_scale */
+    int32_t command_curriculum;   /* commands.curriculum: every max_episode_length common steps, if the resetting envs' mean
+                                     tracking_lin_vel episode sum exceeds 80 % of its maximum, lin_vel_x widens by 0.5 each way
+                                     up to +-max_curriculum (:179-180,422-431).  The live range is HgymEnvState.command_range_x. */
+    float max_curriculum;
 } HgymEnvConfig;
 
 /* fills *cfg with the XBot-L values (the reference defaults) for num_envs environments */
@@ -146,6 +162,16 @@ typedef struct HgymEnvState {
     float* obs_ring;           /* [N][frame_stack][47]   unclipped noisy frames, ring slot = ring step % frame_stack */
     float* priv_ring;          /* [N][c_frame_stack][73] */
     float* episode_acc;        /* [24] fp32 device scalars: sum over resetting envs of episode_sums[k]; [22] unused */
+    /* generic options (HgymEnvConfig tail); NULL when the option is off */
+    int64_t* terrain_levels;        /* (N,) int64  LeggedRobot.terrain_levels */
+    const int64_t* terrain_types;   /* (N,) int64  LeggedRobot.terrain_types */
+    const float* terrain_origins;   /* (terrain_rows, terrain_cols, 3) fp32 = Terrain.env_origins */
+    const int16_t* height_samples;  /* (height_rows, height_cols) int16 = Terrain.heightsamples */
+    const float* height_points;     /* (num_height_points, 3) base-frame sample points, the same for every env (:743-759) */
+    float* height_pose;             /* (N, 7) scratch: base position + quaternion at the point of the step where the reference
+                                       samples the heights (before the reset overwrites them) */
+    float* measured_heights;        /* (N, num_height_points) fp32 = LeggedRobot.measured_heights */
+    double* command_range_x;        /* [2] device doubles: command_ranges["lin_vel_x"] = [lo, hi]; moved by the command curriculum */
 } HgymEnvState;
 
 /* Outputs of one env step = the 5-tuple of VecEnv.step (algo/vec_env.py:50-51) plus the extras tensors. */
@@ -183,6 +209,8 @@ typedef struct HgymEnvNoise {
     const float* u_dof;        /* (N,12)  U[0,1)  legged_robot.py:367 */
     const float* u_push;       /* (N,5)   U[0,1)  humanoid_env.py:88-93 */
     const float* z_obs;        /* (N,47)  N(0,1)  humanoid_env.py:251 */
+    const float* u_xy;         /* (N,2)   U[0,1)  legged_robot.py:385 (custom origins) */
+    const int64_t* r_level;    /* (N,)    integers in [0, terrain_rows)  legged_robot.py:418 (terrain curriculum) */
 } HgymEnvNoise;
 
 /* XBotLFreeEnv.__init__ tail (humanoid_env.py:78-81): state defaults, reset_idx(all), compute_observations. */
@@ -217,6 +245,10 @@ int32_t hgym_post_physics(const HgymEnvConfig* cfg, const HgymSimTensors* sim, c
 /* Fast path: pre_physics + synth_physics + post_physics in ONE launch, then the step finaliser. */
 int32_t hgym_env_step_synth(const HgymEnvConfig* cfg, const HgymSimTensors* sim, const HgymEnvState* st,
                             const HgymEnvOut* out, float* actions_in, void* stream);
+
+/* LeggedRobot._get_heights (legged_robot.py:761-795) for the poses the last env step left in st->height_pose ->
+ * st->measured_heights.  The env-step entry points call it themselves when cfg->num_height_points > 0. */
+int32_t hgym_measure_heights(const HgymEnvConfig* cfg, const HgymEnvState* st, void* stream);
 
 /* The step finaliser of the last env step on its own (flushes HgymEnvOut.defer_finalize; a no-op to call twice it is NOT:
  * the counters advance each time). */

@@ -121,7 +121,9 @@ def exact(a, b, what):
 class EnvUnderTest:
     """Product-side buffers + the call sequence of one vec-step in parity mode (external noise, external sim frames)."""
 
-    def __init__(self, backend, N, friction, body_mass, sim_layout="soa", frame_stack=15, c_frame_stack=3, use_ref_actions=False):
+    def __init__(self, backend, N, friction, body_mass, sim_layout="soa", frame_stack=15, c_frame_stack=3, use_ref_actions=False,
+                 terrain=None, command_curriculum=None):
+        """terrain: an oracle TerrainSpec (its initial levels are copied); command_curriculum: max_curriculum or None."""
         from hgym import EnvBuffers, default_env_config
         self.be = backend
         self.cfg = default_env_config(N, frame_stack=frame_stack, c_frame_stack=c_frame_stack)
@@ -129,26 +131,34 @@ class EnvUnderTest:
         self.buf = EnvBuffers(self.cfg, backend.device, sim_layout=sim_layout)
         self.buf.f["friction"].copy_(friction.view(1, N))
         self.buf.f["body_mass"].copy_(body_mass.view(1, N))
+        if terrain is not None:
+            self.buf.set_terrain(terrain.origins, terrain.levels, terrain.types, terrain.env_length, terrain.curriculum,
+                                 height_samples=terrain.height_samples, height_points=terrain.height_points,
+                                 border_size=terrain.border_size, horizontal_scale=terrain.hscale, vertical_scale=terrain.vscale)
+        if command_curriculum is not None:
+            self.buf.set_command_curriculum(K.CMD_LIN_VEL_X, command_curriculum)
         self.sim, self.st, self.out = self.buf.sim_struct(), self.buf.state_struct(), self.buf.out_struct()
         self.dev = backend.device
 
     def _noise(self, **kw):
-        self._keep = {k: (None if v is None else v.to(self.dev).float().contiguous()) for k, v in kw.items()}
+        conv = lambda k, v: None if v is None else (v.to(self.dev).long().contiguous() if k == "r_level" else v.to(self.dev).float().contiguous())
+        self._keep = {k: conv(k, v) for k, v in kw.items()}
         return self.buf.noise_struct(**self._keep)
 
-    def prime(self, u_dof, u_cmd3, z_obs):
+    def prime(self, u_dof, u_cmd3, z_obs, u_xy=None, r_level=None):
         N = self.buf.N
         u_cmd = torch.zeros(N, 6)
         u_cmd[:, 3:6] = u_cmd3
-        self.be.step_call("prime", self.cfg, self.sim, self.st, self.out, self._noise(u_dof=u_dof, u_cmd=u_cmd, z_obs=z_obs))
+        self.be.step_call("prime", self.cfg, self.sim, self.st, self.out,
+                          self._noise(u_dof=u_dof, u_cmd=u_cmd, z_obs=z_obs, u_xy=u_xy, r_level=r_level))
 
-    def reset_all(self, u_dof, u_cmd3):
+    def reset_all(self, u_dof, u_cmd3, u_xy=None, r_level=None):
         N = self.buf.N
         u_cmd = torch.zeros(N, 6)
         u_cmd[:, 3:6] = u_cmd3
-        self.be.step_call("reset_all", self.cfg, self.sim, self.st, self.out, self._noise(u_dof=u_dof, u_cmd=u_cmd))
+        self.be.step_call("reset_all", self.cfg, self.sim, self.st, self.out, self._noise(u_dof=u_dof, u_cmd=u_cmd, u_xy=u_xy, r_level=r_level))
 
-    def step(self, actions_in, frame, u_delay, z_act, u_cmd, u_dof, u_push, z_obs):
+    def step(self, actions_in, frame, u_delay, z_act, u_cmd, u_dof, u_push, z_obs, u_xy=None, r_level=None):
         a = actions_in.to(self.dev).float().contiguous().clone()
         self.be.pre_physics(self.cfg, self.st, a, self._noise(u_delay=u_delay, z_act=z_act))
         self.actions_after = a                  # the caller's tensor after the call (mutated only with use_ref_actions)
@@ -156,7 +166,7 @@ class EnvUnderTest:
         self.be.sync()
         self.buf.load_sim(*frame)
         self.be.step_call("post", self.cfg, self.sim, self.st, self.out,
-                          self._noise(u_cmd=u_cmd, u_dof=u_dof, u_push=u_push, z_obs=z_obs))
+                          self._noise(u_cmd=u_cmd, u_dof=u_dof, u_push=u_push, z_obs=z_obs, u_xy=u_xy, r_level=r_level))
         self.be.sync()
 
 
@@ -188,21 +198,55 @@ def compare_state(env, o, tag, check_obs=True):
     if check_obs:
         close(b.obs, torch.clip(o.obs, -K.CLIP_OBS, K.CLIP_OBS), tag + " obs")
         close(b.priv_obs, torch.clip(o.priv, -K.CLIP_OBS, K.CLIP_OBS), tag + " priv_obs")
+    if o.terrain is not None:
+        exact(b.terrain_levels, o.terrain.levels, tag + " terrain_levels")
+        exact(b.view("env_origins").contiguous().view(torch.int32), o.env_origins.contiguous().view(torch.int32), tag + " env_origins (bits)")
+        if o.measured_heights is not None:
+            # indices come from a truncated fp32 quotient: bit-exact arithmetic, so the sampled cells must agree everywhere
+            exact(b.measured_heights.contiguous().view(torch.int32), o.measured_heights.contiguous().view(torch.int32), tag + " measured_heights (bits)")
+    if o.command_curriculum:
+        assert [float(v) for v in b.command_range_x.cpu()] == o.cmd_range_x, tag + " command range"
+
+
+def random_terrain_spec(g, N, rows=5, cols=4, points=(7, 5)):
+    """A seeded terrain map with the shapes humanoid.utils.terrain produces (tile origins, int16 height field, sample grid)."""
+    from oracle.xbot_env_oracle import TerrainSpec
+    tile, border, hs = 8.0, 3.0, 0.1
+    origins = torch.zeros(rows, cols, 3)
+    origins[:, :, 0] = (torch.arange(rows).float().view(-1, 1) + 0.5) * tile
+    origins[:, :, 1] = (torch.arange(cols).float().view(1, -1) + 0.5) * tile
+    origins[:, :, 2] = 0.3 * torch.rand(rows, cols, generator=g)
+    field = torch.randint(-60, 90, (int(rows * tile / hs + 2 * border / hs), int(cols * tile / hs + 2 * border / hs)), generator=g).to(torch.int16)
+    px = torch.linspace(-0.6, 0.6, points[0])
+    py = torch.linspace(-0.4, 0.4, points[1])
+    gx, gy = torch.meshgrid(px, py, indexing="ij")
+    hp = torch.zeros(points[0] * points[1], 3)
+    hp[:, 0], hp[:, 1] = gx.flatten(), gy.flatten()
+    levels = torch.randint(0, rows, (N,), generator=g)
+    types = torch.div(torch.arange(N), N / cols, rounding_mode="floor").long()
+    return TerrainSpec(origins, levels, types, tile, True, height_samples=field, height_points=hp, border_size=border,
+                       horizontal_scale=hs, vertical_scale=0.005)
 
 
 def run_random_trace(backend, N, steps, seed, sim_layout="soa", frame_stack=15, c_frame_stack=3, check_every=1,
-                     use_ref_actions=False):
-    """Seeded random trace through product + oracle with identical inputs; returns event counts."""
+                     use_ref_actions=False, generic=False, track_sum=40.0):
+    """Seeded random trace through product + oracle with identical inputs; returns event counts.
+    generic: a terrain map (custom origins, terrain curriculum, height measurements) and the command curriculum are on; the
+    common step counter is planted so that the command curriculum is examined inside the trace and `track_sum` (the planted
+    tracking_lin_vel episode sums) decides whether it moves the range."""
     g = torch.Generator().manual_seed(seed)
     fr = 0.1 + 1.9 * torch.rand(N, 1, generator=g)
     bm = 10.0 + 10.0 * torch.rand(N, 1, generator=g)
+    spec = random_terrain_spec(g, N) if generic else None
     o = XBotEnvOracle(N, frictions=fr, body_mass=bm, frame_stack=frame_stack, c_frame_stack=c_frame_stack,
-                      use_ref_actions=use_ref_actions)
+                      use_ref_actions=use_ref_actions, terrain=spec, command_curriculum=generic, max_curriculum=1.5)
     env = EnvUnderTest(backend, N, fr, bm, sim_layout=sim_layout, frame_stack=frame_stack, c_frame_stack=c_frame_stack,
-                       use_ref_actions=use_ref_actions)
+                       use_ref_actions=use_ref_actions, terrain=spec, command_curriculum=1.5 if generic else None)
     u_dof, u_cmd3, z_obs = torch.rand(N, 12, generator=g), torch.rand(N, 3, generator=g), torch.randn(N, 47, generator=g)
-    o.prime(u_dof, u_cmd3, z_obs)
-    env.prime(u_dof, u_cmd3, z_obs)
+    gen_draws = lambda: (torch.rand(N, 2, generator=g), torch.randint(0, spec.max_level, (N,), generator=g)) if generic else (None, None)
+    u_xy, r_level = gen_draws()
+    o.prime(u_dof, u_cmd3, z_obs, u_xy, r_level)
+    env.prime(u_dof, u_cmd3, z_obs, u_xy, r_level)
     backend.sync()
     compare_state(env, o, "prime")
     ep = torch.randint(0, 2400, (N,), generator=g)
@@ -210,23 +254,45 @@ def run_random_trace(backend, N, steps, seed, sim_layout="soa", frame_stack=15, 
     o.ep_len = ep.clone()
     env.buf.episode_length.copy_(ep)
     csc = 397
+    if generic:
+        csc = 2397                      # step 3 lands on 2400: a push step AND the command-curriculum check (time-out planted below)
+        ep[min(N, 6):min(N, 8)] = 2397
+        o.ep_len = ep.clone()
+        env.buf.episode_length.copy_(ep)
+        sums = o.episode_sums.clone()
+        sums[:, K.REWARD_NAMES.index("tracking_lin_vel")] = track_sum * (0.9 + 0.2 * torch.rand(N, generator=g))
+        o.episode_sums = sums.clone()
+        env.buf.view("episode_sums").copy_(sums)
     o.common_step_counter = csc
     env.buf.counters[0] = csc
-    counts = dict(reset=0, timeout=0, push=0, stale=0)
+    counts = dict(reset=0, timeout=0, push=0, stale=0, level_up=0, level_down=0, range_moves=0)
     for t in range(steps):
         a_in = torch.randn(N, 12, generator=g) * 1.5
         if t % 5 == 2:
             a_in[t % N] *= 40.0
         frame = synth_frames(g, N)
+        if generic:                     # base positions relative to the env's current tile origin: far, near, in between
+            r = torch.rand(N, generator=g)
+            rad = torch.where(r < 0.4, 4.2 + 2.5 * torch.rand(N, generator=g), 3.5 * torch.rand(N, generator=g))
+            ang = 6.2831853 * torch.rand(N, generator=g)
+            frame[0][:, 0] = o.env_origins[:, 0] + rad * torch.cos(ang)
+            frame[0][:, 1] = o.env_origins[:, 1] + rad * torch.sin(ang)
+            frame[0][:, 2] += o.env_origins[:, 2]
         u_delay, z_act = torch.rand(N, generator=g), torch.randn(N, 12, generator=g)
         u_cmd, u_dof = torch.rand(N, 6, generator=g), torch.rand(N, 12, generator=g)
         u_push, z_obs = torch.rand(N, 5, generator=g), torch.randn(N, 47, generator=g)
+        u_xy, r_level = gen_draws()
         a_o = a_in.clone()
         o.pre_physics(a_o, u_delay, z_act)      # mutates a_o when use_ref_actions
         o.pd_torques()
         o.sim.load(*frame)
-        _, _, _, _, info = o.post_physics(u_cmd, u_dof, u_push, z_obs)
-        env.step(a_in, frame, u_delay, z_act, u_cmd, u_dof, u_push, z_obs)
+        before = None if spec is None else (spec.levels.clone(), list(o.cmd_range_x))
+        _, _, _, _, info = o.post_physics(u_cmd, u_dof, u_push, z_obs, u_xy, r_level)
+        env.step(a_in, frame, u_delay, z_act, u_cmd, u_dof, u_push, z_obs, u_xy, r_level)
+        if before is not None:
+            counts["level_up"] += int((spec.levels > before[0]).sum())
+            counts["level_down"] += int((spec.levels < before[0]).sum())
+            counts["range_moves"] += int(before[1] != o.cmd_range_x)
         if t % check_every == 0 or t == steps - 1:
             compare_state(env, o, "step %d" % t)
             close(env.actions_after, a_o, "step %d caller's action tensor" % t)
@@ -235,3 +301,56 @@ def run_random_trace(backend, N, steps, seed, sim_layout="soa", frame_stack=15, 
         counts["push"] += int(info["pushed"])
         counts["stale"] += int((not info["any_reset"]) and o.extras_time_outs is not None and bool(o.extras_time_outs.any()))
     return counts, env, o
+
+
+# ------------------------------------------------------------------------------------------------ generic options
+def terrain_spec_from_golden(G):
+    from oracle.xbot_env_oracle import TerrainSpec
+    T = lambda a: torch.from_numpy(np.asarray(a))
+    return TerrainSpec(T(G["terrain_origins"]), T(G["terrain_levels0"]), T(G["terrain_types"]), float(G["terrain_env_length"]), True,
+                       height_samples=T(G["height_samples"]), height_points=T(G["height_points"]),
+                       border_size=float(G["terrain_border"]), horizontal_scale=float(G["terrain_hscale"]),
+                       vertical_scale=float(G["terrain_vscale"]))
+
+
+def run_generic_golden(backend, golden_dir):
+    """tests/golden/env_trace_generic.npz (recorded from the reference: trimesh terrain map, terrain + command curricula,
+    height measurements) through the product: integer state, origins and sampled heights bit-exact, floats to the usual bars."""
+    T = lambda a: torch.from_numpy(np.asarray(a))
+    G = np.load(os.path.join(golden_dir, "env_trace_generic.npz"))
+    N = G["friction"].shape[0]
+    env = EnvUnderTest(backend, N, T(G["friction"]), T(G["body_mass"]), sim_layout="aos", terrain=terrain_spec_from_golden(G),
+                       command_curriculum=float(G["max_curriculum"]))
+    b = env.buf
+    env.prime(T(G["prime_u_dof"]), T(G["prime_u_cmd"]), T(G["prime_z_obs"]), T(G["prime_u_xy"]), T(G["prime_r_level"]))
+    backend.sync()
+    close(b.obs, G["prime_obs"], "prime obs")
+    close(b.priv_obs, G["prime_priv"], "prime priv")
+    close(b.root, G["prime_root"], "prime root (spawn jitter)")
+    exact(b.terrain_levels, G["terrain_levels0"], "prime levels")
+    b.episode_length.copy_(T(G["init_ep_len"]))
+    b.counters[0] = int(G["init_common_step_counter"])
+    b.view("episode_sums").copy_(T(G["init_episode_sums"]))
+    moved = 0
+    for t in range(G["rew"].shape[0]):
+        frame = (T(G["root"][t]), T(G["dof"][t]), T(G["contact"][t]), T(G["rigid"][t]))
+        env.step(T(G["actions_in"][t]), frame, T(G["u_delay"][t]), T(G["z_act"][t]), T(G["u_cmd"][t]), T(G["u_dof"][t]),
+                 T(G["u_push"][t]), T(G["z_obs"][t]), T(G["u_xy"][t]), T(G["r_level"][t]))
+        tag = "generic step %d " % t
+        exact(b.reset, G["reset"][t], tag + "reset")
+        exact(b.episode_length, G["ep_len"][t], tag + "ep_len")
+        exact(b.terrain_levels, G["terrain_levels"][t], tag + "terrain_levels")
+        exact(b.view("env_origins").contiguous().view(torch.int32), T(G["env_origins"][t]).view(torch.int32), tag + "env_origins (bits)")
+        exact(b.measured_heights.contiguous().view(torch.int32), T(G["measured_heights"][t]).view(torch.int32), tag + "measured_heights (bits)")
+        assert [float(v) for v in b.command_range_x.cpu()] == [float(v) for v in G["cmd_range_x"][t]], tag + "command range"
+        close(b.view("commands"), G["commands"][t], tag + "commands")
+        close(b.root, G["root_after"][t], tag + "root (reset write-back with jitter)")
+        close(b.rew, G["rew"][t], tag + "rew")
+        close(b.view("episode_sums"), G["episode_sums"][t], tag + "episode_sums")
+        H, HC = 15, 3
+        close(b.obs[:, (H - 1) * 47:], np.clip(G["frame"][t], -K.CLIP_OBS, K.CLIP_OBS), tag + "newest obs frame")
+        close(b.priv_obs[:, (HC - 1) * 73:], np.clip(G["priv_frame"][t], -K.CLIP_OBS, K.CLIP_OBS), tag + "newest priv frame")
+        close(b.obs_ring.view(N, H, 47)[:, (int(b.counters[2]) - 1) % H], G["frame"][t], tag + "ring frame")
+        moved += int(t > 0 and list(G["cmd_range_x"][t]) != list(G["cmd_range_x"][t - 1]))
+    assert moved == 1
+    return env

@@ -26,6 +26,7 @@ static EnvArgs make_args(const HgymEnvConfig* cfg, const HgymSimTensors* sim, co
     if (out) A.out = *out;
     if (noise) A.noise = *noise;
     A.actions_in = actions_in;
+    A.origins_hbm = st->env_origins;
     A.mode = mode;
     A.fused = fused;
     A.envs_per_block = epb;
@@ -46,7 +47,7 @@ int hc_env_step(const HgymEnvConfig* cfg, const HgymSimTensors* sim, const HgymE
         for (int t = 0; t < nthreads; ++t) env_stage_in<0>(A, b, t, nthreads, smem.data());
         for (int t = 0; t < nthreads; ++t) env_fill_draws<0>(A, b, t, nthreads, smem.data(), csc0);
         for (int t = 0; t < nthreads; ++t) env_step_joints<0>(A, b, t, nthreads, smem.data());
-        for (int t = 0; t < nthreads; ++t) env_step_phase_a<0>(A, b, t, smem.data(), csc0);
+        for (int t = 0; t < nthreads; ++t) env_step_phase_a<0, true>(A, b, t, smem.data(), csc0);
         for (int t = 0; t < nthreads; ++t) {   // the device runs this on its idle wavefronts, concurrently with phase A
             if (cfg->frame_stack == 15 && cfg->c_frame_stack == 3) env_step_stack_old<15, 3, 0>(A, b, t, nthreads, ring);
             else env_step_stack_old<0, 0, 0>(A, b, t, nthreads, ring);
@@ -56,6 +57,17 @@ int hc_env_step(const HgymEnvConfig* cfg, const HgymSimTensors* sim, const HgymE
             if (cfg->frame_stack == 15 && cfg->c_frame_stack == 3) env_step_phase_b<15, 3, 0>(A, b, t, nthreads, smem.data(), csc0, ring);
             else env_step_phase_b<0, 0, 0>(A, b, t, nthreads, smem.data(), csc0, ring);
         }
+    }
+    if (cfg->num_height_points > 0 && mode == MODE_STEP)
+        for (int e = 0; e < N; ++e)
+            for (int p = 0; p < cfg->num_height_points; ++p) measure_height_point(A, e, p);
+    if (cfg->command_curriculum && mode != MODE_PRIME && command_curriculum_due(A, mode == MODE_STEP ? csc0 + 1 : csc0)) {
+        double lo, hi;                                      // command_curriculum_kernel, one lane
+        command_curriculum_move(A, st->command_range_x[0], st->command_range_x[1], lo, hi);
+        st->command_range_x[0] = lo;
+        st->command_range_x[1] = hi;
+        const RngKey rk = make_rng_key(A, csc0);
+        for (int e = 0; e < N; ++e) command_curriculum_fix_env(A, rk, e, (float)lo, (float)(hi - lo), ring);
     }
     for (int t = 0; t < nthreads; ++t) env_finalize_part1(A, t, nthreads);
     env_finalize_part2(A);

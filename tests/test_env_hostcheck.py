@@ -56,11 +56,37 @@ def test_golden_trace_host(host, golden_dir, name):
     EC.close(env.buf.view("base_euler"), G["final_base_euler"], "base_euler")
 
 
+def test_generic_options_golden_trace_host(host, golden_dir):
+    """Terrain map (custom origins, terrain curriculum, height measurements) + command curriculum: the trace recorded from
+    the reference with those options on."""
+    EC.run_generic_golden(host, golden_dir)
+
+
 @pytest.mark.parametrize("N,layout,epb,nthreads", [(37, "soa", 8, 64), (64, "aos", 16, 256), (5, "soa", 4, 32)])
 def test_random_trace_host(N, layout, epb, nthreads):
     be = EC.HostBackend(envs_per_block=epb, nthreads=nthreads)
     counts, env, o = EC.run_random_trace(be, N, steps=24, seed=100 + N, sim_layout=layout)
     assert counts["push"] == 1 and counts["timeout"] >= 1 and counts["reset"] >= 3
+
+
+@pytest.mark.parametrize("track_sum,moves", [(40.0, 1), (5.0, 0)])
+def test_generic_options_random_trace_host(track_sum, moves):
+    """Oracle vs kernel source with the terrain map, both curricula and the height measurements on; the command range widens
+    exactly when the resetting envs' mean tracking sum is above 80 % of the maximum (23.04)."""
+    be = EC.HostBackend(envs_per_block=8, nthreads=64)
+    counts, env, o = EC.run_random_trace(be, 44, steps=14, seed=321, sim_layout="soa", generic=True, track_sum=track_sum)
+    assert counts["range_moves"] == moves and counts["level_up"] >= 3 and counts["level_down"] >= 3 and counts["push"] == 1
+    assert o.cmd_range_x == ([-0.8, 1.1] if moves else [-0.3, 0.6])
+    # LeggedRobot.reset() with the options on: the terrain curriculum also runs in reset_idx(all)
+    g = torch.Generator().manual_seed(2)
+    N = 44
+    u_dof, u_cmd3 = torch.rand(N, 12, generator=g), torch.rand(N, 3, generator=g)
+    u_xy, r_level = torch.rand(N, 2, generator=g), torch.randint(0, 5, (N,), generator=g)
+    o._reset_masked(torch.ones(N, dtype=torch.bool), u_dof, u_cmd3, u_xy, r_level)
+    env.reset_all(u_dof, u_cmd3, u_xy, r_level)
+    EC.exact(env.buf.terrain_levels, o.terrain.levels, "levels after reset_all")
+    EC.close(env.buf.root_view(), o.sim.root, "root after reset_all")
+    EC.close(env.buf.view("commands"), o.commands, "commands after reset_all")
 
 
 def test_generic_frame_stack_host():
