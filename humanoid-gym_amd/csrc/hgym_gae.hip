@@ -137,11 +137,58 @@ __global__ __launch_bounds__(256) void store_step_kernel(int n, const float* __r
     dones_slot[i] = dones[i] != 0;
 }
 
+// The minibatch permutation of RolloutStorage.mini_batch_generator (rollout_storage.py:149: torch.randperm(T*N)) as a keyed
+// bijection evaluated per index: a 6-round balanced Feistel network over the next even power of two >= n, cycle-walked back
+// into [0, n) (the walk visits < 2 candidates per index on average, < 4/3 for the XBot-L batch of 245 760 in 2^18).
+// torch.randperm on the device is a radix sort of random keys + 8 merge passes (125 us per iteration at this size, measured);
+// this is one launch of a few microseconds and needs no scratch.  Any uniform shuffle serves the PPO update equally; the
+// draw is identified by (seed, draw) so that runs are reproducible and ranks can use different or equal streams.
+HG_HD uint32_t perm_mix(uint32_t x) {
+    x ^= x >> 16;
+    x *= 0x7feb352du;
+    x ^= x >> 15;
+    x *= 0x846ca68bu;
+    x ^= x >> 16;
+    return x;
+}
+HG_HD int64_t perm_index(int64_t i, int64_t n, int half_bits, uint32_t k0, uint32_t k1) {
+    const uint32_t mask = (1u << half_bits) - 1u;
+    uint64_t x = (uint64_t)i;
+    do {
+        uint32_t l = (uint32_t)(x >> half_bits) & mask, r = (uint32_t)x & mask;
+#pragma unroll
+        for (uint32_t round = 0; round < 6; ++round) {
+            const uint32_t f = perm_mix(r ^ perm_mix(k0 + round * 0x9e3779b9u) ^ k1) & mask;
+            const uint32_t t = l ^ f;
+            l = r;
+            r = t;
+        }
+        x = ((uint64_t)l << half_bits) | r;
+    } while (x >= (uint64_t)n);
+    return (int64_t)x;
+}
+__global__ __launch_bounds__(256) void randperm_kernel(int64_t n, int half_bits, uint32_t k0, uint32_t k1, int64_t* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = perm_index(i, n, half_bits, k0, k1);
+}
+
 }  // namespace hgym
 
 using namespace hgym;
 
 extern "C" {
+
+int32_t hgym_randperm(int64_t n, uint64_t seed, uint64_t draw, int64_t* out, void* stream) {
+    HG_REQUIRE(n > 0 && n <= ((int64_t)1 << 40), HGYM_E_SHAPE, "n=%lld", (long long)n);
+    HG_REQUIRE(out, HGYM_E_BADARG, "null output");
+    int half_bits = 1;
+    while (((int64_t)1 << (2 * half_bits)) < n) ++half_bits;
+    const uint64_t key = (seed ^ (draw * 0x9e3779b97f4a7c15ull)) * 0xd1342543de82ef95ull + draw;
+    const int blocks = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+    hipLaunchKernelGGL(randperm_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n, half_bits, (uint32_t)key, (uint32_t)(key >> 32), out);
+    HG_CHECK_LAUNCH("randperm_kernel");
+    return HGYM_OK;
+}
 
 int32_t hgym_store_step(int32_t n, const float* rew, const float* values, const uint8_t* time_outs, const uint8_t* dones,
                         float gamma, float* rewards_slot, uint8_t* dones_slot, void* stream) {

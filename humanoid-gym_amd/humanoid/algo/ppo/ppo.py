@@ -59,6 +59,9 @@ class _DeviceAdam:
 
 class PPO:
     actor_critic: ActorCritic
+    # minibatch permutation: "device" = hgym_randperm (keyed bijection, one launch, reproducible from the seed);
+    # "torch" = torch.randperm from torch's global generator, as the reference draws it (a device sort: 125 us per iteration)
+    permutation = "device"
     # compute precision of the dense layers: "bf16" (MFMA fast path, BASELINE config) or "f32" (parity mode)
     precision = os.environ.get("HGYM_PRECISION", "bf16")
 
@@ -123,6 +126,8 @@ class PPO:
                                              aux_coef=self.denoise_coef if aux else 0.0)
         self.last_denoise_loss = None
         self._sample_step = torch.zeros(1, dtype=torch.int64, device=self.device)
+        self._perm_seed = (torch.initial_seed() * 0x9E3779B97F4A7C15 + 0xABCD + 104729 * self._rank) & 0xFFFFFFFFFFFFFFFF
+        self._perm_draws = 0
         ac._sample_step = self._sample_step
         ac._sample_seed = 0x5EED + 7919 * self._rank
         self._hgym = hgym
@@ -191,14 +196,18 @@ class PPO:
         T, N = st.num_transitions_per_env, st.num_envs
         batch = T * N
         mb = batch // self.num_mini_batches
-        perm = torch.randperm(self.num_mini_batches * mb, device=self.device)     # one permutation for every epoch
+        # one permutation for every epoch (rollout_storage.py:149,165-170)
+        if self.permutation == "device":
+            self._perm_draws += 1
+            perm = st.permutation(self.num_mini_batches * mb, self._perm_seed, self._perm_draws)
+        else:
+            perm = torch.randperm(self.num_mini_batches * mb, device=self.device)
         fl = lambda t: t.flatten(0, 1)
         obs = fl(st.observations)
         priv = fl(st.privileged_observations) if st.privileged_observations is not None else obs
         cols = (obs, priv, fl(st.actions), st.values.view(-1), st.advantages.view(-1), st.returns.view(-1),
                 st.actions_log_prob.view(-1), fl(st.mu), fl(st.sigma))
-        net.opt_state[2:6] = 0.0
-        net.opt_state[7] = 0.0
+        net.opt_state[2:8] = 0.0               # the per-update sums [2..5], [7] (and the informational last norm [6]): one fill
         if self._ppo_cfg.aux_coef > 0.0:
             net.opt_state[10] = 0.0
         for _ in range(self.num_learning_epochs):

@@ -98,6 +98,16 @@ class RolloutStorage:
         idx = torch.cat((flat.new_tensor([-1], dtype=torch.int64), flat.nonzero(as_tuple=False)[:, 0]))
         return (idx[1:] - idx[:-1]).float().mean(), self.rewards.mean()
 
+    def permutation(self, n, seed, draw):
+        """The minibatch permutation (reference :149, torch.randperm) as one hgym_randperm launch: a bijection of [0, n) keyed
+        by (seed, draw), written into a buffer this object keeps."""
+        from hgym import _lib as L
+        if getattr(self, "_perm", None) is None or self._perm.numel() != n:
+            self._perm = torch.empty(n, dtype=torch.int64, device=self.device)
+        L.check(L.lib.hgym_randperm(n, int(seed) & 0xFFFFFFFFFFFFFFFF, int(draw), L.i64ptr(self._perm),
+                                    C.c_void_p(torch.cuda.current_stream().cuda_stream)), "hgym_randperm")
+        return self._perm
+
     def mini_batch_generator(self, num_mini_batches, num_epochs=8):
         """API-compatible generator (gathers with torch); the native PPO.update does not use it -- it hands the
         index slices to hgym_ppo_grad, which fuses the gather into the operand packing."""

@@ -263,6 +263,11 @@ int32_t hgym_env_finalize(const HgymEnvConfig* cfg, const HgymEnvState* st, cons
 int32_t hgym_store_step(int32_t n, const float* rew, const float* values, const uint8_t* time_outs,
                         const uint8_t* dones, float gamma, float* rewards_slot, uint8_t* dones_slot, void* stream);
 
+/* The minibatch permutation of RolloutStorage.mini_batch_generator (rollout_storage.py:149, torch.randperm(T*N)): out[i], i in
+ * [0, n), is a bijection of [0, n) keyed by (seed, draw) -- a 6-round Feistel network, cycle-walked; one launch, no scratch
+ * (torch.randperm on the device: a sort, 125 us per iteration at the XBot-L batch). */
+int32_t hgym_randperm(int64_t n, uint64_t seed, uint64_t draw, int64_t* out, void* stream);
+
 /* RolloutStorage.compute_returns (rollout_storage.py:122-136): GAE(lambda) as a wavefront suffix scan.
  * rewards/values/returns/advantages are (T,N) time-major fp32, dones (T,N) uint8, last_values (N,).
  * stats: 3 doubles on the device [sum adv, sum adv^2, count], accumulated (zeroed by this call). */

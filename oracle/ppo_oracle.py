@@ -251,3 +251,44 @@ def ppo_update(p, opt, storage, perm, lr, epochs=2, minibatches=4, clip=0.2, val
             sum_s += float(out["surrogate"])
     k = epochs * minibatches
     return lr, sum_v / k, sum_s / k
+
+
+# ----------------------------------------------------------------------------------------------
+# The product's minibatch permutation (hgym_randperm).  The reference draws torch.randperm(T*N) (rollout_storage.py:149); any
+# shuffle serves the update, and the product's is a keyed bijection evaluated per index.  This is its restatement for the
+# tests (numpy, vectorised over the indices): 6-round balanced Feistel over 2^(2*half_bits) >= n, cycle-walked into [0, n).
+def _perm_mix(x):
+    import numpy as np
+    x = x.astype(np.uint32)
+    x ^= x >> np.uint32(16)
+    x = (x * np.uint32(0x7feb352d)).astype(np.uint32)
+    x ^= x >> np.uint32(15)
+    x = (x * np.uint32(0x846ca68b)).astype(np.uint32)
+    x ^= x >> np.uint32(16)
+    return x
+
+
+def feistel_permutation(n, seed, draw):
+    import numpy as np
+    M64 = (1 << 64) - 1
+    half_bits = 1
+    while (1 << (2 * half_bits)) < n:
+        half_bits += 1
+    key = (((seed ^ ((draw * 0x9e3779b97f4a7c15) & M64)) * 0xd1342543de82ef95) + draw) & M64
+    k0, k1 = np.uint32(key & 0xFFFFFFFF), np.uint32(key >> 32)
+    mask = np.uint32((1 << half_bits) - 1)
+    rk = [_perm_mix(np.array([(int(k0) + r * 0x9e3779b9) & 0xFFFFFFFF], dtype=np.uint32))[0] for r in range(6)]
+    x = np.arange(n, dtype=np.uint64)
+    todo = np.ones(n, dtype=bool)
+    with np.errstate(over="ignore"):
+        while todo.any():
+            v = x[todo]
+            l = (v >> np.uint64(half_bits)).astype(np.uint32) & mask
+            r = v.astype(np.uint32) & mask
+            for q in range(6):
+                f = _perm_mix(r ^ rk[q] ^ k1) & mask
+                l, r = r, l ^ f
+            v = (l.astype(np.uint64) << np.uint64(half_bits)) | r.astype(np.uint64)
+            x[todo] = v
+            todo[todo] = v >= n
+    return x.astype(np.int64)

@@ -1,0 +1,69 @@
+"""The minibatch permutation (hgym_randperm, stands where rollout_storage.py:149 calls torch.randperm): the oracle's
+restatement is a bijection with shuffle-like statistics (CPU); the kernel reproduces it bit for bit (GPU)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "humanoid-gym_amd"))
+
+from oracle.ppo_oracle import feistel_permutation
+
+SIZES = [1, 2, 3, 7, 64, 1000, 4097, 61440, 245760]
+
+
+@pytest.mark.parametrize("n", SIZES)
+def test_oracle_permutation_is_a_bijection(n):
+    p = feistel_permutation(n, seed=0x1234_5678_9ABC, draw=3)
+    assert p.dtype == np.int64 and np.array_equal(np.sort(p), np.arange(n))
+
+
+def test_oracle_permutation_statistics():
+    n = 245760                                       # the XBot-L batch: 60 steps x 4096 envs
+    p = feistel_permutation(n, seed=5, draw=1)
+    q = feistel_permutation(n, seed=5, draw=2)
+    assert (p == q).mean() < 1e-3 and (p == np.arange(n)).mean() < 1e-3            # draws differ; almost no fixed points
+    # each of the 4 minibatches takes ~1/4 of every contiguous 4096-sample stretch of the storage (one step of all envs)
+    mb = p.reshape(4, -1)
+    share = np.stack([np.bincount(m // 4096, minlength=60) for m in mb]) / 4096.0
+    assert abs(share.mean() - 0.25) < 1e-9 and share.std() < 0.01
+    # neighbours are not kept together: the permuted neighbours of consecutive indices are ~uniformly far apart
+    d = np.abs(np.diff(p)).astype(np.float64) / n
+    assert abs(d.mean() - 1.0 / 3.0) < 0.01
+    # rank correlation with the identity is negligible
+    assert abs(np.corrcoef(p, np.arange(n))[0, 1]) < 0.01
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", SIZES)
+def test_kernel_matches_oracle(n):
+    import ctypes as C
+    from hgym import _lib as L
+    out = torch.empty(n, dtype=torch.int64, device="cuda")
+    for seed, draw in [(5, 1), (0xFFFF_FFFF_FFFF_FFFF, 77), (123456789, 0)]:
+        L.check(L.lib.hgym_randperm(n, seed, draw, L.i64ptr(out), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        assert np.array_equal(out.cpu().numpy(), feistel_permutation(n, seed, draw)), (n, seed, draw)
+
+
+@pytest.mark.gpu
+def test_ppo_update_uses_it_and_torch_mode_still_works(monkeypatch):
+    """PPO.permutation = "device" (default): no torch.randperm call in update(); "torch": the reference's draw."""
+    from humanoid.envs import task_registry
+    from humanoid.utils import get_args
+    from humanoid.algo import PPO
+    args = get_args(["--task=humanoid_ppo", "--headless", "--num_envs", "64", "--seed", "9"])
+    env, _ = task_registry.make_env(name=args.task, args=args)
+    runner, _ = task_registry.make_alg_runner(env=env, name=args.task, args=args, log_root=None)
+    calls = []
+    real = torch.randperm
+    monkeypatch.setattr(torch, "randperm", lambda *a, **k: (calls.append(a), real(*a, **k))[1])
+    runner.learn(num_learning_iterations=2, init_at_random_ep_len=False)
+    assert not calls and runner.alg._perm_draws == 2
+    perm = runner.alg.storage._perm.cpu().numpy()
+    assert np.array_equal(perm, feistel_permutation(perm.size, runner.alg._perm_seed, 2))
+    monkeypatch.setattr(PPO, "permutation", "torch")
+    runner.learn(num_learning_iterations=1, init_at_random_ep_len=False)
+    assert len(calls) == 1
