@@ -359,7 +359,7 @@ __device__ __forceinline__ void fwd_body(const FwdArgs& a, const FusedNet& n, bo
     const FusedLayer& L1 = n.layer[1];
     const FusedLayer& L2 = n.layer[2];
     const FusedLayer& L3 = n.layer[3];
-    const int train = a.train;
+    const int train = a.train & 1, train_h = a.train & 2;     // bit 0: write X0, bit 1: write H[] (both set by the update)
     // the four bias vectors -> LDS: the loads are issued here, ahead of everything else, and parked in registers; they are
     // written to LDS next to the first input chunk, so no epilogue ever waits on a cold global load
     float* bl = reinterpret_cast<float*>(smem + fused_lds_p(n, BM) + fused_lds_q(n, BM));
@@ -470,14 +470,14 @@ __device__ __forceinline__ void fwd_body(const FwdArgs& a, const FusedNet& n, bo
         mma_chunk<G1, MB, D, true, XBF>(r0, wl0, L0.KB * 64, (NC - 1) * 4, Q + ((NC - 1) & 1) * (BM * FUSED_CHUNK * 2), 8, lane, acc);
         phase_stamp(a.dbg, 2);
         if (AHEAD) prime1();
-        epilogue_elu<G1, MB>(acc, bl, nb0, P, L0.NB, train ? n.H[0] : nullptr, mbg0, lane);
+        epilogue_elu<G1, MB>(acc, bl, nb0, P, L0.NB, train_h ? n.H[0] : nullptr, mbg0, lane);
     }
     __syncthreads();
     phase_stamp(a.dbg, 3);
     if (!AHEAD) prime1();
     // ---------------------------------------------------------------- layers 1, 2: input resident in LDS
     auto prime2 = [&]() { hidden_prime<GH, D>(r2, L2, wave, lane); };
-    hidden_layer<GH, MB, NW, D, AHEAD>(r1, L1, bl + L0.N, P, L0.NB, Q, train ? n.H[1] : nullptr, mbg0, wave, lane, prime2);
+    hidden_layer<GH, MB, NW, D, AHEAD>(r1, L1, bl + L0.N, P, L0.NB, Q, train_h ? n.H[1] : nullptr, mbg0, wave, lane, prime2);
     __syncthreads();
     phase_stamp(a.dbg, 4);
     if (!AHEAD) prime2();
@@ -485,7 +485,7 @@ __device__ __forceinline__ void fwd_body(const FwdArgs& a, const FusedNet& n, bo
     auto prime3 = [&]() {
         if (wave < MB) wring_prime<1, 4>(r3, L3.Wf + lane, 0, L3.KB);
     };
-    hidden_layer<GH, MB, NW, D, AHEAD>(r2, L2, bl + L0.N + L1.N, Q, L1.NB, P, train ? n.H[2] : nullptr, mbg0, wave, lane, prime3);
+    hidden_layer<GH, MB, NW, D, AHEAD>(r2, L2, bl + L0.N + L1.N, Q, L1.NB, P, train_h ? n.H[2] : nullptr, mbg0, wave, lane, prime3);
     __syncthreads();
     phase_stamp(a.dbg, 5);
     if (!AHEAD) prime3();

@@ -795,7 +795,8 @@ struct NetRunner {
         a.M = M;
         a.idx = idx;
         if (fin) a.fin = *fin;
-        a.train = train ? 1 : 0;
+        static const int fwd_ablate = getenv("HGYM_FWD_ABLATE") ? atoi(getenv("HGYM_FWD_ABLATE")) : 0;   // profiling only: 1 no X0 stores, 2 no H stores
+        a.train = train ? (3 & ~fwd_ablate) : 0;
         a.A = cfg.num_actions;
         a.std_ = net.params;
         if (smp) {

@@ -21,7 +21,8 @@ src = torch.empty(1 << 28, device=dev, dtype=torch.uint8); dst = torch.empty_lik
 uc = timeit(lambda: dst.copy_(src), 10)
 print("calib: matmul8192 bf16 %.0f us (%.0f TF/s)  copy256MB %.0f us (%.2f TB/s r+w)" % (us, 2 * 8192**3 / us / 1e6, uc, 2 * (1 << 28) / uc / 1e6))
 
-S = B = 61440
+B = 61440
+S = int(os.environ.get('HGYM_S', B))      # storage rows the minibatch is drawn from (245760 = the real XBot-L storage)
 cfg = make_net_config(705, 219, 12, [512, 256, 128], [768, 256, 128], "bf16", B)
 net = NetBuffers(cfg, dev, learning_rate=1e-5)
 g = torch.Generator(device=dev).manual_seed(0)
@@ -34,7 +35,11 @@ act, mu_o = torch.randn(S, 12, device=dev), torch.randn(S, 12, device=dev) * 0.3
 sg_o = torch.ones(S, 12, device=dev)
 val, adv, ret = torch.randn(S, device=dev), torch.randn(S, device=dev), torch.randn(S, device=dev)
 lp_o = -12.0 + torch.randn(S, device=dev)
-idx = torch.randperm(S, device=dev).contiguous()
+idx = torch.randperm(S, device=dev)[:B].contiguous()
+if os.environ.get('HGYM_IDX_SEQ'):
+    idx = torch.arange(B, device=dev)        # the indirection without the scatter: rows 0..B-1 in order
+if os.environ.get('HGYM_SORT'):
+    idx = idx.sort().values.contiguous()      # same minibatch (as a set), ascending storage order
 if os.environ.get('HGYM_IDX0'):
     idx = torch.randint(0, 64, (S,), device=dev)   # every gather hits L2: isolates the input-latency share of mlp_fwd
 ppo = make_ppo_config(grad_norm_ready=True)      # what PPO.update passes on one rank
