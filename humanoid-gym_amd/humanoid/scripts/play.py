@@ -22,9 +22,7 @@ def play(args, steps=1200):
     env, _ = task_registry.make_env(name=args.task, args=args, env_cfg=env_cfg)
     obs = env.get_observations()
     train_cfg.runner.resume = True
-    ppo_runner, train_cfg = task_registry.make_alg_runner(env=env, name=args.task, args=args, train_cfg=train_cfg, log_root=None
-                                                          if not os.path.isdir(os.path.join(LEGGED_GYM_ROOT_DIR, "logs", train_cfg.runner.experiment_name))
-                                                          else os.path.join(LEGGED_GYM_ROOT_DIR, "logs", train_cfg.runner.experiment_name))
+    ppo_runner, train_cfg = task_registry.make_alg_runner(env=env, name=args.task, args=args, train_cfg=train_cfg)
     policy = ppo_runner.get_inference_policy(device=env.device)
     if EXPORT_POLICY:
         path = os.path.join(LEGGED_GYM_ROOT_DIR, "logs", train_cfg.runner.experiment_name, "exported", "policies")

@@ -1,0 +1,42 @@
+"""-m gpu: the three scripts a user of the reference runs, as command lines (README.md:87-104 of the reference):
+train.py (logging + checkpoints) -> play.py (loads the last run, rolls the policy, exports TorchScript) -> sim2sim.py
+(the exported actor in the deployment control loop, driven from a recorded state trace where MuJoCo is absent)."""
+import glob
+import os
+import shutil
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "humanoid-gym_amd")
+SCRIPTS = os.path.join(PKG, "humanoid", "scripts")
+
+
+def _run(*argv):
+    env = dict(os.environ, PYTHONPATH=PKG + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    p = subprocess.run([sys.executable] + list(argv), cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-3000:] + "\n" + p.stderr[-3000:]
+    return p.stdout
+
+
+@pytest.mark.parametrize("task,exp", [("humanoid_ppo", "XBot_e2e_ppo"), ("humanoid_dwl_ppo", "XBot_e2e_dwl")])
+def test_train_play_sim2sim_command_lines(task, exp, golden_dir):
+    from humanoid import LEGGED_GYM_ROOT_DIR
+    logs = os.path.join(LEGGED_GYM_ROOT_DIR, "logs", exp)
+    shutil.rmtree(logs, ignore_errors=True)
+    try:
+        out = _run(os.path.join(SCRIPTS, "train.py"), "--task=" + task, "--headless", "--num_envs", "128", "--max_iterations", "3",
+                   "--experiment_name", exp, "--run_name", "e2e")
+        assert "Learning iteration 2/3" in out and "Computation:" in out and "Value function loss:" in out
+        runs = glob.glob(os.path.join(logs, "*_e2e"))
+        assert len(runs) == 1 and os.path.exists(os.path.join(runs[0], "model_3.pt")) and os.path.exists(os.path.join(runs[0], "model_0.pt"))
+        out = _run(os.path.join(SCRIPTS, "play.py"), "--task=" + task, "--headless", "--experiment_name", exp)
+        pol = os.path.join(logs, "exported", "policies", "policy_1.pt")
+        assert os.path.exists(pol) and "Exported policy as jit script" in out
+        out = _run(os.path.join(SCRIPTS, "sim2sim.py"), "--load_model", pol, "--replay", os.path.join(golden_dir, "sim2sim_trace.npz"))
+        assert "replayed 60 policy steps" in out
+    finally:
+        shutil.rmtree(logs, ignore_errors=True)
