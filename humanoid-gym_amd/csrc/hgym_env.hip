@@ -152,7 +152,6 @@ static int32_t check_common(const HgymEnvConfig* cfg, const HgymSimTensors* sim,
     HG_REQUIRE(cfg && st, HGYM_E_BADARG, "null cfg/state");
     HG_REQUIRE(cfg->num_envs > 0, HGYM_E_SHAPE, "num_envs=%d", cfg->num_envs);
     HG_REQUIRE(cfg->frame_stack >= 1 && cfg->c_frame_stack >= 1, HGYM_E_SHAPE, "frame_stack/c_frame_stack must be >= 1");
-    HG_REQUIRE(cfg->heading_command == 1, HGYM_E_UNSUPPORTED, "only heading_command=True is implemented (XBotLCfg)");
     if (sim) HG_REQUIRE(sim->root.base && sim->dof_pos.base && sim->dof_vel.base && sim->contact.base && sim->rigid.base,
                         HGYM_E_BADARG, "null sim tensor");
     HG_REQUIRE(st->episode_length && st->counters && st->commands && st->actions, HGYM_E_BADARG, "null env state field");
@@ -209,7 +208,8 @@ static int32_t launch_step(const HgymEnvConfig* cfg, const HgymSimTensors* sim, 
     prof_begin(HGYM_PROF_ENV_STEP, s);
     const bool std_stack = cfg->frame_stack == 15 && cfg->c_frame_stack == 3;
     // the generic LeggedRobot options (HgymEnvConfig tail) have their own instantiation: off, none of their code is compiled in
-    const bool generic = cfg->custom_origins || cfg->terrain_curriculum || cfg->num_height_points > 0 || cfg->command_curriculum;
+    const bool generic = cfg->custom_origins || cfg->terrain_curriculum || cfg->num_height_points > 0 || cfg->command_curriculum ||
+                         !cfg->heading_command;
     if (std_stack && A.envs_per_block == 16 && !generic)
         hipLaunchKernelGGL((env_step_kernel<15, 3, 16, false>), dim3(blocks), dim3(256), lds, s, A);
     else if (std_stack && A.envs_per_block == 16)
@@ -276,6 +276,7 @@ int32_t hgym_env_config_default(HgymEnvConfig* c, int32_t num_envs) {
     c->cmd_x_lo = -0.3f;  c->cmd_x_span = (float)(0.6 - (-0.3));
     c->cmd_y_lo = -0.3f;  c->cmd_y_span = (float)(0.3 - (-0.3));
     c->cmd_h_lo = -3.14f; c->cmd_h_span = (float)(3.14 - (-3.14));
+    c->cmd_yaw_lo = -0.3f; c->cmd_yaw_span = (float)(0.3 - (-0.3));
     c->dof_reset_lo = -0.1f; c->dof_reset_span = (float)(0.1 - (-0.1));
     c->push_vel_lo = -0.2f;  c->push_vel_span = (float)(0.2 - (-0.2));
     c->push_ang_lo = -0.4f;  c->push_ang_span = (float)(0.4 - (-0.4));

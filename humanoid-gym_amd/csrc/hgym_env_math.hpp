@@ -293,10 +293,12 @@ HG_HD void cmd_x_range(const EnvArgs& A, float& lo, float& span) {
     }
 }
 
-HG_HD void resample_commands(const HgymEnvConfig& c, float x_lo, float x_span, float cmd[4], const float u[3]) {
+// heading = true: the third draw is the heading target (:331-332); false: the yaw rate itself (:333-334)
+HG_HD void resample_commands(const HgymEnvConfig& c, float x_lo, float x_span, float cmd[4], const float u[3], bool heading = true) {
     cmd[0] = x_span * u[0] + x_lo;
     cmd[1] = c.cmd_y_span * u[1] + c.cmd_y_lo;
-    cmd[3] = c.cmd_h_span * u[2] + c.cmd_h_lo;
+    if (heading) cmd[3] = c.cmd_h_span * u[2] + c.cmd_h_lo;
+    else cmd[2] = c.cmd_yaw_span * u[2] + c.cmd_yaw_lo;
     const float keep = (sqrtf(cmd[0] * cmd[0] + cmd[1] * cmd[1]) > 0.2f) ? 1.0f : 0.0f;
     cmd[0] *= keep;
     cmd[1] *= keep;
@@ -370,9 +372,9 @@ HG_HD StepFlags post_physics_env(const EnvArgs& A, const RngKey& rk, int64_t csc
                                 nz_uniform(A.noise.u_cmd, 6, 2, rk, e, ge, SLOT_DELAY_CMD, 3)};
             float x_lo, x_span;
             cmd_x_range<kGeneric>(A, x_lo, x_span);
-            resample_commands(c, x_lo, x_span, cmd, u);
+            resample_commands(c, x_lo, x_span, cmd, u, !kGeneric || c.heading_command);
         }
-        {
+        if (!kGeneric || c.heading_command) {
             const float fv[3] = {1.0f, 0.0f, 0.0f};
             float fw[3];
             quat_apply(root + 3, fv, fw);
@@ -655,7 +657,7 @@ HG_HD StepFlags post_physics_env(const EnvArgs& A, const RngKey& rk, int64_t csc
                                 nz_uniform(A.noise.u_cmd, 6, 5, rk, e, ge, SLOT_CMD_RESET, 2)};
             float x_lo, x_span;
             cmd_x_range<kGeneric>(A, x_lo, x_span);       // a command-curriculum move this step is applied by command_curriculum_fix
-            resample_commands(c, x_lo, x_span, cmd, u);
+            resample_commands(c, x_lo, x_span, cmd, u, !kGeneric || c.heading_command);
         }
         FG(S.feet_air_time, 0) = 0.0f;
         FG(S.feet_air_time, 1) = 0.0f;

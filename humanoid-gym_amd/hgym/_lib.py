@@ -52,6 +52,7 @@ class EnvConfig(C.Structure):
         ("custom_origins", C.c_int32), ("terrain_curriculum", C.c_int32), ("terrain_rows", C.c_int32), ("terrain_cols", C.c_int32),
         ("terrain_env_length", C.c_float), ("num_height_points", C.c_int32), ("height_rows", C.c_int32), ("height_cols", C.c_int32),
         ("terrain_border", C.c_float), ("terrain_hscale", C.c_float), ("terrain_vscale", C.c_float),
+        ("cmd_yaw_lo", C.c_float), ("cmd_yaw_span", C.c_float),
         ("command_curriculum", C.c_int32), ("max_curriculum", C.c_float),
     ]
 

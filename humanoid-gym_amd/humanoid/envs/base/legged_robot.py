@@ -82,8 +82,6 @@ class LeggedRobot(BaseTask):
             raise ValueError("Terrain mesh type not recognised. Allowed types are [plane, heightfield, trimesh]")
         if cfg.terrain.measure_heights and cfg.terrain.mesh_type == "plane":
             raise NotImplementedError("measure_heights on a plane returns zeros in the reference; there is nothing to sample")
-        if not cfg.commands.heading_command:
-            raise NotImplementedError("only heading_command=True is built (XBotLCfg)")
         c = default_env_config(self.num_envs, seed=getattr(cfg, "seed", 5), frame_stack=cfg.env.frame_stack,
                                c_frame_stack=cfg.env.c_frame_stack)
         c.decimation = cfg.control.decimation
@@ -112,6 +110,8 @@ class LeggedRobot(BaseTask):
         c.cmd_x_lo, c.cmd_x_span = r["lin_vel_x"][0], r["lin_vel_x"][1] - r["lin_vel_x"][0]
         c.cmd_y_lo, c.cmd_y_span = r["lin_vel_y"][0], r["lin_vel_y"][1] - r["lin_vel_y"][0]
         c.cmd_h_lo, c.cmd_h_span = r["heading"][0], r["heading"][1] - r["heading"][0]
+        c.cmd_yaw_lo, c.cmd_yaw_span = r["ang_vel_yaw"][0], r["ang_vel_yaw"][1] - r["ang_vel_yaw"][0]
+        c.heading_command = int(bool(cfg.commands.heading_command))
         pv, pa = cfg.domain_rand.max_push_vel_xy, getattr(cfg.domain_rand, "max_push_ang_vel", 0.0)
         c.push_vel_lo, c.push_vel_span, c.push_ang_lo, c.push_ang_span = -pv, pv - (-pv), -pa, pa - (-pa)
         for j, name in enumerate(self.dof_names):

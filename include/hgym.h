@@ -71,7 +71,8 @@ typedef struct HgymEnvConfig {
     int32_t push_interval;        /* 400 */
     int32_t push_robots;          /* 1 */
     int32_t add_noise;            /* 1 */
-    int32_t heading_command;      /* 1 (only mode supported) */
+    int32_t heading_command;      /* 1 for XBot-L: the yaw-rate command follows a sampled heading (legged_robot.py:311-314); 0: the yaw
+                                     rate itself is sampled from cmd_yaw_lo/span (:333-334) -- one of the generic options below */
     int32_t use_ref_actions;      /* 0 for XBot-L (humanoid_config.py:49); 1: actions += 2 * ref_dof_pos, IN PLACE, before the clip
                                      (humanoid_env.py:190-191) */
     float clip_actions, clip_obs; /* 18, 18 */
@@ -109,6 +110,7 @@ typedef struct HgymEnvConfig {
     int32_t num_height_points;    /* > 0: terrain.measure_heights with that many sample points per env (:316-317,743-795) */
     int32_t height_rows, height_cols;     /* shape of HgymEnvState.height_samples (Terrain.tot_rows, tot_cols) */
     float terrain_border, terrain_hscale, terrain_vscale;   /* terrain.border_size / horizontal_scale / vertical_scale */
+    float cmd_yaw_lo, cmd_yaw_span;   /* commands.ranges.ang_vel_yaw, used when heading_command = 0 */
     int32_t command_curriculum;   /* commands.curriculum: every max_episode_length common steps, if the resetting envs' mean
                                      tracking_lin_vel episode sum exceeds 80 % of its maximum, lin_vel_x widens by 0.5 each way
                                      up to +-max_curriculum (:179-180,422-431).  The live range is HgymEnvState.command_range_x. */

@@ -71,6 +71,7 @@ ADDED_MASS_RANGE = (-5.0, 5.0)
 CMD_LIN_VEL_X = (-0.3, 0.6)
 CMD_LIN_VEL_Y = (-0.3, 0.3)
 CMD_HEADING = (-3.14, 3.14)
+CMD_ANG_VEL_YAW = (-0.3, 0.3)      # humanoid_config.py ranges.ang_vel_yaw (used only with heading_command = False)
 
 # rewards, humanoid_config.py:174-216
 BASE_HEIGHT_TARGET = 0.89

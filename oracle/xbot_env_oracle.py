@@ -130,11 +130,13 @@ class XBotEnvOracle:
     """State record + the per-step functions.  All tensors are (N, k) fp32 unless noted."""
 
     def __init__(self, n, frictions=None, body_mass=None, frame_stack=C.FRAME_STACK,
-                 c_frame_stack=C.C_FRAME_STACK, use_ref_actions=False, terrain=None, command_curriculum=False, max_curriculum=1.0):
+                 c_frame_stack=C.C_FRAME_STACK, use_ref_actions=False, terrain=None, command_curriculum=False, max_curriculum=1.0,
+                 heading_command=True):
         self.n = n
         self.use_ref_actions = bool(use_ref_actions)      # cfg.env.use_ref_actions, humanoid_config.py:49 (False for XBot-L)
         # generic LeggedRobot options XBot-L leaves off (SURVEY.md 8f item 3)
         self.terrain = terrain                            # TerrainSpec or None (plane)
+        self.heading_command = bool(heading_command)         # cfg.commands.heading_command, legged_robot.py:311-314,331-334
         self.command_curriculum = bool(command_curriculum)   # cfg.commands.curriculum, legged_robot.py:179-180,422-431
         self.max_curriculum = max_curriculum
         self.cmd_range_x = [C.CMD_LIN_VEL_X[0], C.CMD_LIN_VEL_X[1]]   # python doubles, moved by the command curriculum
@@ -254,10 +256,12 @@ class XBotEnvOracle:
         m = mask
         cx = uniform(self.cmd_range_x[0], self.cmd_range_x[1], u3[:, 0])
         cy = uniform(C.CMD_LIN_VEL_Y[0], C.CMD_LIN_VEL_Y[1], u3[:, 1])
-        ch = uniform(C.CMD_HEADING[0], C.CMD_HEADING[1], u3[:, 2])
         self.commands[:, 0] = torch.where(m, cx, self.commands[:, 0])
         self.commands[:, 1] = torch.where(m, cy, self.commands[:, 1])
-        self.commands[:, 3] = torch.where(m, ch, self.commands[:, 3])
+        if self.heading_command:
+            self.commands[:, 3] = torch.where(m, uniform(C.CMD_HEADING[0], C.CMD_HEADING[1], u3[:, 2]), self.commands[:, 3])
+        else:
+            self.commands[:, 2] = torch.where(m, uniform(C.CMD_ANG_VEL_YAW[0], C.CMD_ANG_VEL_YAW[1], u3[:, 2]), self.commands[:, 2])
         keep = (torch.norm(self.commands[:, :2], dim=1) > 0.2).unsqueeze(1)
         self.commands[:, :2] = torch.where(m.unsqueeze(1), self.commands[:, :2] * keep, self.commands[:, :2])
 
@@ -485,12 +489,13 @@ class XBotEnvOracle:
         self.base_euler = euler_xyz_wrapped(quat)
         # callback :304-320
         self._resample_commands(self.ep_len % C.RESAMPLE_STEPS == 0, u_cmd[:, 0:3])
-        fwd = quat_apply(quat, self.forward)
-        heading = torch.atan2(fwd[:, 1], fwd[:, 0])
-        ang = self.commands[:, 3] - heading
-        ang = ang % TWO_PI                                   # utils/math.py:46-49 wrap_to_pi
-        ang = ang - TWO_PI * (ang > math.pi)
-        self.commands[:, 2] = torch.clip(0.5 * ang, -1.0, 1.0)
+        if self.heading_command:
+            fwd = quat_apply(quat, self.forward)
+            heading = torch.atan2(fwd[:, 1], fwd[:, 0])
+            ang = self.commands[:, 3] - heading
+            ang = ang % TWO_PI                                   # utils/math.py:46-49 wrap_to_pi
+            ang = ang - TWO_PI * (ang > math.pi)
+            self.commands[:, 2] = torch.clip(0.5 * ang, -1.0, 1.0)
         if self.terrain is not None and self.terrain.height_samples is not None:
             self.measured_heights = self._get_heights()      # :316-317
         pushed = self.common_step_counter % C.PUSH_INTERVAL == 0

@@ -122,12 +122,13 @@ class EnvUnderTest:
     """Product-side buffers + the call sequence of one vec-step in parity mode (external noise, external sim frames)."""
 
     def __init__(self, backend, N, friction, body_mass, sim_layout="soa", frame_stack=15, c_frame_stack=3, use_ref_actions=False,
-                 terrain=None, command_curriculum=None):
+                 terrain=None, command_curriculum=None, heading_command=True):
         """terrain: an oracle TerrainSpec (its initial levels are copied); command_curriculum: max_curriculum or None."""
         from hgym import EnvBuffers, default_env_config
         self.be = backend
         self.cfg = default_env_config(N, frame_stack=frame_stack, c_frame_stack=c_frame_stack)
         self.cfg.use_ref_actions = int(bool(use_ref_actions))
+        self.cfg.heading_command = int(bool(heading_command))
         self.buf = EnvBuffers(self.cfg, backend.device, sim_layout=sim_layout)
         self.buf.f["friction"].copy_(friction.view(1, N))
         self.buf.f["body_mass"].copy_(body_mass.view(1, N))
@@ -229,7 +230,7 @@ def random_terrain_spec(g, N, rows=5, cols=4, points=(7, 5)):
 
 
 def run_random_trace(backend, N, steps, seed, sim_layout="soa", frame_stack=15, c_frame_stack=3, check_every=1,
-                     use_ref_actions=False, generic=False, track_sum=40.0):
+                     use_ref_actions=False, generic=False, track_sum=40.0, heading_command=True):
     """Seeded random trace through product + oracle with identical inputs; returns event counts.
     generic: a terrain map (custom origins, terrain curriculum, height measurements) and the command curriculum are on; the
     common step counter is planted so that the command curriculum is examined inside the trace and `track_sum` (the planted
@@ -239,9 +240,11 @@ def run_random_trace(backend, N, steps, seed, sim_layout="soa", frame_stack=15, 
     bm = 10.0 + 10.0 * torch.rand(N, 1, generator=g)
     spec = random_terrain_spec(g, N) if generic else None
     o = XBotEnvOracle(N, frictions=fr, body_mass=bm, frame_stack=frame_stack, c_frame_stack=c_frame_stack,
-                      use_ref_actions=use_ref_actions, terrain=spec, command_curriculum=generic, max_curriculum=1.5)
+                      use_ref_actions=use_ref_actions, terrain=spec, command_curriculum=generic, max_curriculum=1.5,
+                      heading_command=heading_command)
     env = EnvUnderTest(backend, N, fr, bm, sim_layout=sim_layout, frame_stack=frame_stack, c_frame_stack=c_frame_stack,
-                       use_ref_actions=use_ref_actions, terrain=spec, command_curriculum=1.5 if generic else None)
+                       use_ref_actions=use_ref_actions, terrain=spec, command_curriculum=1.5 if generic else None,
+                       heading_command=heading_command)
     u_dof, u_cmd3, z_obs = torch.rand(N, 12, generator=g), torch.rand(N, 3, generator=g), torch.randn(N, 47, generator=g)
     gen_draws = lambda: (torch.rand(N, 2, generator=g), torch.randint(0, spec.max_level, (N,), generator=g)) if generic else (None, None)
     u_xy, r_level = gen_draws()

@@ -12,6 +12,7 @@ Needs /root/reference (present only in the build container).  Outputs (all small
                                     draw (scattered to full-N tables), outputs, final state
   tests/golden/env_trace_refact.npz the same with cfg.env.use_ref_actions
   tests/golden/env_trace_generic.npz  the same on a trimesh terrain map with terrain + command curricula and height measurements
+  tests/golden/env_trace_yawrate.npz  the same with cfg.commands.heading_command = False
   tests/golden/ppo_update.npz       PPO.act / process_env_step / compute_returns / update on a small net
 The oracle (oracle/*.py) is pinned against these in tests/test_oracle_golden.py; the HIP path is then
 compared against the oracle on the GPU.
@@ -124,7 +125,7 @@ def gen_policy_example():
 
 
 # ------------------------------------------------------------------------------------------------
-def gen_env_trace(R, N=32, S=36, seed=11, use_ref_actions=False, name="env_trace.npz", generic=False):
+def gen_env_trace(R, N=32, S=36, seed=11, use_ref_actions=False, name="env_trace.npz", generic=False, heading_command=True):
     """use_ref_actions=True records the second trace (env_trace_refact.npz): cfg.env.use_ref_actions, humanoid_env.py:190-191
     -- `actions += ref_action` IN PLACE on the caller's tensor, before the clip.
     generic=True records the third (env_trace_generic.npz): the LeggedRobot options XBot-L leaves off -- a trimesh terrain map
@@ -139,6 +140,7 @@ def gen_env_trace(R, N=32, S=36, seed=11, use_ref_actions=False, name="env_trace
     else:
         e, cfg = H.make_ref_env(N, frictions=fr, body_mass=bm)
     cfg.env.use_ref_actions = bool(use_ref_actions)
+    cfg.commands.heading_command = bool(heading_command)    # False: the yaw rate is sampled directly (legged_robot.py:333-334)
     ids_log = []
     orig_resample = e._resample_commands
     orig_reset_dofs = e._reset_dofs
@@ -310,6 +312,7 @@ def gen_env_trace(R, N=32, S=36, seed=11, use_ref_actions=False, name="env_trace
                final_base_ang_vel=npy(e.base_ang_vel), final_projected_gravity=npy(e.projected_gravity),
                final_base_euler=npy(e.base_euler_xyz))
     out["use_ref_actions"] = np.array(bool(use_ref_actions))
+    out["heading_command"] = np.array(bool(heading_command))
     np.savez_compressed(os.path.join(HERE, name), **out)
     if generic:
         lv = np.concatenate([out["terrain_levels0"][None], out["terrain_levels"]])
@@ -412,6 +415,9 @@ if __name__ == "__main__":
     if "--only-generic" in sys.argv:
         gen_env_trace(R, N=32, S=20, seed=13, name="env_trace_generic.npz", generic=True)
         sys.exit(0)
+    if "--only-yawrate" in sys.argv:
+        gen_env_trace(R, N=16, S=14, seed=14, name="env_trace_yawrate.npz", heading_command=False)
+        sys.exit(0)
     gen_constants(R)
     if "--constants-only" not in sys.argv:
         gen_gae(R)
@@ -419,4 +425,5 @@ if __name__ == "__main__":
         gen_env_trace(R)
         gen_env_trace(R, N=16, S=16, seed=12, use_ref_actions=True, name="env_trace_refact.npz")
         gen_env_trace(R, N=32, S=20, seed=13, name="env_trace_generic.npz", generic=True)
+        gen_env_trace(R, N=16, S=14, seed=14, name="env_trace_yawrate.npz", heading_command=False)
         gen_ppo_update(R)

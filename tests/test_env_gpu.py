@@ -18,12 +18,13 @@ def hip():
     return EC.HipBackend()
 
 
-@pytest.mark.parametrize("name", ["env_trace.npz", "env_trace_refact.npz"])
+@pytest.mark.parametrize("name", ["env_trace.npz", "env_trace_refact.npz", "env_trace_yawrate.npz"])
 def test_golden_trace_gpu(hip, golden_dir, name):
     """The traces recorded from the reference's own XBotLFreeEnv.step: XBot-L defaults, and cfg.env.use_ref_actions = True."""
     G = np.load(os.path.join(golden_dir, name))
     N = G["friction"].shape[0]
-    env = EC.EnvUnderTest(hip, N, T(G["friction"]), T(G["body_mass"]), sim_layout="aos", use_ref_actions=bool(G["use_ref_actions"]))
+    env = EC.EnvUnderTest(hip, N, T(G["friction"]), T(G["body_mass"]), sim_layout="aos", use_ref_actions=bool(G["use_ref_actions"]),
+                          heading_command=bool(G["heading_command"]) if "heading_command" in G.files else True)
     env.prime(T(G["prime_u_dof"]), T(G["prime_u_cmd"]), T(G["prime_z_obs"]))
     hip.sync()
     EC.close(env.buf.obs, G["prime_obs"], "prime obs")
@@ -174,3 +175,9 @@ def test_generic_options_fused_step_and_env_surface():
     keep = ~dones
     # (the step samples before the physics of the NEXT step moves the base: compare on the current pose directly)
     assert h.shape == env.measured_heights.shape and bool(torch.isfinite(h).all())
+
+
+def test_yaw_rate_commands_random_trace_gpu(hip):
+    """cfg.commands.heading_command = False, alone and together with the terrain / curriculum options."""
+    EC.run_random_trace(hip, 300, steps=10, seed=77, heading_command=False)
+    EC.run_random_trace(hip, 300, steps=8, seed=78, generic=True, heading_command=False)

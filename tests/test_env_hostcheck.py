@@ -17,12 +17,13 @@ def host():
     return EC.HostBackend(envs_per_block=8, nthreads=64)
 
 
-@pytest.mark.parametrize("name", ["env_trace.npz", "env_trace_refact.npz"])
+@pytest.mark.parametrize("name", ["env_trace.npz", "env_trace_refact.npz", "env_trace_yawrate.npz"])
 def test_golden_trace_host(host, golden_dir, name):
     """The reference's own recorded traces (XBot-L defaults; cfg.env.use_ref_actions = True) through the kernel source."""
     G = np.load(os.path.join(golden_dir, name))
     N = G["friction"].shape[0]
-    env = EC.EnvUnderTest(host, N, T(G["friction"]), T(G["body_mass"]), sim_layout="aos", use_ref_actions=bool(G["use_ref_actions"]))
+    env = EC.EnvUnderTest(host, N, T(G["friction"]), T(G["body_mass"]), sim_layout="aos", use_ref_actions=bool(G["use_ref_actions"]),
+                          heading_command=bool(G["heading_command"]) if "heading_command" in G.files else True)
     env.prime(T(G["prime_u_dof"]), T(G["prime_u_cmd"]), T(G["prime_z_obs"]))
     EC.close(env.buf.obs, G["prime_obs"], "prime obs")
     EC.close(env.buf.priv_obs, G["prime_priv"], "prime priv")
@@ -87,6 +88,13 @@ def test_generic_options_random_trace_host(track_sum, moves):
     EC.exact(env.buf.terrain_levels, o.terrain.levels, "levels after reset_all")
     EC.close(env.buf.root_view(), o.sim.root, "root after reset_all")
     EC.close(env.buf.view("commands"), o.commands, "commands after reset_all")
+
+
+def test_yaw_rate_commands_random_trace_host():
+    """cfg.commands.heading_command = False (legged_robot.py:311-314,333-334) together with the other generic options."""
+    be = EC.HostBackend(envs_per_block=8, nthreads=64)
+    EC.run_random_trace(be, 20, steps=10, seed=77, heading_command=False)
+    EC.run_random_trace(be, 44, steps=8, seed=78, generic=True, heading_command=False)
 
 
 def test_generic_frame_stack_host():

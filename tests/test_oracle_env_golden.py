@@ -13,7 +13,7 @@ from oracle.xbot_env_oracle import XBotEnvOracle
 T = lambda a: torch.from_numpy(np.asarray(a))
 
 
-TRACES = ["env_trace.npz", "env_trace_refact.npz"]
+TRACES = ["env_trace.npz", "env_trace_refact.npz", "env_trace_yawrate.npz"]      # defaults | use_ref_actions | heading_command=False
 
 
 def _load(golden_dir, name="env_trace.npz"):
@@ -22,7 +22,8 @@ def _load(golden_dir, name="env_trace.npz"):
 
 def _prime(G):
     N = G["friction"].shape[0]
-    o = XBotEnvOracle(N, frictions=T(G["friction"]), body_mass=T(G["body_mass"]), use_ref_actions=bool(G["use_ref_actions"]))
+    o = XBotEnvOracle(N, frictions=T(G["friction"]), body_mass=T(G["body_mass"]), use_ref_actions=bool(G["use_ref_actions"]),
+                      heading_command=bool(G["heading_command"]) if "heading_command" in G.files else True)
     o.prime(T(G["prime_u_dof"]), T(G["prime_u_cmd"]), T(G["prime_z_obs"]))
     return o
 
@@ -77,9 +78,12 @@ def test_trace_matches_reference(golden_dir, name):
         saw["resample"] += int((o.ep_len % C.RESAMPLE_STEPS == 0).sum() - reset.sum())
         saw["stale"] += int((not info["any_reset"]) and bool(o.extras_time_outs.any()))
     # the trace must have exercised every event class
-    assert saw["reset"] > 10 and saw["timeout"] >= 3 and saw["push"] == 1
+    assert saw["reset"] > 10 and saw["timeout"] >= 2 and saw["push"] == 1
     if bool(G["use_ref_actions"]):
         assert float(np.abs(G["actions_in_after"] - G["actions_in"]).max()) > 0.5       # the feature really was on
+    if "heading_command" in G.files and not bool(G["heading_command"]):
+        assert float(np.abs(G["commands"][:, :, 3]).max()) == 0.0                       # no heading target is ever drawn
+        assert float(np.abs(G["commands"][:, :, 2]).max()) <= 0.3 + 1e-6
     for k in ("feet_air_time", "last_contacts", "feet_height", "last_feet_z", "last_actions", "last_last_actions",
               "last_dof_vel", "last_root_vel", "ref_dof_pos", "base_lin_vel", "base_ang_vel", "projected_gravity"):
         assert torch.equal(getattr(o, k), T(G["final_" + k])), k
