@@ -51,14 +51,14 @@ struct FusedNet {
     int64_t ldx;
     __bf16* X0;         // bf16 copy of the gathered input, block layout, CB = 2 * layer[0].KB   (train only)
     __bf16* H[3];       // hidden activations, block layout, CB = layer[l].N / 16                 (train only)
-    __bf16* dZ[4];      // pre-activation gradients; dZ[3] (32 columns) is written by the loss kernel
+    __bf16* dZ[4];      // pre-activation gradients; dZ[3] (32 * layer[3].NBB columns) is written by the loss kernel
     float* out;         // fp32 head output (M, layer[3].N) row-major
     int64_t ldo;
 };
 
 HG_HD int fused_lds_p(const FusedNet& n, int BM) { return BM * (n.layer[0].N > n.layer[2].N ? n.layer[0].N : n.layer[2].N) * 2; }
 // fp32 copies of the four bias vectors (fetched at kernel entry so no epilogue waits on a cold global load) + 16 pad
-HG_HD int fused_lds_bias(const FusedNet& n) { return (n.layer[0].N + n.layer[1].N + n.layer[2].N + 16 + 16) * 4; }
+HG_HD int fused_lds_bias(const FusedNet& n) { return (n.layer[0].N + n.layer[1].N + n.layer[2].N + 16 * n.layer[3].NB + 16) * 4; }
 HG_HD int fused_lds_q(const FusedNet& n, int BM) {
     const int a = 2 * BM * FUSED_CHUNK * 2, b = BM * n.layer[1].N * 2;
     return a > b ? a : b;
@@ -326,7 +326,7 @@ __device__ __forceinline__ void phase_stamp(long long* dbg, int slot) {
 
 struct FwdArgs {
     long long* dbg;
-    FusedNet net[2];
+    FusedNet net[3];           // 0 actor, 1 critic, 2 auxiliary head (launched on its own: net0 = 2, one grid row)
     int net0;                 // net index of blockIdx.y == 0
     int M;
     const int64_t* idx;       // optional row gather
@@ -344,7 +344,7 @@ struct FwdArgs {
     FinArgs fin;              // postponed env-step finaliser riding in this launch (blockIdx.y == nets, one workgroup); fin.N == 0: none
 };
 
-template <int BM, int NW, int D, int G1>
+template <int BM, int NW, int D, int G1, bool WIDE = false>
 __device__ __forceinline__ void fwd_body(const FwdArgs& a, const FusedNet& n, bool is_actor, char* smem) {
     constexpr int MB = BM / 16;
     constexpr int IT = BM * 32 / (NW * 64);           // staging items per thread per chunk (BM rows x 32 float4)
@@ -363,9 +363,9 @@ __device__ __forceinline__ void fwd_body(const FwdArgs& a, const FusedNet& n, bo
     // the four bias vectors -> LDS: the loads are issued here, ahead of everything else, and parked in registers; they are
     // written to LDS next to the first input chunk, so no epilogue ever waits on a cold global load
     float* bl = reinterpret_cast<float*>(smem + fused_lds_p(n, BM) + fused_lds_q(n, BM));
-    constexpr int BIT = (768 + 768 + 768 + 16 + NW * 64 - 1) / (NW * 64);     // fused_supported: hidden widths <= 768
+    constexpr int BIT = (768 + 768 + 768 + 96 + NW * 64 - 1) / (NW * 64);     // fused_supported: hidden widths <= 768, head <= 96
     float bv[BIT];
-    const int bn0 = L0.N, bn1 = bn0 + L1.N, bn2 = bn1 + L2.N, bn3 = bn2 + 16;
+    const int bn0 = L0.N, bn1 = bn0 + L1.N, bn2 = bn1 + L2.N, bn3 = bn2 + (WIDE ? 16 * L3.NB : 16);
 #pragma unroll
     for (int u = 0; u < BIT; ++u) {
         int i = tid + u * NW * 64;
@@ -539,6 +539,22 @@ __device__ __forceinline__ void fwd_body(const FwdArgs& a, const FusedNet& n, bo
             lp += __shfl_xor(lp, 32, 64);
             if (q == 0 && m < a.M) a.logp[m] = lp;
         }
+        // heads wider than one n-block (the auxiliary net, its own instantiation): the remaining blocks, same wave, one after
+        // the other
+        for (int nb = 1; WIDE && nb < L3.NB; ++nb) {
+            const u32x4* wl = L3.Wf + (int64_t)nb * L3.KB * 64 + lane;
+            wring_prime<1, 4>(r3, wl, 0, L3.KB);
+            hacc[0][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (L3.KB % 4 == 0) mma_stream<1, 1, 4>(r3, wl, 0, L3.KB, P + wave * CB3 * 512, CB3, lane, hacc);
+            else mma_ring<1, 1, 4>(r3, wl, 0, 0, L3.KB, L3.KB, P + wave * CB3 * 512, CB3, lane, hacc);
+            if (m < a.M) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int col = nb * 16 + 4 * q + e;
+                    if (col < No) n.out[(int64_t)m * n.ldo + col] = hacc[0][0][e] + bl[L0.N + L1.N + L2.N + col];
+                }
+            }
+        }
     }
     phase_stamp(a.dbg, 6);
 }
@@ -554,6 +570,10 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(const FwdArgs a) {
     const FusedNet& n = a.net[which];
     const int g1 = n.layer[0].NB / NW;     // first hidden width 256 / 512 / 768
     constexpr int U = 16 / NW;             // n-blocks per wave per 256 columns
+    if (n.layer[3].NB > 1) {               // wide head: the auxiliary net (first hidden width 512 only)
+        if (g1 == 2 * U) fwd_body<BM, NW, D, 2 * U, true>(a, n, false, smem);
+        return;
+    }
     if (g1 == 2 * U) fwd_body<BM, NW, D, 2 * U>(a, n, which == 0, smem);
     else if (g1 == 3 * U) fwd_body<BM, NW, D, 3 * U>(a, n, which == 0, smem);
     else if (g1 == U) fwd_body<BM, NW, D, U>(a, n, which == 0, smem);
@@ -562,7 +582,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(const FwdArgs a) {
 // ================================================================================================ backward (dX chain)
 struct BwdArgs {
     long long* dbg;
-    FusedNet net[2];
+    FusedNet net[3];           // 0 actor, 1 critic, 2 auxiliary head (launched on its own: net0 = 2, one grid row)
     int net0;
     int M;
 };
@@ -621,8 +641,9 @@ __device__ __forceinline__ void bwd_body(const BwdArgs& a, const FusedNet& n, ch
     const int m0 = blockIdx.x * BM;
     const int64_t mbg0 = m0 >> 4;
     const int N0 = n.layer[0].N, N1 = n.layer[1].N, N2 = n.layer[2].N;
-    char* R0 = smem;                    // head gradient tile: BM x 32
-    char* R1 = R0 + BM * 64;            // dZ2 tile: BM x N2
+    const int NBB3 = n.layer[3].NBB;    // head gradient tile: BM x 32 * NBB3 (1 for the actor / critic heads)
+    char* R0 = smem;
+    char* R1 = R0 + BM * 64 * NBB3;     // dZ2 tile: BM x N2
     char* R2 = R1 + BM * N2 * 2;        // dZ1 tile: BM x N1
     constexpr bool AHEAD = NW <= 8;
     constexpr int GH = NW <= 8 ? 2 : 1;
@@ -630,10 +651,10 @@ __device__ __forceinline__ void bwd_body(const BwdArgs& a, const FusedNet& n, ch
     WRing<GH, D> rb;
     WRing<G0, D> rc;
     phase_stamp(a.dbg, 0);
-    bwd_prime<1, D>(ra, n.layer[3].WTf, N2 / 16, n.layer[3].NBB, wave, lane);
+    bwd_prime<1, D>(ra, n.layer[3].WTf, N2 / 16, NBB3, wave, lane);
     {
-        const u32x4* src = reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(n.dZ[3]) + mbg0 * 2 * 512);
-        if (tid < BM * 4) reinterpret_cast<u32x4*>(R0)[tid] = src[tid];
+        const u32x4* src = reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(n.dZ[3]) + mbg0 * 2 * NBB3 * 512);
+        for (int i = tid; i < BM * 4 * NBB3; i += NW * 64) reinterpret_cast<u32x4*>(R0)[i] = src[i];
     }
     __syncthreads();
     auto prime_b = [&]() { bwd_prime<GH, D>(rb, n.layer[2].WTf, N1 / 16, n.layer[2].NBB, wave, lane); };
@@ -641,7 +662,7 @@ __device__ __forceinline__ void bwd_body(const BwdArgs& a, const FusedNet& n, ch
     auto none = [&]() {};
     phase_stamp(a.dbg, 1);
     // l = 2: through W3 (head)
-    bwd_step<1, MB, NW, D, AHEAD>(ra, n.layer[3].WTf, N2 / 16, n.layer[3].NBB, R0, 2, R1, n.dZ[2], n.H[2], mbg0, wave, lane, prime_b);
+    bwd_step<1, MB, NW, D, AHEAD>(ra, n.layer[3].WTf, N2 / 16, NBB3, R0, 2 * NBB3, R1, n.dZ[2], n.H[2], mbg0, wave, lane, prime_b);
     __syncthreads();
     phase_stamp(a.dbg, 2);
     if (!AHEAD) prime_b();

@@ -44,7 +44,8 @@ struct WsLayout {
     int64_t maxM, Mp;        // max batch and its contraction padding (row stride of every transposed buffer)
     int64_t P;               // total parameters
     int64_t Ps;              // slab stride (P rounded up so every slab starts 256-byte aligned)
-    NetLayout net[3];        // 0 actor, 1 critic, 2 auxiliary head (optional, always the generic layer-by-layer layout)
+    NetLayout net[3];        // 0 actor, 1 critic, 2 auxiliary head (optional)
+    int fused_aux;           // 1: the auxiliary head also has the fused layout (its own launches of the three fused kernels)
     int nnets;               // 2 or 3
     int64_t aux_p0;          // first parameter of the auxiliary head in the flat vector (= P when absent)
     int splits;
@@ -71,6 +72,14 @@ static bool fused_supported(const HgymNetConfig* c) {
         if (d[4] > 16) return false;
     }
     return true;
+}
+// the auxiliary head through the fused kernels: same trunk constraints, head up to 96 columns (three 32-wide contraction blocks)
+static bool fused_aux_supported(const HgymNetConfig* c) {
+    if (c->aux_layers != 4 || getenv("HGYM_NO_FUSED_AUX")) return false;
+    const int32_t* d = c->aux_dims;
+    if (d[1] != 512) return false;         // the wide-head instantiation of the forward exists for this first width only
+    if (d[2] % 128 || d[2] > 768 || d[3] % 128 || d[3] > 768) return false;
+    return d[4] > 16 && d[4] <= 96;
 }
 constexpr int MAX_SPLITS = 32;
 
@@ -104,12 +113,13 @@ static int32_t ws_layout(const HgymNetConfig* c, WsLayout* w) {
                        c->aux_target_offset + c->aux_dims[c->aux_layers] <= c->num_priv && c->actor_layers + c->critic_layers + c->aux_layers <= 16,
                    HGYM_E_SHAPE, "auxiliary head: input must be num_obs, targets must lie inside the privileged row");
     w->nnets = c->aux_layers > 0 ? 3 : 2;
+    w->fused_aux = (w->fused && c->aux_layers > 0 && fused_aux_supported(c)) ? 1 : 0;
     w->aux_p0 = -1;
     for (int which = 0; which < w->nnets; ++which) {
         NetLayout& n = w->net[which];
         n.L = which == 0 ? c->actor_layers : (which == 1 ? c->critic_layers : c->aux_layers);
         const int32_t* dims = which == 0 ? c->actor_dims : (which == 1 ? c->critic_dims : c->aux_dims);
-        const bool fused_net = w->fused && which < 2;
+        const bool fused_net = w->fused && (which < 2 || w->fused_aux);
         if (which == 2) w->aux_p0 = poff;
         for (int l = 0; l < n.L; ++l) {
             LayerLayout& y = n.layer[l];
@@ -146,7 +156,7 @@ static int32_t ws_layout(const HgymNetConfig* c, WsLayout* w) {
                 n.Hb[l] = take(w->Mpad * (int64_t)n.layer[l].N * 2);
                 n.dZb[l] = take(w->Mpad * (int64_t)n.layer[l].N * 2);
             }
-            n.dZb[3] = take(w->Mpad * 32 * 2);
+            n.dZb[3] = take(w->Mpad * 32 * n.layer[3].NBBf * 2);
         }
     }
     w->P = poff;
@@ -243,6 +253,45 @@ __global__ __launch_bounds__(256) void aux_mse_kernel(int B, int Bp, int No, con
         }
     } else if (i < Bp) {
         for (int j = 0; j < No; ++j) dYT[(int64_t)j * ldt + i] = from_f32<T>(0.0f);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) se += __shfl_down(se, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = se;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(&opt[10], (double)(red[0] + red[1] + red[2] + red[3]) / ((double)B * (double)No));
+}
+
+// The same for the fused path: dL/dy as bf16 in block layout (row block m >> 4, CB3 column blocks of 16: block (mb, cb) at
+// (mb * CB3 + cb) * 512 bytes, 32 bytes per row), zero in the padding columns No..16*CB3 and in the padding rows B..Bp.
+__global__ __launch_bounds__(256) void aux_mse_fused_kernel(int B, int Bp, int No, int CB3, const float* __restrict__ y,
+                                                            const float* __restrict__ priv, int64_t ldp, int off,
+                                                            const int64_t* __restrict__ idx, float coef, __bf16* __restrict__ dZ3,
+                                                            double* __restrict__ opt) {
+    __shared__ float red[4];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    float se = 0.0f;
+    if (i < Bp) {
+        char* row = reinterpret_cast<char*>(dZ3) + ((int64_t)(i >> 4) * CB3) * 512 + (i & 15) * 32;
+        const float* t = i < B ? priv + idx[i] * ldp + off : nullptr;
+        const float g = 2.0f * coef / ((float)B * (float)No);
+        for (int cb = 0; cb < CB3; ++cb) {
+            float v[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int j = cb * 16 + e;
+                float d = 0.0f;
+                if (t && j < No) {
+                    d = y[(int64_t)i * No + j] - t[j];
+                    se += d * d;
+                }
+                v[e] = g * d;
+            }
+            const u32x2 p0 = pack_bf16x4(v[0], v[1], v[2], v[3]), p1 = pack_bf16x4(v[4], v[5], v[6], v[7]);
+            const u32x2 p2 = pack_bf16x4(v[8], v[9], v[10], v[11]), p3 = pack_bf16x4(v[12], v[13], v[14], v[15]);
+            u32x4* dst = reinterpret_cast<u32x4*>(row + (int64_t)cb * 512);
+            dst[0] = (u32x4){p0[0], p0[1], p1[0], p1[1]};
+            dst[1] = (u32x4){p2[0], p2[1], p3[0], p3[1]};
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) se += __shfl_down(se, o, 64);
@@ -686,7 +735,7 @@ struct NetRunner {
         for (int which = 0; which < w.nnets; ++which)
             for (int l = 0; l < w.net[which].L; ++l) {
                 const LayerLayout& y = w.net[which].layer[l];
-                const bool fused_net = w.fused && which < 2;      // the auxiliary head always runs layer by layer
+                const bool fused_net = w.fused && (which < 2 || w.fused_aux);
                 Segment& a = t.s[t.n++];
                 a.off = y.w_off;
                 a.rows = y.N;
@@ -708,7 +757,9 @@ struct NetRunner {
                 b.off = y.b_off;
                 b.rows = y.N;
                 b.cols = 1;
-                if (fused_net && with_slabs && l < w.net[which].L - 1) b.splits = w.dw_splits;   // hidden-layer bias grads come from the slabs
+                // bias gradients that come from the slabs: hidden layers (the dW kernel's column sums of dZ); the actor / critic
+                // head biases are written by ppo_scalars_kernel, the auxiliary head's is a column sum like the others
+                if (fused_net && with_slabs && (l < w.net[which].L - 1 || which == 2)) b.splits = w.dw_splits;
             }
         return t;
     }
@@ -785,8 +836,8 @@ struct NetRunner {
     }
 
     // forward of `nets` networks starting at `first` in ONE launch; xs/outs indexed by net id
-    int32_t fused_forward(int first, int nets, int M, const float* const xs[2], const int64_t ldxs[2], const int64_t* idx, float* const outs[2],
-                          const int64_t ldos[2], bool train, const SampleOut* smp, const FinArgs* fin = nullptr) {
+    int32_t fused_forward(int first, int nets, int M, const float* const xs[3], const int64_t ldxs[3], const int64_t* idx, float* const outs[3],
+                          const int64_t ldos[3], bool train, const SampleOut* smp, const FinArgs* fin = nullptr) {
         HG_REQUIRE(M > 0 && M <= w.maxM, HGYM_E_SHAPE, "batch %d exceeds max_batch %lld", M, (long long)w.maxM);
         FwdArgs a;
         memset(&a, 0, sizeof(a));
@@ -827,10 +878,10 @@ struct NetRunner {
         const int B = b.B, A = cfg.num_actions;
         float* mu = at<float>(w.net[0].out_f32);
         float* val = at<float>(w.net[1].out_f32);
-        const float* xs[2] = {b.obs, b.priv};
-        const int64_t ldxs[2] = {cfg.num_obs, cfg.num_priv};
-        float* outs[2] = {mu, val};
-        const int64_t ldos[2] = {A, 1};
+        const float* xs[3] = {b.obs, b.priv, nullptr};
+        const int64_t ldxs[3] = {cfg.num_obs, cfg.num_priv, 0};
+        float* outs[3] = {mu, val, nullptr};
+        const int64_t ldos[3] = {A, 1, 0};
         int32_t rc = fused_forward(0, 2, B, xs, ldxs, b.idx, outs, ldos, true, nullptr);
         if (rc) return rc;
         const int Bp = (int)round_up(B, 64);
@@ -868,13 +919,7 @@ struct NetRunner {
             }
             g.M = B;
             g.dbg = phase_buffer((int64_t)(Bp / 64) * 2);
-            static size_t attr_lds = 0;
-            if (lds > attr_lds) {
-                if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_bwd_kernel<64, 16, 2>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)lds) != hipSuccess)
-                    HG_FAIL(HGYM_E_LAUNCH, "cannot reserve %zu bytes of LDS for mlp_bwd_kernel", lds);
-                attr_lds = lds;
-            }
+            if (reserve_bwd_lds(lds)) HG_FAIL(HGYM_E_LAUNCH, "cannot reserve %zu bytes of LDS for mlp_bwd_kernel", lds);
             prof_begin(HGYM_PROF_MLP_BWD, s);
             hipLaunchKernelGGL((mlp_bwd_kernel<64, 16, 2>), dim3(Bp / 64, 2), dim3(1024), lds, s, g);
             double fl = 0.0;
@@ -934,10 +979,10 @@ struct NetRunner {
     int32_t act(int M, const float* obs, const float* priv, const float* z, uint64_t seed, const int64_t* step, float* actions, float* mu,
                 float* sigma, float* logp, float* values, const FinArgs* fin = nullptr) {
         if (w.fused) {
-            const float* xs[2] = {obs, priv};
-            const int64_t ldxs[2] = {cfg.num_obs, cfg.num_priv};
-            float* outs[2] = {mu, values};
-            const int64_t ldos[2] = {cfg.num_actions, 1};
+            const float* xs[3] = {obs, priv, nullptr};
+            const int64_t ldxs[3] = {cfg.num_obs, cfg.num_priv, 0};
+            float* outs[3] = {mu, values, nullptr};
+            const int64_t ldos[3] = {cfg.num_actions, 1, 0};
             const SampleOut smp = {z, seed, step, actions, sigma, logp};
             return fused_forward(0, 2, M, xs, ldxs, nullptr, outs, ldos, false, &smp, fin);
         }
@@ -956,11 +1001,11 @@ struct NetRunner {
     }
 
     int32_t forward(int which, int M, const float* x, int64_t ldx, const int64_t* idx, float* y_out, int64_t ld_out, bool train) {
-        if (w.fused && which < 2) {
-            const float* xs[2] = {x, x};
-            const int64_t ldxs[2] = {ldx, ldx};
-            float* outs[2] = {y_out, y_out};
-            const int64_t ldos[2] = {ld_out, ld_out};
+        if (w.fused && (which < 2 || w.fused_aux)) {
+            const float* xs[3] = {x, x, x};
+            const int64_t ldxs[3] = {ldx, ldx, ldx};
+            float* outs[3] = {y_out, y_out, y_out};
+            const int64_t ldos[3] = {ld_out, ld_out, ld_out};
             return fused_forward(which, 1, M, xs, ldxs, idx, outs, ldos, train, nullptr);
         }
         const NetLayout& n = w.net[which];
@@ -1065,7 +1110,84 @@ struct NetRunner {
     // Auxiliary (denoising) head, HgymNetConfig::aux_*: forward on the gathered observation rows, MSE against the target
     // columns of the gathered privileged rows, backward.  Leaves its weight gradients in the split-K slabs and its bias
     // gradients in net.grads; the caller's slab reduction finishes them together with everything else.
+    // one high-water mark of the dynamic-LDS attribute for every user of mlp_bwd_kernel (the attribute belongs to the function)
+    static bool reserve_bwd_lds(size_t lds) {
+        static size_t cur = 0;
+        if (lds <= cur) return false;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_bwd_kernel<64, 16, 2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess)
+            return true;
+        cur = lds;
+        return false;
+    }
+
+    // The auxiliary head through the fused kernels: its own launches of mlp_fwd (one grid row, writes its X0 / H), the MSE
+    // kernel (dZ3 in block layout), mlp_bwd and dw_kernel_rs (four products into the slabs the common reduction sums).
+    int32_t fused_aux_grad(const HgymPPOConfig& ppo, const HgymBatch& b) {
+        const NetLayout& n = w.net[2];
+        const int B = b.B, No = n.layer[3].N;
+        const int Bp = (int)round_up(B, 64);
+        float* y = at<float>(n.out_f32);
+        int32_t rc = forward(2, B, b.obs, cfg.num_obs, b.idx, y, No, true);
+        if (rc) return rc;
+        const int CB3 = 2 * n.layer[3].NBBf;
+        hipLaunchKernelGGL(aux_mse_fused_kernel, dim3(ceil_div(Bp, 256)), dim3(256), 0, s, B, Bp, No, CB3, y, b.priv, (int64_t)cfg.num_priv,
+                           cfg.aux_target_offset, b.idx, ppo.aux_coef, at<__bf16>(n.dZb[3]), net.opt_state);
+        HG_CHECK_LAUNCH("aux_mse_fused_kernel");
+        {
+            BwdArgs g;
+            memset(&g, 0, sizeof(g));
+            g.net[2] = fused_net(2, nullptr, 0, nullptr, 0);
+            g.net0 = 2;
+            g.M = B;
+            const size_t lds = (size_t)64 * 64 * n.layer[3].NBBf + (size_t)64 * 2 * (n.layer[2].N + n.layer[1].N);
+            if (reserve_bwd_lds(lds)) HG_FAIL(HGYM_E_LAUNCH, "cannot reserve %zu bytes of LDS for mlp_bwd_kernel", lds);
+            prof_begin(HGYM_PROF_MLP_BWD, s);
+            hipLaunchKernelGGL((mlp_bwd_kernel<64, 16, 2>), dim3(Bp / 64, 1), dim3(1024), lds, s, g);
+            double fl = 0.0;
+            for (int l = 1; l < 4; ++l) fl += 2.0 * (double)B * n.layer[l].K * n.layer[l].N;
+            prof_end(HGYM_PROF_MLP_BWD, s, fl);
+            HG_CHECK_LAUNCH("mlp_bwd_kernel(aux)");
+        }
+        {
+            DwArgs d;
+            memset(&d, 0, sizeof(d));
+            int tile = 0;
+            double fl = 0.0;
+            for (int l = 0; l < 4; ++l) {
+                const LayerLayout& yl = n.layer[l];
+                DwProduct& p = d.p[d.np++];
+                p.Z = at<__bf16>(n.dZb[l]);
+                p.CBz = l < 3 ? yl.N / 16 : CB3;
+                p.X = l == 0 ? at<__bf16>(n.X0b) : at<__bf16>(n.Hb[l - 1]);
+                p.CBx = l == 0 ? 2 * yl.KBf : yl.K / 16;
+                p.N = yl.N;
+                p.K = yl.K;
+                p.w_off = yl.w_off;
+                p.b_off = yl.b_off;            // every bias gradient of this net is a column sum of dZ
+                p.tiles_n = ceil_div(yl.N, 128);
+                p.tiles_k = ceil_div(yl.K, 128);
+                p.tile0 = tile;
+                tile += p.tiles_n * p.tiles_k;
+                fl += 2.0 * (double)B * yl.N * yl.K;
+            }
+            d.total_tiles = tile;
+            d.splits = w.dw_splits;
+            d.steps_total = Bp / 32;
+            d.steps_per_split = ceil_div(d.steps_total, w.dw_splits);
+            d.slabs = at<float>(w.slabs);
+            d.slab_stride = w.Ps;
+            d.zeros = at<char>(w.zeros);
+            prof_begin(HGYM_PROF_DW, s);
+            hipLaunchKernelGGL(dw_kernel_rs<3>, dim3(tile * (int)round_up(w.dw_splits, 8)), dim3(DW_THREADS), 2 * DW_STAGE_BYTES, s, d);
+            prof_end(HGYM_PROF_DW, s, fl);
+            HG_CHECK_LAUNCH("dw_kernel_rs(aux)");
+        }
+        return HGYM_OK;
+    }
+
     int32_t aux_grad(const HgymPPOConfig& ppo, const HgymBatch& b) {
+        if (w.fused_aux) return fused_aux_grad(ppo, b);
         const NetLayout& n = w.net[2];
         const LayerLayout& last = n.layer[n.L - 1];
         const int B = b.B, No = last.N;

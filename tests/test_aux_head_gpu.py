@@ -7,10 +7,13 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
-AUX_H, AUX_OUT, AUX_OFF = [256, 128, 64], 73, 146
+AUX_OUT, AUX_OFF = 73, 146
+# two head shapes: [256, 128, 64] falls outside the fused kernels' layer shapes and runs layer by layer (generic GEMMs);
+# [512, 256, 128] (the humanoid_dwl_ppo task's) runs through the fused forward / backward / weight-gradient kernels in bf16
+AUX_SHAPES = {"generic": [256, 128, 64], "fused": [512, 256, 128]}
 
 
-def _nets(precision, B):
+def _nets(precision, B, AUX_H=AUX_SHAPES["generic"]):
     from hgym import NetBuffers, make_net_config
     torch.manual_seed(3)
     out = []
@@ -39,7 +42,7 @@ def _batch(S, B):
     return cols, idx, make_batch(*cols, idx)
 
 
-def _torch_denoiser(net):
+def _torch_denoiser(net, AUX_H):
     dims = [705] + AUX_H + [AUX_OUT]
     layers = []
     for l in range(len(dims) - 1):
@@ -51,11 +54,13 @@ def _torch_denoiser(net):
     return torch.nn.Sequential(*layers)
 
 
-@pytest.mark.parametrize("precision,tol", [("f32", 2e-4), ("bf16", 4e-2)])
-def test_aux_head_forward_loss_and_gradient_vs_autograd(precision, tol):
+@pytest.mark.parametrize("precision,tol,shape", [("f32", 2e-4, "generic"), ("bf16", 4e-2, "generic"), ("bf16", 4e-2, "fused"),
+                                                 ("f32", 2e-4, "fused")])
+def test_aux_head_forward_loss_and_gradient_vs_autograd(precision, tol, shape):
     from hgym import make_ppo_config
     S, B, coef = 900, 700, 0.5
-    plain, full = _nets(precision, B)
+    AUX_H = AUX_SHAPES[shape]
+    plain, full = _nets(precision, B, AUX_H)
     assert full.P == plain.P + sum(v.numel() for k, v in full.views.items() if k.startswith("denoiser"))
     cols, idx, batch = _batch(S, B)
     ppo_plain, ppo_full = make_ppo_config(), make_ppo_config(aux_coef=coef)
@@ -69,7 +74,7 @@ def test_aux_head_forward_loss_and_gradient_vs_autograd(precision, tol):
     for k in gp:
         assert torch.equal(gp[k], gf[k]), k
     # the head against autograd
-    model = _torch_denoiser(full)
+    model = _torch_denoiser(full, AUX_H)
     obs, priv = cols[0][idx], cols[1][idx]
     y = model(obs)
     mse = ((y - priv[:, AUX_OFF:AUX_OFF + AUX_OUT]) ** 2).mean()
@@ -86,12 +91,13 @@ def test_aux_head_forward_loss_and_gradient_vs_autograd(precision, tol):
             assert err <= tol, (l, nm, err)
 
 
-def test_joint_update_moves_the_head_and_lowers_its_loss():
+@pytest.mark.parametrize("shape", ["generic", "fused"])
+def test_joint_update_moves_the_head_and_lowers_its_loss(shape):
     """A few joint Adam steps (PPO gradient + head gradient, one clip) at the BASELINE minibatch size: the head's MSE on the
     batch falls, everything stays finite, the head's operand copies follow its master weights."""
     from hgym import make_ppo_config
     S = B = 61440
-    _, full = _nets("bf16", B)
+    _, full = _nets("bf16", B, AUX_SHAPES[shape])
     cols, idx, batch = _batch(S, B)
     ppo = make_ppo_config(aux_coef=1.0, grad_norm_ready=True)
     losses = []
