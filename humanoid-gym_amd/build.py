@@ -54,6 +54,27 @@ def build(force=False, verbose=True):
     return LIB
 
 
+def build_variant(name, flags, verbose=False):
+    """Experiment builds for same-box A/B runs (tools/gpu_variants.sh): every source compiled with extra flags (-DHGYM_...)
+    into lib/variants/<name>/libhgym_hip.so; selected at run time with HGYM_LIB=<path>.  Never loaded by default."""
+    vdir = os.path.join(LIBDIR, "variants", name)
+    os.makedirs(vdir, exist_ok=True)
+    objs = []
+    for f in sorted(x for x in os.listdir(CSRC) if x.endswith(".hip")):
+        obj = os.path.join(vdir, f.replace(".hip", ".o"))
+        cmd = [HIPCC] + COMMON + EXTRA.get(f, []) + list(flags) + ["-c", os.path.join(CSRC, f), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        objs.append(obj)
+    lib = os.path.join(vdir, "libhgym_hip.so")
+    subprocess.check_call([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", lib] + objs)
+    return lib
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[1] == "--variant":      # build.py --variant <name> <flags...>
+        print(build_variant(sys.argv[2], sys.argv[3:]))
+        sys.exit(0)
     build(force="--force" in sys.argv)
     print(LIB)

@@ -69,6 +69,29 @@ __device__ __forceinline__ u32x2 pack_bf16x4(float a, float b, float c, float d)
     bf16x4 v = {(__bf16)a, (__bf16)b, (__bf16)c, (__bf16)d};
     return __builtin_bit_cast(u32x2, v);
 }
+// Streaming accesses (data touched once per launch) carry the non-temporal hint so that they do not push the weight
+// fragments, which every workgroup re-reads, out of the XCD's L2: HGYM_NT bit 0 = input gather loads, bit 1 = X0 / H stores
+// of the forward, bit 2 = H loads / dZ stores of the dZ chain.  Same-box A/B per minibatch (B = 61 440, storage 245 760 rows):
+// forward 265.6 -> 257.6..262.8 us (bit 0 alone 255), dZ chain 134.4 -> 127.5 us, dW (reads what those wrote) 185 -> 181 us.
+#ifndef HGYM_NT
+#define HGYM_NT 7
+#endif
+typedef f32x4 f32x4_u4 __attribute__((aligned(4)));
+template <bool NT>
+__device__ __forceinline__ F4 ld_stream_f4(const float* p) {
+    if (NT) return __builtin_bit_cast(F4, __builtin_nontemporal_load(reinterpret_cast<const f32x4_u4*>(p)));
+    return *reinterpret_cast<const F4*>(p);
+}
+template <bool NT>
+__device__ __forceinline__ void st_stream_u2(char* p, u32x2 v) {
+    if (NT) __builtin_nontemporal_store(v, reinterpret_cast<u32x2*>(p));
+    else *reinterpret_cast<u32x2*>(p) = v;
+}
+template <bool NT>
+__device__ __forceinline__ u32x2 ld_stream_u2(const char* p) {
+    if (NT) return __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(p));
+    return *reinterpret_cast<const u32x2*>(p);
+}
 __device__ __forceinline__ float bf16_bits_to_f32(unsigned int lo16) { return __builtin_bit_cast(float, lo16 << 16); }
 
 // ---- weight stream ------------------------------------------------------------------------------------------------------
@@ -276,7 +299,7 @@ __device__ __forceinline__ void epilogue_elu(f32x4 (&acc)[MB][G], const float* _
             for (int e = 0; e < 4; ++e) v[e] = elu_f(acc[i][g][e] + b.v[e]);
             const u32x2 pk = pack_bf16x4(v[0], v[1], v[2], v[3]);
             *reinterpret_cast<u32x2*>(out_lds + (i * CBo + nb0 + g) * 512 + loff) = pk;
-            if (Hg) *reinterpret_cast<u32x2*>(reinterpret_cast<char*>(Hg) + ((mbg0 + i) * CBo + nb0 + g) * 512 + loff) = pk;
+            if (Hg) st_stream_u2<(HGYM_NT & 2) != 0>(reinterpret_cast<char*>(Hg) + ((mbg0 + i) * CBo + nb0 + g) * 512 + loff, pk);
         }
     }
 }
@@ -420,7 +443,7 @@ __device__ __forceinline__ void fwd_body(const FwdArgs& a, const FusedNet& n, bo
             const int col = c * FUSED_CHUNK + f4 * 4;
             const int cc = col < L0.K - 4 ? col : L0.K - 4;
 #pragma unroll
-            for (int u = 0; u < IT; ++u) stg[u] = *reinterpret_cast<const F4*>(srow[u] + cc);
+            for (int u = 0; u < IT; ++u) stg[u] = ld_stream_f4<(HGYM_NT & 1) != 0>(srow[u] + cc);
         };
         auto stage_write = [&](int c, int buf) {
             char* dst = Q + buf * (BM * FUSED_CHUNK * 2);
@@ -444,8 +467,8 @@ __device__ __forceinline__ void fwd_body(const FwdArgs& a, const FusedNet& n, bo
                 const int inblk = (lrow[u] & 15) * 32 + (f4 & 3) * 8;
                 *reinterpret_cast<u32x2*>(dst + ((lrow[u] >> 4) * 8 + (f4 >> 2)) * 512 + inblk) = pk;
                 if (train)
-                    *reinterpret_cast<u32x2*>(reinterpret_cast<char*>(n.X0) +
-                                              ((mbg0 + (lrow[u] >> 4)) * CB0 + c * 8 + (f4 >> 2)) * 512 + inblk) = pk;
+                    st_stream_u2<(HGYM_NT & 2) != 0>(reinterpret_cast<char*>(n.X0) +
+                                                     ((mbg0 + (lrow[u] >> 4)) * CB0 + c * 8 + (f4 >> 2)) * 512 + inblk, pk);
             }
         };
         const int nb0 = wave * G1;
@@ -615,7 +638,7 @@ __device__ __forceinline__ void bwd_step(WRing<GR, D>& R, const u32x4* __restric
         for (int i = 0; i < MB; ++i)
 #pragma unroll
             for (int g = 0; g < G; ++g)
-                aux[i][g] = *reinterpret_cast<const u32x2*>(reinterpret_cast<const char*>(Hg) + ((mbg0 + i) * NBo + nb0 + g) * 512 + loff);
+                aux[i][g] = ld_stream_u2<(HGYM_NT & 4) != 0>(reinterpret_cast<const char*>(Hg) + ((mbg0 + i) * NBo + nb0 + g) * 512 + loff);
 #pragma unroll
         for (int i = 0; i < MB; ++i)
 #pragma unroll
@@ -628,7 +651,7 @@ __device__ __forceinline__ void bwd_step(WRing<GR, D>& R, const u32x4* __restric
                 for (int e = 0; e < 4; ++e) d[e] = acc[i][g][e] * ((y[e] > 0.0f) ? 1.0f : (y[e] + 1.0f));   // elu'(z) from y = elu(z)
                 const u32x2 pk = pack_bf16x4(d[0], d[1], d[2], d[3]);
                 if (out_lds) *reinterpret_cast<u32x2*>(out_lds + (i * NBo + nb0 + g) * 512 + loff) = pk;
-                *reinterpret_cast<u32x2*>(reinterpret_cast<char*>(dZg) + ((mbg0 + i) * NBo + nb0 + g) * 512 + loff) = pk;
+                st_stream_u2<(HGYM_NT & 4) != 0>(reinterpret_cast<char*>(dZg) + ((mbg0 + i) * NBo + nb0 + g) * 512 + loff, pk);
             }
     }
     if (AHEAD && !primed) prime_next();

@@ -66,6 +66,7 @@ out = net.act(o4, p4, seed=1, step_counter=step_c)
 t = timeit(lambda: net.act(o4, p4, seed=1, step_counter=step_c, out=out), 50)
 print("policy_act M=4096: %.1f us" % t)
 M = 61440
-out2 = net.act(obs, priv, seed=1, step_counter=step_c)
-t = timeit(lambda: net.act(obs, priv, seed=1, step_counter=step_c, out=out2), 20)
+obs_m, priv_m = obs[:M], priv[:M]       # (HGYM_S may have made the storage larger than the net's max batch)
+out2 = net.act(obs_m, priv_m, seed=1, step_counter=step_c)
+t = timeit(lambda: net.act(obs_m, priv_m, seed=1, step_counter=step_c, out=out2), 20)
 print("policy_act M=61440 (64-row tiles, no activation stores, no gather): %.1f us" % t)

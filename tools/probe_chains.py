@@ -73,7 +73,7 @@ def run(k, join):
     return e0.elapsed_time(e1) * 1e3 / 10 / STEPS
 
 
-for k in (1, 2, 4, 8):
+for k in [int(x) for x in os.environ.get("HGYM_CHAINS", "1,2,4,8").split(",")]:
     for join in (False, True):
         if k == 1 and join:
             continue
