@@ -283,10 +283,25 @@ __device__ __forceinline__ void mma_chunk(WRing<GR, D>& R, const u32x4* __restri
     }
 }
 
+// ELU of the bf16 path: exp(z) as v_exp_f32(z * log2 e).  The libm expf the fp32 parity path keeps (elu_f) is ~15 VALU
+// instructions per element (argument split, ldexp, two range selects) and the epilogues were VALU-bound on them; the result
+// is rounded to bf16 (2^-8 relative) right after, against this form's <= 1e-6 relative error for |z| <= 18.
+// HGYM_ELU_FAST=0 restores elu_f.
+#ifndef HGYM_ELU_FAST
+#define HGYM_ELU_FAST 1
+#endif
+__device__ __forceinline__ float elu_bf(float z) {
+#if HGYM_ELU_FAST
+    return z > 0.0f ? z : (__builtin_amdgcn_exp2f(z * 1.4426950408889634f) - 1.0f);
+#else
+    return elu_f(z);
+#endif
+}
+
 // bias + ELU, bf16, -> LDS block layout (next layer's input) and, when Hg != null, the same blocks in HBM
-template <int G, int MB>
-__device__ __forceinline__ void epilogue_elu(f32x4 (&acc)[MB][G], const float* __restrict__ bias, int nb0, char* out_lds, int CBo,
-                                             __bf16* __restrict__ Hg, int64_t mbg0, int lane) {
+template <int G, int MB, bool STORE>
+__device__ __forceinline__ void epilogue_elu_t(f32x4 (&acc)[MB][G], const float* __restrict__ bias, int nb0, char* out_lds, int CBo,
+                                               __bf16* __restrict__ Hg, int64_t mbg0, int lane) {
     const int r = lane & 15, q = lane >> 4;
     const int loff = r * 32 + q * 8;
 #pragma unroll
@@ -296,12 +311,19 @@ __device__ __forceinline__ void epilogue_elu(f32x4 (&acc)[MB][G], const float* _
         for (int i = 0; i < MB; ++i) {
             float v[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = elu_f(acc[i][g][e] + b.v[e]);
+            for (int e = 0; e < 4; ++e) v[e] = elu_bf(acc[i][g][e] + b.v[e]);
             const u32x2 pk = pack_bf16x4(v[0], v[1], v[2], v[3]);
             *reinterpret_cast<u32x2*>(out_lds + (i * CBo + nb0 + g) * 512 + loff) = pk;
-            if (Hg) st_stream_u2<(HGYM_NT & 2) != 0>(reinterpret_cast<char*>(Hg) + ((mbg0 + i) * CBo + nb0 + g) * 512 + loff, pk);
+            if (STORE) st_stream_u2<(HGYM_NT & 2) != 0>(reinterpret_cast<char*>(Hg) + ((mbg0 + i) * CBo + nb0 + g) * 512 + loff, pk);
         }
     }
+}
+// (the store decision is wave-uniform and taken once here, not per block inside the unrolled epilogue)
+template <int G, int MB>
+__device__ __forceinline__ void epilogue_elu(f32x4 (&acc)[MB][G], const float* __restrict__ bias, int nb0, char* out_lds, int CBo,
+                                             __bf16* __restrict__ Hg, int64_t mbg0, int lane) {
+    if (Hg) epilogue_elu_t<G, MB, true>(acc, bias, nb0, out_lds, CBo, Hg, mbg0, lane);
+    else epilogue_elu_t<G, MB, false>(acc, bias, nb0, out_lds, CBo, Hg, mbg0, lane);
 }
 
 template <int G, int MB>
