@@ -421,11 +421,13 @@ __device__ __forceinline__ void fwd_body(const FwdArgs& a, const FusedNet& n, bo
     // sampling epilogue inputs (head waves of the actor): fetched now, used ~20 us later
     constexpr bool HOIST = NW <= 8;      // the 16-wave tiles have no registers to park them in (they spill)
     int64_t step_pre = 0;
-    float std_pre[4] = {1.0f, 1.0f, 1.0f, 1.0f};
+    float std_pre[4] = {1.0f, 1.0f, 1.0f, 1.0f}, lsg_pre[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     if (HOIST && is_actor && a.sample && wave < BM / 16) {
         if (!a.z && a.step) step_pre = a.step[0];
 #pragma unroll
         for (int e = 0; e < 4; ++e) std_pre[e] = a.std_[4 * q + e < a.A ? 4 * q + e : 0];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) lsg_pre[e] = logf(std_pre[e]);      // under the first input load instead of in the tail
     }
     auto bias_to_lds = [&]() {
 #pragma unroll
@@ -573,7 +575,7 @@ __device__ __forceinline__ void fwd_body(const FwdArgs& a, const FusedNet& n, bo
                     const float sg = mu[e] * 0.0f + (HOIST ? std_pre[e] : a.std_[j]);      // actor_critic.py:113
                     const float act = mu[e] + sg * zz[e];
                     const float d = act - mu[e];
-                    lp += -(d * d) / (2.0f * sg * sg) - logf(sg) - 0.9189385332046727f;
+                    lp += -(d * d) / (2.0f * sg * sg) - (HOIST ? lsg_pre[e] : logf(sg)) - 0.9189385332046727f;
                     if (m < a.M) {
                         a.actions[(int64_t)m * A + j] = act;
                         a.sigma[(int64_t)m * A + j] = sg;
