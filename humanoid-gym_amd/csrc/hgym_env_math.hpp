@@ -304,12 +304,33 @@ HG_HD void resample_commands(const HgymEnvConfig& c, float x_lo, float x_span, f
     cmd[1] *= keep;
 }
 
+// exp / sqrt of the reward terms.  On the device: v_exp_f32(x * log2 e) and v_sqrt_f32 (1 ulp; the exponent scaling adds
+// <= |x| * 1e-7 relative, i.e. < 2e-6 for the arguments that do not underflow) instead of libm's ~15 / ~10 instruction
+// sequences -- 16 exponentials and 6 roots sit on the single-wave per-env chain of the step kernel.  Nothing thresholded
+// (masks, termination, the command dead-band) goes through these.  The host emulation keeps libm.  HGYM_ENV_FAST=0: libm.
+#ifndef HGYM_ENV_FAST
+#define HGYM_ENV_FAST 1
+#endif
+HG_HD float r_exp(float x) {
+#if defined(__HIP_DEVICE_COMPILE__) && HGYM_ENV_FAST
+    return __builtin_amdgcn_exp2f(x * 1.4426950408889634f);
+#else
+    return expf(x);
+#endif
+}
+HG_HD float r_sqrt(float x) {
+#if defined(__HIP_DEVICE_COMPILE__) && HGYM_ENV_FAST
+    return __builtin_amdgcn_sqrtf(x);
+#else
+    return sqrtf(x);
+#endif
+}
 HG_HD float dist_reward(const HgymEnvConfig& c, float ax, float ay, float bx, float by, float max_df) {
     const float dx = ax - bx, dy = ay - by;
-    const float d = sqrtf(dx * dx + dy * dy);
+    const float d = r_sqrt(dx * dx + dy * dy);
     const float d_min = clampf(d - c.min_dist, -0.5f, 0.0f);
     const float d_max = clampf(d - max_df, 0.0f, 0.5f);
-    return (expf(-fabsf(d_min) * 100.0f) + expf(-fabsf(d_max) * 100.0f)) / 2.0f;
+    return (r_exp(-fabsf(d_min) * 100.0f) + r_exp(-fabsf(d_max) * 100.0f)) / 2.0f;
 }
 
 struct StepFlags {
@@ -455,13 +476,13 @@ HG_HD StepFlags post_physics_env(const EnvArgs& A, const RngKey& rk, int64_t csc
                     const float d = FG(S.last_root_vel, i) - root[7 + i];
                     a2 += d * d;
                 }
-                term[1] = expf(-sqrtf(a2) * 3.0f);
+                term[1] = r_exp(-r_sqrt(a2) * 3.0f);
             }
             // 2 base_height :374-384
             {
                 const float mh = (fpos[0][2] * stance[0] + fpos[1][2] * stance[1]) / (stance[0] + stance[1]);
                 const float bh = root[2] - (mh - 0.05f);
-                term[2] = expf(-fabsf(bh - c.base_height_target) * 100.0f);
+                term[2] = r_exp(-fabsf(bh - c.base_height_target) * 100.0f);
             }
             // 3 collision :523-528
             term[3] = (bn > 0.1f) ? 1.0f : 0.0f;
@@ -473,9 +494,9 @@ HG_HD StepFlags post_physics_env(const EnvArgs& A, const RngKey& rk, int64_t csc
                     jd[j] = q[j] - c.default_dof_pos[j];
                     all2 += jd[j] * jd[j];
                 }
-                float yr = sqrtf(jd[0] * jd[0] + jd[1] * jd[1]) + sqrtf(jd[6] * jd[6] + jd[7] * jd[7]);
+                float yr = r_sqrt(jd[0] * jd[0] + jd[1] * jd[1]) + r_sqrt(jd[6] * jd[6] + jd[7] * jd[7]);
                 yr = clampf(yr - 0.1f, 0.0f, 50.0f);
-                term[4] = expf(-yr * 100.0f) - 0.01f * sqrtf(all2);
+                term[4] = r_exp(-yr * 100.0f) - 0.01f * r_sqrt(all2);
             }
             // 5 dof_acc :516-521 ; 6 dof_vel :509-514 ; 17 torques :502-507
             {
@@ -521,10 +542,10 @@ HG_HD StepFlags post_physics_env(const EnvArgs& A, const RngKey& rk, int64_t csc
                 float r9 = 0.0f, r10 = 0.0f, r12 = 0.0f;
 #pragma unroll
                 for (int f = 0; f < 2; ++f) {
-                    const float fn = sqrtf(fxyz[f][0] * fxyz[f][0] + fxyz[f][1] * fxyz[f][1] + fxyz[f][2] * fxyz[f][2]);
+                    const float fn = r_sqrt(fxyz[f][0] * fxyz[f][0] + fxyz[f][1] * fxyz[f][1] + fxyz[f][2] * fxyz[f][2]);
                     r9 += clampf(fn - c.max_contact_force, 0.0f, 400.0f);
                     r10 += (contact[f] == stance[f]) ? 1.0f : -0.3f;
-                    r12 += sqrtf(sqrtf(fvxy[f][0] * fvxy[f][0] + fvxy[f][1] * fvxy[f][1])) * contact[f];
+                    r12 += r_sqrt(r_sqrt(fvxy[f][0] * fvxy[f][0] + fvxy[f][1] * fvxy[f][1])) * contact[f];
                 }
                 term[9] = r9;
                 term[10] = r10 / 2.0f;
@@ -541,8 +562,8 @@ HG_HD StepFlags post_physics_env(const EnvArgs& A, const RngKey& rk, int64_t csc
                     const float d = q[j] - FG(S.ref_dof_pos, j);
                     e2 += d * d;
                 }
-                const float en = sqrtf(e2);
-                term[13] = expf(-2.0f * en) - 0.2f * clampf(en, 0.0f, 0.5f);
+                const float en = r_sqrt(e2);
+                term[13] = r_exp(-2.0f * en) - 0.2f * clampf(en, 0.0f, 0.5f);
             }
             // 15 low_speed :469-500
             {
@@ -559,21 +580,21 @@ HG_HD StepFlags post_physics_env(const EnvArgs& A, const RngKey& rk, int64_t csc
                 term[15] = r * ((ac > 0.1f) ? 1.0f : 0.0f);
             }
             // 16 orientation :346-353
-            term[16] = (expf(-(fabsf(eul[0]) + fabsf(eul[1])) * 10.0f) +
-                        expf(-sqrtf(grav[0] * grav[0] + grav[1] * grav[1]) * 20.0f)) / 2.0f;
+            term[16] = (r_exp(-(fabsf(eul[0]) + fabsf(eul[1])) * 10.0f) +
+                        r_exp(-r_sqrt(grav[0] * grav[0] + grav[1] * grav[1]) * 20.0f)) / 2.0f;
             // 18 track_vel_hard :408-425 ; 19 tracking_ang_vel :436-444 ; 20 tracking_lin_vel :427-434
             {
                 const float ex = cmd[0] - blv[0], ey = cmd[1] - blv[1];
                 const float le2 = ex * ex + ey * ey;
-                const float le = sqrtf(le2);
+                const float le = r_sqrt(le2);
                 const float ae = fabsf(cmd[2] - bav[2]);
-                term[18] = (expf(-le * 10.0f) + expf(-ae * 10.0f)) / 2.0f - 0.2f * (le + ae);
+                term[18] = (r_exp(-le * 10.0f) + r_exp(-ae * 10.0f)) / 2.0f - 0.2f * (le + ae);
                 const float d = cmd[2] - bav[2];
-                term[19] = expf(-(d * d) * c.tracking_sigma);
-                term[20] = expf(-le2 * c.tracking_sigma);
+                term[19] = r_exp(-(d * d) * c.tracking_sigma);
+                term[20] = r_exp(-le2 * c.tracking_sigma);
             }
             // 21 vel_mismatch_exp :396-406
-            term[21] = (expf(-(blv[2] * blv[2]) * 10.0f) + expf(-sqrtf(bav[0] * bav[0] + bav[1] * bav[1]) * 5.0f)) / 2.0f;
+            term[21] = (r_exp(-(blv[2] * blv[2]) * 10.0f) + r_exp(-r_sqrt(bav[0] * bav[0] + bav[1] * bav[1]) * 5.0f)) / 2.0f;
 
 #pragma unroll
             for (int k = 0; k < HGYM_NUM_REWARDS; ++k) {
