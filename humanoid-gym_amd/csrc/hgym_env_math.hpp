@@ -224,12 +224,21 @@ HG_HD void synth_joint(const EnvArgs& A, int e, int N, int j) {
 // tab: this env's kPhysDraws draws
 HG_HD void synth_rest_env(const EnvArgs& A, const float* tab, int e, int N) {
     const HgymEnvConfig& c = A.cfg;
+    // every input is read before the first store: the stores below go through the same untyped float pointers, so a read
+    // placed after one of them cannot be moved above it by the compiler and costs its own LDS round trip on this
+    // single-wave chain
+    float d[kPhysDraws];
+#pragma unroll
+    for (int i = 0; i < kPhysDraws; ++i) d[i] = tab[i];
+    const float r3 = sget(A.sim.root, e, 3), r4 = sget(A.sim.root, e, 4), r5 = sget(A.sim.root, e, 5);
+    const int64_t ep_next = A.st.episode_length[e] + 1;
+    tab = d;
     const float* n = tab + 4;
     const float* m = tab + 20;
     // root: mean-reverting orientation walk, small height jitter, gaussian velocities
-    float qx = 0.9f * sget(A.sim.root, e, 3) + 0.05f * n[0];
-    float qy = 0.9f * sget(A.sim.root, e, 4) + 0.05f * n[1];
-    float qz = 0.9f * sget(A.sim.root, e, 5) + 0.05f * n[2];
+    float qx = 0.9f * r3 + 0.05f * n[0];
+    float qy = 0.9f * r4 + 0.05f * n[1];
+    float qz = 0.9f * r5 + 0.05f * n[2];
     const float inv = 1.0f / sqrtf(qx * qx + qy * qy + qz * qz + 1.0f);
     sset(A.sim.root, e, 3, qx * inv);
     sset(A.sim.root, e, 4, qy * inv);
@@ -239,7 +248,7 @@ HG_HD void synth_rest_env(const EnvArgs& A, const float* tab, int e, int N) {
 #pragma unroll
     for (int i = 0; i < 6; ++i) sset(A.sim.root, e, 7 + i, 0.3f * n[3 + i]);
     // contacts: feet load follows the gait clock, rare base-link hits end episodes (~ every 500 steps)
-    const float s = sinf(kTwoPi * gait_phase(c, A.st.episode_length[e] + 1));
+    const float s = sinf(kTwoPi * gait_phase(c, ep_next));
     float stance[2];
     stance_from_sin(s, stance);
     const float uf[2] = {tab[16], tab[17]};
@@ -377,6 +386,50 @@ HG_HD StepFlags post_physics_env(const EnvArgs& A, const RngKey& rk, int64_t csc
     }
     int reset = 0, time_out = 0;
     float rew = 0.0f;
+    // Everything the step arithmetic reads from the state / sim tensors is fetched HERE, before the first store.  All of it
+    // goes through untyped float pointers (on the device: into the LDS shadow), so a read placed after a store cannot be
+    // hoisted above it and pays its own LDS round trip; this function is one quarter-filled wavefront's serial chain.
+    float la[12], lla[12], ldv[12], tqv[12], rdp[12], lrv[6], esum[HGYM_NUM_REWARDS];
+    float lcon[2], fat[2], fhs[2], lfz[2], pf[2], pt[3], org[3], bxyz[3];
+    float fpos[2][3], fvxy[2][2], kxy[2][2], fxyz[2][3];
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+        la[j] = FG(S.last_actions, j);
+        lla[j] = FG(S.last_last_actions, j);
+        ldv[j] = FG(S.last_dof_vel, j);
+        tqv[j] = FG(S.torques, j);
+        rdp[j] = FG(S.ref_dof_pos, j);
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) lrv[i] = FG(S.last_root_vel, i);
+#pragma unroll
+    for (int k = 0; k < HGYM_NUM_REWARDS; ++k) esum[k] = FG(S.episode_sums, k);
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+        lcon[f] = FG(S.last_contacts, f);
+        fat[f] = FG(S.feet_air_time, f);
+        fhs[f] = FG(S.feet_height, f);
+        lfz[f] = FG(S.last_feet_z, f);
+        pf[f] = FG(S.push_force, f);
+        const int fb = A.rigid_comp[f], kb = A.rigid_comp[2 + f];
+        fpos[f][0] = sget(A.sim.rigid, e, fb + 0);
+        fpos[f][1] = sget(A.sim.rigid, e, fb + 1);
+        fpos[f][2] = sget(A.sim.rigid, e, fb + 2);
+        fvxy[f][0] = sget(A.sim.rigid, e, fb + 7);
+        fvxy[f][1] = sget(A.sim.rigid, e, fb + 8);
+        kxy[f][0] = sget(A.sim.rigid, e, kb + 0);
+        kxy[f][1] = sget(A.sim.rigid, e, kb + 1);
+        fxyz[f][0] = sget(A.sim.contact, e, A.contact_comp[1 + f] + 0);
+        fxyz[f][1] = sget(A.sim.contact, e, A.contact_comp[1 + f] + 1);
+        fxyz[f][2] = fz[f];
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        pt[i] = FG(S.push_torque, i);
+        org[i] = FG(S.env_origins, i);
+        bxyz[i] = sget(A.sim.contact, e, A.contact_comp[0] + i);
+    }
+    const float friction0 = FG(S.friction, 0), body_mass0 = FG(S.body_mass, 0);
 
     if (mode == MODE_STEP) {
         ep += 1;                                                     // legged_robot.py:128
@@ -411,12 +464,15 @@ HG_HD StepFlags post_physics_env(const EnvArgs& A, const RngKey& rk, int64_t csc
             const float py = c.push_vel_span * nz_uniform(A.noise.u_push, 5, 1, rk, e, ge, SLOT_PUSH, 1) + c.push_vel_lo;
             FG(S.push_force, 0) = px;
             FG(S.push_force, 1) = py;
+            pf[0] = px;
+            pf[1] = py;
             root[7] = px;
             root[8] = py;
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 const float t = c.push_ang_span * nz_uniform(A.noise.u_push, 5, 2 + i, rk, e, ge, SLOT_PUSH, 2 + i) + c.push_ang_lo;
                 FG(S.push_torque, i) = t;
+                pt[i] = t;
                 root[10 + i] = t;
             }
             sset(A.sim.root, e, 7, root[7]);
@@ -427,9 +483,7 @@ HG_HD StepFlags post_physics_env(const EnvArgs& A, const RngKey& rk, int64_t csc
         }
         // check_termination :156-161
         {
-            const float bx = sget(A.sim.contact, e, A.contact_comp[0] + 0);
-            const float by = sget(A.sim.contact, e, A.contact_comp[0] + 1);
-            const float bz = sget(A.sim.contact, e, A.contact_comp[0] + 2);
+            const float bx = bxyz[0], by = bxyz[1], bz = bxyz[2];
             const float bn = sqrtf(bx * bx + by * by + bz * bz);
             time_out = ep > (int64_t)c.max_episode_length;
             reset = (bn > 1.0f) || time_out;
@@ -438,31 +492,15 @@ HG_HD StepFlags post_physics_env(const EnvArgs& A, const RngKey& rk, int64_t csc
             const float s = sinf(kTwoPi * gait_phase(c, ep));
             float stance[2];
             stance_from_sin(s, stance);
-            float fpos[2][3], fvxy[2][2], kxy[2][2], fxyz[2][3];
-#pragma unroll
-            for (int f = 0; f < 2; ++f) {
-                const int fb = A.rigid_comp[f], kb = A.rigid_comp[2 + f];
-                fpos[f][0] = sget(A.sim.rigid, e, fb + 0);
-                fpos[f][1] = sget(A.sim.rigid, e, fb + 1);
-                fpos[f][2] = sget(A.sim.rigid, e, fb + 2);
-                fvxy[f][0] = sget(A.sim.rigid, e, fb + 7);
-                fvxy[f][1] = sget(A.sim.rigid, e, fb + 8);
-                kxy[f][0] = sget(A.sim.rigid, e, kb + 0);
-                kxy[f][1] = sget(A.sim.rigid, e, kb + 1);
-                fxyz[f][0] = sget(A.sim.contact, e, A.contact_comp[1 + f] + 0);
-                fxyz[f][1] = sget(A.sim.contact, e, A.contact_comp[1 + f] + 1);
-                fxyz[f][2] = fz[f];
-            }
             float term[HGYM_NUM_REWARDS];
             // 0 action_smoothness :530-540
             {
                 float t1 = 0.0f, t2 = 0.0f, t3 = 0.0f;
 #pragma unroll
                 for (int j = 0; j < 12; ++j) {
-                    const float la = FG(S.last_actions, j), lla = FG(S.last_last_actions, j);
-                    const float d1 = la - act[j];
+                    const float d1 = la[j] - act[j];
                     t1 += d1 * d1;
-                    const float d2 = act[j] + lla - 2.0f * la;
+                    const float d2 = act[j] + lla[j] - 2.0f * la[j];
                     t2 += d2 * d2;
                     t3 += fabsf(act[j]);
                 }
@@ -473,7 +511,7 @@ HG_HD StepFlags post_physics_env(const EnvArgs& A, const RngKey& rk, int64_t csc
                 float a2 = 0.0f;
 #pragma unroll
                 for (int i = 0; i < 6; ++i) {
-                    const float d = FG(S.last_root_vel, i) - root[7 + i];
+                    const float d = lrv[i] - root[7 + i];
                     a2 += d * d;
                 }
                 term[1] = r_exp(-r_sqrt(a2) * 3.0f);
@@ -503,10 +541,10 @@ HG_HD StepFlags post_physics_env(const EnvArgs& A, const RngKey& rk, int64_t csc
                 float acc = 0.0f, vel = 0.0f, tq = 0.0f;
 #pragma unroll
                 for (int j = 0; j < 12; ++j) {
-                    const float a = (FG(S.last_dof_vel, j) - qd[j]) / c.dt;
+                    const float a = (ldv[j] - qd[j]) / c.dt;
                     acc += a * a;
                     vel += qd[j] * qd[j];
-                    const float t = FG(S.torques, j);
+                    const float t = tqv[j];
                     tq += t * t;
                 }
                 term[5] = acc;
@@ -518,17 +556,17 @@ HG_HD StepFlags post_physics_env(const EnvArgs& A, const RngKey& rk, int64_t csc
                 float r7 = 0.0f, r8 = 0.0f;
 #pragma unroll
                 for (int f = 0; f < 2; ++f) {
-                    const float lc = FG(S.last_contacts, f);
+                    const float lc = lcon[f];
                     const int filt = (contact[f] > 0.5f) || (stance[f] > 0.5f) || (lc > 0.5f);
                     FG(S.last_contacts, f) = contact[f];
-                    float air = FG(S.feet_air_time, f);
+                    float air = fat[f];
                     const int first = (air > 0.0f) && filt;
                     air += c.dt;
                     r7 += clampf(air, 0.0f, 0.5f) * (first ? 1.0f : 0.0f);
                     FG(S.feet_air_time, f) = air * (filt ? 0.0f : 1.0f);
 
                     const float z = fpos[f][2] - 0.05f;
-                    float fh = FG(S.feet_height, f) + (z - FG(S.last_feet_z, f));
+                    float fh = fhs[f] + (z - lfz[f]);
                     FG(S.last_feet_z, f) = z;
                     const float swing = 1.0f - stance[f];
                     r8 += ((fabsf(fh - c.target_feet_height) < 0.01f) ? 1.0f : 0.0f) * swing;
@@ -559,7 +597,7 @@ HG_HD StepFlags post_physics_env(const EnvArgs& A, const RngKey& rk, int64_t csc
                 float e2 = 0.0f;
 #pragma unroll
                 for (int j = 0; j < 12; ++j) {
-                    const float d = q[j] - FG(S.ref_dof_pos, j);
+                    const float d = q[j] - rdp[j];
                     e2 += d * d;
                 }
                 const float en = r_sqrt(e2);
@@ -600,7 +638,8 @@ HG_HD StepFlags post_physics_env(const EnvArgs& A, const RngKey& rk, int64_t csc
             for (int k = 0; k < HGYM_NUM_REWARDS; ++k) {
                 const float t = term[k] * c.reward_scales[k];
                 rew += t;
-                FG(S.episode_sums, k) += t;
+                esum[k] += t;
+                FG(S.episode_sums, k) = esum[k];
             }
             if (c.only_positive_rewards) rew = fmaxf(rew, 0.0f);
         }
@@ -641,7 +680,7 @@ HG_HD StepFlags post_physics_env(const EnvArgs& A, const RngKey& rk, int64_t csc
         if (kGeneric && c.terrain_curriculum && S.terrain_levels) {
             // _update_terrain_curriculum legged_robot.py:400-420 (runs in every reset_idx once init_done, i.e. in all three modes):
             // on the pre-reset base position and the commands this step ends with
-            const float dx = root[0] - FG(S.env_origins, 0), dy = root[1] - FG(S.env_origins, 1);
+            const float dx = root[0] - org[0], dy = root[1] - org[1];
             const float distance = sqrtf(dx * dx + dy * dy);
             const bool up = distance > c.terrain_env_length / 2.0f;
             const float cn = sqrtf(cmd[0] * cmd[0] + cmd[1] * cmd[1]);
@@ -659,13 +698,14 @@ HG_HD StepFlags post_physics_env(const EnvArgs& A, const RngKey& rk, int64_t csc
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 FG(S.env_origins, i) = o[i];
+                org[i] = o[i];
                 A.origins_hbm[(int64_t)i * c.num_envs + ge] = o[i];      // env_origins is a read-only field of the staged state
             }
         }
 #pragma unroll
         for (int i = 0; i < 13; ++i) root[i] = c.base_init_state[i];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) root[i] += FG(S.env_origins, i);
+        for (int i = 0; i < 3; ++i) root[i] += org[i];
         if (kGeneric && c.custom_origins) {  // xy within 1 m of the tile centre, legged_robot.py:382-385
             root[0] += 2.0f * (A.noise.u_xy ? A.noise.u_xy[(int64_t)ge * 2 + 0] : uniform_at(rk, (uint32_t)ge, SLOT_TERRAIN, 0)) + -1.0f;
             root[1] += 2.0f * (A.noise.u_xy ? A.noise.u_xy[(int64_t)ge * 2 + 1] : uniform_at(rk, (uint32_t)ge, SLOT_TERRAIN, 1)) + -1.0f;
@@ -687,7 +727,7 @@ HG_HD StepFlags post_physics_env(const EnvArgs& A, const RngKey& rk, int64_t csc
         hg_atomic_inc(&S.counters[1]);
 #pragma unroll
         for (int k = 0; k < HGYM_NUM_REWARDS; ++k) {
-            hg_atomic_add(&S.episode_acc[k], FG(S.episode_sums, k));
+            hg_atomic_add(&S.episode_acc[k], esum[k]);
             FG(S.episode_sums, k) = 0.0f;
         }
         euler_xyz_wrapped(root + 3, eul);
@@ -734,12 +774,12 @@ HG_HD StepFlags post_physics_env(const EnvArgs& A, const RngKey& rk, int64_t csc
             priv73[53 + i] = blv[i] * c.scale_lin_vel;
             priv73[56 + i] = bav[i] * c.scale_ang_vel;
             priv73[59 + i] = eul[i] * c.scale_quat;
-            priv73[64 + i] = FG(S.push_torque, i);
+            priv73[64 + i] = pt[i];
         }
-        priv73[62] = FG(S.push_force, 0);
-        priv73[63] = FG(S.push_force, 1);
-        priv73[67] = FG(S.friction, 0);
-        priv73[68] = FG(S.body_mass, 0) / 30.0f;
+        priv73[62] = pf[0];
+        priv73[63] = pf[1];
+        priv73[67] = friction0;
+        priv73[68] = body_mass0 / 30.0f;
         priv73[69] = stance[0];
         priv73[70] = stance[1];
         priv73[71] = contact[0];
@@ -760,7 +800,7 @@ HG_HD StepFlags post_physics_env(const EnvArgs& A, const RngKey& rk, int64_t csc
     if (mode == MODE_STEP) {
 #pragma unroll
         for (int j = 0; j < 12; ++j) {
-            FG(S.last_last_actions, j) = reset ? 0.0f : FG(S.last_actions, j);
+            FG(S.last_last_actions, j) = reset ? 0.0f : la[j];
             FG(S.last_actions, j) = act[j];
             FG(S.last_dof_vel, j) = qd[j];
             FG(S.actions, j) = act[j];
