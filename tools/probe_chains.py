@@ -73,8 +73,10 @@ def run(k, join):
     return e0.elapsed_time(e1) * 1e3 / 10 / STEPS
 
 
+# (the per-step cross-chain join variant aborts inside the HIP graph capture on ROCm 7.2; HGYM_CHAINS_JOIN=1 runs it anyway)
+JOINS = (False, True) if os.environ.get("HGYM_CHAINS_JOIN") else (False,)
 for k in [int(x) for x in os.environ.get("HGYM_CHAINS", "1,2,4,8").split(",")]:
-    for join in (False, True):
+    for join in JOINS:
         if k == 1 and join:
             continue
         print("chains=%d join=%d: %.1f us per vec-step of %d envs" % (k, join, run(k, join), N), flush=True)
