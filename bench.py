@@ -2,22 +2,36 @@
 """Headline benchmark: XBot-L PPO, 4096 envs per GPU, synthetic physics step, bf16 MFMA dense layers
 (BASELINE.json configs[1]).
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Both forms work for N > 1: started WITHOUT a torch.distributed environment (no WORLD_SIZE), `--gpus N` re-executes itself
+under torch.distributed.run with N ranks on 127.0.0.1 (one process per GPU, RCCL); started by torch.distributed.run it
+reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment.
 
 A "step" is one learning iteration of the reference's OnPolicyRunner.learn: 60 vec-steps of rollout
 (policy act -> env step -> store), GAE, and the PPO update (2 epochs x 4 minibatches of 61 440 samples with
-grad-norm clip + Adam) -- nothing is skipped.  metric = env-steps/s = T*N*G / (collection_time + learn_time),
-the reference's own Perf/total_fps definition (algo/ppo/on_policy_runner.py:199-203).
+grad-norm clip + Adam) -- nothing is skipped.  metric = env-steps/s = T*N*G / wall time, the reference's own
+Perf/total_fps definition (algo/ppo/on_policy_runner.py:199-203) over the whole job.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline      dominant kernel measured live with HIP events on its launch stream (library hooks)
-  cpu_baseline  the CPU oracle (torch fp32 port of the reference's algorithm) timed on the host cores, bounded sample
+Prints ONE JSON line on rank 0 (contract in the task statement) with these extra objects:
+  roofline      dominant kernel measured live with HIP events on its launch stream (library hooks), others under "kernels"
+  cpu_baseline  N=1 only: the reference itself (kind "reference", when /root/reference exists: the build container) or the
+                CPU oracle (kind "port", the GPU box) timed on the host cores, bounded sample, best thread count
+  comm          N>1 only: the gradient all-reduce as the update sees it (exposed microseconds per minibatch)
+  configs       N=1 only: further single-GPU configurations measured in the same run, each with its own numbers --
+                BASELINE configs[3] (8192 envs/GPU, history stack 15; own roofline), the headline config with logging ON
+                (train.py's default: per-iteration host sync, console / TensorBoard writes), configs[4] (denoising head)
 """
 import argparse
+import contextlib
+import io
 import json
 import os
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -28,6 +42,8 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak
+REFERENCE_ROOT = "/root/reference"
+EXTRA_CONFIGS = ("envs8192", "logging", "dwl")
 
 
 def parse():
@@ -41,13 +57,79 @@ def parse():
                    help="humanoid_ppo = BASELINE configs[1] (the headline); humanoid_dwl_ppo adds the denoising head (configs[4])")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-roofline", action="store_true")
+    p.add_argument("--configs", default=",".join(EXTRA_CONFIGS),
+                   help="extra single-GPU configurations reported under \"configs\" (N=1 only); \"\" or none: skip")
     return p.parse_args()
 
 
-def cpu_baseline(num_envs, T=60):
-    """The oracle timed on the host: a bounded sample scaled to one full iteration.
-    Sample: 2 vec-steps of the env oracle + 2 policy evaluations at N=num_envs, one GAE at (60, N), and one
-    PPO minibatch (forward + hand-written backward + clip + Adam) on 4096 samples, scaled to 8 x 61 440."""
+# ------------------------------------------------------------------------------------------------ CPU baseline
+def _thread_candidates():
+    n = os.cpu_count() or 1
+    return sorted({min(n, c) for c in (8, 16, 32, 64, 128)})
+
+
+def _best_threads(fn, cands):
+    """fn() timed once per candidate thread count (after one untimed call at the first); returns (threads, seconds)."""
+    best = None
+    for i, nt in enumerate(cands):
+        torch.set_num_threads(nt)
+        if i == 0:
+            fn()
+        t0 = time.perf_counter()
+        fn()
+        dt = time.perf_counter() - t0
+        if best is None or dt < best[1]:
+            best = (nt, dt)
+    return best
+
+
+def sim2sim_policy_step_us(steps=2000):
+    """The CPU half of BASELINE configs[0] that can run without MuJoCo (absent, no network): per 100 Hz control step the
+    observation-frame assembly, 15-frame history and TorchScript actor call of the reference's deployment loop
+    (scripts/sim2sim.py:124-150), restated on a random-init actor of XBot-L's shape; microseconds per control step."""
+    import math
+    from collections import deque
+    import numpy as np
+    from oracle import xbot_constants as K
+    layers, d = [], 705
+    for h in K.ACTOR_HIDDEN:
+        layers += [torch.nn.Linear(d, h), torch.nn.ELU()]
+        d = h
+    layers.append(torch.nn.Linear(d, 12))
+    policy = torch.jit.script(torch.nn.Sequential(*layers))
+    rng = np.random.default_rng(0)
+    hist = deque(np.zeros([1, 47], dtype=np.double) for _ in range(15))
+    action = np.zeros(12, dtype=np.double)
+    torch.set_num_threads(1)                      # a 1 x 705 forward: more threads only add wake-up latency
+    t0 = None
+    for k in range(steps + 50):
+        if k == 50:
+            t0 = time.perf_counter()
+        q, dq, omega, eu = rng.standard_normal(12), rng.standard_normal(12), rng.standard_normal(3), rng.standard_normal(3)
+        obs = np.zeros([1, 47], dtype=np.float32)
+        obs[0, 0] = math.sin(2 * math.pi * k * 10 * 0.001 / 0.64)
+        obs[0, 1] = math.cos(2 * math.pi * k * 10 * 0.001 / 0.64)
+        obs[0, 2:5] = (0.4 * 2.0, 0.0, 0.0)
+        obs[0, 5:17] = q
+        obs[0, 17:29] = dq * 0.05
+        obs[0, 29:41] = action
+        obs[0, 41:44] = omega
+        obs[0, 44:47] = eu
+        obs = np.clip(obs, -18.0, 18.0)
+        hist.append(obs)
+        hist.popleft()
+        x = np.zeros([1, 705], dtype=np.float32)
+        for i in range(15):
+            x[0, i * 47:(i + 1) * 47] = hist[i][0, :]
+        action[:] = policy(torch.tensor(x))[0].detach().numpy()
+        action = np.clip(action, -18.0, 18.0)
+    return (time.perf_counter() - t0) / steps * 1e6
+
+
+def cpu_baseline_port(num_envs, T=60, full_minibatch=True):
+    """The oracle (torch-CPU fp32 port of the reference algorithm) timed on the host cores, thread count chosen per phase.
+    Sample: 2 vec-steps of the env oracle + policy at N = num_envs, one GAE at (T, N), ONE FULL PPO minibatch (T*N/4 samples:
+    forward, hand-written backward, clip, Adam); one iteration = T vec-steps + GAE + 8 such minibatches."""
     from oracle import ppo_oracle as P
     from oracle import xbot_constants as K
     from oracle.xbot_env_oracle import XBotEnvOracle
@@ -55,53 +137,207 @@ def cpu_baseline(num_envs, T=60):
     from env_common import synth_frames
     g = torch.Generator().manual_seed(0)
     N = num_envs
-    cores = torch.get_num_threads()
+    cands = _thread_candidates()
     o = XBotEnvOracle(N)
     o.prime(torch.rand(N, 12, generator=g), torch.rand(N, 3, generator=g), torch.randn(N, 47, generator=g))
     o.ep_len = torch.randint(0, 2400, (N,), generator=g)
     p = P.Params.random(705, 219, 12, K.ACTOR_HIDDEN, K.CRITIC_HIDDEN, g)
-    frames = [synth_frames(g, N) for _ in range(3)]
+    frames = [synth_frames(g, N) for _ in range(2)]
     z = torch.randn(N, 12, generator=g)
+    k = [0]
 
-    def vec_step(f):
-        a, v, lp, mu, sg = P.policy_act(p, torch.clip(o.obs, -18, 18), torch.clip(o.priv, -18, 18), z)
-        o.pre_physics(a, torch.rand(N, generator=g), torch.randn(N, 12, generator=g))
-        o.pd_torques()
-        o.sim.load(*f)
-        o.post_physics(torch.rand(N, 6, generator=g), torch.rand(N, 12, generator=g), torch.rand(N, 5, generator=g),
-                       torch.randn(N, 47, generator=g))
-    vec_step(frames[0])
-    t0 = time.perf_counter()
-    vec_step(frames[1])
-    vec_step(frames[2])
-    t_step = (time.perf_counter() - t0) / 2
+    def vec_steps():
+        for _ in range(2):
+            f = frames[k[0] % 2]
+            k[0] += 1
+            a, v, lp, mu, sg = P.policy_act(p, torch.clip(o.obs, -18, 18), torch.clip(o.priv, -18, 18), z)
+            o.pre_physics(a, torch.rand(N, generator=g), torch.randn(N, 12, generator=g))
+            o.pd_torques()
+            o.sim.load(*f)
+            o.post_physics(torch.rand(N, 6, generator=g), torch.rand(N, 12, generator=g), torch.rand(N, 5, generator=g),
+                           torch.randn(N, 47, generator=g))
+    nt_r, t2 = _best_threads(vec_steps, cands)
+    t_step = t2 / 2
     r, v = torch.rand(T, N, generator=g), torch.randn(T, N, generator=g)
     d, lv = torch.rand(T, N, generator=g) < 0.01, torch.randn(N, generator=g)
+    torch.set_num_threads(nt_r)
     t0 = time.perf_counter()
     ret, adv = P.gae_returns(r, v, d, lv, K.GAMMA, K.LAM)
     P.normalize_advantages(adv)
     t_gae = time.perf_counter() - t0
-    B = 4096
+    B = (T * N) // 4 if full_minibatch else min(4096, (T * N) // 4)
     obs, priv = torch.randn(B, 705, generator=g), torch.randn(B, 219, generator=g)
     act, mu_o, sg_o = torch.randn(B, 12, generator=g), torch.randn(B, 12, generator=g) * 0.3, torch.ones(B, 12)
     val, ad, rt, lp_o = (torch.randn(B, generator=g) for _ in range(4))
     opt = P.Adam(p)
-    t0 = time.perf_counter()
-    out = P.ppo_loss_and_grads(p, obs, priv, act, val, ad, rt, lp_o - 12.0, mu_o, sg_o)
-    P.clip_grad_norm(out["grads"], 1.0)
-    opt.step(p, out["grads"], 1e-5)
-    t_mb = time.perf_counter() - t0
-    mb_full = (T * N) // 4
-    t_update = 8 * t_mb * (mb_full / B)
+
+    def minibatch():
+        out = P.ppo_loss_and_grads(p, obs, priv, act, val, ad, rt, lp_o - 12.0, mu_o, sg_o)
+        P.clip_grad_norm(out["grads"], 1.0)
+        opt.step(p, out["grads"], 1e-5)
+    nt_u, t_mb = _best_threads(minibatch, cands)
+    t_update = 8 * t_mb * ((T * N) // 4) / B
     t_iter = T * t_step + t_gae + t_update
-    return dict(value=T * N / t_iter, unit="env-steps/s", cores=cores, kind="port",
-                sample="oracle (torch-CPU fp32 port of the reference algorithm): 2 vec-steps + policy at N=%d, 1 GAE (60xN), "
-                       "1 PPO minibatch of %d samples scaled to 8x%d; rollout %.1f ms/vec-step, update %.2f s/iter (extrapolated)"
-                       % (N, B, mb_full, t_step * 1e3, t_update))
+    return dict(value=T * N / t_iter, unit="env-steps/s", cores=max(nt_r, nt_u), kind="port", threads_rollout=nt_r,
+                threads_update=nt_u, host_cpus=os.cpu_count(), ms_per_vec_step=t_step * 1e3, s_per_minibatch=t_mb,
+                s_per_iteration=t_iter,
+                sample="oracle (torch-CPU fp32 port of the reference algorithm; /root/reference is not on this host): 2 vec-steps + "
+                       "policy at N=%d, 1 GAE (%dxN), 1 PPO minibatch of %d samples (forward, backward, clip, Adam); iteration = %d "
+                       "vec-steps + GAE + 8 minibatches; threads tried %s" % (N, T, B, T, cands))
+
+
+def cpu_baseline(num_envs, T=60, full_minibatch=True, allow_reference=True):
+    """kind "reference" where the reference exists (oracle/ref_timing.py, own interpreter: its package is also called
+    `humanoid`), else the port.  Either way the sim2sim deployment loop's CPU half is timed beside it."""
+    out = None
+    if allow_reference and os.path.isdir(os.path.join(REFERENCE_ROOT, "humanoid")):
+        try:
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "ref_timing.py"), "--num-envs", str(num_envs),
+                                "--threads", ",".join(map(str, _thread_candidates()))],
+                               capture_output=True, text=True, timeout=600)
+            out = json.loads(r.stdout.strip().splitlines()[-1])
+        except Exception as e:      # fall through to the port, say why
+            out = None
+            sys.stderr.write("cpu_baseline: reference timing failed (%s); using the port\n" % (e,))
+    if out is None:
+        out = cpu_baseline_port(num_envs, T, full_minibatch)
+    us = sim2sim_policy_step_us(200 if not full_minibatch else 2000)
+    out["sim2sim"] = dict(policy_step_us=us, env_steps_per_s=1e6 / us, envs=1, cores=1, kind="port",
+                          sample="BASELINE configs[0], the half that runs without MuJoCo (absent): observation frame + 15-frame history "
+                                 "+ TorchScript actor + action clip per 100 Hz control step (reference scripts/sim2sim.py:124-150)")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ GPU runs
+def _roofline(L, runner, elapsed_per_iter_ms, precision, n_profiled_iters):
+    mfma_peak = MFMA_BF16_PEAK_TFLOPS if precision == "bf16" else 157.3
+    classes = [  # (class id, kernel, bound)
+        (L.PROF_ENV_STEP, "env_step_kernel", "hbm"), (L.PROF_MLP_FWD, "mlp_fwd_kernel", "mfma"),
+        (L.PROF_POLICY, "mlp_fwd_kernel<32>", "mfma"),
+        (L.PROF_MLP_BWD, "mlp_bwd_kernel", "mfma"), (L.PROF_DW, "dw_kernel", "mfma"), (L.PROF_GEMM, "gemm_nt_kernel", "mfma"),
+        (L.PROF_LOSS, "ppo_loss_kernel", "hbm"), (L.PROF_REDUCE, "reduce_slabs_kernel", "hbm"),
+        (L.PROF_APPLY, "sqnorm+adam_kernel", "hbm"), (L.PROF_GAE, "gae_kernel", "hbm")]
+    traffic = {}
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")     # HBM bytes per launch from rocprofv3 --pmc passes
+    if os.path.exists(tpath):
+        traffic = json.load(open(tpath)).get("kernels", {})
+    ks = []
+    for cid, name, bound in classes:
+        n, ms, work = L.prof_summary(cid)
+        if n == 0 or ms <= 0:
+            continue
+        peak, unit, scale = (HBM_PEAK_GBS, "GB/s", 1e9) if bound == "hbm" else (mfma_peak, "TFLOP/s", 1e12)
+        ach = work / (ms * 1e-3) / scale
+        ks.append(dict(kernel=name, bound=bound, launches_per_iter=n // n_profiled_iters, avg_launch_us=ms / n * 1e3, achieved=ach,
+                       peak=peak, unit=unit, frac=ach / peak, share_of_iteration=ms / n_profiled_iters / elapsed_per_iter_ms,
+                       traffic=traffic.get(name)))
+    ks.sort(key=lambda k: -k["share_of_iteration"])
+    return ks
+
+
+def run_config(args, task, num_envs, rank, world, local, dist, steps, warmup, log_root=None, want_roofline=True, quiet=False):
+    """Builds env + runner for one configuration, W warm-up iterations, K timed ones (barrier + synchronize on both sides, max
+    over ranks), optionally two more eager iterations under the library's HIP-event hooks for the roofline."""
+    from humanoid.envs import task_registry
+    from humanoid.utils import get_args
+    from hgym import _lib as L
+    dev = "cuda:%d" % local
+    a = get_args(["--task=" + task, "--headless", "--num_envs", str(num_envs), "--sim_device", dev, "--rl_device", dev,
+                  "--seed", str(5 + rank)])
+    sink = io.StringIO() if (quiet or rank != 0) else None
+    with (contextlib.redirect_stdout(sink) if sink is not None else contextlib.nullcontext()):
+        env, env_cfg = task_registry.make_env(name=a.task, args=a)
+        runner, train_cfg = task_registry.make_alg_runner(env=env, name=a.task, args=a, log_root=log_root)
+    T, N = runner.num_steps_per_env, env.num_envs
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # untimed warm-up: W iterations, but never fewer than 2 -- the first iteration runs the rollout eagerly, the second captures it
+    # into the HIP graph the timed iterations replay (a capture inside the timed region would not be the steady state)
+    with (contextlib.redirect_stdout(io.StringIO()) if log_root is not None else contextlib.nullcontext()):
+        runner.learn(num_learning_iterations=max(warmup, 2), init_at_random_ep_len=True)
+        barrier()
+        t0 = time.perf_counter()
+        # K learning iterations, enqueued back to back (the runner reads nothing back between iterations when it does not log)
+        runner.learn(num_learning_iterations=steps, init_at_random_ep_len=False)
+        coll, learn = runner.last_collection_time, runner.last_learn_time     # per iteration (HIP events / host clock when logging)
+        barrier()
+        elapsed = time.perf_counter() - t0
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax)
+    res = dict(value=T * N * world * steps / elapsed, ms_per_step=elapsed / steps * 1e3, ppo_update_ms=learn * 1e3,
+               collection_ms=coll * 1e3, T=T, N=N, obs=env.num_obs, priv=env.num_privileged_obs)
+    if want_roofline:
+        # live per-kernel timing with HIP events on the launch stream (hgym_prof_*).  Events cannot be recorded inside a
+        # replayed HIP graph, so these two iterations run the rollout eagerly (same kernels, same launch order).  EVERY rank
+        # runs them (the update contains the gradient all-reduce); only rank 0 records and reports.
+        os.environ["HGYM_GRAPH"] = "0"
+        if rank == 0:
+            L.lib.hgym_prof_enable(1)
+        runner.alg.comm_timing = [] if world > 1 else None
+        with (contextlib.redirect_stdout(io.StringIO()) if log_root is not None else contextlib.nullcontext()):
+            runner.learn(num_learning_iterations=2, init_at_random_ep_len=False)
+        torch.cuda.synchronize()
+        os.environ["HGYM_GRAPH"] = "1"
+        if rank == 0:
+            res["kernels"] = _roofline(L, runner, res["ms_per_step"], args.precision, 2)
+            L.lib.hgym_prof_enable(0)
+        if world > 1 and runner.alg.comm_timing:
+            ev = runner.alg.comm_timing
+            exposed = [a_.elapsed_time(b_) * 1e3 for a_, b_ in ev]
+            res["comm"] = dict(collective="all_reduce(SUM) of [flat fp32 gradient | minibatch KL], 2 buckets (critic+KL under the "
+                                          "actor's dW, then actor), RCCL",
+                               bytes_per_minibatch=4 * (runner.alg.net.P + 1), minibatches_per_iter=len(ev) // 2,
+                               exposed_us_per_minibatch=sum(exposed) / len(exposed), exposed_us_max=max(exposed),
+                               exposed_ms_per_iter=sum(exposed) / 2 * 1e-3,
+                               note="stream time between the last backward kernel and the start of hgym_ppo_apply (HIP events on the "
+                                    "compute stream, eager profiling iterations, rank 0); includes waiting for the slowest rank")
+        runner.alg.comm_timing = None
+    del runner, env
+    torch.cuda.empty_cache()
+    return res
+
+
+def _workload(task, N, T):
+    return ("XBot-L PPO %d envs/GPU, synthetic physics step, T=%d, 2 epochs x 4 minibatches (BASELINE configs[%s])"
+            % (N, T, "4: + denoising head" if task == "humanoid_dwl_ppo" else "3: history stack 15, 8192 envs/GPU" if N == 8192 else "1"))
+
+
+def _roofline_obj(ks, pick=None):
+    dom = ks[0] if pick is None else next((k for k in ks if k["kernel"] == pick), ks[0])
+    rest = [k for k in ks if k is not dom]
+    return dict(bound=dom["bound"], achieved=dom["achieved"], peak=dom["peak"], unit=dom["unit"], frac=dom["frac"],
+                traffic=dom["traffic"], kernel=dom["kernel"], launches_per_iter=dom["launches_per_iter"],
+                avg_launch_us=dom["avg_launch_us"], share_of_iteration=dom["share_of_iteration"], kernels=rest)
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a torch.distributed environment: run the same command line under
+    torch.distributed.run, one rank per GPU, rendezvous on 127.0.0.1 (the container hostname may not resolve)."""
+    n_dev = torch.cuda.device_count()
+    if os.environ.get("HGYM_DIST_BACKEND", "nccl") == "nccl" and n_dev < args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but only %d device(s) visible; RCCL needs one device per rank\n" % (args.gpus, n_dev))
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+               OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "8"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -118,98 +354,57 @@ def main():
             dist.init_process_group(backend)
     assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
     os.environ["HGYM_PRECISION"] = args.precision
-
     from humanoid.algo import PPO
     PPO.precision = args.precision
-    from humanoid.envs import task_registry
-    from humanoid.utils import get_args
-    from hgym import _lib as L
-    dev = "cuda:%d" % local
-    a = get_args(["--task=" + args.task, "--headless", "--num_envs", str(args.num_envs), "--sim_device", dev, "--rl_device", dev,
-                  "--seed", str(5 + rank)])
-    env, env_cfg = task_registry.make_env(name=a.task, args=a)
-    runner, train_cfg = task_registry.make_alg_runner(env=env, name=a.task, args=a, log_root=None)
-    T = runner.num_steps_per_env
-    N = env.num_envs
 
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    # untimed warm-up: W iterations, but never fewer than 2 -- the first iteration runs the rollout eagerly, the second captures it
-    # into the HIP graph the timed iterations replay (a capture inside the timed region would not be the steady state)
-    runner.learn(num_learning_iterations=max(args.warmup, 2), init_at_random_ep_len=True)
-    barrier()
-    t0 = time.perf_counter()
-    # K learning iterations, enqueued back to back (the runner reads nothing back between iterations when it does not log)
-    runner.learn(num_learning_iterations=args.steps, init_at_random_ep_len=False)
-    coll = runner.last_collection_time * args.steps      # mean per iteration over this call, HIP events on the launch stream
-    learn = runner.last_learn_time * args.steps
-    barrier()
-    elapsed = time.perf_counter() - t0
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if dist is not None:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    elapsed = float(tmax)
-    value = T * N * world * args.steps / elapsed
-
-    roofline = None
-    if not args.no_roofline:
-        # live per-kernel timing with HIP events on the launch stream (hgym_prof_*).  Events cannot be recorded inside a
-        # replayed HIP graph, so these two iterations run the rollout eagerly (same kernels, same launch order).  EVERY rank
-        # runs them (the update contains the gradient all-reduce); only rank 0 records and reports.
-        os.environ["HGYM_GRAPH"] = "0"
-        if rank == 0:
-            L.lib.hgym_prof_enable(1)
-        runner.learn(num_learning_iterations=2, init_at_random_ep_len=False)
-        torch.cuda.synchronize()
-        os.environ["HGYM_GRAPH"] = "1"
-    if rank == 0 and not args.no_roofline:
-        iter_ms = elapsed / args.steps * 1e3
-        mfma_peak = MFMA_BF16_PEAK_TFLOPS if args.precision == "bf16" else 157.3
-        classes = [  # (class id, kernel, bound, unit of `work`)
-            (L.PROF_ENV_STEP, "env_step_kernel", "hbm"), (L.PROF_MLP_FWD, "mlp_fwd_kernel", "mfma"),
-            (L.PROF_POLICY, "mlp_fwd_kernel<32>", "mfma"),
-            (L.PROF_MLP_BWD, "mlp_bwd_kernel", "mfma"), (L.PROF_DW, "dw_kernel", "mfma"), (L.PROF_GEMM, "gemm_nt_kernel", "mfma"),
-            (L.PROF_LOSS, "ppo_loss_kernel", "hbm"), (L.PROF_REDUCE, "reduce_slabs_kernel", "hbm"),
-            (L.PROF_APPLY, "sqnorm+adam_kernel", "hbm"), (L.PROF_GAE, "gae_kernel", "hbm")]
-        traffic = {}
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")     # HBM bytes per launch from rocprofv3 --pmc passes
-        if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get("kernels", {})
-        ks = []
-        for cid, name, bound in classes:
-            n, ms, work = L.prof_summary(cid)
-            if n == 0 or ms <= 0:
+    head = run_config(args, args.task, args.num_envs, rank, world, local, dist, args.steps, args.warmup,
+                      want_roofline=not args.no_roofline)
+    T, N = head["T"], head["N"]
+    extra = []
+    want = [c for c in args.configs.split(",") if c and c != "none"]
+    if world == 1 and want and args.task == "humanoid_ppo" and args.num_envs == 4096:
+        k_steps, k_warm = min(args.steps, 6), min(args.warmup, 2)
+        for c in want:
+            if c == "envs8192":
+                r = run_config(args, "humanoid_ppo", 8192, 0, 1, local, None, k_steps, k_warm, want_roofline=not args.no_roofline, quiet=True)
+                e = dict(name="envs8192", logging=False)
+            elif c == "logging":
+                with tempfile.TemporaryDirectory() as tmp:
+                    r = run_config(args, "humanoid_ppo", 4096, 0, 1, local, None, k_steps, k_warm, log_root=tmp, want_roofline=False, quiet=True)
+                e = dict(name="logging_on", logging=True,
+                         note="train.py's default: log_dir set -> per-iteration host synchronisation, loss / episode statistics read back, "
+                              "console (+ TensorBoard if installed) writes, own step-finaliser launch, final checkpoint inside the timed region")
+            elif c == "dwl":
+                r = run_config(args, "humanoid_dwl_ppo", 4096, 0, 1, local, None, k_steps, k_warm, want_roofline=False, quiet=True)
+                e = dict(name="dwl_head", logging=False, note="BASELINE configs[4] on one GPU; parity of the head is unpinned (no reference code)")
+            else:
                 continue
-            peak, unit, scale = (HBM_PEAK_GBS, "GB/s", 1e9) if bound == "hbm" else (mfma_peak, "TFLOP/s", 1e12)
-            ach = work / (ms * 1e-3) / scale
-            ks.append(dict(kernel=name, bound=bound, launches_per_iter=n // 2, avg_launch_us=ms / n * 1e3, achieved=ach, peak=peak, unit=unit,
-                           frac=ach / peak, share_of_iteration=ms / 2 / iter_ms, traffic=traffic.get(name)))
-        L.lib.hgym_prof_enable(0)
-        ks.sort(key=lambda k: -k["share_of_iteration"])
-        dom = ks[0]
-        roofline = dict(bound=dom["bound"], achieved=dom["achieved"], peak=dom["peak"], unit=dom["unit"], frac=dom["frac"],
-                        traffic=dom["traffic"], kernel=dom["kernel"], launches_per_iter=dom["launches_per_iter"],
-                        avg_launch_us=dom["avg_launch_us"], share_of_iteration=dom["share_of_iteration"], kernels=ks[1:])
+            e.update(workload=_workload("humanoid_dwl_ppo" if c == "dwl" else "humanoid_ppo", r["N"], r["T"]), envs_per_gpu=r["N"],
+                     value=r["value"], unit="env-steps/s", steps=k_steps, warmup=k_warm, ms_per_step=r["ms_per_step"],
+                     collection_ms=r["collection_ms"], ppo_update_ms=r["ppo_update_ms"])
+            if r.get("kernels"):
+                # configs[3] is the HBM stress of the env step: report THAT kernel's roofline for it
+                e["roofline"] = _roofline_obj(r["kernels"], pick="env_step_kernel" if c == "envs8192" else None)
+            extra.append(e)
 
     if dist is not None:
         dist.barrier()
     if rank == 0:
         out = {
-            "metric": "env-steps/s (XBot-L PPO, whole job)", "value": value, "unit": "env-steps/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "metric": "env-steps/s (XBot-L PPO, whole job)", "value": head["value"], "unit": "env-steps/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"], "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": "XBot-L PPO %d envs/GPU, synthetic physics step, T=60, 2 epochs x 4 minibatches (BASELINE configs[%s])"
-                                   % (N, "1" if args.task == "humanoid_ppo" else "4: + denoising head"),
-                       "envs_per_gpu": N, "steps_per_env": T, "obs": env.num_obs, "privileged_obs": env.num_privileged_obs,
-                       "minibatch": T * N // 4, "parallelism": "dp%d (env shards, RCCL grad all-reduce)" % world},
-            "ppo_update_ms": learn / args.steps * 1e3, "collection_ms": coll / args.steps * 1e3,
+            "config": {"workload": _workload(args.task, N, T),
+                       "envs_per_gpu": N, "steps_per_env": T, "obs": head["obs"], "privileged_obs": head["priv"],
+                       "minibatch": T * N // 4, "parallelism": "dp%d (env shards, RCCL grad all-reduce)" % world, "logging": False},
+            "ppo_update_ms": head["ppo_update_ms"], "collection_ms": head["collection_ms"],
         }
-        if roofline is not None:
-            out["roofline"] = roofline
+        if head.get("kernels"):
+            out["roofline"] = _roofline_obj(head["kernels"])
+        if head.get("comm"):
+            out["comm"] = head["comm"]
+        if extra:
+            out["configs"] = extra
         if not args.no_cpu_baseline and world == 1:      # the CPU baseline leg belongs to the N=1 run only
             out["cpu_baseline"] = cpu_baseline(N, T)
         print(json.dumps(out))

@@ -44,7 +44,8 @@ static inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * 
 
 // ---------------------------------------------------------------------------------------------- Philox4x32-10
 // Counter-based RNG (Salmon et al. 2011), keyed by (seed); counter = (env, step_lo, step_hi, slot).
-// Pure 32-bit integer arithmetic: identical on host (oracle/philox.py restates it) and device.
+// Pure 32-bit integer arithmetic: identical on host and device; oracle/philox.py restates it and
+// tests/test_philox.py pins all three (oracle, this source on the host, the device) to the Random123 known-answer vectors.
 struct U4 {
     uint32_t x, y, z, w;
 };

@@ -874,8 +874,74 @@ struct NetRunner {
         return rc;
     }
 
-    int32_t fused_grad(const HgymPPOConfig& ppo, const HgymBatch& b) {
+    // all weight (and hidden bias) gradients of nets [first, first + count): one launch, split-K slabs
+    int32_t fused_dw(int first, int count, int B) {
+        const int Bp = (int)round_up(B, 64);
+        DwArgs d;
+        memset(&d, 0, sizeof(d));
+        int tile = 0;
+        double fl = 0.0;
+        for (int i = first; i < first + count; ++i)
+            for (int l = 0; l < 4; ++l) {
+                const NetLayout& n = w.net[i];
+                const LayerLayout& y = n.layer[l];
+                DwProduct& p = d.p[d.np++];
+                p.Z = at<__bf16>(n.dZb[l]);
+                p.CBz = l < 3 ? y.N / 16 : 2;
+                p.X = l == 0 ? at<__bf16>(n.X0b) : at<__bf16>(n.Hb[l - 1]);
+                p.CBx = l == 0 ? 2 * y.KBf : y.K / 16;
+                p.N = y.N;
+                p.K = y.K;
+                p.w_off = y.w_off;
+                p.b_off = l < 3 ? y.b_off : -1;
+                p.tiles_n = ceil_div(y.N, 128);
+                p.tiles_k = ceil_div(y.K, 128);
+                p.tile0 = tile;
+                tile += p.tiles_n * p.tiles_k;
+                fl += 2.0 * (double)B * y.N * y.K;
+            }
+        d.total_tiles = tile;
+        d.splits = w.dw_splits;
+        d.steps_total = Bp / 32;
+        d.steps_per_split = ceil_div(d.steps_total, w.dw_splits);
+        d.slabs = at<float>(w.slabs);
+        d.slab_stride = w.Ps;
+        d.zeros = at<char>(w.zeros);
+        prof_begin(HGYM_PROF_DW, s);
+        hipLaunchKernelGGL(dw_kernel_rs<3>, dim3(tile * (int)round_up(w.dw_splits, 8)), dim3(DW_THREADS), 2 * DW_STAGE_BYTES, s, d);
+        prof_end(HGYM_PROF_DW, s, fl);
+        HG_CHECK_LAUNCH("dw_kernel_rs");
+        return HGYM_OK;
+    }
+
+    // slab reduction of the segments whose parameters lie in [lo, hi) of the flat vector
+    int32_t reduce_range(int64_t lo, int64_t hi) {
+        const SegTable all = segments(true);
+        SegTable tab;
+        memset(&tab, 0, sizeof(tab));
+        int64_t elems = 0;
+        for (int i = 0; i < all.n; ++i)
+            if (all.s[i].off >= lo && all.s[i].off < hi) {
+                tab.s[tab.n++] = all.s[i];
+                elems += (int64_t)all.s[i].rows * all.s[i].cols;
+            }
+        if (tab.n == 0) return HGYM_OK;
+        prof_begin(HGYM_PROF_REDUCE, s);
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(96, tab.n), dim3(256), 0, s, tab, w.Ps, at<float>(w.slabs), net.grads, net.opt_state);
+        prof_end(HGYM_PROF_REDUCE, s, (double)elems * 4.0 * (w.dw_splits + 1));
+        HG_CHECK_LAUNCH("reduce_slabs_kernel");
+        return HGYM_OK;
+    }
+
+    // part < 0: the whole minibatch gradient.  part 0 / 1: the two halves of hgym_ppo_grad_part -- 0 leaves the critic's (and the
+    // auxiliary head's) gradient and the KL slot final, 1 the actor's and std's.
+    int32_t fused_grad(const HgymPPOConfig& ppo, const HgymBatch& b, int part = -1) {
         const int B = b.B, A = cfg.num_actions;
+        const int64_t critic_off = w.net[1].layer[0].w_off;
+        if (part == 1) {
+            const int32_t rc1 = fused_dw(0, 1, B);
+            return rc1 ? rc1 : reduce_range(0, critic_off);
+        }
         float* mu = at<float>(w.net[0].out_f32);
         float* val = at<float>(w.net[1].out_f32);
         const float* xs[3] = {b.obs, b.priv, nullptr};
@@ -928,52 +994,22 @@ struct NetRunner {
             prof_end(HGYM_PROF_MLP_BWD, s, fl);
             HG_CHECK_LAUNCH("mlp_bwd_kernel");
         }
-        {   // all weight (and hidden bias) gradients: one launch, split-K slabs
-            DwArgs d;
-            memset(&d, 0, sizeof(d));
-            int tile = 0;
-            double fl = 0.0;
-            for (int i = 0; i < 2; ++i)
-                for (int l = 0; l < 4; ++l) {
-                    const NetLayout& n = w.net[i];
-                    const LayerLayout& y = n.layer[l];
-                    DwProduct& p = d.p[d.np++];
-                    p.Z = at<__bf16>(n.dZb[l]);
-                    p.CBz = l < 3 ? y.N / 16 : 2;
-                    p.X = l == 0 ? at<__bf16>(n.X0b) : at<__bf16>(n.Hb[l - 1]);
-                    p.CBx = l == 0 ? 2 * y.KBf : y.K / 16;
-                    p.N = y.N;
-                    p.K = y.K;
-                    p.w_off = y.w_off;
-                    p.b_off = l < 3 ? y.b_off : -1;
-                    p.tiles_n = ceil_div(y.N, 128);
-                    p.tiles_k = ceil_div(y.K, 128);
-                    p.tile0 = tile;
-                    tile += p.tiles_n * p.tiles_k;
-                    fl += 2.0 * (double)B * y.N * y.K;
-                }
-            d.total_tiles = tile;
-            d.splits = w.dw_splits;
-            d.steps_total = Bp / 32;
-            d.steps_per_split = ceil_div(d.steps_total, w.dw_splits);
-            d.slabs = at<float>(w.slabs);
-            d.slab_stride = w.Ps;
-            d.zeros = at<char>(w.zeros);
-            prof_begin(HGYM_PROF_DW, s);
-            hipLaunchKernelGGL(dw_kernel_rs<3>, dim3(tile * (int)round_up(w.dw_splits, 8)), dim3(DW_THREADS), 2 * DW_STAGE_BYTES, s, d);
-            prof_end(HGYM_PROF_DW, s, fl);
-            HG_CHECK_LAUNCH("dw_kernel_rs");
+        if (part == 0) {
+            int32_t rc0 = fused_dw(1, 1, B);
+            if (rc0) return rc0;
+            if (w.nnets > 2) {
+                rc0 = aux_grad(ppo, b);
+                if (rc0) return rc0;
+            }
+            return reduce_range(critic_off, w.P);
         }
+        rc = fused_dw(0, 2, B);
+        if (rc) return rc;
         if (w.nnets > 2) {
             const int32_t rca = aux_grad(ppo, b);
             if (rca) return rca;
         }
-        const SegTable tab = segments(true);
-        prof_begin(HGYM_PROF_REDUCE, s);
-        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(96, tab.n), dim3(256), 0, s, tab, w.Ps, at<float>(w.slabs), net.grads, net.opt_state);
-        prof_end(HGYM_PROF_REDUCE, s, (double)w.P * 4.0 * (w.dw_splits + 1));
-        HG_CHECK_LAUNCH("reduce_slabs_kernel");
-        return HGYM_OK;
+        return reduce_range(0, w.P);
     }
 
     int32_t act(int M, const float* obs, const float* priv, const float* z, uint64_t seed, const int64_t* step, float* actions, float* mu,
@@ -1205,10 +1241,11 @@ struct NetRunner {
         return backward(2, B);
     }
 
-    int32_t grad(const HgymPPOConfig& ppo, const HgymBatch& b) {
+    int32_t grad(const HgymPPOConfig& ppo, const HgymBatch& b, int part = -1) {
         const int B = b.B, A = cfg.num_actions;
         HG_REQUIRE(B > 0 && B <= w.maxM, HGYM_E_SHAPE, "minibatch %d exceeds max_batch %lld", B, (long long)w.maxM);
-        if (w.fused) return fused_grad(ppo, b);
+        if (w.fused) return fused_grad(ppo, b, part);
+        if (part == 1) return HGYM_OK;      // layer-by-layer path: part 0 did everything
         float* mu = at<float>(w.net[0].out_f32);
         float* val = at<float>(w.net[1].out_f32);
         if (hipMemsetAsync(net.grads, 0, (size_t)w.P * sizeof(float), s) != hipSuccess) HG_FAIL(HGYM_E_LAUNCH, "memset of grads failed");
@@ -1377,6 +1414,26 @@ int32_t hgym_ppo_grad(const HgymNetConfig* cfg, const HgymPPOConfig* ppo, const 
     HG_REQUIRE(batch->obs && batch->priv && batch->actions && batch->values && batch->advantages && batch->returns && batch->logp &&
                    batch->mu && batch->sigma && batch->idx, HGYM_E_BADARG, "null batch tensor");
     HG_DISPATCH(cfg, net, w, stream, grad(*ppo, *batch));
+}
+
+int32_t hgym_ppo_grad_part(const HgymNetConfig* cfg, const HgymPPOConfig* ppo, const HgymNet* net, const HgymBatch* batch, int32_t part,
+                           void* stream) {
+    WsLayout w;
+    const int32_t rc = check_net(cfg, net, &w);
+    if (rc) return rc;
+    HG_REQUIRE(ppo && batch, HGYM_E_BADARG, "null ppo / batch");
+    HG_REQUIRE(part == 0 || part == 1, HGYM_E_BADARG, "part=%d (0 or 1)", part);
+    HG_REQUIRE(net->grads && net->opt_state, HGYM_E_BADARG, "null grads / opt_state");
+    HG_REQUIRE(batch->obs && batch->priv && batch->actions && batch->values && batch->advantages && batch->returns && batch->logp &&
+                   batch->mu && batch->sigma && batch->idx, HGYM_E_BADARG, "null batch tensor");
+    HG_DISPATCH(cfg, net, w, stream, grad(*ppo, *batch, part));
+}
+
+int64_t hgym_net_param_offset(const HgymNetConfig* cfg, int32_t which) {
+    WsLayout w;
+    if (ws_layout(cfg, &w) != HGYM_OK) return -1;
+    if (which < 0 || which >= w.nnets) return which == w.nnets ? w.P : -1;
+    return w.net[which].layer[0].w_off;
 }
 
 int32_t hgym_ppo_apply(const HgymNetConfig* cfg, const HgymPPOConfig* ppo, const HgymNet* net, void* stream) {

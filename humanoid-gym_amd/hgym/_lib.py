@@ -156,6 +156,8 @@ SYMBOLS = {
     "hgym_policy_act_fin": (C.c_int32, [_P(NetConfig), _P(Net), C.c_int32, c_float_p, c_float_p, c_float_p, C.c_uint64, c_i64_p,
                                     c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, _P(EnvConfig), _P(EnvState), _P(EnvOut), C.c_void_p]),
     "hgym_ppo_grad": (C.c_int32, [_P(NetConfig), _P(PPOConfig), _P(Net), _P(Batch), C.c_void_p]),
+    "hgym_ppo_grad_part": (C.c_int32, [_P(NetConfig), _P(PPOConfig), _P(Net), _P(Batch), C.c_int32, C.c_void_p]),
+    "hgym_net_param_offset": (C.c_int64, [_P(NetConfig), C.c_int32]),
     "hgym_ppo_apply": (C.c_int32, [_P(NetConfig), _P(PPOConfig), _P(Net), C.c_void_p]),
     "hgym_prof_enable": (C.c_int32, [C.c_int32]),
     "hgym_prof_phase_buffer": (C.c_int32, [C.c_void_p, C.c_int64]),

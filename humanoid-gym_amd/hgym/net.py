@@ -135,6 +135,17 @@ class NetBuffers:
     def ppo_grad(self, ppo, batch):
         L.check(L.lib.hgym_ppo_grad(C.byref(self.cfg), C.byref(ppo), C.byref(self.struct), C.byref(batch), self.stream()), "hgym_ppo_grad")
 
+    def ppo_grad_part(self, ppo, batch, part):
+        """hgym_ppo_grad in two halves (data-parallel update): after part 0 `grads_ext[bucket_split:]` (critic | auxiliary head | KL
+        slot) is final, after part 1 `grads_ext[:bucket_split]` (std | actor)."""
+        L.check(L.lib.hgym_ppo_grad_part(C.byref(self.cfg), C.byref(ppo), C.byref(self.struct), C.byref(batch), int(part), self.stream()),
+                "hgym_ppo_grad_part")
+
+    @property
+    def bucket_split(self):
+        """Offset of the critic's first parameter in the flat vector: the boundary of the two gradient buckets."""
+        return int(L.lib.hgym_net_param_offset(C.byref(self.cfg), 1))
+
     def ppo_apply(self, ppo):
         L.check(L.lib.hgym_ppo_apply(C.byref(self.cfg), C.byref(ppo), C.byref(self.struct), self.stream()), "hgym_ppo_apply")
 

@@ -1,6 +1,8 @@
 """Data-parallel glue: envs shard across ranks with no data-path collective; the only exchanges are
-  * per minibatch: ONE in-place all-reduce of [flat fp32 gradient (926 105) | minibatch mean KL]; the means are formed
-    inside hgym_ppo_apply, so every rank clips the same gradient and takes the same adaptive-KL learning-rate decision;
+  * per minibatch: the in-place all-reduce (SUM) of [flat fp32 gradient (926 105) | minibatch mean KL], issued as TWO buckets
+    -- [critic | auxiliary head | KL] as soon as hgym_ppo_grad_part(0) has produced it, so that it travels under the actor's
+    weight-gradient kernels, then [std | actor] -- the means are formed inside hgym_ppo_apply, so every rank clips the same
+    gradient and takes the same adaptive-KL learning-rate decision;
   * per iteration: one all-reduce of (sum adv, sum adv^2, count) so advantages are normalised over the global batch.
 Backend: torch.distributed "nccl" (= RCCL over xGMI) on the GPUs; the same functions run over "gloo" in the CPU tests."""
 import torch
@@ -16,6 +18,21 @@ def sum_grads_and_kl(grads_ext):
     no staging copies; hgym_ppo_apply divides by world_size on the device (HgymPPOConfig.world_size)."""
     if world_size() > 1:
         dist.all_reduce(grads_ext)
+
+
+def start_sum(t):
+    """Asynchronous in-place all-reduce (SUM) of one gradient bucket; returns a handle for `finish` (None on a single rank).
+    With RCCL the collective runs on the process group's own stream, ordered after everything enqueued on the current
+    stream so far -- kernels launched after this call overlap with it."""
+    if world_size() > 1:
+        return dist.all_reduce(t, async_op=True)
+    return None
+
+
+def finish(handle):
+    """Order the current stream behind the collective (RCCL: a stream-side wait, the host does not block)."""
+    if handle is not None:
+        handle.wait()
 
 
 def allreduce_adv_stats(stats):

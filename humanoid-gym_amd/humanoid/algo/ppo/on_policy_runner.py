@@ -146,6 +146,11 @@ class OnPolicyRunner:
         async_iters = ((not log_on) and str(self.device).startswith("cuda") and isinstance(alg, PPO)
                        and os.environ.get("HGYM_ASYNC", "1") != "0")
         marks = []
+        # the captured launches hold HgymEnvConfig and the sink's gamma BY VALUE: a change between learn() calls (reward scales,
+        # command ranges, push / noise settings written into the env's native config, alg.gamma -- what a curriculum script does)
+        # must re-capture, as the eager reference would simply see it
+        gkey = (id(env), id(alg.storage), log_on, sink_ok, defer_ok, getattr(alg, "gamma", None),
+                env.native_config_digest() if hasattr(env, "native_config_digest") else None)
         tot_iter = self.current_learning_iteration + num_learning_iterations
         for it in range(self.current_learning_iteration, tot_iter):
             start = time.time()
@@ -154,7 +159,7 @@ class OnPolicyRunner:
                 ev[0].record()
             with torch.inference_mode():
                 g = self._graph
-                if use_graph and g is not None and g["key"] == (id(env), id(alg.storage), log_on, sink_ok, defer_ok):
+                if use_graph and g is not None and g["key"] == gkey:
                     g["graph"].replay()
                     alg.storage.step = self.num_steps_per_env
                     obs, critic_obs = g["out"]
@@ -168,7 +173,7 @@ class OnPolicyRunner:
                     # concurrently; only this thread's launches belong to the capture
                     with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                         out = rollout(obs_all[0], priv_all[0])
-                    self._graph = dict(graph=graph, out=out, ep_infos=ep_infos, key=(id(env), id(alg.storage), log_on, sink_ok, defer_ok),
+                    self._graph = dict(graph=graph, out=out, ep_infos=ep_infos, key=gkey,
                                        stats=(cur_reward_sum, cur_episode_length, done_stats))
                     alg.storage.step = 0
                     graph.replay()                  # capture does not execute: run the captured rollout once
@@ -266,6 +271,10 @@ class OnPolicyRunner:
                 f"""{'ETA:':>{pad}} {eta:.1f}s\n""")
         print(out)
 
+    def invalidate_graph(self):
+        """Drop the captured rollout; the next learn() iteration runs eagerly and the one after re-captures."""
+        self._graph, self._graph_warm = None, False
+
     def save(self, path, infos=None):
         torch.save({"model_state_dict": self.alg.actor_critic.state_dict(),
                     "optimizer_state_dict": self.alg.optimizer.state_dict(),
@@ -277,6 +286,8 @@ class OnPolicyRunner:
         if load_optimizer:
             self.alg.optimizer.load_state_dict(loaded["optimizer_state_dict"])
         self.current_learning_iteration = loaded["iter"]
+        if hasattr(self.alg, "seek"):
+            self.alg.seek(self.current_learning_iteration, self.num_steps_per_env)
         return loaded["infos"]
 
     def get_inference_policy(self, device=None):

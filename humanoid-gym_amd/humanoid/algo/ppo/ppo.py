@@ -3,7 +3,8 @@
 act() = one hgym_policy_act call whose outputs land directly in the rollout-storage slot; process_env_step() =
 hgym_store_step (time-out bootstrap) ; compute_returns() = wavefront-scan GAE ; update() = for every minibatch
 hgym_ppo_grad (gather + forward + KL + loss + hand-written backward, all on the device, no host sync) ->
-[RCCL all-reduce of the flat gradient + KL when torch.distributed is initialised] -> hgym_ppo_apply (adaptive-KL
+[when torch.distributed is initialised: hgym_ppo_grad_part 0 / 1 with the RCCL all-reduce of the critic's gradient bucket
+(+ KL) running under the actor's weight-gradient kernels, then the actor's bucket] -> hgym_ppo_apply (adaptive-KL
 learning rate, grad-norm clip, Adam, operand-shadow refresh).  The host reads the loss sums back once per update.
 """
 import os
@@ -90,6 +91,7 @@ class PPO:
         self.denoise_coef = float(denoise_coef)     # weight of the ActorCritic denoiser head's MSE (0: head absent / not trained)
         # True while a runner has the env store the scalar columns and bump the sampling step itself (transition_sink)
         self.env_stores_transitions = False
+        self.comm_timing = None      # a list: update() appends a pair of HIP events around the wait for the gradient exchange
         self._world = 1
         self._rank = 0
         if torch.distributed.is_available() and torch.distributed.is_initialized():
@@ -129,8 +131,17 @@ class PPO:
         self._perm_seed = (torch.initial_seed() * 0x9E3779B97F4A7C15 + 0xABCD + 104729 * self._rank) & 0xFFFFFFFFFFFFFFFF
         self._perm_draws = 0
         ac._sample_step = self._sample_step
-        ac._sample_seed = 0x5EED + 7919 * self._rank
+        # exploration-noise key: from the run's seed (as the permutation key above) and the rank
+        ac._sample_seed = (torch.initial_seed() * 0xD1342543DE82EF95 + 0x5EED + 7919 * self._rank) & 0xFFFFFFFFFFFFFFFF
         self._hgym = hgym
+
+    def seek(self, iteration, steps_per_iteration):
+        """Position the device generators' counters where a run that has done `iteration` learning iterations has them
+        (OnPolicyRunner.load): a resumed run continues the exploration-noise and permutation streams instead of replaying them
+        from the start.  The reference's checkpoint carries no generator state (on_policy_runner.py:274-281); the counters are
+        functions of the iteration number, so neither does this one."""
+        self._sample_step.fill_(int(iteration) * int(steps_per_iteration))
+        self._perm_draws = int(iteration)
 
     def test_mode(self):
         self.actor_critic.eval()
@@ -213,8 +224,26 @@ class PPO:
         for _ in range(self.num_learning_epochs):
             for i in range(self.num_mini_batches):
                 idx = perm[i * mb:(i + 1) * mb]
-                net.ppo_grad(self._ppo_cfg, hgym.make_batch(*cols, idx))
-                dist_utils.sum_grads_and_kl(net.grads_ext)
+                batch = hgym.make_batch(*cols, idx)
+                if self._world == 1:
+                    net.ppo_grad(self._ppo_cfg, batch)
+                else:
+                    # two buckets: [critic | aux | KL] is reduced across ranks while this rank's actor weight gradients are
+                    # still being computed; [std | actor] follows; apply waits (stream-side) for both
+                    split = net.bucket_split
+                    net.ppo_grad_part(self._ppo_cfg, batch, 0)
+                    h0 = dist_utils.start_sum(net.grads_ext[split:])
+                    net.ppo_grad_part(self._ppo_cfg, batch, 1)
+                    h1 = dist_utils.start_sum(net.grads_ext[:split])
+                    probe = self.comm_timing is not None
+                    if probe:
+                        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                        ev[0].record()
+                    dist_utils.finish(h0)
+                    dist_utils.finish(h1)
+                    if probe:
+                        ev[1].record()
+                        self.comm_timing.append(ev)
                 net.ppo_apply(self._ppo_cfg)
         st.clear()
         if not sync:

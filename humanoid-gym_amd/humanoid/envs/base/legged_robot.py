@@ -15,7 +15,7 @@ import numpy as np
 import torch
 
 from humanoid.envs.base.base_task import BaseTask
-from humanoid.utils.helpers import class_to_dict
+from humanoid.utils.helpers import class_to_dict, shard_seed
 from .legged_robot_config import LeggedRobotCfg
 
 # reward terms the fused kernel implements, in the alphabetical order class_to_dict imposes
@@ -68,6 +68,11 @@ class LeggedRobot(BaseTask):
         self.max_episode_length = np.ceil(self.max_episode_length_s / self.dt)
         self.cfg.domain_rand.push_interval = np.ceil(self.cfg.domain_rand.push_interval_s / self.dt)
 
+    def native_config_digest(self):
+        """Hash of the HgymEnvConfig the next launches will carry (by value): lets a caller that captured launches into a HIP
+        graph notice that the configuration was edited since."""
+        return hash(bytes(self._ncfg)) if self._ncfg is not None else None
+
     def _native_config(self):
         """XBotLCfg -> HgymEnvConfig.  Scalars are combined in python double arithmetic and rounded to fp32 last,
         exactly where the reference's tensors round them."""
@@ -82,7 +87,7 @@ class LeggedRobot(BaseTask):
             raise ValueError("Terrain mesh type not recognised. Allowed types are [plane, heightfield, trimesh]")
         if cfg.terrain.measure_heights and cfg.terrain.mesh_type == "plane":
             raise NotImplementedError("measure_heights on a plane returns zeros in the reference; there is nothing to sample")
-        c = default_env_config(self.num_envs, seed=getattr(cfg, "seed", 5), frame_stack=cfg.env.frame_stack,
+        c = default_env_config(self.num_envs, seed=shard_seed(getattr(cfg, "seed", 5)), frame_stack=cfg.env.frame_stack,
                                c_frame_stack=cfg.env.c_frame_stack)
         c.decimation = cfg.control.decimation
         c.sim_dt = self.sim_params.dt

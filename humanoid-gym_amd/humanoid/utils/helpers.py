@@ -45,6 +45,17 @@ def set_seed(seed):
     return seed
 
 
+def shard_seed(seed):
+    """The seed of THIS rank's env shard.  The reference is single-process (its `--horovod` flag is dead, helpers.py:207-212);
+    with one process per GPU every rank must own an independent stream of command resamples, pushes, observation noise,
+    reset offsets, frictions and base masses -- the same `cfg.seed` on every rank would make the data-parallel shards copies
+    of each other up to the policy noise.  Rank 0 keeps the configured seed (single-GPU runs are unchanged)."""
+    rank = 0
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        rank = torch.distributed.get_rank()
+    return seed if seed == -1 else int(seed) + 100003 * rank
+
+
 def parse_sim_params(args, cfg):
     """The reference builds gymapi.SimParams for PhysX here; the synthetic physics backend only needs dt."""
     sim = cfg.get("sim", {}) if isinstance(cfg, dict) else {}

@@ -4,7 +4,7 @@ from datetime import datetime
 
 from humanoid import LEGGED_GYM_ROOT_DIR
 from humanoid.algo import OnPolicyRunner  # noqa: F401  (resolved by name from the train config)
-from .helpers import get_args, update_cfg_from_args, class_to_dict, get_load_path, set_seed, parse_sim_params
+from .helpers import get_args, update_cfg_from_args, class_to_dict, get_load_path, set_seed, shard_seed, parse_sim_params
 
 
 class TaskRegistry:
@@ -30,7 +30,10 @@ class TaskRegistry:
         if env_cfg is None:
             env_cfg, _ = self.get_cfgs(name)
         env_cfg, _ = update_cfg_from_args(env_cfg, None, args)
-        set_seed(env_cfg.seed)
+        # as in the reference, --seed reaches the train cfg only (helpers.py:159-160); the env keeps cfg.seed.  With one process
+        # per GPU the rank is folded in (helpers.shard_seed), here for the torch / numpy draws of create_sim (friction, base mass,
+        # terrain levels) and in LeggedRobot._native_config for the device generator's key
+        set_seed(shard_seed(env_cfg.seed))
         sim_params = parse_sim_params(args, {"sim": class_to_dict(env_cfg.sim)})
         env = self.task_classes[name](cfg=env_cfg, sim_params=sim_params, physics_engine=args.physics_engine,
                                       sim_device=args.sim_device, headless=args.headless)

@@ -383,6 +383,21 @@ typedef struct HgymBatch {
 int32_t hgym_ppo_grad(const HgymNetConfig* cfg, const HgymPPOConfig* ppo, const HgymNet* net,
                       const HgymBatch* batch, void* stream);
 
+/* hgym_ppo_grad in two halves, for the data-parallel update (one process per GPU; the reference is single-process, its
+ * `--horovod` flag is dead: utils/helpers.py:207-212): the flat gradient is exchanged in two buckets so that the first
+ * all-reduce runs under the second half's kernels.
+ *   part 0: forward, loss, dZ chain, then the weight gradients of the CRITIC (and of the auxiliary head): on return (stream
+ *           order) grads[hgym_net_param_offset(cfg, 1) .. P] -- critic | auxiliary head | the KL slot -- are final;
+ *   part 1: the weight gradients of the ACTOR: grads[0 .. hgym_net_param_offset(cfg, 1)) -- std | actor -- are final.
+ * part 0 followed by part 1 leaves net->grads exactly as hgym_ppo_grad does (bit-identical); only opt_state[9] (the squared
+ * norm hgym_ppo_apply may reuse with grad_norm_ready) is not maintained: apply must be called with grad_norm_ready = 0 or
+ * world_size > 1. */
+int32_t hgym_ppo_grad_part(const HgymNetConfig* cfg, const HgymPPOConfig* ppo, const HgymNet* net,
+                           const HgymBatch* batch, int32_t part, void* stream);
+/* offset (floats) in the flat parameter / gradient vector of the first parameter of net `which` (0 actor, 1 critic, 2 auxiliary
+ * head; which == number of nets: the parameter count); -1 on a bad argument */
+int64_t hgym_net_param_offset(const HgymNetConfig* cfg, int32_t which);
+
 /* clip_grad_norm_ + Adam.step (ppo.py:173-174) on net->grads (the rank-SUM when world_size > 1: divided by
  * world_size here, as is the KL in grads[P] before the learning-rate decision), refreshes the
  * compute-precision shadows, bumps opt_state. */

@@ -14,8 +14,9 @@ Needs /root/reference (present only in the build container).  Outputs (all small
   tests/golden/env_trace_generic.npz  the same on a trimesh terrain map with terrain + command curricula and height measurements
   tests/golden/env_trace_yawrate.npz  the same with cfg.commands.heading_command = False
   tests/golden/ppo_update.npz       PPO.act / process_env_step / compute_returns / update on a small net
-The oracle (oracle/*.py) is pinned against these in tests/test_oracle_golden.py; the HIP path is then
-compared against the oracle on the GPU.
+  tests/golden/ppo_update_full.npz  the same at the FULL XBot-L layer widths (inputs regenerated from a seed: ppo_full_case.py)
+The oracle (oracle/*.py) is pinned against these in tests/test_oracle_env_golden.py and tests/test_oracle_algo_golden.py
+(CPU); the HIP path replays the same vectors on the GPU (tests/test_env_gpu.py, test_net_gpu.py, test_gae_gpu.py).
 """
 import hashlib
 import json
@@ -410,8 +411,83 @@ def gen_ppo_update(R, N=24, T=8, seed=3):
     print("ppo_update.npz lrs", lrs, "losses", mvl, msl)
 
 
+def gen_ppo_update_full(R):
+    """The reference's PPO (algo/ppo/ppo.py:91-184, unmodified) on the FULL XBot-L layer widths: one iteration on the inputs of
+    tests/golden/ppo_full_case.py.  Stored: everything small in fp32 (per-step act outputs, rewards / returns / advantages, the
+    learning-rate sequence, losses, per-tensor norms of the first minibatch's clipped gradient and of the parameter change);
+    the 926 105-element tensors as fp16 (x a power-of-two scale; for rel-L2 / cosine checks) plus an fp32-exact sample of 4096
+    entries per large tensor (for the element-wise fp32 checks)."""
+    import ppo_full_case as CASE
+    seed = CASE.SEED
+    torch.manual_seed(seed)
+    ac = R.ActorCritic(705, 219, 12, actor_hidden_dims=CASE.ACTOR_HIDDEN, critic_hidden_dims=CASE.CRITIC_HIDDEN, init_noise_std=1.0)
+    p0 = CASE.initial_parameters(seed)
+    ac.load_state_dict({k: torch.from_numpy(v) for k, v in p0.items()})
+    alg = R.PPO(ac, device="cpu", **CASE.HYPER)
+    N, T = CASE.N, CASE.T
+    alg.init_storage(N, T, [705], [219], [12])
+    I = {k: torch.from_numpy(v) for k, v in CASE.rollout_inputs(seed).items()}
+    out = dict(seed=np.array(seed), N=np.array(N), T=np.array(T))
+    act_l, val_l, logp_l, mu_l = [], [], [], []
+    _orig_normal = torch.normal
+    for t in range(T):
+        z = I["z"][t]
+        torch.normal = lambda mean, std, **k: mean + std * z          # Normal.sample() with the recorded standard draw
+        try:
+            with torch.inference_mode():
+                a = alg.act(I["obs"][t], I["priv"][t])
+        finally:
+            torch.normal = _orig_normal
+        act_l.append(npy(a)); val_l.append(npy(alg.transition.values)); logp_l.append(npy(alg.transition.actions_log_prob))
+        mu_l.append(npy(alg.transition.action_mean))
+        with torch.inference_mode():
+            alg.process_env_step(I["rew_in"][t].clone(), I["done"][t], {"time_outs": I["time_outs"][t]})
+    with torch.inference_mode():
+        alg.compute_returns(I["last_priv"])
+    st = alg.storage
+    out.update(actions=np.stack(act_l), values=np.stack(val_l), logp=np.stack(logp_l), mu=np.stack(mu_l),
+               st_rewards=npy(st.rewards), st_returns=npy(st.returns), st_advantages=npy(st.advantages))
+    _orig_randperm = torch.randperm
+    torch.randperm = lambda n, **k: I["perm"].clone()
+    lrs = []
+    _orig_step = alg.optimizer.step
+    big = {}
+
+    def keep(prefix, name, t, scale):
+        a = npy(t).reshape(-1).astype(np.float32)
+        key = name.replace(".", "_")
+        out["%s_norm_%s" % (prefix, key)] = np.array(np.sqrt((a.astype(np.float64) ** 2).sum()))
+        idx = CASE.sample_index(name, a.size, seed)
+        out["%s_s32_%s" % (prefix, key)] = a[idx]                    # fp32-exact sample (whole tensor when small)
+        if a.size > idx.size:
+            out["%s_h16_%s" % (prefix, key)] = (a * scale).astype(np.float16)
+            big[prefix] = scale
+
+    def step(*a, **k):
+        lrs.append(alg.optimizer.param_groups[0]["lr"])
+        if len(lrs) == 1:   # gradients of the first minibatch, after clipping
+            for kname, p in ac.named_parameters():
+                keep("g0", kname, p.grad, 1024.0)
+        return _orig_step(*a, **k)
+
+    alg.optimizer.step = step
+    try:
+        mvl, msl = alg.update()
+    finally:
+        torch.randperm = _orig_randperm
+    for kname, p in ac.named_parameters():
+        keep("dP", kname, p.data - torch.from_numpy(p0[kname]), 64.0)           # parameter change over the 8 Adam steps
+    out.update(lrs=np.array(lrs), mean_value_loss=np.array(mvl), mean_surrogate_loss=np.array(msl), final_lr=np.array(alg.learning_rate),
+               g0_h16_scale=np.array(1024.0), dP_h16_scale=np.array(64.0))
+    np.savez_compressed(os.path.join(HERE, "ppo_update_full.npz"), **out)
+    print("ppo_update_full.npz lrs", lrs, "losses", mvl, msl, "size %.2f MB" % (os.path.getsize(os.path.join(HERE, "ppo_update_full.npz")) / 1e6))
+
+
 if __name__ == "__main__":
     R = H.load_reference()
+    if "--only-ppo-full" in sys.argv:
+        gen_ppo_update_full(R)
+        sys.exit(0)
     if "--only-generic" in sys.argv:
         gen_env_trace(R, N=32, S=20, seed=13, name="env_trace_generic.npz", generic=True)
         sys.exit(0)
@@ -427,3 +503,4 @@ if __name__ == "__main__":
         gen_env_trace(R, N=32, S=20, seed=13, name="env_trace_generic.npz", generic=True)
         gen_env_trace(R, N=16, S=14, seed=14, name="env_trace_yawrate.npz", heading_command=False)
         gen_ppo_update(R)
+        gen_ppo_update_full(R)

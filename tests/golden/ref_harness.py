@@ -1,8 +1,8 @@
 """Fixture-generation harness: runs the UNMODIFIED reference (`/root/reference/humanoid`) on CPU.
 
 Test infrastructure only.  It is imported by `tests/golden/gen_fixtures.py` (which writes the
-committed `tests/golden/*.npz` vectors) and by the in-container-only cross-check tests
-(`tests/test_oracle_vs_reference.py`, skipped when `/root/reference` is absent, e.g. on the GPU box).
+committed `tests/golden/*.npz` vectors), by `tests/golden/gen_sim2sim_fixture.py` / `gen_terrain_fixture.py`, and by
+`bench.py`'s `cpu_baseline` leg when `/root/reference` is present (never on the GPU box: nothing there reads it).
 
 Recipe = SURVEY.md Appendix B: stub the three absent third-party imports (`isaacgym`, `wandb`,
 `torch.utils.tensorboard`), restate `isaacgym.torch_utils` (closed source, Isaac Gym Preview 4,

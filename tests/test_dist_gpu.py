@@ -15,27 +15,39 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, backend="gloo"):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "humanoid-gym_amd"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if backend == "nccl":            # RCCL: one device per rank
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+        dev = "cuda:%d" % rank
+    else:
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dev = "cuda:0"
     from humanoid.algo import PPO
     PPO.precision = "bf16"
     from humanoid.envs import task_registry
     from humanoid.utils import get_args
-    args = get_args(["--task=humanoid_ppo", "--headless", "--num_envs", "256", "--seed", str(5 + rank)])
+    args = get_args(["--task=humanoid_ppo", "--headless", "--num_envs", "256", "--seed", str(5 + rank), "--sim_device", dev,
+                     "--rl_device", dev])
     env, _ = task_registry.make_env(name=args.task, args=args)
     runner, _ = task_registry.make_alg_runner(env=env, name=args.task, args=args, log_root=None)
     assert runner.alg._world == world
     p_init = runner.alg.net.params.clone()
+    friction, commands0, seed = env.env_frictions.clone().cpu(), env.commands.clone().cpu(), int(env._ncfg.seed)
+    runner.alg.comm_timing = []
     runner.learn(num_learning_iterations=4, init_at_random_ep_len=True)     # eager, capture + replay, replay, replay
     torch.cuda.synchronize()
     net = runner.alg.net
     torch.save(dict(p_init=p_init.cpu(), params=net.params.cpu(), lr=float(net.opt_state[0]), steps=float(net.opt_state[1]),
-                    obs=runner.alg.storage._obs_all[1].cpu(), graph=runner._graph is not None), os.path.join(out_dir, "r%d.pt" % rank))
+                    obs=runner.alg.storage._obs_all[1].cpu(), graph=runner._graph is not None, friction=friction, commands0=commands0,
+                    env_seed=seed, comm_events=len(runner.alg.comm_timing), split=net.bucket_split, P=net.P),
+               os.path.join(out_dir, "r%d.pt" % rank))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -49,4 +61,44 @@ def test_two_ranks_one_gpu_stay_in_lockstep(tmp_path):
     assert torch.equal(a["params"], b["params"])                  # bit-identical after 32 synchronised Adam steps
     assert a["lr"] == b["lr"] and a["steps"] == b["steps"] == 4 * 8
     assert a["graph"] and b["graph"]
-    assert not torch.equal(a["obs"], b["obs"])                    # different env shards (seed + rank)
+    assert not torch.equal(a["obs"], b["obs"])                    # different env shards
+    # every rank owns an independent env stream: Philox key, frictions and the first command draws all differ (helpers.shard_seed)
+    assert a["env_seed"] != b["env_seed"] and a["env_seed"] == 5
+    assert not torch.equal(a["friction"], b["friction"]) and not torch.equal(a["commands0"], b["commands0"])
+    # the gradient exchange ran as two buckets per minibatch (one event pair per minibatch: 4 iterations x 8)
+    assert a["comm_events"] == 32 and 0 < a["split"] < a["P"]
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one device per rank; this box has one GPU")
+def test_two_ranks_two_gpus_rccl(tmp_path):
+    """The same run over RCCL (backend "nccl"), rank r on device r: bit-identical parameters after 32 synchronised steps."""
+    port = 29900 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(2, port, str(tmp_path), "nccl"), nprocs=2, join=True)
+    a, b = (torch.load(os.path.join(str(tmp_path), "r%d.pt" % i)) for i in range(2))
+    assert torch.equal(a["p_init"], b["p_init"]) and torch.equal(a["params"], b["params"])
+    assert torch.isfinite(a["params"]).all() and not torch.equal(a["params"], a["p_init"])
+    assert a["lr"] == b["lr"] and a["steps"] == b["steps"] == 32 and a["graph"] and b["graph"]
+    assert not torch.equal(a["friction"], b["friction"])
+
+
+def test_bench_spawns_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` with no torch.distributed environment (how the driver starts the N = 1 run) must launch its two
+    ranks itself and print ONE JSON line with n_gpus = 2.  On a one-GPU box the ranks share the device over gloo
+    (HGYM_DIST_BACKEND); with two devices the default RCCL path runs."""
+    import json
+    import subprocess
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    if torch.cuda.device_count() < 2:
+        env["HGYM_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "2", "--num-envs", "512"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
+    assert out["config"]["envs_per_gpu"] == 512 and "cpu_baseline" not in out and "configs" not in out
+    assert out["comm"]["minibatches_per_iter"] == 8 and out["comm"]["exposed_us_per_minibatch"] >= 0
+    assert out["roofline"]["frac"] > 0

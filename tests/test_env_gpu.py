@@ -24,7 +24,7 @@ def test_golden_trace_gpu(hip, golden_dir, name):
     G = np.load(os.path.join(golden_dir, name))
     N = G["friction"].shape[0]
     env = EC.EnvUnderTest(hip, N, T(G["friction"]), T(G["body_mass"]), sim_layout="aos", use_ref_actions=bool(G["use_ref_actions"]),
-                          heading_command=bool(G["heading_command"]) if "heading_command" in G.files else True)
+                          heading_command=bool(G["heading_command"]))
     env.prime(T(G["prime_u_dof"]), T(G["prime_u_cmd"]), T(G["prime_z_obs"]))
     hip.sync()
     EC.close(env.buf.obs, G["prime_obs"], "prime obs")

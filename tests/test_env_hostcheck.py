@@ -23,7 +23,7 @@ def test_golden_trace_host(host, golden_dir, name):
     G = np.load(os.path.join(golden_dir, name))
     N = G["friction"].shape[0]
     env = EC.EnvUnderTest(host, N, T(G["friction"]), T(G["body_mass"]), sim_layout="aos", use_ref_actions=bool(G["use_ref_actions"]),
-                          heading_command=bool(G["heading_command"]) if "heading_command" in G.files else True)
+                          heading_command=bool(G["heading_command"]))
     env.prime(T(G["prime_u_dof"]), T(G["prime_u_cmd"]), T(G["prime_z_obs"]))
     EC.close(env.buf.obs, G["prime_obs"], "prime obs")
     EC.close(env.buf.priv_obs, G["prime_priv"], "prime priv")

@@ -306,3 +306,108 @@ def test_apply_can_reuse_the_norm_left_by_grad(precision):
     assert float(a.opt_state[6]) > 1.0                         # the clip really acted (advantages x30)
     np.testing.assert_allclose(float(b.opt_state[6]), float(a.opt_state[6]), rtol=1e-6)
     np.testing.assert_allclose(b.params.cpu().numpy(), a.params.cpu().numpy(), rtol=1e-7, atol=1e-9)
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+def test_grad_in_two_parts_is_the_whole_gradient(precision):
+    """hgym_ppo_grad_part 0 then 1 (the data-parallel update's two gradient buckets) leaves net.grads and the KL slot exactly
+    as hgym_ppo_grad does; after part 0 alone the critic bucket [split, P] is already final."""
+    from hgym import NetBuffers, make_net_config, make_ppo_config, make_batch
+    S = B = 777
+    torch.manual_seed(3)
+    cfg = make_net_config(705, 219, 12, [512, 256, 128], [768, 256, 128], precision, B)
+    net = NetBuffers(cfg, "cuda", learning_rate=1e-3)
+    for k, v in net.views.items():
+        v.copy_(torch.randn(v.shape, device="cuda") * (0.05 if v.dim() > 1 else 0.01))
+    net.views["std"].fill_(0.9)
+    net.sync_shadow()
+    r = lambda *s: torch.randn(*s, device="cuda")
+    cols = (r(S, 705), r(S, 219), r(S, 12), r(S), r(S), r(S), r(S) - 12.0, r(S, 12) * 0.3, torch.ones(S, 12, device="cuda"))
+    idx = torch.randperm(S, device="cuda").contiguous()
+    ppo = make_ppo_config()
+    split = net.bucket_split
+    assert split == 12 + 705 * 512 + 512 + 512 * 256 + 256 + 256 * 128 + 128 + 128 * 12 + 12
+    net.ppo_grad(ppo, make_batch(*cols, idx))
+    torch.cuda.synchronize()
+    whole = net.grads_ext.clone()
+    net.grads_ext.fill_(float("nan"))
+    net.ppo_grad_part(ppo, make_batch(*cols, idx), 0)
+    torch.cuda.synchronize()
+    assert torch.equal(net.grads_ext[split:], whole[split:])
+    net.ppo_grad_part(ppo, make_batch(*cols, idx), 1)
+    torch.cuda.synchronize()
+    assert torch.equal(net.grads_ext, whole)
+
+
+# ---------------------------------------------------------------------------------------------- full-width reference fixture
+def _full_case():
+    import ppo_full_common as F
+    G, p0, I = F.load()
+    Gin = dict(I)
+    Gin.update(actor_hidden=np.array(F.CASE.ACTOR_HIDDEN), critic_hidden=np.array(F.CASE.CRITIC_HIDDEN))
+    Gin.update({"p0_" + k.replace(".", "_"): v for k, v in p0.items()})
+    return F, G, p0, Gin
+
+
+def test_ppo_iteration_full_width_matches_reference_f32():
+    """tests/golden/ppo_update_full.npz: the reference's PPO (ppo.py:91-184) at the real layer widths 705-512-256-128-12 /
+    219-768-256-128-1, 4 minibatches of 164 rows.  fp32 path: element-wise on the fp32-exact samples."""
+    F, G, p0, Gin = _full_case()
+    r = _run_iteration(Gin, "f32")
+    st = r["st"]
+    for k, ref, tol in (("actions", G["actions"], 1e-5), ("values", G["values"], 1e-5), ("mu", G["mu"], 1e-5),
+                        ("rewards", G["st_rewards"].squeeze(-1), 1e-5), ("returns", G["st_returns"].squeeze(-1), 1e-5),
+                        ("advantages", G["st_advantages"].squeeze(-1), 1e-4)):
+        assert _rel_err(st[k].cpu().numpy(), ref) <= tol, (k, _rel_err(st[k].cpu().numpy(), ref))
+    np.testing.assert_allclose(r["lrs"], G["lrs"], rtol=1e-12)
+    rep = []
+    for name, d in F.compare(G, "g0", {k: v.numpy() for k, v in r["g0"].items()}, rep).items():
+        assert d["sample_max_err"] <= 5e-5 and abs(d["norm_ratio"] - 1) <= 2e-4, (name, d)
+    dP = {k: r["net"].views[k].cpu().numpy() - p0[k] for k in NAMES}
+    for name, d in F.compare(G, "dP", dP, rep).items():
+        assert d["sample_max_err"] <= 5e-3 and abs(d["norm_ratio"] - 1) <= 2e-3, (name, d)
+    print("\n".join(rep))
+    opt = r["opt"]
+    np.testing.assert_allclose(float(opt[4] / opt[7]), float(G["mean_value_loss"]), rtol=1e-4)
+    np.testing.assert_allclose(float(opt[3] / opt[7]), float(G["mean_surrogate_loss"]), rtol=1e-3, atol=1e-6)
+
+
+# per-tensor tolerance of the bf16 FUSED path against the reference's fp32 autograd, first-minibatch clipped gradient (measured:
+# profiles/r02_bf16_full_width_parity.txt); rel-L2 error | cosine
+BF16_G0_TOL = {"rel_l2": 6e-2, "cos": 0.998}
+
+
+def test_ppo_iteration_full_width_bf16_fused_kernels_vs_reference(capsys):
+    """The same fixture through the kernels bench.py times: mlp_fwd_kernel<32,8,4> (rollout, 82 rows = two 32-row tiles + a
+    ragged one), mlp_fwd_kernel<64,16,2> / mlp_bwd_kernel / dw_kernel_rs (update, 164 rows = two 64-row tiles + a ragged one).
+    bf16 operands, fp32 accumulation: activations within 2e-2, first learning-rate decision identical, the clipped gradient of
+    the first minibatch within BF16_G0_TOL per tensor, the 8-step parameter change in the same direction."""
+    from hgym import _lib as L
+    F, G, p0, Gin = _full_case()
+    L.lib.hgym_prof_enable(1)
+    r = _run_iteration(Gin, "bf16")
+    fused = [L.prof_summary(c)[0] for c in (L.PROF_POLICY, L.PROF_MLP_FWD, L.PROF_MLP_BWD, L.PROF_DW)]
+    generic = L.prof_summary(L.PROF_GEMM)[0]
+    L.lib.hgym_prof_enable(0)
+    assert fused[0] >= F.CASE.T and fused[1:] == [8, 8, 8], fused      # the fused kernels ran (T rollout steps + bootstrap; 8 minibatches) ...
+    assert generic == 0                                                 # ... and no layer-by-layer GEMM did
+    st = r["st"]
+    assert _rel_err(st["values"].cpu().numpy(), G["values"]) <= 2e-2
+    assert _rel_err(st["mu"].cpu().numpy(), G["mu"]) <= 2e-2
+    assert _rel_err(st["returns"].cpu().numpy(), G["st_returns"].squeeze(-1)) <= 2e-2
+    assert r["lrs"][0] == G["lrs"][0]
+    rep = ["bf16 fused path vs reference fp32, clipped gradient of minibatch 0:"]
+    cmp_g = F.compare(G, "g0", {k: v.numpy() for k, v in r["g0"].items()}, rep)
+    rep.append("total cosine %.6f" % F.total_cosine(G, "g0", {k: v.numpy() for k, v in r["g0"].items()}))
+    dP = {k: r["net"].views[k].cpu().numpy() - p0[k] for k in NAMES}
+    rep.append("parameter change over 8 Adam steps:")
+    cmp_p = F.compare(G, "dP", dP, rep)
+    rep.append("total cosine %.6f ; lrs %s vs %s" % (F.total_cosine(G, "dP", dP), r["lrs"], list(G["lrs"])))
+    with capsys.disabled():
+        print("\n" + "\n".join(rep))
+    for name, d in cmp_g.items():
+        if name == "std":
+            continue       # 12 numbers, each a sum over the batch of a difference of O(1) terms: compared in absolute terms below
+        assert d["rel_l2"] <= BF16_G0_TOL["rel_l2"] and d["cos"] >= BF16_G0_TOL["cos"], (name, d)
+    assert F.total_cosine(G, "g0", {k: v.numpy() for k, v in r["g0"].items()}) >= 0.999
+    assert F.total_cosine(G, "dP", dP) >= 0.9

@@ -98,3 +98,32 @@ def test_ppo_iteration_matches_reference(golden_dir):
     np.testing.assert_allclose(msl, float(G["mean_surrogate_loss"]), rtol=1e-4, atol=1e-7)
     for nme, t in zip(names, p.tensors()):
         np.testing.assert_allclose(t.numpy(), G["pF_" + nme], rtol=1e-4, atol=2e-6, err_msg=nme)
+
+
+def test_ppo_iteration_full_width_matches_reference():
+    """The same iteration at the FULL XBot-L layer widths (tests/golden/ppo_update_full.npz: the reference's PPO on inputs
+    regenerated from a seed, ppo_full_case.py): oracle vs reference, fp32."""
+    import ppo_full_common as F
+    G, p0, I = F.load()
+    p = P.Params.from_npz({"p0_" + k.replace(".", "_"): v for k, v in p0.items()}, "p0_")
+    Gin = dict(obs=I["obs"], priv=I["priv"], z=I["z"], rew_in=I["rew_in"], time_outs=I["time_outs"], actions=G["actions"],
+               values=G["values"], logp=G["logp"], mu=G["mu"], sigma=np.ones_like(G["mu"]), st_rewards=G["st_rewards"])
+    st = _storage(Gin, p)
+    last_v = P.mlp_forward(T(I["last_priv"]), p.critic).squeeze(-1)
+    ret, adv = P.gae_returns(st["rewards"].squeeze(-1), st["values"].squeeze(-1), T(I["done"]), last_v, 0.994, 0.9)
+    np.testing.assert_allclose(ret.numpy(), G["st_returns"].squeeze(-1), rtol=1e-5, atol=1e-5)
+    st["returns"] = ret.unsqueeze(-1)
+    st["advantages"] = P.normalize_advantages(adv).unsqueeze(-1)
+    np.testing.assert_allclose(st["advantages"].numpy(), G["st_advantages"], rtol=1e-4, atol=1e-5)
+    opt = P.Adam(p)
+    trace = []
+    lr, mvl, msl = P.ppo_update(p, opt, st, T(I["perm"]), lr=1e-3, trace=trace)
+    np.testing.assert_allclose([t["lr"] for t in trace], G["lrs"], rtol=1e-12)
+    g0 = dict(zip(F.CASE.NAMES, (g.numpy() for g in trace[0]["grads"].tensors())))
+    for name, d in F.compare(G, "g0", g0).items():
+        assert d["sample_max_err"] <= 2e-5 and abs(d["norm_ratio"] - 1) <= 1e-4, (name, d)
+    dP = {k: t.numpy() - p0[k] for k, t in zip(F.CASE.NAMES, p.tensors())}
+    for name, d in F.compare(G, "dP", dP).items():
+        assert d["sample_max_err"] <= 2e-3 and abs(d["norm_ratio"] - 1) <= 1e-3, (name, d)
+    np.testing.assert_allclose(mvl, float(G["mean_value_loss"]), rtol=1e-5)
+    np.testing.assert_allclose(msl, float(G["mean_surrogate_loss"]), rtol=1e-4, atol=1e-7)

@@ -23,7 +23,7 @@ def _load(golden_dir, name="env_trace.npz"):
 def _prime(G):
     N = G["friction"].shape[0]
     o = XBotEnvOracle(N, frictions=T(G["friction"]), body_mass=T(G["body_mass"]), use_ref_actions=bool(G["use_ref_actions"]),
-                      heading_command=bool(G["heading_command"]) if "heading_command" in G.files else True)
+                      heading_command=bool(G["heading_command"]))
     o.prime(T(G["prime_u_dof"]), T(G["prime_u_cmd"]), T(G["prime_z_obs"]))
     return o
 
@@ -81,7 +81,7 @@ def test_trace_matches_reference(golden_dir, name):
     assert saw["reset"] > 10 and saw["timeout"] >= 2 and saw["push"] == 1
     if bool(G["use_ref_actions"]):
         assert float(np.abs(G["actions_in_after"] - G["actions_in"]).max()) > 0.5       # the feature really was on
-    if "heading_command" in G.files and not bool(G["heading_command"]):
+    if not bool(G["heading_command"]):
         assert float(np.abs(G["commands"][:, :, 3]).max()) == 0.0                       # no heading target is ever drawn
         assert float(np.abs(G["commands"][:, :, 2]).max()) <= 0.3 + 1e-6
     for k in ("feet_air_time", "last_contacts", "feet_height", "last_feet_z", "last_actions", "last_last_actions",
