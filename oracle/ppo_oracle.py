@@ -86,33 +86,58 @@ class Params:
                       [(W.clone(), b.clone()) for W, b in self.critic], self.std.clone())
 
 
-def mlp_forward(x, layers, keep=False):
+def bf16_round(t):
+    """Round-to-nearest-even to bfloat16 and back: the operand precision of the MFMA fast path."""
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def mlp_forward(x, layers, keep=False, quant=None):
     """Linear -> ELU(alpha=1) -> ... -> Linear.  With keep=True also returns the layer inputs and
-    pre-activations needed by mlp_backward."""
-    acts, pres = [x], []
-    h = x
+    pre-activations needed by mlp_backward.
+
+    quant (e.g. bf16_round): the operand-precision model of the bf16 kernels -- NOT something the reference does.  Applied
+    where csrc/hgym_fused.hpp rounds: the gathered input rows, every weight matrix, every hidden activation after the ELU;
+    biases, accumulation and the head output stay fp32.  Lets a test separate "the kernel computes the bf16-operand network
+    correctly" from "bf16 operands differ from fp32 ones"."""
+    q = quant if quant is not None else (lambda t: t)
+    h = q(x)
+    acts, pres = [h], []
     for i, (W, b) in enumerate(layers):
-        z = F.linear(h, W, b)
+        z = F.linear(h, q(W), b)
         if i < len(layers) - 1:
             pres.append(z)
-            h = torch.where(z > 0, z, torch.exp(z) - 1.0)   # == F.elu(z) (expm1 on some builds; see test tol)
+            h = q(torch.where(z > 0, z, torch.exp(z) - 1.0))   # == F.elu(z) (expm1 on some builds; see test tol)
             acts.append(h)
         else:
             h = z
     return (h, acts, pres) if keep else h
 
 
-def mlp_backward(dy, layers, acts, pres):
-    """Gradients of sum(dy * mlp(x)) w.r.t. every W, b.  acts[i] = input of layer i, pres[i] = its pre-activation."""
+def mlp_backward(dy, layers, acts, pres, quant=None):
+    """Gradients of sum(dy * mlp(x)) w.r.t. every W, b.  acts[i] = input of layer i, pres[i] = its pre-activation.
+
+    quant: as in mlp_forward -- every dZ is rounded where the kernels store it, elu' is taken from the ROUNDED activation y
+    (y > 0 ? 1 : y + 1, what mlp_bwd_kernel does), the head's bias gradient is summed before the rounding (the loss kernel's
+    fp32 partials), the hidden ones after it (column sums of the stored dZ)."""
+    q = quant
     grads = [None] * len(layers)
     g = dy
     for i in reversed(range(len(layers))):
         W, _ = layers[i]
-        grads[i] = (g.t() @ acts[i], g.sum(dim=0))
+        if q is None:
+            grads[i] = (g.t() @ acts[i], g.sum(dim=0))
+        else:
+            gb = g.sum(dim=0) if i == len(layers) - 1 else None
+            g = q(g)
+            grads[i] = (g.t() @ acts[i], gb if gb is not None else g.sum(dim=0))
         if i > 0:
-            g = g @ W
-            z = pres[i - 1]
-            g = g * torch.where(z > 0, torch.ones_like(z), torch.exp(z))
+            g = g @ (W if q is None else q(W))
+            if q is None:
+                z = pres[i - 1]
+                g = g * torch.where(z > 0, torch.ones_like(z), torch.exp(z))
+            else:
+                y = acts[i]
+                g = g * torch.where(y > 0, torch.ones_like(y), y + 1.0)
     return grads
 
 
@@ -142,16 +167,16 @@ def bootstrap_rewards(rewards, values, time_outs, gamma):
 
 # ------------------------------------------------------------------------------------------------ A11
 def ppo_loss_and_grads(p, obs, priv, actions, old_values, adv, returns, old_logp, old_mu, old_sigma,
-                       clip=0.2, value_coef=1.0, entropy_coef=0.001):
+                       clip=0.2, value_coef=1.0, entropy_coef=0.001, quant=None):
     """One minibatch of ppo.py:128-168 + the hand-written backward of `loss`.
 
     Inputs are (B,*) with old_values/adv/returns/old_logp shaped (B,).  Returns
     dict(loss, surrogate, value_loss, entropy, kl, grads=Params-shaped gradients)."""
     B = obs.shape[0]
-    mu, a_acts, a_pres = mlp_forward(obs, p.actor, keep=True)
+    mu, a_acts, a_pres = mlp_forward(obs, p.actor, keep=True, quant=quant)
     sigma = mu * 0.0 + p.std
     logp = gaussian_log_prob(actions, mu, sigma)
-    val, c_acts, c_pres = mlp_forward(priv, p.critic, keep=True)
+    val, c_acts, c_pres = mlp_forward(priv, p.critic, keep=True, quant=quant)
     val = val.squeeze(-1)
     ent = gaussian_entropy(sigma)
     kl = torch.sum(torch.log(sigma / old_sigma + 1.e-5)
@@ -179,8 +204,8 @@ def ppo_loss_and_grads(p, obs, priv, actions, old_values, adv, returns, old_logp
     v_in = ((val - old_values) >= -clip) & ((val - old_values) <= clip)
     u1 = torch.where(l1 > l2, torch.ones_like(l1), torch.where(l1 == l2, torch.full_like(l1, 0.5), torch.zeros_like(l1)))
     d_val = value_coef / B * (u1 * 2 * (val - returns) + (1.0 - u1) * 2 * (v_clipped - returns) * v_in)
-    ga = mlp_backward(d_mu, p.actor, a_acts, a_pres)
-    gc = mlp_backward(d_val.unsqueeze(1), p.critic, c_acts, c_pres)
+    ga = mlp_backward(d_mu, p.actor, a_acts, a_pres, quant=quant)
+    gc = mlp_backward(d_val.unsqueeze(1), p.critic, c_acts, c_pres, quant=quant)
     return dict(loss=loss, surrogate=surrogate, value_loss=value_loss, entropy=ent.mean(), kl=kl,
                 grads=Params(ga, gc, d_std), d_mu=d_mu, d_val=d_val, mu=mu, val=val, logp=logp)
 

@@ -365,7 +365,9 @@ def test_ppo_iteration_full_width_matches_reference_f32():
         assert d["sample_max_err"] <= 5e-5 and abs(d["norm_ratio"] - 1) <= 2e-4, (name, d)
     dP = {k: r["net"].views[k].cpu().numpy() - p0[k] for k in NAMES}
     for name, d in F.compare(G, "dP", dP, rep).items():
-        assert d["sample_max_err"] <= 5e-3 and abs(d["norm_ratio"] - 1) <= 2e-3, (name, d)
+        # Adam divides by sqrt(v): entries whose gradient is ~0 amplify fp32 summation-order differences, so the element-wise
+        # bound on the parameter CHANGE is looser than on the gradient; the tensor as a whole agrees to 1e-3
+        assert d["sample_max_err"] <= 2e-2 and d["rel_l2"] <= 1e-3 and abs(d["norm_ratio"] - 1) <= 2e-3, (name, d)
     print("\n".join(rep))
     opt = r["opt"]
     np.testing.assert_allclose(float(opt[4] / opt[7]), float(G["mean_value_loss"]), rtol=1e-4)
@@ -374,7 +376,7 @@ def test_ppo_iteration_full_width_matches_reference_f32():
 
 # per-tensor tolerance of the bf16 FUSED path against the reference's fp32 autograd, first-minibatch clipped gradient (measured:
 # profiles/r02_bf16_full_width_parity.txt); rel-L2 error | cosine
-BF16_G0_TOL = {"rel_l2": 6e-2, "cos": 0.998}
+BF16_G0_TOL = {"rel_l2": 2e-2, "cos": 0.9997}      # measured: rel-L2 1.8e-3 .. 7.7e-3, cosine >= 0.99997
 
 
 def test_ppo_iteration_full_width_bf16_fused_kernels_vs_reference(capsys):
@@ -395,7 +397,7 @@ def test_ppo_iteration_full_width_bf16_fused_kernels_vs_reference(capsys):
     assert _rel_err(st["values"].cpu().numpy(), G["values"]) <= 2e-2
     assert _rel_err(st["mu"].cpu().numpy(), G["mu"]) <= 2e-2
     assert _rel_err(st["returns"].cpu().numpy(), G["st_returns"].squeeze(-1)) <= 2e-2
-    assert r["lrs"][0] == G["lrs"][0]
+    np.testing.assert_allclose(r["lrs"], G["lrs"], rtol=1e-12)       # all 8 adaptive-KL decisions as the reference took them
     rep = ["bf16 fused path vs reference fp32, clipped gradient of minibatch 0:"]
     cmp_g = F.compare(G, "g0", {k: v.numpy() for k, v in r["g0"].items()}, rep)
     rep.append("total cosine %.6f" % F.total_cosine(G, "g0", {k: v.numpy() for k, v in r["g0"].items()}))
@@ -410,4 +412,4 @@ def test_ppo_iteration_full_width_bf16_fused_kernels_vs_reference(capsys):
             continue       # 12 numbers, each a sum over the batch of a difference of O(1) terms: compared in absolute terms below
         assert d["rel_l2"] <= BF16_G0_TOL["rel_l2"] and d["cos"] >= BF16_G0_TOL["cos"], (name, d)
     assert F.total_cosine(G, "g0", {k: v.numpy() for k, v in r["g0"].items()}) >= 0.999
-    assert F.total_cosine(G, "dP", dP) >= 0.9
+    assert F.total_cosine(G, "dP", dP) >= 0.995                     # measured 0.9986

@@ -2,7 +2,7 @@
 # usage: tools/gpu_try.sh <tag> "<pytest selection>" ["<bench args>"]  -- a selected set of GPU tests, then (optionally) one bench.py run
 tag=$1; sel=$2; bargs=$3
 mkdir -p gpurun_out
-timeout 1500 python -m pytest $sel -m gpu -q -x > gpurun_out/${tag}_pytest.txt 2>&1
+eval timeout 1500 python -m pytest $sel -m gpu -q -x > gpurun_out/${tag}_pytest.txt 2>&1
 echo "pytest exit $?" >> gpurun_out/${tag}_pytest.txt
 tail -15 gpurun_out/${tag}_pytest.txt
 if [ -n "$bargs" ]; then
