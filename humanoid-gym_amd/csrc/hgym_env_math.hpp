@@ -1019,61 +1019,90 @@ HG_HD void stage_sim(const EnvArgs& A, const LdsMap& m, float* smem, int E, int 
 // lanes re-read the last item) plus its share of the state rows, all before its first LDS write: the stage costs one
 // memory round trip instead of one per field.  Every base pointer is a fixed struct member -- a lane-varying choice
 // between tensors would make the compiler index the kernel argument dynamically and spill it to scratch.
+// The loads of the fast path live in a register record so that a caller can put other independent loads (the history
+// prefetch, whose addresses wait for the ring-step counter) between their issue and their LDS writes: issue first, wait last.
 template <int E_T>
-HG_HD void env_stage_in(const EnvArgs& A, int block, int t, int nthreads, float* smem) {
+struct StageRegs {
+    static constexpr int EE = E_T > 0 ? E_T : 4;
+    static constexpr int Q = EE / 4;                                 // 16-byte items per component row
+    static constexpr int NS = (kStateComps * Q + 255) / 256;
+    EnvF4 rs[NS], r_root, r_dp, r_dv, r_ct, r_rg, r_act, r_ep;
+    int fast;
+};
+template <int E_T>
+HG_HD bool env_stage_fast(const EnvArgs& A, int block, int nthreads) {
+    const int E = E_T > 0 ? E_T : A.envs_per_block;
+    const int N = A.cfg.num_envs, e0 = block * E;
+    const int nE = (E < N - e0) ? E : (N - e0);
+    constexpr int Q = StageRegs<E_T>::Q;
+    return E_T > 0 && (E_T & 3) == 0 && 14 * Q <= 256 && nthreads == 256 && nE == E && A.state_contig &&
+           A.sim.root.env_stride == 1 && A.sim.dof_pos.env_stride == 1 && A.sim.dof_vel.env_stride == 1 &&
+           A.sim.contact.env_stride == 1 && A.sim.rigid.env_stride == 1;
+}
+template <int E_T>
+HG_HD void env_stage_in_load(const EnvArgs& A, int block, int t, int nthreads, StageRegs<E_T>& R) {
+    const int E = E_T > 0 ? E_T : A.envs_per_block;
+    const int N = A.cfg.num_envs, e0 = block * E;
+    constexpr int EE = StageRegs<E_T>::EE, Q = StageRegs<E_T>::Q, NS = StageRegs<E_T>::NS;
+    R.fast = env_stage_fast<E_T>(A, block, nthreads) ? 1 : 0;
+    if (!R.fast) return;
+    auto cl = [](int i, int n) { return i < n ? i : n - 1; };
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+        const int i = cl(t + u * 256, kStateComps * Q);
+        R.rs[u] = *reinterpret_cast<const EnvF4*>(A.st.commands + (int64_t)(i / Q) * N + e0 + 4 * (i % Q));
+    }
+    const int i13 = cl(t, 13 * Q), i12 = cl(t, 12 * Q), i9 = cl(t, 9 * Q), i14 = cl(t, 14 * Q);
+    R.r_root = *reinterpret_cast<const EnvF4*>(A.sim.root.base + (int64_t)(i13 / Q) * A.sim.root.comp_stride + e0 + 4 * (i13 % Q));
+    R.r_dp = *reinterpret_cast<const EnvF4*>(A.sim.dof_pos.base + (int64_t)(i12 / Q) * A.sim.dof_pos.comp_stride + e0 + 4 * (i12 % Q));
+    R.r_dv = *reinterpret_cast<const EnvF4*>(A.sim.dof_vel.base + (int64_t)(i12 / Q) * A.sim.dof_vel.comp_stride + e0 + 4 * (i12 % Q));
+    const int cc0 = A.contact_comp[0], cc1 = A.contact_comp[1], cc2 = A.contact_comp[2];
+    const int k9 = i9 / Q;
+    const int ccomp = (k9 < 3 ? cc0 : (k9 < 6 ? cc1 : cc2)) + k9 % 3;
+    R.r_ct = *reinterpret_cast<const EnvF4*>(A.sim.contact.base + (int64_t)ccomp * A.sim.contact.comp_stride + e0 + 4 * (i9 % Q));
+    const int rc0 = A.rigid_comp[0], rc1 = A.rigid_comp[1], rc2 = A.rigid_comp[2], rc3 = A.rigid_comp[3];
+    const int k14 = i14 / Q;                              // feet {x,y,z,vx,vy}, knees {x,y}
+    const int body = k14 < 10 ? k14 / 5 : 2 + (k14 - 10) / 2;
+    const int c5 = k14 % 5;
+    const int rcomp = k14 < 10 ? (c5 < 3 ? c5 : c5 + 4) : (k14 - 10) % 2;
+    const int rbase = body == 0 ? rc0 : (body == 1 ? rc1 : (body == 2 ? rc2 : rc3));
+    R.r_rg = *reinterpret_cast<const EnvF4*>(A.sim.rigid.base + (int64_t)(rbase + rcomp) * A.sim.rigid.comp_stride + e0 + 4 * (i14 % Q));
+    const int ia = cl(t, 3 * EE), ie = cl(t, EE / 2);
+    R.r_ep = *reinterpret_cast<const EnvF4*>(reinterpret_cast<const float*>(A.st.episode_length + e0) + 4 * ie);
+    // unconditional load (from the episode-length row when there are no actions): a conditionally initialised vector ends
+    // up in scratch memory, and a kernel with a private segment is dispatched differently from its neighbours
+    R.r_act = *reinterpret_cast<const EnvF4*>(A.actions_in ? A.actions_in + (int64_t)e0 * 12 + 4 * ia
+                                                            : reinterpret_cast<const float*>(A.st.episode_length + e0) + 4 * ie);
+}
+template <int E_T>
+HG_HD void env_stage_in_store(const EnvArgs& A, int block, int t, int nthreads, float* smem, const StageRegs<E_T>& R) {
     const int E = E_T > 0 ? E_T : A.envs_per_block;
     const int N = A.cfg.num_envs, e0 = block * E;
     const int nE = (E < N - e0) ? E : (N - e0);
     const LdsMap m = lds_map(E);
-    constexpr int EE = E_T > 0 ? E_T : 4;
-    constexpr int Q = EE / 4;                                 // 16-byte items per component row
-    const bool fast = E_T > 0 && (E_T & 3) == 0 && 14 * Q <= 256 && nthreads == 256 && nE == E && A.state_contig &&
-                      A.sim.root.env_stride == 1 && A.sim.dof_pos.env_stride == 1 && A.sim.dof_vel.env_stride == 1 &&
-                      A.sim.contact.env_stride == 1 && A.sim.rigid.env_stride == 1;
-    if (fast) {
-        constexpr int NS = (kStateComps * Q + 255) / 256;
+    constexpr int EE = StageRegs<E_T>::EE, Q = StageRegs<E_T>::Q, NS = StageRegs<E_T>::NS;
+    if (R.fast) {
         auto cl = [](int i, int n) { return i < n ? i : n - 1; };
-        EnvF4 rs[NS], r_root, r_dp, r_dv, r_ct, r_rg, r_act, r_ep;
-#pragma unroll
-        for (int u = 0; u < NS; ++u) {
-            const int i = cl(t + u * 256, kStateComps * Q);
-            rs[u] = *reinterpret_cast<const EnvF4*>(A.st.commands + (int64_t)(i / Q) * N + e0 + 4 * (i % Q));
-        }
         const int i13 = cl(t, 13 * Q), i12 = cl(t, 12 * Q), i9 = cl(t, 9 * Q), i14 = cl(t, 14 * Q);
-        r_root = *reinterpret_cast<const EnvF4*>(A.sim.root.base + (int64_t)(i13 / Q) * A.sim.root.comp_stride + e0 + 4 * (i13 % Q));
-        r_dp = *reinterpret_cast<const EnvF4*>(A.sim.dof_pos.base + (int64_t)(i12 / Q) * A.sim.dof_pos.comp_stride + e0 + 4 * (i12 % Q));
-        r_dv = *reinterpret_cast<const EnvF4*>(A.sim.dof_vel.base + (int64_t)(i12 / Q) * A.sim.dof_vel.comp_stride + e0 + 4 * (i12 % Q));
-        const int cc0 = A.contact_comp[0], cc1 = A.contact_comp[1], cc2 = A.contact_comp[2];
-        const int k9 = i9 / Q;
-        const int ccomp = (k9 < 3 ? cc0 : (k9 < 6 ? cc1 : cc2)) + k9 % 3;
-        r_ct = *reinterpret_cast<const EnvF4*>(A.sim.contact.base + (int64_t)ccomp * A.sim.contact.comp_stride + e0 + 4 * (i9 % Q));
-        const int rc0 = A.rigid_comp[0], rc1 = A.rigid_comp[1], rc2 = A.rigid_comp[2], rc3 = A.rigid_comp[3];
-        const int k14 = i14 / Q;                              // feet {x,y,z,vx,vy}, knees {x,y}
+        const int k9 = i9 / Q, k14 = i14 / Q;
         const int body = k14 < 10 ? k14 / 5 : 2 + (k14 - 10) / 2;
         const int c5 = k14 % 5;
         const int rcomp = k14 < 10 ? (c5 < 3 ? c5 : c5 + 4) : (k14 - 10) % 2;
-        const int rbase = body == 0 ? rc0 : (body == 1 ? rc1 : (body == 2 ? rc2 : rc3));
-        r_rg = *reinterpret_cast<const EnvF4*>(A.sim.rigid.base + (int64_t)(rbase + rcomp) * A.sim.rigid.comp_stride + e0 + 4 * (i14 % Q));
         const int ia = cl(t, 3 * EE), ie = cl(t, EE / 2);
-        r_ep = *reinterpret_cast<const EnvF4*>(reinterpret_cast<const float*>(A.st.episode_length + e0) + 4 * ie);
-        // unconditional load (from the episode-length row when there are no actions): a conditionally initialised vector ends
-        // up in scratch memory, and a kernel with a private segment is dispatched differently from its neighbours
-        r_act = *reinterpret_cast<const EnvF4*>(A.actions_in ? A.actions_in + (int64_t)e0 * 12 + 4 * ia
-                                                              : reinterpret_cast<const float*>(A.st.episode_length + e0) + 4 * ie);
 #pragma unroll
         for (int u = 0; u < NS; ++u) {
             const int i = t + u * 256;
-            if (i < kStateComps * Q) *reinterpret_cast<EnvF4*>(smem + m.state + (i / Q) * E + 4 * (i % Q)) = rs[u];
+            if (i < kStateComps * Q) *reinterpret_cast<EnvF4*>(smem + m.state + (i / Q) * E + 4 * (i % Q)) = R.rs[u];
         }
-        if (t < 13 * Q) *reinterpret_cast<EnvF4*>(smem + m.root + (i13 / Q) * E + 4 * (i13 % Q)) = r_root;
+        if (t < 13 * Q) *reinterpret_cast<EnvF4*>(smem + m.root + (i13 / Q) * E + 4 * (i13 % Q)) = R.r_root;
         if (t < 12 * Q) {
-            *reinterpret_cast<EnvF4*>(smem + m.dof_pos + (i12 / Q) * E + 4 * (i12 % Q)) = r_dp;
-            *reinterpret_cast<EnvF4*>(smem + m.dof_vel + (i12 / Q) * E + 4 * (i12 % Q)) = r_dv;
+            *reinterpret_cast<EnvF4*>(smem + m.dof_pos + (i12 / Q) * E + 4 * (i12 % Q)) = R.r_dp;
+            *reinterpret_cast<EnvF4*>(smem + m.dof_vel + (i12 / Q) * E + 4 * (i12 % Q)) = R.r_dv;
         }
-        if (t < 9 * Q) *reinterpret_cast<EnvF4*>(smem + m.contact + k9 * E + 4 * (i9 % Q)) = r_ct;
-        if (t < 14 * Q) *reinterpret_cast<EnvF4*>(smem + m.rigid + (body * 13 + rcomp) * E + 4 * (i14 % Q)) = r_rg;
-        if (A.actions_in && t < 3 * EE) *reinterpret_cast<EnvF4*>(smem + m.actions_in + 4 * ia) = r_act;
-        if (t < EE / 2) *reinterpret_cast<EnvF4*>(smem + m.ep_len + 4 * ie) = r_ep;
+        if (t < 9 * Q) *reinterpret_cast<EnvF4*>(smem + m.contact + k9 * E + 4 * (i9 % Q)) = R.r_ct;
+        if (t < 14 * Q) *reinterpret_cast<EnvF4*>(smem + m.rigid + (body * 13 + rcomp) * E + 4 * (i14 % Q)) = R.r_rg;
+        if (A.actions_in && t < 3 * EE) *reinterpret_cast<EnvF4*>(smem + m.actions_in + 4 * ia) = R.r_act;
+        if (t < EE / 2) *reinterpret_cast<EnvF4*>(smem + m.ep_len + 4 * ie) = R.r_ep;
     } else {
         copy_comp_rows<true>(nullptr, A, 0, kStateComps, smem + m.state, E, e0, nE, N, t, nthreads);
         stage_sim<true>(A, m, smem, E, e0, nE, t, nthreads, true);
@@ -1087,6 +1116,12 @@ HG_HD void env_stage_in(const EnvArgs& A, int block, int t, int nthreads, float*
     copy_rows_in(A.noise.u_push, smem + m.u_push, 5, e0, nE, t, nthreads);
     copy_rows_in(A.noise.z_obs, smem + m.z_obs, HGYM_OBS_FRAME, e0, nE, t, nthreads);
     for (int i = t; i < HGYM_OBS_FRAME; i += nthreads) smem[m.noise_vec + i] = A.cfg.obs_noise[i];
+}
+template <int E_T>
+HG_HD void env_stage_in(const EnvArgs& A, int block, int t, int nthreads, float* smem) {
+    StageRegs<E_T> R;
+    env_stage_in_load<E_T>(A, block, t, nthreads, R);
+    env_stage_in_store<E_T>(A, block, t, nthreads, smem, R);
 }
 
 // Random draws not supplied by the caller, one Philox call per work item, into the LDS tables (row-major per env,

@@ -10,7 +10,7 @@ out=$O/benchab_$(echo "$@" | tr ' ' '_').txt
 : > $out
 for rep in 1 2; do
   for v in "$@"; do
-    HGYM_LIB=$(lib $v) timeout 300 python bench.py --no-cpu-baseline --no-roofline --steps 20 2>&1 | tail -1 > $O/_line.json
+    HGYM_LIB=$(lib $v) timeout 300 python bench.py --no-cpu-baseline --no-roofline --configs none --steps 20 2>&1 | tail -1 > $O/_line.json
     python - "$v" "$rep" $O/_line.json >> $out <<'P'
 import json, sys
 try:
