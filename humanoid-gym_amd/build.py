@@ -20,6 +20,7 @@ COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno
 EXTRA = {
     "hgym_env.hip": ["-ffp-contract=off"],
     "hgym_gae.hip": ["-ffp-contract=off"],
+    "hgym_rollout.hip": ["-ffp-contract=off"],      # contains the env arithmetic; hgym_fused.hpp restores its own setting by pragma
 }
 
 

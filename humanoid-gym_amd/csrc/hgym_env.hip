@@ -251,6 +251,45 @@ static int32_t launch_step(const HgymEnvConfig* cfg, const HgymSimTensors* sim, 
     return HGYM_OK;
 }
 
+// For hgym_rollout.hip: the EnvArgs record of one synthetic-physics env step in 32-env workgroups, as launch_step builds it,
+// after checking everything the fused rollout kernel compiles in (XBot-L default options, 15 / 3 history, contiguous SoA state
+// and sim tensors, a whole number of 32-env blocks).
+int32_t rollout_env_args(const HgymEnvConfig* cfg, const HgymSimTensors* sim, const HgymEnvState* st, const HgymEnvOut* out,
+                         float* actions, EnvArgs* A) {
+    int32_t rc = check_common(cfg, sim, st);
+    if (rc) return rc;
+    HG_REQUIRE(sim && out && actions, HGYM_E_BADARG, "null sim / out / actions");
+    HG_REQUIRE(out->obs && out->priv_obs && out->rew && out->reset && out->time_out && out->extras_time_outs && out->extras_episode,
+               HGYM_E_BADARG, "null output buffer");
+    HG_REQUIRE(st->obs_ring && st->priv_ring && st->episode_acc, HGYM_E_BADARG, "null ring/episode_acc");
+    HG_REQUIRE(out->t_rewards && out->t_values && out->t_dones && out->t_step && out->defer_finalize, HGYM_E_BADARG,
+               "the fused rollout step stores the transition itself: transition sink + defer_finalize required");
+    const bool generic = cfg->custom_origins || cfg->terrain_curriculum || cfg->num_height_points > 0 || cfg->command_curriculum ||
+                         !cfg->heading_command;
+    HG_REQUIRE(!generic && !cfg->use_ref_actions && cfg->frame_stack == 15 && cfg->c_frame_stack == 3, HGYM_E_UNSUPPORTED,
+               "fused rollout step: XBot-L default options only");
+    HG_REQUIRE(cfg->num_envs % 32 == 0, HGYM_E_UNSUPPORTED, "fused rollout step: num_envs must be a multiple of 32");
+    memset(A, 0, sizeof(*A));
+    A->cfg = *cfg;
+    A->sim = *sim;
+    A->st = *st;
+    A->out = *out;
+    A->actions_in = actions;
+    A->origins_hbm = st->env_origins;
+    A->mode = MODE_STEP;
+    A->fused = 1;
+    A->envs_per_block = 32;
+    set_body_offsets(*A);
+    bool contig = true;
+    float* const* f = &st->commands;
+    for (int i = 0; i + 1 < kNumStateFields; ++i) contig = contig && (f[i + 1] == f[i] + (int64_t)state_field_comps(i) * cfg->num_envs);
+    A->state_contig = contig ? 1 : 0;
+    HG_REQUIRE(contig && sim->root.env_stride == 1 && sim->dof_pos.env_stride == 1 && sim->dof_vel.env_stride == 1 &&
+                   sim->contact.env_stride == 1 && sim->rigid.env_stride == 1, HGYM_E_UNSUPPORTED,
+               "fused rollout step: contiguous [136][N] state and SoA sim tensors required");
+    return HGYM_OK;
+}
+
 }  // namespace hgym
 
 using namespace hgym;

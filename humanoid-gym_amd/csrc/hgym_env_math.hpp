@@ -27,6 +27,7 @@ struct EnvArgs {
     HgymEnvNoise noise;
     float* actions_in;        // (N,12) row-major or null; written only when cfg.use_ref_actions (humanoid_env.py:190-191)
     float* origins_hbm;       // st.env_origins as the caller gave it (the LDS shadow replaces st.env_origins by its staged copy)
+    int64_t* reset_count;     // where resetting envs count themselves for the step finaliser; null: &st.counters[1]
     int mode;
     int fused;                // 1: pre_physics + synthetic physics run inside the step kernel
     int envs_per_block;
@@ -724,7 +725,7 @@ HG_HD StepFlags post_physics_env(const EnvArgs& A, const RngKey& rk, int64_t csc
         FG(S.feet_air_time, 1) = 0.0f;
         ep = 0;
         // extras["episode"]: mean over resetting envs, finished by the step finaliser
-        hg_atomic_inc(&S.counters[1]);
+        hg_atomic_inc(A.reset_count ? A.reset_count : &S.counters[1]);
 #pragma unroll
         for (int k = 0; k < HGYM_NUM_REWARDS; ++k) {
             hg_atomic_add(&S.episode_acc[k], esum[k]);
@@ -1021,12 +1022,22 @@ HG_HD void stage_sim(const EnvArgs& A, const LdsMap& m, float* smem, int E, int 
 // between tensors would make the compiler index the kernel argument dynamically and spill it to scratch.
 // The loads of the fast path live in a register record so that a caller can put other independent loads (the history
 // prefetch, whose addresses wait for the ring-step counter) between their issue and their LDS writes: issue first, wait last.
+HG_HD void stage_ld(float (&r)[4], const float* p) {
+    const EnvF4 q = *reinterpret_cast<const EnvF4*>(p);
+    r[0] = q.v[0]; r[1] = q.v[1]; r[2] = q.v[2]; r[3] = q.v[3];
+}
+HG_HD void stage_st(float* p, const float (&r)[4]) {
+    const EnvF4 q = {{r[0], r[1], r[2], r[3]}};
+    *reinterpret_cast<EnvF4*>(p) = q;
+}
 template <int E_T>
 struct StageRegs {
     static constexpr int EE = E_T > 0 ? E_T : 4;
     static constexpr int Q = EE / 4;                                 // 16-byte items per component row
     static constexpr int NS = (kStateComps * Q + 255) / 256;
-    EnvF4 rs[NS], r_root, r_dp, r_dv, r_ct, r_rg, r_act, r_ep;
+    // plain float quads (as hist_load keeps its prefetch): records of the packed 16-byte struct were left in private memory by the
+    // compiler, and a kernel with a private segment is dispatched differently from its neighbours
+    float rs[NS][4], r_root[4], r_dp[4], r_dv[4], r_ct[4], r_rg[4], r_act[4], r_ep[4];
     int fast;
 };
 template <int E_T>
@@ -1050,28 +1061,28 @@ HG_HD void env_stage_in_load(const EnvArgs& A, int block, int t, int nthreads, S
 #pragma unroll
     for (int u = 0; u < NS; ++u) {
         const int i = cl(t + u * 256, kStateComps * Q);
-        R.rs[u] = *reinterpret_cast<const EnvF4*>(A.st.commands + (int64_t)(i / Q) * N + e0 + 4 * (i % Q));
+        stage_ld(R.rs[u], A.st.commands + (int64_t)(i / Q) * N + e0 + 4 * (i % Q));
     }
     const int i13 = cl(t, 13 * Q), i12 = cl(t, 12 * Q), i9 = cl(t, 9 * Q), i14 = cl(t, 14 * Q);
-    R.r_root = *reinterpret_cast<const EnvF4*>(A.sim.root.base + (int64_t)(i13 / Q) * A.sim.root.comp_stride + e0 + 4 * (i13 % Q));
-    R.r_dp = *reinterpret_cast<const EnvF4*>(A.sim.dof_pos.base + (int64_t)(i12 / Q) * A.sim.dof_pos.comp_stride + e0 + 4 * (i12 % Q));
-    R.r_dv = *reinterpret_cast<const EnvF4*>(A.sim.dof_vel.base + (int64_t)(i12 / Q) * A.sim.dof_vel.comp_stride + e0 + 4 * (i12 % Q));
+    stage_ld(R.r_root, A.sim.root.base + (int64_t)(i13 / Q) * A.sim.root.comp_stride + e0 + 4 * (i13 % Q));
+    stage_ld(R.r_dp, A.sim.dof_pos.base + (int64_t)(i12 / Q) * A.sim.dof_pos.comp_stride + e0 + 4 * (i12 % Q));
+    stage_ld(R.r_dv, A.sim.dof_vel.base + (int64_t)(i12 / Q) * A.sim.dof_vel.comp_stride + e0 + 4 * (i12 % Q));
     const int cc0 = A.contact_comp[0], cc1 = A.contact_comp[1], cc2 = A.contact_comp[2];
     const int k9 = i9 / Q;
     const int ccomp = (k9 < 3 ? cc0 : (k9 < 6 ? cc1 : cc2)) + k9 % 3;
-    R.r_ct = *reinterpret_cast<const EnvF4*>(A.sim.contact.base + (int64_t)ccomp * A.sim.contact.comp_stride + e0 + 4 * (i9 % Q));
+    stage_ld(R.r_ct, A.sim.contact.base + (int64_t)ccomp * A.sim.contact.comp_stride + e0 + 4 * (i9 % Q));
     const int rc0 = A.rigid_comp[0], rc1 = A.rigid_comp[1], rc2 = A.rigid_comp[2], rc3 = A.rigid_comp[3];
     const int k14 = i14 / Q;                              // feet {x,y,z,vx,vy}, knees {x,y}
     const int body = k14 < 10 ? k14 / 5 : 2 + (k14 - 10) / 2;
     const int c5 = k14 % 5;
     const int rcomp = k14 < 10 ? (c5 < 3 ? c5 : c5 + 4) : (k14 - 10) % 2;
     const int rbase = body == 0 ? rc0 : (body == 1 ? rc1 : (body == 2 ? rc2 : rc3));
-    R.r_rg = *reinterpret_cast<const EnvF4*>(A.sim.rigid.base + (int64_t)(rbase + rcomp) * A.sim.rigid.comp_stride + e0 + 4 * (i14 % Q));
+    stage_ld(R.r_rg, A.sim.rigid.base + (int64_t)(rbase + rcomp) * A.sim.rigid.comp_stride + e0 + 4 * (i14 % Q));
     const int ia = cl(t, 3 * EE), ie = cl(t, EE / 2);
-    R.r_ep = *reinterpret_cast<const EnvF4*>(reinterpret_cast<const float*>(A.st.episode_length + e0) + 4 * ie);
+    stage_ld(R.r_ep, reinterpret_cast<const float*>(A.st.episode_length + e0) + 4 * ie);
     // unconditional load (from the episode-length row when there are no actions): a conditionally initialised vector ends
     // up in scratch memory, and a kernel with a private segment is dispatched differently from its neighbours
-    R.r_act = *reinterpret_cast<const EnvF4*>(A.actions_in ? A.actions_in + (int64_t)e0 * 12 + 4 * ia
+    stage_ld(R.r_act, A.actions_in ? A.actions_in + (int64_t)e0 * 12 + 4 * ia
                                                             : reinterpret_cast<const float*>(A.st.episode_length + e0) + 4 * ie);
 }
 template <int E_T>
@@ -1092,17 +1103,17 @@ HG_HD void env_stage_in_store(const EnvArgs& A, int block, int t, int nthreads, 
 #pragma unroll
         for (int u = 0; u < NS; ++u) {
             const int i = t + u * 256;
-            if (i < kStateComps * Q) *reinterpret_cast<EnvF4*>(smem + m.state + (i / Q) * E + 4 * (i % Q)) = R.rs[u];
+            if (i < kStateComps * Q) stage_st(smem + m.state + (i / Q) * E + 4 * (i % Q), R.rs[u]);
         }
-        if (t < 13 * Q) *reinterpret_cast<EnvF4*>(smem + m.root + (i13 / Q) * E + 4 * (i13 % Q)) = R.r_root;
+        if (t < 13 * Q) stage_st(smem + m.root + (i13 / Q) * E + 4 * (i13 % Q), R.r_root);
         if (t < 12 * Q) {
-            *reinterpret_cast<EnvF4*>(smem + m.dof_pos + (i12 / Q) * E + 4 * (i12 % Q)) = R.r_dp;
-            *reinterpret_cast<EnvF4*>(smem + m.dof_vel + (i12 / Q) * E + 4 * (i12 % Q)) = R.r_dv;
+            stage_st(smem + m.dof_pos + (i12 / Q) * E + 4 * (i12 % Q), R.r_dp);
+            stage_st(smem + m.dof_vel + (i12 / Q) * E + 4 * (i12 % Q), R.r_dv);
         }
-        if (t < 9 * Q) *reinterpret_cast<EnvF4*>(smem + m.contact + k9 * E + 4 * (i9 % Q)) = R.r_ct;
-        if (t < 14 * Q) *reinterpret_cast<EnvF4*>(smem + m.rigid + (body * 13 + rcomp) * E + 4 * (i14 % Q)) = R.r_rg;
-        if (A.actions_in && t < 3 * EE) *reinterpret_cast<EnvF4*>(smem + m.actions_in + 4 * ia) = R.r_act;
-        if (t < EE / 2) *reinterpret_cast<EnvF4*>(smem + m.ep_len + 4 * ie) = R.r_ep;
+        if (t < 9 * Q) stage_st(smem + m.contact + k9 * E + 4 * (i9 % Q), R.r_ct);
+        if (t < 14 * Q) stage_st(smem + m.rigid + (body * 13 + rcomp) * E + 4 * (i14 % Q), R.r_rg);
+        if (A.actions_in && t < 3 * EE) stage_st(smem + m.actions_in + 4 * ia, R.r_act);
+        if (t < EE / 2) stage_st(smem + m.ep_len + 4 * ie, R.r_ep);
     } else {
         copy_comp_rows<true>(nullptr, A, 0, kStateComps, smem + m.state, E, e0, nE, N, t, nthreads);
         stage_sim<true>(A, m, smem, E, e0, nE, t, nthreads, true);
@@ -1296,7 +1307,7 @@ HG_HD bool command_curriculum_due(const EnvArgs& A, int64_t csc) {
     const HgymEnvConfig& c = A.cfg;
     if (!c.command_curriculum || !A.st.command_range_x || A.mode == MODE_PRIME) return false;
     if (csc % c.max_episode_length != 0) return false;
-    const int64_t cnt = A.st.counters[1];
+    const int64_t cnt = A.reset_count ? A.reset_count[0] : A.st.counters[1];
     if (cnt <= 0) return false;
     constexpr int kTrack = 20;                       // "tracking_lin_vel" in the alphabetical reward order
     const float mean_sum = A.st.episode_acc[kTrack] / (float)cnt;
@@ -1550,7 +1561,11 @@ HG_HD void env_step_phase_b(const EnvArgs& A, int block, int t, int nthreads, fl
 }
 
 // Step finaliser (hgym_finalize.hpp) on an EnvArgs record.
-HG_HD FinArgs fin_of(const EnvArgs& A) { return make_fin_args(A.cfg, A.st, A.out, A.mode); }
+HG_HD FinArgs fin_of(const EnvArgs& A) {
+    FinArgs f = make_fin_args(A.cfg, A.st, A.out, A.mode);
+    if (A.reset_count) f.reset_count = A.reset_count;
+    return f;
+}
 HG_HD void env_finalize_part1(const EnvArgs& A, int t, int nthreads) { fin_part1(fin_of(A), t, nthreads); }
 HG_HD void env_finalize_store(const EnvArgs& A, int t, int nthreads) { fin_store(fin_of(A), t, nthreads); }
 HG_HD void env_finalize_part2(const EnvArgs& A) { fin_part2(fin_of(A)); }

@@ -21,7 +21,9 @@ struct FinArgs {
     int mode;
     float episode_length_s;
     int64_t* counters;       // HgymEnvState::counters
-    float* episode_acc;      // HgymEnvState::episode_acc
+    int64_t* reset_count;    // envs that reset in the step being finalised: &counters[1], or the step's own slot when the finaliser
+                             // runs concurrently with the NEXT step's env phase (rollout_step_kernel)
+    float* episode_acc;      // HgymEnvState::episode_acc (same remark)
     HgymEnvOut out;
 };
 
@@ -31,13 +33,14 @@ HG_HD FinArgs make_fin_args(const HgymEnvConfig& cfg, const HgymEnvState& st, co
     f.mode = mode;
     f.episode_length_s = cfg.episode_length_s;
     f.counters = st.counters;
+    f.reset_count = st.counters + 1;
     f.episode_acc = st.episode_acc;
     f.out = out;
     return f;
 }
 
 HG_HD void fin_part1(const FinArgs& F, int t, int nthreads) {
-    const int64_t cnt = F.counters[1];
+    const int64_t cnt = F.reset_count[0];
     if (cnt > 0) {
         if (t < HGYM_NUM_REWARDS) {
             F.out.extras_episode[t] = F.episode_acc[t] / (float)cnt / F.episode_length_s;
@@ -62,7 +65,7 @@ HG_HD void fin_part2(const FinArgs& F) {
     // with a deferred finaliser the env kernel itself bumps the policy's sampling step (the policy launch this rides in
     // reads it at entry)
     if (F.out.t_rewards && F.out.t_step && !F.out.defer_finalize) F.out.t_step[0] += 1;
-    F.counters[1] = 0;
+    F.reset_count[0] = 0;
     if (F.mode == FIN_MODE_STEP) F.counters[0] += 1;
     if (F.mode != FIN_MODE_RESET_ALL) F.counters[2] += 1;
 }

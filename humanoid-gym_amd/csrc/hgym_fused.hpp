@@ -20,6 +20,9 @@
 // k = kb*32 + 8*(l>>4) .. +7), so a wavefront's weight load is one contiguous 1 KiB global_load_dwordx4.
 #pragma once
 #include "hgym_finalize.hpp"
+// This header's arithmetic is compiled with the same contraction setting in every translation unit (hgym_net.hip: the default;
+// hgym_rollout.hip: built with -ffp-contract=off for the env arithmetic it also contains, and defines HGYM_TU_CONTRACT_OFF).
+#pragma clang fp contract(fast)
 #include "hgym_gemm.hpp"
 
 namespace hgym {
@@ -369,6 +372,12 @@ __device__ __forceinline__ void phase_stamp(long long* dbg, int slot) {
     if (dbg && threadIdx.x == 0) dbg[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + slot] = (long long)__builtin_amdgcn_s_memrealtime();
 }
 
+// log(sigma) of the sampling epilogue: hardware log2 times ln 2 as ONE non-fusable multiply.  libm's logf is inlined library
+// code whose internal multiply-adds the backend contracts or not depending on the translation unit's -ffp-contract setting, so
+// it returned different last bits in hgym_net.hip and hgym_rollout.hip; this form is the same instruction pair everywhere
+// (<= 2 ulp of log for sigma in [1e-3, 1e3]; the log-probability is compared with the reference at 1e-5 relative).
+__device__ __forceinline__ float log_sigma(float s) { return __fmul_rn(__builtin_amdgcn_logf(s), 0.6931471805599453f); }
+
 struct FwdArgs {
     long long* dbg;
     FusedNet net[3];           // 0 actor, 1 critic, 2 auxiliary head (launched on its own: net0 = 2, one grid row)
@@ -389,8 +398,25 @@ struct FwdArgs {
     FinArgs fin;              // postponed env-step finaliser riding in this launch (blockIdx.y == nets, one workgroup); fin.N == 0: none
 };
 
-template <int BM, int NW, int D, int G1, bool WIDE = false>
-__device__ __forceinline__ void fwd_body(const FwdArgs& a, const FusedNet& n, bool is_actor, char* smem) {
+// Hooks of the fused rollout step (hgym_rollout.hip), three callables: `early()` runs once per workgroup right after the tile's
+// first loads (bias, first weight k-steps, first input chunk) have been ISSUED and before anything waits for them -- the env
+// step's own input loads and its Philox draws go there, under the same memory round trip; `mid()` runs between the first
+// layer and the second, where the first layer's weight ring and accumulators are dead and ~60 registers are free for loads that
+// may take the rest of the tile to arrive (the observation history); `put_action(row, j, a)` receives every sampled action of
+// the tile (row within the tile, action index) so that the env phase reads them from LDS.  They are lambdas that capture the
+// caller's locals by reference (a hook OBJECT carrying the prefetch arrays as members was kept in private memory by the
+// compiler: 500 scratch instructions and a kernel four times slower).
+// `extra` (whatever the hooks need from the kernel argument) reaches them as a call PARAMETER: a closure that captured a
+// reference to the kernel argument would count as a capture of the whole argument block, of which the compiler then keeps a
+// private-memory copy (3 KB of scratch per lane).
+struct FwdNoop {
+    template <class X> __device__ __forceinline__ void operator()(const X&) const {}
+    __device__ __forceinline__ void operator()(int, int, float) const {}
+};
+
+template <int BM, int NW, int D, int G1, bool WIDE = false, class Early = FwdNoop, class Mid = FwdNoop, class Put = FwdNoop, class Extra = int>
+__device__ __forceinline__ void fwd_body(const FwdArgs& a, const FusedNet& n, bool is_actor, char* smem, Early&& hook_early = Early(),
+                                         Mid&& hook_mid = Mid(), Put&& hook_put = Put(), const Extra& extra = Extra()) {
     constexpr int MB = BM / 16;
     constexpr int IT = BM * 32 / (NW * 64);           // staging items per thread per chunk (BM rows x 32 float4)
     constexpr int RPP = NW * 2;                       // rows covered per staging pass (32 lanes per row)
@@ -427,7 +453,7 @@ __device__ __forceinline__ void fwd_body(const FwdArgs& a, const FusedNet& n, bo
 #pragma unroll
         for (int e = 0; e < 4; ++e) std_pre[e] = a.std_[4 * q + e < a.A ? 4 * q + e : 0];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) lsg_pre[e] = logf(std_pre[e]);      // under the first input load instead of in the tail
+        for (int e = 0; e < 4; ++e) lsg_pre[e] = log_sigma(std_pre[e]);      // under the first input load instead of in the tail
     }
     auto bias_to_lds = [&]() {
 #pragma unroll
@@ -503,6 +529,7 @@ __device__ __forceinline__ void fwd_body(const FwdArgs& a, const FusedNet& n, bo
         phase_stamp(a.dbg, 0);
         wring_prime<G1, D>(r0, wl0, L0.KB * 64, L0.KB);
         stage_load(0);
+        hook_early(extra);
         stage_write(0, 0);
         bias_to_lds();
         __syncthreads();
@@ -521,6 +548,7 @@ __device__ __forceinline__ void fwd_body(const FwdArgs& a, const FusedNet& n, bo
     }
     __syncthreads();
     phase_stamp(a.dbg, 3);
+    hook_mid(extra);
     if (!AHEAD) prime1();
     // ---------------------------------------------------------------- layers 1, 2: input resident in LDS
     auto prime2 = [&]() { hidden_prime<GH, D>(r2, L2, wave, lane); };
@@ -555,6 +583,7 @@ __device__ __forceinline__ void fwd_body(const FwdArgs& a, const FusedNet& n, bo
                 if (4 * q + e < No) n.out[(int64_t)m * n.ldo + 4 * q + e] = mu[e];
         }
         if (is_actor && a.sample) {
+#pragma clang fp contract(off)      // a = mu + sigma z and the log-probability as separate fp32 roundings, identically in every translation unit
             const int A = a.A;
             float zz[4];
             if (a.z) {
@@ -575,11 +604,12 @@ __device__ __forceinline__ void fwd_body(const FwdArgs& a, const FusedNet& n, bo
                     const float sg = mu[e] * 0.0f + (HOIST ? std_pre[e] : a.std_[j]);      // actor_critic.py:113
                     const float act = mu[e] + sg * zz[e];
                     const float d = act - mu[e];
-                    lp += -(d * d) / (2.0f * sg * sg) - (HOIST ? lsg_pre[e] : logf(sg)) - 0.9189385332046727f;
+                    lp += -(d * d) / (2.0f * sg * sg) - (HOIST ? lsg_pre[e] : log_sigma(sg)) - 0.9189385332046727f;
                     if (m < a.M) {
                         a.actions[(int64_t)m * A + j] = act;
                         a.sigma[(int64_t)m * A + j] = sg;
                     }
+                    hook_put(wave * 16 + r, j, act);
                 }
             }
             lp += __shfl_xor(lp, 16, 64);
@@ -904,3 +934,7 @@ __global__ __launch_bounds__(DW_THREADS, 2) void dw_kernel_rs(const DwArgs a) {
 }
 
 }  // namespace hgym
+
+#ifdef HGYM_TU_CONTRACT_OFF
+#pragma clang fp contract(off)
+#endif

@@ -835,10 +835,8 @@ struct NetRunner {
         return a.fin.N > 0 ? launch_fwd_k<BM, NW, D, true>(a, nets) : launch_fwd_k<BM, NW, D, false>(a, nets);
     }
 
-    // forward of `nets` networks starting at `first` in ONE launch; xs/outs indexed by net id
-    int32_t fused_forward(int first, int nets, int M, const float* const xs[3], const int64_t ldxs[3], const int64_t* idx, float* const outs[3],
-                          const int64_t ldos[3], bool train, const SampleOut* smp, const FinArgs* fin = nullptr) {
-        HG_REQUIRE(M > 0 && M <= w.maxM, HGYM_E_SHAPE, "batch %d exceeds max_batch %lld", M, (long long)w.maxM);
+    FwdArgs make_fwd_args(int first, int nets, int M, const float* const xs[3], const int64_t ldxs[3], const int64_t* idx, float* const outs[3],
+                          const int64_t ldos[3], bool train, const SampleOut* smp, const FinArgs* fin) const {
         FwdArgs a;
         memset(&a, 0, sizeof(a));
         for (int i = first; i < first + nets; ++i) a.net[i] = fused_net(i, xs[i], ldxs[i], outs[i], ldos[i]);
@@ -860,6 +858,14 @@ struct NetRunner {
             a.sigma = smp->sigma;
             a.logp = smp->logp;
         }
+        return a;
+    }
+
+    // forward of `nets` networks starting at `first` in ONE launch; xs/outs indexed by net id
+    int32_t fused_forward(int first, int nets, int M, const float* const xs[3], const int64_t ldxs[3], const int64_t* idx, float* const outs[3],
+                          const int64_t ldos[3], bool train, const SampleOut* smp, const FinArgs* fin = nullptr) {
+        HG_REQUIRE(M > 0 && M <= w.maxM, HGYM_E_SHAPE, "batch %d exceeds max_batch %lld", M, (long long)w.maxM);
+        const FwdArgs a = make_fwd_args(first, nets, M, xs, ldxs, idx, outs, ldos, train, smp, fin);
         const int pcls = train ? HGYM_PROF_MLP_FWD : HGYM_PROF_POLICY;
         prof_begin(pcls, s);
         // 32-row tiles x 8 waves (weight ring depth 4) while they fit the chip in one round (one workgroup per CU: 2 * M / 32
@@ -1329,6 +1335,35 @@ static int32_t check_net(const HgymNetConfig* cfg, const HgymNet* net, WsLayout*
     if (rc) return rc;
     HG_REQUIRE(net->params && net->workspace, HGYM_E_BADARG, "null params / workspace");
     HG_REQUIRE(((uintptr_t)net->workspace & 255) == 0, HGYM_E_BADARG, "workspace must be 256-byte aligned");
+    return HGYM_OK;
+}
+
+// For hgym_rollout.hip (the fused policy + env step lives in a translation unit of its own: it also contains the env
+// arithmetic, which is built with -ffp-contract=off): the FwdArgs record of one PPO.act launch over the actor and the critic
+// with 32-row tiles, and the dynamic LDS those tiles need.  Fails unless the fused bf16 path serves this configuration with
+// XBot-L's first hidden widths (actor 512, critic 768: the instantiations the rollout kernel carries).
+int32_t rollout_fwd_args(const HgymNetConfig* cfg, const HgymNet* net, int M, const float* obs, const float* priv, uint64_t seed,
+                         const int64_t* step, float* actions, float* mu, float* sigma, float* logp, float* values, FwdArgs* out,
+                         size_t* lds_bytes) {
+    WsLayout w;
+    const int32_t rc = check_net(cfg, net, &w);
+    if (rc) return rc;
+    HG_REQUIRE(cfg->precision == HGYM_BF16 && w.fused, HGYM_E_UNSUPPORTED, "the fused rollout step needs the bf16 fused path");
+    HG_REQUIRE(M > 0 && M <= w.maxM, HGYM_E_SHAPE, "batch %d exceeds max_batch %lld", M, (long long)w.maxM);
+    HG_REQUIRE(cfg->actor_dims[1] == 512 && cfg->critic_dims[1] == 768, HGYM_E_UNSUPPORTED,
+               "fused rollout step: first hidden widths 512 / 768 (XBot-L) only, not %d / %d", cfg->actor_dims[1], cfg->critic_dims[1]);
+    NetRunner<__bf16> R{*cfg, *net, w, nullptr, (char*)net->workspace};
+    const float* xs[3] = {obs, priv, nullptr};
+    const int64_t ldxs[3] = {cfg->num_obs, cfg->num_priv, 0};
+    float* outs[3] = {mu, values, nullptr};
+    const int64_t ldos[3] = {cfg->num_actions, 1, 0};
+    const NetRunner<__bf16>::SampleOut smp = {nullptr, seed, step, actions, sigma, logp};
+    *out = R.make_fwd_args(0, 2, M, xs, ldxs, nullptr, outs, ldos, false, &smp, nullptr);
+    out->nets = 2;
+    size_t lds = 0;
+    for (int i = 0; i < 2; ++i)
+        lds = std::max(lds, (size_t)fused_lds_p(out->net[i], 32) + (size_t)fused_lds_q(out->net[i], 32) + (size_t)fused_lds_bias(out->net[i]));
+    *lds_bytes = lds;
     return HGYM_OK;
 }
 

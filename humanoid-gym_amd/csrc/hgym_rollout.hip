@@ -1,0 +1,246 @@
+// hgym_rollout.hip -- ONE launch per vec-step of the rollout: PPO.act, the env step and the previous step's finaliser.
+//
+// The rollout is a latency chain: [policy step -> env step] x 60, each link a kernel whose first act is
+// a round trip to memory for its inputs and whose launch costs ~4 us before any wave runs.  Nothing in step t of env e depends
+// on another env's step t -- the only cross-env pieces are the step finaliser's means, which already ride one launch behind
+// (HgymEnvOut.defer_finalize).  So the two links are fused per env slice:
+//
+//   grid (N / 32, 2 [+ 1])    blockIdx.y = 0: ACTOR tile of 32 rows (mlp_fwd body, 8 wavefronts) and then the ENV STEP of the same
+//                                            32 envs, fed with the tile's sampled actions through LDS;
+//                             blockIdx.y = 1: CRITIC tile (values of the transition being collected);
+//                             blockIdx.y = 2: the finaliser of the PREVIOUS env step, one workgroup.
+//
+//   actor workgroup timeline  issue {bias, first weight k-steps, first input chunk} | issue the env step's state / sim loads |
+//   Philox draws of the env step (ALU under all of those loads) | layer 0 | issue the loads of the 14 + 2 older history frames
+//   of the 32 envs (registers; they have the rest of the tile to arrive) | layers 1, 2, head, sampling -> actions to HBM
+//   (storage slot) and to LDS | older frames -> stacked outputs | joints | per-env chain (wavefront 0) | state write-back,
+//   newest frame, reset fix-ups.
+//
+// The env phases are the functions of hgym_env_math.hpp that env_step_kernel runs (32 envs per workgroup, 512 lanes), so the
+// arithmetic -- and hence every mask and every float -- is the unfused kernel's.  This translation unit is built with
+// -ffp-contract=off like hgym_env.hip; hgym_fused.hpp restores the policy kernels' own setting for its part.
+//
+// Step counters.  env_step_kernel reads the common step counter / ring step from HgymEnvState::counters and the policy reads its
+// sampling step from *step_counter; here the finaliser that bumps the former runs CONCURRENTLY (it belongs to the previous
+// step), so the launch takes its three counters from a ping-pong record in the caller's scratch block: launch t reads
+// pp[parity], workgroup (0, 0) writes pp[parity ^ 1] = pp[parity] + 1 for launch t + 1.  For the same reason the reset count
+// and the episode-sum accumulators the finaliser consumes, and the rew / reset / time_out outputs it reads, are per parity:
+// the caller hands two HgymEnvOut records (this step's, the previous step's) with distinct rew / reset / time_out buffers.
+#define HGYM_TU_CONTRACT_OFF 1
+#include <stdlib.h>
+
+#include <algorithm>
+
+#include "hgym_env_math.hpp"
+#include "hgym_fused.hpp"
+
+#ifndef HGYM_RO_VARIANT
+#define HGYM_RO_VARIANT 0      // experiments only: 1 = policy tiles alone (no env work at all), 2 = env part without its early loads
+#endif
+
+namespace hgym {
+
+int32_t rollout_fwd_args(const HgymNetConfig* cfg, const HgymNet* net, int M, const float* obs, const float* priv, uint64_t seed,
+                         const int64_t* step, float* actions, float* mu, float* sigma, float* logp, float* values, FwdArgs* out,
+                         size_t* lds_bytes);
+int32_t rollout_env_args(const HgymEnvConfig* cfg, const HgymSimTensors* sim, const HgymEnvState* st, const HgymEnvOut* out,
+                         float* actions, EnvArgs* A);
+
+constexpr int RO_E = 32;       // envs (= policy rows) per workgroup
+constexpr int RO_NT = 512;     // lanes per workgroup: 8 wavefronts, as mlp_fwd_kernel<32, 8, 4>
+
+// caller's scratch block (HGYM_ROLLOUT_SCRATCH_BYTES, zero-filled once)
+struct RolloutScratch {
+    int64_t pp[2][4];          // [parity]{common step counter, ring step, sampling step, -}
+    int64_t reset_cnt[2];      // [parity] envs that reset in the step of that parity
+    int64_t pad[6];
+    float acc[2][24];          // [parity] episode-sum accumulators of that step (HgymEnvState::episode_acc layout)
+};
+static_assert(sizeof(RolloutScratch) <= HGYM_ROLLOUT_SCRATCH_BYTES, "scratch block too small");
+
+// The three argument records are SEPARATE kernel parameters: as members of one 3 KB struct the compiler, past some size of the
+// kernel body, stopped seeing that the argument block is only read and kept a private-memory copy of all of it.
+struct RolloutPP {
+    const int64_t* in;         // {common step counter, ring step, sampling step} this launch works with
+    int64_t* out;              // the same + 1, written by workgroup (0, 0) for the next launch
+    int env_lds_off;           // byte offset of the env image in dynamic LDS (behind the policy tile's buffers)
+};
+
+constexpr int RO_NIO = hist_ni<15, HGYM_OBS_FRAME, RO_E, RO_NT>();
+constexpr int RO_NIP = hist_ni<3, HGYM_PRIV_FRAME, RO_E, RO_NT>();
+
+template <bool FIN>
+__global__ __launch_bounds__(RO_NT) void rollout_step_kernel(const FwdArgs f, const EnvArgs e, const FinArgs fin, const RolloutPP pp) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (FIN && blockIdx.y >= 2) {
+        if (blockIdx.x == 0) fin_block(fin, threadIdx.x, RO_NT);
+        return;
+    }
+    constexpr int U = 16 / 8;                       // n-blocks per wave per 256 first-layer columns (mlp_fwd_kernel)
+    if (blockIdx.y == 1) {                          // critic tile
+        // one instantiation only (first hidden layer 768 wide, rollout_fwd_args checks): with the three-way dispatch of
+        // mlp_fwd_kernel next to the actor + env branch the compiler keeps a private-memory copy of the whole 3 KB argument
+        fwd_body<32, 8, 4, 3 * U>(f, f.net[1], false, smem);
+        return;
+    }
+    const int t = threadIdx.x, block = blockIdx.x;
+    const int64_t csc0 = pp.in[0], ring_step = pp.in[1], sstep = pp.in[2];
+    float* esm = reinterpret_cast<float*>(smem + pp.env_lds_off);
+    float hist_o[RO_NIO][4], hist_p[RO_NIP][4];
+    const int act_off = lds_map(RO_E).actions_in;
+    auto early = [&](const EnvArgs& E) {
+#if HGYM_RO_VARIANT == 3
+        env_fill_draws<RO_E>(E, block, t, RO_NT, esm, csc0);
+#elif HGYM_RO_VARIANT == 4
+        if (t < 256) env_stage_in<RO_E>(E, block, t, 256, esm);
+#endif
+#if HGYM_RO_VARIANT == 0
+        // issue the state / sim loads, compute the draws under them, then write the loaded quads to the env image
+        StageRegs<RO_E> R;
+        R.fast = 0;
+        if (t < 256) env_stage_in_load<RO_E>(E, block, t, 256, R);
+        env_fill_draws<RO_E>(E, block, t, RO_NT, esm, csc0);
+        if (t < 256) env_stage_in_store<RO_E>(E, block, t, 256, esm, R);
+#endif
+    };
+    auto mid = [&](const EnvArgs& E) {
+#if HGYM_RO_VARIANT == 0 || HGYM_RO_VARIANT == 5
+        hist_load<15, HGYM_OBS_FRAME, RO_NIO>(E.st.obs_ring, block * RO_E, RO_E, (int)(ring_step % 15), t, RO_NT, hist_o);
+#endif
+    };
+    auto put = [&](int row, int j, float v) { esm[act_off + row * 12 + j] = v; };
+    fwd_body<32, 8, 4, 2 * U, false>(f, f.net[0], true, smem, early, mid, put, e);
+    __syncthreads();                                // the tile's actions are in the env image; the policy buffers are dead
+    // phase clock of the env part (hgym_prof_phase_buffer): the slots of grid row 2, which stamps nothing itself
+    long long* dbg = f.dbg ? f.dbg + (int64_t)2 * gridDim.x * 8 + (int64_t)block * 8 : nullptr;
+    auto stamp = [&](int slot) {
+        if (dbg && t == 0) dbg[slot] = (long long)__builtin_amdgcn_s_memrealtime();
+    };
+    stamp(0);
+#if HGYM_RO_VARIANT == 1
+    return;
+#endif
+    const EnvArgs& A = e;
+    // the two older privileged frames (12 registers the policy tile could not spare): loaded here, stored behind the joints phase
+    hist_load<3, HGYM_PRIV_FRAME, RO_NIP>(A.st.priv_ring, block * RO_E, RO_E, (int)(ring_step % 3), t, RO_NT, hist_p);
+    hist_store<15, HGYM_OBS_FRAME, RO_NIO>(A.out.obs, block * RO_E, RO_E, (int)(ring_step % 15), t, RO_NT, nullptr, A.cfg.clip_obs, hist_o);
+    stamp(1);
+    env_step_joints<RO_E>(A, block, t, RO_NT, esm);
+    hist_store<3, HGYM_PRIV_FRAME, RO_NIP>(A.out.priv_obs, block * RO_E, RO_E, (int)(ring_step % 3), t, RO_NT, nullptr, A.cfg.clip_obs,
+                                           hist_p);
+    __syncthreads();
+    stamp(2);
+    if (t < 64) env_step_phase_a<RO_E, false>(A, block, t, esm, csc0);
+    __syncthreads();
+    stamp(3);
+    env_stage_out<RO_E>(A, block, t, RO_NT, esm);
+    stamp(4);
+    env_step_phase_b<15, 3, RO_E>(A, block, t, RO_NT, esm, csc0, ring_step, false);
+    stamp(5);
+    if (block == 0 && t == 0) {
+        pp.out[0] = csc0 + 1;
+        pp.out[1] = ring_step + 1;
+        pp.out[2] = sstep + 1;
+        if (A.out.t_step) A.out.t_step[0] = sstep + 1;     // the caller's sampling-step counter stays current
+    }
+}
+
+__global__ void rollout_begin_kernel(const int64_t* __restrict__ counters, const int64_t* __restrict__ step, RolloutScratch* scr, int parity) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    scr->pp[parity][0] = counters[0];
+    scr->pp[parity][1] = counters[2];
+    scr->pp[parity][2] = step[0];
+}
+
+__global__ __launch_bounds__(1024) void rollout_fin_kernel(const FinArgs f) { fin_block(f, threadIdx.x, blockDim.x); }
+
+static FinArgs parity_fin(const HgymEnvConfig& cfg, const HgymEnvState& st, const HgymEnvOut& out, RolloutScratch* scr, int parity) {
+    FinArgs f = make_fin_args(cfg, st, out, FIN_MODE_STEP);
+    f.reset_count = &scr->reset_cnt[parity];
+    f.episode_acc = scr->acc[parity];
+    return f;
+}
+
+}  // namespace hgym
+
+using namespace hgym;
+
+extern "C" {
+
+int32_t hgym_rollout_begin(const HgymEnvState* st, const int64_t* step_counter, void* scratch, int32_t parity, void* stream) {
+    HG_REQUIRE(st && st->counters && step_counter && scratch, HGYM_E_BADARG, "null state / step counter / scratch");
+    HG_REQUIRE(parity == 0 || parity == 1, HGYM_E_BADARG, "parity=%d", parity);
+    hipLaunchKernelGGL(rollout_begin_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, st->counters, step_counter, (RolloutScratch*)scratch,
+                       parity);
+    HG_CHECK_LAUNCH("rollout_begin_kernel");
+    return HGYM_OK;
+}
+
+int32_t hgym_rollout_step(const HgymNetConfig* cfg, const HgymNet* net, const HgymEnvConfig* env_cfg, const HgymSimTensors* sim,
+                          const HgymEnvState* st, const HgymEnvOut* out, const HgymEnvOut* prev_out, const float* obs, const float* priv,
+                          uint64_t seed, float* actions, float* mu, float* sigma, float* logp, float* values, void* scratch,
+                          int32_t parity, void* stream) {
+    HG_REQUIRE(cfg && net && env_cfg && sim && st && out && scratch, HGYM_E_BADARG, "null argument");
+    HG_REQUIRE(obs && priv && actions && mu && sigma && logp && values, HGYM_E_BADARG, "null policy buffer");
+    HG_REQUIRE(parity == 0 || parity == 1, HGYM_E_BADARG, "parity=%d", parity);
+    RolloutScratch* scr = (RolloutScratch*)scratch;
+    const int M = env_cfg->num_envs;
+    FwdArgs f;
+    EnvArgs e;
+    FinArgs fin;
+    RolloutPP pp;
+    memset(&fin, 0, sizeof(fin));
+    size_t lds_pol = 0;
+    int32_t rc = rollout_fwd_args(cfg, net, M, obs, priv, seed, &scr->pp[parity][2], actions, mu, sigma, logp, values, &f, &lds_pol);
+    if (rc) return rc;
+    rc = rollout_env_args(env_cfg, sim, st, out, actions, &e);
+    if (rc) return rc;
+    HG_REQUIRE(out->t_values == values, HGYM_E_BADARG, "the transition sink must take this launch's values");
+    e.reset_count = &scr->reset_cnt[parity];
+    e.st.episode_acc = scr->acc[parity];
+    if (prev_out) {
+        HG_REQUIRE(prev_out->rew != out->rew && prev_out->reset != out->reset && prev_out->time_out != out->time_out, HGYM_E_BADARG,
+                   "this step's and the previous step's rew / reset / time_out must be distinct buffers (the finaliser runs concurrently)");
+        HG_REQUIRE(prev_out->time_out && prev_out->extras_time_outs && prev_out->extras_episode && prev_out->rew && prev_out->reset,
+                   HGYM_E_BADARG, "null finaliser buffer");
+        fin = parity_fin(*env_cfg, *st, *prev_out, scr, parity ^ 1);
+    }
+    pp.in = scr->pp[parity];
+    pp.out = scr->pp[parity ^ 1];
+    pp.env_lds_off = (int)round_up((int64_t)lds_pol, 16);
+    f.dbg = phase_buffer((int64_t)(M / RO_E) * 3);
+    const size_t lds = (size_t)pp.env_lds_off + step_smem_bytes(RO_E);
+    static size_t attr_lds[2] = {0, 0};
+    const int fi = prev_out ? 1 : 0;
+    if (lds > attr_lds[fi]) {
+        const void* fn = prev_out ? reinterpret_cast<const void*>(&rollout_step_kernel<true>) : reinterpret_cast<const void*>(&rollout_step_kernel<false>);
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            HG_FAIL(HGYM_E_LAUNCH, "cannot reserve %zu bytes of LDS for rollout_step_kernel", lds);
+        attr_lds[fi] = lds;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    prof_begin(HGYM_PROF_ROLLOUT, s);
+    if (prev_out) hipLaunchKernelGGL(rollout_step_kernel<true>, dim3(M / RO_E, 3), dim3(RO_NT), lds, s, f, e, fin, pp);
+    else hipLaunchKernelGGL(rollout_step_kernel<false>, dim3(M / RO_E, 2), dim3(RO_NT), lds, s, f, e, fin, pp);
+    {   // algorithmic HBM bytes of the fused step: the env step's + the policy's input rows and outputs
+        const double env_b = 4.0 * (245 + 14 * 47 + 2 * 73 + 15 * 47 + 3 * 73) + 6;
+        const double pol_b = 4.0 * (cfg->num_obs + cfg->num_priv + 3 * cfg->num_actions + 2);
+        prof_end(HGYM_PROF_ROLLOUT, s, (double)M * (env_b + pol_b));
+    }
+    HG_CHECK_LAUNCH("rollout_step_kernel");
+    return HGYM_OK;
+}
+
+int32_t hgym_rollout_end(const HgymEnvConfig* env_cfg, const HgymEnvState* st, const HgymEnvOut* last_out, void* scratch, int32_t parity,
+                         void* stream) {
+    HG_REQUIRE(env_cfg && st && last_out && scratch, HGYM_E_BADARG, "null argument");
+    HG_REQUIRE(parity == 0 || parity == 1, HGYM_E_BADARG, "parity=%d", parity);
+    HG_REQUIRE(st->counters && last_out->time_out && last_out->extras_time_outs && last_out->extras_episode && last_out->rew && last_out->reset,
+               HGYM_E_BADARG, "null finaliser buffer");
+    const FinArgs f = parity_fin(*env_cfg, *st, *last_out, (RolloutScratch*)scratch, parity);
+    hipLaunchKernelGGL(rollout_fin_kernel, dim3(1), dim3(env_cfg->num_envs > 256 ? 1024 : 256), 0, (hipStream_t)stream, f);
+    HG_CHECK_LAUNCH("rollout_fin_kernel");
+    return HGYM_OK;
+}
+
+}  // extern "C"

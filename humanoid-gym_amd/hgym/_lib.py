@@ -155,6 +155,11 @@ SYMBOLS = {
                                     c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, C.c_void_p]),
     "hgym_policy_act_fin": (C.c_int32, [_P(NetConfig), _P(Net), C.c_int32, c_float_p, c_float_p, c_float_p, C.c_uint64, c_i64_p,
                                     c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, _P(EnvConfig), _P(EnvState), _P(EnvOut), C.c_void_p]),
+    "hgym_rollout_begin": (C.c_int32, [_P(EnvState), c_i64_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    "hgym_rollout_step": (C.c_int32, [_P(NetConfig), _P(Net), _P(EnvConfig), _P(SimTensors), _P(EnvState), _P(EnvOut), _P(EnvOut), c_float_p,
+                                      c_float_p, C.c_uint64, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, C.c_void_p, C.c_int32,
+                                      C.c_void_p]),
+    "hgym_rollout_end": (C.c_int32, [_P(EnvConfig), _P(EnvState), _P(EnvOut), C.c_void_p, C.c_int32, C.c_void_p]),
     "hgym_ppo_grad": (C.c_int32, [_P(NetConfig), _P(PPOConfig), _P(Net), _P(Batch), C.c_void_p]),
     "hgym_ppo_grad_part": (C.c_int32, [_P(NetConfig), _P(PPOConfig), _P(Net), _P(Batch), C.c_int32, C.c_void_p]),
     "hgym_net_param_offset": (C.c_int64, [_P(NetConfig), C.c_int32]),
@@ -163,7 +168,8 @@ SYMBOLS = {
     "hgym_prof_phase_buffer": (C.c_int32, [C.c_void_p, C.c_int64]),
     "hgym_prof_summary": (C.c_int32, [C.c_int32, _P(C.c_int64), _P(C.c_double), _P(C.c_double)]),
 }
-PROF_GEMM, PROF_ENV_STEP, PROF_GAE, PROF_LOSS, PROF_MLP_FWD, PROF_MLP_BWD, PROF_DW, PROF_REDUCE, PROF_APPLY, PROF_POLICY = range(10)
+PROF_GEMM, PROF_ENV_STEP, PROF_GAE, PROF_LOSS, PROF_MLP_FWD, PROF_MLP_BWD, PROF_DW, PROF_REDUCE, PROF_APPLY, PROF_POLICY, PROF_ROLLOUT = range(11)
+ROLLOUT_SCRATCH_BYTES = 512
 
 
 def prof_summary(cls):

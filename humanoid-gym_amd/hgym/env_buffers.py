@@ -64,6 +64,10 @@ class EnvBuffers:
         self.time_out = z(N, dtype=torch.bool)
         self.extras_time_outs = z(N, dtype=torch.bool)
         self.extras_episode = z(L.NUM_REWARDS)
+        # the fused rollout step (hgym_rollout_step) runs the finaliser of step t - 1 concurrently with the env phase of step t: a
+        # second rew / reset / time_out set for the alternate steps, and the library's scratch block (zero-filled once)
+        self.rew_alt, self.reset_alt, self.time_out_alt = z(N), torch.zeros(N, dtype=torch.bool, device=dev), z(N, dtype=torch.bool)
+        self.rollout_scratch = torch.zeros(L.ROLLOUT_SCRATCH_BYTES, dtype=torch.uint8, device=dev)
         # sim tensors
         self.sim_layout = sim_layout
         if sim_layout == "soa":
@@ -199,11 +203,13 @@ class EnvBuffers:
             st.command_range_x = C.cast(self.command_range_x.data_ptr(), L.c_f64_p)
         return st
 
-    def out_struct(self, obs=None, priv=None, sink=None, defer_finalize=False):
+    def out_struct(self, obs=None, priv=None, sink=None, defer_finalize=False, alt=False):
         """sink: optional dict(values, rewards, dones, step, gamma) -- HgymEnvOut's transition sink (caller keeps the tensors alive).
-        defer_finalize: the env-step call does not launch the step finaliser (see HgymEnvOut.defer_finalize)."""
+        defer_finalize: the env-step call does not launch the step finaliser (see HgymEnvOut.defer_finalize).
+        alt: the alternate rew / reset / time_out set (fused rollout step)."""
+        rew, reset, time_out = (self.rew_alt, self.reset_alt, self.time_out_alt) if alt else (self.rew, self.reset, self.time_out)
         o = L.EnvOut(L.fptr(self.obs if obs is None else obs), L.fptr(self.priv_obs if priv is None else priv),
-                     L.fptr(self.rew), L.u8ptr(self.reset), L.u8ptr(self.time_out), L.u8ptr(self.extras_time_outs),
+                     L.fptr(rew), L.u8ptr(reset), L.u8ptr(time_out), L.u8ptr(self.extras_time_outs),
                      L.fptr(self.extras_episode))
         if sink is not None:
             o.t_values, o.t_rewards = L.fptr(sink["values"]), L.fptr(sink["rewards"])

@@ -111,7 +111,19 @@ class OnPolicyRunner:
         defer_ok = (sink_ok and not log_on and hasattr(env, "take_pending_finalize") and isinstance(alg, PPO)
                     and os.environ.get("HGYM_DEFER_FIN", "1") != "0")
 
+        # ... and with the synthetic-physics backend the whole loop body -- act, env.step, process_env_step -- is ONE launch per
+        # vec-step (hgym_rollout_step): the env step of a 32-env slice runs right behind the actor tile of the same slice
+        fuse_ok = (defer_ok and hasattr(env, "rollout_fused_supported") and hasattr(alg, "fused_rollout_step")
+                   and os.environ.get("HGYM_FUSE_ROLLOUT", "1") != "0" and env.rollout_fused_supported(alg.net))
+
         def rollout(obs, critic_obs):
+            if fuse_ok:
+                env.rollout_begin(alg._sample_step, self.num_steps_per_env)
+                for i in range(self.num_steps_per_env):
+                    alg.fused_rollout_step(env, i, obs, critic_obs, obs_all[i + 1], priv_all[i + 1])
+                    obs, critic_obs = obs_all[i + 1], priv_all[i + 1]
+                env.rollout_end()
+                return obs, critic_obs
             fin = None
             for i in range(self.num_steps_per_env):
                 actions = alg.act(obs, critic_obs, env_fin=fin) if defer_ok else alg.act(obs, critic_obs)
@@ -149,7 +161,7 @@ class OnPolicyRunner:
         # the captured launches hold HgymEnvConfig and the sink's gamma BY VALUE: a change between learn() calls (reward scales,
         # command ranges, push / noise settings written into the env's native config, alg.gamma -- what a curriculum script does)
         # must re-capture, as the eager reference would simply see it
-        gkey = (id(env), id(alg.storage), log_on, sink_ok, defer_ok, getattr(alg, "gamma", None),
+        gkey = (id(env), id(alg.storage), log_on, sink_ok, defer_ok, fuse_ok, getattr(alg, "gamma", None),
                 env.native_config_digest() if hasattr(env, "native_config_digest") else None)
         tot_iter = self.current_learning_iteration + num_learning_iterations
         for it in range(self.current_learning_iteration, tot_iter):

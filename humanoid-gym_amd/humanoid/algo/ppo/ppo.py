@@ -167,6 +167,18 @@ class PPO:
             self._sample_step += 1
         return t.actions
 
+    def fused_rollout_step(self, env, i, obs, critic_obs, next_obs, next_critic_obs):
+        """act() + env.step() + process_env_step() of rollout step i as ONE launch (LeggedRobot.rollout_step): the policy's outputs
+        land in storage slot i, the env writes the next observations into the slots handed in, the finaliser riding in the
+        following launch stores rewards / dones of slot i (time-out bootstrap included)."""
+        st, s = self.storage, self.storage.step
+        if s >= st.num_transitions_per_env:
+            raise AssertionError("Rollout buffer overflow")
+        out = dict(actions=st.actions[s], mu=st.mu[s], sigma=st.sigma[s], logp=st.actions_log_prob[s].view(-1), values=st.values[s])
+        sink = dict(values=st.values[s], rewards=st.rewards[s], dones=st.dones[s], step=self._sample_step, gamma=self.gamma)
+        env.rollout_step(self.net, i, obs, critic_obs, next_obs, next_critic_obs, sink, self.actor_critic._sample_seed, out)
+        st.step += 1
+
     def transition_sink(self):
         """The scalar columns of the storage slot act() has just filled, for an env that can store them itself
         (LeggedRobot.bind_transition); the caller sets `env_stores_transitions` for the duration and follows env.step

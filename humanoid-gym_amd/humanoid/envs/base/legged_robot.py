@@ -360,6 +360,52 @@ class LeggedRobot(BaseTask):
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
+    # ------------------------------------------------------------------ fused rollout step (native extension)
+    # One launch per vec-step: PPO.act, this env's step (synthetic-physics backend) and the previous step's finaliser
+    # (include/hgym.h: hgym_rollout_begin / _step / _end).  Used by OnPolicyRunner when nothing on the host needs the per-step
+    # results; every other caller keeps act() + step().
+    def rollout_fused_supported(self, net):
+        """XBot-L default options (none of the generic ones), 15 / 3 history, a whole number of 32-env blocks, the bf16 fused net
+        path with XBot-L's first hidden widths, and one actor + one critic workgroup per 32 envs fitting the chip in one round."""
+        c, nc = self._ncfg, net.cfg
+        generic = c.custom_origins or c.terrain_curriculum or c.num_height_points > 0 or c.command_curriculum or not c.heading_command
+        cus = int(self._L.lib.hgym_device_cus())
+        return bool(not generic and not c.use_ref_actions and c.frame_stack == 15 and c.c_frame_stack == 3 and self.num_envs % 32 == 0
+                    and nc.precision == self._L.BF16 and nc.actor_layers == 4 and nc.critic_layers == 4 and nc.actor_dims[1] == 512
+                    and nc.critic_dims[1] == 768 and nc.num_actions == 12 and 2 * (self.num_envs // 32) <= max(cus, 1)
+                    and getattr(self.cfg.env, "send_timeouts", False))
+
+    def rollout_begin(self, step_counter, num_steps):
+        if getattr(self, "_pending_fin", None) is not None:
+            raise RuntimeError("a postponed step finaliser is pending; run it before a fused rollout")
+        self._ro_T, self._ro_prev = int(num_steps), None
+        self._L.check(self._L.lib.hgym_rollout_begin(C.byref(self._st_s), self._L.i64ptr(step_counter), C.c_void_p(self._buf.rollout_scratch.data_ptr()),
+                                                     (self._ro_T - 1) & 1, self._stream()), "hgym_rollout_begin")
+
+    def rollout_step(self, net, i, obs, priv, next_obs, next_priv, sink, seed, out):
+        """Step i of the rollout begun with rollout_begin: actions / mu / sigma / logp / values of PPO.act into `out`, this env's
+        step on those actions with the observations written to next_obs / next_priv, the transition sink of step i stored by
+        the finaliser that rides in step i + 1 (or in rollout_end).  The last step uses the primary rew / reset / time_out
+        buffers, so that they read as after a plain step() once the rollout is over."""
+        L = self._L
+        parity = (self._ro_T - 1 - i) & 1
+        o = self._buf.out_struct(next_obs, next_priv, sink, True, alt=bool(parity))
+        prev = self._ro_prev
+        L.check(L.lib.hgym_rollout_step(C.byref(net.cfg), C.byref(net.struct), C.byref(self._ncfg), C.byref(self._sim_s), C.byref(self._st_s),
+                                        C.byref(o), C.byref(prev[0]) if prev is not None else None, L.fptr(obs), L.fptr(priv),
+                                        int(seed) & 0xFFFFFFFFFFFFFFFF, L.fptr(out["actions"]), L.fptr(out["mu"]), L.fptr(out["sigma"]),
+                                        L.fptr(out["logp"]), L.fptr(out["values"]), C.c_void_p(self._buf.rollout_scratch.data_ptr()), parity,
+                                        self._stream()), "hgym_rollout_step")
+        self._ro_prev = (o, parity, sink)          # keeps the struct (and the tensors it points at) alive for the next launch
+        self.obs_buf, self.privileged_obs_buf = next_obs, next_priv
+
+    def rollout_end(self):
+        """The finaliser of the last step on its own."""
+        o, parity, _ = self._ro_prev
+        self._L.check(self._L.lib.hgym_rollout_end(C.byref(self._ncfg), C.byref(self._st_s), C.byref(o), C.c_void_p(self._buf.rollout_scratch.data_ptr()),
+                                                   parity, self._stream()), "hgym_rollout_end")
+        self._ro_prev = None
+
     def _next_out(self):
         if self._bound_out is not None:
             obs, priv = self._bound_out

@@ -362,6 +362,36 @@ int32_t hgym_policy_act_fin(const HgymNetConfig* cfg, const HgymNet* net, int32_
                             const HgymEnvConfig* env_cfg, const HgymEnvState* env_st, const HgymEnvOut* env_out,
                             void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Fused rollout step: PPO.act + XBotLFreeEnv.step (synthetic-physics backend) + the previous step's finaliser in ONE launch
+ * (algo/ppo/on_policy_runner.py:129-141 is the loop body this stands for: act -> env.step -> process_env_step).
+ * Workgroup b computes the actor tile of envs [32 b, 32 b + 32), samples their actions and runs their env step right behind it;
+ * a second grid row holds the critic tiles, a third the finaliser of the PREVIOUS step (HgymEnvOut.defer_finalize semantics:
+ * the transition sink of `prev_out`, extras, counters).  Results are those of hgym_policy_act_fin followed by
+ * hgym_env_step_synth: same kernels' source, same arithmetic.
+ *
+ * Calling sequence for a rollout of T steps, parity(t) alternating 0 / 1:
+ *     hgym_rollout_begin(st, step_counter, scratch, parity(0))
+ *     for t in 0..T-1:  hgym_rollout_step(..., out[t], t ? out[t-1] : NULL, obs[t], priv[t], ..., scratch, parity(t))
+ *     hgym_rollout_end(env_cfg, st, out[T-1], scratch, parity(T-1))
+ * where out[t] has obs / priv_obs = where the observations of step t+1 go, the transition sink of step t (t_values = the
+ * `values` buffer of the same call, t_rewards / t_dones, t_step = step_counter), defer_finalize = 1, and -- because the
+ * finaliser of step t-1 runs concurrently with the env phase of step t -- rew / reset / time_out buffers DISTINCT from
+ * out[t-1]'s (two sets, alternating).  Between begin and end no other env entry point may run on this state.
+ * scratch: HGYM_ROLLOUT_SCRATCH_BYTES bytes owned by the caller, zero-filled once (ping-pong step counters, per-parity reset
+ * count and episode-sum accumulators).  Supported: the XBot-L default options (none of the generic ones, no use_ref_actions),
+ * 15 / 3 history, contiguous [136][N] state, SoA sim tensors, N a multiple of 32, the bf16 fused net path;
+ * HGYM_E_UNSUPPORTED otherwise (callers fall back to hgym_policy_act_fin + hgym_env_step_synth).
+ * ---------------------------------------------------------------------------------------------- */
+#define HGYM_ROLLOUT_SCRATCH_BYTES 512
+int32_t hgym_rollout_begin(const HgymEnvState* st, const int64_t* step_counter, void* scratch, int32_t parity, void* stream);
+int32_t hgym_rollout_step(const HgymNetConfig* cfg, const HgymNet* net, const HgymEnvConfig* env_cfg, const HgymSimTensors* sim,
+                          const HgymEnvState* st, const HgymEnvOut* out, const HgymEnvOut* prev_out, const float* obs,
+                          const float* priv, uint64_t seed, float* actions, float* mu, float* sigma, float* logp, float* values,
+                          void* scratch, int32_t parity, void* stream);
+int32_t hgym_rollout_end(const HgymEnvConfig* env_cfg, const HgymEnvState* st, const HgymEnvOut* last_out, void* scratch,
+                         int32_t parity, void* stream);
+
 /* One minibatch of PPO.update up to and including backward (ppo.py:128-171), device side only:
  * gathers rows `idx[0..B)` (indices into the flattened (T*N) storage, rollout_storage.py:151-182) of the
  * nine storage tensors, forward, KL -> learning-rate adaptation (written to opt_state[0]), clipped
@@ -418,7 +448,8 @@ enum {
     HGYM_PROF_REDUCE = 7,    /* split-K slab reduction */
     HGYM_PROF_APPLY = 8,     /* grad-norm + clip + Adam */
     HGYM_PROF_POLICY = 9,    /* fused forward, rollout / inference (32-row tiles, sampling epilogue) */
-    HGYM_PROF_CLASSES = 10
+    HGYM_PROF_ROLLOUT = 10,  /* fused rollout step (policy + env step + previous finaliser); work = algorithmic HBM bytes */
+    HGYM_PROF_CLASSES = 11
 };
 int32_t hgym_prof_enable(int32_t on);  /* 1: start collecting (clears previous events), 0: stop */
 int32_t hgym_prof_summary(int32_t cls, int64_t* launches, double* total_ms, double* work);

@@ -2,6 +2,7 @@
 and the single-launch synthetic env step -- against the oracle, against the generic fp32 path and against their own
 component-wise forms.  Tolerances are written next to each check."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -199,6 +200,49 @@ def test_graph_replay_equals_eager_rollout(monkeypatch):
         del r
     for a, b in zip(outs["1"], outs["0"]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("graph", ["0", "1"])
+def test_fused_rollout_step_equals_act_then_step(monkeypatch, graph):
+    """hgym_rollout_step (ONE launch per vec-step: actor tile + env step of the same 32 envs, critic tile, the previous step's
+    finaliser) against hgym_policy_act_fin followed by hgym_env_step_synth (two launches): after two learning iterations from
+    the same seeds the rollout storage, the env state (state fields, sim tensors, history rings, episode lengths, counters,
+    extras) and the parameters are bit-identical -- the fused kernel runs the same source for every phase, and its ping-pong
+    step counters / per-parity accumulators reproduce the sequence the device-resident counters go through."""
+    from humanoid.algo import PPO
+    PPO.precision = "bf16"
+    monkeypatch.setenv("HGYM_GRAPH", graph)
+    outs = {}
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("HGYM_FUSE_ROLLOUT", fuse)
+        torch.manual_seed(4321)
+        np.random.seed(4321)
+        r = _runner(512, 31)
+        r.env.episode_length_buf = (torch.arange(512, device="cuda") * 37) % 2400       # time-outs, command resampling inside the window
+        r.env._buf.counters[0] = 390                                                   # a push (every 400 steps) too
+        n_iter = 3 if graph == "1" else 2
+        r.learn(num_learning_iterations=n_iter, init_at_random_ep_len=False)
+        torch.cuda.synchronize()
+        st, b = r.alg.storage, r.env._buf
+        assert int(st.dones.sum()) > 0
+        outs[fuse] = dict(params=r.alg.net.params.clone(), obs=st._obs_all.clone(), priv=st._priv_all.clone(), rewards=st.rewards.clone(),
+                          actions=st.actions.clone(), values=st.values.clone(), logp=st.actions_log_prob.clone(), mu=st.mu.clone(),
+                          dones=st.dones.clone(), returns=st.returns.clone(), sample_step=r.alg._sample_step.clone(),
+                          state=b._state.clone(), root=b.root.clone(), dof_pos=b.dof_pos.clone(), dof_vel=b.dof_vel.clone(),
+                          contact=b.contact.clone(), rigid=b.rigid.clone(), obs_ring=b.obs_ring.clone(), priv_ring=b.priv_ring.clone(),
+                          ep_len=b.episode_length.clone(), counters=b.counters.clone(), rew=b.rew.clone(), reset=b.reset.clone(),
+                          time_out=b.time_out.clone(), extras_time_outs=b.extras_time_outs.clone(), episode_acc=b.episode_acc.clone(),
+                          env_obs=r.env.obs_buf.clone())
+        fused_ran = os.environ.get("HGYM_FUSE_ROLLOUT") == "1" and r.env.rollout_fused_supported(r.alg.net)
+        assert fused_ran == (fuse == "1")
+        extras = b.extras_episode.clone()
+        outs[fuse]["extras_episode"] = extras
+        del r
+    for k in outs["1"]:
+        if k == "extras_episode":        # means over resetting envs: fp32 atomics, order-dependent in the last bit
+            np.testing.assert_allclose(outs["1"][k].cpu().numpy(), outs["0"][k].cpu().numpy(), rtol=1e-5, atol=1e-9)
+        else:
+            assert torch.equal(outs["1"][k], outs["0"][k]), k
 
 
 @pytest.mark.parametrize("use_ref_actions", [0, 1])

@@ -1,0 +1,47 @@
+"""GPU probe: phase clock of the fused rollout step (hgym_rollout_step) -- per-phase mean durations per workgroup of the actor
+tile, the critic tile and the env part behind the actor tile (hgym_prof_phase_buffer; 100 MHz stamps)."""
+import ctypes as C
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "humanoid-gym_amd"))
+import torch
+from hgym import _lib as L
+from humanoid.algo import PPO
+PPO.precision = "bf16"
+from humanoid.envs import task_registry
+from humanoid.utils import get_args
+
+N = int(os.environ.get("HGYM_N", "4096"))
+os.environ["HGYM_GRAPH"] = "0"
+a = get_args(["--task=humanoid_ppo", "--headless", "--num_envs", str(N)])
+env, _ = task_registry.make_env(name=a.task, args=a)
+runner, _ = task_registry.make_alg_runner(env=env, name=a.task, args=a, log_root=None)
+runner.learn(num_learning_iterations=1, init_at_random_ep_len=True)
+torch.cuda.synchronize()
+nb = N // 32
+buf = torch.zeros(nb * 3 * 8, dtype=torch.int64, device="cuda")
+L.check(L.lib.hgym_prof_phase_buffer(C.c_void_p(buf.data_ptr()), buf.numel()))
+alg, st = runner.alg, runner.alg.storage
+obs_all, priv_all = st._obs_all, st._priv_all
+alg.env_stores_transitions = True
+env.rollout_begin(alg._sample_step, 4)
+acc = []
+for i in range(4):
+    buf.zero_()
+    alg.fused_rollout_step(env, i, obs_all[i], priv_all[i], obs_all[i + 1], priv_all[i + 1])
+    torch.cuda.synchronize()
+    acc.append(buf.clone())
+env.rollout_end()
+st.step = 0
+L.check(L.lib.hgym_prof_phase_buffer(None, 0))
+FWD = ["input0+draws", "layer0 k-loop", "epilogue0+sync", "layer1+sync", "layer2+sync", "head"]
+ENV = ["hist stores", "joints+sync", "per-env chain+sync", "stage-out", "phase B"]
+for i, b in enumerate(acc[1:], 1):
+    t = b.view(3, nb, 8).cpu().double() * 0.01
+    for row, tag, names in ((0, "actor", FWD), (1, "critic", FWD), (2, "env (behind the actor tile)", ENV)):
+        d = t[row]
+        segs = [(d[:, k + 1] - d[:, k]).mean().item() for k in range(len(names))]
+        print("step %d %-28s block mean %.1f us: " % (i, tag, (d[:, len(names)] - d[:, 0]).mean().item()) +
+              ", ".join("%s %.1f" % (n, s) for n, s in zip(names, segs)))
+    print("step %d actor start -> env end: mean %.1f us, grid span %.1f us" % (
+        i, (t[2][:, 5] - t[0][:, 0]).mean().item(), (t[2][:, 5].max() - t[0][:, 0].min()).item()))
