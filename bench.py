@@ -212,6 +212,7 @@ def cpu_baseline(num_envs, T=60, full_minibatch=True, allow_reference=True):
 def _roofline(L, runner, elapsed_per_iter_ms, precision, n_profiled_iters):
     mfma_peak = MFMA_BF16_PEAK_TFLOPS if precision == "bf16" else 157.3
     classes = [  # (class id, kernel, bound)
+        (L.PROF_ROLLOUT, "rollout_step_kernel", "hbm"),      # policy act + env step + previous finaliser, one launch per vec-step
         (L.PROF_ENV_STEP, "env_step_kernel", "hbm"), (L.PROF_MLP_FWD, "mlp_fwd_kernel", "mfma"),
         (L.PROF_POLICY, "mlp_fwd_kernel<32>", "mfma"),
         (L.PROF_MLP_BWD, "mlp_bwd_kernel", "mfma"), (L.PROF_DW, "dw_kernel", "mfma"), (L.PROF_GEMM, "gemm_nt_kernel", "mfma"),

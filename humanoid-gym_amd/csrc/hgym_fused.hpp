@@ -403,7 +403,8 @@ struct FwdArgs {
 // step's own input loads and its Philox draws go there, under the same memory round trip; `mid()` runs between the first
 // layer and the second, where the first layer's weight ring and accumulators are dead and ~60 registers are free for loads that
 // may take the rest of the tile to arrive (the observation history); `put_action(row, j, a)` receives every sampled action of
-// the tile (row within the tile, action index) so that the env phase reads them from LDS.  They are lambdas that capture the
+// the tile (row within the tile, action index) so that the env phase reads them from LDS; `idle()` runs on the wavefronts that
+// have no head block while the others compute the head.  They are lambdas that capture the
 // caller's locals by reference (a hook OBJECT carrying the prefetch arrays as members was kept in private memory by the
 // compiler: 500 scratch instructions and a kernel four times slower).
 // `extra` (whatever the hooks need from the kernel argument) reaches them as a call PARAMETER: a closure that captured a
@@ -414,9 +415,11 @@ struct FwdNoop {
     __device__ __forceinline__ void operator()(int, int, float) const {}
 };
 
-template <int BM, int NW, int D, int G1, bool WIDE = false, class Early = FwdNoop, class Mid = FwdNoop, class Put = FwdNoop, class Extra = int>
+template <int BM, int NW, int D, int G1, bool WIDE = false, class Early = FwdNoop, class Mid = FwdNoop, class Put = FwdNoop, class Extra = int,
+          class Idle = FwdNoop>
 __device__ __forceinline__ void fwd_body(const FwdArgs& a, const FusedNet& n, bool is_actor, char* smem, Early&& hook_early = Early(),
-                                         Mid&& hook_mid = Mid(), Put&& hook_put = Put(), const Extra& extra = Extra()) {
+                                         Mid&& hook_mid = Mid(), Put&& hook_put = Put(), const Extra& extra = Extra(),
+                                         Idle&& hook_idle = Idle()) {
     constexpr int MB = BM / 16;
     constexpr int IT = BM * 32 / (NW * 64);           // staging items per thread per chunk (BM rows x 32 float4)
     constexpr int RPP = NW * 2;                       // rows covered per staging pass (32 lanes per row)
@@ -632,6 +635,8 @@ __device__ __forceinline__ void fwd_body(const FwdArgs& a, const FusedNet& n, bo
                 }
             }
         }
+    } else {
+        hook_idle(extra);      // the wavefronts without a head block (NW - BM / 16 of them): free for the duration of the head
     }
     phase_stamp(a.dbg, 6);
 }

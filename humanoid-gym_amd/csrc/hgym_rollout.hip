@@ -34,6 +34,12 @@
 #include "hgym_env_math.hpp"
 #include "hgym_fused.hpp"
 
+#ifndef HGYM_RO_DRAWS_IDLE
+#define HGYM_RO_DRAWS_IDLE 1
+#endif
+#ifndef HGYM_RO_INTERLEAVE
+#define HGYM_RO_INTERLEAVE 1
+#endif
 #ifndef HGYM_RO_VARIANT
 #define HGYM_RO_VARIANT 0      // experiments only: 1 = policy tiles alone (no env work at all), 2 = env part without its early loads
 #endif
@@ -77,7 +83,14 @@ __global__ __launch_bounds__(RO_NT) void rollout_step_kernel(const FwdArgs f, co
         return;
     }
     constexpr int U = 16 / 8;                       // n-blocks per wave per 256 first-layer columns (mlp_fwd_kernel)
-    if (blockIdx.y == 1) {                          // critic tile
+#if HGYM_RO_INTERLEAVE
+    // actor and critic workgroups alternate in dispatch order (tile b: row 0 holds its actor when b is even, its critic when b
+    // is odd), so that the long actor + env workgroups are spread evenly over neighbouring compute units
+    const bool critic_wg = ((blockIdx.x + blockIdx.y) & 1) != 0;
+#else
+    const bool critic_wg = blockIdx.y == 1;
+#endif
+    if (critic_wg) {                                // critic tile
         // one instantiation only (first hidden layer 768 wide, rollout_fwd_args checks): with the three-way dispatch of
         // mlp_fwd_kernel next to the actor + env branch the compiler keeps a private-memory copy of the whole 3 KB argument
         fwd_body<32, 8, 4, 3 * U>(f, f.net[1], false, smem);
@@ -95,12 +108,16 @@ __global__ __launch_bounds__(RO_NT) void rollout_step_kernel(const FwdArgs f, co
         if (t < 256) env_stage_in<RO_E>(E, block, t, 256, esm);
 #endif
 #if HGYM_RO_VARIANT == 0
+#if HGYM_RO_DRAWS_IDLE
+        if (t < 256) env_stage_in<RO_E>(E, block, t, 256, esm);      // travels with the tile's own first loads
+#else
         // issue the state / sim loads, compute the draws under them, then write the loaded quads to the env image
         StageRegs<RO_E> R;
         R.fast = 0;
         if (t < 256) env_stage_in_load<RO_E>(E, block, t, 256, R);
         env_fill_draws<RO_E>(E, block, t, RO_NT, esm, csc0);
         if (t < 256) env_stage_in_store<RO_E>(E, block, t, 256, esm, R);
+#endif
 #endif
     };
     auto mid = [&](const EnvArgs& E) {
@@ -109,7 +126,13 @@ __global__ __launch_bounds__(RO_NT) void rollout_step_kernel(const FwdArgs f, co
 #endif
     };
     auto put = [&](int row, int j, float v) { esm[act_off + row * 12 + j] = v; };
-    fwd_body<32, 8, 4, 2 * U, false>(f, f.net[0], true, smem, early, mid, put, e);
+    // the env step's Philox draws: on the six wavefronts that have no head block, while the other two compute the head
+    auto idle = [&](const EnvArgs& E) {
+#if HGYM_RO_DRAWS_IDLE && HGYM_RO_VARIANT == 0
+        env_fill_draws<RO_E>(E, block, t - 128, RO_NT - 128, esm, csc0);
+#endif
+    };
+    fwd_body<32, 8, 4, 2 * U, false>(f, f.net[0], true, smem, early, mid, put, e, idle);
     __syncthreads();                                // the tile's actions are in the env image; the policy buffers are dead
     // phase clock of the env part (hgym_prof_phase_buffer): the slots of grid row 2, which stamps nothing itself
     long long* dbg = f.dbg ? f.dbg + (int64_t)2 * gridDim.x * 8 + (int64_t)block * 8 : nullptr;

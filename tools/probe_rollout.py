@@ -45,3 +45,13 @@ for i, b in enumerate(acc[1:], 1):
               ", ".join("%s %.1f" % (n, s) for n, s in zip(names, segs)))
     print("step %d actor start -> env end: mean %.1f us, grid span %.1f us" % (
         i, (t[2][:, 5] - t[0][:, 0]).mean().item(), (t[2][:, 5].max() - t[0][:, 0].min()).item()))
+    t0 = t[0][:, 0].min()
+    q = lambda x: "min %.1f p50 %.1f p90 %.1f max %.1f" % (x.min().item(), x.median().item(), x.quantile(0.9).item(), x.max().item())
+    print("step %d   actor start offsets: %s | critic start offsets: %s" % (i, q(t[0][:, 0] - t0), q(t[1][:, 0] - t0)))
+    print("step %d   actor+env durations: %s | env end offsets: %s" % (i, q(t[2][:, 5] - t[0][:, 0]), q(t[2][:, 5] - t0)))
+    slow = (t[2][:, 5] - t[0][:, 0]) >= (t[2][:, 5] - t[0][:, 0]).quantile(0.9)
+    for row, tag, names in ((0, "actor", FWD), (2, "env", ENV)):
+        d = t[row]
+        print("step %d   %s phases, slowest 10%% of workgroups vs the rest: " % (i, tag) + ", ".join(
+            "%s %.1f/%.1f" % (n, (d[slow, k + 1] - d[slow, k]).mean().item(), (d[~slow, k + 1] - d[~slow, k]).mean().item()) for k, n in enumerate(names)))
+    print("step %d   slow workgroups (block ids): %s" % (i, torch.nonzero(slow).flatten().tolist()))
