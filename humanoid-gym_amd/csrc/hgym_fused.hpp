@@ -404,7 +404,8 @@ struct FwdArgs {
 // layer and the second, where the first layer's weight ring and accumulators are dead and ~60 registers are free for loads that
 // may take the rest of the tile to arrive (the observation history); `put_action(row, j, a)` receives every sampled action of
 // the tile (row within the tile, action index) so that the env phase reads them from LDS; `idle()` runs on the wavefronts that
-// have no head block while the others compute the head.  They are lambdas that capture the
+// have no head block while the others compute the head; `head(wave, row, out[4])` runs on the head wavefronts with each lane's
+// row and its four head outputs (the fused forward + backward kernel computes the PPO loss gradient there).  They are lambdas that capture the
 // caller's locals by reference (a hook OBJECT carrying the prefetch arrays as members was kept in private memory by the
 // compiler: 500 scratch instructions and a kernel four times slower).
 // `extra` (whatever the hooks need from the kernel argument) reaches them as a call PARAMETER: a closure that captured a
@@ -413,13 +414,14 @@ struct FwdArgs {
 struct FwdNoop {
     template <class X> __device__ __forceinline__ void operator()(const X&) const {}
     __device__ __forceinline__ void operator()(int, int, float) const {}
+    __device__ __forceinline__ void operator()(int, int, const float (&)[4]) const {}
 };
 
 template <int BM, int NW, int D, int G1, bool WIDE = false, class Early = FwdNoop, class Mid = FwdNoop, class Put = FwdNoop, class Extra = int,
-          class Idle = FwdNoop>
+          class Idle = FwdNoop, class Head = FwdNoop>
 __device__ __forceinline__ void fwd_body(const FwdArgs& a, const FusedNet& n, bool is_actor, char* smem, Early&& hook_early = Early(),
                                          Mid&& hook_mid = Mid(), Put&& hook_put = Put(), const Extra& extra = Extra(),
-                                         Idle&& hook_idle = Idle()) {
+                                         Idle&& hook_idle = Idle(), Head&& hook_head = Head()) {
     constexpr int MB = BM / 16;
     constexpr int IT = BM * 32 / (NW * 64);           // staging items per thread per chunk (BM rows x 32 float4)
     constexpr int RPP = NW * 2;                       // rows covered per staging pass (32 lanes per row)
@@ -585,6 +587,7 @@ __device__ __forceinline__ void fwd_body(const FwdArgs& a, const FusedNet& n, bo
             for (int e = 0; e < 4; ++e)
                 if (4 * q + e < No) n.out[(int64_t)m * n.ldo + 4 * q + e] = mu[e];
         }
+        hook_head(wave, m, mu);     // `idle()`'s counterpart: every lane of the head wavefronts, with its row and its 4 head outputs
         if (is_actor && a.sample) {
 #pragma clang fp contract(off)      // a = mu + sigma z and the log-probability as separate fp32 roundings, identically in every translation unit
             const int A = a.A;
@@ -677,10 +680,13 @@ __device__ __forceinline__ void bwd_prime(WRing<GR, D>& R, const u32x4* __restri
     if (nb0 < NBo) wring_prime<G, D>(R, WTf + (int64_t)nb0 * NBBc * 64 + lane, NBBc * 64, NBBc);
 }
 
-template <int G, int MB, int NW, int D, bool AHEAD, int GR, class Next>
+// HLDS / H_lds: the tile's y = elu(z) in LDS (block layout, NBo column blocks) instead of the global Hg -- the fused forward +
+// backward kernel still has it there; out_lds may then be the SAME buffer (every lane reads a block entry and later writes that
+// very entry).
+template <int G, int MB, int NW, int D, bool AHEAD, bool HLDS = false, int GR, class Next>
 __device__ __forceinline__ void bwd_step(WRing<GR, D>& R, const u32x4* __restrict__ WTf, int NBo, int NBBc, const char* in_lds, int CBin,
                                          char* out_lds, __bf16* __restrict__ dZg, const __bf16* __restrict__ Hg, int64_t mbg0, int wave,
-                                         int lane, Next prime_next) {
+                                         int lane, Next prime_next, const char* H_lds = nullptr) {
     const int r = lane & 15, q = lane >> 4;
     const int loff = r * 32 + q * 8;
     bool primed = false;
@@ -696,8 +702,10 @@ __device__ __forceinline__ void bwd_step(WRing<GR, D>& R, const u32x4* __restric
 #pragma unroll
         for (int i = 0; i < MB; ++i)
 #pragma unroll
-            for (int g = 0; g < G; ++g)
-                aux[i][g] = ld_stream_u2<(HGYM_NT & 4) != 0>(reinterpret_cast<const char*>(Hg) + ((mbg0 + i) * NBo + nb0 + g) * 512 + loff);
+            for (int g = 0; g < G; ++g) {
+                if (HLDS) aux[i][g] = *reinterpret_cast<const u32x2*>(H_lds + (i * NBo + nb0 + g) * 512 + loff);
+                else aux[i][g] = ld_stream_u2<(HGYM_NT & 4) != 0>(reinterpret_cast<const char*>(Hg) + ((mbg0 + i) * NBo + nb0 + g) * 512 + loff);
+            }
 #pragma unroll
         for (int i = 0; i < MB; ++i)
 #pragma unroll
@@ -767,6 +775,176 @@ __global__ __launch_bounds__(NW * 64) void mlp_bwd_kernel(const BwdArgs a) {
     if (g0 == 2 * U) bwd_body<BM, NW, D, 2 * U>(a, n, smem);
     else if (g0 == 3 * U) bwd_body<BM, NW, D, 3 * U>(a, n, smem);
     else if (g0 == U) bwd_body<BM, NW, D, U>(a, n, smem);
+}
+
+// ================================================================================================ forward + loss + dZ chain
+// One kernel per minibatch instead of mlp_fwd_kernel -> ppo_loss_kernel -> ppo_scalars' inputs -> mlp_bwd_kernel: a tile's
+// forward leaves H1 and H2 in LDS (the two ping-pong buffers), the head wavefronts turn their outputs into the PPO loss gradient
+// (the per-sample arithmetic of ppo_loss_kernel, one lane per (row, 4 actions)) -- dZ3 goes to LDS and to HBM -- and the dZ chain
+// runs on the resident tile: through W3 against H2 (LDS, in place), through W2 against H1 (LDS, in place), through W1 against
+// H0, the one activation the forward's buffer reuse has evicted (re-read from the copy this workgroup has just written: L2).
+// HBM traffic per minibatch drops by the H1 / H2 re-reads and the loss kernel's own gathers; three launch boundaries go away.
+struct FbLoss {
+    const float* actions;      // (T*N, A) storage columns, gathered through FwdArgs::idx
+    const float* old_mu;
+    const float* old_sigma;
+    const float* values;       // (T*N,)
+    const float* advantages;
+    const float* returns;
+    const float* logp;
+    float clip, value_coef, entropy_coef;
+    float* partials;           // [tiles][32] per-tile sums, ppo_loss_kernel's layout: 0 surrogate, 1 value loss, 2 entropy, 3 kl,
+                               // 4..15 d std, 16..27 sum d mu (head bias gradient), 28 sum d V; the actor tile writes its entries, the
+                               // critic tile its two
+};
+
+HG_HD int fb_lds_extra() { return 64 * 64 + 4 * 32 * 4; }      // dZ3 tile (64 rows x 32 bf16 columns) + the head waves' partial sums
+
+template <int G1>
+__device__ __forceinline__ void fb_body(const FwdArgs& a, const FbLoss& L, const FusedNet& n, bool is_actor, char* smem) {
+    constexpr int BM = 64, NW = 16, D = 2, MB = BM / 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const int m0 = blockIdx.x * BM;
+    const int64_t mbg0 = m0 >> 4;
+    char* P = smem;
+    char* Q = smem + fused_lds_p(n, BM);
+    char* R0 = smem + fused_lds_p(n, BM) + fused_lds_q(n, BM) + fused_lds_bias(n);
+    float* red = reinterpret_cast<float*>(R0 + BM * 64);
+    const int A = a.A;
+    const float invB = 1.0f / (float)a.M;
+    auto head = [&](int hw, int m, const float (&out)[4]) {
+        // lane (r, q) of head wave hw: row m, head outputs 4q .. 4q + 3.  ppo.py:128-168 forward scalars + the hand-written
+        // backward of the loss w.r.t. mu, std and V (oracle/ppo_oracle.py: ppo_loss_and_grads), as in ppo_loss_kernel
+        const bool valid = m < a.M;
+        const int64_t row = a.idx ? a.idx[valid ? m : a.M - 1] : (int64_t)(valid ? m : a.M - 1);
+        float g[4] = {0.f, 0.f, 0.f, 0.f};
+        float part[11];
+#pragma unroll
+        for (int k = 0; k < 11; ++k) part[k] = 0.0f;
+        if (is_actor) {
+            float act[4] = {0.f, 0.f, 0.f, 0.f}, mo[4] = {0.f, 0.f, 0.f, 0.f}, so[4] = {1.f, 1.f, 1.f, 1.f}, sg[4] = {1.f, 1.f, 1.f, 1.f};
+            if (4 * q + 3 < A) {
+                const F4 qa = *reinterpret_cast<const F4*>(L.actions + row * A + 4 * q);
+                const F4 qo = *reinterpret_cast<const F4*>(L.old_mu + row * A + 4 * q);
+                const F4 qs = *reinterpret_cast<const F4*>(L.old_sigma + row * A + 4 * q);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { act[e] = qa.v[e]; mo[e] = qo.v[e]; so[e] = qs.v[e]; }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (4 * q + e < A) { act[e] = L.actions[row * A + 4 * q + e]; mo[e] = L.old_mu[row * A + 4 * q + e]; so[e] = L.old_sigma[row * A + 4 * q + e]; }
+            }
+            const float adv = L.advantages[row], lpold = L.logp[row];
+            float lp = 0.0f, ent = 0.0f, kl = 0.0f, diff[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                diff[e] = 0.0f;
+                if (4 * q + e < A) {
+                    const float mm = out[e];
+                    const float s = mm * 0.0f + a.std_[4 * q + e];
+                    const float d = act[e] - mm;
+                    diff[e] = d;
+                    sg[e] = s;
+                    lp += -(d * d) / (2.0f * s * s) - logf(s) - 0.9189385332046727f;
+                    ent += 0.5f + 0.9189385332046727f + logf(s);
+                    kl += logf(s / so[e] + 1.e-5f) + (so[e] * so[e] + (mo[e] - mm) * (mo[e] - mm)) / (2.0f * (s * s)) - 0.5f;
+                }
+            }
+            lp += __shfl_xor(lp, 16, 64);  lp += __shfl_xor(lp, 32, 64);
+            ent += __shfl_xor(ent, 16, 64); ent += __shfl_xor(ent, 32, 64);
+            kl += __shfl_xor(kl, 16, 64);  kl += __shfl_xor(kl, 32, 64);
+            const float ratio = expf(lp - lpold);
+            const float s1 = -adv * ratio;
+            const float s2 = -adv * clampf(ratio, 1.0f - L.clip, 1.0f + L.clip);
+            const float in_range = (ratio >= 1.0f - L.clip && ratio <= 1.0f + L.clip) ? 1.0f : 0.0f;
+            const float w1 = s1 > s2 ? 1.0f : (s1 == s2 ? 0.5f : 0.0f);
+            const float d_lp = (-adv) * (w1 + (1.0f - w1) * in_range) * invB * ratio;
+            if (valid) {
+                if (q == 0) { part[0] = fmaxf(s1, s2); part[1] = ent; part[2] = kl; }
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (4 * q + e < A) {
+                        const float s = sg[e], d = diff[e];
+                        g[e] = d_lp * d / (s * s);
+                        part[3 + e] = d_lp * (d * d / (s * s * s) - 1.0f / s) - (L.entropy_coef * invB) / s;
+                        part[7 + e] = g[e];
+                    }
+            }
+        } else {
+            const float ret = L.returns[row], vold = L.values[row];
+            const float v = out[0];
+            const float vc = vold + clampf(v - vold, -L.clip, L.clip);
+            const float l1 = (v - ret) * (v - ret), l2 = (vc - ret) * (vc - ret);
+            const float v_in = ((v - vold) >= -L.clip && (v - vold) <= L.clip) ? 1.0f : 0.0f;
+            const float u1 = l1 > l2 ? 1.0f : (l1 == l2 ? 0.5f : 0.0f);
+            if (valid && q == 0) {
+                g[0] = L.value_coef * invB * (u1 * 2.0f * (v - ret) + (1.0f - u1) * 2.0f * (vc - ret) * v_in);
+                part[0] = fmaxf(l1, l2);
+                part[1] = g[0];
+            }
+        }
+        // dZ3 tile, block layout: row block hw, column block 0 holds this lane's 4 columns (block 1 is zero padding)
+        const u32x2 pk = pack_bf16x4(g[0], g[1], g[2], g[3]);
+        const u32x2 zero = {0u, 0u};
+        const int off0 = (hw * 2 + 0) * 512 + r * 32 + q * 8, off1 = (hw * 2 + 1) * 512 + r * 32 + q * 8;
+        *reinterpret_cast<u32x2*>(R0 + off0) = pk;
+        *reinterpret_cast<u32x2*>(R0 + off1) = zero;
+        char* gz = reinterpret_cast<char*>(n.dZ[3]) + mbg0 * 2 * 512;
+        *reinterpret_cast<u32x2*>(gz + off0) = pk;
+        *reinterpret_cast<u32x2*>(gz + off1) = zero;
+        // sums over the 16 rows of this wave (lanes sharing q), then across the head waves through `red`
+#pragma unroll
+        for (int k = 0; k < 11; ++k) {
+            float v = part[k];
+            v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+            part[k] = v;
+        }
+        if (r == 0) {
+            float* w = red + hw * 32;
+            if (is_actor) {
+                if (q == 0) { w[0] = part[0]; w[2] = part[1]; w[3] = part[2]; }
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (4 * q + e < 12) { w[4 + 4 * q + e] = part[3 + e]; w[16 + 4 * q + e] = part[7 + e]; }
+            } else if (q == 0) {
+                w[1] = part[0];
+                w[28] = part[1];
+            }
+        }
+    };
+    fwd_body<BM, NW, D, G1, false>(a, n, is_actor, smem, FwdNoop(), FwdNoop(), FwdNoop(), 0, FwdNoop(), head);
+    __syncthreads();          // dZ3 tile and the per-wave sums are in LDS; H2 sits in P, H1 in Q
+    if (tid < 32) {
+        const bool mine = is_actor ? (tid != 1 && tid < 28) : (tid == 1 || tid == 28);
+        if (mine) L.partials[(int64_t)blockIdx.x * 32 + tid] = red[tid] + red[32 + tid] + red[64 + tid] + red[96 + tid];
+    }
+    // ---- dZ chain on the resident tile (mlp_bwd_kernel's steps)
+    const int N0 = n.layer[0].N, N1 = n.layer[1].N, N2 = n.layer[2].N;
+    const int NBB3 = n.layer[3].NBB;
+    WRing<1, D> ra;
+    WRing<1, D> rb;
+    WRing<G1, D> rc;
+    auto none = [&]() {};
+    bwd_prime<1, D>(ra, n.layer[3].WTf, N2 / 16, NBB3, wave, lane);
+    bwd_step<1, MB, NW, D, false, true>(ra, n.layer[3].WTf, N2 / 16, NBB3, R0, 2 * NBB3, P, n.dZ[2], nullptr, mbg0, wave, lane, none, P);
+    __syncthreads();
+    bwd_prime<1, D>(rb, n.layer[2].WTf, N1 / 16, n.layer[2].NBB, wave, lane);
+    bwd_step<1, MB, NW, D, false, true>(rb, n.layer[2].WTf, N1 / 16, n.layer[2].NBB, P, N2 / 16, Q, n.dZ[1], nullptr, mbg0, wave, lane, none, Q);
+    __syncthreads();
+    bwd_prime<G1, D>(rc, n.layer[1].WTf, N0 / 16, n.layer[1].NBB, wave, lane);
+    bwd_step<G1, MB, NW, D, false>(rc, n.layer[1].WTf, N0 / 16, n.layer[1].NBB, Q, N1 / 16, nullptr, n.dZ[0], n.H[0], mbg0, wave, lane, none);
+}
+
+template <int UNUSED = 0>      // a template only so that the header can be included by several translation units
+__global__ __launch_bounds__(1024) void mlp_fb_kernel(const FwdArgs a, const FbLoss L) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int which = a.net0 + blockIdx.y;
+    const FusedNet& n = a.net[which];
+    const int g1 = n.layer[0].NB / 16;     // first hidden width 256 / 512 / 768
+    if (g1 == 2) fb_body<2>(a, L, n, which == 0, smem);
+    else if (g1 == 3) fb_body<3>(a, L, n, which == 0, smem);
+    else if (g1 == 1) fb_body<1>(a, L, n, which == 0, smem);
 }
 
 // ================================================================================================ weight gradients

@@ -954,52 +954,52 @@ struct NetRunner {
         const int64_t ldxs[3] = {cfg.num_obs, cfg.num_priv, 0};
         float* outs[3] = {mu, val, nullptr};
         const int64_t ldos[3] = {A, 1, 0};
-        int32_t rc = fused_forward(0, 2, B, xs, ldxs, b.idx, outs, ldos, true, nullptr);
-        if (rc) return rc;
         const int Bp = (int)round_up(B, 64);
-        const int nblocks = ceil_div(Bp, 256);
-        HG_REQUIRE(nblocks <= MAX_LOSS_BLOCKS, HGYM_E_UNSUPPORTED, "minibatch %d too large for the loss partial buffer", B);
-        LossArgs a;
-        memset(&a, 0, sizeof(a));
-        a.b = b;
-        a.A = A;
-        a.mu = mu;
-        a.val = val;
-        a.std_ = net.params;
-        a.clip = ppo.clip_param;
-        a.value_coef = ppo.value_loss_coef;
-        a.entropy_coef = ppo.entropy_coef;
-        a.fused = 1;
-        a.dmu = at<T>(w.net[0].dZb[3]);
-        a.dval = at<T>(w.net[1].dZb[3]);
-        a.Bp = Bp;
-        a.partials = at<float>(w.partials);
-        prof_begin(HGYM_PROF_LOSS, s);
-        hipLaunchKernelGGL((ppo_loss_kernel<T>), dim3(nblocks), dim3(256), 0, s, a);
-        prof_end(HGYM_PROF_LOSS, s, (double)B * (4.0 * (5 * A + 6) + 2.0 * 64));
-        HG_CHECK_LAUNCH("ppo_loss_kernel");
-        hipLaunchKernelGGL(ppo_scalars_kernel, dim3(1), dim3(512), 0, s, nblocks, B, A, at<float>(w.partials), net.grads,
+        const int tiles = Bp / 64;
+        HG_REQUIRE(tiles <= MAX_LOSS_BLOCKS, HGYM_E_UNSUPPORTED, "minibatch %d too large for the loss partial buffer", B);
+        HG_REQUIRE(B <= w.maxM, HGYM_E_SHAPE, "minibatch %d exceeds max_batch %lld", B, (long long)w.maxM);
+        int32_t rc = HGYM_OK;
+        {   // forward + PPO loss + dZ chain of both nets: ONE launch (hgym_fused.hpp: mlp_fb_kernel)
+            const FwdArgs fa = make_fwd_args(0, 2, B, xs, ldxs, b.idx, outs, ldos, true, nullptr, nullptr);
+            FbLoss fl;
+            memset(&fl, 0, sizeof(fl));
+            fl.actions = b.actions;
+            fl.old_mu = b.mu;
+            fl.old_sigma = b.sigma;
+            fl.values = b.values;
+            fl.advantages = b.advantages;
+            fl.returns = b.returns;
+            fl.logp = b.logp;
+            fl.clip = ppo.clip_param;
+            fl.value_coef = ppo.value_loss_coef;
+            fl.entropy_coef = ppo.entropy_coef;
+            fl.partials = at<float>(w.partials);
+            size_t lds = 0;
+            for (int i = 0; i < 2; ++i)
+                lds = std::max(lds, (size_t)fused_lds_p(fa.net[i], 64) + (size_t)fused_lds_q(fa.net[i], 64) + (size_t)fused_lds_bias(fa.net[i]));
+            lds += (size_t)fb_lds_extra();
+            static size_t attr_lds = 0;
+            if (lds > attr_lds) {
+                if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fb_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+                    HG_FAIL(HGYM_E_LAUNCH, "cannot reserve %zu bytes of LDS for mlp_fb_kernel", lds);
+                attr_lds = lds;
+            }
+            FwdArgs fb = fa;
+            fb.nets = 2;
+            fb.dbg = phase_buffer((int64_t)tiles * 2);
+            prof_begin(HGYM_PROF_MLP_FWD, s);
+            hipLaunchKernelGGL(mlp_fb_kernel<0>, dim3(tiles, 2), dim3(1024), lds, s, fb, fl);
+            double flops = 0.0;
+            for (int i = 0; i < 2; ++i) {
+                for (int l = 0; l < 4; ++l) flops += 2.0 * (double)B * w.net[i].layer[l].N * w.net[i].layer[l].K;
+                for (int l = 1; l < 4; ++l) flops += 2.0 * (double)B * w.net[i].layer[l].K * w.net[i].layer[l].N;
+            }
+            prof_end(HGYM_PROF_MLP_FWD, s, flops);
+            HG_CHECK_LAUNCH("mlp_fb_kernel");
+        }
+        hipLaunchKernelGGL(ppo_scalars_kernel, dim3(1), dim3(512), 0, s, tiles, B, A, at<float>(w.partials), net.grads,
                            net.grads + w.net[0].layer[3].b_off, net.grads + w.net[1].layer[3].b_off, net.grads + w.P, net.opt_state);
         HG_CHECK_LAUNCH("ppo_scalars_kernel");
-        {   // dZ chain of both nets
-            BwdArgs g;
-            memset(&g, 0, sizeof(g));
-            size_t lds = 0;
-            for (int i = 0; i < 2; ++i) {
-                g.net[i] = fused_net(i, nullptr, 0, nullptr, 0);
-                lds = std::max(lds, (size_t)64 * 64 + (size_t)64 * 2 * (w.net[i].layer[2].N + w.net[i].layer[1].N));
-            }
-            g.M = B;
-            g.dbg = phase_buffer((int64_t)(Bp / 64) * 2);
-            if (reserve_bwd_lds(lds)) HG_FAIL(HGYM_E_LAUNCH, "cannot reserve %zu bytes of LDS for mlp_bwd_kernel", lds);
-            prof_begin(HGYM_PROF_MLP_BWD, s);
-            hipLaunchKernelGGL((mlp_bwd_kernel<64, 16, 2>), dim3(Bp / 64, 2), dim3(1024), lds, s, g);
-            double fl = 0.0;
-            for (int i = 0; i < 2; ++i)
-                for (int l = 1; l < 4; ++l) fl += 2.0 * (double)B * w.net[i].layer[l].K * w.net[i].layer[l].N;
-            prof_end(HGYM_PROF_MLP_BWD, s, fl);
-            HG_CHECK_LAUNCH("mlp_bwd_kernel");
-        }
         if (part == 0) {
             int32_t rc0 = fused_dw(1, 1, B);
             if (rc0) return rc0;
