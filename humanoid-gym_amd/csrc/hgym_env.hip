@@ -17,6 +17,9 @@
 
 #include "hgym_env_math.hpp"
 
+#ifndef HGYM_ENV_SPLIT
+#define HGYM_ENV_SPLIT 1
+#endif
 #ifndef HGYM_ENV_STAGE_FIRST
 #define HGYM_ENV_STAGE_FIRST 0   // measured (fast-class box, same call): 3.386 ms collection with 1, 3.304 with 0 -- the history loads are better issued first
 #endif
@@ -57,12 +60,20 @@ __global__ __launch_bounds__(256) void env_step_kernel(const EnvArgs A) {
 #endif
     if (!(A.ablate & 64)) env_fill_draws<E_T>(A, blockIdx.x, t, blockDim.x, smem, csc0);
     __syncthreads();
-    if (!(A.ablate & 128)) env_step_joints<E_T>(A, blockIdx.x, t, blockDim.x, smem);
+    // The XBot-L instantiation splits the per-env chain of a plain step (HGYM_ENV_SPLIT): what is the same few instructions
+    // for each of the 12 joints runs one (env, joint) pair per lane before (phase J) and after (phase F) a shorter chain, and
+    // the synthetic physics' per-env remainder runs on two otherwise idle wavefronts of phase J.
+    const bool split = HGYM_ENV_SPLIT && !kGeneric && E_T > 0 && A.mode == MODE_STEP;
+    if (split) env_step_phase_j<E_T>(A, blockIdx.x, t, blockDim.x, smem);
+    else if (!(A.ablate & 128)) env_step_joints<E_T>(A, blockIdx.x, t, blockDim.x, smem);
     __syncthreads();
     // wavefront 0 runs the per-env scalar chains (one lane per env); the other wavefronts meanwhile move the older frames of
     // the observation history, which depend on nothing this step computes (reset envs are fixed up in phase B)
     if (t < 64) {
-        if (!(A.ablate & 2)) env_step_phase_a<E_T, kGeneric>(A, blockIdx.x, t, smem, csc0);
+        if (!(A.ablate & 2)) {
+            if (split) env_step_phase_a<E_T, kGeneric, true>(A, blockIdx.x, t, smem, csc0);
+            else env_step_phase_a<E_T, kGeneric>(A, blockIdx.x, t, smem, csc0);
+        }
     } else if (kPrefetch) {
         if (stack_on) {
             hist_store<HP, HGYM_OBS_FRAME, NIO>(A.out.obs, geom.e0, geom.nE, (int)(ring_step % HP), t - 64, NTH, nullptr, A.cfg.clip_obs, hist_o);
@@ -73,6 +84,10 @@ __global__ __launch_bounds__(256) void env_step_kernel(const EnvArgs A) {
         env_step_stack_old<H_T, HC_T, E_T>(A, blockIdx.x, t - 64, blockDim.x - 64, ring_step);
     }
     __syncthreads();
+    if (split) {
+        env_step_phase_f<E_T>(A, blockIdx.x, t, blockDim.x, smem);
+        __syncthreads();
+    }
     if (!(A.ablate & 4)) env_stage_out<E_T>(A, blockIdx.x, t, blockDim.x, smem);
     if (!(A.ablate & 8)) env_step_phase_b<H_T, HC_T, E_T>(A, blockIdx.x, t, blockDim.x, smem, csc0, ring_step, false);
     // postponed finaliser (HgymEnvOut.defer_finalize): the sampling step the NEXT policy launch reads is bumped here -- no policy
@@ -165,7 +180,8 @@ static int pick_envs_per_block(int N) {
 
 static int32_t check_common(const HgymEnvConfig* cfg, const HgymSimTensors* sim, const HgymEnvState* st) {
     HG_REQUIRE(cfg && st, HGYM_E_BADARG, "null cfg/state");
-    HG_REQUIRE(cfg->num_envs > 0, HGYM_E_SHAPE, "num_envs=%d", cfg->num_envs);
+    HG_REQUIRE(cfg->num_envs > 0 && cfg->num_envs <= (1 << 22), HGYM_E_SHAPE, "num_envs=%d (1 .. 4 194 304: the kernels index with 32 bits)",
+               cfg->num_envs);
     HG_REQUIRE(cfg->frame_stack >= 1 && cfg->c_frame_stack >= 1, HGYM_E_SHAPE, "frame_stack/c_frame_stack must be >= 1");
     if (sim) HG_REQUIRE(sim->root.base && sim->dof_pos.base && sim->dof_vel.base && sim->contact.base && sim->rigid.base,
                         HGYM_E_BADARG, "null sim tensor");

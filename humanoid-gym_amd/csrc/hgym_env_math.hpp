@@ -50,10 +50,13 @@ HG_HD void set_body_offsets(EnvArgs& A) {   // full Isaac-Gym-shaped tensors: bo
     A.rigid_comp[3] = A.cfg.knee_bodies[1] * 13;
 }
 
-HG_HD float sget(const HgymStrided& s, int env, int comp) { return s.base[(int64_t)env * s.env_stride + (int64_t)comp * s.comp_stride]; }
-HG_HD void sset(const HgymStrided& s, int env, int comp, float v) { s.base[(int64_t)env * s.env_stride + (int64_t)comp * s.comp_stride] = v; }
+// 32-bit index arithmetic (check_common bounds num_envs so that every product fits): with 64-bit indices the per-env chain, which
+// runs against an LDS image through these accessors, spent a third of its ~4200 instructions on 64-bit address arithmetic
+// (v_mad_u64_u32 / v_lshl_add_u64) for addresses that end up as 32-bit LDS offsets
+HG_HD float sget(const HgymStrided& s, int env, int comp) { return s.base[env * (int)s.env_stride + comp * (int)s.comp_stride]; }
+HG_HD void sset(const HgymStrided& s, int env, int comp, float v) { s.base[env * (int)s.env_stride + comp * (int)s.comp_stride] = v; }
 
-#define FG(p, c) (p)[(int64_t)(c) * N + e]
+#define FG(p, c) (p)[(c) * N + e]
 
 HG_HD void hg_atomic_add(float* p, float v) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -222,20 +225,16 @@ HG_HD void synth_joint(const EnvArgs& A, int e, int N, int j) {
     sset(A.sim.dof_vel, e, j, qd);
 }
 
-// tab: this env's kPhysDraws draws
-HG_HD void synth_rest_env(const EnvArgs& A, const float* tab, int e, int N) {
-    const HgymEnvConfig& c = A.cfg;
-    // every input is read before the first store: the stores below go through the same untyped float pointers, so a read
-    // placed after one of them cannot be moved above it by the compiler and costs its own LDS round trip on this
-    // single-wave chain
-    float d[kPhysDraws];
+// tab: this env's kPhysDraws draws.  Two independent halves (the step kernel runs them on two different wavefronts):
+// the root pose / velocities + the rare base-link hit (draws 0 .. 15), and the feet contact loads + feet / knee rigid-body
+// entries (draws 16 .. 35, gait clock).  Each reads every input before its first store: the stores go through the same untyped
+// float pointers, so a read placed after one of them cannot be moved above it by the compiler and costs its own LDS round trip.
+HG_HD void synth_root_env(const EnvArgs& A, const float* tab, int e, int N) {
+    float d[16];
 #pragma unroll
-    for (int i = 0; i < kPhysDraws; ++i) d[i] = tab[i];
+    for (int i = 0; i < 16; ++i) d[i] = tab[i];
     const float r3 = sget(A.sim.root, e, 3), r4 = sget(A.sim.root, e, 4), r5 = sget(A.sim.root, e, 5);
-    const int64_t ep_next = A.st.episode_length[e] + 1;
-    tab = d;
-    const float* n = tab + 4;
-    const float* m = tab + 20;
+    const float* n = d + 4;
     // root: mean-reverting orientation walk, small height jitter, gaussian velocities
     float qx = 0.9f * r3 + 0.05f * n[0];
     float qy = 0.9f * r4 + 0.05f * n[1];
@@ -245,27 +244,35 @@ HG_HD void synth_rest_env(const EnvArgs& A, const float* tab, int e, int N) {
     sset(A.sim.root, e, 4, qy * inv);
     sset(A.sim.root, e, 5, qz * inv);
     sset(A.sim.root, e, 6, inv);
-    sset(A.sim.root, e, 2, 0.9f + 0.02f * (2.0f * tab[0] - 1.0f));
+    sset(A.sim.root, e, 2, 0.9f + 0.02f * (2.0f * d[0] - 1.0f));
 #pragma unroll
     for (int i = 0; i < 6; ++i) sset(A.sim.root, e, 7 + i, 0.3f * n[3 + i]);
-    // contacts: feet load follows the gait clock, rare base-link hits end episodes (~ every 500 steps)
+    // rare base-link hits end episodes (~ every 500 steps)
+    const float hit = (d[1] < 0.002f) ? 2.0f : 0.0f;
+    sset(A.sim.contact, e, A.contact_comp[0] + 0, hit * n[9]);
+    sset(A.sim.contact, e, A.contact_comp[0] + 1, hit * n[10]);
+    sset(A.sim.contact, e, A.contact_comp[0] + 2, hit * n[11]);
+}
+HG_HD void synth_feet_env(const EnvArgs& A, const float* tab, int e, int N) {
+    const HgymEnvConfig& c = A.cfg;
+    float d[20];
+#pragma unroll
+    for (int i = 0; i < 20; ++i) d[i] = tab[16 + i];
+    const int64_t ep_next = A.st.episode_length[e] + 1;
+    const float* m = d + 4;
+    // contacts: feet load follows the gait clock (all other contact entries stay at their initial zero)
     const float s = sinf(kTwoPi * gait_phase(c, ep_next));
     float stance[2];
     stance_from_sin(s, stance);
-    const float uf[2] = {tab[16], tab[17]};
-    const float ug[2] = {tab[18], tab[19]};
-    // (all other contact entries stay at their initial zero)
+    const float uf[2] = {d[0], d[1]};
+    const float ug[2] = {d[2], d[3]};
 #pragma unroll
     for (int f = 0; f < 2; ++f) {
         const float on = (stance[f] > 0.5f || ug[f] > 0.4f) ? 1.0f : 0.0f;
         sset(A.sim.contact, e, A.contact_comp[1 + f] + 2, 600.0f * uf[f] * on);
     }
-    const float hit = (tab[1] < 0.002f) ? 2.0f : 0.0f;
-    sset(A.sim.contact, e, A.contact_comp[0] + 0, hit * n[9]);
-    sset(A.sim.contact, e, A.contact_comp[0] + 1, hit * n[10]);
-    sset(A.sim.contact, e, A.contact_comp[0] + 2, hit * n[11]);
     // rigid bodies: only the entries the rewards read (feet x,y,z,vx,vy ; knees x,y)
-    const float uz[2] = {tab[32], tab[33]};
+    const float uz[2] = {d[16], d[17]};
 #pragma unroll
     for (int f = 0; f < 2; ++f) {
         const int fb = A.rigid_comp[f], kb = A.rigid_comp[2 + f];
@@ -278,6 +285,10 @@ HG_HD void synth_rest_env(const EnvArgs& A, const float* tab, int e, int N) {
         sset(A.sim.rigid, e, kb + 0, 0.2f * m[f * 6 + 4]);
         sset(A.sim.rigid, e, kb + 1, 0.8f * side + 0.05f * m[f * 6 + 5]);
     }
+}
+HG_HD void synth_rest_env(const EnvArgs& A, const float* tab, int e, int N) {
+    synth_root_env(A, tab, e, N);
+    synth_feet_env(A, tab, e, N);
 }
 
 HG_HD void synth_physics_env(const EnvArgs& A, const RngKey& rk, int e, int N) {
@@ -347,6 +358,27 @@ struct StepFlags {
     int reset;     // env resets this step (history must be zeroed before the push)
 };
 
+// The per-joint products of the reward terms that sum over the 12 joints (humanoid_env.py: 0 action_smoothness :530-540,
+// 4 default_joint_pos :362-372, 5 dof_acc :516-521, 6 dof_vel :509-514, 17 torques :502-507, 13 joint_pos :272-280), joint j:
+// a = this step's action, la / lla = the previous two, ldv = last joint velocity, tq = torque, rdp = reference pose of the
+// previous step.
+HG_HD void joint_terms(const HgymEnvConfig& c, int j, float a, float la, float lla, float ldv, float q, float qd, float tq, float rdp,
+                       float (&o)[8]) {
+    const float d1 = la - a;
+    o[0] = d1 * d1;
+    const float d2 = a + lla - 2.0f * la;
+    o[1] = d2 * d2;
+    o[2] = fabsf(a);
+    const float jd = q - c.default_dof_pos[j];
+    o[3] = jd * jd;
+    const float ac = (ldv - qd) / c.dt;
+    o[4] = ac * ac;
+    o[5] = qd * qd;
+    o[6] = tq * tq;
+    const float d = q - rdp;
+    o[7] = d * d;
+}
+
 // ------------------------------------------------------------------------------------------------ E4-E12
 // LeggedRobot.post_physics_step for ONE env (legged_robot.py:119-151) with XBotLFreeEnv's reward terms
 // (humanoid_env.py:272-540, alphabetical order), mask-driven reset_idx (legged_robot.py:163-215) and the
@@ -354,9 +386,15 @@ struct StepFlags {
 // (LDS on the device); noise, history stacking and clipping happen in the cooperative phase.
 // kGeneric = false compiles the generic LeggedRobot options (terrain map, curricula, height measurements) OUT: the XBot-L
 // default configuration runs the instantiation that has none of their branches on its per-env latency chain.
-template <bool kGeneric>
+// kSplit (the compiled-in fast kernels, MODE_STEP only): everything that is the same few instructions for each of the 12 joints
+// has been taken off this single-wavefront chain and runs one (env, joint) pair per lane around it -- the per-joint products of
+// reward terms 0 / 4 / 5 / 6 / 13 / 17 before it (env_step_joint_terms -> `jpart`, summed here in the reference's order), the
+// per-joint part of the reset, the reference pose, the per-joint frame entries and the last_* write-back after it
+// (env_step_phase_f, which takes this step's reset flag and gait-clock sine from `cscal`).  Same arithmetic, same order.
+constexpr int kJointTerms = 8;     // per-joint products: d1^2, d2^2, |a| (term 0), jd^2 (4), acc^2 (5), qd^2 (6), tq^2 (17), (q - ref)^2 (13)
+template <bool kGeneric, bool kSplit = false>
 HG_HD StepFlags post_physics_env(const EnvArgs& A, const RngKey& rk, int64_t csc, int e, int N, float* frame47,
-                                 float* priv73) {
+                                 float* priv73, const float* jpart = nullptr, float* cscal = nullptr) {
     const HgymEnvConfig& c = A.cfg;
     const HgymEnvState& S = A.st;
     const int mode = A.mode;
@@ -371,13 +409,14 @@ HG_HD StepFlags post_physics_env(const EnvArgs& A, const RngKey& rk, int64_t csc
     float q[12], qd[12];
 #pragma unroll
     for (int j = 0; j < 12; ++j) {
-        q[j] = sget(A.sim.dof_pos, e, j);
-        qd[j] = sget(A.sim.dof_vel, e, j);
+        const bool need = !kSplit || j == 0 || j == 1 || j == 6 || j == 7;     // split: only the four hip joints of term 4
+        q[j] = need ? sget(A.sim.dof_pos, e, j) : 0.0f;
+        qd[j] = kSplit ? 0.0f : sget(A.sim.dof_vel, e, j);
     }
     float cmd[4] = {FG(S.commands, 0), FG(S.commands, 1), FG(S.commands, 2), FG(S.commands, 3)};
     float act[12];
 #pragma unroll
-    for (int j = 0; j < 12; ++j) act[j] = FG(S.actions, j);
+    for (int j = 0; j < 12; ++j) act[j] = kSplit ? 0.0f : FG(S.actions, j);
     float blv[3], bav[3], grav[3], eul[3];
     float fz[2], contact[2];
 #pragma unroll
@@ -395,11 +434,21 @@ HG_HD StepFlags post_physics_env(const EnvArgs& A, const RngKey& rk, int64_t csc
     float fpos[2][3], fvxy[2][2], kxy[2][2], fxyz[2][3];
 #pragma unroll
     for (int j = 0; j < 12; ++j) {
-        la[j] = FG(S.last_actions, j);
-        lla[j] = FG(S.last_last_actions, j);
-        ldv[j] = FG(S.last_dof_vel, j);
-        tqv[j] = FG(S.torques, j);
-        rdp[j] = FG(S.ref_dof_pos, j);
+        la[j] = kSplit ? 0.0f : FG(S.last_actions, j);
+        lla[j] = kSplit ? 0.0f : FG(S.last_last_actions, j);
+        ldv[j] = kSplit ? 0.0f : FG(S.last_dof_vel, j);
+        tqv[j] = kSplit ? 0.0f : FG(S.torques, j);
+        rdp[j] = kSplit ? 0.0f : FG(S.ref_dof_pos, j);
+    }
+    // split: the sums over the joints of the per-joint products, accumulated j = 0 .. 11 like the loops they replace
+    float jsum[kJointTerms];
+#pragma unroll
+    for (int k = 0; k < kJointTerms; ++k) {
+        jsum[k] = 0.0f;
+        if (kSplit) {
+#pragma unroll
+            for (int j = 0; j < 12; ++j) jsum[k] += jpart[(k * 12 + j) * N + e];
+        }
     }
 #pragma unroll
     for (int i = 0; i < 6; ++i) lrv[i] = FG(S.last_root_vel, i);
@@ -497,13 +546,17 @@ HG_HD StepFlags post_physics_env(const EnvArgs& A, const RngKey& rk, int64_t csc
             // 0 action_smoothness :530-540
             {
                 float t1 = 0.0f, t2 = 0.0f, t3 = 0.0f;
+                if (kSplit) {
+                    t1 = jsum[0]; t2 = jsum[1]; t3 = jsum[2];
+                } else {
 #pragma unroll
-                for (int j = 0; j < 12; ++j) {
-                    const float d1 = la[j] - act[j];
-                    t1 += d1 * d1;
-                    const float d2 = act[j] + lla[j] - 2.0f * la[j];
-                    t2 += d2 * d2;
-                    t3 += fabsf(act[j]);
+                    for (int j = 0; j < 12; ++j) {
+                        float jt[kJointTerms];
+                        joint_terms(c, j, act[j], la[j], lla[j], ldv[j], q[j], qd[j], tqv[j], rdp[j], jt);
+                        t1 += jt[0];
+                        t2 += jt[1];
+                        t3 += jt[2];
+                    }
                 }
                 term[0] = t1 + t2 + 0.05f * t3;
             }
@@ -531,8 +584,9 @@ HG_HD StepFlags post_physics_env(const EnvArgs& A, const RngKey& rk, int64_t csc
 #pragma unroll
                 for (int j = 0; j < 12; ++j) {
                     jd[j] = q[j] - c.default_dof_pos[j];
-                    all2 += jd[j] * jd[j];
+                    if (!kSplit) all2 += jd[j] * jd[j];
                 }
+                if (kSplit) all2 = jsum[3];
                 float yr = r_sqrt(jd[0] * jd[0] + jd[1] * jd[1]) + r_sqrt(jd[6] * jd[6] + jd[7] * jd[7]);
                 yr = clampf(yr - 0.1f, 0.0f, 50.0f);
                 term[4] = r_exp(-yr * 100.0f) - 0.01f * r_sqrt(all2);
@@ -540,13 +594,17 @@ HG_HD StepFlags post_physics_env(const EnvArgs& A, const RngKey& rk, int64_t csc
             // 5 dof_acc :516-521 ; 6 dof_vel :509-514 ; 17 torques :502-507
             {
                 float acc = 0.0f, vel = 0.0f, tq = 0.0f;
+                if (kSplit) {
+                    acc = jsum[4]; vel = jsum[5]; tq = jsum[6];
+                } else {
 #pragma unroll
-                for (int j = 0; j < 12; ++j) {
-                    const float a = (ldv[j] - qd[j]) / c.dt;
-                    acc += a * a;
-                    vel += qd[j] * qd[j];
-                    const float t = tqv[j];
-                    tq += t * t;
+                    for (int j = 0; j < 12; ++j) {
+                        const float a = (ldv[j] - qd[j]) / c.dt;
+                        acc += a * a;
+                        vel += qd[j] * qd[j];
+                        const float t = tqv[j];
+                        tq += t * t;
+                    }
                 }
                 term[5] = acc;
                 term[6] = vel;
@@ -596,10 +654,14 @@ HG_HD StepFlags post_physics_env(const EnvArgs& A, const RngKey& rk, int64_t csc
             // 13 joint_pos :272-280 -- the PREVIOUS step's reference pose
             {
                 float e2 = 0.0f;
+                if (kSplit) {
+                    e2 = jsum[7];
+                } else {
 #pragma unroll
-                for (int j = 0; j < 12; ++j) {
-                    const float d = q[j] - rdp[j];
-                    e2 += d * d;
+                    for (int j = 0; j < 12; ++j) {
+                        const float d = q[j] - rdp[j];
+                        e2 += d * d;
+                    }
                 }
                 const float en = r_sqrt(e2);
                 term[13] = r_exp(-2.0f * en) - 0.2f * clampf(en, 0.0f, 0.5f);
@@ -669,6 +731,7 @@ HG_HD StepFlags post_physics_env(const EnvArgs& A, const RngKey& rk, int64_t csc
         fl.reset = 1;
 #pragma unroll
         for (int j = 0; j < 12; ++j) {
+            if (kSplit) break;        // env_step_phase_f, one (env, joint) pair per lane
             q[j] = c.default_dof_pos[j] + (c.dof_reset_span * nz_uniform(A.noise.u_dof, 12, j, rk, e, ge, SLOT_DOF, j) + c.dof_reset_lo);
             qd[j] = 0.0f;
             sset(A.sim.dof_pos, e, j, q[j]);
@@ -755,12 +818,16 @@ HG_HD StepFlags post_physics_env(const EnvArgs& A, const RngKey& rk, int64_t csc
             for (int j = 0; j < 12; ++j) ref[j] = 0.0f;
         }
 #pragma unroll
-        for (int j = 0; j < 12; ++j) FG(S.ref_dof_pos, j) = ref[j];
+        for (int j = 0; j < 12; ++j) {
+            if (!kSplit) FG(S.ref_dof_pos, j) = ref[j];
+        }
+        if (kSplit) cscal[e] = s;     // the gait-clock sine the per-joint lanes rebuild the reference pose from
         float ci[5] = {s, co, cmd[0] * c.scale_lin_vel, cmd[1] * c.scale_lin_vel, cmd[2] * c.scale_ang_vel};
 #pragma unroll
         for (int i = 0; i < 5; ++i) { frame47[i] = ci[i]; priv73[i] = ci[i]; }
 #pragma unroll
         for (int j = 0; j < 12; ++j) {
+            if (kSplit) break;
             const float qq = (q[j] - c.default_dof_pos[j]) * c.scale_dof_pos;
             const float dq = qd[j] * c.scale_dof_vel;
             frame47[5 + j] = qq;   priv73[5 + j] = qq;
@@ -801,6 +868,7 @@ HG_HD StepFlags post_physics_env(const EnvArgs& A, const RngKey& rk, int64_t csc
     if (mode == MODE_STEP) {
 #pragma unroll
         for (int j = 0; j < 12; ++j) {
+            if (kSplit) break;
             FG(S.last_last_actions, j) = reset ? 0.0f : la[j];
             FG(S.last_actions, j) = act[j];
             FG(S.last_dof_vel, j) = qd[j];
@@ -872,7 +940,7 @@ HG_HD float* state_comp_row(const EnvArgs& A, int comp, int N) {
 // LDS carve (float offsets) for a block of E envs
 struct LdsMap {
     int state, root, dof_pos, dof_vel, contact, rigid, actions_in, u_delay, z_act, u_cmd, u_dof, u_push, z_obs, phys, frame, priv, rew,
-        noise_vec, ep_len, flags, reset_i, total;
+        noise_vec, ep_len, flags, reset_i, jpart, cscal, total;
 };
 HG_HD LdsMap lds_map(int E) {
     LdsMap m;
@@ -899,6 +967,8 @@ HG_HD LdsMap lds_map(int E) {
     m.ep_len = o;     o += 2 * E;          // int64[E]
     m.flags = o;      o += (2 * E + 3) / 4;  // uint8 reset[E], time_out[E]
     m.reset_i = o;    o += E;              // int[E]: "history must be cleared" flags for the stacking phase
+    m.jpart = o;      o += kJointTerms * 12 * E;   // [8][12][E] per-joint reward products (split per-env chain)
+    m.cscal = o;      o += E;              // [E] gait-clock sine of the new observation (split per-env chain -> per-joint lanes)
     m.total = o;
     return m;
 }
@@ -1230,7 +1300,108 @@ HG_HD void env_step_joints(const EnvArgs& A, int block, int t, int nthreads, flo
     }
 }
 
-template <int E_T, bool kGeneric>
+// ---- the split per-env chain (post_physics_env<.., kSplit = true>), MODE_STEP only ---------------------------------------
+constexpr int kStateOffLastActions = 4 + 12;
+constexpr int kStateOffLastLastActions = 4 + 12 * 2;
+constexpr int kStateOffLastDofVel = 4 + 12 * 3;
+
+// the per-joint reward products, one (env, joint) pair per lane, same item mapping as env_step_joints (a lane reads what it has
+// just written there: no barrier in between): jpart[(k * 12 + j) * E + le]
+template <int E_T>
+HG_HD void env_step_joint_terms(const EnvArgs& A, int block, int t, int nthreads, float* smem) {
+    const int E = E_T > 0 ? E_T : A.envs_per_block;
+    const int N = A.cfg.num_envs, e0 = block * E;
+    const int nE = (E < N - e0) ? E : (N - e0);
+    const LdsMap m = lds_map(E);
+    const float* st = smem + m.state;
+    for (int i = t; i < 12 * E; i += nthreads) {
+        const int j = i / E, le = i - j * E;
+        if (le >= nE) continue;
+        float jt[kJointTerms];
+        joint_terms(A.cfg, j, st[(kStateOffActions + j) * E + le], st[(kStateOffLastActions + j) * E + le],
+                    st[(kStateOffLastLastActions + j) * E + le], st[(kStateOffLastDofVel + j) * E + le], smem[m.dof_pos + j * E + le],
+                    smem[m.dof_vel + j * E + le], st[(kStateOffTorques + j) * E + le], st[(kStateOffRefPos + j) * E + le], jt);
+#pragma unroll
+        for (int k = 0; k < kJointTerms; ++k) smem[m.jpart + (k * 12 + j) * E + le] = jt[k];
+    }
+}
+
+// everything between the draws and the per-env chain: action filter + joint integration (fused backend), the per-joint reward
+// products, and -- on the last two wavefronts, next to the joint lanes -- the two halves of the synthetic physics' per-env
+// remainder (with a single wavefront, as in the host emulation, they simply follow)
+template <int E_T>
+HG_HD void env_step_phase_j(const EnvArgs& A, int block, int t, int nthreads, float* smem) {
+    const int E = E_T > 0 ? E_T : A.envs_per_block;
+    const int N = A.cfg.num_envs, e0 = block * E;
+    const int nE = (E < N - e0) ? E : (N - e0);
+    if (!(A.ablate & 128)) env_step_joints<E_T>(A, block, t, nthreads, smem);
+    env_step_joint_terms<E_T>(A, block, t, nthreads, smem);
+    if (A.mode == MODE_STEP && A.fused && !(A.ablate & 16)) {
+        const LdsMap m = lds_map(E);
+        const int nw = nthreads >= 64 ? nthreads / 64 : 1;
+        const int w_root = nw - 1, w_feet = nw >= 2 ? nw - 2 : nw - 1;
+        const int lr = t - 64 * w_root, lf = t - 64 * w_feet;
+        if ((lr >= 0 && lr < nE) || (lf >= 0 && lf < nE)) {
+            const EnvArgs S = make_shadow(A, smem, block, E);
+            if (lr >= 0 && lr < nE) synth_root_env(S, smem + m.phys + lr * kPhysDraws, lr, E);
+            if (lf >= 0 && lf < nE) synth_feet_env(S, smem + m.phys + lf * kPhysDraws, lf, E);
+        }
+    }
+}
+
+// after the per-env chain, one (env, joint) pair per lane: the per-joint part of reset_idx (legged_robot.py:358-371 + the last_*
+// buffers, :189-195), the reference pose (humanoid_env.py:100-118), the per-joint entries of the two clean observation frames
+// (:200-244) and the tail copies of post_physics_step (legged_robot.py:147-151)
+template <int E_T>
+HG_HD void env_step_phase_f(const EnvArgs& A, int block, int t, int nthreads, float* smem) {
+    const int E = E_T > 0 ? E_T : A.envs_per_block;
+    const int N = A.cfg.num_envs, e0 = block * E;
+    const int nE = (E < N - e0) ? E : (N - e0);
+    const LdsMap m = lds_map(E);
+    const HgymEnvConfig& c = A.cfg;
+    float* st = smem + m.state;
+    const int* s_reset = reinterpret_cast<const int*>(smem + m.reset_i);
+    for (int i = t; i < 12 * E; i += nthreads) {
+        const int j = i / E, le = i - j * E;
+        if (le >= nE) continue;
+        const int reset = s_reset[le];
+        const float s = smem[m.cscal + le];
+        float q = smem[m.dof_pos + j * E + le], qd = smem[m.dof_vel + j * E + le];
+        float act = st[(kStateOffActions + j) * E + le];
+        const float la = st[(kStateOffLastActions + j) * E + le];
+        const float dflt = c.default_dof_pos[j];
+        if (reset) {
+            q = dflt + (c.dof_reset_span * smem[m.u_dof + le * 12 + j] + c.dof_reset_lo);
+            qd = 0.0f;
+            act = 0.0f;
+            smem[m.dof_pos + j * E + le] = q;
+            smem[m.dof_vel + j * E + le] = 0.0f;
+        }
+        const float sl = (s > 0.0f) ? 0.0f : s, sr = (s < 0.0f) ? 0.0f : s;
+        const float s1 = c.target_joint_pos_scale, s2 = 2.0f * c.target_joint_pos_scale;
+        float ref = 0.0f;
+        if (j == 2 || j == 4) ref = sl * s1;
+        if (j == 3) ref = sl * s2;
+        if (j == 8 || j == 10) ref = sr * s1;
+        if (j == 9) ref = sr * s2;
+        if (fabsf(s) < 0.1f) ref = 0.0f;
+        st[(kStateOffRefPos + j) * E + le] = ref;
+        float* f47 = smem + m.frame + le * HGYM_OBS_FRAME;
+        float* p73 = smem + m.priv + le * HGYM_PRIV_FRAME;
+        const float qq = (q - dflt) * c.scale_dof_pos;
+        const float dq = qd * c.scale_dof_vel;
+        f47[5 + j] = qq;   p73[5 + j] = qq;
+        f47[17 + j] = dq;  p73[17 + j] = dq;
+        f47[29 + j] = act; p73[29 + j] = act;
+        p73[41 + j] = q - ref;
+        st[(kStateOffLastLastActions + j) * E + le] = reset ? 0.0f : la;
+        st[(kStateOffLastActions + j) * E + le] = act;
+        st[(kStateOffLastDofVel + j) * E + le] = qd;
+        st[(kStateOffActions + j) * E + le] = act;
+    }
+}
+
+template <int E_T, bool kGeneric, bool kSplit = false>
 HG_HD void env_step_phase_a(const EnvArgs& A, int block, int t, float* smem, int64_t csc0) {
     const int E = E_T > 0 ? E_T : A.envs_per_block;
     const int N = A.cfg.num_envs, e0 = block * E;
@@ -1239,11 +1410,12 @@ HG_HD void env_step_phase_a(const EnvArgs& A, int block, int t, float* smem, int
     const LdsMap m = lds_map(E);
     const EnvArgs S = make_shadow(A, smem, block, E);
     const RngKey rk = make_rng_key(A, csc0);
-    if (A.mode == MODE_STEP && A.fused && !(A.ablate & 16)) synth_rest_env(S, smem + m.phys + t * kPhysDraws, t, E);
+    if (!kSplit && A.mode == MODE_STEP && A.fused && !(A.ablate & 16)) synth_rest_env(S, smem + m.phys + t * kPhysDraws, t, E);
     StepFlags fl;
     fl.reset = 0;
     if (!(A.ablate & 32))
-        fl = post_physics_env<kGeneric>(S, rk, csc0 + 1, t, E, smem + m.frame + t * HGYM_OBS_FRAME, smem + m.priv + t * HGYM_PRIV_FRAME);
+        fl = post_physics_env<kGeneric, kSplit>(S, rk, csc0 + 1, t, E, smem + m.frame + t * HGYM_OBS_FRAME, smem + m.priv + t * HGYM_PRIV_FRAME,
+                                                smem + m.jpart, smem + m.cscal);
     reinterpret_cast<int*>(smem + m.reset_i)[t] = fl.reset;
 }
 

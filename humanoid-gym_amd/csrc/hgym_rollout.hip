@@ -34,6 +34,9 @@
 #include "hgym_env_math.hpp"
 #include "hgym_fused.hpp"
 
+#ifndef HGYM_ENV_SPLIT
+#define HGYM_ENV_SPLIT 1       // the split per-env chain (hgym_env_math.hpp: env_step_phase_j / _a<split> / _f); 0: the monolithic one
+#endif
 #ifndef HGYM_RO_DRAWS_IDLE
 #define HGYM_RO_DRAWS_IDLE 1
 #endif
@@ -148,13 +151,24 @@ __global__ __launch_bounds__(RO_NT) void rollout_step_kernel(const FwdArgs f, co
     hist_load<3, HGYM_PRIV_FRAME, RO_NIP>(A.st.priv_ring, block * RO_E, RO_E, (int)(ring_step % 3), t, RO_NT, hist_p);
     hist_store<15, HGYM_OBS_FRAME, RO_NIO>(A.out.obs, block * RO_E, RO_E, (int)(ring_step % 15), t, RO_NT, nullptr, A.cfg.clip_obs, hist_o);
     stamp(1);
+#if HGYM_ENV_SPLIT
+    env_step_phase_j<RO_E>(A, block, t, RO_NT, esm);       // joints + per-joint reward products; synthetic-physics remainder on waves 6, 7
+#else
     env_step_joints<RO_E>(A, block, t, RO_NT, esm);
+#endif
     hist_store<3, HGYM_PRIV_FRAME, RO_NIP>(A.out.priv_obs, block * RO_E, RO_E, (int)(ring_step % 3), t, RO_NT, nullptr, A.cfg.clip_obs,
                                            hist_p);
     __syncthreads();
     stamp(2);
+#if HGYM_ENV_SPLIT
+    if (t < 64) env_step_phase_a<RO_E, false, true>(A, block, t, esm, csc0);
+    __syncthreads();
+    env_step_phase_f<RO_E>(A, block, t, RO_NT, esm);       // per-joint reset / reference pose / frame entries / last_* copies
+    __syncthreads();
+#else
     if (t < 64) env_step_phase_a<RO_E, false>(A, block, t, esm, csc0);
     __syncthreads();
+#endif
     stamp(3);
     env_stage_out<RO_E>(A, block, t, RO_NT, esm);
     stamp(4);

@@ -85,16 +85,18 @@ class HostBackend:
     name = "host"
     device = "cpu"
 
-    def __init__(self, envs_per_block=8, nthreads=64):
+    def __init__(self, envs_per_block=8, nthreads=64, split=False):
+        """split: the phase sequence of the XBot-L fast kernels (per-joint work on (env, joint) lanes around a shorter per-env
+        chain: env_step_phase_j / _a<split> / _f) instead of the monolithic per-env chain; default options only."""
         sys.path.insert(0, os.path.join(ROOT, "tests", "hostcheck"))
         import build_hostcheck
         self.lib = C.CDLL(build_hostcheck.build())
-        self.epb, self.nthreads = envs_per_block, nthreads
+        self.epb, self.nthreads, self.split = envs_per_block, nthreads, int(bool(split))
 
     def step_call(self, mode, cfg, sim, st, out, noise):
         m = {"post": 0, "prime": 1, "reset_all": 2}[mode]
-        self.lib.hc_env_step(C.byref(cfg), C.byref(sim), C.byref(st), C.byref(out), C.byref(noise), None, m, 0,
-                             self.epb, self.nthreads)
+        self.lib.hc_env_step_ex(C.byref(cfg), C.byref(sim), C.byref(st), C.byref(out), C.byref(noise), None, m, 0,
+                                self.epb, self.nthreads, self.split)
 
     def pre_physics(self, cfg, st, actions, noise):
         self.lib.hc_pre_physics(C.byref(cfg), C.byref(st), C.cast(actions.data_ptr(), C.POINTER(C.c_float)), C.byref(noise))

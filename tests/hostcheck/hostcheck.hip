@@ -36,8 +36,16 @@ static EnvArgs make_args(const HgymEnvConfig* cfg, const HgymSimTensors* sim, co
 
 extern "C" {
 
+// split != 0: the phase sequence of the XBot-L fast kernels (per-joint work on (env, joint) lanes around a shorter per-env chain;
+// env_step_kernel<15, 3, 16, false> and rollout_step_kernel), plain steps of the default options only
+int hc_env_step_ex(const HgymEnvConfig* cfg, const HgymSimTensors* sim, const HgymEnvState* st, const HgymEnvOut* out,
+                   const HgymEnvNoise* noise, float* actions_in, int mode, int fused, int epb, int nthreads, int split);
 int hc_env_step(const HgymEnvConfig* cfg, const HgymSimTensors* sim, const HgymEnvState* st, const HgymEnvOut* out,
                 const HgymEnvNoise* noise, float* actions_in, int mode, int fused, int epb, int nthreads) {
+    return hc_env_step_ex(cfg, sim, st, out, noise, actions_in, mode, fused, epb, nthreads, 0);
+}
+int hc_env_step_ex(const HgymEnvConfig* cfg, const HgymSimTensors* sim, const HgymEnvState* st, const HgymEnvOut* out,
+                   const HgymEnvNoise* noise, float* actions_in, int mode, int fused, int epb, int nthreads, int split) {
     const EnvArgs A = make_args(cfg, sim, st, out, noise, actions_in, mode, fused, epb);
     const int N = cfg->num_envs;
     const int blocks = (N + epb - 1) / epb;
@@ -46,8 +54,17 @@ int hc_env_step(const HgymEnvConfig* cfg, const HgymSimTensors* sim, const HgymE
     for (int b = 0; b < blocks; ++b) {
         for (int t = 0; t < nthreads; ++t) env_stage_in<0>(A, b, t, nthreads, smem.data());
         for (int t = 0; t < nthreads; ++t) env_fill_draws<0>(A, b, t, nthreads, smem.data(), csc0);
-        for (int t = 0; t < nthreads; ++t) env_step_joints<0>(A, b, t, nthreads, smem.data());
-        for (int t = 0; t < nthreads; ++t) env_step_phase_a<0, true>(A, b, t, smem.data(), csc0);
+        const bool generic = cfg->custom_origins || cfg->terrain_curriculum || cfg->num_height_points > 0 || cfg->command_curriculum ||
+                             !cfg->heading_command;
+        const bool sp = split && mode == MODE_STEP && !generic;       // as launch_step picks the instantiation
+        if (sp) {
+            for (int t = 0; t < nthreads; ++t) env_step_phase_j<0>(A, b, t, nthreads, smem.data());
+            for (int t = 0; t < nthreads; ++t) env_step_phase_a<0, false, true>(A, b, t, smem.data(), csc0);
+            for (int t = 0; t < nthreads; ++t) env_step_phase_f<0>(A, b, t, nthreads, smem.data());
+        } else {
+            for (int t = 0; t < nthreads; ++t) env_step_joints<0>(A, b, t, nthreads, smem.data());
+            for (int t = 0; t < nthreads; ++t) env_step_phase_a<0, true>(A, b, t, smem.data(), csc0);
+        }
         for (int t = 0; t < nthreads; ++t) {   // the device runs this on its idle wavefronts, concurrently with phase A
             if (cfg->frame_stack == 15 && cfg->c_frame_stack == 3) env_step_stack_old<15, 3, 0>(A, b, t, nthreads, ring);
             else env_step_stack_old<0, 0, 0>(A, b, t, nthreads, ring);

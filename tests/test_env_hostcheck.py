@@ -12,9 +12,11 @@ import env_common as EC
 T = lambda a: torch.from_numpy(np.asarray(a))
 
 
-@pytest.fixture(scope="module")
-def host():
-    return EC.HostBackend(envs_per_block=8, nthreads=64)
+@pytest.fixture(scope="module", params=["chain", "split"])
+def host(request):
+    """chain: the monolithic per-env chain; split: the phase sequence of the XBot-L fast kernels (per-joint work on (env, joint)
+    lanes before and after a shorter chain).  Traces with generic options fall back to the chain inside the kernel source."""
+    return EC.HostBackend(envs_per_block=8, nthreads=64, split=request.param == "split")
 
 
 @pytest.mark.parametrize("name", ["env_trace.npz", "env_trace_refact.npz", "env_trace_yawrate.npz"])
@@ -63,9 +65,10 @@ def test_generic_options_golden_trace_host(host, golden_dir):
     EC.run_generic_golden(host, golden_dir)
 
 
+@pytest.mark.parametrize("split", [False, True])
 @pytest.mark.parametrize("N,layout,epb,nthreads", [(37, "soa", 8, 64), (64, "aos", 16, 256), (5, "soa", 4, 32)])
-def test_random_trace_host(N, layout, epb, nthreads):
-    be = EC.HostBackend(envs_per_block=epb, nthreads=nthreads)
+def test_random_trace_host(N, layout, epb, nthreads, split):
+    be = EC.HostBackend(envs_per_block=epb, nthreads=nthreads, split=split)
     counts, env, o = EC.run_random_trace(be, N, steps=24, seed=100 + N, sim_layout=layout)
     assert counts["push"] == 1 and counts["timeout"] >= 1 and counts["reset"] >= 3
 
