@@ -95,12 +95,7 @@ __global__ __launch_bounds__(256) void env_step_kernel(const EnvArgs A) {
     if (A.out.defer_finalize && blockIdx.x == 0 && t == 0 && A.out.t_rewards && A.out.t_step) A.out.t_step[0] += 1;
 }
 
-__global__ __launch_bounds__(1024) void env_finalize_kernel(const EnvArgs A) {
-    env_finalize_part1(A, threadIdx.x, blockDim.x);
-    __syncthreads();
-    env_finalize_store(A, threadIdx.x, blockDim.x);
-    if (threadIdx.x == 0) env_finalize_part2(A);
-}
+__global__ __launch_bounds__(1024) void env_finalize_kernel(const EnvArgs A) { fin_block(fin_of(A), threadIdx.x, blockDim.x); }
 
 // generic options; neither kernel is launched in the XBot-L default configuration
 __global__ __launch_bounds__(256) void measure_heights_kernel(const EnvArgs A) {

@@ -70,11 +70,71 @@ HG_HD void fin_part2(const FinArgs& F) {
     if (F.mode != FIN_MODE_RESET_ALL) F.counters[2] += 1;
 }
 
+// Optional logging sink (HgymEnvOut::log_*): OnPolicyRunner.learn's per-step book-keeping (on_policy_runner.py:143-156).
+// Thread t refreshed extras_episode[t] in part 1, so it may add it up here without a barrier.  Finished episodes are appended to
+// the two 100-entry rings in env order (the reference extends its deques with cur_reward_sum[new_ids], ascending ids): envs are
+// walked in rows of `nthreads`, a workgroup-wide exclusive scan of the done flags gives each its place.
+__device__ __forceinline__ void fin_log(const FinArgs& F, int t, int nthreads) {
+    float* LS = F.out.log_stats;
+    if (!LS) return;
+    float* cur = F.out.log_cur;
+    __shared__ int s_wave[32];
+    __shared__ int s_head;
+    if (t < HGYM_NUM_REWARDS) LS[t] += F.out.extras_episode[t];
+    if (t == 0) {
+        LS[22] += 1.0f;
+        s_head = (int)LS[24];
+    }
+    const int lane = t & 63, wave = t >> 6, nw = (nthreads + 63) >> 6;
+    int appended = 0;                    // finished episodes of the rows walked so far (uniform)
+    for (int row0 = 0; row0 < F.N; row0 += nthreads) {
+        const int i = row0 + t;
+        const bool in = i < F.N;
+        const bool done = in && F.out.reset[i] != 0;
+        float r = 0.0f, l = 0.0f;
+        if (in) {
+            r = cur[i] + F.out.rew[i];
+            l = cur[F.N + i] + 1.0f;
+        }
+        const unsigned long long b = __ballot(done);
+        const int before = __popcll(b & ((1ull << lane) - 1ull));
+        if (lane == 0) s_wave[wave] = __popcll(b);
+        __syncthreads();
+        int off = before, total = 0;
+        for (int w = 0; w < nw; ++w) {
+            const int c = s_wave[w];
+            if (w < wave) off += c;
+            total += c;
+        }
+        if (done) {
+            if (off >= total - 100) {    // more than 100 in one row: only the last 100 can survive (and keep their slots distinct)
+                const int pos = (s_head + appended + off) % 100;
+                LS[32 + pos] = r;
+                LS[132 + pos] = l;
+            }
+            r = 0.0f;
+            l = 0.0f;
+        }
+        if (in) {
+            cur[i] = r;
+            cur[F.N + i] = l;
+        }
+        appended += total;
+        __syncthreads();
+    }
+    if (t == 0) {
+        LS[24] = (float)((s_head + appended) % 100);
+        const float filled = LS[25] + (float)appended;
+        LS[25] = filled > 100.0f ? 100.0f : filled;
+    }
+}
+
 // all of it, for one workgroup of `nthreads` lanes
 __device__ __forceinline__ void fin_block(const FinArgs& F, int t, int nthreads) {
     fin_part1(F, t, nthreads);
     __syncthreads();
     fin_store(F, t, nthreads);
+    fin_log(F, t, nthreads);
     if (t == 0) fin_part2(F);
 }
 

@@ -86,7 +86,7 @@ class EnvOut(C.Structure):
     _fields_ = [("obs", c_float_p), ("priv_obs", c_float_p), ("rew", c_float_p), ("reset", c_u8_p), ("time_out", c_u8_p),
                 ("extras_time_outs", c_u8_p), ("extras_episode", c_float_p),
                 ("t_values", c_float_p), ("t_rewards", c_float_p), ("t_dones", c_u8_p), ("t_step", c_i64_p),
-                ("t_gamma", C.c_float), ("defer_finalize", C.c_int32)]
+                ("t_gamma", C.c_float), ("defer_finalize", C.c_int32), ("log_cur", c_float_p), ("log_stats", c_float_p)]
 
 
 class EnvNoise(C.Structure):
@@ -170,6 +170,7 @@ SYMBOLS = {
 }
 PROF_GEMM, PROF_ENV_STEP, PROF_GAE, PROF_LOSS, PROF_MLP_FWD, PROF_MLP_BWD, PROF_DW, PROF_REDUCE, PROF_APPLY, PROF_POLICY, PROF_ROLLOUT = range(11)
 ROLLOUT_SCRATCH_BYTES = 512
+LOG_STATS = 256
 
 
 def prof_summary(cls):

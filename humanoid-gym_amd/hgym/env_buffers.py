@@ -68,6 +68,10 @@ class EnvBuffers:
         # second rew / reset / time_out set for the alternate steps, and the library's scratch block (zero-filled once)
         self.rew_alt, self.reset_alt, self.time_out_alt = z(N), torch.zeros(N, dtype=torch.bool, device=dev), z(N, dtype=torch.bool)
         self.rollout_scratch = torch.zeros(L.ROLLOUT_SCRATCH_BYTES, dtype=torch.uint8, device=dev)
+        # logging sink of the step finaliser (HgymEnvOut.log_*): per-env running episode return / length, and the statistics block
+        self.log_cur = z(2, N)
+        self.log_stats = z(L.LOG_STATS)
+        self.log_sink = False
         # sim tensors
         self.sim_layout = sim_layout
         if sim_layout == "soa":
@@ -215,6 +219,8 @@ class EnvBuffers:
             o.t_values, o.t_rewards = L.fptr(sink["values"]), L.fptr(sink["rewards"])
             o.t_dones, o.t_step, o.t_gamma = L.u8ptr(sink["dones"]), L.i64ptr(sink.get("step")), float(sink["gamma"])
         o.defer_finalize = 1 if defer_finalize else 0
+        if self.log_sink:
+            o.log_cur, o.log_stats = L.fptr(self.log_cur), L.fptr(self.log_stats)
         return o
 
     @staticmethod

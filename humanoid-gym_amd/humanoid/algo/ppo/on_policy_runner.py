@@ -106,9 +106,15 @@ class OnPolicyRunner:
 
         if sink_ok:
             alg.env_stores_transitions = True
-        # ... and, when nothing on the host looks at the per-step extras (no logging), the finaliser of vec-step t is not
+        # With logging the reference reads rewards / dones / infos on the host after every vec-step (:143-156).  Here the step
+        # finaliser keeps that book-keeping on the device (LeggedRobot.bind_log_sink: running episode returns / lengths, the
+        # last-100-episodes rings, the per-step sums of extras["episode"]) and the host reads it once per iteration.
+        log_sink = bool(log_on and sink_ok and hasattr(env, "bind_log_sink") and os.environ.get("HGYM_LOG_SINK", "1") != "0"
+                        and env.bind_log_sink(True))
+        host_log = log_on and not log_sink
+        # ... and, when nothing on the host looks at the per-step extras, the finaliser of vec-step t is not
         # launched by the env at all: it rides as one extra workgroup of the policy launch of step t+1 (2 launches per vec-step)
-        defer_ok = (sink_ok and not log_on and hasattr(env, "take_pending_finalize") and isinstance(alg, PPO)
+        defer_ok = (sink_ok and not host_log and hasattr(env, "take_pending_finalize") and isinstance(alg, PPO)
                     and os.environ.get("HGYM_DEFER_FIN", "1") != "0")
 
         # ... and with the synthetic-physics backend the whole loop body -- act, env.step, process_env_step -- is ONE launch per
@@ -136,7 +142,7 @@ class OnPolicyRunner:
                     fin = env.take_pending_finalize()
                 critic_obs = privileged_obs if privileged_obs is not None else obs
                 alg.process_env_step(rewards, dones, infos, **({"stored": True} if sink_ok else {}))
-                if log_on:
+                if host_log:
                     if "episode" in infos:
                         ep_infos.append({k: v.clone() for k, v in infos["episode"].items()})
                     cur_reward_sum.add_(rewards)
@@ -161,7 +167,7 @@ class OnPolicyRunner:
         # the captured launches hold HgymEnvConfig and the sink's gamma BY VALUE: a change between learn() calls (reward scales,
         # command ranges, push / noise settings written into the env's native config, alg.gamma -- what a curriculum script does)
         # must re-capture, as the eager reference would simply see it
-        gkey = (id(env), id(alg.storage), log_on, sink_ok, defer_ok, fuse_ok, getattr(alg, "gamma", None),
+        gkey = (id(env), id(alg.storage), log_on, log_sink, sink_ok, defer_ok, fuse_ok, getattr(alg, "gamma", None),
                 env.native_config_digest() if hasattr(env, "native_config_digest") else None)
         tot_iter = self.current_learning_iteration + num_learning_iterations
         for it in range(self.current_learning_iteration, tot_iter):
@@ -213,11 +219,18 @@ class OnPolicyRunner:
             else:
                 self.last_collection_time, self.last_learn_time = collection_time, learn_time
             if self.log_dir is not None:
-                s = done_stats.cpu()
-                if float(s[2]) > 0:
-                    rewbuffer.append(float(s[0] / s[2]))
-                    lenbuffer.append(float(s[1] / s[2]))
-                done_stats.zero_()
+                if log_sink:
+                    # one read-back: mean over this iteration's steps of extras["episode"] (what the reference's ep_infos list
+                    # averages to), and the rings that ARE the reference's rewbuffer / lenbuffer (the last 100 finished episodes)
+                    ep_mean, ring_r, ring_l = env.log_sink_read()
+                    ep_infos = [ep_mean]
+                    rewbuffer, lenbuffer = deque(ring_r, maxlen=100), deque(ring_l, maxlen=100)
+                else:
+                    s = done_stats.cpu()
+                    if float(s[2]) > 0:
+                        rewbuffer.append(float(s[0] / s[2]))
+                        lenbuffer.append(float(s[1] / s[2]))
+                    done_stats.zero_()
                 self.log(locals())
                 if it % self.save_interval == 0:
                     self.save(os.path.join(self.log_dir, "model_{}.pt".format(it)))
@@ -232,6 +245,8 @@ class OnPolicyRunner:
         if sink_ok:
             env.bind_transition(None)
             alg.env_stores_transitions = False
+        if log_sink:
+            env.bind_log_sink(False)
         self.current_learning_iteration += num_learning_iterations
         if self.log_dir is not None:
             self.save(os.path.join(self.log_dir, "model_{}.pt".format(self.current_learning_iteration)))

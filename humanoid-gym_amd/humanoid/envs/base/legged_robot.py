@@ -347,6 +347,27 @@ class LeggedRobot(BaseTask):
         self._sink = sink
         self._defer = bool(defer_finalize) and sink is not None
 
+    def bind_log_sink(self, on):
+        """Native extension: while on, the step finaliser keeps the runner's per-step logging book-keeping on the device
+        (HgymEnvOut.log_*: running episode return / length per env, the last-100-episodes rings, the per-step sums of
+        extras["episode"]); read with log_sink_read().  Only the kernel's own reward terms are covered."""
+        on = bool(on) and set(self.extras.get("episode", {})) == {"rew_" + n for n in self.reward_names}
+        self._buf.log_sink = on
+        if on:
+            self._buf.log_cur.zero_()
+            self._buf.log_stats.zero_()
+        return on
+
+    def log_sink_read(self):
+        """(episode means dict, returns of the last <= 100 finished episodes, their lengths) since the last call; one device
+        read-back.  The per-step sums are cleared, the rings persist (they are the runner's rewbuffer / lenbuffer)."""
+        ls = self._buf.log_stats.cpu()
+        steps = max(float(ls[22]), 1.0)
+        ep = {"rew_" + n: float(ls[KERNEL_REWARD_TERMS.index(n)]) / steps for n in self.reward_names}
+        k = int(ls[25])
+        self._buf.log_stats[:23].zero_()
+        return ep, ls[32:32 + k].tolist(), ls[132:132 + k].tolist()
+
     def take_pending_finalize(self):
         p, self._pending_fin = getattr(self, "_pending_fin", None), None
         return p

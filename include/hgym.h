@@ -200,7 +200,20 @@ typedef struct HgymEnvOut {
      * then bumped by the env kernel itself.  Until the finaliser has run, the extras_* outputs, the transition-sink slots
      * and the step counters are those of the previous step. */
     int32_t defer_finalize;
+    /* Optional logging sink (log_stats == NULL: off): the step finaliser also keeps OnPolicyRunner.learn's per-step book-keeping
+     * (algo/ppo/on_policy_runner.py:143-156) on the device, so that a logging run needs no host work between vec-steps:
+     *   log_cur   (2, N) fp32   cur_reward_sum | cur_episode_length of every env (+= rew, += 1; zeroed when the env is done)
+     *   log_stats HGYM_LOG_STATS floats:
+     *     [0, 22)    sum over the steps since the caller last cleared it of extras["episode"][k] (what ep_infos.append collects)
+     *     [22]       number of those steps
+     *     [24], [25] head / fill count of the two rings below
+     *     [32, 132)  returns of the last 100 finished episodes (rewbuffer, a deque(maxlen=100)), in env order within a step
+     *     [132, 232) their lengths (lenbuffer)
+     * The caller zero-fills both once and clears log_stats[0, 23) after reading it. */
+    float* log_cur;
+    float* log_stats;
 } HgymEnvOut;
+#define HGYM_LOG_STATS 256
 
 /* Optional externally supplied random draws (parity mode), row-major (N,k) tables indexed by env id.
  * A NULL member means "draw it from the internal Philox4x32-10 stream keyed by (seed, step, env, slot)". */

@@ -102,3 +102,47 @@ def test_f32_runner_matches_torch_module():
         assert float((a - b).abs().max() / b.abs().max()) < 1e-5
     finally:
         PPO.precision = "bf16"
+
+
+def test_log_sink_is_the_reference_bookkeeping():
+    """HgymEnvOut.log_*: the step finaliser's device-side logging book-keeping against the reference's host loop
+    (on_policy_runner.py:143-156) replayed on the same per-step rewards / dones / infos: running returns and lengths per env,
+    rewbuffer / lenbuffer = the last 100 finished episodes in env order, ep_infos = extras["episode"] appended every step."""
+    from collections import deque
+    from humanoid.envs import task_registry
+    from humanoid.utils import get_args
+    N, steps = 384, 70
+    args = get_args(["--task=humanoid_ppo", "--headless", "--num_envs", str(N)])
+    env, _ = task_registry.make_env(name=args.task, args=args)
+    env.episode_length_buf = torch.randint(2300, 2400, (N,), device="cuda")      # many time-outs inside the window (> 100 episodes)
+    assert env.bind_log_sink(True)
+    values = torch.zeros(N, 1, device="cuda")
+    sink = dict(values=values, rewards=torch.zeros(N, 1, device="cuda"), dones=torch.zeros(N, 1, dtype=torch.uint8, device="cuda"),
+                step=torch.zeros(1, dtype=torch.int64, device="cuda"), gamma=0.99)
+    env.bind_transition(sink)
+    g = torch.Generator().manual_seed(0)
+    rewbuffer, lenbuffer, ep_infos = deque(maxlen=100), deque(maxlen=100), []
+    cur_r, cur_l = torch.zeros(N), torch.zeros(N)
+    for t in range(steps):
+        a = (torch.randn(N, 12, generator=g) * 0.5).cuda()
+        obs, priv, rew, dones, infos = env.step(a)
+        torch.cuda.synchronize()
+        rew, dones = rew.cpu().clone(), dones.cpu().clone()
+        ep_infos.append({k: float(v) for k, v in infos["episode"].items()})
+        cur_r += rew
+        cur_l += 1
+        ids = (dones > 0).nonzero(as_tuple=False)
+        rewbuffer.extend(cur_r[ids][:, 0].numpy().tolist())
+        lenbuffer.extend(cur_l[ids][:, 0].numpy().tolist())
+        cur_r[ids] = 0
+        cur_l[ids] = 0
+    ep_mean, ring_r, ring_l = env.log_sink_read()
+    assert len(rewbuffer) == 100 == len(ring_r)
+    assert sorted(ring_l) == sorted(lenbuffer) and sorted(ring_r) == sorted(rewbuffer)     # the same 100 episodes (ring order is a rotation)
+    for k in ep_infos[0]:
+        want = float(np.mean([e[k] for e in ep_infos]))
+        assert abs(ep_mean[k] - want) <= 1e-6 + 1e-5 * abs(want), (k, ep_mean[k], want)
+    torch.testing.assert_close(env._buf.log_cur[0].cpu(), cur_r, rtol=0, atol=0)
+    torch.testing.assert_close(env._buf.log_cur[1].cpu(), cur_l, rtol=0, atol=0)
+    env.bind_transition(None)
+    env.bind_log_sink(False)
