@@ -421,7 +421,7 @@ template <int BM, int NW, int D, int G1, bool WIDE = false, class Early = FwdNoo
           class Idle = FwdNoop, class Head = FwdNoop>
 __device__ __forceinline__ void fwd_body(const FwdArgs& a, const FusedNet& n, bool is_actor, char* smem, Early&& hook_early = Early(),
                                          Mid&& hook_mid = Mid(), Put&& hook_put = Put(), const Extra& extra = Extra(),
-                                         Idle&& hook_idle = Idle(), Head&& hook_head = Head()) {
+                                         Idle&& hook_idle = Idle(), Head&& hook_head = Head(), char* h2_lds = nullptr) {
     constexpr int MB = BM / 16;
     constexpr int IT = BM * 32 / (NW * 64);           // staging items per thread per chunk (BM rows x 32 float4)
     constexpr int RPP = NW * 2;                       // rows covered per staging pass (32 lanes per row)
@@ -431,6 +431,9 @@ __device__ __forceinline__ void fwd_body(const FwdArgs& a, const FusedNet& n, bo
     const int64_t mbg0 = m0 >> 4;
     char* P = smem;
     char* Q = smem + fused_lds_p(n, BM);
+    // third-layer activations: over the first layer's (dead) in P, unless the caller wants H0 to survive (the fused forward +
+    // backward kernel needs all three for its dZ chain) and provides a buffer of BM x layer[2].N bf16
+    char* PH2 = h2_lds ? h2_lds : P;
     const FusedLayer& L0 = n.layer[0];
     const FusedLayer& L1 = n.layer[1];
     const FusedLayer& L2 = n.layer[2];
@@ -565,7 +568,7 @@ __device__ __forceinline__ void fwd_body(const FwdArgs& a, const FusedNet& n, bo
     auto prime3 = [&]() {
         if (wave < MB) wring_prime<1, 4>(r3, L3.Wf + lane, 0, L3.KB);
     };
-    hidden_layer<GH, MB, NW, D, AHEAD>(r2, L2, bl + L0.N + L1.N, Q, L1.NB, P, train_h ? n.H[2] : nullptr, mbg0, wave, lane, prime3);
+    hidden_layer<GH, MB, NW, D, AHEAD>(r2, L2, bl + L0.N + L1.N, Q, L1.NB, PH2, train_h ? n.H[2] : nullptr, mbg0, wave, lane, prime3);
     __syncthreads();
     phase_stamp(a.dbg, 5);
     if (!AHEAD) prime3();
@@ -574,8 +577,8 @@ __device__ __forceinline__ void fwd_body(const FwdArgs& a, const FusedNet& n, bo
         f32x4 hacc[1][1];
         hacc[0][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
         const int CB3 = L2.NB;
-        if (L3.KB % 4 == 0) mma_stream<1, 1, 4>(r3, L3.Wf + lane, 0, L3.KB, P + wave * CB3 * 512, CB3, lane, hacc);
-        else mma_ring<1, 1, 4>(r3, L3.Wf + lane, 0, 0, L3.KB, L3.KB, P + wave * CB3 * 512, CB3, lane, hacc);
+        if (L3.KB % 4 == 0) mma_stream<1, 1, 4>(r3, L3.Wf + lane, 0, L3.KB, PH2 + wave * CB3 * 512, CB3, lane, hacc);
+        else mma_ring<1, 1, 4>(r3, L3.Wf + lane, 0, 0, L3.KB, L3.KB, PH2 + wave * CB3 * 512, CB3, lane, hacc);
         const f32x4 acc = hacc[0][0];
         const int m = m0 + wave * 16 + r;
         const int No = L3.N;
@@ -628,8 +631,8 @@ __device__ __forceinline__ void fwd_body(const FwdArgs& a, const FusedNet& n, bo
             const u32x4* wl = L3.Wf + (int64_t)nb * L3.KB * 64 + lane;
             wring_prime<1, 4>(r3, wl, 0, L3.KB);
             hacc[0][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (L3.KB % 4 == 0) mma_stream<1, 1, 4>(r3, wl, 0, L3.KB, P + wave * CB3 * 512, CB3, lane, hacc);
-            else mma_ring<1, 1, 4>(r3, wl, 0, 0, L3.KB, L3.KB, P + wave * CB3 * 512, CB3, lane, hacc);
+            if (L3.KB % 4 == 0) mma_stream<1, 1, 4>(r3, wl, 0, L3.KB, PH2 + wave * CB3 * 512, CB3, lane, hacc);
+            else mma_ring<1, 1, 4>(r3, wl, 0, 0, L3.KB, L3.KB, PH2 + wave * CB3 * 512, CB3, lane, hacc);
             if (m < a.M) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -782,8 +785,8 @@ __global__ __launch_bounds__(NW * 64) void mlp_bwd_kernel(const BwdArgs a) {
 // forward leaves H1 and H2 in LDS (the two ping-pong buffers), the head wavefronts turn their outputs into the PPO loss gradient
 // (the per-sample arithmetic of ppo_loss_kernel, one lane per (row, 4 actions)) -- dZ3 goes to LDS and to HBM -- and the dZ chain
 // runs on the resident tile: through W3 against H2 (LDS, in place), through W2 against H1 (LDS, in place), through W1 against
-// H0, the one activation the forward's buffer reuse has evicted (re-read from the copy this workgroup has just written: L2).
-// HBM traffic per minibatch drops by the H1 / H2 re-reads and the loss kernel's own gathers; three launch boundaries go away.
+// H0 (LDS: the forward is told to put H2 into a buffer of its own instead of over H0).
+// HBM traffic per minibatch drops by the H re-reads and the loss kernel's own gathers; three launch boundaries go away.
 struct FbLoss {
     const float* actions;      // (T*N, A) storage columns, gathered through FwdArgs::idx
     const float* old_mu;
@@ -798,7 +801,10 @@ struct FbLoss {
                                // critic tile its two
 };
 
-HG_HD int fb_lds_extra() { return 64 * 64 + 4 * 32 * 4; }      // dZ3 tile (64 rows x 32 bf16 columns) + the head waves' partial sums
+// LDS of the fused kernel behind the forward's P / Q / bias regions: the dZ3 tile (64 rows x 32 bf16 columns), the head waves'
+// partial sums, and H2 (64 x layer[2].N bf16) -- the forward writes it there instead of over H0, so that all three activations
+// are resident for the dZ chain
+HG_HD int fb_lds_extra(const FusedNet& n) { return 64 * 64 + 4 * 32 * 4 + 64 * n.layer[2].N * 2; }
 
 template <int G1>
 __device__ __forceinline__ void fb_body(const FwdArgs& a, const FbLoss& L, const FusedNet& n, bool is_actor, char* smem) {
@@ -811,6 +817,7 @@ __device__ __forceinline__ void fb_body(const FwdArgs& a, const FbLoss& L, const
     char* Q = smem + fused_lds_p(n, BM);
     char* R0 = smem + fused_lds_p(n, BM) + fused_lds_q(n, BM) + fused_lds_bias(n);
     float* red = reinterpret_cast<float*>(R0 + BM * 64);
+    char* H2 = R0 + BM * 64 + 4 * 32 * 4;
     const int A = a.A;
     const float invB = 1.0f / (float)a.M;
     auto head = [&](int hw, int m, const float (&out)[4]) {
@@ -913,8 +920,8 @@ __device__ __forceinline__ void fb_body(const FwdArgs& a, const FbLoss& L, const
             }
         }
     };
-    fwd_body<BM, NW, D, G1, false>(a, n, is_actor, smem, FwdNoop(), FwdNoop(), FwdNoop(), 0, FwdNoop(), head);
-    __syncthreads();          // dZ3 tile and the per-wave sums are in LDS; H2 sits in P, H1 in Q
+    fwd_body<BM, NW, D, G1, false>(a, n, is_actor, smem, FwdNoop(), FwdNoop(), FwdNoop(), 0, FwdNoop(), head, H2);
+    __syncthreads();          // dZ3 tile and the per-wave sums are in LDS; H0 sits in P, H1 in Q, H2 in its own buffer
     if (tid < 32) {
         const bool mine = is_actor ? (tid != 1 && tid < 28) : (tid == 1 || tid == 28);
         if (mine) L.partials[(int64_t)blockIdx.x * 32 + tid] = red[tid] + red[32 + tid] + red[64 + tid] + red[96 + tid];
@@ -927,13 +934,13 @@ __device__ __forceinline__ void fb_body(const FwdArgs& a, const FbLoss& L, const
     WRing<G1, D> rc;
     auto none = [&]() {};
     bwd_prime<1, D>(ra, n.layer[3].WTf, N2 / 16, NBB3, wave, lane);
-    bwd_step<1, MB, NW, D, false, true>(ra, n.layer[3].WTf, N2 / 16, NBB3, R0, 2 * NBB3, P, n.dZ[2], nullptr, mbg0, wave, lane, none, P);
+    bwd_step<1, MB, NW, D, false, true>(ra, n.layer[3].WTf, N2 / 16, NBB3, R0, 2 * NBB3, H2, n.dZ[2], nullptr, mbg0, wave, lane, none, H2);
     __syncthreads();
     bwd_prime<1, D>(rb, n.layer[2].WTf, N1 / 16, n.layer[2].NBB, wave, lane);
-    bwd_step<1, MB, NW, D, false, true>(rb, n.layer[2].WTf, N1 / 16, n.layer[2].NBB, P, N2 / 16, Q, n.dZ[1], nullptr, mbg0, wave, lane, none, Q);
+    bwd_step<1, MB, NW, D, false, true>(rb, n.layer[2].WTf, N1 / 16, n.layer[2].NBB, H2, N2 / 16, Q, n.dZ[1], nullptr, mbg0, wave, lane, none, Q);
     __syncthreads();
     bwd_prime<G1, D>(rc, n.layer[1].WTf, N0 / 16, n.layer[1].NBB, wave, lane);
-    bwd_step<G1, MB, NW, D, false>(rc, n.layer[1].WTf, N0 / 16, n.layer[1].NBB, Q, N1 / 16, nullptr, n.dZ[0], n.H[0], mbg0, wave, lane, none);
+    bwd_step<G1, MB, NW, D, false, true>(rc, n.layer[1].WTf, N0 / 16, n.layer[1].NBB, Q, N1 / 16, nullptr, n.dZ[0], nullptr, mbg0, wave, lane, none, P);
 }
 
 template <int UNUSED = 0>      // a template only so that the header can be included by several translation units

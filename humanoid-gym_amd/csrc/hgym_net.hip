@@ -976,8 +976,9 @@ struct NetRunner {
             fl.partials = at<float>(w.partials);
             size_t lds = 0;
             for (int i = 0; i < 2; ++i)
-                lds = std::max(lds, (size_t)fused_lds_p(fa.net[i], 64) + (size_t)fused_lds_q(fa.net[i], 64) + (size_t)fused_lds_bias(fa.net[i]));
-            lds += (size_t)fb_lds_extra();
+                lds = std::max(lds, (size_t)fused_lds_p(fa.net[i], 64) + (size_t)fused_lds_q(fa.net[i], 64) + (size_t)fused_lds_bias(fa.net[i]) +
+                                        (size_t)fb_lds_extra(fa.net[i]));
+            HG_REQUIRE(lds <= 160 * 1024, HGYM_E_UNSUPPORTED, "mlp_fb_kernel needs %zu bytes of LDS", lds);
             static size_t attr_lds = 0;
             if (lds > attr_lds) {
                 if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fb_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)

@@ -5,6 +5,6 @@ import torch
 src = torch.empty(1 << 28, device="cuda", dtype=torch.uint8); dst = torch.empty_like(src)
 for _ in range(5): torch.add(src, 1, out=dst)   # a plain streaming kernel: reads 256 MiB, writes 256 MiB
 torch.cuda.synchronize()
-sys.argv = ["bench.py", "--steps", "2", "--warmup", "2", "--no-cpu-baseline", "--no-roofline"]
+sys.argv = ["bench.py", "--steps", "2", "--warmup", "2", "--no-cpu-baseline", "--no-roofline", "--configs", "none"]
 import runpy
 runpy.run_path(os.path.join(R, "bench.py"), run_name="__main__")
