@@ -499,9 +499,17 @@ __global__ __launch_bounds__(512) void ppo_scalars_kernel(int nblocks, int B, in
                                                           double* __restrict__ opt) {
     __shared__ double red[16][LOSS_PARTIALS + 1];
     const int k = threadIdx.x & (LOSS_PARTIALS - 1), part = threadIdx.x / LOSS_PARTIALS;   // 16 partial sums per quantity
-    double s = 0.0;
-    for (int b = part; b < nblocks; b += 16) s += (double)partials[(int64_t)b * LOSS_PARTIALS + k];
-    red[part][k] = s;
+    // four independent partial sums per thread (combined in a fixed order): a single dependent chain of nblocks / 16 loads was
+    // latency-bound once the fused forward + backward kernel started handing in one partial row per 64-row tile (960 rows)
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int b = part;
+    for (; b + 48 < nblocks; b += 64) {
+        const float v0 = partials[(int64_t)b * LOSS_PARTIALS + k], v1 = partials[(int64_t)(b + 16) * LOSS_PARTIALS + k];
+        const float v2 = partials[(int64_t)(b + 32) * LOSS_PARTIALS + k], v3 = partials[(int64_t)(b + 48) * LOSS_PARTIALS + k];
+        s0 += (double)v0; s1 += (double)v1; s2 += (double)v2; s3 += (double)v3;
+    }
+    for (; b < nblocks; b += 16) s0 += (double)partials[(int64_t)b * LOSS_PARTIALS + k];
+    red[part][k] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (threadIdx.x < LOSS_PARTIALS) {
         double t = 0.0;
