@@ -26,7 +26,9 @@
 
 namespace hgym {
 
-template <int H_T, int HC_T, int E_T, bool kGeneric>
+// kStep: the instantiation for plain steps (A.mode == MODE_STEP) -- the split per-env chain is then the only one compiled in, which
+// is what sets the kernel's register count (and with it how many workgroups share a CU when there are more envs than one round).
+template <int H_T, int HC_T, int E_T, bool kGeneric, bool kStep = false>
 __global__ __launch_bounds__(256) void env_step_kernel(const EnvArgs A) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int64_t csc0 = A.st.counters[0];
@@ -63,7 +65,7 @@ __global__ __launch_bounds__(256) void env_step_kernel(const EnvArgs A) {
     // The XBot-L instantiation splits the per-env chain of a plain step (HGYM_ENV_SPLIT): what is the same few instructions
     // for each of the 12 joints runs one (env, joint) pair per lane before (phase J) and after (phase F) a shorter chain, and
     // the synthetic physics' per-env remainder runs on two otherwise idle wavefronts of phase J.
-    const bool split = HGYM_ENV_SPLIT && !kGeneric && E_T > 0 && A.mode == MODE_STEP;
+    const bool split = HGYM_ENV_SPLIT && !kGeneric && E_T > 0 && (kStep || A.mode == MODE_STEP);
     if (split) env_step_phase_j<E_T>(A, blockIdx.x, t, blockDim.x, smem);
     else if (!(A.ablate & 128)) env_step_joints<E_T>(A, blockIdx.x, t, blockDim.x, smem);
     __syncthreads();
@@ -236,7 +238,9 @@ static int32_t launch_step(const HgymEnvConfig* cfg, const HgymSimTensors* sim, 
     // the generic LeggedRobot options (HgymEnvConfig tail) have their own instantiation: off, none of their code is compiled in
     const bool generic = cfg->custom_origins || cfg->terrain_curriculum || cfg->num_height_points > 0 || cfg->command_curriculum ||
                          !cfg->heading_command;
-    if (std_stack && A.envs_per_block == 16 && !generic)
+    if (std_stack && A.envs_per_block == 16 && !generic && mode == MODE_STEP && HGYM_ENV_SPLIT)
+        hipLaunchKernelGGL((env_step_kernel<15, 3, 16, false, true>), dim3(blocks), dim3(256), lds, s, A);
+    else if (std_stack && A.envs_per_block == 16 && !generic)
         hipLaunchKernelGGL((env_step_kernel<15, 3, 16, false>), dim3(blocks), dim3(256), lds, s, A);
     else if (std_stack && A.envs_per_block == 16)
         hipLaunchKernelGGL((env_step_kernel<15, 3, 16, true>), dim3(blocks), dim3(256), lds, s, A);

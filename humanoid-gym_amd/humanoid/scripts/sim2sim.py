@@ -160,14 +160,26 @@ def run_replay(policy, cfg, trace):
     return dict(policy_inputs=np.stack(inputs), actions=np.stack(actions), tau=np.stack(taus))
 
 
-def make_cfg(terrain=False, sim_duration=60.0):
+def mjcf_path(terrain=False, mjcf=None):
+    """Where the MuJoCo model of XBot-L is.  The robot assets (URDF / MJCF / meshes: SURVEY.md §2, out of scope) are NOT shipped with
+    this repo; they live in the reference checkout under resources/robots/XBot/mjcf/.  Resolution order: the explicit path, the
+    HGYM_ROBOT_ASSETS directory (the reference's `resources/robots` or a copy of it), the reference's layout next to this package."""
+    name = "XBot-L-terrain.xml" if terrain else "XBot-L.xml"
+    if mjcf:
+        return mjcf
+    root = os.environ.get("HGYM_ROBOT_ASSETS")
+    if root:
+        return os.path.join(root, "XBot", "mjcf", name)
+    return os.path.join(LEGGED_GYM_ROOT_DIR, "resources", "robots", "XBot", "mjcf", name)
+
+
+def make_cfg(terrain=False, sim_duration=60.0, mjcf=None):
     """The reference's `Sim2simCfg` (:176-190): XBotLCfg + simulator and PD settings."""
     from humanoid.envs import XBotLCfg
 
     class Sim2simCfg(XBotLCfg):
         class sim_config:
-            mujoco_model_path = os.path.join(LEGGED_GYM_ROOT_DIR, "resources", "robots", "XBot", "mjcf",
-                                             "XBot-L-terrain.xml" if terrain else "XBot-L.xml")
+            mujoco_model_path = mjcf_path(terrain, mjcf)
             dt = 0.001
             decimation = 10
 
@@ -186,10 +198,19 @@ if __name__ == "__main__":
     parser.add_argument("--load_model", type=str, required=True, help="Run to load from.")
     parser.add_argument("--terrain", action="store_true", help="terrain or plane")
     parser.add_argument("--replay", type=str, default=None, help="npz state trace (q, dq, quat, omega): run without MuJoCo")
+    parser.add_argument("--mjcf", type=str, default=None,
+                        help="MuJoCo model of XBot-L (default: $HGYM_ROBOT_ASSETS/XBot/mjcf/XBot-L[-terrain].xml, else the reference's "
+                             "resources/robots/ layout next to this package; the assets are not shipped here)")
     args = parser.parse_args()
     pol = torch.jit.load(args.load_model)
     if args.replay:
         out = run_replay(pol, make_cfg(args.terrain), dict(np.load(args.replay)))
         print("replayed %d policy steps; |tau| max %.3f" % (len(out["actions"]), float(np.abs(out["tau"]).max())))
     else:
-        run_mujoco(pol, make_cfg(args.terrain))
+        cfg = make_cfg(args.terrain, mjcf=args.mjcf)
+        if not os.path.exists(cfg.sim_config.mujoco_model_path):
+            raise SystemExit("sim2sim: MuJoCo model not found at %s\nThe robot assets are not part of this repository: point --mjcf at "
+                             "XBot-L.xml, or HGYM_ROBOT_ASSETS at the reference checkout's resources/robots directory "
+                             "(roboterax/humanoid-gym), or use --replay <trace.npz> to run the control loop without a simulator."
+                             % cfg.sim_config.mujoco_model_path)
+        run_mujoco(pol, cfg)
