@@ -65,6 +65,13 @@ HG_HD void hg_atomic_add(float* p, float v) {
     *p += v;
 #endif
 }
+HG_HD void hg_atomic_inc_int(int* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    atomicAdd(p, 1);
+#else
+    *p += 1;
+#endif
+}
 HG_HD void hg_atomic_inc(int64_t* p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     atomicAdd((unsigned long long*)p, 1ull);
@@ -940,7 +947,7 @@ HG_HD float* state_comp_row(const EnvArgs& A, int comp, int N) {
 // LDS carve (float offsets) for a block of E envs
 struct LdsMap {
     int state, root, dof_pos, dof_vel, contact, rigid, actions_in, u_delay, z_act, u_cmd, u_dof, u_push, z_obs, phys, frame, priv, rew,
-        noise_vec, ep_len, flags, reset_i, jpart, cscal, total;
+        noise_vec, ep_len, flags, reset_i, reset_cnt, jpart, cscal, total;
 };
 HG_HD LdsMap lds_map(int E) {
     LdsMap m;
@@ -967,6 +974,7 @@ HG_HD LdsMap lds_map(int E) {
     m.ep_len = o;     o += 2 * E;          // int64[E]
     m.flags = o;      o += (2 * E + 3) / 4;  // uint8 reset[E], time_out[E]
     m.reset_i = o;    o += E;              // int[E]: "history must be cleared" flags for the stacking phase
+    m.reset_cnt = o;  o += 1;              // int: how many of them are set (zeroed by the stage-in, counted by the per-env phase)
     m.jpart = o;      o += kJointTerms * 12 * E;   // [8][12][E] per-joint reward products (split per-env chain)
     m.cscal = o;      o += E;              // [E] gait-clock sine of the new observation (split per-env chain -> per-joint lanes)
     m.total = o;
@@ -1197,6 +1205,7 @@ HG_HD void env_stage_in_store(const EnvArgs& A, int block, int t, int nthreads, 
     copy_rows_in(A.noise.u_push, smem + m.u_push, 5, e0, nE, t, nthreads);
     copy_rows_in(A.noise.z_obs, smem + m.z_obs, HGYM_OBS_FRAME, e0, nE, t, nthreads);
     for (int i = t; i < HGYM_OBS_FRAME; i += nthreads) smem[m.noise_vec + i] = A.cfg.obs_noise[i];
+    if (t == 0) reinterpret_cast<int*>(smem + m.reset_cnt)[0] = 0;
 }
 template <int E_T>
 HG_HD void env_stage_in(const EnvArgs& A, int block, int t, int nthreads, float* smem) {
@@ -1417,6 +1426,7 @@ HG_HD void env_step_phase_a(const EnvArgs& A, int block, int t, float* smem, int
         fl = post_physics_env<kGeneric, kSplit>(S, rk, csc0 + 1, t, E, smem + m.frame + t * HGYM_OBS_FRAME, smem + m.priv + t * HGYM_PRIV_FRAME,
                                                 smem + m.jpart, smem + m.cscal);
     reinterpret_cast<int*>(smem + m.reset_i)[t] = fl.reset;
+    if (fl.reset) hg_atomic_inc_int(reinterpret_cast<int*>(smem + m.reset_cnt));
 }
 
 template <int E_T>
@@ -1614,10 +1624,44 @@ HG_HD void stack_new(const EnvArgs& A, float* __restrict__ ring, const float* cl
     }
 }
 
+// The same pass in 16-byte pieces (compiled-in frame width): a work item is (env, quad of 4 consecutive frame entries) -- the last
+// quad of a frame is shifted back to end at the frame's end and rewrites identical values -- so the ring slot and the output
+// row's last frame each receive F / 4 (+1) unaligned 16-byte stores per env instead of F 4-byte ones.  Same arithmetic per entry.
+template <bool kNoisy, int F>
+HG_HD void stack_new_vec(const EnvArgs& A, float* __restrict__ ring, const float* clean_all, const float* z_all, const float* noise_vec,
+                         float* __restrict__ dst, int e0, int nE, int H, int slot_new, int t, int nthreads) {
+    constexpr int Q = (F + 3) / 4;
+    const int row = H * F;
+    const float lim = A.cfg.clip_obs;
+    for (int i = t; i < nE * Q; i += nthreads) {
+        const int le = i / Q, j = i - le * Q;
+        int off = 4 * j;
+        off = off < F - 4 ? off : F - 4;
+        EnvF4 r, o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int idx = le * F + off + k;
+            float v = clean_all[idx];
+            if (kNoisy && A.cfg.add_noise) {
+                const float ns = noise_vec[off + k];
+                if (ns != 0.0f) v = v + z_all[idx] * ns * A.cfg.noise_level;
+                else v = v + 0.0f;   // clean + z*0*level in the reference
+            }
+            r.v[k] = v;
+            o.v[k] = clampf(v, -lim, lim);
+        }
+        *reinterpret_cast<EnvF4*>(ring + ((int64_t)(e0 + le) * H + slot_new) * F + off) = r;
+        *reinterpret_cast<EnvF4*>(dst + (int64_t)le * row + (H - 1) * F + off) = o;
+    }
+}
+
 // Envs that reset this step: their history is cleared (humanoid_env.py:264-269) -- older frames of the output row and
 // of the ring become zero.  Rare (a handful of envs per step), so a plain element loop per flagged env.
 HG_HD void stack_reset_fix(float* __restrict__ ring, const int* s_reset, float* __restrict__ dst, int e0, int nE, int H, int F, int slot_new,
-                           int t, int nthreads, bool zero_dst) {
+                           int t, int nthreads, bool zero_dst, int reset_count = -1) {
+    // reset_count: how many flags are set when the caller knows (0 in all but a few steps: the walk over the flags -- a serial
+    // chain of LDS reads on every lane, 2.7 us for 32 envs -- is then skipped), -1 when it does not
+    if (reset_count == 0) return;
     const int row = H * F, hrow = (H - 1) * F;
     const int start = (slot_new + 1) * F;
     for (int le = 0; le < nE; ++le) {
@@ -1725,11 +1769,20 @@ HG_HD void env_step_phase_b(const EnvArgs& A, int block, int t, int nthreads, fl
     }
     float* dobs = A.out.obs + (int64_t)e0 * H * HGYM_OBS_FRAME;
     float* dpriv = A.out.priv_obs + (int64_t)e0 * HC * HGYM_PRIV_FRAME;
-    stack_new<true>(A, A.st.obs_ring, smem + m.frame, smem + m.z_obs, smem + m.noise_vec, dobs, e0, nE, H, HGYM_OBS_FRAME,
-                    (int)(ring_step % H), t, nthreads);
-    stack_new<false>(A, A.st.priv_ring, smem + m.priv, nullptr, nullptr, dpriv, e0, nE, HC, HGYM_PRIV_FRAME, (int)(ring_step % HC), t, nthreads);
-    stack_reset_fix(A.st.obs_ring, s_reset, dobs, e0, nE, H, HGYM_OBS_FRAME, (int)(ring_step % H), t, nthreads, !old_rows_final);
-    stack_reset_fix(A.st.priv_ring, s_reset, dpriv, e0, nE, HC, HGYM_PRIV_FRAME, (int)(ring_step % HC), t, nthreads, !old_rows_final);
+    if (H_T > 0 && HC_T > 0) {
+        stack_new_vec<true, HGYM_OBS_FRAME>(A, A.st.obs_ring, smem + m.frame, smem + m.z_obs, smem + m.noise_vec, dobs, e0, nE, H,
+                                            (int)(ring_step % H), t, nthreads);
+        stack_new_vec<false, HGYM_PRIV_FRAME>(A, A.st.priv_ring, smem + m.priv, nullptr, nullptr, dpriv, e0, nE, HC, (int)(ring_step % HC), t,
+                                              nthreads);
+    } else {
+        stack_new<true>(A, A.st.obs_ring, smem + m.frame, smem + m.z_obs, smem + m.noise_vec, dobs, e0, nE, H, HGYM_OBS_FRAME,
+                        (int)(ring_step % H), t, nthreads);
+        stack_new<false>(A, A.st.priv_ring, smem + m.priv, nullptr, nullptr, dpriv, e0, nE, HC, HGYM_PRIV_FRAME, (int)(ring_step % HC), t,
+                         nthreads);
+    }
+    const int nreset = reinterpret_cast<const int*>(smem + m.reset_cnt)[0];
+    stack_reset_fix(A.st.obs_ring, s_reset, dobs, e0, nE, H, HGYM_OBS_FRAME, (int)(ring_step % H), t, nthreads, !old_rows_final, nreset);
+    stack_reset_fix(A.st.priv_ring, s_reset, dpriv, e0, nE, HC, HGYM_PRIV_FRAME, (int)(ring_step % HC), t, nthreads, !old_rows_final, nreset);
 }
 
 // Step finaliser (hgym_finalize.hpp) on an EnvArgs record.
