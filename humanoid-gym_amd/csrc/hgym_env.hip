@@ -61,6 +61,7 @@ __global__ __launch_bounds__(256) void env_step_kernel(const EnvArgs A) {
     if (!(A.ablate & 1)) env_stage_in<E_T>(A, blockIdx.x, t, blockDim.x, smem);
 #endif
     if (!(A.ablate & 64)) env_fill_draws<E_T>(A, blockIdx.x, t, blockDim.x, smem, csc0);
+    env_reset_pose<E_T>(A, t, blockDim.x, smem);
     __syncthreads();
     // The XBot-L instantiation splits the per-env chain of a plain step (HGYM_ENV_SPLIT): what is the same few instructions
     // for each of the 12 joints runs one (env, joint) pair per lane before (phase J) and after (phase F) a shorter chain, and

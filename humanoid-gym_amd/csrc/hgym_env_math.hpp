@@ -65,11 +65,11 @@ HG_HD void hg_atomic_add(float* p, float v) {
     *p += v;
 #endif
 }
-HG_HD void hg_atomic_inc_int(int* p) {
+HG_HD int hg_atomic_inc_int(int* p) {      // returns the previous value
 #if defined(__HIP_DEVICE_COMPILE__)
-    atomicAdd(p, 1);
+    return atomicAdd(p, 1);
 #else
-    *p += 1;
+    return (*p)++;
 #endif
 }
 HG_HD void hg_atomic_inc(int64_t* p) {
@@ -401,7 +401,7 @@ HG_HD void joint_terms(const HgymEnvConfig& c, int j, float a, float la, float l
 constexpr int kJointTerms = 8;     // per-joint products: d1^2, d2^2, |a| (term 0), jd^2 (4), acc^2 (5), qd^2 (6), tq^2 (17), (q - ref)^2 (13)
 template <bool kGeneric, bool kSplit = false>
 HG_HD StepFlags post_physics_env(const EnvArgs& A, const RngKey& rk, int64_t csc, int e, int N, float* frame47,
-                                 float* priv73, const float* jpart = nullptr, float* cscal = nullptr) {
+                                 float* priv73, const float* jpart = nullptr, float* cscal = nullptr, const float* reset_pose = nullptr) {
     const HgymEnvConfig& c = A.cfg;
     const HgymEnvState& S = A.st;
     const int mode = A.mode;
@@ -801,9 +801,17 @@ HG_HD StepFlags post_physics_env(const EnvArgs& A, const RngKey& rk, int64_t csc
             hg_atomic_add(&S.episode_acc[k], esum[k]);
             FG(S.episode_sums, k) = 0.0f;
         }
-        euler_xyz_wrapped(root + 3, eul);
-        const float gvec[3] = {0.0f, 0.0f, -1.0f};
-        quat_rotate_inverse(root + 3, gvec, grav);
+        if (kSplit) {       // the reset orientation is cfg.base_init_state's for every env: evaluated once per block (env_step_phase_j)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                eul[i] = reset_pose[i];
+                grav[i] = reset_pose[3 + i];
+            }
+        } else {
+            euler_xyz_wrapped(root + 3, eul);
+            const float gvec[3] = {0.0f, 0.0f, -1.0f};
+            quat_rotate_inverse(root + 3, gvec, grav);
+        }
     }
 
     if (mode != MODE_RESET_ALL) {
@@ -947,7 +955,7 @@ HG_HD float* state_comp_row(const EnvArgs& A, int comp, int N) {
 // LDS carve (float offsets) for a block of E envs
 struct LdsMap {
     int state, root, dof_pos, dof_vel, contact, rigid, actions_in, u_delay, z_act, u_cmd, u_dof, u_push, z_obs, phys, frame, priv, rew,
-        noise_vec, ep_len, flags, reset_i, reset_cnt, jpart, cscal, total;
+        noise_vec, ep_len, flags, reset_i, reset_cnt, reset_list, reset_pose, jpart, cscal, total;
 };
 HG_HD LdsMap lds_map(int E) {
     LdsMap m;
@@ -975,6 +983,8 @@ HG_HD LdsMap lds_map(int E) {
     m.flags = o;      o += (2 * E + 3) / 4;  // uint8 reset[E], time_out[E]
     m.reset_i = o;    o += E;              // int[E]: "history must be cleared" flags for the stacking phase
     m.reset_cnt = o;  o += 1;              // int: how many of them are set (zeroed by the stage-in, counted by the per-env phase)
+    m.reset_list = o; o += E;              // int[reset_cnt]: the local ids of the envs that reset, in arrival order
+    m.reset_pose = o; o += 8;              // euler angles [0..2] and projected gravity [3..5] of the reset orientation (split chain)
     m.jpart = o;      o += kJointTerms * 12 * E;   // [8][12][E] per-joint reward products (split per-env chain)
     m.cscal = o;      o += E;              // [E] gait-clock sine of the new observation (split per-env chain -> per-joint lanes)
     m.total = o;
@@ -1249,6 +1259,27 @@ HG_HD int draw_dest(const EnvArgs& A, const LdsMap& m, int c, int le, int k) {
     return m.phys + le * kPhysDraws + 4 * (c - 22) + k;
 }
 
+// euler angles / projected gravity of a freshly reset env (cfg.base_init_state's orientation: the same for all of them), evaluated
+// by ONE lane per block while the block waits for its input loads, instead of inside the divergent reset branch of the per-env
+// chain (about one block in ten has a resetting env in any step, and the launch ends with its slowest block)
+template <int E_T>
+HG_HD void env_reset_pose(const EnvArgs& A, int t, int nthreads, float* smem) {
+    if (t != nthreads - 1) return;
+    const int E = E_T > 0 ? E_T : A.envs_per_block;
+    const LdsMap m = lds_map(E);
+    float q[4], eul[3], grav[3];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) q[i] = A.cfg.base_init_state[3 + i];
+    euler_xyz_wrapped(q, eul);
+    const float gvec[3] = {0.0f, 0.0f, -1.0f};
+    quat_rotate_inverse(q, gvec, grav);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        smem[m.reset_pose + i] = eul[i];
+        smem[m.reset_pose + 3 + i] = grav[i];
+    }
+}
+
 template <int E_T>
 HG_HD void env_fill_draws(const EnvArgs& A, int block, int t, int nthreads, float* smem, int64_t csc0) {
     const int E = E_T > 0 ? E_T : A.envs_per_block;
@@ -1345,9 +1376,9 @@ HG_HD void env_step_phase_j(const EnvArgs& A, int block, int t, int nthreads, fl
     const int nE = (E < N - e0) ? E : (N - e0);
     if (!(A.ablate & 128)) env_step_joints<E_T>(A, block, t, nthreads, smem);
     env_step_joint_terms<E_T>(A, block, t, nthreads, smem);
+    const LdsMap m = lds_map(E);
+    const int nw = nthreads >= 64 ? nthreads / 64 : 1;
     if (A.mode == MODE_STEP && A.fused && !(A.ablate & 16)) {
-        const LdsMap m = lds_map(E);
-        const int nw = nthreads >= 64 ? nthreads / 64 : 1;
         const int w_root = nw - 1, w_feet = nw >= 2 ? nw - 2 : nw - 1;
         const int lr = t - 64 * w_root, lf = t - 64 * w_feet;
         if ((lr >= 0 && lr < nE) || (lf >= 0 && lf < nE)) {
@@ -1424,9 +1455,9 @@ HG_HD void env_step_phase_a(const EnvArgs& A, int block, int t, float* smem, int
     fl.reset = 0;
     if (!(A.ablate & 32))
         fl = post_physics_env<kGeneric, kSplit>(S, rk, csc0 + 1, t, E, smem + m.frame + t * HGYM_OBS_FRAME, smem + m.priv + t * HGYM_PRIV_FRAME,
-                                                smem + m.jpart, smem + m.cscal);
+                                                smem + m.jpart, smem + m.cscal, smem + m.reset_pose);
     reinterpret_cast<int*>(smem + m.reset_i)[t] = fl.reset;
-    if (fl.reset) hg_atomic_inc_int(reinterpret_cast<int*>(smem + m.reset_cnt));
+    if (fl.reset) reinterpret_cast<int*>(smem + m.reset_list)[hg_atomic_inc_int(reinterpret_cast<int*>(smem + m.reset_cnt))] = t;
 }
 
 template <int E_T>
@@ -1658,14 +1689,18 @@ HG_HD void stack_new_vec(const EnvArgs& A, float* __restrict__ ring, const float
 // Envs that reset this step: their history is cleared (humanoid_env.py:264-269) -- older frames of the output row and
 // of the ring become zero.  Rare (a handful of envs per step), so a plain element loop per flagged env.
 HG_HD void stack_reset_fix(float* __restrict__ ring, const int* s_reset, float* __restrict__ dst, int e0, int nE, int H, int F, int slot_new,
-                           int t, int nthreads, bool zero_dst, int reset_count = -1) {
-    // reset_count: how many flags are set when the caller knows (0 in all but a few steps: the walk over the flags -- a serial
-    // chain of LDS reads on every lane, 2.7 us for 32 envs -- is then skipped), -1 when it does not
+                           int t, int nthreads, bool zero_dst, int reset_count = -1, const int* reset_list = nullptr) {
+    // reset_count / reset_list: the envs of this block that reset, when the caller has them as a compact list (the per-env phase
+    // appends to it): about one workgroup in ten has one in any given step, and walking the 32 flags instead is a serial chain
+    // of LDS reads on every lane (2.7 us) -- on the slowest workgroups of the launch, i.e. on its critical path.  -1: walk the flags.
     if (reset_count == 0) return;
     const int row = H * F, hrow = (H - 1) * F;
     const int start = (slot_new + 1) * F;
-    for (int le = 0; le < nE; ++le) {
-        if (!s_reset[le]) continue;
+    const int n = reset_count > 0 ? reset_count : nE;
+    for (int r = 0; r < n; ++r) {
+        int le = r;
+        if (reset_count > 0) le = reset_list[r];
+        else if (!s_reset[le]) continue;
         float* rp = ring + (int64_t)(e0 + le) * row;
         float* dp = dst + (int64_t)le * row;
         for (int i = t; i < hrow; i += nthreads) {
@@ -1781,8 +1816,10 @@ HG_HD void env_step_phase_b(const EnvArgs& A, int block, int t, int nthreads, fl
                          nthreads);
     }
     const int nreset = reinterpret_cast<const int*>(smem + m.reset_cnt)[0];
-    stack_reset_fix(A.st.obs_ring, s_reset, dobs, e0, nE, H, HGYM_OBS_FRAME, (int)(ring_step % H), t, nthreads, !old_rows_final, nreset);
-    stack_reset_fix(A.st.priv_ring, s_reset, dpriv, e0, nE, HC, HGYM_PRIV_FRAME, (int)(ring_step % HC), t, nthreads, !old_rows_final, nreset);
+    const int* rlist = reinterpret_cast<const int*>(smem + m.reset_list);
+    stack_reset_fix(A.st.obs_ring, s_reset, dobs, e0, nE, H, HGYM_OBS_FRAME, (int)(ring_step % H), t, nthreads, !old_rows_final, nreset, rlist);
+    stack_reset_fix(A.st.priv_ring, s_reset, dpriv, e0, nE, HC, HGYM_PRIV_FRAME, (int)(ring_step % HC), t, nthreads, !old_rows_final, nreset,
+                    rlist);
 }
 
 // Step finaliser (hgym_finalize.hpp) on an EnvArgs record.

@@ -111,6 +111,7 @@ __global__ __launch_bounds__(RO_NT) void rollout_step_kernel(const FwdArgs f, co
         if (t < 256) env_stage_in<RO_E>(E, block, t, 256, esm);
 #endif
 #if HGYM_RO_VARIANT == 0
+        env_reset_pose<RO_E>(E, t, RO_NT, esm);                       // one lane, under the tile's first loads
 #if HGYM_RO_DRAWS_IDLE
         if (t < 256) env_stage_in<RO_E>(E, block, t, 256, esm);      // travels with the tile's own first loads
 #else

@@ -54,6 +54,7 @@ int hc_env_step_ex(const HgymEnvConfig* cfg, const HgymSimTensors* sim, const Hg
     for (int b = 0; b < blocks; ++b) {
         for (int t = 0; t < nthreads; ++t) env_stage_in<0>(A, b, t, nthreads, smem.data());
         for (int t = 0; t < nthreads; ++t) env_fill_draws<0>(A, b, t, nthreads, smem.data(), csc0);
+        for (int t = 0; t < nthreads; ++t) env_reset_pose<0>(A, t, nthreads, smem.data());
         const bool generic = cfg->custom_origins || cfg->terrain_curriculum || cfg->num_height_points > 0 || cfg->command_curriculum ||
                              !cfg->heading_command;
         const bool sp = split && mode == MODE_STEP && !generic;       // as launch_step picks the instantiation
