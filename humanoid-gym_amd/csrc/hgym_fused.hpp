@@ -941,6 +941,7 @@ __device__ __forceinline__ void fb_body(const FwdArgs& a, const FbLoss& L, const
     __syncthreads();
     bwd_prime<G1, D>(rc, n.layer[1].WTf, N0 / 16, n.layer[1].NBB, wave, lane);
     bwd_step<G1, MB, NW, D, false, true>(rc, n.layer[1].WTf, N0 / 16, n.layer[1].NBB, Q, N1 / 16, nullptr, n.dZ[0], nullptr, mbg0, wave, lane, none, P);
+    phase_stamp(a.dbg, 7);
 }
 
 template <int UNUSED = 0>      // a template only so that the header can be included by several translation units

@@ -56,7 +56,7 @@ report("fwd<64> (no stores, M=61440)", buf, nb, FWD, nb // 2)
 buf.zero_()
 net.ppo_grad(ppo, batch)
 torch.cuda.synchronize()
-report("bwd<64>", buf, nb, BWD, nb // 2)
+report("mlp_fb<64> (forward + loss + dZ chain, B=61440)", buf, nb, FWD + ["loss + dZ chain"], nb // 2)
 M = 4096
 o4, p4 = torch.randn(M, 705, device=dev), torch.randn(M, 219, device=dev)
 sc = torch.zeros(1, dtype=torch.int64, device=dev)
