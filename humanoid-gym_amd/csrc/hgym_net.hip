@@ -947,14 +947,19 @@ struct NetRunner {
         return HGYM_OK;
     }
 
-    // part < 0: the whole minibatch gradient.  part 0 / 1: the two halves of hgym_ppo_grad_part -- 0 leaves the critic's (and the
-    // auxiliary head's) gradient and the KL slot final, 1 the actor's and std's.
+    // part < 0: the whole minibatch gradient.  part 0 / 1: the two halves of hgym_ppo_grad_part -- 0 leaves std's and the actor's
+    // gradient final (the LARGER bucket: it travels under part 1's kernels), 1 the critic's, the auxiliary head's and the KL slot.
     int32_t fused_grad(const HgymPPOConfig& ppo, const HgymBatch& b, int part = -1) {
         const int B = b.B, A = cfg.num_actions;
         const int64_t critic_off = w.net[1].layer[0].w_off;
         if (part == 1) {
-            const int32_t rc1 = fused_dw(0, 1, B);
-            return rc1 ? rc1 : reduce_range(0, critic_off);
+            int32_t rc1 = fused_dw(1, 1, B);
+            if (rc1) return rc1;
+            if (w.nnets > 2) {
+                rc1 = aux_grad(ppo, b);
+                if (rc1) return rc1;
+            }
+            return reduce_range(critic_off, w.P);
         }
         float* mu = at<float>(w.net[0].out_f32);
         float* val = at<float>(w.net[1].out_f32);
@@ -1010,13 +1015,8 @@ struct NetRunner {
                            net.grads + w.net[0].layer[3].b_off, net.grads + w.net[1].layer[3].b_off, net.grads + w.P, net.opt_state);
         HG_CHECK_LAUNCH("ppo_scalars_kernel");
         if (part == 0) {
-            int32_t rc0 = fused_dw(1, 1, B);
-            if (rc0) return rc0;
-            if (w.nnets > 2) {
-                rc0 = aux_grad(ppo, b);
-                if (rc0) return rc0;
-            }
-            return reduce_range(critic_off, w.P);
+            const int32_t rc0 = fused_dw(0, 1, B);
+            return rc0 ? rc0 : reduce_range(0, critic_off);
         }
         rc = fused_dw(0, 2, B);
         if (rc) return rc;
@@ -1260,7 +1260,7 @@ struct NetRunner {
         const int B = b.B, A = cfg.num_actions;
         HG_REQUIRE(B > 0 && B <= w.maxM, HGYM_E_SHAPE, "minibatch %d exceeds max_batch %lld", B, (long long)w.maxM);
         if (w.fused) return fused_grad(ppo, b, part);
-        if (part == 1) return HGYM_OK;      // layer-by-layer path: part 0 did everything
+        if (part == 1) return HGYM_OK;      // layer-by-layer path: part 0 does everything (the caller's first bucket goes out complete, just later)
         float* mu = at<float>(w.net[0].out_f32);
         float* val = at<float>(w.net[1].out_f32);
         if (hipMemsetAsync(net.grads, 0, (size_t)w.P * sizeof(float), s) != hipSuccess) HG_FAIL(HGYM_E_LAUNCH, "memset of grads failed");

@@ -136,8 +136,8 @@ class NetBuffers:
         L.check(L.lib.hgym_ppo_grad(C.byref(self.cfg), C.byref(ppo), C.byref(self.struct), C.byref(batch), self.stream()), "hgym_ppo_grad")
 
     def ppo_grad_part(self, ppo, batch, part):
-        """hgym_ppo_grad in two halves (data-parallel update): after part 0 `grads_ext[bucket_split:]` (critic | auxiliary head | KL
-        slot) is final, after part 1 `grads_ext[:bucket_split]` (std | actor)."""
+        """hgym_ppo_grad in two halves (data-parallel update): after part 0 `grads_ext[:bucket_split]` (std | actor, the larger
+        bucket) is final, after part 1 `grads_ext[bucket_split:]` (critic | auxiliary head | KL slot)."""
         L.check(L.lib.hgym_ppo_grad_part(C.byref(self.cfg), C.byref(ppo), C.byref(self.struct), C.byref(batch), int(part), self.stream()),
                 "hgym_ppo_grad_part")
 

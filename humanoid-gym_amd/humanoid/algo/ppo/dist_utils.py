@@ -1,7 +1,7 @@
 """Data-parallel glue: envs shard across ranks with no data-path collective; the only exchanges are
   * per minibatch: the in-place all-reduce (SUM) of [flat fp32 gradient (926 105) | minibatch mean KL], issued as TWO buckets
-    -- [critic | auxiliary head | KL] as soon as hgym_ppo_grad_part(0) has produced it, so that it travels under the actor's
-    weight-gradient kernels, then [std | actor] -- the means are formed inside hgym_ppo_apply, so every rank clips the same
+    -- [std | actor] (the larger one) as soon as hgym_ppo_grad_part(0) has produced it, so that it travels under the critic's (and
+    the denoiser's) weight-gradient kernels, then [critic | auxiliary head | KL] -- the means are formed inside hgym_ppo_apply, so every rank clips the same
     gradient and takes the same adaptive-KL learning-rate decision;
   * per iteration: one all-reduce of (sum adv, sum adv^2, count) so advantages are normalised over the global batch.
 Backend: torch.distributed "nccl" (= RCCL over xGMI) on the GPUs; the same functions run over "gloo" in the CPU tests."""

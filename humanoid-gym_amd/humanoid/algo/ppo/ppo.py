@@ -3,8 +3,8 @@
 act() = one hgym_policy_act call whose outputs land directly in the rollout-storage slot; process_env_step() =
 hgym_store_step (time-out bootstrap) ; compute_returns() = wavefront-scan GAE ; update() = for every minibatch
 hgym_ppo_grad (gather + forward + KL + loss + hand-written backward, all on the device, no host sync) ->
-[when torch.distributed is initialised: hgym_ppo_grad_part 0 / 1 with the RCCL all-reduce of the critic's gradient bucket
-(+ KL) running under the actor's weight-gradient kernels, then the actor's bucket] -> hgym_ppo_apply (adaptive-KL
+[when torch.distributed is initialised: hgym_ppo_grad_part 0 / 1 with the RCCL all-reduce of the actor's gradient bucket
+running under the critic's weight-gradient kernels, then the critic's bucket (+ KL)] -> hgym_ppo_apply (adaptive-KL
 learning rate, grad-norm clip, Adam, operand-shadow refresh).  The host reads the loss sums back once per update.
 """
 import os
@@ -240,13 +240,13 @@ class PPO:
                 if self._world == 1:
                     net.ppo_grad(self._ppo_cfg, batch)
                 else:
-                    # two buckets: [critic | aux | KL] is reduced across ranks while this rank's actor weight gradients are
-                    # still being computed; [std | actor] follows; apply waits (stream-side) for both
+                    # two buckets: [std | actor] (the larger one) is reduced across ranks while this rank's critic (and denoiser)
+                    # weight gradients are still being computed; [critic | aux | KL] follows; apply waits (stream-side) for both
                     split = net.bucket_split
                     net.ppo_grad_part(self._ppo_cfg, batch, 0)
-                    h0 = dist_utils.start_sum(net.grads_ext[split:])
+                    h0 = dist_utils.start_sum(net.grads_ext[:split])
                     net.ppo_grad_part(self._ppo_cfg, batch, 1)
-                    h1 = dist_utils.start_sum(net.grads_ext[:split])
+                    h1 = dist_utils.start_sum(net.grads_ext[split:])
                     probe = self.comm_timing is not None
                     if probe:
                         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))

@@ -429,9 +429,10 @@ int32_t hgym_ppo_grad(const HgymNetConfig* cfg, const HgymPPOConfig* ppo, const 
 /* hgym_ppo_grad in two halves, for the data-parallel update (one process per GPU; the reference is single-process, its
  * `--horovod` flag is dead: utils/helpers.py:207-212): the flat gradient is exchanged in two buckets so that the first
  * all-reduce runs under the second half's kernels.
- *   part 0: forward, loss, dZ chain, then the weight gradients of the CRITIC (and of the auxiliary head): on return (stream
- *           order) grads[hgym_net_param_offset(cfg, 1) .. P] -- critic | auxiliary head | the KL slot -- are final;
- *   part 1: the weight gradients of the ACTOR: grads[0 .. hgym_net_param_offset(cfg, 1)) -- std | actor -- are final.
+ *   part 0: forward, loss, dZ chain, then the weight gradients of the ACTOR: on return (stream order)
+ *           grads[0 .. hgym_net_param_offset(cfg, 1)) -- std | actor, the larger bucket (527 256 of 926 106 floats) -- are final;
+ *   part 1: the weight gradients of the CRITIC (and the auxiliary head's forward / backward / weight gradients):
+ *           grads[hgym_net_param_offset(cfg, 1) .. P] -- critic | auxiliary head | the KL slot -- are final.
  * part 0 followed by part 1 leaves net->grads exactly as hgym_ppo_grad does (bit-identical); only opt_state[9] (the squared
  * norm hgym_ppo_apply may reuse with grad_norm_ready) is not maintained: apply must be called with grad_norm_ready = 0 or
  * world_size > 1. */
