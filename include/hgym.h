@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define HGYM_VERSION 1
+#define HGYM_VERSION 2      /* 2: HgymEnvOut carries the logging sink; hgym_rollout_*, hgym_ppo_grad_part, hgym_net_param_offset */
 
 enum {
     HGYM_OK = 0,
