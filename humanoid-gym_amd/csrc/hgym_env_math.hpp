@@ -928,6 +928,30 @@ HG_HD RngKey make_rng_key(const EnvArgs& A, int64_t csc0) {
 struct __attribute__((packed, aligned(4))) EnvF4 {
     float v[4];
 };
+// The observation history (14 + 2 older frames per env read, the stacked rows and the ring slot written) is touched once per
+// step: with the non-temporal hint it does not push the policy's weight fragments -- which every actor / critic tile of the XCD
+// re-reads at the next launch -- out of the 4 MB L2 (HGYM_ENV_NT=0: plain accesses).
+#ifndef HGYM_ENV_NT
+#define HGYM_ENV_NT 1
+#endif
+typedef float envf4_nt __attribute__((ext_vector_type(4), aligned(4)));
+HG_HD EnvF4 ld_stream4(const float* p) {
+#if HGYM_ENV_NT && defined(__HIP_DEVICE_COMPILE__)
+    const envf4_nt v = __builtin_nontemporal_load(reinterpret_cast<const envf4_nt*>(p));
+    EnvF4 q = {{v[0], v[1], v[2], v[3]}};
+    return q;
+#else
+    return *reinterpret_cast<const EnvF4*>(p);
+#endif
+}
+HG_HD void st_stream4(float* p, const EnvF4& q) {
+#if HGYM_ENV_NT && defined(__HIP_DEVICE_COMPILE__)
+    const envf4_nt v = {q.v[0], q.v[1], q.v[2], q.v[3]};
+    __builtin_nontemporal_store(v, reinterpret_cast<envf4_nt*>(p));
+#else
+    *reinterpret_cast<EnvF4*>(p) = q;
+#endif
+}
 
 // components of every [C][N] state field, in HgymEnvState order (commands ... env_origins)
 constexpr int kNumStateFields = 22;
@@ -1681,8 +1705,8 @@ HG_HD void stack_new_vec(const EnvArgs& A, float* __restrict__ ring, const float
             r.v[k] = v;
             o.v[k] = clampf(v, -lim, lim);
         }
-        *reinterpret_cast<EnvF4*>(ring + ((int64_t)(e0 + le) * H + slot_new) * F + off) = r;
-        *reinterpret_cast<EnvF4*>(dst + (int64_t)le * row + (H - 1) * F + off) = o;
+        st_stream4(ring + ((int64_t)(e0 + le) * H + slot_new) * F + off, r);
+        st_stream4(dst + (int64_t)le * row + (H - 1) * F + off, o);
     }
 }
 
@@ -1752,7 +1776,7 @@ HG_HD void hist_load(const float* __restrict__ ring, int e0, int nE, int slot_ne
         const int le = i / S;
         int so, d_o;
         hist_slot<H, F>(slot_new, i - le * S, so, d_o);
-        const EnvF4 q = *reinterpret_cast<const EnvF4*>(ring + (int64_t)(e0 + le) * ROW + so);
+        const EnvF4 q = ld_stream4(ring + (int64_t)(e0 + le) * ROW + so);
         v[u][0] = q.v[0]; v[u][1] = q.v[1]; v[u][2] = q.v[2]; v[u][3] = q.v[3];
     }
 }
@@ -1771,7 +1795,7 @@ HG_HD void hist_store(float* __restrict__ dst, int e0, int nE, int slot_new, int
         EnvF4 q;
 #pragma unroll
         for (int k = 0; k < 4; ++k) q.v[k] = rs ? 0.0f : clampf(v[u][k], -lim, lim);
-        *reinterpret_cast<EnvF4*>(dst + (int64_t)(e0 + le) * ROW + d_o) = q;
+        st_stream4(dst + (int64_t)(e0 + le) * ROW + d_o, q);
     }
 }
 
