@@ -932,25 +932,30 @@ struct __attribute__((packed, aligned(4))) EnvF4 {
 // step: with the non-temporal hint it does not push the policy's weight fragments -- which every actor / critic tile of the XCD
 // re-reads at the next launch -- out of the 4 MB L2 (HGYM_ENV_NT=0: plain accesses).
 #ifndef HGYM_ENV_NT
-#define HGYM_ENV_NT 1
+#define HGYM_ENV_NT 7      // bit 0: loads of the older frames, bit 1: their stores into the stacked rows, bit 2: newest frame (ring slot + row)
 #endif
 typedef float envf4_nt __attribute__((ext_vector_type(4), aligned(4)));
+template <bool NT = true>
 HG_HD EnvF4 ld_stream4(const float* p) {
-#if HGYM_ENV_NT && defined(__HIP_DEVICE_COMPILE__)
-    const envf4_nt v = __builtin_nontemporal_load(reinterpret_cast<const envf4_nt*>(p));
-    EnvF4 q = {{v[0], v[1], v[2], v[3]}};
-    return q;
-#else
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (NT) {
+        const envf4_nt v = __builtin_nontemporal_load(reinterpret_cast<const envf4_nt*>(p));
+        EnvF4 q = {{v[0], v[1], v[2], v[3]}};
+        return q;
+    }
+#endif
     return *reinterpret_cast<const EnvF4*>(p);
-#endif
 }
+template <bool NT = true>
 HG_HD void st_stream4(float* p, const EnvF4& q) {
-#if HGYM_ENV_NT && defined(__HIP_DEVICE_COMPILE__)
-    const envf4_nt v = {q.v[0], q.v[1], q.v[2], q.v[3]};
-    __builtin_nontemporal_store(v, reinterpret_cast<envf4_nt*>(p));
-#else
-    *reinterpret_cast<EnvF4*>(p) = q;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (NT) {
+        const envf4_nt v = {q.v[0], q.v[1], q.v[2], q.v[3]};
+        __builtin_nontemporal_store(v, reinterpret_cast<envf4_nt*>(p));
+        return;
+    }
 #endif
+    *reinterpret_cast<EnvF4*>(p) = q;
 }
 
 // components of every [C][N] state field, in HgymEnvState order (commands ... env_origins)
@@ -1705,8 +1710,8 @@ HG_HD void stack_new_vec(const EnvArgs& A, float* __restrict__ ring, const float
             r.v[k] = v;
             o.v[k] = clampf(v, -lim, lim);
         }
-        st_stream4(ring + ((int64_t)(e0 + le) * H + slot_new) * F + off, r);
-        st_stream4(dst + (int64_t)le * row + (H - 1) * F + off, o);
+        st_stream4<(HGYM_ENV_NT & 4) != 0>(ring + ((int64_t)(e0 + le) * H + slot_new) * F + off, r);
+        st_stream4<(HGYM_ENV_NT & 4) != 0>(dst + (int64_t)le * row + (H - 1) * F + off, o);
     }
 }
 
@@ -1776,7 +1781,7 @@ HG_HD void hist_load(const float* __restrict__ ring, int e0, int nE, int slot_ne
         const int le = i / S;
         int so, d_o;
         hist_slot<H, F>(slot_new, i - le * S, so, d_o);
-        const EnvF4 q = ld_stream4(ring + (int64_t)(e0 + le) * ROW + so);
+        const EnvF4 q = ld_stream4<(HGYM_ENV_NT & 1) != 0>(ring + (int64_t)(e0 + le) * ROW + so);
         v[u][0] = q.v[0]; v[u][1] = q.v[1]; v[u][2] = q.v[2]; v[u][3] = q.v[3];
     }
 }
@@ -1795,7 +1800,7 @@ HG_HD void hist_store(float* __restrict__ dst, int e0, int nE, int slot_new, int
         EnvF4 q;
 #pragma unroll
         for (int k = 0; k < 4; ++k) q.v[k] = rs ? 0.0f : clampf(v[u][k], -lim, lim);
-        st_stream4(dst + (int64_t)(e0 + le) * ROW + d_o, q);
+        st_stream4<(HGYM_ENV_NT & 2) != 0>(dst + (int64_t)(e0 + le) * ROW + d_o, q);
     }
 }
 
