@@ -213,7 +213,7 @@ def _roofline(L, runner, elapsed_per_iter_ms, precision, n_profiled_iters):
     mfma_peak = MFMA_BF16_PEAK_TFLOPS if precision == "bf16" else 157.3
     classes = [  # (class id, kernel, bound)
         (L.PROF_ROLLOUT, "rollout_step_kernel", "hbm"),      # policy act + env step + previous finaliser, one launch per vec-step
-        (L.PROF_ENV_STEP, "env_step_kernel", "hbm"), (L.PROF_MLP_FWD, "mlp_fwd_kernel", "mfma"),
+        (L.PROF_ENV_STEP, "env_step_kernel", "hbm"), (L.PROF_MLP_FWD, "mlp_fb_kernel", "mfma"),        # the update: forward + loss + dZ chain of a 64-row tile
         (L.PROF_POLICY, "mlp_fwd_kernel<32>", "mfma"),
         (L.PROF_MLP_BWD, "mlp_bwd_kernel", "mfma"), (L.PROF_DW, "dw_kernel", "mfma"), (L.PROF_GEMM, "gemm_nt_kernel", "mfma"),
         (L.PROF_LOSS, "ppo_loss_kernel", "hbm"), (L.PROF_REDUCE, "reduce_slabs_kernel", "hbm"),

@@ -1,11 +1,13 @@
-// hgym_fused.hpp -- the bf16 fast path of the actor/critic: three kernels that replace ~70 launches per minibatch.
+// hgym_fused.hpp -- the bf16 fast path of the actor / critic (/ auxiliary head): three kernels that replace ~70 launches per minibatch.
 //
 //   mlp_fwd_kernel<BM>   gather + fp32->bf16 + Linear/ELU x3 + head (+ Gaussian sample / log-prob) for a tile of BM rows;
 //                        activations never leave the CU between layers (LDS), weights stream from L2 straight into
-//                        MFMA operand registers.  Used by the rollout (PPO.act, BM = 32) and by the update (BM = 64,
-//                        which also writes the activations the backward pass needs).
-//   mlp_bwd_kernel<BM>   dZ_l = (dZ_{l+1} * W_{l+1}) .* elu'(H_l) for l = 2, 1, 0 in one launch, same structure.
-//   dw_kernel_rs         all eight weight-gradient products dW_l = dZ_l^T * X_l (+ bias gradients) in ONE launch:
+//                        MFMA operand registers.  Used by the rollout (PPO.act, BM = 32; hgym_rollout.hip puts the env step of
+//                        the tile's 32 envs behind it in the same launch) and for inference.
+//   mlp_fb_kernel        the update: the same forward on 64-row tiles, the loss gradient on the head wavefronts (PPO surrogate /
+//                        value loss / the auxiliary head's MSE) and dZ_l = (dZ_{l+1} * W_{l+1}) .* elu'(H_l) for l = 2, 1, 0 on the
+//                        activations still resident in LDS; one grid row per net.
+//   dw_kernel_rs         all weight-gradient products dW_l = dZ_l^T * X_l (+ bias gradients) in ONE launch:
 //                        contraction over the batch, operands staged registers -> LDS and read with the gfx950
 //                        transpose read (ds_read_b64_tr_b16), so no transposed copy of anything exists in HBM.
 //
@@ -380,7 +382,7 @@ __device__ __forceinline__ float log_sigma(float s) { return __fmul_rn(__builtin
 
 struct FwdArgs {
     long long* dbg;
-    FusedNet net[3];           // 0 actor, 1 critic, 2 auxiliary head (launched on its own: net0 = 2, one grid row)
+    FusedNet net[3];           // 0 actor, 1 critic, 2 auxiliary head
     int net0;                 // net index of blockIdx.y == 0
     int M;
     const int64_t* idx;       // optional row gather
@@ -404,8 +406,8 @@ struct FwdArgs {
 // layer and the second, where the first layer's weight ring and accumulators are dead and ~60 registers are free for loads that
 // may take the rest of the tile to arrive (the observation history); `put_action(row, j, a)` receives every sampled action of
 // the tile (row within the tile, action index) so that the env phase reads them from LDS; `idle()` runs on the wavefronts that
-// have no head block while the others compute the head; `head(wave, row, out[4])` runs on the head wavefronts with each lane's
-// row and its four head outputs (the fused forward + backward kernel computes the PPO loss gradient there).  They are lambdas that capture the
+// have no head block while the others compute the head; `head(wave, row, nb, out[4])` runs on the head wavefronts with each lane's
+// row, the head's 16-column block and its four head outputs (the fused forward + backward kernel computes the PPO loss gradient there).  They are lambdas that capture the
 // caller's locals by reference (a hook OBJECT carrying the prefetch arrays as members was kept in private memory by the
 // compiler: 500 scratch instructions and a kernel four times slower).
 // `extra` (whatever the hooks need from the kernel argument) reaches them as a call PARAMETER: a closure that captured a
@@ -414,7 +416,7 @@ struct FwdArgs {
 struct FwdNoop {
     template <class X> __device__ __forceinline__ void operator()(const X&) const {}
     __device__ __forceinline__ void operator()(int, int, float) const {}
-    __device__ __forceinline__ void operator()(int, int, const float (&)[4]) const {}
+    __device__ __forceinline__ void operator()(int, int, int, const float (&)[4]) const {}
 };
 
 template <int BM, int NW, int D, int G1, bool WIDE = false, class Early = FwdNoop, class Mid = FwdNoop, class Put = FwdNoop, class Extra = int,
@@ -438,7 +440,7 @@ __device__ __forceinline__ void fwd_body(const FwdArgs& a, const FusedNet& n, bo
     const FusedLayer& L1 = n.layer[1];
     const FusedLayer& L2 = n.layer[2];
     const FusedLayer& L3 = n.layer[3];
-    const int train = a.train & 1, train_h = a.train & 2;     // bit 0: write X0, bit 1: write H[] (both set by the update)
+    const int train = (a.train & 1) && n.X0, train_h = a.train & 2;     // bit 0: write X0 (a net without an X0 buffer shares another net's copy of the same rows), bit 1: write H[]
     // the four bias vectors -> LDS: the loads are issued here, ahead of everything else, and parked in registers; they are
     // written to LDS next to the first input chunk, so no epilogue ever waits on a cold global load
     float* bl = reinterpret_cast<float*>(smem + fused_lds_p(n, BM) + fused_lds_q(n, BM));
@@ -585,12 +587,12 @@ __device__ __forceinline__ void fwd_body(const FwdArgs& a, const FusedNet& n, bo
         float mu[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) mu[e] = acc[e] + ((4 * q + e < No) ? bl[L0.N + L1.N + L2.N + 4 * q + e] : 0.0f);
-        if (m < a.M) {
+        if (m < a.M && n.out) {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
                 if (4 * q + e < No) n.out[(int64_t)m * n.ldo + 4 * q + e] = mu[e];
         }
-        hook_head(wave, m, mu);     // `idle()`'s counterpart: every lane of the head wavefronts, with its row and its 4 head outputs
+        hook_head(wave, m, 0, mu);  // `idle()`'s counterpart: every lane of the head wavefronts, with its row, the head's column block and its 4 outputs
         if (is_actor && a.sample) {
 #pragma clang fp contract(off)      // a = mu + sigma z and the log-probability as separate fp32 roundings, identically in every translation unit
             const int A = a.A;
@@ -633,13 +635,18 @@ __device__ __forceinline__ void fwd_body(const FwdArgs& a, const FusedNet& n, bo
             hacc[0][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
             if (L3.KB % 4 == 0) mma_stream<1, 1, 4>(r3, wl, 0, L3.KB, PH2 + wave * CB3 * 512, CB3, lane, hacc);
             else mma_ring<1, 1, 4>(r3, wl, 0, 0, L3.KB, L3.KB, PH2 + wave * CB3 * 512, CB3, lane, hacc);
-            if (m < a.M) {
+            float y[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int col = nb * 16 + 4 * q + e;
-                    if (col < No) n.out[(int64_t)m * n.ldo + col] = hacc[0][0][e] + bl[L0.N + L1.N + L2.N + col];
-                }
+            for (int e = 0; e < 4; ++e) {
+                const int col = nb * 16 + 4 * q + e;
+                y[e] = hacc[0][0][e] + (col < No ? bl[L0.N + L1.N + L2.N + col] : 0.0f);
             }
+            if (m < a.M && n.out) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (nb * 16 + 4 * q + e < No) n.out[(int64_t)m * n.ldo + nb * 16 + 4 * q + e] = y[e];
+            }
+            hook_head(wave, m, nb, y);
         }
     } else {
         hook_idle(extra);      // the wavefronts without a head block (NW - BM / 16 of them): free for the duration of the head
@@ -668,13 +675,6 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(const FwdArgs a) {
 }
 
 // ================================================================================================ backward (dX chain)
-struct BwdArgs {
-    long long* dbg;
-    FusedNet net[3];           // 0 actor, 1 critic, 2 auxiliary head (launched on its own: net0 = 2, one grid row)
-    int net0;
-    int M;
-};
-
 // dZ_out[m][k'] = (sum_n dZ_in[m][n] * W[n][k']) * elu'(H[m][k']): W^T fragments as the MFMA A operand.
 // R: ring primed with this wave's first strip (bwd_prime); prime_next: called before the epilogue of the last strip.
 template <int G, int D, int GR>
@@ -727,61 +727,8 @@ __device__ __forceinline__ void bwd_step(WRing<GR, D>& R, const u32x4* __restric
     if (AHEAD && !primed) prime_next();
 }
 
-template <int BM, int NW, int D, int G0>
-__device__ __forceinline__ void bwd_body(const BwdArgs& a, const FusedNet& n, char* smem) {
-    constexpr int MB = BM / 16;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m0 = blockIdx.x * BM;
-    const int64_t mbg0 = m0 >> 4;
-    const int N0 = n.layer[0].N, N1 = n.layer[1].N, N2 = n.layer[2].N;
-    const int NBB3 = n.layer[3].NBB;    // head gradient tile: BM x 32 * NBB3 (1 for the actor / critic heads)
-    char* R0 = smem;
-    char* R1 = R0 + BM * 64 * NBB3;     // dZ2 tile: BM x N2
-    char* R2 = R1 + BM * N2 * 2;        // dZ1 tile: BM x N1
-    constexpr bool AHEAD = NW <= 8;
-    constexpr int GH = NW <= 8 ? 2 : 1;
-    WRing<1, D> ra;
-    WRing<GH, D> rb;
-    WRing<G0, D> rc;
-    phase_stamp(a.dbg, 0);
-    bwd_prime<1, D>(ra, n.layer[3].WTf, N2 / 16, NBB3, wave, lane);
-    {
-        const u32x4* src = reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(n.dZ[3]) + mbg0 * 2 * NBB3 * 512);
-        for (int i = tid; i < BM * 4 * NBB3; i += NW * 64) reinterpret_cast<u32x4*>(R0)[i] = src[i];
-    }
-    __syncthreads();
-    auto prime_b = [&]() { bwd_prime<GH, D>(rb, n.layer[2].WTf, N1 / 16, n.layer[2].NBB, wave, lane); };
-    auto prime_c = [&]() { bwd_prime<G0, D>(rc, n.layer[1].WTf, N0 / 16, n.layer[1].NBB, wave, lane); };
-    auto none = [&]() {};
-    phase_stamp(a.dbg, 1);
-    // l = 2: through W3 (head)
-    bwd_step<1, MB, NW, D, AHEAD>(ra, n.layer[3].WTf, N2 / 16, NBB3, R0, 2 * NBB3, R1, n.dZ[2], n.H[2], mbg0, wave, lane, prime_b);
-    __syncthreads();
-    phase_stamp(a.dbg, 2);
-    if (!AHEAD) prime_b();
-    // l = 1: through W2
-    bwd_step<GH, MB, NW, D, AHEAD>(rb, n.layer[2].WTf, N1 / 16, n.layer[2].NBB, R1, N2 / 16, R2, n.dZ[1], n.H[1], mbg0, wave, lane, prime_c);
-    __syncthreads();
-    phase_stamp(a.dbg, 3);
-    if (!AHEAD) prime_c();
-    // l = 0: through W1 (widest: 256 / 512 / 768 columns)
-    bwd_step<G0, MB, NW, D, AHEAD>(rc, n.layer[1].WTf, N0 / 16, n.layer[1].NBB, R2, N1 / 16, nullptr, n.dZ[0], n.H[0], mbg0, wave, lane, none);
-    phase_stamp(a.dbg, 4);
-}
-
-template <int BM, int NW, int D>
-__global__ __launch_bounds__(NW * 64) void mlp_bwd_kernel(const BwdArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const FusedNet& n = a.net[a.net0 + blockIdx.y];
-    const int g0 = n.layer[0].N / 16 / NW;     // first hidden width 256 / 512 / 768
-    constexpr int U = 16 / NW;
-    if (g0 == 2 * U) bwd_body<BM, NW, D, 2 * U>(a, n, smem);
-    else if (g0 == 3 * U) bwd_body<BM, NW, D, 3 * U>(a, n, smem);
-    else if (g0 == U) bwd_body<BM, NW, D, U>(a, n, smem);
-}
-
 // ================================================================================================ forward + loss + dZ chain
-// One kernel per minibatch instead of mlp_fwd_kernel -> ppo_loss_kernel -> ppo_scalars' inputs -> mlp_bwd_kernel: a tile's
+// One kernel per minibatch instead of forward -> loss -> backward launches: a tile's
 // forward leaves H1 and H2 in LDS (the two ping-pong buffers), the head wavefronts turn their outputs into the PPO loss gradient
 // (the per-sample arithmetic of ppo_loss_kernel, one lane per (row, 4 actions)) -- dZ3 goes to LDS and to HBM -- and the dZ chain
 // runs on the resident tile: through W3 against H2 (LDS, in place), through W2 against H1 (LDS, in place), through W1 against
@@ -797,16 +744,21 @@ struct FbLoss {
     const float* logp;
     float clip, value_coef, entropy_coef;
     float* partials;           // [tiles][32] per-tile sums, ppo_loss_kernel's layout: 0 surrogate, 1 value loss, 2 entropy, 3 kl,
-                               // 4..15 d std, 16..27 sum d mu (head bias gradient), 28 sum d V; the actor tile writes its entries, the
-                               // critic tile its two
+                               // 4..15 d std, 16..27 sum d mu (head bias gradient), 28 sum d V, 29 the auxiliary head's squared error;
+                               // the actor tile writes its entries, the critic tile its two, the auxiliary tile its one
+    // auxiliary (denoising) head, a third grid row: MSE against columns [aux_off, aux_off + layer[3].N) of the gathered target rows
+    const float* aux_target;
+    int64_t aux_ldt;
+    int aux_off;
+    float aux_coef;
 };
 
-// LDS of the fused kernel behind the forward's P / Q / bias regions: the dZ3 tile (64 rows x 32 bf16 columns), the head waves'
-// partial sums, and H2 (64 x layer[2].N bf16) -- the forward writes it there instead of over H0, so that all three activations
-// are resident for the dZ chain
-HG_HD int fb_lds_extra(const FusedNet& n) { return 64 * 64 + 4 * 32 * 4 + 64 * n.layer[2].N * 2; }
+// LDS of the fused kernel behind the forward's P / Q / bias regions: the dZ3 tile (64 rows x 32 * layer[3].NBB bf16 columns), the
+// head waves' partial sums, and H2 (64 x layer[2].N bf16) -- the forward writes it there instead of over H0, so that all three
+// activations are resident for the dZ chain
+HG_HD int fb_lds_extra(const FusedNet& n) { return 64 * 64 * n.layer[3].NBB + 4 * 32 * 4 + 64 * n.layer[2].N * 2; }
 
-template <int G1>
+template <int G1, bool AUX = false>
 __device__ __forceinline__ void fb_body(const FwdArgs& a, const FbLoss& L, const FusedNet& n, bool is_actor, char* smem) {
     constexpr int BM = 64, NW = 16, D = 2, MB = BM / 16;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -816,11 +768,46 @@ __device__ __forceinline__ void fb_body(const FwdArgs& a, const FbLoss& L, const
     char* P = smem;
     char* Q = smem + fused_lds_p(n, BM);
     char* R0 = smem + fused_lds_p(n, BM) + fused_lds_q(n, BM) + fused_lds_bias(n);
-    float* red = reinterpret_cast<float*>(R0 + BM * 64);
-    char* H2 = R0 + BM * 64 + 4 * 32 * 4;
+    const int NBB3 = n.layer[3].NBB, CB3 = 2 * NBB3;      // the head gradient's column blocks of 16 (padded to the backward's k-steps of 32)
+    float* red = reinterpret_cast<float*>(R0 + BM * 64 * NBB3);
+    char* H2 = R0 + BM * 64 * NBB3 + 4 * 32 * 4;
     const int A = a.A;
     const float invB = 1.0f / (float)a.M;
-    auto head = [&](int hw, int m, const float (&out)[4]) {
+    float aux_se = 0.0f;
+    // auxiliary head: lane (r, q) of head wave hw, row m, outputs nb * 16 + 4q .. + 3 (called once per column block).
+    // loss = coef * mean_b sum_j (y - t)^2 / No, dL/dy = 2 coef (y - t) / (B No)    (aux_mse_kernel's arithmetic)
+    auto head_aux = [&](int hw, int m, int nb, const float (&out)[4]) {
+        const int No = n.layer[3].N;
+        const bool valid = m < a.M;
+        const int64_t row = a.idx ? a.idx[valid ? m : a.M - 1] : (int64_t)(valid ? m : a.M - 1);
+        const float* t = L.aux_target + row * L.aux_ldt + L.aux_off;
+        const float gs = 2.0f * L.aux_coef / ((float)a.M * (float)No);
+        float g[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int j = nb * 16 + 4 * q + e;
+            float d = 0.0f;
+            if (valid && j < No) {
+                d = out[e] - t[j];
+                aux_se += d * d;
+            }
+            g[e] = gs * d;
+        }
+        const u32x2 pk = pack_bf16x4(g[0], g[1], g[2], g[3]);
+        const int off = (hw * CB3 + nb) * 512 + r * 32 + q * 8;
+        char* gz = reinterpret_cast<char*>(n.dZ[3]) + mbg0 * CB3 * 512;
+        *reinterpret_cast<u32x2*>(R0 + off) = pk;
+        *reinterpret_cast<u32x2*>(gz + off) = pk;
+        if (nb == 0) {      // the padding blocks behind the head's last one
+            const u32x2 zero = {0u, 0u};
+            for (int cb = n.layer[3].NB; cb < CB3; ++cb) {
+                const int offz = (hw * CB3 + cb) * 512 + r * 32 + q * 8;
+                *reinterpret_cast<u32x2*>(R0 + offz) = zero;
+                *reinterpret_cast<u32x2*>(gz + offz) = zero;
+            }
+        }
+    };
+    auto head = [&](int hw, int m, int, const float (&out)[4]) {
         // lane (r, q) of head wave hw: row m, head outputs 4q .. 4q + 3.  ppo.py:128-168 forward scalars + the hand-written
         // backward of the loss w.r.t. mu, std and V (oracle/ppo_oracle.py: ppo_loss_and_grads), as in ppo_loss_kernel
         const bool valid = m < a.M;
@@ -920,15 +907,23 @@ __device__ __forceinline__ void fb_body(const FwdArgs& a, const FbLoss& L, const
             }
         }
     };
-    fwd_body<BM, NW, D, G1, false>(a, n, is_actor, smem, FwdNoop(), FwdNoop(), FwdNoop(), 0, FwdNoop(), head, H2);
+    if constexpr (AUX) {
+        fwd_body<BM, NW, D, G1, true>(a, n, false, smem, FwdNoop(), FwdNoop(), FwdNoop(), 0, FwdNoop(), head_aux, H2);
+        if (wave < MB) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) aux_se += __shfl_xor(aux_se, o, 64);
+            if (lane == 0) red[wave * 32 + 29] = aux_se;
+        }
+    } else {
+        fwd_body<BM, NW, D, G1, false>(a, n, is_actor, smem, FwdNoop(), FwdNoop(), FwdNoop(), 0, FwdNoop(), head, H2);
+    }
     __syncthreads();          // dZ3 tile and the per-wave sums are in LDS; H0 sits in P, H1 in Q, H2 in its own buffer
     if (tid < 32) {
-        const bool mine = is_actor ? (tid != 1 && tid < 28) : (tid == 1 || tid == 28);
+        const bool mine = AUX ? tid == 29 : (is_actor ? (tid != 1 && tid < 28) : (tid == 1 || tid == 28));
         if (mine) L.partials[(int64_t)blockIdx.x * 32 + tid] = red[tid] + red[32 + tid] + red[64 + tid] + red[96 + tid];
     }
-    // ---- dZ chain on the resident tile (mlp_bwd_kernel's steps)
+    // ---- dZ chain on the resident tile
     const int N0 = n.layer[0].N, N1 = n.layer[1].N, N2 = n.layer[2].N;
-    const int NBB3 = n.layer[3].NBB;
     WRing<1, D> ra;
     WRing<1, D> rb;
     WRing<G1, D> rc;
@@ -950,6 +945,10 @@ __global__ __launch_bounds__(1024) void mlp_fb_kernel(const FwdArgs a, const FbL
     const int which = a.net0 + blockIdx.y;
     const FusedNet& n = a.net[which];
     const int g1 = n.layer[0].NB / 16;     // first hidden width 256 / 512 / 768
+    if (which == 2) {                      // the auxiliary head (wide head, first hidden width 512 only): MSE instead of the PPO loss
+        if (g1 == 2) fb_body<2, true>(a, L, n, false, smem);
+        return;
+    }
     if (g1 == 2) fb_body<2>(a, L, n, which == 0, smem);
     else if (g1 == 3) fb_body<3>(a, L, n, which == 0, smem);
     else if (g1 == 1) fb_body<1>(a, L, n, which == 0, smem);
@@ -962,7 +961,7 @@ __global__ __launch_bounds__(1024) void mlp_fb_kernel(const FwdArgs a, const FbL
 #endif
 constexpr int DW_THREADS = 256;
 constexpr int DW_STAGE_BYTES = 16384;     // 32 rows x (8 Z blocks + 8 X blocks) x 512 B
-constexpr int DW_MAX_PRODUCTS = 8;
+constexpr int DW_MAX_PRODUCTS = 12;    // actor + critic + auxiliary head, four layers each
 
 struct DwProduct {
     const __bf16* Z;      // block layout, CBz column blocks per row block

@@ -261,45 +261,6 @@ __global__ __launch_bounds__(256) void aux_mse_kernel(int B, int Bp, int No, con
     if (threadIdx.x == 0) atomicAdd(&opt[10], (double)(red[0] + red[1] + red[2] + red[3]) / ((double)B * (double)No));
 }
 
-// The same for the fused path: dL/dy as bf16 in block layout (row block m >> 4, CB3 column blocks of 16: block (mb, cb) at
-// (mb * CB3 + cb) * 512 bytes, 32 bytes per row), zero in the padding columns No..16*CB3 and in the padding rows B..Bp.
-__global__ __launch_bounds__(256) void aux_mse_fused_kernel(int B, int Bp, int No, int CB3, const float* __restrict__ y,
-                                                            const float* __restrict__ priv, int64_t ldp, int off,
-                                                            const int64_t* __restrict__ idx, float coef, __bf16* __restrict__ dZ3,
-                                                            double* __restrict__ opt) {
-    __shared__ float red[4];
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    float se = 0.0f;
-    if (i < Bp) {
-        char* row = reinterpret_cast<char*>(dZ3) + ((int64_t)(i >> 4) * CB3) * 512 + (i & 15) * 32;
-        const float* t = i < B ? priv + idx[i] * ldp + off : nullptr;
-        const float g = 2.0f * coef / ((float)B * (float)No);
-        for (int cb = 0; cb < CB3; ++cb) {
-            float v[16];
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int j = cb * 16 + e;
-                float d = 0.0f;
-                if (t && j < No) {
-                    d = y[(int64_t)i * No + j] - t[j];
-                    se += d * d;
-                }
-                v[e] = g * d;
-            }
-            const u32x2 p0 = pack_bf16x4(v[0], v[1], v[2], v[3]), p1 = pack_bf16x4(v[4], v[5], v[6], v[7]);
-            const u32x2 p2 = pack_bf16x4(v[8], v[9], v[10], v[11]), p3 = pack_bf16x4(v[12], v[13], v[14], v[15]);
-            u32x4* dst = reinterpret_cast<u32x4*>(row + (int64_t)cb * 512);
-            dst[0] = (u32x4){p0[0], p0[1], p1[0], p1[1]};
-            dst[1] = (u32x4){p2[0], p2[1], p3[0], p3[1]};
-        }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) se += __shfl_down(se, o, 64);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = se;
-    __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(&opt[10], (double)(red[0] + red[1] + red[2] + red[3]) / ((double)B * (double)No));
-}
-
 // PPO.act epilogue (actor_critic.py:111-120): a = mu + sigma*z, logp = sum log N(a; mu, sigma); sigma = std.
 __global__ __launch_bounds__(256) void act_sample_kernel(int M, int A, const float* __restrict__ mu, const float* __restrict__ std_,
                                                          const float* __restrict__ z, uint64_t seed, const int64_t* __restrict__ step,
@@ -496,7 +457,7 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(const LossArgs a) {
 __global__ __launch_bounds__(512) void ppo_scalars_kernel(int nblocks, int B, int A, const float* __restrict__ partials,
                                                           float* __restrict__ grads_std, float* __restrict__ grads_bmu,
                                                           float* __restrict__ grads_bv, float* __restrict__ kl_slot,
-                                                          double* __restrict__ opt) {
+                                                          double* __restrict__ opt, int aux_No = 0) {
     __shared__ double red[16][LOSS_PARTIALS + 1];
     const int k = threadIdx.x & (LOSS_PARTIALS - 1), part = threadIdx.x / LOSS_PARTIALS;   // 16 partial sums per quantity
     // four independent partial sums per thread (combined in a fixed order): a single dependent chain of nblocks / 16 loads was
@@ -528,6 +489,7 @@ __global__ __launch_bounds__(512) void ppo_scalars_kernel(int nblocks, int B, in
         if (q >= 4 && q < 16 && q - 4 < A) grads_std[q - 4] = (float)t;
         if (q >= 16 && q < 28 && q - 16 < A && grads_bmu) grads_bmu[q - 16] = (float)t;
         if (q == 28 && grads_bv) grads_bv[0] = (float)t;
+        if (q == 29 && aux_No > 0) opt[10] += t / ((double)B * (double)aux_No);    // auxiliary head's MSE (the fused kernel's third grid row)
     }
 }
 
@@ -564,22 +526,27 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const SegTable tab, i
             const float g = grads[sg.off + i];
             sq += (double)g * (double)g;
         }
-    } else if (((sg.off | n) & 3) == 0 && (P & 3) == 0 && (((uintptr_t)grads) & 15) == 0) {   // 16-byte path (P = slab stride)
-        const int64_t n4 = n >> 2;
+    } else {
+        // 16-byte body between a scalar head and tail: a segment need not start on a 16-byte boundary of the flat vector (the
+        // critic's one-element head bias puts every segment of the auxiliary net at offset = 1 mod 4)
+        const bool vec = (P & 3) == 0 && (((uintptr_t)grads | (uintptr_t)slabs) & 15) == 0;      // P = slab stride
+        const int64_t head = vec ? ((4 - (sg.off & 3)) & 3) < n ? ((4 - (sg.off & 3)) & 3) : n : n;
+        const int64_t n4 = (n - head) >> 2, tail0 = head + 4 * n4;
+        const int64_t base = sg.off + head;
         for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
             for (int z = 0; z < sg.splits; ++z) {
-                const float4 v = *reinterpret_cast<const float4*>(slabs + (int64_t)z * P + sg.off + 4 * i);
+                const float4 v = *reinterpret_cast<const float4*>(slabs + (int64_t)z * P + base + 4 * i);
                 acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
             }
-            *reinterpret_cast<float4*>(grads + sg.off + 4 * i) = acc;
+            *reinterpret_cast<float4*>(grads + base + 4 * i) = acc;
             sq += (double)acc.x * (double)acc.x + (double)acc.y * (double)acc.y + (double)acc.z * (double)acc.z + (double)acc.w * (double)acc.w;
         }
-    } else {
-        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < head + (n - tail0); i += stride) {
+            const int64_t e = i < head ? i : tail0 + (i - head);
             float s = 0.0f;
-            for (int z = 0; z < sg.splits; ++z) s += slabs[(int64_t)z * P + sg.off + i];
-            grads[sg.off + i] = s;
+            for (int z = 0; z < sg.splits; ++z) s += slabs[(int64_t)z * P + sg.off + e];
+            grads[sg.off + e] = s;
             sq += (double)s * (double)s;
         }
     }
@@ -889,6 +856,8 @@ struct NetRunner {
     }
 
     // all weight (and hidden bias) gradients of nets [first, first + count): one launch, split-K slabs
+    // (the auxiliary head, net 2, reads the ACTOR's bf16 copy of the gathered observation rows as its first-layer operand -- same
+    // rows, same columns -- and every bias gradient of it is a column sum of dZ: its loss has no per-tile partial sums for them)
     int32_t fused_dw(int first, int count, int B) {
         const int Bp = (int)round_up(B, 64);
         DwArgs d;
@@ -899,15 +868,16 @@ struct NetRunner {
             for (int l = 0; l < 4; ++l) {
                 const NetLayout& n = w.net[i];
                 const LayerLayout& y = n.layer[l];
+                HG_REQUIRE(d.np < DW_MAX_PRODUCTS, HGYM_E_UNSUPPORTED, "too many weight-gradient products in one launch");
                 DwProduct& p = d.p[d.np++];
                 p.Z = at<__bf16>(n.dZb[l]);
-                p.CBz = l < 3 ? y.N / 16 : 2;
-                p.X = l == 0 ? at<__bf16>(n.X0b) : at<__bf16>(n.Hb[l - 1]);
+                p.CBz = l < 3 ? y.N / 16 : 2 * y.NBBf;
+                p.X = l == 0 ? at<__bf16>(w.net[i == 2 ? 0 : i].X0b) : at<__bf16>(n.Hb[l - 1]);
                 p.CBx = l == 0 ? 2 * y.KBf : y.K / 16;
                 p.N = y.N;
                 p.K = y.K;
                 p.w_off = y.w_off;
-                p.b_off = l < 3 ? y.b_off : -1;
+                p.b_off = (l < 3 || i == 2) ? y.b_off : -1;
                 p.tiles_n = ceil_div(y.N, 128);
                 p.tiles_k = ceil_div(y.K, 128);
                 p.tile0 = tile;
@@ -952,10 +922,11 @@ struct NetRunner {
     int32_t fused_grad(const HgymPPOConfig& ppo, const HgymBatch& b, int part = -1) {
         const int B = b.B, A = cfg.num_actions;
         const int64_t critic_off = w.net[1].layer[0].w_off;
+        const bool aux_fb = w.nnets > 2 && w.fused_aux;      // the auxiliary head as a third grid row of the same launches
         if (part == 1) {
-            int32_t rc1 = fused_dw(1, 1, B);
+            int32_t rc1 = fused_dw(1, aux_fb ? 2 : 1, B);
             if (rc1) return rc1;
-            if (w.nnets > 2) {
+            if (w.nnets > 2 && !aux_fb) {
                 rc1 = aux_grad(ppo, b);
                 if (rc1) return rc1;
             }
@@ -963,17 +934,19 @@ struct NetRunner {
         }
         float* mu = at<float>(w.net[0].out_f32);
         float* val = at<float>(w.net[1].out_f32);
-        const float* xs[3] = {b.obs, b.priv, nullptr};
-        const int64_t ldxs[3] = {cfg.num_obs, cfg.num_priv, 0};
+        const float* xs[3] = {b.obs, b.priv, b.obs};
+        const int64_t ldxs[3] = {cfg.num_obs, cfg.num_priv, cfg.num_obs};
         float* outs[3] = {mu, val, nullptr};
         const int64_t ldos[3] = {A, 1, 0};
         const int Bp = (int)round_up(B, 64);
         const int tiles = Bp / 64;
+        const int nets = aux_fb ? 3 : 2;
         HG_REQUIRE(tiles <= MAX_LOSS_BLOCKS, HGYM_E_UNSUPPORTED, "minibatch %d too large for the loss partial buffer", B);
         HG_REQUIRE(B <= w.maxM, HGYM_E_SHAPE, "minibatch %d exceeds max_batch %lld", B, (long long)w.maxM);
         int32_t rc = HGYM_OK;
         {   // forward + PPO loss + dZ chain of both nets: ONE launch (hgym_fused.hpp: mlp_fb_kernel)
-            const FwdArgs fa = make_fwd_args(0, 2, B, xs, ldxs, b.idx, outs, ldos, true, nullptr, nullptr);
+            FwdArgs fa = make_fwd_args(0, nets, B, xs, ldxs, b.idx, outs, ldos, true, nullptr, nullptr);
+            fa.net[2].X0 = nullptr;       // the head's first-layer operand for the weight gradient is the actor's copy (fused_dw)
             FbLoss fl;
             memset(&fl, 0, sizeof(fl));
             fl.actions = b.actions;
@@ -987,8 +960,12 @@ struct NetRunner {
             fl.value_coef = ppo.value_loss_coef;
             fl.entropy_coef = ppo.entropy_coef;
             fl.partials = at<float>(w.partials);
+            fl.aux_target = b.priv;
+            fl.aux_ldt = cfg.num_priv;
+            fl.aux_off = cfg.aux_target_offset;
+            fl.aux_coef = ppo.aux_coef;
             size_t lds = 0;
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < nets; ++i)
                 lds = std::max(lds, (size_t)fused_lds_p(fa.net[i], 64) + (size_t)fused_lds_q(fa.net[i], 64) + (size_t)fused_lds_bias(fa.net[i]) +
                                         (size_t)fb_lds_extra(fa.net[i]));
             HG_REQUIRE(lds <= 160 * 1024, HGYM_E_UNSUPPORTED, "mlp_fb_kernel needs %zu bytes of LDS", lds);
@@ -999,12 +976,12 @@ struct NetRunner {
                 attr_lds = lds;
             }
             FwdArgs fb = fa;
-            fb.nets = 2;
-            fb.dbg = phase_buffer((int64_t)tiles * 2);
+            fb.nets = nets;
+            fb.dbg = phase_buffer((int64_t)tiles * nets);
             prof_begin(HGYM_PROF_MLP_FWD, s);
-            hipLaunchKernelGGL(mlp_fb_kernel<0>, dim3(tiles, 2), dim3(1024), lds, s, fb, fl);
+            hipLaunchKernelGGL(mlp_fb_kernel<0>, dim3(tiles, nets), dim3(1024), lds, s, fb, fl);
             double flops = 0.0;
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < nets; ++i) {
                 for (int l = 0; l < 4; ++l) flops += 2.0 * (double)B * w.net[i].layer[l].N * w.net[i].layer[l].K;
                 for (int l = 1; l < 4; ++l) flops += 2.0 * (double)B * w.net[i].layer[l].K * w.net[i].layer[l].N;
             }
@@ -1012,15 +989,16 @@ struct NetRunner {
             HG_CHECK_LAUNCH("mlp_fb_kernel");
         }
         hipLaunchKernelGGL(ppo_scalars_kernel, dim3(1), dim3(512), 0, s, tiles, B, A, at<float>(w.partials), net.grads,
-                           net.grads + w.net[0].layer[3].b_off, net.grads + w.net[1].layer[3].b_off, net.grads + w.P, net.opt_state);
+                           net.grads + w.net[0].layer[3].b_off, net.grads + w.net[1].layer[3].b_off, net.grads + w.P, net.opt_state,
+                           aux_fb ? w.net[2].layer[3].N : 0);
         HG_CHECK_LAUNCH("ppo_scalars_kernel");
         if (part == 0) {
             const int32_t rc0 = fused_dw(0, 1, B);
             return rc0 ? rc0 : reduce_range(0, critic_off);
         }
-        rc = fused_dw(0, 2, B);
+        rc = fused_dw(0, nets, B);
         if (rc) return rc;
-        if (w.nnets > 2) {
+        if (w.nnets > 2 && !aux_fb) {
             const int32_t rca = aux_grad(ppo, b);
             if (rca) return rca;
         }
@@ -1161,84 +1139,7 @@ struct NetRunner {
     // Auxiliary (denoising) head, HgymNetConfig::aux_*: forward on the gathered observation rows, MSE against the target
     // columns of the gathered privileged rows, backward.  Leaves its weight gradients in the split-K slabs and its bias
     // gradients in net.grads; the caller's slab reduction finishes them together with everything else.
-    // one high-water mark of the dynamic-LDS attribute for every user of mlp_bwd_kernel (the attribute belongs to the function)
-    static bool reserve_bwd_lds(size_t lds) {
-        static size_t cur = 0;
-        if (lds <= cur) return false;
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_bwd_kernel<64, 16, 2>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds) != hipSuccess)
-            return true;
-        cur = lds;
-        return false;
-    }
-
-    // The auxiliary head through the fused kernels: its own launches of mlp_fwd (one grid row, writes its X0 / H), the MSE
-    // kernel (dZ3 in block layout), mlp_bwd and dw_kernel_rs (four products into the slabs the common reduction sums).
-    int32_t fused_aux_grad(const HgymPPOConfig& ppo, const HgymBatch& b) {
-        const NetLayout& n = w.net[2];
-        const int B = b.B, No = n.layer[3].N;
-        const int Bp = (int)round_up(B, 64);
-        float* y = at<float>(n.out_f32);
-        int32_t rc = forward(2, B, b.obs, cfg.num_obs, b.idx, y, No, true);
-        if (rc) return rc;
-        const int CB3 = 2 * n.layer[3].NBBf;
-        hipLaunchKernelGGL(aux_mse_fused_kernel, dim3(ceil_div(Bp, 256)), dim3(256), 0, s, B, Bp, No, CB3, y, b.priv, (int64_t)cfg.num_priv,
-                           cfg.aux_target_offset, b.idx, ppo.aux_coef, at<__bf16>(n.dZb[3]), net.opt_state);
-        HG_CHECK_LAUNCH("aux_mse_fused_kernel");
-        {
-            BwdArgs g;
-            memset(&g, 0, sizeof(g));
-            g.net[2] = fused_net(2, nullptr, 0, nullptr, 0);
-            g.net0 = 2;
-            g.M = B;
-            const size_t lds = (size_t)64 * 64 * n.layer[3].NBBf + (size_t)64 * 2 * (n.layer[2].N + n.layer[1].N);
-            if (reserve_bwd_lds(lds)) HG_FAIL(HGYM_E_LAUNCH, "cannot reserve %zu bytes of LDS for mlp_bwd_kernel", lds);
-            prof_begin(HGYM_PROF_MLP_BWD, s);
-            hipLaunchKernelGGL((mlp_bwd_kernel<64, 16, 2>), dim3(Bp / 64, 1), dim3(1024), lds, s, g);
-            double fl = 0.0;
-            for (int l = 1; l < 4; ++l) fl += 2.0 * (double)B * n.layer[l].K * n.layer[l].N;
-            prof_end(HGYM_PROF_MLP_BWD, s, fl);
-            HG_CHECK_LAUNCH("mlp_bwd_kernel(aux)");
-        }
-        {
-            DwArgs d;
-            memset(&d, 0, sizeof(d));
-            int tile = 0;
-            double fl = 0.0;
-            for (int l = 0; l < 4; ++l) {
-                const LayerLayout& yl = n.layer[l];
-                DwProduct& p = d.p[d.np++];
-                p.Z = at<__bf16>(n.dZb[l]);
-                p.CBz = l < 3 ? yl.N / 16 : CB3;
-                p.X = l == 0 ? at<__bf16>(n.X0b) : at<__bf16>(n.Hb[l - 1]);
-                p.CBx = l == 0 ? 2 * yl.KBf : yl.K / 16;
-                p.N = yl.N;
-                p.K = yl.K;
-                p.w_off = yl.w_off;
-                p.b_off = yl.b_off;            // every bias gradient of this net is a column sum of dZ
-                p.tiles_n = ceil_div(yl.N, 128);
-                p.tiles_k = ceil_div(yl.K, 128);
-                p.tile0 = tile;
-                tile += p.tiles_n * p.tiles_k;
-                fl += 2.0 * (double)B * yl.N * yl.K;
-            }
-            d.total_tiles = tile;
-            d.splits = w.dw_splits;
-            d.steps_total = Bp / 32;
-            d.steps_per_split = ceil_div(d.steps_total, w.dw_splits);
-            d.slabs = at<float>(w.slabs);
-            d.slab_stride = w.Ps;
-            d.zeros = at<char>(w.zeros);
-            prof_begin(HGYM_PROF_DW, s);
-            hipLaunchKernelGGL(dw_kernel_rs<3>, dim3(tile * (int)round_up(w.dw_splits, 8)), dim3(DW_THREADS), 2 * DW_STAGE_BYTES, s, d);
-            prof_end(HGYM_PROF_DW, s, fl);
-            HG_CHECK_LAUNCH("dw_kernel_rs(aux)");
-        }
-        return HGYM_OK;
-    }
-
     int32_t aux_grad(const HgymPPOConfig& ppo, const HgymBatch& b) {
-        if (w.fused_aux) return fused_aux_grad(ppo, b);
         const NetLayout& n = w.net[2];
         const LayerLayout& last = n.layer[n.L - 1];
         const int B = b.B, No = last.N;
@@ -1297,7 +1198,7 @@ struct NetRunner {
         prof_end(HGYM_PROF_LOSS, s, (double)B * (4.0 * (5 * A + 6) + (double)sizeof(T) * (2 * A + 2)));
         HG_CHECK_LAUNCH("ppo_loss_kernel");
         hipLaunchKernelGGL(ppo_scalars_kernel, dim3(1), dim3(512), 0, s, nblocks, B, A, at<float>(w.partials), net.grads, (float*)nullptr,
-                           (float*)nullptr, net.grads + w.P, net.opt_state);
+                           (float*)nullptr, net.grads + w.P, net.opt_state, 0);
         HG_CHECK_LAUNCH("ppo_scalars_kernel");
         cur_Mp = Bp;
         rc = backward(0, B);

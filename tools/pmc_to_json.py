@@ -27,7 +27,7 @@ def main(fetch_csv, write_csv, out, copy_bytes):
                 if wv[1]:
                     cal_w = copy_bytes / (wv[0] / wv[1] * 1024)
     res = {}
-    names = {"rollout_step_kernel": "rollout_step_kernel", "mlp_fb_kernel": "mlp_fwd_kernel",      # forward + loss + dZ chain: reported in the forward class
+    names = {"rollout_step_kernel": "rollout_step_kernel", "mlp_fb_kernel": "mlp_fb_kernel",
              "env_step_kernel": "env_step_kernel", "mlp_fwd_kernelILi64": "mlp_fwd_kernel", "mlp_fwd_kernel<64": "mlp_fwd_kernel",
              "mlp_fwd_kernelILi32": "mlp_fwd_kernel<32>", "mlp_fwd_kernel<32": "mlp_fwd_kernel<32>", "mlp_bwd_kernel": "mlp_bwd_kernel",
              "dw_kernel": "dw_kernel", "ppo_loss_kernel": "ppo_loss_kernel", "reduce_slabs_kernel": "reduce_slabs_kernel",

@@ -23,7 +23,6 @@ for mb in [int(x) for x in (sys.argv[1:] or ["4", "16", "32"])]:
         L.lib.hgym_prof_enable(1)
         runner.learn(num_learning_iterations=2, init_at_random_ep_len=False)
         torch.cuda.synchronize()
-        L.lib.hgym_prof_enable(0)
     rows = 4096 * 60 // mb
     out = []
     for cid, nm in [(L.PROF_MLP_FWD, "fb"), (L.PROF_DW, "dw"), (L.PROF_REDUCE, "reduce"), (L.PROF_APPLY, "apply")]:
@@ -31,5 +30,6 @@ for mb in [int(x) for x in (sys.argv[1:] or ["4", "16", "32"])]:
         if n:
             out.append("%s %7.1f us (%6.2f ns/row, n=%d)" % (nm, ms / n * 1e3, ms / n * 1e6 / rows, n))
     print("minibatches=%2d rows=%6d  update %.2f ms | %s" % (mb, rows, runner.last_learn_time * 1e3, " | ".join(out)), flush=True)
+    L.lib.hgym_prof_enable(0)
     del runner, env
     torch.cuda.empty_cache()
