@@ -245,49 +245,6 @@ __device__ __forceinline__ void mma_stream(WRing<GR, D>& R, const u32x4* __restr
     }
 }
 
-// mma_chunk: the 4 k-steps t0 .. t0 + 3 (t0 % 4 == 0, D divides 4) of a stream whose input arrives in 4-k-block LDS chunks
-// (first layer).  LAST: this is the final chunk, nothing beyond k-step t0 + 3 exists.
-template <int G, int MB, int D, bool LAST, int XBP = -1, int GR>
-__device__ __forceinline__ void mma_chunk(WRing<GR, D>& R, const u32x4* __restrict__ wl, int wstride, int t0, const char* xl, int CBx,
-                                          int lane, f32x4 (&acc)[MB][G]) {
-    static_assert(D == 2 || D == 4, "ring depth must divide the chunk");
-    constexpr bool XB = XBP < 0 ? (MB <= 2) : (XBP != 0);
-    const int r = lane & 15, q = lane >> 4;
-    const char* xb = xl + (q >> 1) * 512 + r * 32 + (q & 1) * 16;
-    u32x4 xa[MB], xc[XB ? MB : 1];
-    if (XB) {
-#pragma unroll
-        for (int i = 0; i < MB; ++i) xa[i] = *reinterpret_cast<const u32x4*>(xb + (i * CBx) * 512);
-    }
-#pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) {
-        const int d = s4 % D;
-        if (XB) {
-            if (s4 + 1 < 4) {
-#pragma unroll
-                for (int i = 0; i < MB; ++i) {
-                    const u32x4 v = *reinterpret_cast<const u32x4*>(xb + (i * CBx + 2 * (s4 + 1)) * 512);
-                    if (s4 & 1) xa[i] = v; else xc[i] = v;
-                }
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < MB; ++i) xa[i] = *reinterpret_cast<const u32x4*>(xb + (i * CBx + 2 * s4) * 512);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < MB; ++i)
-#pragma unroll
-            for (int g = 0; g < G; ++g) mma_frag<__bf16>(R.w[d][g], (XB && (s4 & 1)) ? xc[i] : xa[i], acc[i][g]);
-        __builtin_amdgcn_sched_barrier(0);
-        if (!LAST || s4 + D < 4) {
-#pragma unroll
-            for (int g = 0; g < G; ++g) R.w[d][g] = wl[(int64_t)g * wstride + (t0 + s4 + D) * 64];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
 // ELU of the bf16 path: exp(z) as v_exp_f32(z * log2 e).  The libm expf the fp32 parity path keeps (elu_f) is ~15 VALU
 // instructions per element (argument split, ldexp, two range selects) and the epilogues were VALU-bound on them; the result
 // is rounded to bf16 (2^-8 relative) right after, against this form's <= 1e-6 relative error for |z| <= 18.
@@ -478,8 +435,14 @@ __device__ __forceinline__ void fwd_body(const FwdArgs& a, const FusedNet& n, bo
     WRing<GH, D> r1, r2;             // weight streams of the two hidden layers
     auto prime1 = [&]() { hidden_prime<GH, D>(r1, L1, wave, lane); };
 
-    // ---------------------------------------------------------------- layer 0: input streamed in 128-column chunks
+    // ---------------------------------------------------------------- layer 0: the whole input tile staged once, then a pure weight stream
+    // All gathers of the tile (NC chunks of 128 columns, IT 16-byte items per thread each) are issued at kernel entry and land as
+    // bf16 in LDS over P and Q (both dead until this layer's epilogue): BM x 32 KB columns = P + Q exactly for the 768-column input.
+    // One memory round trip instead of one per chunk: the wave's loads return in order, so a chunk-by-chunk gather (one chunk
+    // ahead of the MFMAs) put an HBM round trip in front of the weight stream at every chunk boundary -- 6 x ~1.6 us of the
+    // actor tile's first layer, in the rollout and in the update alike.
     {
+        constexpr int NCMAX = 768 / FUSED_CHUNK;       // fused_supported: first-layer input <= 768 columns
         const int NC = L0.KB / 4;
         const int CB0 = 2 * L0.KB;
         const int f4 = tid & 31;
@@ -494,41 +457,46 @@ __device__ __forceinline__ void fwd_body(const FwdArgs& a, const FusedNet& n, bo
             srow[u] = n.x + src * n.ldx;
             lrow[u] = row;
         }
-        F4 stg[IT];
-        // one unconditional 16-byte load per item: the address is clamped to the last full vector of the row.  stage_load
-        // ONLY issues the loads (nothing here may consume them: the data must stay in flight under the MFMAs of the current
-        // chunk); stage_write re-aligns / zero-fills the (at most one per row) straddling item with selects, converts and
-        // stores to LDS.
-        auto stage_load = [&](int c) {
-            const int col = c * FUSED_CHUNK + f4 * 4;
-            const int cc = col < L0.K - 4 ? col : L0.K - 4;
+        F4 stg[NCMAX][IT];
+        // one unconditional 16-byte load per item: the address is clamped to the last full vector of the row (chunks past the
+        // input's last one re-read it and are not written).  stage_write re-aligns / zero-fills the (at most one per row)
+        // straddling item with selects, converts and stores to LDS.
+        auto stage_load = [&]() {
 #pragma unroll
-            for (int u = 0; u < IT; ++u) stg[u] = ld_stream_f4<(HGYM_NT & 1) != 0>(srow[u] + cc);
+            for (int c = 0; c < NCMAX; ++c) {
+                const int col = c * FUSED_CHUNK + f4 * 4;
+                const int cc = col < L0.K - 4 ? col : L0.K - 4;
+#pragma unroll
+                for (int u = 0; u < IT; ++u) stg[c][u] = ld_stream_f4<(HGYM_NT & 1) != 0>(srow[u] + cc);
+            }
         };
-        auto stage_write = [&](int c, int buf) {
-            char* dst = Q + buf * (BM * FUSED_CHUNK * 2);
-            const int col = c * FUSED_CHUNK + f4 * 4;
-            const int cc = col < L0.K - 4 ? col : L0.K - 4;
-            const int sh = col - cc;                       // 0 for full items, 1..3 for the straddling one, >= 4: all padding
+        auto stage_write = [&]() {
 #pragma unroll
-            for (int u = 0; u < IT; ++u) {
-                float v[4];
+            for (int c = 0; c < NCMAX; ++c) {
+                if (c >= NC) break;
+                const int col = c * FUSED_CHUNK + f4 * 4;
+                const int cc = col < L0.K - 4 ? col : L0.K - 4;
+                const int sh = col - cc;                       // 0 for full items, 1..3 for the straddling one, >= 4: all padding
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int k = e + sh;
-                    float r = 0.0f;
-                    r = k == 0 ? stg[u].v[0] : r;
-                    r = k == 1 ? stg[u].v[1] : r;
-                    r = k == 2 ? stg[u].v[2] : r;
-                    r = k == 3 ? stg[u].v[3] : r;
-                    v[e] = r;
+                for (int u = 0; u < IT; ++u) {
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int k = e + sh;
+                        float r = 0.0f;
+                        r = k == 0 ? stg[c][u].v[0] : r;
+                        r = k == 1 ? stg[c][u].v[1] : r;
+                        r = k == 2 ? stg[c][u].v[2] : r;
+                        r = k == 3 ? stg[c][u].v[3] : r;
+                        v[e] = r;
+                    }
+                    const u32x2 pk = pack_bf16x4(v[0], v[1], v[2], v[3]);
+                    const int inblk = (lrow[u] & 15) * 32 + (f4 & 3) * 8;
+                    *reinterpret_cast<u32x2*>(P + ((lrow[u] >> 4) * CB0 + c * 8 + (f4 >> 2)) * 512 + inblk) = pk;
+                    if (train)
+                        st_stream_u2<(HGYM_NT & 2) != 0>(reinterpret_cast<char*>(n.X0) +
+                                                         ((mbg0 + (lrow[u] >> 4)) * CB0 + c * 8 + (f4 >> 2)) * 512 + inblk, pk);
                 }
-                const u32x2 pk = pack_bf16x4(v[0], v[1], v[2], v[3]);
-                const int inblk = (lrow[u] & 15) * 32 + (f4 & 3) * 8;
-                *reinterpret_cast<u32x2*>(dst + ((lrow[u] >> 4) * 8 + (f4 >> 2)) * 512 + inblk) = pk;
-                if (train)
-                    st_stream_u2<(HGYM_NT & 2) != 0>(reinterpret_cast<char*>(n.X0) +
-                                                     ((mbg0 + (lrow[u] >> 4)) * CB0 + c * 8 + (f4 >> 2)) * 512 + inblk, pk);
             }
         };
         const int nb0 = wave * G1;
@@ -538,22 +506,16 @@ __device__ __forceinline__ void fwd_body(const FwdArgs& a, const FusedNet& n, bo
         const u32x4* wl0 = L0.Wf + (int64_t)nb0 * L0.KB * 64 + lane;
         phase_stamp(a.dbg, 0);
         wring_prime<G1, D>(r0, wl0, L0.KB * 64, L0.KB);
-        stage_load(0);
+        stage_load();
         hook_early(extra);
-        stage_write(0, 0);
+        stage_write();
         bias_to_lds();
         __syncthreads();
         phase_stamp(a.dbg, 1);
-        // steady state: no condition inside the body (see mma_stream); the last chunk is peeled
-        for (int c = 0; c + 1 < NC; ++c) {
-            stage_load(c + 1);
-            mma_chunk<G1, MB, D, false, XBF>(r0, wl0, L0.KB * 64, c * 4, Q + (c & 1) * (BM * FUSED_CHUNK * 2), 8, lane, acc);
-            stage_write(c + 1, (c + 1) & 1);
-            __syncthreads();
-        }
-        mma_chunk<G1, MB, D, true, XBF>(r0, wl0, L0.KB * 64, (NC - 1) * 4, Q + ((NC - 1) & 1) * (BM * FUSED_CHUNK * 2), 8, lane, acc);
+        mma_stream<G1, MB, D, XBF>(r0, wl0, L0.KB * 64, L0.KB, P, CB0, lane, acc);
         phase_stamp(a.dbg, 2);
         if (AHEAD) prime1();
+        __syncthreads();          // every wave is done reading the input tile: the epilogue writes H0 over it
         epilogue_elu<G1, MB>(acc, bl, nb0, P, L0.NB, train_h ? n.H[0] : nullptr, mbg0, lane);
     }
     __syncthreads();

@@ -132,7 +132,7 @@ __global__ __launch_bounds__(RO_NT) void rollout_step_kernel(const FwdArgs f, co
     auto put = [&](int row, int j, float v) { esm[act_off + row * 12 + j] = v; };
     // the env step's Philox draws: on the six wavefronts that have no head block, while the other two compute the head
     auto idle = [&](const EnvArgs& E) {
-#if HGYM_RO_DRAWS_IDLE && HGYM_RO_VARIANT == 0
+#if HGYM_RO_DRAWS_IDLE && HGYM_RO_VARIANT == 0 && !defined(HGYM_RO_NO_DRAWS)
         env_fill_draws<RO_E>(E, block, t - 128, RO_NT - 128, esm, csc0);
 #endif
     };

@@ -237,7 +237,7 @@ class PPO:
             for i in range(self.num_mini_batches):
                 idx = perm[i * mb:(i + 1) * mb]
                 batch = hgym.make_batch(*cols, idx)
-                if self._world == 1:
+                if not dist_utils.active():
                     net.ppo_grad(self._ppo_cfg, batch)
                 else:
                     # two buckets: [std | actor] (the larger one) is reduced across ranks while this rank's critic (and denoiser)

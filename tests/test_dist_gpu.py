@@ -81,6 +81,50 @@ def test_two_ranks_two_gpus_rccl(tmp_path):
     assert not torch.equal(a["friction"], b["friction"])
 
 
+def _single_rank_worker(rank, world, port, out_dir, collectives):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "humanoid-gym_amd"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    if collectives:
+        os.environ["HGYM_DIST_SINGLE"] = "1"
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    from humanoid.algo import PPO
+    PPO.precision = "bf16"
+    from humanoid.algo.ppo import dist_utils
+    from humanoid.envs import task_registry
+    from humanoid.utils import get_args
+    assert dist_utils.active() == bool(collectives)
+    args = get_args(["--task=humanoid_ppo", "--headless", "--num_envs", "256", "--seed", "5"])
+    env, _ = task_registry.make_env(name=args.task, args=args)
+    runner, _ = task_registry.make_alg_runner(env=env, name=args.task, args=args, log_root=None)
+    runner.alg.comm_timing = []
+    runner.learn(num_learning_iterations=4, init_at_random_ep_len=True)
+    torch.cuda.synchronize()
+    net = runner.alg.net
+    torch.save(dict(params=net.params.cpu(), lr=float(net.opt_state[0]), comm_events=len(runner.alg.comm_timing)),
+               os.path.join(out_dir, "single%d.pt" % int(collectives)))
+    if collectives:
+        dist.destroy_process_group()
+
+
+def test_one_rank_rccl_collective_path_changes_nothing(tmp_path):
+    """A box with one GPU cannot run two RCCL ranks, but it can run ONE: HGYM_DIST_SINGLE=1 sends the update through everything
+    the N > 1 path does -- parameter broadcast, the advantage-statistics all-reduce, the gradient in two parts with an asynchronous
+    all-reduce (backend "nccl" = RCCL, its own stream) behind each, the stream-side waits before hgym_ppo_apply -- on a one-rank
+    group, where every collective is the identity.  Parameters after 32 Adam steps must equal the plain run's bit for bit: a
+    missing stream dependency between the kernels and the collectives would not."""
+    port = 29300 + (os.getpid() % 2000)
+    for c in (0, 1):
+        mp.spawn(_single_rank_worker, args=(1, port + c, str(tmp_path), c), nprocs=1, join=True)
+    a, b = (torch.load(os.path.join(str(tmp_path), "single%d.pt" % c)) for c in (0, 1))
+    assert torch.isfinite(a["params"]).all()
+    assert torch.equal(a["params"], b["params"]) and a["lr"] == b["lr"]
+    assert a["comm_events"] == 0 and b["comm_events"] == 32
+
+
 def test_bench_spawns_its_own_ranks(tmp_path):
     """`python bench.py --gpus 2` with no torch.distributed environment (how the driver starts the N = 1 run) must launch its two
     ranks itself and print ONE JSON line with n_gpus = 2.  On a one-GPU box the ranks share the device over gloo

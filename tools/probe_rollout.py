@@ -38,6 +38,11 @@ FWD = ["input0+draws", "layer0 k-loop", "epilogue0+sync", "layer1+sync", "layer2
 ENV = ["hist stores", "joints+sync", "per-env chain+sync", "stage-out", "phase B"]
 for i, b in enumerate(acc[1:], 1):
     t = b.view(3, nb, 8).cpu().double() * 0.01
+    if os.environ.get("HGYM_RO_INTERLEAVE", "1") != "0":     # the default build: tile b's actor sits in grid row b & 1, its critic in the other
+        odd = (torch.arange(nb) & 1).bool()
+        a_, c_ = t[0].clone(), t[1].clone()
+        a_[odd], c_[odd] = t[1][odd], t[0][odd]
+        t = torch.stack([a_, c_, t[2]])
     for row, tag, names in ((0, "actor", FWD), (1, "critic", FWD), (2, "env (behind the actor tile)", ENV)):
         d = t[row]
         segs = [(d[:, k + 1] - d[:, k]).mean().item() for k in range(len(names))]
