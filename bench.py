@@ -373,8 +373,9 @@ def main():
                 with tempfile.TemporaryDirectory() as tmp:
                     r = run_config(args, "humanoid_ppo", 4096, 0, 1, local, None, k_steps, k_warm, log_root=tmp, want_roofline=False, quiet=True)
                 e = dict(name="logging_on", logging=True,
-                         note="train.py's default: log_dir set -> per-iteration host synchronisation, loss / episode statistics read back, "
-                              "console (+ TensorBoard if installed) writes, own step-finaliser launch, final checkpoint inside the timed region")
+                         note="train.py's default: log_dir set -> episode statistics kept by the step finaliser, loss / episode statistics copied to "
+                              "pinned host memory behind every update and printed (console, + TensorBoard if installed) while the next "
+                              "iteration runs, checkpoints inside the timed region")
             elif c == "dwl":
                 r = run_config(args, "humanoid_dwl_ppo", 4096, 0, 1, local, None, k_steps, k_warm, want_roofline=False, quiet=True)
                 e = dict(name="dwl_head", logging=False, note="BASELINE configs[4] on one GPU; parity of the head is unpinned (no reference code)")

@@ -718,10 +718,15 @@ struct FbLoss {
 // LDS of the fused kernel behind the forward's P / Q / bias regions: the dZ3 tile (64 rows x 32 * layer[3].NBB bf16 columns), the
 // head waves' partial sums, and H2 (64 x layer[2].N bf16) -- the forward writes it there instead of over H0, so that all three
 // activations are resident for the dZ chain
-HG_HD int fb_lds_extra(const FusedNet& n) { return 64 * 64 * n.layer[3].NBB + 4 * 32 * 4 + 64 * n.layer[2].N * 2; }
+// ... and the tile's loss inputs (fb_loss_width floats per row), gathered at kernel entry with the observation rows
+HG_HD int fb_loss_width(int which, int A, int No) { return which == 0 ? 3 * A + 2 : (which == 1 ? 2 : No); }
+HG_HD int fb_lds_extra(const FusedNet& n, int which, int A) {
+    return 64 * 64 * n.layer[3].NBB + 4 * 32 * 4 + 64 * n.layer[2].N * 2 + 64 * 4 * fb_loss_width(which, A, n.layer[3].N);
+}
 
 template <int G1, bool AUX = false>
 __device__ __forceinline__ void fb_body(const FwdArgs& a, const FbLoss& L, const FusedNet& n, bool is_actor, char* smem) {
+    constexpr int LI_MAX = AUX ? 6 : 3;       // loss-input floats per thread: 64 rows x (3 * 12 + 2 | 2 | <= 96) / 1024 threads
     constexpr int BM = 64, NW = 16, D = 2, MB = BM / 16;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
@@ -735,14 +740,56 @@ __device__ __forceinline__ void fb_body(const FwdArgs& a, const FbLoss& L, const
     char* H2 = R0 + BM * 64 * NBB3 + 4 * 32 * 4;
     const int A = a.A;
     const float invB = 1.0f / (float)a.M;
+    // The loss inputs of the tile's 64 rows -- actor: actions, old mu, old sigma, advantage, old log-prob; critic: return, old
+    // value; auxiliary head: its target columns -- are gathered through the minibatch indices at kernel ENTRY, between the issue of
+    // the observation gather and its LDS writes, and parked in LDS (row-major, W floats per row).  Read on the head wavefronts at
+    // the end of the forward they were a dependent chain of HBM round trips (index, then row) with nothing to hide under.
+    float* LI = reinterpret_cast<float*>(H2 + BM * n.layer[2].N * 2);
+    const int W = fb_loss_width(AUX ? 2 : (is_actor ? 0 : 1), A, n.layer[3].N);
+    // (the row indices first, ahead of every other load of the tile: a wave's loads return in order, so the addresses below are
+    // ready as soon as the indices are, not one memory round trip behind the observation gather)
+    int64_t li_row[LI_MAX];
+#pragma unroll
+    for (int u = 0; u < LI_MAX; ++u) {
+        const int i = tid + u * (NW * 64);
+        int rl = i / W;
+        rl = rl < BM ? rl : BM - 1;
+        int m = m0 + rl;
+        m = m < a.M ? m : a.M - 1;
+        li_row[u] = a.idx ? a.idx[m] : (int64_t)m;
+    }
+    auto loss_inputs = [&](int) {
+        float lv[LI_MAX];
+#pragma unroll
+        for (int u = 0; u < LI_MAX; ++u) {
+            const int i = tid + u * (NW * 64);
+            lv[u] = 0.0f;
+            if (i < BM * W) {
+                const int rl = i / W, c = i - rl * W;
+                const int64_t row = li_row[u];
+                const float* src;
+                if (AUX) src = L.aux_target + row * L.aux_ldt + L.aux_off + c;
+                else if (!is_actor) src = (c == 0 ? L.returns : L.values) + row;
+                else if (c < A) src = L.actions + row * A + c;
+                else if (c < 2 * A) src = L.old_mu + row * A + (c - A);
+                else if (c < 3 * A) src = L.old_sigma + row * A + (c - 2 * A);
+                else src = (c == 3 * A ? L.advantages : L.logp) + row;
+                lv[u] = *src;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < LI_MAX; ++u) {
+            const int i = tid + u * (NW * 64);
+            if (i < BM * W) LI[i] = lv[u];
+        }
+    };
     float aux_se = 0.0f;
     // auxiliary head: lane (r, q) of head wave hw, row m, outputs nb * 16 + 4q .. + 3 (called once per column block).
     // loss = coef * mean_b sum_j (y - t)^2 / No, dL/dy = 2 coef (y - t) / (B No)    (aux_mse_kernel's arithmetic)
     auto head_aux = [&](int hw, int m, int nb, const float (&out)[4]) {
         const int No = n.layer[3].N;
         const bool valid = m < a.M;
-        const int64_t row = a.idx ? a.idx[valid ? m : a.M - 1] : (int64_t)(valid ? m : a.M - 1);
-        const float* t = L.aux_target + row * L.aux_ldt + L.aux_off;
+        const float* t = LI + (hw * 16 + r) * W;
         const float gs = 2.0f * L.aux_coef / ((float)a.M * (float)No);
         float g[4];
 #pragma unroll
@@ -773,25 +820,17 @@ __device__ __forceinline__ void fb_body(const FwdArgs& a, const FbLoss& L, const
         // lane (r, q) of head wave hw: row m, head outputs 4q .. 4q + 3.  ppo.py:128-168 forward scalars + the hand-written
         // backward of the loss w.r.t. mu, std and V (oracle/ppo_oracle.py: ppo_loss_and_grads), as in ppo_loss_kernel
         const bool valid = m < a.M;
-        const int64_t row = a.idx ? a.idx[valid ? m : a.M - 1] : (int64_t)(valid ? m : a.M - 1);
+        const float* li = LI + (hw * 16 + r) * W;       // this row's loss inputs (loss_inputs(): gathered at kernel entry)
         float g[4] = {0.f, 0.f, 0.f, 0.f};
         float part[11];
 #pragma unroll
         for (int k = 0; k < 11; ++k) part[k] = 0.0f;
         if (is_actor) {
             float act[4] = {0.f, 0.f, 0.f, 0.f}, mo[4] = {0.f, 0.f, 0.f, 0.f}, so[4] = {1.f, 1.f, 1.f, 1.f}, sg[4] = {1.f, 1.f, 1.f, 1.f};
-            if (4 * q + 3 < A) {
-                const F4 qa = *reinterpret_cast<const F4*>(L.actions + row * A + 4 * q);
-                const F4 qo = *reinterpret_cast<const F4*>(L.old_mu + row * A + 4 * q);
-                const F4 qs = *reinterpret_cast<const F4*>(L.old_sigma + row * A + 4 * q);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { act[e] = qa.v[e]; mo[e] = qo.v[e]; so[e] = qs.v[e]; }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (4 * q + e < A) { act[e] = L.actions[row * A + 4 * q + e]; mo[e] = L.old_mu[row * A + 4 * q + e]; so[e] = L.old_sigma[row * A + 4 * q + e]; }
-            }
-            const float adv = L.advantages[row], lpold = L.logp[row];
+            for (int e = 0; e < 4; ++e)
+                if (4 * q + e < A) { act[e] = li[4 * q + e]; mo[e] = li[A + 4 * q + e]; so[e] = li[2 * A + 4 * q + e]; }
+            const float adv = li[3 * A], lpold = li[3 * A + 1];
             float lp = 0.0f, ent = 0.0f, kl = 0.0f, diff[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -828,7 +867,7 @@ __device__ __forceinline__ void fb_body(const FwdArgs& a, const FbLoss& L, const
                     }
             }
         } else {
-            const float ret = L.returns[row], vold = L.values[row];
+            const float ret = li[0], vold = li[1];
             const float v = out[0];
             const float vc = vold + clampf(v - vold, -L.clip, L.clip);
             const float l1 = (v - ret) * (v - ret), l2 = (vc - ret) * (vc - ret);
@@ -870,14 +909,14 @@ __device__ __forceinline__ void fb_body(const FwdArgs& a, const FbLoss& L, const
         }
     };
     if constexpr (AUX) {
-        fwd_body<BM, NW, D, G1, true>(a, n, false, smem, FwdNoop(), FwdNoop(), FwdNoop(), 0, FwdNoop(), head_aux, H2);
+        fwd_body<BM, NW, D, G1, true>(a, n, false, smem, loss_inputs, FwdNoop(), FwdNoop(), 0, FwdNoop(), head_aux, H2);
         if (wave < MB) {
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) aux_se += __shfl_xor(aux_se, o, 64);
             if (lane == 0) red[wave * 32 + 29] = aux_se;
         }
     } else {
-        fwd_body<BM, NW, D, G1, false>(a, n, is_actor, smem, FwdNoop(), FwdNoop(), FwdNoop(), 0, FwdNoop(), head, H2);
+        fwd_body<BM, NW, D, G1, false>(a, n, is_actor, smem, loss_inputs, FwdNoop(), FwdNoop(), 0, FwdNoop(), head, H2);
     }
     __syncthreads();          // dZ3 tile and the per-wave sums are in LDS; H0 sits in P, H1 in Q, H2 in its own buffer
     if (tid < 32) {

@@ -971,7 +971,7 @@ struct NetRunner {
             size_t lds = 0;
             for (int i = 0; i < nets; ++i)
                 lds = std::max(lds, (size_t)fused_lds_p(fa.net[i], 64) + (size_t)fused_lds_q(fa.net[i], 64) + (size_t)fused_lds_bias(fa.net[i]) +
-                                        (size_t)fb_lds_extra(fa.net[i]));
+                                        (size_t)fb_lds_extra(fa.net[i], i, A));
             HG_REQUIRE(lds <= 160 * 1024, HGYM_E_UNSUPPORTED, "mlp_fb_kernel needs %zu bytes of LDS", lds);
             static size_t attr_lds = 0;
             if (lds > attr_lds) {

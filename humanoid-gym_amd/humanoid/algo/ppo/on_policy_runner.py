@@ -163,6 +163,12 @@ class OnPolicyRunner:
         # boundaries).  With logging the reference's per-iteration host synchronisation is kept.
         async_iters = ((not log_on) and str(self.device).startswith("cuda") and isinstance(alg, PPO)
                        and os.environ.get("HGYM_ASYNC", "1") != "0")
+        # With the device-side log sink the logging run does not synchronise per iteration either: everything log() prints is
+        # copied to pinned host memory behind the update (stream-ordered), and the host formats iteration k's block while the
+        # device runs iteration k + 1 -- the log appears one iteration late, with the same content in the same order.
+        async_log = (log_sink and str(self.device).startswith("cuda") and isinstance(alg, PPO)
+                     and os.environ.get("HGYM_ASYNC", "1") != "0")
+        pending = None
         marks = []
         # the captured launches hold HgymEnvConfig and the sink's gamma BY VALUE: a change between learn() calls (reward scales,
         # command ranges, push / noise settings written into the env's native config, alg.gamma -- what a curriculum script does)
@@ -172,7 +178,7 @@ class OnPolicyRunner:
         tot_iter = self.current_learning_iteration + num_learning_iterations
         for it in range(self.current_learning_iteration, tot_iter):
             start = time.time()
-            if async_iters:
+            if async_iters or async_log:
                 ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
                 ev[0].record()
             with torch.inference_mode():
@@ -200,7 +206,7 @@ class OnPolicyRunner:
                 else:
                     obs, critic_obs = rollout(obs, critic_obs)
                     self._graph_warm = True
-                if async_iters:
+                if async_iters or async_log:
                     ev[1].record()
                 elif str(self.device).startswith("cuda"):
                     torch.cuda.synchronize()
@@ -208,7 +214,7 @@ class OnPolicyRunner:
                 collection_time = stop - start
                 start = stop
                 alg.compute_returns(critic_obs)
-            mean_value_loss, mean_surrogate_loss = alg.update(sync=False) if async_iters else alg.update()
+            mean_value_loss, mean_surrogate_loss = alg.update(sync=False) if (async_iters or async_log) else alg.update()
             if zero_copy:                       # storage.clear() rotated slot T into slot 0
                 obs, critic_obs = obs_all[0], priv_all[0]
             stop = time.time()
@@ -216,6 +222,15 @@ class OnPolicyRunner:
             if async_iters:
                 ev[2].record()
                 marks.append(ev)
+            elif async_log:
+                ev[2].record()
+                snap = self._log_snapshot(env, alg, it & 1)
+                if pending is not None:
+                    self._log_flush(pending, num_learning_iterations)
+                pending = dict(it=it, ev=ev, snap=snap)
+                if it % self.save_interval == 0:
+                    self.save(os.path.join(self.log_dir, "model_{}.pt".format(it)))
+                continue
             else:
                 self.last_collection_time, self.last_learn_time = collection_time, learn_time
             if self.log_dir is not None:
@@ -236,6 +251,8 @@ class OnPolicyRunner:
                     self.save(os.path.join(self.log_dir, "model_{}.pt".format(it)))
             if self._graph is None or ep_infos is not self._graph["ep_infos"]:
                 ep_infos.clear()
+        if pending is not None:
+            self._log_flush(pending, num_learning_iterations)
         if marks:                               # mean device time per iteration of this call (HIP events, one sync)
             torch.cuda.synchronize()
             self.last_collection_time = sum(a.elapsed_time(b) for a, b, _ in marks) * 1e-3 / len(marks)
@@ -252,6 +269,43 @@ class OnPolicyRunner:
             self.save(os.path.join(self.log_dir, "model_{}.pt".format(self.current_learning_iteration)))
 
     # ------------------------------------------------------------------
+    def _log_snapshot(self, env, alg, slot):
+        """Enqueue the device -> pinned-host copies of everything one iteration's log block needs (the optimiser's scalar state:
+        loss sums, learning rate; the env's log sink: extras["episode"] sums and the last-100-episodes rings; the mean action
+        std), then clear the sink's per-iteration sums.  Stream-ordered behind the update; read in _log_flush after the event."""
+        if getattr(self, "_log_pin", None) is None:
+            mk = lambda n, dt: [torch.empty(n, dtype=dt).pin_memory() for _ in range(2)]
+            self._log_pin = dict(opt=mk(alg.net.opt_state.numel(), alg.net.opt_state.dtype), ls=mk(env._buf.log_stats.numel(), torch.float32),
+                                 std=mk(1, torch.float32))
+        pin = self._log_pin
+        pin["opt"][slot].copy_(alg.net.opt_state, non_blocking=True)
+        pin["ls"][slot].copy_(env._buf.log_stats, non_blocking=True)
+        pin["std"][slot].copy_(alg.actor_critic.std.detach().mean().reshape(1), non_blocking=True)
+        env._buf.log_stats[:23].zero_()
+        done = torch.cuda.Event()
+        done.record()
+        return dict(slot=slot, done=done, aux=alg._ppo_cfg.aux_coef > 0.0)
+
+    def _log_flush(self, pending, num_learning_iterations):
+        """Print / record the log block of a finished iteration from its host snapshot (no device access: the device is busy with
+        the next iteration)."""
+        from humanoid.envs.base.legged_robot import KERNEL_REWARD_TERMS
+        snap, ev = pending["snap"], pending["ev"]
+        snap["done"].synchronize()
+        pin, slot = self._log_pin, snap["slot"]
+        o, ls = pin["opt"][slot], pin["ls"][slot]
+        n = max(float(o[7]), 1.0)
+        self.alg.last_denoise_loss = float(o[10]) / n if snap["aux"] else None
+        steps = max(float(ls[22]), 1.0)
+        ep = {"rew_" + nm: float(ls[KERNEL_REWARD_TERMS.index(nm)]) / steps for nm in self.env.reward_names}
+        k = int(ls[25])
+        collection_time, learn_time = ev[0].elapsed_time(ev[1]) * 1e-3, ev[1].elapsed_time(ev[2]) * 1e-3
+        self.last_collection_time, self.last_learn_time = collection_time, learn_time
+        self.log(dict(it=pending["it"], num_learning_iterations=num_learning_iterations, collection_time=collection_time,
+                      learn_time=learn_time, mean_value_loss=float(o[4]) / n, mean_surrogate_loss=float(o[3]) / n, ep_infos=[ep],
+                      rewbuffer=deque(ls[32:32 + k].tolist(), maxlen=100), lenbuffer=deque(ls[132:132 + k].tolist(), maxlen=100),
+                      learning_rate=float(o[0]), mean_std=float(pin["std"][slot][0])))
+
     def log(self, locs, width=80, pad=35):
         self.tot_timesteps += self.num_steps_per_env * self.env.num_envs
         iteration_time = locs["collection_time"] + locs["learn_time"]
@@ -260,15 +314,19 @@ class OnPolicyRunner:
         ep_string = ""
         if locs["ep_infos"]:
             for key in locs["ep_infos"][0]:
-                vals = torch.stack([torch.as_tensor(e[key], device=self.device).float().reshape(()) for e in locs["ep_infos"]])
-                value = float(vals.mean())
+                if all(isinstance(e[key], float) for e in locs["ep_infos"]):        # the device-side log sink hands in host numbers
+                    value = sum(e[key] for e in locs["ep_infos"]) / len(locs["ep_infos"])
+                else:
+                    vals = torch.stack([torch.as_tensor(e[key], device=self.device).float().reshape(()) for e in locs["ep_infos"]])
+                    value = float(vals.mean())
                 scal("Episode/" + key, value, locs["it"])
                 ep_string += f"""{f'Mean episode {key}:':>{pad}} {value:.4f}\n"""
-        mean_std = float(self.alg.actor_critic.std.mean())
+        mean_std = locs["mean_std"] if "mean_std" in locs else float(self.alg.actor_critic.std.mean())
+        learning_rate = locs["learning_rate"] if "learning_rate" in locs else self.alg.learning_rate
         fps = int(self.num_steps_per_env * self.env.num_envs / iteration_time)
         scal("Loss/value_function", locs["mean_value_loss"], locs["it"])
         scal("Loss/surrogate", locs["mean_surrogate_loss"], locs["it"])
-        scal("Loss/learning_rate", self.alg.learning_rate, locs["it"])
+        scal("Loss/learning_rate", learning_rate, locs["it"])
         if getattr(self.alg, "denoise_coef", 0.0) and getattr(self.alg, "last_denoise_loss", None) is not None:
             scal("Loss/denoise_mse", self.alg.last_denoise_loss, locs["it"])
         scal("Policy/mean_noise_std", mean_std, locs["it"])
