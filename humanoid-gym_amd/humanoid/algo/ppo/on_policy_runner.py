@@ -321,7 +321,7 @@ class OnPolicyRunner:
                     value = float(vals.mean())
                 scal("Episode/" + key, value, locs["it"])
                 ep_string += f"""{f'Mean episode {key}:':>{pad}} {value:.4f}\n"""
-        mean_std = locs["mean_std"] if "mean_std" in locs else float(self.alg.actor_critic.std.mean())
+        mean_std = locs["mean_std"] if "mean_std" in locs else float(self.alg.actor_critic.std.detach().mean())
         learning_rate = locs["learning_rate"] if "learning_rate" in locs else self.alg.learning_rate
         fps = int(self.num_steps_per_env * self.env.num_envs / iteration_time)
         scal("Loss/value_function", locs["mean_value_loss"], locs["it"])

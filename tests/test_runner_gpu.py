@@ -146,3 +146,33 @@ def test_log_sink_is_the_reference_bookkeeping():
     torch.testing.assert_close(env._buf.log_cur[1].cpu(), cur_l, rtol=0, atol=0)
     env.bind_transition(None)
     env.bind_log_sink(False)
+
+
+def test_asynchronous_log_prints_what_the_synchronous_one_does(tmp_path, capsys, monkeypatch):
+    """Logging runs format iteration k's block from a pinned-host snapshot while iteration k + 1 runs (OnPolicyRunner._log_flush).
+    Same seed, HGYM_ASYNC=0 (the per-iteration synchronising loop) against the default: every block present, in order, and every
+    line that is not a wall-clock figure identical (losses, noise std, mean reward / episode length, all 22 episode terms)."""
+    from humanoid.envs import task_registry
+    from humanoid.utils import get_args
+
+    def run(tag, async_on):
+        monkeypatch.setenv("HGYM_ASYNC", "1" if async_on else "0")
+        args = get_args(["--task=humanoid_ppo", "--headless", "--num_envs", "256", "--seed", "3"])
+        env, _ = task_registry.make_env(name=args.task, args=args)
+        env.episode_length_buf = torch.randint(2340, 2400, (256,), device="cuda")     # time-outs inside the window: episode statistics exist
+        runner, _ = task_registry.make_alg_runner(env=env, name=args.task, args=args, log_root=str(tmp_path / tag))
+        capsys.readouterr()
+        runner.learn(num_learning_iterations=4, init_at_random_ep_len=False)
+        torch.cuda.synchronize()
+        out = capsys.readouterr().out
+        keep = [ln for ln in out.splitlines() if ":" in ln and not any(w in ln for w in ("steps/s", "time:", "ETA", "Iteration time"))]
+        return keep, out.count("Learning iteration")
+
+    # (as in the reference, `--seed` reaches the ENV through the task's registered train cfg, i.e. from the second make_env of a
+    # process on: helpers.update_cfg_from_args / task_registry.get_cfgs -- one throw-away run puts both compared runs behind that)
+    run("warm", True)
+    sync_lines, sync_blocks = run("sync", False)
+    async_lines, async_blocks = run("async", True)
+    assert sync_blocks == async_blocks == 4
+    assert any("Mean reward" in ln for ln in sync_lines) and any("rew_tracking_lin_vel" in ln for ln in sync_lines)
+    assert sync_lines == async_lines
