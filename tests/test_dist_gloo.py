@@ -23,7 +23,8 @@ def _worker(rank, world, port, out_dir):
     P = 1000
     grads = torch.randn(P, generator=g)
     # [gradient | KL] exactly as hgym_ppo_grad leaves net.grads (P + 1 floats); hgym_ppo_apply then multiplies by
-    # 1 / world_size on the device (fp32 product) -- done here on the host
+    # 1 / world_size on the device (fp32 product) -- done here on the host: this file has no GPU.  The device-side mean is checked by
+    # tests/test_net_gpu.py::test_apply_with_world_size_forms_the_rank_mean_itself, the whole loop by tests/test_dist_gpu.py
     ext = torch.cat([grads, torch.tensor([0.01 * (rank + 1)])])
     g_in = grads.clone()
     D.sum_grads_and_kl(ext)
