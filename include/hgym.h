@@ -429,9 +429,10 @@ int32_t hgym_ppo_grad(const HgymNetConfig* cfg, const HgymPPOConfig* ppo, const 
 /* hgym_ppo_grad in two halves, for the data-parallel update (one process per GPU; the reference is single-process, its
  * `--horovod` flag is dead: utils/helpers.py:207-212): the flat gradient is exchanged in two buckets so that the first
  * all-reduce runs under the second half's kernels.
- *   part 0: forward, loss, dZ chain, then the weight gradients of the ACTOR: on return (stream order)
+ *   part 0: forward, loss, dZ chain (of every net, the auxiliary head included), then the weight gradients of the ACTOR: on return
+ *           (stream order)
  *           grads[0 .. hgym_net_param_offset(cfg, 1)) -- std | actor, the larger bucket (527 256 of 926 106 floats) -- are final;
- *   part 1: the weight gradients of the CRITIC (and the auxiliary head's forward / backward / weight gradients):
+ *   part 1: the weight gradients of the CRITIC (and of the auxiliary head):
  *           grads[hgym_net_param_offset(cfg, 1) .. P] -- critic | auxiliary head | the KL slot -- are final.
  * part 0 followed by part 1 leaves net->grads exactly as hgym_ppo_grad does (bit-identical); only opt_state[9] (the squared
  * norm hgym_ppo_apply may reuse with grad_norm_ready) is not maintained: apply must be called with grad_norm_ready = 0 or
@@ -456,8 +457,8 @@ int32_t hgym_ppo_apply(const HgymNetConfig* cfg, const HgymPPOConfig* ppo, const
 enum {
     HGYM_PROF_GEMM = 0,      /* generic MFMA GEMM launches (fp32 parity path / unsupported layer shapes) */
     HGYM_PROF_ENV_STEP = 1, HGYM_PROF_GAE = 2, HGYM_PROF_LOSS = 3,
-    HGYM_PROF_MLP_FWD = 4,   /* fused forward, update (64-row tiles, writes the activations) */
-    HGYM_PROF_MLP_BWD = 5,   /* fused dZ chain */
+    HGYM_PROF_MLP_FWD = 4,   /* the update's fused forward + loss + dZ chain (64-row tiles, writes the activations and their gradients) */
+    HGYM_PROF_MLP_BWD = 5,   /* (unused since the dZ chain runs inside the class-4 kernel; the value is kept) */
     HGYM_PROF_DW = 6,        /* all weight-gradient products */
     HGYM_PROF_REDUCE = 7,    /* split-K slab reduction */
     HGYM_PROF_APPLY = 8,     /* grad-norm + clip + Adam */
@@ -468,7 +469,7 @@ enum {
 int32_t hgym_prof_enable(int32_t on);  /* 1: start collecting (clears previous events), 0: stop */
 int32_t hgym_prof_summary(int32_t cls, int64_t* launches, double* total_ms, double* work);
 /* Kernel-internal phase clock for tuning the fused MLP kernels: while a caller-owned device buffer of `slots` int64 is
- * set, thread 0 of workgroup b of every mlp_fwd / mlp_bwd launch writes the 100 MHz wall clock at up to 8 phase
+ * set, thread 0 of workgroup b of every fused MLP launch (forward, update, rollout step) writes the 100 MHz wall clock at up to 8 phase
  * boundaries into dev[b*8 + phase] (launches with more than slots/8 workgroups are not instrumented).  NULL: off. */
 int32_t hgym_prof_phase_buffer(void* dev, int64_t slots);
 
