@@ -7,7 +7,8 @@ import torch
 from humanoid.envs import task_registry
 from humanoid.utils import get_args
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 100
-a = get_args(["--task=humanoid_ppo", "--headless", "--num_envs", "4096"])
+task = sys.argv[2] if len(sys.argv) > 2 else "humanoid_ppo"       # humanoid_dwl_ppo: + the denoising head's MSE
+a = get_args(["--task=" + task, "--headless", "--num_envs", "4096"])
 env, _ = task_registry.make_env(name=a.task, args=a)
 runner, _ = task_registry.make_alg_runner(env=env, name=a.task, args=a, log_root=None)
 alg = runner.alg
@@ -18,6 +19,7 @@ for it in range(iters):
     if it % 10 == 0 or it == iters - 1:
         st = alg.storage
         n = max(float(o[7]), 1.0)
-        print("it %3d  value_loss %.5f  surrogate %+.5f  kl %.5f  lr %.2e  |grad| %.3f  mean_rew/step %.4f  std %.3f  finite %s" % (
+        print("it %3d  value_loss %.5f  surrogate %+.5f  kl %.5f  lr %.2e  |grad| %.3f  mean_rew/step %.4f  std %.3f  finite %s%s" % (
             it, float(o[4]) / n, float(o[3]) / n, float(o[2]) / n, float(o[0]), float(o[6]), float(st.rewards.mean()),
-            float(alg.actor_critic.std.mean()), bool(torch.isfinite(alg.net.params).all())), flush=True)
+            float(alg.actor_critic.std.detach().mean()), bool(torch.isfinite(alg.net.params).all()),
+            ("  denoise_mse %.5f" % (float(o[10]) / n)) if "dwl" in task else ""), flush=True)
