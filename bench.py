@@ -229,9 +229,13 @@ def _roofline(L, runner, elapsed_per_iter_ms, precision, n_profiled_iters):
             continue
         peak, unit, scale = (HBM_PEAK_GBS, "GB/s", 1e9) if bound == "hbm" else (mfma_peak, "TFLOP/s", 1e12)
         ach = work / (ms * 1e-3) / scale
+        tr = traffic.get(name)
         ks.append(dict(kernel=name, bound=bound, launches_per_iter=n // n_profiled_iters, avg_launch_us=ms / n * 1e3, achieved=ach,
                        peak=peak, unit=unit, frac=ach / peak, share_of_iteration=ms / n_profiled_iters / elapsed_per_iter_ms,
-                       traffic=traffic.get(name)))
+                       traffic=tr,
+                       # counter traffic per launch over this run's launch time, as a fraction of the HBM peak: how close the kernel
+                       # is to being bound by the bytes it actually moves, whatever its algorithmic bound says
+                       traffic_frac_of_hbm_peak=(tr / (ms / n * 1e-3) / 1e9 / HBM_PEAK_GBS) if tr else None))
     ks.sort(key=lambda k: -k["share_of_iteration"])
     return ks
 
@@ -314,7 +318,7 @@ def _roofline_obj(ks, pick=None):
     dom = ks[0] if pick is None else next((k for k in ks if k["kernel"] == pick), ks[0])
     rest = [k for k in ks if k is not dom]
     return dict(bound=dom["bound"], achieved=dom["achieved"], peak=dom["peak"], unit=dom["unit"], frac=dom["frac"],
-                traffic=dom["traffic"], kernel=dom["kernel"], launches_per_iter=dom["launches_per_iter"],
+                traffic=dom["traffic"], traffic_frac_of_hbm_peak=dom.get("traffic_frac_of_hbm_peak"), kernel=dom["kernel"], launches_per_iter=dom["launches_per_iter"],
                 avg_launch_us=dom["avg_launch_us"], share_of_iteration=dom["share_of_iteration"], kernels=rest)
 
 
