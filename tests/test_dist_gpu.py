@@ -52,6 +52,7 @@ def _worker(rank, world, port, out_dir, backend="gloo"):
     dist.destroy_process_group()
 
 
+@pytest.mark.timeout(600)
 def test_two_ranks_one_gpu_stay_in_lockstep(tmp_path):
     port = 29700 + (os.getpid() % 2000)
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
@@ -69,6 +70,7 @@ def test_two_ranks_one_gpu_stay_in_lockstep(tmp_path):
     assert a["comm_events"] == 32 and 0 < a["split"] < a["P"]
 
 
+@pytest.mark.timeout(600)
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one device per rank; this box has one GPU")
 def test_two_ranks_two_gpus_rccl(tmp_path):
     """The same run over RCCL (backend "nccl"), rank r on device r: bit-identical parameters after 32 synchronised steps."""
@@ -110,6 +112,7 @@ def _single_rank_worker(rank, world, port, out_dir, collectives):
         dist.destroy_process_group()
 
 
+@pytest.mark.timeout(600)
 def test_one_rank_rccl_collective_path_changes_nothing(tmp_path):
     """A box with one GPU cannot run two RCCL ranks, but it can run ONE: HGYM_DIST_SINGLE=1 sends the update through everything
     the N > 1 path does -- parameter broadcast, the advantage-statistics all-reduce, the gradient in two parts with an asynchronous
