@@ -245,6 +245,49 @@ __device__ __forceinline__ void mma_stream(WRing<GR, D>& R, const u32x4* __restr
     }
 }
 
+// mma_chunk: the 4 k-steps t0 .. t0 + 3 (t0 % 4 == 0, D divides 4) of a stream whose input arrives in 4-k-block LDS chunks
+// (first layer).  LAST: this is the final chunk, nothing beyond k-step t0 + 3 exists.
+template <int G, int MB, int D, bool LAST, int XBP = -1, int GR>
+__device__ __forceinline__ void mma_chunk(WRing<GR, D>& R, const u32x4* __restrict__ wl, int wstride, int t0, const char* xl, int CBx,
+                                          int lane, f32x4 (&acc)[MB][G]) {
+    static_assert(D == 2 || D == 4, "ring depth must divide the chunk");
+    constexpr bool XB = XBP < 0 ? (MB <= 2) : (XBP != 0);
+    const int r = lane & 15, q = lane >> 4;
+    const char* xb = xl + (q >> 1) * 512 + r * 32 + (q & 1) * 16;
+    u32x4 xa[MB], xc[XB ? MB : 1];
+    if (XB) {
+#pragma unroll
+        for (int i = 0; i < MB; ++i) xa[i] = *reinterpret_cast<const u32x4*>(xb + (i * CBx) * 512);
+    }
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+        const int d = s4 % D;
+        if (XB) {
+            if (s4 + 1 < 4) {
+#pragma unroll
+                for (int i = 0; i < MB; ++i) {
+                    const u32x4 v = *reinterpret_cast<const u32x4*>(xb + (i * CBx + 2 * (s4 + 1)) * 512);
+                    if (s4 & 1) xa[i] = v; else xc[i] = v;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < MB; ++i) xa[i] = *reinterpret_cast<const u32x4*>(xb + (i * CBx + 2 * s4) * 512);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < MB; ++i)
+#pragma unroll
+            for (int g = 0; g < G; ++g) mma_frag<__bf16>(R.w[d][g], (XB && (s4 & 1)) ? xc[i] : xa[i], acc[i][g]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!LAST || s4 + D < 4) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) R.w[d][g] = wl[(int64_t)g * wstride + (t0 + s4 + D) * 64];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // ELU of the bf16 path: exp(z) as v_exp_f32(z * log2 e).  The libm expf the fp32 parity path keeps (elu_f) is ~15 VALU
 // instructions per element (argument split, ldexp, two range selects) and the epilogues were VALU-bound on them; the result
 // is rounded to bf16 (2^-8 relative) right after, against this form's <= 1e-6 relative error for |z| <= 18.
@@ -435,14 +478,8 @@ __device__ __forceinline__ void fwd_body(const FwdArgs& a, const FusedNet& n, bo
     WRing<GH, D> r1, r2;             // weight streams of the two hidden layers
     auto prime1 = [&]() { hidden_prime<GH, D>(r1, L1, wave, lane); };
 
-    // ---------------------------------------------------------------- layer 0: the whole input tile staged once, then a pure weight stream
-    // All gathers of the tile (NC chunks of 128 columns, IT 16-byte items per thread each) are issued at kernel entry and land as
-    // bf16 in LDS over P and Q (both dead until this layer's epilogue): BM x 32 KB columns = P + Q exactly for the 768-column input.
-    // One memory round trip instead of one per chunk: the wave's loads return in order, so a chunk-by-chunk gather (one chunk
-    // ahead of the MFMAs) put an HBM round trip in front of the weight stream at every chunk boundary -- 6 x ~1.6 us of the
-    // actor tile's first layer, in the rollout and in the update alike.
+    // ---------------------------------------------------------------- layer 0: input streamed in 128-column chunks
     {
-        constexpr int NCMAX = 768 / FUSED_CHUNK;       // fused_supported: first-layer input <= 768 columns
         const int NC = L0.KB / 4;
         const int CB0 = 2 * L0.KB;
         const int f4 = tid & 31;
@@ -457,46 +494,41 @@ __device__ __forceinline__ void fwd_body(const FwdArgs& a, const FusedNet& n, bo
             srow[u] = n.x + src * n.ldx;
             lrow[u] = row;
         }
-        F4 stg[NCMAX][IT];
-        // one unconditional 16-byte load per item: the address is clamped to the last full vector of the row (chunks past the
-        // input's last one re-read it and are not written).  stage_write re-aligns / zero-fills the (at most one per row)
-        // straddling item with selects, converts and stores to LDS.
-        auto stage_load = [&]() {
+        F4 stg[IT];
+        // one unconditional 16-byte load per item: the address is clamped to the last full vector of the row.  stage_load
+        // ONLY issues the loads (nothing here may consume them: the data must stay in flight under the MFMAs of the current
+        // chunk); stage_write re-aligns / zero-fills the (at most one per row) straddling item with selects, converts and
+        // stores to LDS.
+        auto stage_load = [&](int c) {
+            const int col = c * FUSED_CHUNK + f4 * 4;
+            const int cc = col < L0.K - 4 ? col : L0.K - 4;
 #pragma unroll
-            for (int c = 0; c < NCMAX; ++c) {
-                const int col = c * FUSED_CHUNK + f4 * 4;
-                const int cc = col < L0.K - 4 ? col : L0.K - 4;
-#pragma unroll
-                for (int u = 0; u < IT; ++u) stg[c][u] = ld_stream_f4<(HGYM_NT & 1) != 0>(srow[u] + cc);
-            }
+            for (int u = 0; u < IT; ++u) stg[u] = ld_stream_f4<(HGYM_NT & 1) != 0>(srow[u] + cc);
         };
-        auto stage_write = [&]() {
+        auto stage_write = [&](int c, int buf) {
+            char* dst = Q + buf * (BM * FUSED_CHUNK * 2);
+            const int col = c * FUSED_CHUNK + f4 * 4;
+            const int cc = col < L0.K - 4 ? col : L0.K - 4;
+            const int sh = col - cc;                       // 0 for full items, 1..3 for the straddling one, >= 4: all padding
 #pragma unroll
-            for (int c = 0; c < NCMAX; ++c) {
-                if (c >= NC) break;
-                const int col = c * FUSED_CHUNK + f4 * 4;
-                const int cc = col < L0.K - 4 ? col : L0.K - 4;
-                const int sh = col - cc;                       // 0 for full items, 1..3 for the straddling one, >= 4: all padding
+            for (int u = 0; u < IT; ++u) {
+                float v[4];
 #pragma unroll
-                for (int u = 0; u < IT; ++u) {
-                    float v[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int k = e + sh;
-                        float r = 0.0f;
-                        r = k == 0 ? stg[c][u].v[0] : r;
-                        r = k == 1 ? stg[c][u].v[1] : r;
-                        r = k == 2 ? stg[c][u].v[2] : r;
-                        r = k == 3 ? stg[c][u].v[3] : r;
-                        v[e] = r;
-                    }
-                    const u32x2 pk = pack_bf16x4(v[0], v[1], v[2], v[3]);
-                    const int inblk = (lrow[u] & 15) * 32 + (f4 & 3) * 8;
-                    *reinterpret_cast<u32x2*>(P + ((lrow[u] >> 4) * CB0 + c * 8 + (f4 >> 2)) * 512 + inblk) = pk;
-                    if (train)
-                        st_stream_u2<(HGYM_NT & 2) != 0>(reinterpret_cast<char*>(n.X0) +
-                                                         ((mbg0 + (lrow[u] >> 4)) * CB0 + c * 8 + (f4 >> 2)) * 512 + inblk, pk);
+                for (int e = 0; e < 4; ++e) {
+                    const int k = e + sh;
+                    float r = 0.0f;
+                    r = k == 0 ? stg[u].v[0] : r;
+                    r = k == 1 ? stg[u].v[1] : r;
+                    r = k == 2 ? stg[u].v[2] : r;
+                    r = k == 3 ? stg[u].v[3] : r;
+                    v[e] = r;
                 }
+                const u32x2 pk = pack_bf16x4(v[0], v[1], v[2], v[3]);
+                const int inblk = (lrow[u] & 15) * 32 + (f4 & 3) * 8;
+                *reinterpret_cast<u32x2*>(dst + ((lrow[u] >> 4) * 8 + (f4 >> 2)) * 512 + inblk) = pk;
+                if (train)
+                    st_stream_u2<(HGYM_NT & 2) != 0>(reinterpret_cast<char*>(n.X0) +
+                                                     ((mbg0 + (lrow[u] >> 4)) * CB0 + c * 8 + (f4 >> 2)) * 512 + inblk, pk);
             }
         };
         const int nb0 = wave * G1;
@@ -506,16 +538,22 @@ __device__ __forceinline__ void fwd_body(const FwdArgs& a, const FusedNet& n, bo
         const u32x4* wl0 = L0.Wf + (int64_t)nb0 * L0.KB * 64 + lane;
         phase_stamp(a.dbg, 0);
         wring_prime<G1, D>(r0, wl0, L0.KB * 64, L0.KB);
-        stage_load();
+        stage_load(0);
         hook_early(extra);
-        stage_write();
+        stage_write(0, 0);
         bias_to_lds();
         __syncthreads();
         phase_stamp(a.dbg, 1);
-        mma_stream<G1, MB, D, XBF>(r0, wl0, L0.KB * 64, L0.KB, P, CB0, lane, acc);
+        // steady state: no condition inside the body (see mma_stream); the last chunk is peeled
+        for (int c = 0; c + 1 < NC; ++c) {
+            stage_load(c + 1);
+            mma_chunk<G1, MB, D, false, XBF>(r0, wl0, L0.KB * 64, c * 4, Q + (c & 1) * (BM * FUSED_CHUNK * 2), 8, lane, acc);
+            stage_write(c + 1, (c + 1) & 1);
+            __syncthreads();
+        }
+        mma_chunk<G1, MB, D, true, XBF>(r0, wl0, L0.KB * 64, (NC - 1) * 4, Q + ((NC - 1) & 1) * (BM * FUSED_CHUNK * 2), 8, lane, acc);
         phase_stamp(a.dbg, 2);
         if (AHEAD) prime1();
-        __syncthreads();          // every wave is done reading the input tile: the epilogue writes H0 over it
         epilogue_elu<G1, MB>(acc, bl, nb0, P, L0.NB, train_h ? n.H[0] : nullptr, mbg0, lane);
     }
     __syncthreads();
@@ -718,15 +756,10 @@ struct FbLoss {
 // LDS of the fused kernel behind the forward's P / Q / bias regions: the dZ3 tile (64 rows x 32 * layer[3].NBB bf16 columns), the
 // head waves' partial sums, and H2 (64 x layer[2].N bf16) -- the forward writes it there instead of over H0, so that all three
 // activations are resident for the dZ chain
-// ... and the tile's loss inputs (fb_loss_width floats per row), gathered at kernel entry with the observation rows
-HG_HD int fb_loss_width(int which, int A, int No) { return which == 0 ? 3 * A + 2 : (which == 1 ? 2 : No); }
-HG_HD int fb_lds_extra(const FusedNet& n, int which, int A) {
-    return 64 * 64 * n.layer[3].NBB + 4 * 32 * 4 + 64 * n.layer[2].N * 2 + 64 * 4 * fb_loss_width(which, A, n.layer[3].N);
-}
+HG_HD int fb_lds_extra(const FusedNet& n) { return 64 * 64 * n.layer[3].NBB + 4 * 32 * 4 + 64 * n.layer[2].N * 2; }
 
 template <int G1, bool AUX = false>
 __device__ __forceinline__ void fb_body(const FwdArgs& a, const FbLoss& L, const FusedNet& n, bool is_actor, char* smem) {
-    constexpr int LI_MAX = AUX ? 6 : 3;       // loss-input floats per thread: 64 rows x (3 * 12 + 2 | 2 | <= 96) / 1024 threads
     constexpr int BM = 64, NW = 16, D = 2, MB = BM / 16;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
@@ -740,56 +773,14 @@ __device__ __forceinline__ void fb_body(const FwdArgs& a, const FbLoss& L, const
     char* H2 = R0 + BM * 64 * NBB3 + 4 * 32 * 4;
     const int A = a.A;
     const float invB = 1.0f / (float)a.M;
-    // The loss inputs of the tile's 64 rows -- actor: actions, old mu, old sigma, advantage, old log-prob; critic: return, old
-    // value; auxiliary head: its target columns -- are gathered through the minibatch indices at kernel ENTRY, between the issue of
-    // the observation gather and its LDS writes, and parked in LDS (row-major, W floats per row).  Read on the head wavefronts at
-    // the end of the forward they were a dependent chain of HBM round trips (index, then row) with nothing to hide under.
-    float* LI = reinterpret_cast<float*>(H2 + BM * n.layer[2].N * 2);
-    const int W = fb_loss_width(AUX ? 2 : (is_actor ? 0 : 1), A, n.layer[3].N);
-    // (the row indices first, ahead of every other load of the tile: a wave's loads return in order, so the addresses below are
-    // ready as soon as the indices are, not one memory round trip behind the observation gather)
-    int64_t li_row[LI_MAX];
-#pragma unroll
-    for (int u = 0; u < LI_MAX; ++u) {
-        const int i = tid + u * (NW * 64);
-        int rl = i / W;
-        rl = rl < BM ? rl : BM - 1;
-        int m = m0 + rl;
-        m = m < a.M ? m : a.M - 1;
-        li_row[u] = a.idx ? a.idx[m] : (int64_t)m;
-    }
-    auto loss_inputs = [&](int) {
-        float lv[LI_MAX];
-#pragma unroll
-        for (int u = 0; u < LI_MAX; ++u) {
-            const int i = tid + u * (NW * 64);
-            lv[u] = 0.0f;
-            if (i < BM * W) {
-                const int rl = i / W, c = i - rl * W;
-                const int64_t row = li_row[u];
-                const float* src;
-                if (AUX) src = L.aux_target + row * L.aux_ldt + L.aux_off + c;
-                else if (!is_actor) src = (c == 0 ? L.returns : L.values) + row;
-                else if (c < A) src = L.actions + row * A + c;
-                else if (c < 2 * A) src = L.old_mu + row * A + (c - A);
-                else if (c < 3 * A) src = L.old_sigma + row * A + (c - 2 * A);
-                else src = (c == 3 * A ? L.advantages : L.logp) + row;
-                lv[u] = *src;
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < LI_MAX; ++u) {
-            const int i = tid + u * (NW * 64);
-            if (i < BM * W) LI[i] = lv[u];
-        }
-    };
     float aux_se = 0.0f;
     // auxiliary head: lane (r, q) of head wave hw, row m, outputs nb * 16 + 4q .. + 3 (called once per column block).
     // loss = coef * mean_b sum_j (y - t)^2 / No, dL/dy = 2 coef (y - t) / (B No)    (aux_mse_kernel's arithmetic)
     auto head_aux = [&](int hw, int m, int nb, const float (&out)[4]) {
         const int No = n.layer[3].N;
         const bool valid = m < a.M;
-        const float* t = LI + (hw * 16 + r) * W;
+        const int64_t row = a.idx ? a.idx[valid ? m : a.M - 1] : (int64_t)(valid ? m : a.M - 1);
+        const float* t = L.aux_target + row * L.aux_ldt + L.aux_off;
         const float gs = 2.0f * L.aux_coef / ((float)a.M * (float)No);
         float g[4];
 #pragma unroll
@@ -820,17 +811,25 @@ __device__ __forceinline__ void fb_body(const FwdArgs& a, const FbLoss& L, const
         // lane (r, q) of head wave hw: row m, head outputs 4q .. 4q + 3.  ppo.py:128-168 forward scalars + the hand-written
         // backward of the loss w.r.t. mu, std and V (oracle/ppo_oracle.py: ppo_loss_and_grads), as in ppo_loss_kernel
         const bool valid = m < a.M;
-        const float* li = LI + (hw * 16 + r) * W;       // this row's loss inputs (loss_inputs(): gathered at kernel entry)
+        const int64_t row = a.idx ? a.idx[valid ? m : a.M - 1] : (int64_t)(valid ? m : a.M - 1);
         float g[4] = {0.f, 0.f, 0.f, 0.f};
         float part[11];
 #pragma unroll
         for (int k = 0; k < 11; ++k) part[k] = 0.0f;
         if (is_actor) {
             float act[4] = {0.f, 0.f, 0.f, 0.f}, mo[4] = {0.f, 0.f, 0.f, 0.f}, so[4] = {1.f, 1.f, 1.f, 1.f}, sg[4] = {1.f, 1.f, 1.f, 1.f};
+            if (4 * q + 3 < A) {
+                const F4 qa = *reinterpret_cast<const F4*>(L.actions + row * A + 4 * q);
+                const F4 qo = *reinterpret_cast<const F4*>(L.old_mu + row * A + 4 * q);
+                const F4 qs = *reinterpret_cast<const F4*>(L.old_sigma + row * A + 4 * q);
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (4 * q + e < A) { act[e] = li[4 * q + e]; mo[e] = li[A + 4 * q + e]; so[e] = li[2 * A + 4 * q + e]; }
-            const float adv = li[3 * A], lpold = li[3 * A + 1];
+                for (int e = 0; e < 4; ++e) { act[e] = qa.v[e]; mo[e] = qo.v[e]; so[e] = qs.v[e]; }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (4 * q + e < A) { act[e] = L.actions[row * A + 4 * q + e]; mo[e] = L.old_mu[row * A + 4 * q + e]; so[e] = L.old_sigma[row * A + 4 * q + e]; }
+            }
+            const float adv = L.advantages[row], lpold = L.logp[row];
             float lp = 0.0f, ent = 0.0f, kl = 0.0f, diff[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -867,7 +866,7 @@ __device__ __forceinline__ void fb_body(const FwdArgs& a, const FbLoss& L, const
                     }
             }
         } else {
-            const float ret = li[0], vold = li[1];
+            const float ret = L.returns[row], vold = L.values[row];
             const float v = out[0];
             const float vc = vold + clampf(v - vold, -L.clip, L.clip);
             const float l1 = (v - ret) * (v - ret), l2 = (vc - ret) * (vc - ret);
@@ -909,14 +908,14 @@ __device__ __forceinline__ void fb_body(const FwdArgs& a, const FbLoss& L, const
         }
     };
     if constexpr (AUX) {
-        fwd_body<BM, NW, D, G1, true>(a, n, false, smem, loss_inputs, FwdNoop(), FwdNoop(), 0, FwdNoop(), head_aux, H2);
+        fwd_body<BM, NW, D, G1, true>(a, n, false, smem, FwdNoop(), FwdNoop(), FwdNoop(), 0, FwdNoop(), head_aux, H2);
         if (wave < MB) {
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) aux_se += __shfl_xor(aux_se, o, 64);
             if (lane == 0) red[wave * 32 + 29] = aux_se;
         }
     } else {
-        fwd_body<BM, NW, D, G1, false>(a, n, is_actor, smem, loss_inputs, FwdNoop(), FwdNoop(), 0, FwdNoop(), head, H2);
+        fwd_body<BM, NW, D, G1, false>(a, n, is_actor, smem, FwdNoop(), FwdNoop(), FwdNoop(), 0, FwdNoop(), head, H2);
     }
     __syncthreads();          // dZ3 tile and the per-wave sums are in LDS; H0 sits in P, H1 in Q, H2 in its own buffer
     if (tid < 32) {

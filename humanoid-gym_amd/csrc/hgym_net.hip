@@ -70,9 +70,6 @@ static bool fused_supported(const HgymNetConfig* c) {
         if (d[1] % 128 || !(g1 == 2 || g1 == 4 || g1 == 6)) return false;
         if (d[2] % 128 || d[2] > 768 || d[3] % 128 || d[3] > 768) return false;
         if (d[4] > 16) return false;
-        // the first layer keeps the whole (128-padded) input tile in the LDS the hidden activations use later (fwd_body: P and Q)
-        const int k0 = (int)round_up(d[0], 128);
-        if (k0 > 768 || k0 > std::max(d[1], d[3]) + std::max(256, d[2])) return false;
     }
     return true;
 }
@@ -81,7 +78,6 @@ static bool fused_aux_supported(const HgymNetConfig* c) {
     if (c->aux_layers != 4 || getenv("HGYM_NO_FUSED_AUX")) return false;
     const int32_t* d = c->aux_dims;
     if (d[1] != 512) return false;         // the wide-head instantiation of the forward exists for this first width only
-    if (round_up(d[0], 128) > 768) return false;
     if (d[2] % 128 || d[2] > 768 || d[3] % 128 || d[3] > 768) return false;
     return d[4] > 16 && d[4] <= 96;
 }
@@ -971,7 +967,7 @@ struct NetRunner {
             size_t lds = 0;
             for (int i = 0; i < nets; ++i)
                 lds = std::max(lds, (size_t)fused_lds_p(fa.net[i], 64) + (size_t)fused_lds_q(fa.net[i], 64) + (size_t)fused_lds_bias(fa.net[i]) +
-                                        (size_t)fb_lds_extra(fa.net[i], i, A));
+                                        (size_t)fb_lds_extra(fa.net[i]));
             HG_REQUIRE(lds <= 160 * 1024, HGYM_E_UNSUPPORTED, "mlp_fb_kernel needs %zu bytes of LDS", lds);
             static size_t attr_lds = 0;
             if (lds > attr_lds) {
