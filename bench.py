@@ -209,7 +209,7 @@ def cpu_baseline(num_envs, T=60, full_minibatch=True, allow_reference=True):
 
 
 # ------------------------------------------------------------------------------------------------ GPU runs
-def _roofline(L, runner, elapsed_per_iter_ms, precision, n_profiled_iters):
+def _roofline(L, runner, elapsed_per_iter_ms, precision, n_profiled_iters, traffic_ok=True):
     mfma_peak = MFMA_BF16_PEAK_TFLOPS if precision == "bf16" else 157.3
     classes = [  # (class id, kernel, bound)
         (L.PROF_ROLLOUT, "rollout_step_kernel", "hbm"),      # policy act + env step + previous finaliser, one launch per vec-step
@@ -220,7 +220,7 @@ def _roofline(L, runner, elapsed_per_iter_ms, precision, n_profiled_iters):
         (L.PROF_APPLY, "sqnorm+adam_kernel", "hbm"), (L.PROF_GAE, "gae_kernel", "hbm")]
     traffic = {}
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")     # HBM bytes per launch from rocprofv3 --pmc passes
-    if os.path.exists(tpath):
+    if os.path.exists(tpath) and traffic_ok:     # the counters were collected on the headline workload: they say nothing about another size
         traffic = json.load(open(tpath)).get("kernels", {})
     ks = []
     for cid, name, bound in classes:
@@ -291,7 +291,8 @@ def run_config(args, task, num_envs, rank, world, local, dist, steps, warmup, lo
         torch.cuda.synchronize()
         os.environ["HGYM_GRAPH"] = "1"
         if rank == 0:
-            res["kernels"] = _roofline(L, runner, res["ms_per_step"], args.precision, 2)
+            res["kernels"] = _roofline(L, runner, res["ms_per_step"], args.precision, 2,
+                                       traffic_ok=(task == "humanoid_ppo" and num_envs == 4096 and args.precision == "bf16"))
             L.lib.hgym_prof_enable(0)
         if world > 1 and runner.alg.comm_timing:
             ev = runner.alg.comm_timing
