@@ -954,6 +954,63 @@ __global__ __launch_bounds__(1024) void mlp_fb_kernel(const FwdArgs a, const FbL
     else if (g1 == 1) fb_body<1>(a, L, n, which == 0, smem);
 }
 
+// ================================================================================================ per-minibatch loss scalars
+constexpr int LOSS_PARTIALS = 32;   // floats per loss workgroup: surrogate, value loss, entropy, kl, dstd[12], dbias_mu[12], dbias_v, aux, pad
+// Sums the per-tile loss partials of a minibatch ([nblocks][32], mlp_fb_kernel / ppo_loss_kernel) into opt_state and writes the
+// gradients that are plain column sums: std, the two head biases (fused path), the KL slot behind the flat gradient.
+// One workgroup of 256 or 512 threads -- its own launch (ppo_scalars_kernel) or, on the fused path, one extra workgroup of the
+// weight-gradient launch that follows the loss anyway (dw_kernel_rs: DwArgs::scal_bid).  The summation order does not depend on the
+// thread count (16 interleaved partial sums per quantity, combined in a fixed order).
+struct ScalArgs {
+    int nblocks, B, A, aux_No;
+    const float* partials;
+    float* grads_std;
+    float* grads_bmu;      // may be null (generic path: the head bias gradients come from the GEMMs)
+    float* grads_bv;
+    float* kl_slot;
+    double* opt;
+};
+__device__ __forceinline__ void ppo_scalars_block(const ScalArgs& a, int tid, int nthreads) {
+    __shared__ double red[16][LOSS_PARTIALS + 1];
+    const float* __restrict__ partials = a.partials;
+    const int nblocks = a.nblocks, B = a.B, A = a.A;
+    const int k = tid & (LOSS_PARTIALS - 1);
+    for (int part = tid / LOSS_PARTIALS; part < 16; part += nthreads / LOSS_PARTIALS) {     // 16 partial sums per quantity
+        // four independent partial sums (combined in a fixed order): a single dependent chain of nblocks / 16 loads was
+        // latency-bound once the fused forward + backward kernel started handing in one partial row per 64-row tile (960 rows)
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        int b = part;
+        for (; b + 48 < nblocks; b += 64) {
+            const float v0 = partials[(int64_t)b * LOSS_PARTIALS + k], v1 = partials[(int64_t)(b + 16) * LOSS_PARTIALS + k];
+            const float v2 = partials[(int64_t)(b + 32) * LOSS_PARTIALS + k], v3 = partials[(int64_t)(b + 48) * LOSS_PARTIALS + k];
+            s0 += (double)v0; s1 += (double)v1; s2 += (double)v2; s3 += (double)v3;
+        }
+        for (; b < nblocks; b += 16) s0 += (double)partials[(int64_t)b * LOSS_PARTIALS + k];
+        red[part][k] = (s0 + s1) + (s2 + s3);
+    }
+    __syncthreads();
+    if (tid < LOSS_PARTIALS) {
+        double t = 0.0;
+        for (int p = 0; p < 16; ++p) t += red[p][tid];
+        const int q = tid;
+        double* __restrict__ opt = a.opt;
+        if (q == 0) opt[3] += t / B;
+        if (q == 1) opt[4] += t / B;
+        if (q == 2) opt[5] += t / B;
+        if (q == 3) {
+            opt[2] += t / B;
+            opt[8] = t / B;
+            opt[7] += 1.0;
+            opt[9] = 0.0;                     // squared gradient norm: accumulated by reduce_slabs_kernel later in this call
+            a.kl_slot[0] = (float)(t / B);    // grads[P]: travels with the gradient in the ranks' one all-reduce
+        }
+        if (q >= 4 && q < 16 && q - 4 < A) a.grads_std[q - 4] = (float)t;
+        if (q >= 16 && q < 28 && q - 16 < A && a.grads_bmu) a.grads_bmu[q - 16] = (float)t;
+        if (q == 28 && a.grads_bv) a.grads_bv[0] = (float)t;
+        if (q == 29 && a.aux_No > 0) opt[10] += t / ((double)B * (double)a.aux_No);    // auxiliary head's MSE (the fused kernel's third grid row)
+    }
+}
+
 // ================================================================================================ weight gradients
 // dW[n][k] = sum_m Z[m][n] * X[m][k]  (Z = dZ_l, X = layer input), 128 x 128 output tiles, contraction split over blockIdx.y.
 #ifndef HGYM_DW_LOCKSTEP
@@ -983,6 +1040,8 @@ struct DwArgs {
     float* slabs;
     int64_t slab_stride;   // floats
     const char* zeros;     // >= 1 KiB of zeros (workspace): source of the stages past the end of a split
+    int scal_bid;          // >= 0: this workgroup sums the minibatch's loss partials instead (ppo_scalars_block); -1: none
+    ScalArgs sc;
 };
 
 __device__ __forceinline__ u32x4 tr_frag(const char* p0, const char* p1) {
@@ -1007,6 +1066,10 @@ __global__ __launch_bounds__(DW_THREADS, 2) void dw_kernel_rs(const DwArgs a) {
     const int wi = wave >> 1, wj = wave & 1;
     const int r = lane & 15, q = lane >> 4;
     const int bid = blockIdx.x;
+    if (bid == a.scal_bid) {      // the loss scalars ride in this launch: one workgroup, ~10 us beside 180 us of tiles
+        ppo_scalars_block(a.sc, tid, DW_THREADS);
+        return;
+    }
     // Block -> (tile, split).  Workgroups are dealt round-robin to the 8 XCDs (block b -> XCD b % 8), each with a private
     // 4 MiB L2.  All tiles of one split stream the SAME batch rows, so a split is pinned to one XCD: its ~62 tiles run there
     // concurrently and every operand block is fetched from HBM once and re-read from that L2 by the other tiles.

@@ -59,7 +59,6 @@ struct WsLayout {
 };
 
 constexpr int MAX_LOSS_BLOCKS = 8192;   // 256 samples each: minibatches up to 2 M samples
-constexpr int LOSS_PARTIALS = 32;   // floats per loss workgroup: surrogate, value loss, entropy, kl, dstd[12], dbias_mu[12], dbias_v, pad
 
 static bool fused_supported(const HgymNetConfig* c) {
     if (c->precision != HGYM_BF16 || c->actor_layers != 4 || c->critic_layers != 4) return false;
@@ -454,44 +453,7 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(const LossArgs a) {
 // opt_state: [0] lr [1] adam step [2] kl sum [3] surrogate sum [4] value-loss sum [5] entropy sum [6] grad norm
 //            [7] minibatches accumulated [8] last minibatch mean KL [9] grad sq-norm accumulator
 // grads_bmu / grads_bv (fused path only): gradients of the two head biases = column sums of the head gradients.
-__global__ __launch_bounds__(512) void ppo_scalars_kernel(int nblocks, int B, int A, const float* __restrict__ partials,
-                                                          float* __restrict__ grads_std, float* __restrict__ grads_bmu,
-                                                          float* __restrict__ grads_bv, float* __restrict__ kl_slot,
-                                                          double* __restrict__ opt, int aux_No = 0) {
-    __shared__ double red[16][LOSS_PARTIALS + 1];
-    const int k = threadIdx.x & (LOSS_PARTIALS - 1), part = threadIdx.x / LOSS_PARTIALS;   // 16 partial sums per quantity
-    // four independent partial sums per thread (combined in a fixed order): a single dependent chain of nblocks / 16 loads was
-    // latency-bound once the fused forward + backward kernel started handing in one partial row per 64-row tile (960 rows)
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    int b = part;
-    for (; b + 48 < nblocks; b += 64) {
-        const float v0 = partials[(int64_t)b * LOSS_PARTIALS + k], v1 = partials[(int64_t)(b + 16) * LOSS_PARTIALS + k];
-        const float v2 = partials[(int64_t)(b + 32) * LOSS_PARTIALS + k], v3 = partials[(int64_t)(b + 48) * LOSS_PARTIALS + k];
-        s0 += (double)v0; s1 += (double)v1; s2 += (double)v2; s3 += (double)v3;
-    }
-    for (; b < nblocks; b += 16) s0 += (double)partials[(int64_t)b * LOSS_PARTIALS + k];
-    red[part][k] = (s0 + s1) + (s2 + s3);
-    __syncthreads();
-    if (threadIdx.x < LOSS_PARTIALS) {
-        double t = 0.0;
-        for (int p = 0; p < 16; ++p) t += red[p][threadIdx.x];
-        const int q = threadIdx.x;
-        if (q == 0) opt[3] += t / B;
-        if (q == 1) opt[4] += t / B;
-        if (q == 2) opt[5] += t / B;
-        if (q == 3) {
-            opt[2] += t / B;
-            opt[8] = t / B;
-            opt[7] += 1.0;
-            opt[9] = 0.0;                     // squared gradient norm: accumulated by reduce_slabs_kernel later in this call
-            kl_slot[0] = (float)(t / B);      // grads[P]: travels with the gradient in the ranks' one all-reduce
-        }
-        if (q >= 4 && q < 16 && q - 4 < A) grads_std[q - 4] = (float)t;
-        if (q >= 16 && q < 28 && q - 16 < A && grads_bmu) grads_bmu[q - 16] = (float)t;
-        if (q == 28 && grads_bv) grads_bv[0] = (float)t;
-        if (q == 29 && aux_No > 0) opt[10] += t / ((double)B * (double)aux_No);    // auxiliary head's MSE (the fused kernel's third grid row)
-    }
-}
+__global__ __launch_bounds__(512) void ppo_scalars_kernel(const ScalArgs a) { ppo_scalars_block(a, threadIdx.x, blockDim.x); }
 
 // gradient finalise: sum the split-K slabs of every weight matrix into the flat gradient vector
 struct Segment {
@@ -858,7 +820,7 @@ struct NetRunner {
     // all weight (and hidden bias) gradients of nets [first, first + count): one launch, split-K slabs
     // (the auxiliary head, net 2, reads the ACTOR's bf16 copy of the gathered observation rows as its first-layer operand -- same
     // rows, same columns -- and every bias gradient of it is a column sum of dZ: its loss has no per-tile partial sums for them)
-    int32_t fused_dw(int first, int count, int B) {
+    int32_t fused_dw(int first, int count, int B, const ScalArgs* sc = nullptr) {
         const int Bp = (int)round_up(B, 64);
         DwArgs d;
         memset(&d, 0, sizeof(d));
@@ -891,8 +853,14 @@ struct NetRunner {
         d.slabs = at<float>(w.slabs);
         d.slab_stride = w.Ps;
         d.zeros = at<char>(w.zeros);
+        int blocks = tile * (int)round_up(w.dw_splits, 8);
+        d.scal_bid = -1;
+        if (sc) {
+            d.sc = *sc;
+            d.scal_bid = blocks++;
+        }
         prof_begin(HGYM_PROF_DW, s);
-        hipLaunchKernelGGL(dw_kernel_rs<3>, dim3(tile * (int)round_up(w.dw_splits, 8)), dim3(DW_THREADS), 2 * DW_STAGE_BYTES, s, d);
+        hipLaunchKernelGGL(dw_kernel_rs<3>, dim3(blocks), dim3(DW_THREADS), 2 * DW_STAGE_BYTES, s, d);
         prof_end(HGYM_PROF_DW, s, fl);
         HG_CHECK_LAUNCH("dw_kernel_rs");
         return HGYM_OK;
@@ -988,15 +956,15 @@ struct NetRunner {
             prof_end(HGYM_PROF_MLP_FWD, s, flops);
             HG_CHECK_LAUNCH("mlp_fb_kernel");
         }
-        hipLaunchKernelGGL(ppo_scalars_kernel, dim3(1), dim3(512), 0, s, tiles, B, A, at<float>(w.partials), net.grads,
-                           net.grads + w.net[0].layer[3].b_off, net.grads + w.net[1].layer[3].b_off, net.grads + w.P, net.opt_state,
-                           aux_fb ? w.net[2].layer[3].N : 0);
-        HG_CHECK_LAUNCH("ppo_scalars_kernel");
+        // the minibatch's loss scalars (per-tile partials -> opt_state, std / head-bias gradients, KL slot): one extra workgroup of
+        // the weight-gradient launch that follows anyway (it needs nothing but the partials mlp_fb_kernel has just written)
+        const ScalArgs sc = {tiles, B, A, aux_fb ? w.net[2].layer[3].N : 0, at<float>(w.partials), net.grads,
+                             net.grads + w.net[0].layer[3].b_off, net.grads + w.net[1].layer[3].b_off, net.grads + w.P, net.opt_state};
         if (part == 0) {
-            const int32_t rc0 = fused_dw(0, 1, B);
+            const int32_t rc0 = fused_dw(0, 1, B, &sc);
             return rc0 ? rc0 : reduce_range(0, critic_off);
         }
-        rc = fused_dw(0, nets, B);
+        rc = fused_dw(0, nets, B, &sc);
         if (rc) return rc;
         if (w.nnets > 2 && !aux_fb) {
             const int32_t rca = aux_grad(ppo, b);
@@ -1197,8 +1165,8 @@ struct NetRunner {
         hipLaunchKernelGGL((ppo_loss_kernel<T>), dim3(nblocks), dim3(256), 0, s, a);
         prof_end(HGYM_PROF_LOSS, s, (double)B * (4.0 * (5 * A + 6) + (double)sizeof(T) * (2 * A + 2)));
         HG_CHECK_LAUNCH("ppo_loss_kernel");
-        hipLaunchKernelGGL(ppo_scalars_kernel, dim3(1), dim3(512), 0, s, nblocks, B, A, at<float>(w.partials), net.grads, (float*)nullptr,
-                           (float*)nullptr, net.grads + w.P, net.opt_state, 0);
+        const ScalArgs sc = {nblocks, B, A, 0, at<float>(w.partials), net.grads, nullptr, nullptr, net.grads + w.P, net.opt_state};
+        hipLaunchKernelGGL(ppo_scalars_kernel, dim3(1), dim3(512), 0, s, sc);
         HG_CHECK_LAUNCH("ppo_scalars_kernel");
         cur_Mp = Bp;
         rc = backward(0, B);
