@@ -176,3 +176,53 @@ def test_asynchronous_log_prints_what_the_synchronous_one_does(tmp_path, capsys,
     assert sync_blocks == async_blocks == 4
     assert any("Mean reward" in ln for ln in sync_lines) and any("rew_tracking_lin_vel" in ln for ln in sync_lines)
     assert sync_lines == async_lines
+
+
+def test_full_size_rollout_storage_is_self_consistent():
+    """BASELINE size (4096 envs x 60 steps through the one-launch-per-step rollout, replayed from its HIP graph), size-independent
+    properties of what the rollout leaves in the storage: the stored log-probabilities are those of the stored actions under the
+    stored (mu, sigma); sigma is the std parameter; mu and the values are what the actor / critic return for the stored rows
+    when asked again in one batch (the 64-row-tile forward instead of the rollout's 32-row tiles); every row's history is the
+    previous row's shifted by one frame, or zero where the env had just been reset; rewards finite, dones boolean."""
+    import math
+    from humanoid.algo import PPO
+    PPO.precision = "bf16"
+    env, args, reg = _make(4096)
+    runner, _ = reg.make_alg_runner(env=env, name=args.task, args=args, log_root=None)
+    alg, ac = runner.alg, runner.alg.actor_critic
+    alg.learning_rate = 0.0                     # the updates of this run must not move the parameters the rollout used
+    p0 = alg.net.params.clone()
+    runner.learn(num_learning_iterations=3, init_at_random_ep_len=True)     # eager, captured, replayed
+    torch.cuda.synchronize()
+    assert torch.equal(alg.net.params, p0) and runner._graph is not None
+    st = alg.storage
+    T, N = st.num_transitions_per_env, st.num_envs
+    assert (T, N) == (60, 4096)
+    obs, priv = st.observations, st.privileged_observations
+    act, mu, sg, lp, val = st.actions, st.mu, st.sigma, st.actions_log_prob.view(T, N), st.values.view(T, N)
+    # sampling epilogue
+    assert torch.equal(sg, ac.std.detach().expand_as(sg))
+    want = (-((act - mu) ** 2) / (2 * sg ** 2) - sg.log() - 0.5 * math.log(2 * math.pi)).sum(-1)
+    assert float((lp - want).abs().max()) <= 2e-5 * float(want.abs().max())
+    z = (act - mu) / sg
+    assert abs(float(z.mean())) < 5e-3 and abs(float(z.std()) - 1.0) < 5e-3           # 2.9 M standard normals
+    # the networks, asked again over whole slabs of rows (another tile shape, same arithmetic per row)
+    # (slot 0 is skipped throughout: storage.clear() has already rotated the rollout's last observation into it for the next iteration)
+    for t0 in (1, 29, 58):
+        rows_o, rows_p = obs[t0:t0 + 2].reshape(2 * N, -1), priv[t0:t0 + 2].reshape(2 * N, -1)
+        mu2 = ac.act_inference(rows_o).view(2, N, -1)
+        v2 = ac.evaluate(rows_p).view(2, N)
+        assert float((mu2 - mu[t0:t0 + 2]).abs().max()) <= 1e-6 * max(1.0, float(mu.abs().max()))
+        assert float((v2 - val[t0:t0 + 2]).abs().max()) <= 1e-6 * max(1.0, float(val.abs().max()))
+    # history: 15 x 47 actor frames, 3 x 73 critic frames
+    dones = st.dones.view(T, N).bool()
+    assert st.dones.dtype in (torch.uint8, torch.bool) or set(st.dones.unique().tolist()) <= {0, 1}
+    for t in range(1, T - 1):
+        keep, gone = ~dones[t], dones[t]
+        assert torch.equal(obs[t + 1][keep][:, :14 * 47], obs[t][keep][:, 47:])
+        assert torch.equal(priv[t + 1][keep][:, :2 * 73], priv[t][keep][:, 73:])
+        if bool(gone.any()):
+            assert float(obs[t + 1][gone][:, :14 * 47].abs().max()) == 0.0
+            assert float(priv[t + 1][gone][:, :2 * 73].abs().max()) == 0.0
+    assert int(dones.sum()) > 0                                  # resets did occur in the window
+    assert torch.isfinite(st.rewards).all() and torch.isfinite(obs).all() and torch.isfinite(priv).all()
