@@ -35,6 +35,9 @@
 #include "hgym_fused.hpp"
 
 #ifndef HGYM_ENV_SPLIT
+#ifndef HGYM_RO_DRAWS_AHEAD
+#define HGYM_RO_DRAWS_AHEAD 1    // the next step's env draws computed by the critic workgroups of this launch (0: every launch draws its own)
+#endif
 #define HGYM_ENV_SPLIT 1       // the split per-env chain (hgym_env_math.hpp: env_step_phase_j / _a<split> / _f); 0: the monolithic one
 #endif
 #ifndef HGYM_RO_DRAWS_IDLE
@@ -58,14 +61,15 @@ int32_t rollout_env_args(const HgymEnvConfig* cfg, const HgymSimTensors* sim, co
 constexpr int RO_E = 32;       // envs (= policy rows) per workgroup
 constexpr int RO_NT = 512;     // lanes per workgroup: 8 wavefronts, as mlp_fwd_kernel<32, 8, 4>
 
-// caller's scratch block (HGYM_ROLLOUT_SCRATCH_BYTES, zero-filled once)
+// caller's scratch block (HGYM_ROLLOUT_SCRATCH_BYTES(num_envs), zero-filled once): this header, then two per-parity images of the
+// env step's draw tables ([tile][125 floats x 32 envs], the layout of the LDS noise tables u_delay .. phys)
 struct RolloutScratch {
     int64_t pp[2][4];          // [parity]{common step counter, ring step, sampling step, -}
     int64_t reset_cnt[2];      // [parity] envs that reset in the step of that parity
     int64_t pad[6];
     float acc[2][24];          // [parity] episode-sum accumulators of that step (HgymEnvState::episode_acc layout)
 };
-static_assert(sizeof(RolloutScratch) <= HGYM_ROLLOUT_SCRATCH_BYTES, "scratch block too small");
+static_assert(sizeof(RolloutScratch) <= HGYM_ROLLOUT_SCRATCH_HEADER_BYTES, "scratch block too small");
 
 // The three argument records are SEPARATE kernel parameters: as members of one 3 KB struct the compiler, past some size of the
 // kernel body, stopped seeing that the argument block is only read and kept a private-memory copy of all of it.
@@ -73,6 +77,14 @@ struct RolloutPP {
     const int64_t* in;         // {common step counter, ring step, sampling step} this launch works with
     int64_t* out;              // the same + 1, written by workgroup (0, 0) for the next launch
     int env_lds_off;           // byte offset of the env image in dynamic LDS (behind the policy tile's buffers)
+    // The env step's Philox draws depend on (seed, step, env) only, so the draws of step t + 1 are computed during step t by the
+    // CRITIC workgroup of the same tile -- idle for the second half of the launch -- and handed over through global memory:
+    // draws_out = where this launch leaves the tables of the next step, draws_in = the tables of this step (null: the first step
+    // of a rollout, the actor workgroup computes them itself on its idle wavefronts).  Layout: tile-major, each tile the
+    // contiguous LDS noise-table region [u_delay .. phys] of lds_map(32).
+    const float* draws_in;
+    float* draws_out;
+    int draws_len;             // floats per tile
 };
 
 constexpr int RO_NIO = hist_ni<15, HGYM_OBS_FRAME, RO_E, RO_NT>();
@@ -97,6 +109,12 @@ __global__ __launch_bounds__(RO_NT) void rollout_step_kernel(const FwdArgs f, co
         // one instantiation only (first hidden layer 768 wide, rollout_fwd_args checks): with the three-way dispatch of
         // mlp_fwd_kernel next to the actor + env branch the compiler keeps a private-memory copy of the whole 3 KB argument
         fwd_body<32, 8, 4, 3 * U>(f, f.net[1], false, smem);
+#if HGYM_RO_DRAWS_AHEAD
+        if (pp.draws_out) {      // next step's draw tables of this tile (step counter + 1), written where the LDS tables would be
+            float* base = pp.draws_out + (int64_t)blockIdx.x * pp.draws_len - lds_map(RO_E).u_delay;
+            env_fill_draws<RO_E>(e, (int)blockIdx.x, (int)threadIdx.x, RO_NT, base, pp.in[0] + 1);
+        }
+#endif
         return;
     }
     const int t = threadIdx.x, block = blockIdx.x;
@@ -104,6 +122,13 @@ __global__ __launch_bounds__(RO_NT) void rollout_step_kernel(const FwdArgs f, co
     float* esm = reinterpret_cast<float*>(smem + pp.env_lds_off);
     float hist_o[RO_NIO][4], hist_p[RO_NIP][4];
     const int act_off = lds_map(RO_E).actions_in;
+#if HGYM_RO_DRAWS_AHEAD
+    const float* const draws_in = pp.draws_in ? pp.draws_in + (int64_t)block * pp.draws_len : nullptr;
+    const int draws_len = pp.draws_len;
+#else
+    const float* const draws_in = nullptr;
+    const int draws_len = 0;
+#endif
     auto early = [&](const EnvArgs& E) {
 #if HGYM_RO_VARIANT == 3
         env_fill_draws<RO_E>(E, block, t, RO_NT, esm, csc0);
@@ -113,7 +138,25 @@ __global__ __launch_bounds__(RO_NT) void rollout_step_kernel(const FwdArgs f, co
 #if HGYM_RO_VARIANT == 0
         env_reset_pose<RO_E>(E, t, RO_NT, esm);                       // one lane, under the tile's first loads
 #if HGYM_RO_DRAWS_IDLE
+        // this step's draw tables, computed during the previous launch: a plain copy that travels with the tile's first loads
+        // (plain float quads and unconditional clamped loads: a packed-struct array behind a condition is kept in private memory)
+        float dq[2][4];
+        const int dq4 = draws_len >> 2, dq_off = lds_map(RO_E).u_delay;
+        const float* const dsrc = draws_in ? draws_in : E.st.commands;      // any readable address when there is nothing to copy
+        const int dmax = draws_in ? dq4 - 1 : 0;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = t + u * RO_NT;
+            stage_ld(dq[u], dsrc + 4 * (i < dmax ? i : dmax));
+        }
         if (t < 256) env_stage_in<RO_E>(E, block, t, 256, esm);      // travels with the tile's own first loads
+        if (draws_in) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int i = t + u * RO_NT;
+                if (i < dq4) stage_st(esm + dq_off + 4 * i, dq[u]);
+            }
+        }
 #else
         // issue the state / sim loads, compute the draws under them, then write the loaded quads to the env image
         StageRegs<RO_E> R;
@@ -133,7 +176,7 @@ __global__ __launch_bounds__(RO_NT) void rollout_step_kernel(const FwdArgs f, co
     // the env step's Philox draws: on the six wavefronts that have no head block, while the other two compute the head
     auto idle = [&](const EnvArgs& E) {
 #if HGYM_RO_DRAWS_IDLE && HGYM_RO_VARIANT == 0 && !defined(HGYM_RO_NO_DRAWS)
-        env_fill_draws<RO_E>(E, block, t - 128, RO_NT - 128, esm, csc0);
+        if (!draws_in) env_fill_draws<RO_E>(E, block, t - 128, RO_NT - 128, esm, csc0);
 #endif
     };
     fwd_body<32, 8, 4, 2 * U, false>(f, f.net[0], true, smem, early, mid, put, e, idle);
@@ -246,6 +289,17 @@ int32_t hgym_rollout_step(const HgymNetConfig* cfg, const HgymNet* net, const Hg
     pp.in = scr->pp[parity];
     pp.out = scr->pp[parity ^ 1];
     pp.env_lds_off = (int)round_up((int64_t)lds_pol, 16);
+    {   // draw tables handed from launch to launch: [parity][tile][draws_len] floats behind the scratch header
+        const LdsMap m = lds_map(RO_E);
+        pp.draws_len = m.frame - m.u_delay;
+        HG_REQUIRE((pp.draws_len & 3) == 0 && (m.u_delay & 3) == 0 && pp.draws_len <= 2 * 4 * RO_NT &&
+                       (size_t)pp.draws_len * 4 * 2 <= (size_t)HGYM_ROLLOUT_DRAW_BYTES_PER_ENV * RO_E,
+                   HGYM_E_UNSUPPORTED, "draw tables of %d floats per tile do not fit the scratch layout", pp.draws_len);
+        float* tables = reinterpret_cast<float*>(reinterpret_cast<char*>(scratch) + HGYM_ROLLOUT_SCRATCH_HEADER_BYTES);
+        const int64_t per_parity = (int64_t)(M / RO_E) * pp.draws_len;
+        pp.draws_in = prev_out ? tables + parity * per_parity : nullptr;       // the first step of a rollout draws its own
+        pp.draws_out = tables + (parity ^ 1) * per_parity;
+    }
     f.dbg = phase_buffer((int64_t)(M / RO_E) * 3);
     const size_t lds = (size_t)pp.env_lds_off + step_smem_bytes(RO_E);
     static size_t attr_lds[2] = {0, 0};

@@ -169,7 +169,14 @@ SYMBOLS = {
     "hgym_prof_summary": (C.c_int32, [C.c_int32, _P(C.c_int64), _P(C.c_double), _P(C.c_double)]),
 }
 PROF_GEMM, PROF_ENV_STEP, PROF_GAE, PROF_LOSS, PROF_MLP_FWD, PROF_MLP_BWD, PROF_DW, PROF_REDUCE, PROF_APPLY, PROF_POLICY, PROF_ROLLOUT = range(11)
-ROLLOUT_SCRATCH_BYTES = 512
+ROLLOUT_SCRATCH_HEADER_BYTES = 512
+ROLLOUT_DRAW_BYTES_PER_ENV = 1000
+
+
+def rollout_scratch_bytes(num_envs):
+    """HGYM_ROLLOUT_SCRATCH_BYTES(num_envs) of include/hgym.h."""
+    return ROLLOUT_SCRATCH_HEADER_BYTES + ROLLOUT_DRAW_BYTES_PER_ENV * int(num_envs)
+
 LOG_STATS = 256
 
 

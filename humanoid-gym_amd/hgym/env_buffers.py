@@ -67,7 +67,7 @@ class EnvBuffers:
         # the fused rollout step (hgym_rollout_step) runs the finaliser of step t - 1 concurrently with the env phase of step t: a
         # second rew / reset / time_out set for the alternate steps, and the library's scratch block (zero-filled once)
         self.rew_alt, self.reset_alt, self.time_out_alt = z(N), torch.zeros(N, dtype=torch.bool, device=dev), z(N, dtype=torch.bool)
-        self.rollout_scratch = torch.zeros(L.ROLLOUT_SCRATCH_BYTES, dtype=torch.uint8, device=dev)
+        self.rollout_scratch = torch.zeros(L.rollout_scratch_bytes(N), dtype=torch.uint8, device=dev)
         # logging sink of the step finaliser (HgymEnvOut.log_*): per-env running episode return / length, and the statistics block
         self.log_cur = z(2, N)
         self.log_stats = z(L.LOG_STATS)

@@ -28,7 +28,8 @@
 extern "C" {
 #endif
 
-#define HGYM_VERSION 2      /* 2: HgymEnvOut carries the logging sink; hgym_rollout_*, hgym_ppo_grad_part, hgym_net_param_offset */
+#define HGYM_VERSION 3      /* 2: HgymEnvOut carries the logging sink; hgym_rollout_*, hgym_ppo_grad_part, hgym_net_param_offset
+                             * 3: the rollout scratch block grows with the env count (HGYM_ROLLOUT_SCRATCH_BYTES(num_envs)) */
 
 enum {
     HGYM_OK = 0,
@@ -391,12 +392,15 @@ int32_t hgym_policy_act_fin(const HgymNetConfig* cfg, const HgymNet* net, int32_
  * `values` buffer of the same call, t_rewards / t_dones, t_step = step_counter), defer_finalize = 1, and -- because the
  * finaliser of step t-1 runs concurrently with the env phase of step t -- rew / reset / time_out buffers DISTINCT from
  * out[t-1]'s (two sets, alternating).  Between begin and end no other env entry point may run on this state.
- * scratch: HGYM_ROLLOUT_SCRATCH_BYTES bytes owned by the caller, zero-filled once (ping-pong step counters, per-parity reset
- * count and episode-sum accumulators).  Supported: the XBot-L default options (none of the generic ones, no use_ref_actions),
+ * scratch: HGYM_ROLLOUT_SCRATCH_BYTES(num_envs) bytes owned by the caller, 16-byte aligned, zero-filled once (ping-pong step
+ * counters, per-parity reset count and episode-sum accumulators; behind that header the env step's draw tables, which the
+ * critic workgroups of step t compute for step t + 1).  Supported: the XBot-L default options (none of the generic ones, no use_ref_actions),
  * 15 / 3 history, contiguous [136][N] state, SoA sim tensors, N a multiple of 32, the bf16 fused net path;
  * HGYM_E_UNSUPPORTED otherwise (callers fall back to hgym_policy_act_fin + hgym_env_step_synth).
  * ---------------------------------------------------------------------------------------------- */
-#define HGYM_ROLLOUT_SCRATCH_BYTES 512
+#define HGYM_ROLLOUT_SCRATCH_HEADER_BYTES 512
+#define HGYM_ROLLOUT_DRAW_BYTES_PER_ENV 1000      /* two parities x 125 floats */
+#define HGYM_ROLLOUT_SCRATCH_BYTES(num_envs) (HGYM_ROLLOUT_SCRATCH_HEADER_BYTES + (size_t)HGYM_ROLLOUT_DRAW_BYTES_PER_ENV * (size_t)(num_envs))
 int32_t hgym_rollout_begin(const HgymEnvState* st, const int64_t* step_counter, void* scratch, int32_t parity, void* stream);
 int32_t hgym_rollout_step(const HgymNetConfig* cfg, const HgymNet* net, const HgymEnvConfig* env_cfg, const HgymSimTensors* sim,
                           const HgymEnvState* st, const HgymEnvOut* out, const HgymEnvOut* prev_out, const float* obs,
