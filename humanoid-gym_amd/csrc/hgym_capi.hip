@@ -1,4 +1,7 @@
 // hgym_capi.hip -- library-level entry points (version, error string, device probe).
+#include <map>
+#include <mutex>
+#include <utility>
 #include <vector>
 
 #include "hgym_common.hpp"
@@ -19,6 +22,22 @@ bool g_prof = false;
 std::vector<ProfRec> g_rec[HGYM_PROF_CLASSES];
 hipEvent_t g_open[HGYM_PROF_CLASSES];
 }  // namespace
+
+int32_t ensure_dynamic_lds(const void* fn, size_t bytes, const char* what) {
+    static std::mutex mu;
+    static std::map<std::pair<const void*, int>, size_t> reserved;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) HG_FAIL(HGYM_E_NODEVICE, "%s: no current device", what);
+    std::lock_guard<std::mutex> lock(mu);
+    size_t& have = reserved[std::make_pair(fn, dev)];
+    if (bytes <= have) return HGYM_OK;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        HG_FAIL(HGYM_E_LAUNCH, "cannot reserve %zu bytes of LDS for %s on device %d", bytes, what, dev);
+    }
+    have = bytes;
+    return HGYM_OK;
+}
 
 long long* g_phase_buf = nullptr;
 int64_t g_phase_slots = 0;

@@ -36,8 +36,13 @@ char* last_error_buf();  // thread-local, defined in hgym_capi.hip
 bool prof_on();
 void prof_begin(int cls, hipStream_t s);
 void prof_end(int cls, hipStream_t s, double work);
-long long* phase_buffer(int64_t blocks);
-int device_cus();                           // compute units of the current device (hgym_env.hip)   // hgym_prof_phase_buffer: null unless set and large enough
+long long* phase_buffer(int64_t blocks);     // hgym_prof_phase_buffer: null unless set and large enough
+int device_cus();                           // compute units of the CURRENT device (cached per device id)
+// Opt-in for more than 64 KiB of dynamic LDS: hipFuncSetAttribute(MaxDynamicSharedMemorySize) for kernel `fn` on the CURRENT device.
+// The attribute is per (function, device): the reservation is cached under that pair (mutex-guarded), so a process that drives
+// several devices, or several host threads, never launches with more dynamic LDS than was reserved on that device.
+// Returns HGYM_OK or HGYM_E_LAUNCH (message in hgym_last_error).
+int32_t ensure_dynamic_lds(const void* fn, size_t bytes, const char* what);
 
 static inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 static inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }

@@ -158,14 +158,17 @@ __global__ __launch_bounds__(256) void synth_physics_kernel(const EnvArgs A) {
 
 // ------------------------------------------------------------------------------------------------ host side
 int device_cus() {
-    static int cus = -1;
-    if (cus < 0) {
-        int dev = 0;
+    constexpr int kMaxDev = 64;
+    static int cus[kMaxDev];           // 0: not asked yet (a benign race: every thread writes the same value)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (dev < 0 || dev >= kMaxDev || cus[dev] == 0) {
         hipDeviceProp_t p;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) cus = 0;
-        else cus = p.multiProcessorCount;
+        const int n = hipGetDeviceProperties(&p, dev) == hipSuccess ? p.multiProcessorCount : 0;
+        if (dev < 0 || dev >= kMaxDev) return n;
+        cus[dev] = n;
     }
-    return cus;
+    return cus[dev];
 }
 
 static int pick_envs_per_block(int N) {

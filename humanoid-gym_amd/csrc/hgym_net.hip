@@ -618,12 +618,8 @@ template <typename T, int BM, int BN, int WMs, int WNs>
 static void launch_cfg(const GemmArgs& g, int splits, hipStream_t s) {
     constexpr int F = ((BM / 16) + (BN / 16)) * KSTAGE;
     constexpr size_t lds = (size_t)2 * F * 1024;
-    static bool attr_done = false;
-    if (!attr_done) {   // > 64 KiB of LDS needs the opt-in
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<T, BM, BN, WMs, WNs>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
-    }
+    // > 64 KiB of LDS needs the opt-in, per device (a failure surfaces as the launch error the caller checks)
+    (void)ensure_dynamic_lds(reinterpret_cast<const void*>(&gemm_nt_kernel<T, BM, BN, WMs, WNs>), lds, "gemm_nt_kernel");
     dim3 grid(ceil_div(g.N, BN), ceil_div(g.M, BM), splits);
     hipLaunchKernelGGL((gemm_nt_kernel<T, BM, BN, WMs, WNs>), grid, dim3(WMs * WNs * 64), lds, s, g);
 }
@@ -752,13 +748,8 @@ struct NetRunner {
             const FusedNet& n = a.net[a.net0 + i];
             lds = std::max(lds, (size_t)fused_lds_p(n, BM) + (size_t)fused_lds_q(n, BM) + (size_t)fused_lds_bias(n));
         }
-        static size_t attr_lds = 0;
-        if (lds > attr_lds) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fwd_kernel<BM, NW, D, FIN>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)lds) != hipSuccess)
-                HG_FAIL(HGYM_E_LAUNCH, "cannot reserve %zu bytes of LDS for mlp_fwd_kernel", lds);
-            attr_lds = lds;
-        }
+        const int32_t rc_lds = ensure_dynamic_lds(reinterpret_cast<const void*>(&mlp_fwd_kernel<BM, NW, D, FIN>), lds, "mlp_fwd_kernel");
+        if (rc_lds) return rc_lds;
         FwdArgs b = a;
         b.nets = nets;
         const int rows = nets + (FIN ? 1 : 0);          // + the finaliser's grid row (its workgroup 0 works, the rest exit)
@@ -937,12 +928,8 @@ struct NetRunner {
                 lds = std::max(lds, (size_t)fused_lds_p(fa.net[i], 64) + (size_t)fused_lds_q(fa.net[i], 64) + (size_t)fused_lds_bias(fa.net[i]) +
                                         (size_t)fb_lds_extra(fa.net[i]));
             HG_REQUIRE(lds <= 160 * 1024, HGYM_E_UNSUPPORTED, "mlp_fb_kernel needs %zu bytes of LDS", lds);
-            static size_t attr_lds = 0;
-            if (lds > attr_lds) {
-                if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fb_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-                    HG_FAIL(HGYM_E_LAUNCH, "cannot reserve %zu bytes of LDS for mlp_fb_kernel", lds);
-                attr_lds = lds;
-            }
+            const int32_t rc_lds = ensure_dynamic_lds(reinterpret_cast<const void*>(&mlp_fb_kernel<0>), lds, "mlp_fb_kernel");
+            if (rc_lds) return rc_lds;
             FwdArgs fb = fa;
             fb.nets = nets;
             fb.dbg = phase_buffer((int64_t)tiles * nets);

@@ -264,6 +264,11 @@ int32_t hgym_rollout_step(const HgymNetConfig* cfg, const HgymNet* net, const Hg
     HG_REQUIRE(cfg && net && env_cfg && sim && st && out && scratch, HGYM_E_BADARG, "null argument");
     HG_REQUIRE(obs && priv && actions && mu && sigma && logp && values, HGYM_E_BADARG, "null policy buffer");
     HG_REQUIRE(parity == 0 || parity == 1, HGYM_E_BADARG, "parity=%d", parity);
+    // what the kernel compiles in (the header's "Supported:" list): the actor epilogue writes 12 actions per row into the env image
+    // and the env part produces 15 x 47 / 3 x 73 wide rows, which the policy tiles read with these leading dimensions
+    HG_REQUIRE(cfg->num_actions == HGYM_NUM_ACTIONS && cfg->num_obs == 15 * HGYM_OBS_FRAME && cfg->num_priv == 3 * HGYM_PRIV_FRAME,
+               HGYM_E_UNSUPPORTED, "fused rollout step: net shape %d / %d -> %d is not XBot-L's 705 / 219 -> 12", cfg->num_obs, cfg->num_priv,
+               cfg->num_actions);
     RolloutScratch* scr = (RolloutScratch*)scratch;
     const int M = env_cfg->num_envs;
     FwdArgs f;
@@ -302,13 +307,10 @@ int32_t hgym_rollout_step(const HgymNetConfig* cfg, const HgymNet* net, const Hg
     }
     f.dbg = phase_buffer((int64_t)(M / RO_E) * 3);
     const size_t lds = (size_t)pp.env_lds_off + step_smem_bytes(RO_E);
-    static size_t attr_lds[2] = {0, 0};
-    const int fi = prev_out ? 1 : 0;
-    if (lds > attr_lds[fi]) {
+    {
         const void* fn = prev_out ? reinterpret_cast<const void*>(&rollout_step_kernel<true>) : reinterpret_cast<const void*>(&rollout_step_kernel<false>);
-        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            HG_FAIL(HGYM_E_LAUNCH, "cannot reserve %zu bytes of LDS for rollout_step_kernel", lds);
-        attr_lds[fi] = lds;
+        rc = ensure_dynamic_lds(fn, lds, "rollout_step_kernel");
+        if (rc) return rc;
     }
     hipStream_t s = (hipStream_t)stream;
     prof_begin(HGYM_PROF_ROLLOUT, s);

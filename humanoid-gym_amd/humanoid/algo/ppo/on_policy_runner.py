@@ -176,94 +176,101 @@ class OnPolicyRunner:
         gkey = (id(env), id(alg.storage), log_on, log_sink, sink_ok, defer_ok, fuse_ok, getattr(alg, "gamma", None),
                 env.native_config_digest() if hasattr(env, "native_config_digest") else None)
         tot_iter = self.current_learning_iteration + num_learning_iterations
-        for it in range(self.current_learning_iteration, tot_iter):
-            start = time.time()
-            if async_iters or async_log:
-                ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-                ev[0].record()
-            with torch.inference_mode():
-                g = self._graph
-                if use_graph and g is not None and g["key"] == gkey:
-                    g["graph"].replay()
-                    alg.storage.step = self.num_steps_per_env
-                    obs, critic_obs = g["out"]
-                    ep_infos = g["ep_infos"]
-                    cur_reward_sum, cur_episode_length, done_stats = g["stats"]
-                elif use_graph and self._graph_warm:
-                    graph = torch.cuda.CUDAGraph()
-                    ep_infos = []
-                    torch.cuda.synchronize()
-                    # thread-local capture mode: with torch.distributed initialised, the RCCL watchdog thread polls events
-                    # concurrently; only this thread's launches belong to the capture
-                    with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-                        out = rollout(obs_all[0], priv_all[0])
-                    self._graph = dict(graph=graph, out=out, ep_infos=ep_infos, key=gkey,
-                                       stats=(cur_reward_sum, cur_episode_length, done_stats))
-                    alg.storage.step = 0
-                    graph.replay()                  # capture does not execute: run the captured rollout once
-                    alg.storage.step = self.num_steps_per_env
-                    obs, critic_obs = out
-                else:
-                    obs, critic_obs = rollout(obs, critic_obs)
-                    self._graph_warm = True
+        try:
+            for it in range(self.current_learning_iteration, tot_iter):
+                start = time.time()
                 if async_iters or async_log:
-                    ev[1].record()
-                elif str(self.device).startswith("cuda"):
-                    torch.cuda.synchronize()
+                    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+                    ev[0].record()
+                with torch.inference_mode():
+                    g = self._graph
+                    if use_graph and g is not None and g["key"] == gkey:
+                        g["graph"].replay()
+                        alg.storage.step = self.num_steps_per_env
+                        obs, critic_obs = g["out"]
+                        ep_infos = g["ep_infos"]
+                        cur_reward_sum, cur_episode_length, done_stats = g["stats"]
+                    elif use_graph and self._graph_warm:
+                        graph = torch.cuda.CUDAGraph()
+                        ep_infos = []
+                        torch.cuda.synchronize()
+                        # thread-local capture mode: with torch.distributed initialised, the RCCL watchdog thread polls events
+                        # concurrently; only this thread's launches belong to the capture
+                        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                            out = rollout(obs_all[0], priv_all[0])
+                        self._graph = dict(graph=graph, out=out, ep_infos=ep_infos, key=gkey,
+                                           stats=(cur_reward_sum, cur_episode_length, done_stats))
+                        alg.storage.step = 0
+                        graph.replay()                  # capture does not execute: run the captured rollout once
+                        alg.storage.step = self.num_steps_per_env
+                        obs, critic_obs = out
+                    else:
+                        obs, critic_obs = rollout(obs, critic_obs)
+                        self._graph_warm = True
+                    if async_iters or async_log:
+                        ev[1].record()
+                    elif str(self.device).startswith("cuda"):
+                        torch.cuda.synchronize()
+                    stop = time.time()
+                    collection_time = stop - start
+                    start = stop
+                    alg.compute_returns(critic_obs)
+                mean_value_loss, mean_surrogate_loss = alg.update(sync=False) if (async_iters or async_log) else alg.update()
+                if zero_copy:                       # storage.clear() rotated slot T into slot 0
+                    obs, critic_obs = obs_all[0], priv_all[0]
                 stop = time.time()
-                collection_time = stop - start
-                start = stop
-                alg.compute_returns(critic_obs)
-            mean_value_loss, mean_surrogate_loss = alg.update(sync=False) if (async_iters or async_log) else alg.update()
-            if zero_copy:                       # storage.clear() rotated slot T into slot 0
-                obs, critic_obs = obs_all[0], priv_all[0]
-            stop = time.time()
-            learn_time = stop - start
-            if async_iters:
-                ev[2].record()
-                marks.append(ev)
-            elif async_log:
-                ev[2].record()
-                snap = self._log_snapshot(env, alg, it & 1)
-                if pending is not None:
-                    self._log_flush(pending, num_learning_iterations)
-                pending = dict(it=it, ev=ev, snap=snap)
-                if it % self.save_interval == 0:
-                    self.save(os.path.join(self.log_dir, "model_{}.pt".format(it)))
-                continue
-            else:
-                self.last_collection_time, self.last_learn_time = collection_time, learn_time
-            if self.log_dir is not None:
-                if log_sink:
-                    # one read-back: mean over this iteration's steps of extras["episode"] (what the reference's ep_infos list
-                    # averages to), and the rings that ARE the reference's rewbuffer / lenbuffer (the last 100 finished episodes)
-                    ep_mean, ring_r, ring_l = env.log_sink_read()
-                    ep_infos = [ep_mean]
-                    rewbuffer, lenbuffer = deque(ring_r, maxlen=100), deque(ring_l, maxlen=100)
+                learn_time = stop - start
+                if async_iters:
+                    ev[2].record()
+                    marks.append(ev)
+                elif async_log:
+                    ev[2].record()
+                    snap = self._log_snapshot(env, alg, it & 1)
+                    if pending is not None:
+                        self._log_flush(pending, num_learning_iterations)
+                    pending = dict(it=it, ev=ev, snap=snap)
+                    if it % self.save_interval == 0:
+                        self.save(os.path.join(self.log_dir, "model_{}.pt".format(it)))
+                    continue
                 else:
-                    s = done_stats.cpu()
-                    if float(s[2]) > 0:
-                        rewbuffer.append(float(s[0] / s[2]))
-                        lenbuffer.append(float(s[1] / s[2]))
-                    done_stats.zero_()
-                self.log(locals())
-                if it % self.save_interval == 0:
-                    self.save(os.path.join(self.log_dir, "model_{}.pt".format(it)))
-            if self._graph is None or ep_infos is not self._graph["ep_infos"]:
-                ep_infos.clear()
-        if pending is not None:
-            self._log_flush(pending, num_learning_iterations)
+                    self.last_collection_time, self.last_learn_time = collection_time, learn_time
+                if self.log_dir is not None:
+                    if log_sink:
+                        # one read-back: mean over this iteration's steps of extras["episode"] (what the reference's ep_infos list
+                        # averages to), and the rings that ARE the reference's rewbuffer / lenbuffer (the last 100 finished episodes)
+                        ep_mean, ring_r, ring_l = env.log_sink_read()
+                        ep_infos = [ep_mean]
+                        rewbuffer, lenbuffer = deque(ring_r, maxlen=100), deque(ring_l, maxlen=100)
+                    else:
+                        s = done_stats.cpu()
+                        if float(s[2]) > 0:
+                            rewbuffer.append(float(s[0] / s[2]))
+                            lenbuffer.append(float(s[1] / s[2]))
+                        done_stats.zero_()
+                    self.log(locals())
+                    if it % self.save_interval == 0:
+                        self.save(os.path.join(self.log_dir, "model_{}.pt".format(it)))
+                if self._graph is None or ep_infos is not self._graph["ep_infos"]:
+                    ep_infos.clear()
+        finally:
+            # also on an exception / KeyboardInterrupt inside the loop: the last finished iteration's log block is still printed
+            # (async logging runs one iteration behind) and the env's bindings into the rollout storage are released
+            if pending is not None:
+                try:
+                    self._log_flush(pending, num_learning_iterations)
+                except Exception:      # the device may be the thing that failed
+                    pass
+            if zero_copy:
+                env.bind_outputs(None, None)
+            if sink_ok:
+                env.bind_transition(None)
+                alg.env_stores_transitions = False
+            if log_sink:
+                env.bind_log_sink(False)
         if marks:                               # mean device time per iteration of this call (HIP events, one sync)
             torch.cuda.synchronize()
             self.last_collection_time = sum(a.elapsed_time(b) for a, b, _ in marks) * 1e-3 / len(marks)
             self.last_learn_time = sum(b.elapsed_time(c) for _, b, c in marks) * 1e-3 / len(marks)
-        if zero_copy:
-            env.bind_outputs(None, None)
-        if sink_ok:
-            env.bind_transition(None)
-            alg.env_stores_transitions = False
-        if log_sink:
-            env.bind_log_sink(False)
         self.current_learning_iteration += num_learning_iterations
         if self.log_dir is not None:
             self.save(os.path.join(self.log_dir, "model_{}.pt".format(self.current_learning_iteration)))
@@ -373,6 +380,8 @@ class OnPolicyRunner:
         self.current_learning_iteration = loaded["iter"]
         if hasattr(self.alg, "seek"):
             self.alg.seek(self.current_learning_iteration, self.num_steps_per_env)
+        if hasattr(self.env, "seek"):       # the env's draw streams (commands, pushes, noise, resets) continue as well
+            self.env.seek(self.current_learning_iteration, self.num_steps_per_env)
         return loaded["infos"]
 
     def get_inference_policy(self, device=None):

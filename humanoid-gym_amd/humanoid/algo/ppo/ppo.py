@@ -139,7 +139,8 @@ class PPO:
         """Position the device generators' counters where a run that has done `iteration` learning iterations has them
         (OnPolicyRunner.load): a resumed run continues the exploration-noise and permutation streams instead of replaying them
         from the start.  The reference's checkpoint carries no generator state (on_policy_runner.py:274-281); the counters are
-        functions of the iteration number, so neither does this one."""
+        functions of the iteration number, so neither does this one.  (The env's own draw streams are positioned by
+        LeggedRobot.seek, which the runner calls next to this.)"""
         self._sample_step.fill_(int(iteration) * int(steps_per_iteration))
         self._perm_draws = int(iteration)
 

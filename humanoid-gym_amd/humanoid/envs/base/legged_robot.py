@@ -381,6 +381,16 @@ class LeggedRobot(BaseTask):
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
+    def seek(self, iteration, steps_per_iteration):
+        """Native extension (OnPolicyRunner.load): put the common step counter -- the Philox counter word of every env draw
+        (commands, pushes, noise, reset offsets) and the clock of the push / curriculum intervals -- where a run that has done
+        `iteration` learning iterations has it, so that a resumed run continues the env's draw streams instead of replaying them
+        from step 0.  The reference's checkpoint carries no generator state either (on_policy_runner.py:274-281); the counter is
+        a function of the iteration number.  The history ring position is left alone."""
+        if not hasattr(self, "_seek_base"):
+            self._seek_base = int(self._buf.counters[0])       # the freshly constructed + reset env (= iteration 0)
+        self._buf.counters[0] = self._seek_base + int(iteration) * int(steps_per_iteration)
+
     # ------------------------------------------------------------------ fused rollout step (native extension)
     # One launch per vec-step: PPO.act, this env's step (synthetic-physics backend) and the previous step's finaliser
     # (include/hgym.h: hgym_rollout_begin / _step / _end).  Used by OnPolicyRunner when nothing on the host needs the per-step
@@ -391,7 +401,10 @@ class LeggedRobot(BaseTask):
         c, nc = self._ncfg, net.cfg
         generic = c.custom_origins or c.terrain_curriculum or c.num_height_points > 0 or c.command_curriculum or not c.heading_command
         cus = int(self._L.lib.hgym_device_cus())
-        return bool(not generic and not c.use_ref_actions and c.frame_stack == 15 and c.c_frame_stack == 3 and self.num_envs % 32 == 0
+        # the fused launch never calls step(): a task class that overrides step() / post_physics_step() (a wrapper, extra
+        # book-keeping around the step) must keep getting its own code, i.e. the act() + step() path
+        own_step = type(self).step is LeggedRobot.step and type(self).post_physics_step is LeggedRobot.post_physics_step
+        return bool(own_step and not generic and not c.use_ref_actions and c.frame_stack == 15 and c.c_frame_stack == 3 and self.num_envs % 32 == 0
                     and nc.precision == self._L.BF16 and nc.actor_layers == 4 and nc.critic_layers == 4 and nc.actor_dims[1] == 512
                     and nc.critic_dims[1] == 768 and nc.num_actions == 12 and 2 * (self.num_envs // 32) <= max(cus, 1)
                     and getattr(self.cfg.env, "send_timeouts", False))

@@ -438,9 +438,10 @@ int32_t hgym_ppo_grad(const HgymNetConfig* cfg, const HgymPPOConfig* ppo, const 
  *           grads[0 .. hgym_net_param_offset(cfg, 1)) -- std | actor, the larger bucket (527 256 of 926 106 floats) -- are final;
  *   part 1: the weight gradients of the CRITIC (and of the auxiliary head):
  *           grads[hgym_net_param_offset(cfg, 1) .. P] -- critic | auxiliary head | the KL slot -- are final.
- * part 0 followed by part 1 leaves net->grads exactly as hgym_ppo_grad does (bit-identical); only opt_state[9] (the squared
- * norm hgym_ppo_apply may reuse with grad_norm_ready) is not maintained: apply must be called with grad_norm_ready = 0 or
- * world_size > 1. */
+ * part 0 followed by part 1 leaves net->grads exactly as hgym_ppo_grad does (bit-identical), and opt_state[9] (the squared norm
+ * hgym_ppo_apply may reuse with grad_norm_ready) complete: part 0 zeroes it and adds its bucket's share, part 1 adds the rest --
+ * so a single rank may follow the two halves with grad_norm_ready = 1 (what PPO.update does under HGYM_DIST_SINGLE).  Between
+ * part 0 and part 1 it is partial; with world_size > 1 apply recomputes the norm of the rank mean regardless. */
 int32_t hgym_ppo_grad_part(const HgymNetConfig* cfg, const HgymPPOConfig* ppo, const HgymNet* net,
                            const HgymBatch* batch, int32_t part, void* stream);
 /* offset (floats) in the flat parameter / gradient vector of the first parameter of net `which` (0 actor, 1 critic, 2 auxiliary
@@ -453,7 +454,10 @@ int64_t hgym_net_param_offset(const HgymNetConfig* cfg, int32_t which);
 int32_t hgym_ppo_apply(const HgymNetConfig* cfg, const HgymPPOConfig* ppo, const HgymNet* net, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
- * Measurement hooks (bench.py's roofline leg).  When enabled, every launch of a profiled kernel class is
+ * Measurement hooks (bench.py's roofline leg).  PROCESS-GLOBAL state, unlike the rest of this interface: one event list and one
+ * phase buffer per process, not per device or per stream, and not thread-safe -- enable them from one thread, for one device at
+ * a time.  (Everything else keeps no state between calls except the per-(kernel, device) record of how much dynamic LDS has been
+ * reserved, which is mutex-guarded: one process may drive several devices and streams.)  When enabled, every launch of a profiled kernel class is
  * bracketed by a pair of HIP events recorded on the launch stream; the summary synchronises those events and
  * returns launches, summed duration and summed ALGORITHMIC work (flops for the GEMM class, bytes for the
  * HBM-bound classes; DESIGN.md states the per-unit figures).  Off by default; not capturable in a hipGraph.

@@ -307,3 +307,66 @@ def test_adam_writes_the_same_operand_copies_as_the_refresh_from_master():
     net.sync_shadow()
     torch.cuda.synchronize()
     assert torch.equal(after_adam, net.workspace)
+
+
+def test_rollout_step_refuses_foreign_net_shapes_on_the_c_side():
+    """include/hgym.h's "Supported:" list is enforced by hgym_rollout_step itself, not only by the Python wrapper: a net whose
+    observation width is not XBot-L's 705 would make the env part write 705-wide rows the policy tiles then read with another
+    leading dimension.  HGYM_E_UNSUPPORTED before anything is launched."""
+    from hgym import EnvBuffers, NetBuffers, default_env_config, make_net_config, _lib as L
+    N = 64
+    cfg = default_env_config(N)
+    buf = EnvBuffers(cfg, "cuda")
+    net = NetBuffers(make_net_config(700, 219, 12, K.ACTOR_HIDDEN, K.CRITIC_HIDDEN, "bf16", 64), "cuda")
+    z = lambda *s: torch.zeros(*s, device="cuda")
+    val = z(N)
+    sink = dict(values=val, rewards=z(N), dones=torch.zeros(N, dtype=torch.uint8, device="cuda"),
+                step=torch.zeros(1, dtype=torch.int64, device="cuda"), gamma=0.99)
+    out = buf.out_struct(z(N, 705), z(N, 219), sink, True)
+    before = buf._state.clone()
+    rc = L.lib.hgym_rollout_step(C.byref(net.cfg), C.byref(net.struct), C.byref(cfg), C.byref(buf.sim_struct()), C.byref(buf.state_struct()),
+                                 C.byref(out), None, L.fptr(z(N, 700)), L.fptr(z(N, 219)), 1, L.fptr(z(N, 12)), L.fptr(z(N, 12)),
+                                 L.fptr(z(N, 12)), L.fptr(z(N)), L.fptr(val), C.c_void_p(buf.rollout_scratch.data_ptr()), 0,
+                                 C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    assert rc == -4 and b"705" in L.lib.hgym_last_error()
+    assert torch.equal(before, buf._state)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two devices in one process")
+def test_two_devices_in_one_process_share_nothing():
+    """The library keeps one piece of state between calls -- how much dynamic LDS was reserved per (kernel, device).  One process
+    driving two devices (one runner each, alternating) must get, on each device, exactly what that runner produces alone."""
+    from humanoid.algo import PPO
+    PPO.precision = "bf16"
+    outs = {}
+    for mode in ("alone", "interleaved"):
+        rs = []
+        for d in (0, 1):
+            torch.cuda.set_device(d)
+            torch.manual_seed(7)
+            np.random.seed(7)
+            from humanoid.envs import task_registry
+            from humanoid.utils import get_args
+            dev = "cuda:%d" % d
+            args = get_args(["--task=humanoid_ppo", "--headless", "--num_envs", "256", "--seed", "3", "--sim_device", dev, "--rl_device", dev])
+            task_registry.train_cfgs[args.task].seed = 3
+            env, _ = task_registry.make_env(name=args.task, args=args)
+            r, _ = task_registry.make_alg_runner(env=env, name=args.task, args=args, log_root=None)
+            rs.append(r)
+            if mode == "alone":
+                r.learn(num_learning_iterations=2, init_at_random_ep_len=False)
+        if mode == "interleaved":
+            for _ in range(2):
+                for d, r in enumerate(rs):
+                    torch.cuda.set_device(d)
+                    r.learn(num_learning_iterations=1, init_at_random_ep_len=False)
+        for d, r in enumerate(rs):
+            torch.cuda.set_device(d)
+            torch.cuda.synchronize()
+            outs[(mode, d)] = r.alg.net.params.cpu().clone()
+        del rs
+    torch.cuda.set_device(0)
+    for d in (0, 1):
+        assert torch.equal(outs[("alone", d)], outs[("interleaved", d)]), d
+    assert torch.equal(outs[("alone", 0)], outs[("alone", 1)])

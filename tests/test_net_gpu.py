@@ -214,36 +214,65 @@ def test_grad_vs_oracle_full_width():
     np.testing.assert_allclose(float(opt[3]), float(out["surrogate"]), rtol=1e-4, atol=1e-6)
 
 
-def test_update_full_size_properties():
-    """BASELINE size (B = 61 440 samples, XBot-L widths), bf16 fast path vs fp32 path on the same inputs: the two
-    gradients agree to bf16 accuracy, are finite, and an Adam step moves the parameters."""
+FULL_SIZE_BF16_TOL = 5e-3      # fused kernels vs the bf16-operand oracle per tensor, rel-L2: the bound tests/test_fused_gpu.py holds at B = 4096
+
+
+def test_update_full_size_vs_oracle():
+    """BASELINE minibatch: B = 61 440 rows (960 tiles of 64 rows x 8 split-K slabs) gathered by a permutation out of a
+    T * N = 245 760-row storage, XBot-L widths.  One minibatch through the fused bf16 kernels (mlp_fb_kernel, dw_kernel_rs, slab
+    reduction) against the ORACLE's hand-written backward of /root/reference/humanoid/algo/ppo/ppo.py:128-174 evaluated on bf16
+    operands (oracle/ppo_oracle.py: quant = bf16_round -- inputs, weights, activations and stored dZ rounded where the kernels
+    round them, fp32 accumulation): per parameter tensor rel-L2 <= 5e-3, scalar losses within 1e-3.  The fp32 path on the same
+    minibatch against the fp32 oracle: <= 1e-4 per tensor (accumulation order over 61 440 rows).  Then an Adam step moves the
+    parameters."""
     from hgym import make_ppo_config, make_batch
     g = torch.Generator().manual_seed(11)
-    S = B = 61440
+    S, B = 245760, 61440
     p = P.Params.random(705, 219, 12, K.ACTOR_HIDDEN, K.CRITIC_HIDDEN, g)
+    p.std = torch.rand(12, generator=g) * 0.5 + 0.75
     dev = "cuda"
-    obs, priv = torch.randn(S, 705, device=dev), torch.randn(S, 219, device=dev)
-    act, mu_o = torch.randn(S, 12, device=dev), torch.randn(S, 12, device=dev) * 0.3
-    sg_o = torch.ones(S, 12, device=dev)
-    val, adv, ret = torch.randn(S, device=dev), torch.randn(S, device=dev), torch.randn(S, device=dev)
-    lp_o = -12.0 + torch.randn(S, device=dev)
-    idx = torch.randperm(S, device=dev).contiguous()
-    grads = {}
-    for prec in ("f32", "bf16"):
+    gd = torch.Generator(device=dev).manual_seed(12)
+    obs, priv = torch.randn(S, 705, device=dev, generator=gd).clamp_(-18, 18), torch.randn(S, 219, device=dev, generator=gd).clamp_(-18, 18)
+    act, mu_o = torch.randn(S, 12, device=dev, generator=gd), torch.randn(S, 12, device=dev, generator=gd) * 0.3
+    sg_o = torch.rand(S, 12, device=dev, generator=gd) * 0.5 + 0.75
+    val, adv, ret = (torch.randn(S, device=dev, generator=gd) for _ in range(3))
+    idx = torch.randperm(S, device=dev, generator=gd)[:B].contiguous()
+    ic = idx.cpu()
+    rows = lambda t: t[idx].cpu()
+    o_obs, o_priv, o_act, o_mu, o_sg, o_val, o_adv, o_ret = (rows(t) for t in (obs, priv, act, mu_o, sg_o, val, adv, ret))
+    # old log-probs near the current policy's (ratios around 1, both sides of the clip range populated)
+    mu_now = P.mlp_forward(o_obs, p.actor)
+    lp_rows = P.gaussian_log_prob(o_act, mu_now, mu_now * 0 + p.std) + torch.randn(B, generator=g) * 0.3
+    lp_o = torch.zeros(S, device=dev)
+    lp_o[idx] = lp_rows.to(dev)
+    want = {None: P.ppo_loss_and_grads(p, o_obs, o_priv, o_act, o_val, o_adv, o_ret, lp_rows, o_mu, o_sg),
+            "bf16": P.ppo_loss_and_grads(p, o_obs, o_priv, o_act, o_val, o_adv, o_ret, lp_rows, o_mu, o_sg, quant=P.bf16_round)}
+    in_range = float(((want[None]["ratio"] > 0.8) & (want[None]["ratio"] < 1.2)).float().mean()) if "ratio" in want[None] else None
+    rep = []
+    for prec, ref, tol in (("f32", want[None], 1e-4), ("bf16", want["bf16"], FULL_SIZE_BF16_TOL)):
         net = _net(705, 219, K.ACTOR_HIDDEN, K.CRITIC_HIDDEN, prec, B)
         net.load_state_dict(dict(zip(NAMES, p.tensors())))
         net.ppo_grad(make_ppo_config(), make_batch(obs, priv, act, val, adv, ret, lp_o, mu_o, sg_o, idx))
         torch.cuda.synchronize()
-        grads[prec] = net.grads.clone()
         assert torch.isfinite(net.grads).all()
+        gv = net.grad_views()
+        worst = 0.0
+        for k, r in zip(NAMES, ref["grads"].tensors()):
+            a, b = gv[k].cpu().double().flatten(), r.double().flatten()
+            l2 = float((a - b).norm() / b.norm().clamp_min(1e-30))
+            worst = max(worst, l2)
+            assert l2 <= tol, (prec, k, l2)
+        opt = net.opt_state.cpu()
+        np.testing.assert_allclose(float(opt[8]), float(ref["kl"]), rtol=1e-3, atol=1e-5)
+        np.testing.assert_allclose(float(opt[4]), float(ref["value_loss"]), rtol=1e-3)
+        np.testing.assert_allclose(float(opt[3]), float(ref["surrogate"]), rtol=1e-3, atol=1e-5)
+        rep.append("%s path vs %s oracle at B = %d: worst per-tensor rel-L2 %.3e (bound %.0e)" % (prec, "bf16-operand" if prec == "bf16" else "fp32", B, worst, tol))
         before = net.params.clone()
         net.ppo_apply(make_ppo_config())
         torch.cuda.synchronize()
         assert not torch.equal(before, net.params) and torch.isfinite(net.params).all()
         del net
-    a, b = grads["f32"].double(), grads["bf16"].double()
-    cos = float(a @ b) / float(a.norm() * b.norm())
-    assert cos > 0.99, cos
+    print("\n".join(rep), "| ratios inside the clip range:", in_range)
 
 
 @pytest.mark.parametrize("precision", ["f32", "bf16"])
@@ -379,6 +408,8 @@ def test_ppo_iteration_full_width_matches_reference_f32():
 # per-tensor tolerance of the bf16 FUSED path against the reference's fp32 autograd, first-minibatch clipped gradient (measured:
 # profiles/r02_bf16_full_width_parity.txt); rel-L2 error | cosine
 BF16_G0_TOL = {"rel_l2": 2e-2, "cos": 0.9997}      # measured: rel-L2 1.8e-3 .. 7.7e-3, cosine >= 0.99997
+# ... and of the 8-step parameter change, per tensor
+BF16_DP_TOL = {"rel_l2": 8e-2, "cos": 0.997, "norm": 5e-3}
 
 
 def test_ppo_iteration_full_width_bf16_fused_kernels_vs_reference(capsys):
@@ -417,3 +448,9 @@ def test_ppo_iteration_full_width_bf16_fused_kernels_vs_reference(capsys):
         assert d["rel_l2"] <= BF16_G0_TOL["rel_l2"] and d["cos"] >= BF16_G0_TOL["cos"], (name, d)
     assert F.total_cosine(G, "g0", {k: v.numpy() for k, v in r["g0"].items()}) >= 0.999
     assert F.total_cosine(G, "dP", dP) >= 0.995                     # measured 0.9986
+    # per tensor (measured, profiles/r02_bf16_full_width_parity.txt: rel-L2 <= 5.9e-2, cosine >= 0.99828, norm ratio within 2.7e-3).
+    # An Adam step is lr * m / (sqrt(v) + eps) ~ lr * sign(g) for the first steps: an entry whose gradient is within the bf16
+    # error of zero moves by the full step in the other direction, so single ENTRIES differ by up to 2 steps (sample_max_err ~ 1)
+    # while every tensor as a whole keeps its direction and length -- that is the statement asserted.
+    for name, d in cmp_p.items():
+        assert d["rel_l2"] <= BF16_DP_TOL["rel_l2"] and d["cos"] >= BF16_DP_TOL["cos"] and abs(d["norm_ratio"] - 1) <= BF16_DP_TOL["norm"], (name, d)

@@ -73,6 +73,13 @@ def test_training_iterations_and_checkpoint(tmp_path):
     env2, args2, reg2 = _make(64)
     r2, _ = reg2.make_alg_runner(env=env2, name=args2.task, args=args2, log_root=None)
     r2.load(os.path.join(runner.log_dir, "model_3.pt"))
+    # ... and every device generator continues where a run of 3 iterations has it: the policy's sampling step, the minibatch
+    # permutation draw and the env's common step counter (the Philox counter word of commands / pushes / noise / reset draws)
+    T = r2.num_steps_per_env
+    assert int(r2.alg._sample_step) == 3 * T and r2.alg._perm_draws == 3
+    assert int(env2._buf.counters[0]) == int(runner.env._buf.counters[0]) == 1 + 3 * T
+    r2.load(os.path.join(runner.log_dir, "model_3.pt"))        # idempotent
+    assert int(env2._buf.counters[0]) == 1 + 3 * T
     x = torch.randn(64, 705, device="cuda")
     a1 = runner.alg.actor_critic.act_inference(x)
     a2 = r2.alg.actor_critic.act_inference(x)
