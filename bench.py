@@ -57,6 +57,9 @@ def parse():
                    help="humanoid_ppo = BASELINE configs[1] (the headline); humanoid_dwl_ppo adds the denoising head (configs[4])")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-roofline", action="store_true")
+    p.add_argument("--pmc", action="store_true",
+                   help="collect roofline.traffic IN THIS RUN: two extra rocprofv3 passes (--kernel-trace --pmc FETCH_SIZE, then WRITE_SIZE) "
+                        "over a short run of the same workload; without it the committed profiles/pmc_traffic.json is quoted, with its provenance")
     p.add_argument("--configs", default=",".join(EXTRA_CONFIGS),
                    help="extra single-GPU configurations reported under \"configs\" (N=1 only); \"\" or none: skip")
     return p.parse_args()
@@ -209,7 +212,40 @@ def cpu_baseline(num_envs, T=60, full_minibatch=True, allow_reference=True):
 
 
 # ------------------------------------------------------------------------------------------------ GPU runs
-def _roofline(L, runner, elapsed_per_iter_ms, precision, n_profiled_iters, traffic_ok=True):
+def collect_pmc_traffic():
+    """roofline.traffic measured in this run: rocprofv3 --kernel-trace --pmc <counter> (one pass per counter, as
+    MI355X_MICROARCH.md's HBM section prescribes) around tools/traffic_run.py -- a 256 MiB streaming kernel for the FETCH_SIZE
+    calibration, then 4 iterations of this bench's headline workload -- converted by tools/pmc_to_json.py.  Returns the dict of
+    profiles/pmc_traffic.json's shape, or None (with the reason on stderr)."""
+    import glob
+    import shutil
+    rp = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rp):
+        sys.stderr.write("--pmc: rocprofv3 not found\n")
+        return None
+    tmp = tempfile.mkdtemp(prefix="hgym_pmc_")
+    csvs = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = os.path.join(tmp, ctr)
+        r = subprocess.run([rp, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "t", "--", sys.executable,
+                            os.path.join(ROOT, "tools", "traffic_run.py")], cwd=tmp, env=dict(os.environ, TMPDIR=tmp),
+                           capture_output=True, text=True, timeout=900)
+        found = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+        if r.returncode != 0 or not found:
+            sys.stderr.write("--pmc: %s pass failed (rc %d): %s\n" % (ctr, r.returncode, r.stderr[-300:]))
+            return None
+        csvs[ctr] = found[0]
+    out = os.path.join(tmp, "pmc_traffic.json")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pmc_to_json
+    with contextlib.redirect_stdout(io.StringIO()):
+        pmc_to_json.main(csvs["FETCH_SIZE"], csvs["WRITE_SIZE"], out, float(1 << 28))
+    res = json.load(open(out))
+    shutil.rmtree(tmp, ignore_errors=True)
+    return res
+
+
+def _roofline(L, runner, elapsed_per_iter_ms, precision, n_profiled_iters, traffic_ok=True, pmc=None):
     mfma_peak = MFMA_BF16_PEAK_TFLOPS if precision == "bf16" else 157.3
     classes = [  # (class id, kernel, bound)
         (L.PROF_ROLLOUT, "rollout_step_kernel", "hbm"),      # policy act + env step + previous finaliser, one launch per vec-step
@@ -218,10 +254,17 @@ def _roofline(L, runner, elapsed_per_iter_ms, precision, n_profiled_iters, traff
         (L.PROF_MLP_BWD, "mlp_bwd_kernel", "mfma"), (L.PROF_DW, "dw_kernel", "mfma"), (L.PROF_GEMM, "gemm_nt_kernel", "mfma"),
         (L.PROF_LOSS, "ppo_loss_kernel", "hbm"), (L.PROF_REDUCE, "reduce_slabs_kernel", "hbm"),
         (L.PROF_APPLY, "sqnorm+adam_kernel", "hbm"), (L.PROF_GAE, "gae_kernel", "hbm")]
-    traffic = {}
+    traffic, source = {}, None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")     # HBM bytes per launch from rocprofv3 --pmc passes
-    if os.path.exists(tpath) and traffic_ok:     # the counters were collected on the headline workload: they say nothing about another size
-        traffic = json.load(open(tpath)).get("kernels", {})
+    if pmc is not None and traffic_ok:
+        traffic = pmc.get("kernels", {})
+        source = dict(kind="measured in this run", how="rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE, separate passes (bench.py --pmc)",
+                      fetch_calibration=pmc.get("fetch_calibration"))
+    elif os.path.exists(tpath) and traffic_ok:     # the counters were collected on the headline workload: they say nothing about another size
+        tj = json.load(open(tpath))
+        traffic = tj.get("kernels", {})
+        # NOT a measurement of this run: a committed file, quoted with where it came from so that the reader can tell
+        source = dict(kind="committed file, not measured in this run", path="profiles/pmc_traffic.json", **tj.get("provenance", {}))
     ks = []
     for cid, name, bound in classes:
         n, ms, work = L.prof_summary(cid)
@@ -232,7 +275,7 @@ def _roofline(L, runner, elapsed_per_iter_ms, precision, n_profiled_iters, traff
         tr = traffic.get(name)
         ks.append(dict(kernel=name, bound=bound, launches_per_iter=n // n_profiled_iters, avg_launch_us=ms / n * 1e3, achieved=ach,
                        peak=peak, unit=unit, frac=ach / peak, share_of_iteration=ms / n_profiled_iters / elapsed_per_iter_ms,
-                       traffic=tr,
+                       traffic=tr, traffic_source=source if tr else None,
                        # counter traffic per launch over this run's launch time, as a fraction of the HBM peak: how close the kernel
                        # is to being bound by the bytes it actually moves, whatever its algorithmic bound says
                        traffic_frac_of_hbm_peak=(tr / (ms / n * 1e-3) / 1e9 / HBM_PEAK_GBS) if tr else None))
@@ -268,16 +311,21 @@ def run_config(args, task, num_envs, rank, world, local, dist, steps, warmup, lo
         barrier()
         t0 = time.perf_counter()
         # K learning iterations, enqueued back to back (the runner reads nothing back between iterations when it does not log)
+        save0 = getattr(runner, "save_time_s", 0.0)
         runner.learn(num_learning_iterations=steps, init_at_random_ep_len=False)
         coll, learn = runner.last_collection_time, runner.last_learn_time     # per iteration (HIP events / host clock when logging)
         barrier()
         elapsed = time.perf_counter() - t0
+        ckpt_s = getattr(runner, "save_time_s", 0.0) - save0                  # checkpoint writes inside the timed region (logging runs)
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if dist is not None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax)
     res = dict(value=T * N * world * steps / elapsed, ms_per_step=elapsed / steps * 1e3, ppo_update_ms=learn * 1e3,
                collection_ms=coll * 1e3, T=T, N=N, obs=env.num_obs, priv=env.num_privileged_obs)
+    if log_root is not None:
+        res["checkpoint_ms_total"] = ckpt_s * 1e3
+        res["value_without_checkpoints"] = T * N * world * steps / max(elapsed - ckpt_s, 1e-9)
     if want_roofline:
         # live per-kernel timing with HIP events on the launch stream (hgym_prof_*).  Events cannot be recorded inside a
         # replayed HIP graph, so these two iterations run the rollout eagerly (same kernels, same launch order).  EVERY rank
@@ -292,7 +340,8 @@ def run_config(args, task, num_envs, rank, world, local, dist, steps, warmup, lo
         os.environ["HGYM_GRAPH"] = "1"
         if rank == 0:
             res["kernels"] = _roofline(L, runner, res["ms_per_step"], args.precision, 2,
-                                       traffic_ok=(task == "humanoid_ppo" and num_envs == 4096 and args.precision == "bf16"))
+                                       traffic_ok=(task == "humanoid_ppo" and num_envs == 4096 and args.precision == "bf16"),
+                                       pmc=getattr(args, "pmc_result", None))
             L.lib.hgym_prof_enable(0)
         if world > 1 and runner.alg.comm_timing:
             ev = runner.alg.comm_timing
@@ -319,7 +368,8 @@ def _roofline_obj(ks, pick=None):
     dom = ks[0] if pick is None else next((k for k in ks if k["kernel"] == pick), ks[0])
     rest = [k for k in ks if k is not dom]
     return dict(bound=dom["bound"], achieved=dom["achieved"], peak=dom["peak"], unit=dom["unit"], frac=dom["frac"],
-                traffic=dom["traffic"], traffic_frac_of_hbm_peak=dom.get("traffic_frac_of_hbm_peak"), kernel=dom["kernel"], launches_per_iter=dom["launches_per_iter"],
+                traffic=dom["traffic"], traffic_source=dom.get("traffic_source"), traffic_frac_of_hbm_peak=dom.get("traffic_frac_of_hbm_peak"),
+                kernel=dom["kernel"], launches_per_iter=dom["launches_per_iter"],
                 avg_launch_us=dom["avg_launch_us"], share_of_iteration=dom["share_of_iteration"], kernels=rest)
 
 
@@ -363,6 +413,11 @@ def main():
     from humanoid.algo import PPO
     PPO.precision = args.precision
 
+    args.pmc_result = None
+    if args.pmc and world == 1 and not args.no_roofline and not os.environ.get("HGYM_BENCH_CHILD"):
+        os.environ["HGYM_BENCH_CHILD"] = "1"            # tools/traffic_run.py runs this file again: not recursively
+        args.pmc_result = collect_pmc_traffic()
+        del os.environ["HGYM_BENCH_CHILD"]
     head = run_config(args, args.task, args.num_envs, rank, world, local, dist, args.steps, args.warmup,
                       want_roofline=not args.no_roofline)
     T, N = head["T"], head["N"]
@@ -386,6 +441,10 @@ def main():
                 e = dict(name="dwl_head", logging=False, note="BASELINE configs[4] on one GPU; parity of the head is unpinned (no reference code)")
             else:
                 continue
+            if "checkpoint_ms_total" in r:
+                e.update(checkpoint_ms_total=r["checkpoint_ms_total"], value_without_checkpoints=r["value_without_checkpoints"],
+                         checkpoint_note="`value` includes the checkpoint(s) OnPolicyRunner.learn writes inside the timed region (the final "
+                                         "model_<it>.pt of the call); value_without_checkpoints = the same run with their host time taken out")
             e.update(workload=_workload("humanoid_dwl_ppo" if c == "dwl" else "humanoid_ppo", r["N"], r["T"]), envs_per_gpu=r["N"],
                      value=r["value"], unit="env-steps/s", steps=k_steps, warmup=k_warm, ms_per_step=r["ms_per_step"],
                      collection_ms=r["collection_ms"], ppo_update_ms=r["ppo_update_ms"])

@@ -54,6 +54,15 @@ struct FusedNet {
     FusedLayer layer[4];
     const float* x;     // fp32 input rows (observations), leading dimension ldx
     int64_t ldx;
+    // bf16 shadow of the input rows: row-major, leading dimension a multiple of 8 and >= 32 * layer[0].KB, pad columns zero.
+    //   xb != null (XB16 instantiations): the first layer gathers ITS INPUT from here -- 2 B per element, no conversion, and
+    //              the weight-gradient kernel gathers the same rows again by index, so no X0 copy is written at all;
+    //   xs != null (fp32-input instantiations, no row gather): the tile also stores the bf16 it has just formed for LDS as row
+    //              m of this array -- how the rollout's policy launches leave the shadow of every storage slot behind.
+    const __bf16* xb;
+    int64_t ldxb;
+    __bf16* xs;
+    int64_t ldxs;
     __bf16* X0;         // bf16 copy of the gathered input, block layout, CB = 2 * layer[0].KB   (train only)
     __bf16* H[3];       // hidden activations, block layout, CB = layer[l].N / 16                 (train only)
     __bf16* dZ[4];      // pre-activation gradients; dZ[3] (32 * layer[3].NBB columns) is written by the loss kernel
@@ -96,6 +105,11 @@ template <bool NT>
 __device__ __forceinline__ u32x2 ld_stream_u2(const char* p) {
     if (NT) return __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(p));
     return *reinterpret_cast<const u32x2*>(p);
+}
+template <bool NT>
+__device__ __forceinline__ u32x4 ld_stream_u4(const char* p) {
+    if (NT) return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+    return *reinterpret_cast<const u32x4*>(p);
 }
 __device__ __forceinline__ float bf16_bits_to_f32(unsigned int lo16) { return __builtin_bit_cast(float, lo16 << 16); }
 
@@ -419,8 +433,8 @@ struct FwdNoop {
     __device__ __forceinline__ void operator()(int, int, int, const float (&)[4]) const {}
 };
 
-template <int BM, int NW, int D, int G1, bool WIDE = false, class Early = FwdNoop, class Mid = FwdNoop, class Put = FwdNoop, class Extra = int,
-          class Idle = FwdNoop, class Head = FwdNoop>
+template <int BM, int NW, int D, int G1, bool WIDE = false, bool XB16 = false, class Early = FwdNoop, class Mid = FwdNoop, class Put = FwdNoop,
+          class Extra = int, class Idle = FwdNoop, class Head = FwdNoop>
 __device__ __forceinline__ void fwd_body(const FwdArgs& a, const FusedNet& n, bool is_actor, char* smem, Early&& hook_early = Early(),
                                          Mid&& hook_mid = Mid(), Put&& hook_put = Put(), const Extra& extra = Extra(),
                                          Idle&& hook_idle = Idle(), Head&& hook_head = Head(), char* h2_lds = nullptr) {
@@ -479,7 +493,47 @@ __device__ __forceinline__ void fwd_body(const FwdArgs& a, const FusedNet& n, bo
     auto prime1 = [&]() { hidden_prime<GH, D>(r1, L1, wave, lane); };
 
     // ---------------------------------------------------------------- layer 0: input streamed in 128-column chunks
-    {
+    if constexpr (XB16) {
+        // input rows from the bf16 shadow: a chunk is 64 (32) rows x 256 B = one 16-byte item per lane, loaded as it will lie in
+        // LDS.  Lane map: 16 consecutive lanes = 8 rows x the two halves of one block row (a conflict-free 256-byte LDS
+        // write), the four lane groups = four consecutive column blocks (128 contiguous bytes of each row per instruction);
+        // waves = row groups of 8 x the two halves of the chunk.
+        constexpr int RG = BM / 8;
+        static_assert(NW == 2 * RG, "one 16-byte item per lane per chunk");
+        const int NC = L0.KB / 4;
+        const int row = (wave % RG) * 8 + ((lane >> 1) & 7), cb = (wave / RG) * 4 + (lane >> 4), hf = lane & 1;
+        int m = m0 + row;
+        m = m < a.M ? m : a.M - 1;
+        const int64_t src = a.idx ? a.idx[m] : (int64_t)m;
+        const char* srow = reinterpret_cast<const char*>(n.xb + src * n.ldxb + cb * 16 + hf * 8);
+        const int loff = ((row >> 4) * 8 + cb) * 512 + (row & 15) * 32 + hf * 16;
+        u32x4 stg;
+        auto stage_load = [&](int c) { stg = ld_stream_u4<(HGYM_NT & 1) != 0>(srow + c * (FUSED_CHUNK * 2)); };
+        auto stage_write = [&](int buf) { *reinterpret_cast<u32x4*>(Q + buf * (BM * FUSED_CHUNK * 2) + loff) = stg; };
+        const int nb0 = wave * G1;
+        f32x4 acc[MB][G1];
+        zero_acc<G1, MB>(acc);
+        WRing<G1, D> r0;
+        const u32x4* wl0 = L0.Wf + (int64_t)nb0 * L0.KB * 64 + lane;
+        phase_stamp(a.dbg, 0);
+        wring_prime<G1, D>(r0, wl0, L0.KB * 64, L0.KB);
+        stage_load(0);
+        hook_early(extra);
+        stage_write(0);
+        bias_to_lds();
+        __syncthreads();
+        phase_stamp(a.dbg, 1);
+        for (int c = 0; c + 1 < NC; ++c) {
+            stage_load(c + 1);
+            mma_chunk<G1, MB, D, false, XBF>(r0, wl0, L0.KB * 64, c * 4, Q + (c & 1) * (BM * FUSED_CHUNK * 2), 8, lane, acc);
+            stage_write((c + 1) & 1);
+            __syncthreads();
+        }
+        mma_chunk<G1, MB, D, true, XBF>(r0, wl0, L0.KB * 64, (NC - 1) * 4, Q + ((NC - 1) & 1) * (BM * FUSED_CHUNK * 2), 8, lane, acc);
+        phase_stamp(a.dbg, 2);
+        if (AHEAD) prime1();
+        epilogue_elu<G1, MB>(acc, bl, nb0, P, L0.NB, train_h ? n.H[0] : nullptr, mbg0, lane);
+    } else {
         const int NC = L0.KB / 4;
         const int CB0 = 2 * L0.KB;
         const int f4 = tid & 31;
@@ -529,6 +583,8 @@ __device__ __forceinline__ void fwd_body(const FwdArgs& a, const FusedNet& n, bo
                 if (train)
                     st_stream_u2<(HGYM_NT & 2) != 0>(reinterpret_cast<char*>(n.X0) +
                                                      ((mbg0 + (lrow[u] >> 4)) * CB0 + c * 8 + (f4 >> 2)) * 512 + inblk, pk);
+                if (n.xs && m0 + lrow[u] < a.M)      // row m of the bf16 shadow (pad columns receive the zeros formed above)
+                    st_stream_u2<(HGYM_NT & 2) != 0>(reinterpret_cast<char*>(n.xs + (int64_t)(m0 + lrow[u]) * n.ldxs + col), pk);
             }
         };
         const int nb0 = wave * G1;
@@ -758,7 +814,7 @@ struct FbLoss {
 // activations are resident for the dZ chain
 HG_HD int fb_lds_extra(const FusedNet& n) { return 64 * 64 * n.layer[3].NBB + 4 * 32 * 4 + 64 * n.layer[2].N * 2; }
 
-template <int G1, bool AUX = false>
+template <int G1, bool AUX = false, bool XB16 = false>
 __device__ __forceinline__ void fb_body(const FwdArgs& a, const FbLoss& L, const FusedNet& n, bool is_actor, char* smem) {
     constexpr int BM = 64, NW = 16, D = 2, MB = BM / 16;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -908,14 +964,14 @@ __device__ __forceinline__ void fb_body(const FwdArgs& a, const FbLoss& L, const
         }
     };
     if constexpr (AUX) {
-        fwd_body<BM, NW, D, G1, true>(a, n, false, smem, FwdNoop(), FwdNoop(), FwdNoop(), 0, FwdNoop(), head_aux, H2);
+        fwd_body<BM, NW, D, G1, true, XB16>(a, n, false, smem, FwdNoop(), FwdNoop(), FwdNoop(), 0, FwdNoop(), head_aux, H2);
         if (wave < MB) {
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) aux_se += __shfl_xor(aux_se, o, 64);
             if (lane == 0) red[wave * 32 + 29] = aux_se;
         }
     } else {
-        fwd_body<BM, NW, D, G1, false>(a, n, is_actor, smem, FwdNoop(), FwdNoop(), FwdNoop(), 0, FwdNoop(), head, H2);
+        fwd_body<BM, NW, D, G1, false, XB16>(a, n, is_actor, smem, FwdNoop(), FwdNoop(), FwdNoop(), 0, FwdNoop(), head, H2);
     }
     __syncthreads();          // dZ3 tile and the per-wave sums are in LDS; H0 sits in P, H1 in Q, H2 in its own buffer
     if (tid < 32) {
@@ -939,19 +995,20 @@ __device__ __forceinline__ void fb_body(const FwdArgs& a, const FbLoss& L, const
     phase_stamp(a.dbg, 7);
 }
 
-template <int UNUSED = 0>      // a template only so that the header can be included by several translation units
+// XB16: every net of the launch gathers its input rows from the bf16 shadow (FusedNet::xb) instead of the fp32 storage rows
+template <bool XB16 = false>
 __global__ __launch_bounds__(1024) void mlp_fb_kernel(const FwdArgs a, const FbLoss L) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int which = a.net0 + blockIdx.y;
     const FusedNet& n = a.net[which];
     const int g1 = n.layer[0].NB / 16;     // first hidden width 256 / 512 / 768
     if (which == 2) {                      // the auxiliary head (wide head, first hidden width 512 only): MSE instead of the PPO loss
-        if (g1 == 2) fb_body<2, true>(a, L, n, false, smem);
+        if (g1 == 2) fb_body<2, true, XB16>(a, L, n, false, smem);
         return;
     }
-    if (g1 == 2) fb_body<2>(a, L, n, which == 0, smem);
-    else if (g1 == 3) fb_body<3>(a, L, n, which == 0, smem);
-    else if (g1 == 1) fb_body<1>(a, L, n, which == 0, smem);
+    if (g1 == 2) fb_body<2, false, XB16>(a, L, n, which == 0, smem);
+    else if (g1 == 3) fb_body<3, false, XB16>(a, L, n, which == 0, smem);
+    else if (g1 == 1) fb_body<1, false, XB16>(a, L, n, which == 0, smem);
 }
 
 // ================================================================================================ per-minibatch loss scalars
@@ -1022,7 +1079,10 @@ constexpr int DW_MAX_PRODUCTS = 12;    // actor + critic + auxiliary head, four 
 
 struct DwProduct {
     const __bf16* Z;      // block layout, CBz column blocks per row block
-    const __bf16* X;      // block layout, CBx
+    const __bf16* X;      // block layout, CBx -- or, with gidx, the row-major bf16 shadow the rows are gathered from
+    const int64_t* gidx;  // non-null: batch row m of X is row gidx[m] of the shadow (leading dimension ldg elements, CBx = ldg / 16):
+                          // a first-layer product whose operand was never copied (mlp_fb_kernel<XB16>)
+    int64_t ldg;
     int CBz, CBx;
     int N, K;             // valid rows / cols of dW (row-major, leading dimension K)
     int64_t w_off;        // offset of dW in a slab (floats)
@@ -1040,6 +1100,8 @@ struct DwArgs {
     float* slabs;
     int64_t slab_stride;   // floats
     const char* zeros;     // >= 1 KiB of zeros (workspace): source of the stages past the end of a split
+    int B;                 // valid batch rows (gathered products clamp their row indices to it)
+    int gather;            // any product gathers: the launch carries steps_per_split * 32 row indices of LDS behind the two stages
     int scal_bid;          // >= 0: this workgroup sums the minibatch's loss partials instead (ppo_scalars_block); -1: none
     ScalArgs sc;
 };
@@ -1105,13 +1167,43 @@ __global__ __launch_bounds__(DW_THREADS, 2) void dw_kernel_rs(const DwArgs a) {
     const int64_t gstep = (int64_t)2 * (op ? P.CBx : P.CBz) * 512;   // bytes per 32-row step
     const int64_t zofs = a.zeros - gbase;
     const int lofs = lane * 16;
+    // Gathered X operand (first-layer products on the bf16 shadow): the lane that holds bytes [16 l, 16 l + 16) of a piece holds
+    // row (l & 31) >> 1 of the row block, block l >> 5 of the pair, half l & 1 -- in the row-major shadow that is 16 bytes of row
+    // gidx[m].  The split's row indices are copied to LDS once (int32) so that the steady state reads them with a ds_read: a
+    // global load of the index in front of every stage would sit in the wave's in-order return queue ahead of the stage's data.
+    const bool gx = a.gather && op && P.gidx != nullptr;              // wave-uniform
+    int* lidx = reinterpret_cast<int*>(smem + (a.gather ? 2 * DW_STAGE_BYTES : 0));
+    if (a.gather) {
+        if (P.gidx) {
+            const int rows = nsteps * 32;
+            for (int i = tid; i < rows; i += DW_THREADS) {
+                int mrow = step0 * 32 + i;
+                mrow = mrow < a.B ? mrow : a.B - 1;
+                lidx[i] = (int)P.gidx[mrow];
+            }
+        }
+        __syncthreads();
+    }
+    const int64_t ldgb = P.ldg * 2;
+    const int grow = mbl * 16 + ((lane & 31) >> 1);                   // row of the 32-row step this lane fetches
+    int64_t gcol[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int cb = cbx0 + 2 * j;
+        cb = cb + 1 < P.CBx ? cb : P.CBx - 2;
+        gcol[j] = ((int64_t)(cb + (lane >> 5)) * 16 + (lane & 1) * 8) * 2;
+    }
     u32x4 R[DW_RS][4];
     auto load = [&](int t, u32x4 (&rr)[4]) {
-        const int64_t m = t < nsteps ? -1 : 0;                // all-ones / zero: branch-free select of the byte offset
+        const bool in = t < nsteps;
+        const int tc = in ? t : nsteps - 1;
+        // unconditional LDS read (unused unless gx; a launch without gathered products has no index region: word 0 of the stages)
+        const int64_t rofs = (int64_t)lidx[a.gather ? tc * 32 + grow : 0] * ldgb;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int64_t o = ((gofs[j] + (int64_t)t * gstep) & m) | (zofs & ~m);
-            rr[j] = *reinterpret_cast<const u32x4*>(gbase + o + lofs);
+            const int64_t lin = gofs[j] + (int64_t)t * gstep + lofs, gat = rofs + gcol[j];
+            const int64_t o = in ? (gx ? gat : lin) : zofs + lofs;    // stages past the end of the split: the zero page
+            rr[j] = *reinterpret_cast<const u32x4*>(gbase + o);
         }
     };
     auto store = [&](int buf, const u32x4 (&rr)[4]) {

@@ -763,11 +763,19 @@ struct NetRunner {
         return a.fin.N > 0 ? launch_fwd_k<BM, NW, D, true>(a, nets) : launch_fwd_k<BM, NW, D, false>(a, nets);
     }
 
+    // bf16 shadow rows of net `which`'s input (hgym_net_shadow_ld): the first layer's padded width
+    int64_t shadow_ld(int which) const { return (int64_t)w.net[which].layer[0].KBf * 32; }
+
+    // sh (policy launches, no row gather): net 0 / 1 also store the bf16 of their input rows as rows of sh->obs / sh->priv
     FwdArgs make_fwd_args(int first, int nets, int M, const float* const xs[3], const int64_t ldxs[3], const int64_t* idx, float* const outs[3],
-                          const int64_t ldos[3], bool train, const SampleOut* smp, const FinArgs* fin) const {
+                          const int64_t ldos[3], bool train, const SampleOut* smp, const FinArgs* fin, const HgymObsShadow* sh = nullptr) const {
         FwdArgs a;
         memset(&a, 0, sizeof(a));
         for (int i = first; i < first + nets; ++i) a.net[i] = fused_net(i, xs[i], ldxs[i], outs[i], ldos[i]);
+        if (sh && !idx && !train) {
+            if (first == 0 && sh->obs) { a.net[0].xs = (__bf16*)sh->obs; a.net[0].ldxs = sh->ld_obs; }
+            if (first <= 1 && first + nets > 1 && sh->priv) { a.net[1].xs = (__bf16*)sh->priv; a.net[1].ldxs = sh->ld_priv; }
+        }
         a.net0 = first;
         a.M = M;
         a.idx = idx;
@@ -791,9 +799,15 @@ struct NetRunner {
 
     // forward of `nets` networks starting at `first` in ONE launch; xs/outs indexed by net id
     int32_t fused_forward(int first, int nets, int M, const float* const xs[3], const int64_t ldxs[3], const int64_t* idx, float* const outs[3],
-                          const int64_t ldos[3], bool train, const SampleOut* smp, const FinArgs* fin = nullptr) {
+                          const int64_t ldos[3], bool train, const SampleOut* smp, const FinArgs* fin = nullptr, const HgymObsShadow* sh = nullptr) {
         HG_REQUIRE(M > 0 && M <= w.maxM, HGYM_E_SHAPE, "batch %d exceeds max_batch %lld", M, (long long)w.maxM);
-        const FwdArgs a = make_fwd_args(first, nets, M, xs, ldxs, idx, outs, ldos, train, smp, fin);
+        if (sh) {
+            HG_REQUIRE((!sh->obs || (sh->ld_obs >= shadow_ld(0) && sh->ld_obs % 8 == 0 && ((uintptr_t)sh->obs & 15) == 0)) &&
+                           (!sh->priv || (sh->ld_priv >= shadow_ld(1) && sh->ld_priv % 8 == 0 && ((uintptr_t)sh->priv & 15) == 0)),
+                       HGYM_E_SHAPE, "observation shadow: leading dimensions %lld / %lld (need >= %lld / %lld, multiples of 8, 16-byte aligned rows)",
+                       (long long)sh->ld_obs, (long long)sh->ld_priv, (long long)shadow_ld(0), (long long)shadow_ld(1));
+        }
+        const FwdArgs a = make_fwd_args(first, nets, M, xs, ldxs, idx, outs, ldos, train, smp, fin, sh);
         const int pcls = train ? HGYM_PROF_MLP_FWD : HGYM_PROF_POLICY;
         prof_begin(pcls, s);
         // 32-row tiles x 8 waves (weight ring depth 4) while they fit the chip in one round (one workgroup per CU: 2 * M / 32
@@ -811,10 +825,18 @@ struct NetRunner {
     // all weight (and hidden bias) gradients of nets [first, first + count): one launch, split-K slabs
     // (the auxiliary head, net 2, reads the ACTOR's bf16 copy of the gathered observation rows as its first-layer operand -- same
     // rows, same columns -- and every bias gradient of it is a column sum of dZ: its loss has no per-tile partial sums for them)
-    int32_t fused_dw(int first, int count, int B, const ScalArgs* sc = nullptr) {
+    // gb (mlp_fb_kernel<XB16> ran): the first-layer operands were never copied -- those products gather their rows by gb->idx from the
+    // bf16 shadows
+    static constexpr int DW_GATHER_MAX_IDX_BYTES = 48 * 1024;      // two 80 KB workgroups per CU: 32 KB of stages + the split's row indices
+    bool dw_gather_fits(int B) const {
+        const int steps = (int)round_up(B, 64) / 32;
+        return (int64_t)ceil_div(steps, w.dw_splits) * 32 * 4 <= DW_GATHER_MAX_IDX_BYTES;
+    }
+    int32_t fused_dw(int first, int count, int B, const ScalArgs* sc = nullptr, const HgymBatch* gb = nullptr) {
         const int Bp = (int)round_up(B, 64);
         DwArgs d;
         memset(&d, 0, sizeof(d));
+        d.B = B;
         int tile = 0;
         double fl = 0.0;
         for (int i = first; i < first + count; ++i)
@@ -827,6 +849,13 @@ struct NetRunner {
                 p.CBz = l < 3 ? y.N / 16 : 2 * y.NBBf;
                 p.X = l == 0 ? at<__bf16>(w.net[i == 2 ? 0 : i].X0b) : at<__bf16>(n.Hb[l - 1]);
                 p.CBx = l == 0 ? 2 * y.KBf : y.K / 16;
+                if (l == 0 && gb) {
+                    p.X = (const __bf16*)(i == 1 ? gb->priv_bf16 : gb->obs_bf16);
+                    p.gidx = gb->idx;
+                    p.ldg = shadow_ld(i == 1 ? 1 : 0);
+                    p.CBx = (int)(p.ldg / 16);
+                    d.gather = 1;
+                }
                 p.N = y.N;
                 p.K = y.K;
                 p.w_off = y.w_off;
@@ -850,8 +879,13 @@ struct NetRunner {
             d.sc = *sc;
             d.scal_bid = blocks++;
         }
+        const size_t lds = 2 * DW_STAGE_BYTES + (d.gather ? (size_t)d.steps_per_split * 32 * 4 : 0);
+        if (lds > 64 * 1024) {
+            const int32_t rc_lds = ensure_dynamic_lds(reinterpret_cast<const void*>(&dw_kernel_rs<3>), lds, "dw_kernel_rs");
+            if (rc_lds) return rc_lds;
+        }
         prof_begin(HGYM_PROF_DW, s);
-        hipLaunchKernelGGL(dw_kernel_rs<3>, dim3(blocks), dim3(DW_THREADS), 2 * DW_STAGE_BYTES, s, d);
+        hipLaunchKernelGGL(dw_kernel_rs<3>, dim3(blocks), dim3(DW_THREADS), lds, s, d);
         prof_end(HGYM_PROF_DW, s, fl);
         HG_CHECK_LAUNCH("dw_kernel_rs");
         return HGYM_OK;
@@ -882,8 +916,15 @@ struct NetRunner {
         const int B = b.B, A = cfg.num_actions;
         const int64_t critic_off = w.net[1].layer[0].w_off;
         const bool aux_fb = w.nnets > 2 && w.fused_aux;      // the auxiliary head as a third grid row of the same launches
+        // batch splits of the weight-gradient contraction: one per XCD up to ~100 k rows, two beyond (8192 envs per GPU: 122 880-row
+        // minibatches -- twice the slab traffic, which is then half as large a share, and a split's row indices fit LDS again)
+        w.dw_splits = B > 98304 ? 16 : 8;
+        // bf16 shadows of the storage rows (HgymBatch.obs_bf16 / priv_bf16): gather 2 B per element, keep no operand copy
+        static const bool no_shadow = getenv("HGYM_NO_SHADOW") != nullptr;       // A/B experiments only
+        const bool shadow = b.obs_bf16 && b.priv_bf16 && !no_shadow && dw_gather_fits(B);
+        const HgymBatch* gb = shadow ? &b : nullptr;
         if (part == 1) {
-            int32_t rc1 = fused_dw(1, aux_fb ? 2 : 1, B);
+            int32_t rc1 = fused_dw(1, aux_fb ? 2 : 1, B, nullptr, gb);
             if (rc1) return rc1;
             if (w.nnets > 2 && !aux_fb) {
                 rc1 = aux_grad(ppo, b);
@@ -906,6 +947,14 @@ struct NetRunner {
         {   // forward + PPO loss + dZ chain of both nets: ONE launch (hgym_fused.hpp: mlp_fb_kernel)
             FwdArgs fa = make_fwd_args(0, nets, B, xs, ldxs, b.idx, outs, ldos, true, nullptr, nullptr);
             fa.net[2].X0 = nullptr;       // the head's first-layer operand for the weight gradient is the actor's copy (fused_dw)
+            if (shadow) {
+                HG_REQUIRE((((uintptr_t)b.obs_bf16 | (uintptr_t)b.priv_bf16) & 15) == 0, HGYM_E_BADARG, "observation shadows must be 16-byte aligned");
+                for (int i = 0; i < nets; ++i) {
+                    fa.net[i].xb = (const __bf16*)(i == 1 ? b.priv_bf16 : b.obs_bf16);
+                    fa.net[i].ldxb = shadow_ld(i == 1 ? 1 : 0);
+                    fa.net[i].X0 = nullptr;
+                }
+            }
             FbLoss fl;
             memset(&fl, 0, sizeof(fl));
             fl.actions = b.actions;
@@ -928,13 +977,15 @@ struct NetRunner {
                 lds = std::max(lds, (size_t)fused_lds_p(fa.net[i], 64) + (size_t)fused_lds_q(fa.net[i], 64) + (size_t)fused_lds_bias(fa.net[i]) +
                                         (size_t)fb_lds_extra(fa.net[i]));
             HG_REQUIRE(lds <= 160 * 1024, HGYM_E_UNSUPPORTED, "mlp_fb_kernel needs %zu bytes of LDS", lds);
-            const int32_t rc_lds = ensure_dynamic_lds(reinterpret_cast<const void*>(&mlp_fb_kernel<0>), lds, "mlp_fb_kernel");
+            const int32_t rc_lds = shadow ? ensure_dynamic_lds(reinterpret_cast<const void*>(&mlp_fb_kernel<true>), lds, "mlp_fb_kernel<shadow>")
+                                          : ensure_dynamic_lds(reinterpret_cast<const void*>(&mlp_fb_kernel<false>), lds, "mlp_fb_kernel");
             if (rc_lds) return rc_lds;
             FwdArgs fb = fa;
             fb.nets = nets;
             fb.dbg = phase_buffer((int64_t)tiles * nets);
             prof_begin(HGYM_PROF_MLP_FWD, s);
-            hipLaunchKernelGGL(mlp_fb_kernel<0>, dim3(tiles, nets), dim3(1024), lds, s, fb, fl);
+            if (shadow) hipLaunchKernelGGL(mlp_fb_kernel<true>, dim3(tiles, nets), dim3(1024), lds, s, fb, fl);
+            else hipLaunchKernelGGL(mlp_fb_kernel<false>, dim3(tiles, nets), dim3(1024), lds, s, fb, fl);
             double flops = 0.0;
             for (int i = 0; i < nets; ++i) {
                 for (int l = 0; l < 4; ++l) flops += 2.0 * (double)B * w.net[i].layer[l].N * w.net[i].layer[l].K;
@@ -948,10 +999,10 @@ struct NetRunner {
         const ScalArgs sc = {tiles, B, A, aux_fb ? w.net[2].layer[3].N : 0, at<float>(w.partials), net.grads,
                              net.grads + w.net[0].layer[3].b_off, net.grads + w.net[1].layer[3].b_off, net.grads + w.P, net.opt_state};
         if (part == 0) {
-            const int32_t rc0 = fused_dw(0, 1, B, &sc);
+            const int32_t rc0 = fused_dw(0, 1, B, &sc, gb);
             return rc0 ? rc0 : reduce_range(0, critic_off);
         }
-        rc = fused_dw(0, nets, B, &sc);
+        rc = fused_dw(0, nets, B, &sc, gb);
         if (rc) return rc;
         if (w.nnets > 2 && !aux_fb) {
             const int32_t rca = aux_grad(ppo, b);
@@ -961,15 +1012,16 @@ struct NetRunner {
     }
 
     int32_t act(int M, const float* obs, const float* priv, const float* z, uint64_t seed, const int64_t* step, float* actions, float* mu,
-                float* sigma, float* logp, float* values, const FinArgs* fin = nullptr) {
+                float* sigma, float* logp, float* values, const FinArgs* fin = nullptr, const HgymObsShadow* sh = nullptr) {
         if (w.fused) {
             const float* xs[3] = {obs, priv, nullptr};
             const int64_t ldxs[3] = {cfg.num_obs, cfg.num_priv, 0};
             float* outs[3] = {mu, values, nullptr};
             const int64_t ldos[3] = {cfg.num_actions, 1, 0};
             const SampleOut smp = {z, seed, step, actions, sigma, logp};
-            return fused_forward(0, 2, M, xs, ldxs, nullptr, outs, ldos, false, &smp, fin);
+            return fused_forward(0, 2, M, xs, ldxs, nullptr, outs, ldos, false, &smp, fin, sh);
         }
+        HG_REQUIRE(!sh || (!sh->obs && !sh->priv), HGYM_E_UNSUPPORTED, "the observation shadow exists on the fused bf16 path only (hgym_net_shadow_ld = 0 here)");
         if (fin) {     // generic path: the postponed finaliser as its own (tiny) launch
             hipLaunchKernelGGL(fin_only_kernel, dim3(1), dim3(1024), 0, s, *fin);
             HG_CHECK_LAUNCH("fin_only_kernel");
@@ -1209,7 +1261,7 @@ static int32_t check_net(const HgymNetConfig* cfg, const HgymNet* net, WsLayout*
 // XBot-L's first hidden widths (actor 512, critic 768: the instantiations the rollout kernel carries).
 int32_t rollout_fwd_args(const HgymNetConfig* cfg, const HgymNet* net, int M, const float* obs, const float* priv, uint64_t seed,
                          const int64_t* step, float* actions, float* mu, float* sigma, float* logp, float* values, FwdArgs* out,
-                         size_t* lds_bytes) {
+                         size_t* lds_bytes, const HgymObsShadow* sh) {
     WsLayout w;
     const int32_t rc = check_net(cfg, net, &w);
     if (rc) return rc;
@@ -1223,7 +1275,11 @@ int32_t rollout_fwd_args(const HgymNetConfig* cfg, const HgymNet* net, int M, co
     float* outs[3] = {mu, values, nullptr};
     const int64_t ldos[3] = {cfg->num_actions, 1, 0};
     const NetRunner<__bf16>::SampleOut smp = {nullptr, seed, step, actions, sigma, logp};
-    *out = R.make_fwd_args(0, 2, M, xs, ldxs, nullptr, outs, ldos, false, &smp, nullptr);
+    if (sh)
+        HG_REQUIRE((!sh->obs || (sh->ld_obs >= R.shadow_ld(0) && sh->ld_obs % 8 == 0 && ((uintptr_t)sh->obs & 15) == 0)) &&
+                       (!sh->priv || (sh->ld_priv >= R.shadow_ld(1) && sh->ld_priv % 8 == 0 && ((uintptr_t)sh->priv & 15) == 0)),
+                   HGYM_E_SHAPE, "observation shadow: bad leading dimension / alignment");
+    *out = R.make_fwd_args(0, 2, M, xs, ldxs, nullptr, outs, ldos, false, &smp, nullptr, sh);
     out->nets = 2;
     size_t lds = 0;
     for (int i = 0; i < 2; ++i)
@@ -1279,20 +1335,26 @@ int32_t hgym_mlp_forward(const HgymNetConfig* cfg, const HgymNet* net, int32_t w
     HG_DISPATCH(cfg, net, w, stream, forward(which, M, x, ldx, nullptr, y, nout, false));
 }
 
+int64_t hgym_net_shadow_ld(const HgymNetConfig* cfg, int32_t which) {
+    WsLayout w;
+    if (ws_layout(cfg, &w) != HGYM_OK || !w.fused || which < 0 || which > 1) return 0;
+    return (int64_t)w.net[which].layer[0].KBf * 32;
+}
+
 int32_t hgym_policy_act(const HgymNetConfig* cfg, const HgymNet* net, int32_t M, const float* obs, const float* priv, const float* z,
                         uint64_t seed, const int64_t* step_counter, float* actions, float* mu, float* sigma, float* logp, float* values,
-                        void* stream) {
+                        const HgymObsShadow* shadow, void* stream) {
     WsLayout w;
     int32_t rc = check_net(cfg, net, &w);
     if (rc) return rc;
     HG_REQUIRE(obs && priv && actions && mu && sigma && logp && values, HGYM_E_BADARG, "null pointer");
-    HG_DISPATCH(cfg, net, w, stream, act(M, obs, priv, z, seed, step_counter, actions, mu, sigma, logp, values));
+    HG_DISPATCH(cfg, net, w, stream, act(M, obs, priv, z, seed, step_counter, actions, mu, sigma, logp, values, nullptr, shadow));
 }
 
 int32_t hgym_policy_act_fin(const HgymNetConfig* cfg, const HgymNet* net, int32_t M, const float* obs, const float* priv, const float* z,
                             uint64_t seed, const int64_t* step_counter, float* actions, float* mu, float* sigma, float* logp,
                             float* values, const HgymEnvConfig* env_cfg, const HgymEnvState* env_st, const HgymEnvOut* env_out,
-                            void* stream) {
+                            const HgymObsShadow* shadow, void* stream) {
     WsLayout w;
     int32_t rc = check_net(cfg, net, &w);
     if (rc) return rc;
@@ -1302,7 +1364,7 @@ int32_t hgym_policy_act_fin(const HgymNetConfig* cfg, const HgymNet* net, int32_
                    env_out->rew && env_out->reset, HGYM_E_BADARG, "null finaliser buffer");
     HG_REQUIRE(env_cfg->num_envs > 0, HGYM_E_SHAPE, "num_envs=%d", env_cfg->num_envs);
     const FinArgs fin = make_fin_args(*env_cfg, *env_st, *env_out, FIN_MODE_STEP);
-    HG_DISPATCH(cfg, net, w, stream, act(M, obs, priv, z, seed, step_counter, actions, mu, sigma, logp, values, &fin));
+    HG_DISPATCH(cfg, net, w, stream, act(M, obs, priv, z, seed, step_counter, actions, mu, sigma, logp, values, &fin, shadow));
 }
 
 int32_t hgym_ppo_grad(const HgymNetConfig* cfg, const HgymPPOConfig* ppo, const HgymNet* net, const HgymBatch* batch, void* stream) {

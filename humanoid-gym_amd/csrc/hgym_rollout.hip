@@ -54,7 +54,7 @@ namespace hgym {
 
 int32_t rollout_fwd_args(const HgymNetConfig* cfg, const HgymNet* net, int M, const float* obs, const float* priv, uint64_t seed,
                          const int64_t* step, float* actions, float* mu, float* sigma, float* logp, float* values, FwdArgs* out,
-                         size_t* lds_bytes);
+                         size_t* lds_bytes, const HgymObsShadow* sh);
 int32_t rollout_env_args(const HgymEnvConfig* cfg, const HgymSimTensors* sim, const HgymEnvState* st, const HgymEnvOut* out,
                          float* actions, EnvArgs* A);
 
@@ -260,7 +260,7 @@ int32_t hgym_rollout_begin(const HgymEnvState* st, const int64_t* step_counter, 
 int32_t hgym_rollout_step(const HgymNetConfig* cfg, const HgymNet* net, const HgymEnvConfig* env_cfg, const HgymSimTensors* sim,
                           const HgymEnvState* st, const HgymEnvOut* out, const HgymEnvOut* prev_out, const float* obs, const float* priv,
                           uint64_t seed, float* actions, float* mu, float* sigma, float* logp, float* values, void* scratch,
-                          int32_t parity, void* stream) {
+                          int32_t parity, const HgymObsShadow* shadow, void* stream) {
     HG_REQUIRE(cfg && net && env_cfg && sim && st && out && scratch, HGYM_E_BADARG, "null argument");
     HG_REQUIRE(obs && priv && actions && mu && sigma && logp && values, HGYM_E_BADARG, "null policy buffer");
     HG_REQUIRE(parity == 0 || parity == 1, HGYM_E_BADARG, "parity=%d", parity);
@@ -277,7 +277,7 @@ int32_t hgym_rollout_step(const HgymNetConfig* cfg, const HgymNet* net, const Hg
     RolloutPP pp;
     memset(&fin, 0, sizeof(fin));
     size_t lds_pol = 0;
-    int32_t rc = rollout_fwd_args(cfg, net, M, obs, priv, seed, &scr->pp[parity][2], actions, mu, sigma, logp, values, &f, &lds_pol);
+    int32_t rc = rollout_fwd_args(cfg, net, M, obs, priv, seed, &scr->pp[parity][2], actions, mu, sigma, logp, values, &f, &lds_pol, shadow);
     if (rc) return rc;
     rc = rollout_env_args(env_cfg, sim, st, out, actions, &e);
     if (rc) return rc;

@@ -118,12 +118,18 @@ class Net(C.Structure):
 class Batch(C.Structure):
     _fields_ = [("obs", c_float_p), ("priv", c_float_p), ("actions", c_float_p), ("values", c_float_p),
                 ("advantages", c_float_p), ("returns", c_float_p), ("logp", c_float_p), ("mu", c_float_p),
-                ("sigma", c_float_p), ("idx", c_i64_p), ("B", C.c_int32)]
+                ("sigma", c_float_p), ("idx", c_i64_p), ("B", C.c_int32),
+                ("obs_bf16", C.c_void_p), ("priv_bf16", C.c_void_p)]
+
+
+class ObsShadow(C.Structure):
+    """HgymObsShadow: where a policy launch leaves the bf16 of the observation rows it reads (row-major, ld in elements)."""
+    _fields_ = [("obs", C.c_void_p), ("ld_obs", C.c_int64), ("priv", C.c_void_p), ("ld_priv", C.c_int64)]
 
 
 STRUCTS = dict(HgymEnvConfig=EnvConfig, HgymStrided=Strided, HgymSimTensors=SimTensors, HgymEnvState=EnvState,
                HgymEnvOut=EnvOut, HgymEnvNoise=EnvNoise, HgymNetConfig=NetConfig, HgymPPOConfig=PPOConfig,
-               HgymNet=Net, HgymBatch=Batch)
+               HgymNet=Net, HgymBatch=Batch, HgymObsShadow=ObsShadow)
 
 # every symbol include/hgym.h declares: name -> (restype, argtypes)
 _P = C.POINTER
@@ -151,14 +157,16 @@ SYMBOLS = {
     "hgym_net_workspace_bytes": (C.c_int64, [_P(NetConfig)]),
     "hgym_net_sync_shadow": (C.c_int32, [_P(NetConfig), _P(Net), C.c_void_p]),
     "hgym_mlp_forward": (C.c_int32, [_P(NetConfig), _P(Net), C.c_int32, C.c_int32, c_float_p, C.c_int64, c_float_p, C.c_void_p]),
+    "hgym_net_shadow_ld": (C.c_int64, [_P(NetConfig), C.c_int32]),
     "hgym_policy_act": (C.c_int32, [_P(NetConfig), _P(Net), C.c_int32, c_float_p, c_float_p, c_float_p, C.c_uint64, c_i64_p,
-                                    c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, C.c_void_p]),
+                                    c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, _P(ObsShadow), C.c_void_p]),
     "hgym_policy_act_fin": (C.c_int32, [_P(NetConfig), _P(Net), C.c_int32, c_float_p, c_float_p, c_float_p, C.c_uint64, c_i64_p,
-                                    c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, _P(EnvConfig), _P(EnvState), _P(EnvOut), C.c_void_p]),
+                                    c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, _P(EnvConfig), _P(EnvState), _P(EnvOut),
+                                    _P(ObsShadow), C.c_void_p]),
     "hgym_rollout_begin": (C.c_int32, [_P(EnvState), c_i64_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "hgym_rollout_step": (C.c_int32, [_P(NetConfig), _P(Net), _P(EnvConfig), _P(SimTensors), _P(EnvState), _P(EnvOut), _P(EnvOut), c_float_p,
                                       c_float_p, C.c_uint64, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, C.c_void_p, C.c_int32,
-                                      C.c_void_p]),
+                                      _P(ObsShadow), C.c_void_p]),
     "hgym_rollout_end": (C.c_int32, [_P(EnvConfig), _P(EnvState), _P(EnvOut), C.c_void_p, C.c_int32, C.c_void_p]),
     "hgym_ppo_grad": (C.c_int32, [_P(NetConfig), _P(PPOConfig), _P(Net), _P(Batch), C.c_void_p]),
     "hgym_ppo_grad_part": (C.c_int32, [_P(NetConfig), _P(PPOConfig), _P(Net), _P(Batch), C.c_int32, C.c_void_p]),

@@ -112,9 +112,20 @@ class NetBuffers:
                                        self.stream()), "hgym_mlp_forward")
         return y
 
-    def act(self, obs, priv, z=None, seed=0, step_counter=None, out=None, env_fin=None):
+    def shadow_ld(self, which):
+        """Leading dimension (elements) of the bf16 shadow of the actor's (0) / critic's (1) input rows; 0: no shadow on this path."""
+        return int(L.lib.hgym_net_shadow_ld(C.byref(self.cfg), int(which)))
+
+    def shadow_struct(self, obs_bf16, priv_bf16):
+        """HgymObsShadow over two (M, ld) torch.bfloat16 tensors (the caller keeps them alive)."""
+        assert obs_bf16.dtype == torch.bfloat16 and priv_bf16.dtype == torch.bfloat16 and obs_bf16.is_contiguous() and priv_bf16.is_contiguous()
+        return L.ObsShadow(C.c_void_p(obs_bf16.data_ptr()), obs_bf16.shape[-1], C.c_void_p(priv_bf16.data_ptr()), priv_bf16.shape[-1])
+
+    def act(self, obs, priv, z=None, seed=0, step_counter=None, out=None, env_fin=None, shadow=None):
         """env_fin: optional (HgymEnvConfig, HgymEnvState, HgymEnvOut) of an env step whose finaliser was postponed
-        (HgymEnvOut.defer_finalize): it runs as one extra workgroup of this launch (hgym_policy_act_fin)."""
+        (HgymEnvOut.defer_finalize): it runs as one extra workgroup of this launch (hgym_policy_act_fin).
+        shadow: optional (obs_bf16, priv_bf16) tensors receiving the bf16 of the rows read (HgymObsShadow)."""
+        sh = None if shadow is None else C.byref(self.shadow_struct(*shadow))
         M = obs.shape[0]
         A = self.cfg.num_actions
         if out is None:
@@ -124,12 +135,12 @@ class NetBuffers:
             ecfg, est, eout = env_fin
             L.check(L.lib.hgym_policy_act_fin(C.byref(self.cfg), C.byref(self.struct), M, L.fptr(obs), L.fptr(priv), L.fptr(z), int(seed),
                                               L.i64ptr(step_counter), L.fptr(out["actions"]), L.fptr(out["mu"]), L.fptr(out["sigma"]),
-                                              L.fptr(out["logp"]), L.fptr(out["values"]), C.byref(ecfg), C.byref(est), C.byref(eout),
+                                              L.fptr(out["logp"]), L.fptr(out["values"]), C.byref(ecfg), C.byref(est), C.byref(eout), sh,
                                               self.stream()), "hgym_policy_act_fin")
             return out
         L.check(L.lib.hgym_policy_act(C.byref(self.cfg), C.byref(self.struct), M, L.fptr(obs), L.fptr(priv), L.fptr(z), int(seed),
                                       L.i64ptr(step_counter), L.fptr(out["actions"]), L.fptr(out["mu"]), L.fptr(out["sigma"]),
-                                      L.fptr(out["logp"]), L.fptr(out["values"]), self.stream()), "hgym_policy_act")
+                                      L.fptr(out["logp"]), L.fptr(out["values"]), sh, self.stream()), "hgym_policy_act")
         return out
 
     def ppo_grad(self, ppo, batch):
@@ -150,10 +161,17 @@ class NetBuffers:
         L.check(L.lib.hgym_ppo_apply(C.byref(self.cfg), C.byref(ppo), C.byref(self.struct), self.stream()), "hgym_ppo_apply")
 
 
-def make_batch(obs, priv, actions, values, advantages, returns, logp, mu, sigma, idx):
-    """All (T*N, *) flattened, contiguous fp32; idx int64 (B,)."""
+def make_batch(obs, priv, actions, values, advantages, returns, logp, mu, sigma, idx, obs_bf16=None, priv_bf16=None):
+    """All (T*N, *) flattened, contiguous fp32; idx int64 (B,).  obs_bf16 / priv_bf16: optional (T*N, ld) bfloat16 shadows of obs /
+    priv (ld = NetBuffers.shadow_ld), both or neither."""
     for t in (obs, priv, actions, values, advantages, returns, logp, mu, sigma):
         assert t.is_contiguous() and t.dtype == torch.float32
     assert idx.dtype == torch.int64 and idx.is_contiguous()
+    assert (obs_bf16 is None) == (priv_bf16 is None)
+    sb = (None, None)
+    if obs_bf16 is not None:
+        assert obs_bf16.dtype == torch.bfloat16 and priv_bf16.dtype == torch.bfloat16 and obs_bf16.is_contiguous() and priv_bf16.is_contiguous()
+        assert obs_bf16.shape[0] == obs.shape[0] and priv_bf16.shape[0] == priv.shape[0]
+        sb = (C.c_void_p(obs_bf16.data_ptr()), C.c_void_p(priv_bf16.data_ptr()))
     return L.Batch(L.fptr(obs), L.fptr(priv), L.fptr(actions), L.fptr(values), L.fptr(advantages), L.fptr(returns), L.fptr(logp),
-                   L.fptr(mu), L.fptr(sigma), L.i64ptr(idx), int(idx.numel()))
+                   L.fptr(mu), L.fptr(sigma), L.i64ptr(idx), int(idx.numel()), sb[0], sb[1])

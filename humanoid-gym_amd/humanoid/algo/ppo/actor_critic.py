@@ -109,7 +109,7 @@ class ActorCritic(nn.Module):
         mu = net.forward(0, observations.contiguous())
         self._last = dict(mu=mu, sigma=mu * 0.0 + self.std.detach())
 
-    def act(self, observations, critic_observations=None, out=None, env_fin=None, **kwargs):
+    def act(self, observations, critic_observations=None, out=None, env_fin=None, shadow=None, **kwargs):
         """Sample actions.  With critic_observations the critic runs in the same call (what PPO.act needs)."""
         net = self._need_net()
         if critic_observations is None:
@@ -119,7 +119,7 @@ class ActorCritic(nn.Module):
             self._last["actions"] = a
             return a
         self._last = net.act(observations.contiguous(), critic_observations.contiguous(), seed=self._sample_seed,
-                             step_counter=self._sample_step, out=out, env_fin=env_fin)
+                             step_counter=self._sample_step, out=out, env_fin=env_fin, shadow=shadow)
         return self._last["actions"]
 
     def get_actions_log_prob(self, actions):

@@ -187,6 +187,7 @@ class OnPolicyRunner:
                     if use_graph and g is not None and g["key"] == gkey:
                         g["graph"].replay()
                         alg.storage.step = self.num_steps_per_env
+                        alg.storage.shadow_valid = list(g["shadow_valid"])     # the replayed launches wrote the same shadow slots
                         obs, critic_obs = g["out"]
                         ep_infos = g["ep_infos"]
                         cur_reward_sum, cur_episode_length, done_stats = g["stats"]
@@ -199,7 +200,8 @@ class OnPolicyRunner:
                         with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                             out = rollout(obs_all[0], priv_all[0])
                         self._graph = dict(graph=graph, out=out, ep_infos=ep_infos, key=gkey,
-                                           stats=(cur_reward_sum, cur_episode_length, done_stats))
+                                           stats=(cur_reward_sum, cur_episode_length, done_stats),
+                                           shadow_valid=list(getattr(alg.storage, "shadow_valid", [])))
                         alg.storage.step = 0
                         graph.replay()                  # capture does not execute: run the captured rollout once
                         alg.storage.step = self.num_steps_per_env
@@ -368,9 +370,11 @@ class OnPolicyRunner:
         self._graph, self._graph_warm = None, False
 
     def save(self, path, infos=None):
+        t0 = time.time()
         torch.save({"model_state_dict": self.alg.actor_critic.state_dict(),
                     "optimizer_state_dict": self.alg.optimizer.state_dict(),
                     "iter": self.current_learning_iteration, "infos": infos}, path)
+        self.save_time_s = getattr(self, "save_time_s", 0.0) + (time.time() - t0)     # host time spent in checkpoints (bench.py reports it)
 
     def load(self, path, load_optimizer=True):
         loaded = torch.load(path, map_location=self.device)

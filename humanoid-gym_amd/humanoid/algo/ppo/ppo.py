@@ -120,6 +120,9 @@ class PPO:
         self.net = hgym.NetBuffers(cfg, self.device, learning_rate=self._lr0)
         dist_utils.broadcast_parameters(ac.parameters())   # identical initial parameters on every rank
         ac.bind(self.net)
+        # bf16 shadows of the stored observation rows: the policy launches leave them behind, the update gathers from them
+        if os.environ.get("HGYM_SHADOW", "1") != "0":
+            self.storage.enable_shadow(self.net.shadow_ld(0), self.net.shadow_ld(1))
         self._ppo_cfg = hgym.make_ppo_config(self.clip_param, self.value_loss_coef, self.entropy_coef, self.max_grad_norm,
                                              self.desired_kl if self.desired_kl is not None else 0.0,
                                              adaptive=(self.desired_kl is not None and self.schedule == "adaptive"),
@@ -159,7 +162,11 @@ class PPO:
         if s < st.num_transitions_per_env:     # write straight into the storage slot (no add_transitions copies)
             out = dict(actions=st.actions[s], mu=st.mu[s], sigma=st.sigma[s], logp=st.actions_log_prob[s].view(-1), values=st.values[s])
         t = self.transition
-        t.actions = self.actor_critic.act(obs, critic_obs, out=out, env_fin=env_fin)
+        # the slot's bf16 shadow only when `obs` IS the slot (the zero-copy runner): a copy made later by add_transitions
+        # invalidates it again
+        sh = st.shadow_slot(s) if (out is not None and obs.data_ptr() == st._obs_all[s].data_ptr()
+                                   and st._priv_all is not None and critic_obs.data_ptr() == st._priv_all[s].data_ptr()) else None
+        t.actions = self.actor_critic.act(obs, critic_obs, out=out, env_fin=env_fin, shadow=sh)
         last = self.actor_critic._last
         t.values, t.actions_log_prob = last["values"], last["logp"]
         t.action_mean, t.action_sigma = last["mu"], last["sigma"]
@@ -177,7 +184,8 @@ class PPO:
             raise AssertionError("Rollout buffer overflow")
         out = dict(actions=st.actions[s], mu=st.mu[s], sigma=st.sigma[s], logp=st.actions_log_prob[s].view(-1), values=st.values[s])
         sink = dict(values=st.values[s], rewards=st.rewards[s], dones=st.dones[s], step=self._sample_step, gamma=self.gamma)
-        env.rollout_step(self.net, i, obs, critic_obs, next_obs, next_critic_obs, sink, self.actor_critic._sample_seed, out)
+        sh = st.shadow_slot(s) if (obs.data_ptr() == st._obs_all[s].data_ptr() and critic_obs.data_ptr() == st._priv_all[s].data_ptr()) else None
+        env.rollout_step(self.net, i, obs, critic_obs, next_obs, next_critic_obs, sink, self.actor_critic._sample_seed, out, shadow=sh)
         st.step += 1
 
     def transition_sink(self):
@@ -231,13 +239,15 @@ class PPO:
         priv = fl(st.privileged_observations) if st.privileged_observations is not None else obs
         cols = (obs, priv, fl(st.actions), st.values.view(-1), st.advantages.view(-1), st.returns.view(-1),
                 st.actions_log_prob.view(-1), fl(st.mu), fl(st.sigma))
+        sh = st.shadows() if hasattr(st, "shadows") else None
+        sh = dict(obs_bf16=sh[0], priv_bf16=sh[1]) if sh is not None else {}
         net.opt_state[2:8] = 0.0               # the per-update sums [2..5], [7] (and the informational last norm [6]): one fill
         if self._ppo_cfg.aux_coef > 0.0:
             net.opt_state[10] = 0.0
         for _ in range(self.num_learning_epochs):
             for i in range(self.num_mini_batches):
                 idx = perm[i * mb:(i + 1) * mb]
-                batch = hgym.make_batch(*cols, idx)
+                batch = hgym.make_batch(*cols, idx, **sh)
                 if not dist_utils.active():
                     net.ppo_grad(self._ppo_cfg, batch)
                 else:

@@ -52,6 +52,33 @@ class RolloutStorage:
         self.saved_hidden_states_a = self.saved_hidden_states_c = None
         self._stats = z(3, dtype=torch.float64)
         self.step = 0
+        # optional bf16 shadows of the two observation buffers (enable_shadow): written by the policy launch that reads the slot,
+        # read by the update instead of the fp32 rows
+        self._obs_bf16 = self._priv_bf16 = None
+        self.shadow_valid = [False] * T
+
+    def enable_shadow(self, ld_obs, ld_priv):
+        """Native extension: allocate (T, N, ld) bfloat16 copies of `observations` / `privileged_observations` (ld = the widths
+        padded to 128, zero pad columns).  Slot s counts as valid once a policy launch has written it (shadow_slot)."""
+        if self._priv_all is None or ld_obs <= 0 or ld_priv <= 0:
+            return False
+        T, N = self.num_transitions_per_env, self.num_envs
+        self._obs_bf16 = torch.zeros(T, N, int(ld_obs), dtype=torch.bfloat16, device=self.device)
+        self._priv_bf16 = torch.zeros(T, N, int(ld_priv), dtype=torch.bfloat16, device=self.device)
+        return True
+
+    def shadow_slot(self, s):
+        """(obs_bf16[s], priv_bf16[s]) for the policy launch that reads slot s, which thereby becomes valid; None without shadows."""
+        if self._obs_bf16 is None or s >= self.num_transitions_per_env:
+            return None
+        self.shadow_valid[s] = True
+        return self._obs_bf16[s], self._priv_bf16[s]
+
+    def shadows(self):
+        """The flattened (T*N, ld) shadows when every slot of the current rollout was written by its policy launch, else None."""
+        if self._obs_bf16 is None or not all(self.shadow_valid):
+            return None
+        return self._obs_bf16.flatten(0, 1), self._priv_bf16.flatten(0, 1)
 
     # ------------------------------------------------------------------
     def _same(self, a, b):
@@ -67,9 +94,11 @@ class RolloutStorage:
                  (self.mu[s], transition.action_mean), (self.sigma[s], transition.action_sigma)]
         if self.privileged_observations is not None:
             pairs.append((self.privileged_observations[s], transition.critic_observations))
-        for dst, src in pairs:
+        for k, (dst, src) in enumerate(pairs):
             if not self._same(dst, src):          # producers that already wrote the slot are not copied again
                 dst.copy_(src)
+                if k == 0 or k == 8:              # observations copied in from elsewhere: the slot's bf16 shadow does not describe them
+                    self.shadow_valid[s] = False
         self.step += 1
 
     def clear(self):
@@ -77,6 +106,7 @@ class RolloutStorage:
         if self._priv_all is not None:
             self._priv_all[0].copy_(self._priv_all[self.num_transitions_per_env])
         self.step = 0
+        self.shadow_valid = [False] * self.num_transitions_per_env
 
     def compute_returns(self, last_values, gamma, lam, stats_hook=None):
         from hgym import _lib as L

@@ -397,7 +397,9 @@ class LeggedRobot(BaseTask):
     # results; every other caller keeps act() + step().
     def rollout_fused_supported(self, net):
         """XBot-L default options (none of the generic ones), 15 / 3 history, a whole number of 32-env blocks, the bf16 fused net
-        path with XBot-L's first hidden widths, and one actor + one critic workgroup per 32 envs fitting the chip in one round."""
+        path with XBot-L's first hidden widths, and one actor + one critic workgroup per 32 envs fitting the chip in one round.
+        (Beyond that -- 8192 envs, BASELINE configs[3] -- the two-launch path with 64-row policy tiles is faster: every CU streaming
+        the weights of a 32-row tile saturates the L2 -> CU path; measured, profiles/r03_seq_rollout_8192_negative_result.txt.)"""
         c, nc = self._ncfg, net.cfg
         generic = c.custom_origins or c.terrain_curriculum or c.num_height_points > 0 or c.command_curriculum or not c.heading_command
         cus = int(self._L.lib.hgym_device_cus())
@@ -416,11 +418,13 @@ class LeggedRobot(BaseTask):
         self._L.check(self._L.lib.hgym_rollout_begin(C.byref(self._st_s), self._L.i64ptr(step_counter), C.c_void_p(self._buf.rollout_scratch.data_ptr()),
                                                      (self._ro_T - 1) & 1, self._stream()), "hgym_rollout_begin")
 
-    def rollout_step(self, net, i, obs, priv, next_obs, next_priv, sink, seed, out):
+    def rollout_step(self, net, i, obs, priv, next_obs, next_priv, sink, seed, out, shadow=None):
         """Step i of the rollout begun with rollout_begin: actions / mu / sigma / logp / values of PPO.act into `out`, this env's
         step on those actions with the observations written to next_obs / next_priv, the transition sink of step i stored by
         the finaliser that rides in step i + 1 (or in rollout_end).  The last step uses the primary rew / reset / time_out
-        buffers, so that they read as after a plain step() once the rollout is over."""
+        buffers, so that they read as after a plain step() once the rollout is over.  shadow: optional (obs_bf16, priv_bf16)
+        storage-slot tensors receiving the bf16 of `obs` / `priv` (HgymObsShadow)."""
+        sh = None if shadow is None else net.shadow_struct(*shadow)
         L = self._L
         parity = (self._ro_T - 1 - i) & 1
         o = self._buf.out_struct(next_obs, next_priv, sink, True, alt=bool(parity))
@@ -429,7 +433,7 @@ class LeggedRobot(BaseTask):
                                         C.byref(o), C.byref(prev[0]) if prev is not None else None, L.fptr(obs), L.fptr(priv),
                                         int(seed) & 0xFFFFFFFFFFFFFFFF, L.fptr(out["actions"]), L.fptr(out["mu"]), L.fptr(out["sigma"]),
                                         L.fptr(out["logp"]), L.fptr(out["values"]), C.c_void_p(self._buf.rollout_scratch.data_ptr()), parity,
-                                        self._stream()), "hgym_rollout_step")
+                                        None if sh is None else C.byref(sh), self._stream()), "hgym_rollout_step")
         self._ro_prev = (o, parity, sink)          # keeps the struct (and the tensors it points at) alive for the next launch
         self.obs_buf, self.privileged_obs_buf = next_obs, next_priv
 

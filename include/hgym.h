@@ -28,8 +28,10 @@
 extern "C" {
 #endif
 
-#define HGYM_VERSION 3      /* 2: HgymEnvOut carries the logging sink; hgym_rollout_*, hgym_ppo_grad_part, hgym_net_param_offset
-                             * 3: the rollout scratch block grows with the env count (HGYM_ROLLOUT_SCRATCH_BYTES(num_envs)) */
+#define HGYM_VERSION 4      /* 2: HgymEnvOut carries the logging sink; hgym_rollout_*, hgym_ppo_grad_part, hgym_net_param_offset
+                             * 3: the rollout scratch block grows with the env count (HGYM_ROLLOUT_SCRATCH_BYTES(num_envs))
+                             * 4: bf16 observation shadow: HgymObsShadow argument of the policy launches, HgymBatch.obs_bf16 /
+                             *    priv_bf16, hgym_net_shadow_ld */
 
 enum {
     HGYM_OK = 0,
@@ -361,12 +363,30 @@ int32_t hgym_net_sync_shadow(const HgymNetConfig* cfg, const HgymNet* net, void*
 int32_t hgym_mlp_forward(const HgymNetConfig* cfg, const HgymNet* net, int32_t which, int32_t M,
                          const float* x, int64_t ldx, float* y, void* stream);
 
+/* bf16 shadow of the observation rows (optional; the update's fast path).  The update reads every stored observation row twice per
+ * epoch -- the forward gathers it, the first layer's weight-gradient product gathers it again -- and only ever in bf16.  A policy
+ * launch has each row in hand as bf16 anyway (it converts the fp32 row for its first layer), so it can leave that copy behind:
+ * `shadow->obs` / `shadow->priv` receive, row m, the bf16 of row m of `obs` / `priv` (row-major, leading dimensions ld_obs /
+ * ld_priv in elements = hgym_net_shadow_ld(cfg, 0 / 1): the input width padded to 128, pad columns written as zero).  Handed
+ * back through HgymBatch.obs_bf16 / priv_bf16, the update gathers 2 bytes per element instead of 4 and writes no operand copy
+ * of its own.  NULL: no shadow is written.  Only the fused bf16 path writes / reads it (hgym_net_shadow_ld returns 0 otherwise). */
+typedef struct HgymObsShadow {
+    void* obs;       /* (M, ld_obs) bf16 */
+    int64_t ld_obs;
+    void* priv;      /* (M, ld_priv) bf16 */
+    int64_t ld_priv;
+} HgymObsShadow;
+/* leading dimension (elements) of the bf16 shadow of net `which`'s input rows (0 actor: obs, 1 critic: privileged obs), or 0 when
+ * this configuration does not take the fused bf16 path */
+int64_t hgym_net_shadow_ld(const HgymNetConfig* cfg, int32_t which);
+
 /* PPO.act (ppo.py:91-101): mu = actor(obs); sigma = std; a = mu + sigma*z; V = critic(priv);
  * logp = sum log N(a; mu, sigma).  z (M,12) standard normal draws or NULL -> Philox(seed, *step_counter).
  * Outputs row-major: actions/mu/sigma (M,12), logp (M,), values (M,). */
 int32_t hgym_policy_act(const HgymNetConfig* cfg, const HgymNet* net, int32_t M, const float* obs,
                         const float* priv, const float* z, uint64_t seed, const int64_t* step_counter,
-                        float* actions, float* mu, float* sigma, float* logp, float* values, void* stream);
+                        float* actions, float* mu, float* sigma, float* logp, float* values,
+                        const HgymObsShadow* shadow, void* stream);
 
 /* hgym_policy_act + the postponed step finaliser of the PREVIOUS env step (env_cfg / env_st / env_out as that step got them,
  * env_out->defer_finalize = 1) as one extra workgroup of the same launch: one launch less per vec-step. */
@@ -374,7 +394,7 @@ int32_t hgym_policy_act_fin(const HgymNetConfig* cfg, const HgymNet* net, int32_
                             const float* priv, const float* z, uint64_t seed, const int64_t* step_counter,
                             float* actions, float* mu, float* sigma, float* logp, float* values,
                             const HgymEnvConfig* env_cfg, const HgymEnvState* env_st, const HgymEnvOut* env_out,
-                            void* stream);
+                            const HgymObsShadow* shadow, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Fused rollout step: PPO.act + XBotLFreeEnv.step (synthetic-physics backend) + the previous step's finaliser in ONE launch
@@ -405,7 +425,7 @@ int32_t hgym_rollout_begin(const HgymEnvState* st, const int64_t* step_counter, 
 int32_t hgym_rollout_step(const HgymNetConfig* cfg, const HgymNet* net, const HgymEnvConfig* env_cfg, const HgymSimTensors* sim,
                           const HgymEnvState* st, const HgymEnvOut* out, const HgymEnvOut* prev_out, const float* obs,
                           const float* priv, uint64_t seed, float* actions, float* mu, float* sigma, float* logp, float* values,
-                          void* scratch, int32_t parity, void* stream);
+                          void* scratch, int32_t parity, const HgymObsShadow* shadow, void* stream);
 int32_t hgym_rollout_end(const HgymEnvConfig* env_cfg, const HgymEnvState* st, const HgymEnvOut* last_out, void* scratch,
                          int32_t parity, void* stream);
 
@@ -425,6 +445,11 @@ typedef struct HgymBatch {
     const float* sigma;      /* (T*N, 12) */
     const int64_t* idx;      /* (B,) */
     int32_t B;
+    /* optional bf16 shadows of obs / priv, same rows (HgymObsShadow: written by the policy launches that read those rows), leading
+     * dimensions hgym_net_shadow_ld(cfg, 0 / 1); both or neither.  NULL: the fp32 rows are gathered and converted (and a bf16
+     * operand copy of the gathered rows is kept for the weight-gradient kernel). */
+    const void* obs_bf16;
+    const void* priv_bf16;
 } HgymBatch;
 
 int32_t hgym_ppo_grad(const HgymNetConfig* cfg, const HgymPPOConfig* ppo, const HgymNet* net,

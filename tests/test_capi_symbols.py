@@ -16,7 +16,7 @@ def test_header_symbols_exported():
     assert declared == set(L.SYMBOLS), (declared ^ set(L.SYMBOLS))
     for name in declared:
         assert hasattr(L.lib, name), name
-    assert L.lib.hgym_version() == 3
+    assert L.lib.hgym_version() == 4
 
 
 def test_struct_layouts_match():

@@ -326,7 +326,7 @@ def test_rollout_step_refuses_foreign_net_shapes_on_the_c_side():
     before = buf._state.clone()
     rc = L.lib.hgym_rollout_step(C.byref(net.cfg), C.byref(net.struct), C.byref(cfg), C.byref(buf.sim_struct()), C.byref(buf.state_struct()),
                                  C.byref(out), None, L.fptr(z(N, 700)), L.fptr(z(N, 219)), 1, L.fptr(z(N, 12)), L.fptr(z(N, 12)),
-                                 L.fptr(z(N, 12)), L.fptr(z(N)), L.fptr(val), C.c_void_p(buf.rollout_scratch.data_ptr()), 0,
+                                 L.fptr(z(N, 12)), L.fptr(z(N)), L.fptr(val), C.c_void_p(buf.rollout_scratch.data_ptr()), 0, None,
                                  C.c_void_p(torch.cuda.current_stream().cuda_stream))
     torch.cuda.synchronize()
     assert rc == -4 and b"705" in L.lib.hgym_last_error()
@@ -370,3 +370,95 @@ def test_two_devices_in_one_process_share_nothing():
     for d in (0, 1):
         assert torch.equal(outs[("alone", d)], outs[("interleaved", d)]), d
     assert torch.equal(outs[("alone", 0)], outs[("alone", 1)])
+
+
+# ------------------------------------------------------------------------------------------------ bf16 observation shadow
+@pytest.mark.parametrize("M", [64, 100, 4096, 5000, 20000])
+def test_policy_launch_leaves_the_bf16_shadow_of_its_input_rows(M):
+    """HgymObsShadow: hgym_policy_act with a shadow argument stores, row m, the bf16 (round-to-nearest-even) of obs[m] / priv[m],
+    zero in the pad columns -- through both tile shapes (32-row tiles up to 4096 rows, 64-row tiles beyond) and ragged row counts;
+    the launch's other outputs do not change."""
+    g = torch.Generator().manual_seed(M)
+    p = P.Params.random(705, 219, 12, K.ACTOR_HIDDEN, K.CRITIC_HIDDEN, g)
+    net = _net("bf16", max(M, 64))
+    net.load_state_dict(dict(zip(NAMES, p.tensors())))
+    assert (net.shadow_ld(0), net.shadow_ld(1)) == (768, 256)
+    obs = (torch.randn(M, 705, generator=g) * 3).clamp(-18, 18).cuda()
+    priv = (torch.randn(M, 219, generator=g) * 3).clamp(-18, 18).cuda()
+    z = torch.randn(M, 12, generator=g).cuda()
+    so = torch.full((M, 768), 7.0, dtype=torch.bfloat16, device="cuda")
+    sp = torch.full((M, 256), 7.0, dtype=torch.bfloat16, device="cuda")
+    a = net.act(obs, priv, z=z)
+    b = net.act(obs, priv, z=z, shadow=(so, sp))
+    torch.cuda.synchronize()
+    for k in ("actions", "mu", "sigma", "logp", "values"):
+        assert torch.equal(a[k], b[k]), k
+    assert torch.equal(so[:, :705], obs.to(torch.bfloat16)) and torch.equal(sp[:, :219], priv.to(torch.bfloat16))
+    assert float(so[:, 705:].float().abs().max()) == 0.0 and float(sp[:, 219:].float().abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("S,B", [(700, 333), (5000, 4096), (61440, 61440)])
+def test_update_from_the_bf16_shadow_equals_update_from_fp32_rows(S, B):
+    """hgym_ppo_grad with HgymBatch.obs_bf16 / priv_bf16 (first layer gathers 2-byte elements, the weight-gradient kernel
+    gathers its first-layer operand from the same shadow by index, no operand copy is written) against the same call on the
+    fp32 rows (gather + convert + X0 copy): the shadow holds exactly the bf16 the other path forms on the fly, every product
+    sees the same operands in the same order -- the gradients are bit-identical.  Ragged batches and the BASELINE minibatch."""
+    from hgym import make_ppo_config, make_batch
+    g = torch.Generator().manual_seed(S + B)
+    p = P.Params.random(705, 219, 12, K.ACTOR_HIDDEN, K.CRITIC_HIDDEN, g)
+    net = _net("bf16", max(B, 512))
+    net.load_state_dict(dict(zip(NAMES, p.tensors())))
+    dev = "cuda"
+    gd = torch.Generator(device=dev).manual_seed(S)
+    obs, priv = torch.randn(S, 705, device=dev, generator=gd).clamp_(-18, 18), torch.randn(S, 219, device=dev, generator=gd).clamp_(-18, 18)
+    act, mu_o = torch.randn(S, 12, device=dev, generator=gd), torch.randn(S, 12, device=dev, generator=gd) * 0.3
+    sg_o = torch.rand(S, 12, device=dev, generator=gd) * 0.5 + 0.75
+    val, adv, ret = (torch.randn(S, device=dev, generator=gd) for _ in range(3))
+    lp_o = -12.0 + torch.randn(S, device=dev, generator=gd)
+    idx = torch.randperm(S, device=dev, generator=gd)[:B].contiguous()
+    so = torch.zeros(S, 768, dtype=torch.bfloat16, device=dev)
+    sp = torch.zeros(S, 256, dtype=torch.bfloat16, device=dev)
+    so[:, :705] = obs.to(torch.bfloat16)
+    sp[:, :219] = priv.to(torch.bfloat16)
+    cols = (obs, priv, act, val, adv, ret, lp_o, mu_o, sg_o, idx)
+    net.ppo_grad(make_ppo_config(), make_batch(*cols))
+    torch.cuda.synchronize()
+    want, want_opt = net.grads_ext.clone(), net.opt_state.clone()
+    net.grads_ext.zero_()
+    net.opt_state[2:10] = 0.0
+    net.ppo_grad(make_ppo_config(), make_batch(*cols, obs_bf16=so, priv_bf16=sp))
+    torch.cuda.synchronize()
+    assert torch.equal(net.grads_ext, want)
+    assert torch.equal(net.opt_state[2:9], want_opt[2:9])          # loss sums, KL, counters
+    # the squared gradient norm is accumulated with fp64 atomics across workgroups: order-dependent in the last bits
+    np.testing.assert_allclose(float(net.opt_state[9]), float(want_opt[9]), rtol=1e-12)
+    # ... and in two halves (the data-parallel update's buckets)
+    net.grads_ext.zero_()
+    for part in (0, 1):
+        net.ppo_grad_part(make_ppo_config(), make_batch(*cols, obs_bf16=so, priv_bf16=sp), part)
+    torch.cuda.synchronize()
+    assert torch.equal(net.grads_ext, want)
+
+
+def test_runner_update_reads_the_shadow_the_rollout_wrote(monkeypatch):
+    """End to end: two learning iterations with the shadow (default) and without (HGYM_SHADOW=0) from the same seeds end in
+    bit-identical parameters, and the shadow slots hold the bf16 of the stored observation rows."""
+    from humanoid.algo import PPO
+    PPO.precision = "bf16"
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("HGYM_SHADOW", mode)
+        torch.manual_seed(5)
+        np.random.seed(5)
+        r = _runner(512, 23)
+        r.learn(num_learning_iterations=3, init_at_random_ep_len=True)
+        torch.cuda.synchronize()
+        st = r.alg.storage
+        assert (st._obs_bf16 is not None) == (mode == "1")
+        if mode == "1":
+            # slot 0 was rewritten by storage.clear() after its launch; the others still hold what their launches read
+            assert torch.equal(st._obs_bf16[1:, :, :705], st.observations[1:].to(torch.bfloat16))
+            assert torch.equal(st._priv_bf16[1:, :, :219], st.privileged_observations[1:].to(torch.bfloat16))
+        outs[mode] = r.alg.net.params.clone()
+        del r
+    assert torch.equal(outs["1"], outs["0"])

@@ -43,7 +43,13 @@ if os.environ.get('HGYM_SORT'):
 if os.environ.get('HGYM_IDX0'):
     idx = torch.randint(0, 64, (S,), device=dev)   # every gather hits L2: isolates the input-latency share of mlp_fwd
 ppo = make_ppo_config(grad_norm_ready=True)      # what PPO.update passes on one rank
-batch = make_batch(obs, priv, act, val, adv, ret, lp_o, mu_o, sg_o, idx)
+shadow = {}
+if os.environ.get('HGYM_BU_SHADOW', '1') != '0' and net.shadow_ld(0) > 0:      # bf16 shadows of the storage rows (what the rollout leaves behind)
+    so = torch.zeros(S, net.shadow_ld(0), dtype=torch.bfloat16, device=dev); so[:, :705] = obs.to(torch.bfloat16)
+    sp = torch.zeros(S, net.shadow_ld(1), dtype=torch.bfloat16, device=dev); sp[:, :219] = priv.to(torch.bfloat16)
+    shadow = dict(obs_bf16=so, priv_bf16=sp)
+print("shadow:", bool(shadow))
+batch = make_batch(obs, priv, act, val, adv, ret, lp_o, mu_o, sg_o, idx, **shadow)
 names = {0: "gemm(all)", 3: "loss", 4: "mlp_fwd", 5: "mlp_bwd", 6: "dw", 7: "reduce", 8: "apply", 9: "policy"}
 def step():
     net.ppo_grad(ppo, batch); net.ppo_apply(ppo)

@@ -1,7 +1,7 @@
 """rocprofv3 counter_collection.csv (FETCH_SIZE pass, WRITE_SIZE pass) -> profiles/pmc_traffic.json: HBM bytes per launch per kernel.
 Correction (MI355X_MICROARCH.md §HBM): on gfx950 FETCH_SIZE counts 64 B per 128-B request for wide coalesced streams; the
 factor is calibrated here on a device-to-device copy of known size collected in the same pass (kernel name contains 'copy')."""
-import csv, json, re, sys
+import csv, json, os, re, sys
 from collections import defaultdict
 
 
@@ -39,8 +39,19 @@ def main(fetch_csv, write_csv, out, copy_bytes):
                 w = W[k]["WRITE_SIZE"][0] / max(W[k]["WRITE_SIZE"][1], 1) * 1024
                 res[nm] = dict(fetch_raw=f, write_raw=w, fetch_bytes=f * (cal_f or 1.0), write_bytes=w * (cal_w or 1.0),
                                hbm_bytes=f * (cal_f or 1.0) + w * (cal_w or 1.0), launches=cs["FETCH_SIZE"][1])
+    import datetime, subprocess
+    def sh(cmd):
+        try:
+            return subprocess.run(cmd, shell=True, capture_output=True, text=True, timeout=20).stdout.strip()
+        except Exception:
+            return ""
+    prov = dict(collected_utc=datetime.datetime.utcnow().strftime("%Y-%m-%dT%H:%M:%SZ"),
+                git_head=sh("git -C %s rev-parse --short HEAD" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))) or
+                         "(no .git on the GPU box: stamped by tools/stamp_traffic.py when the file is committed)",
+                gpu=sh("rocm-smi --showproductname 2>/dev/null | grep -m1 'Card Series' | sed 's/.*: *//'") or sh("rocminfo | grep -m1 'Marketing Name' | sed 's/.*: *//'"),
+                workload="tools/traffic_run.py: bench.py --steps 2 --warmup 2 (4096 envs, bf16), averaged per kernel over all its launches")
     json.dump(dict(note="HBM bytes per launch: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), scaled by the factor that makes a "
-                        "device copy of known size read right", fetch_calibration=cal_f, write_calibration=cal_w,
+                        "device copy of known size read right", provenance=prov, fetch_calibration=cal_f, write_calibration=cal_w,
                    kernels={k: v["hbm_bytes"] for k, v in res.items()}, detail=res), open(out, "w"), indent=1)
     print(json.dumps(dict(cal_f=cal_f, cal_w=cal_w, kernels={k: round(v["hbm_bytes"] / 1e6, 2) for k, v in res.items()})))
 

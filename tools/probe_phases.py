@@ -21,7 +21,13 @@ val, adv, ret = torch.randn(S, device=dev), torch.randn(S, device=dev), torch.ra
 lp_o = -12.0 + torch.randn(S, device=dev)
 idx = torch.randperm(S, device=dev).contiguous()
 ppo = make_ppo_config()
-batch = make_batch(obs, priv, act, val, adv, ret, lp_o, mu_o, sg_o, idx)
+shadow = {}
+if os.environ.get('HGYM_BU_SHADOW', '1') != '0' and net.shadow_ld(0) > 0:
+    so = torch.zeros(S, net.shadow_ld(0), dtype=torch.bfloat16, device=dev); so[:, :705] = obs.to(torch.bfloat16)
+    sp = torch.zeros(S, net.shadow_ld(1), dtype=torch.bfloat16, device=dev); sp[:, :219] = priv.to(torch.bfloat16)
+    shadow = dict(obs_bf16=so, priv_bf16=sp)
+print("shadow:", bool(shadow))
+batch = make_batch(obs, priv, act, val, adv, ret, lp_o, mu_o, sg_o, idx, **shadow)
 for _ in range(3):
     net.ppo_grad(ppo, batch)
 torch.cuda.synchronize()
