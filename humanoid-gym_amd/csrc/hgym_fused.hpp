@@ -1101,7 +1101,6 @@ struct DwArgs {
     int64_t slab_stride;   // floats
     const char* zeros;     // >= 1 KiB of zeros (workspace): source of the stages past the end of a split
     int B;                 // valid batch rows (gathered products clamp their row indices to it)
-    int gather;            // any product gathers: the launch carries steps_per_split * 32 row indices of LDS behind the two stages
     int scal_bid;          // >= 0: this workgroup sums the minibatch's loss partials instead (ppo_scalars_block); -1: none
     ScalArgs sc;
 };
@@ -1169,23 +1168,14 @@ __global__ __launch_bounds__(DW_THREADS, 2) void dw_kernel_rs(const DwArgs a) {
     const int lofs = lane * 16;
     // Gathered X operand (first-layer products on the bf16 shadow): the lane that holds bytes [16 l, 16 l + 16) of a piece holds
     // row (l & 31) >> 1 of the row block, block l >> 5 of the pair, half l & 1 -- in the row-major shadow that is 16 bytes of row
-    // gidx[m].  The split's row indices are copied to LDS once (int32) so that the steady state reads them with a ds_read: a
-    // global load of the index in front of every stage would sit in the wave's in-order return queue ahead of the stage's data.
-    const bool gx = a.gather && op && P.gidx != nullptr;              // wave-uniform
-    int* lidx = reinterpret_cast<int*>(smem + (a.gather ? 2 * DW_STAGE_BYTES : 0));
-    if (a.gather) {
-        if (P.gidx) {
-            const int rows = nsteps * 32;
-            for (int i = tid; i < rows; i += DW_THREADS) {
-                int mrow = step0 * 32 + i;
-                mrow = mrow < a.B ? mrow : a.B - 1;
-                lidx[i] = (int)P.gidx[mrow];
-            }
-        }
-        __syncthreads();
-    }
+    // gidx[m].  The 16 row indices of a stage are one 128-byte load (lane l: row l & 15, replicated over the wave) issued TWO stages
+    // ahead of the stage's data and in front of the data loads of the stage issued with it: a wave's loads return in order, so
+    // when the index is needed only the two younger stages (and the next index) are behind it -- the data ring keeps its depth.
+    // Every wave issues the index load (from the zero page when it has nothing to gather): one instruction stream, exact vmcnt.
+    const bool gx = op && P.gidx != nullptr;                          // wave-uniform
     const int64_t ldgb = P.ldg * 2;
-    const int grow = mbl * 16 + ((lane & 31) >> 1);                   // row of the 32-row step this lane fetches
+    const int irow = mbl * 16 + (lane & 15);                          // row of the 32-row step whose index this lane fetches
+    const int bsrc = ((lane & 31) >> 1) * 4;                          // ds_bpermute address: the lane that holds this lane's row
     int64_t gcol[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -1193,16 +1183,31 @@ __global__ __launch_bounds__(DW_THREADS, 2) void dw_kernel_rs(const DwArgs a) {
         cb = cb + 1 < P.CBx ? cb : P.CBx - 2;
         gcol[j] = ((int64_t)(cb + (lane >> 5)) * 16 + (lane & 1) * 8) * 2;
     }
+    const int64_t* ibase = gx ? P.gidx : reinterpret_cast<const int64_t*>(a.zeros);
+    const int mg0 = gx ? -1 : 0;
+    auto load_idx = [&](int t) -> int {
+        int mrow = (step0 + (t < nsteps ? t : nsteps - 1)) * 32 + irow;
+        mrow = mrow < a.B ? mrow : a.B - 1;
+        // the low word only (indices are < 2^31): the dead upper half of an 8-byte load is a register the allocator hands out
+        // again at once, and overwriting it has to wait for the load -- i.e. for every older load of the ring
+        return reinterpret_cast<const int*>(ibase)[2 * ((mrow & mg0) | ((lane & 15) & ~mg0))];
+    };
+    // index ring: slot t % DW_RS holds the indices of stage t (a compile-time slot in the unrolled loop: rotating two registers
+    // instead costs a move of a just-loaded value, i.e. a wait that drains the data ring once per revolution)
+    static_assert(DW_RS >= 3, "the index of stage t + 2 is loaded into the slot stage t - 1 has left");
+    int GI[DW_RS];
+    GI[0] = load_idx(0);
+    GI[1] = load_idx(1);
     u32x4 R[DW_RS][4];
-    auto load = [&](int t, u32x4 (&rr)[4]) {
-        const bool in = t < nsteps;
-        const int tc = in ? t : nsteps - 1;
-        // unconditional LDS read (unused unless gx; a launch without gathered products has no index region: word 0 of the stages)
-        const int64_t rofs = (int64_t)lidx[a.gather ? tc * 32 + grow : 0] * ldgb;
+    auto load = [&](int t, int slot, u32x4 (&rr)[4]) {                // slot == t % DW_RS
+        const int64_t m = t < nsteps ? -1 : 0;                        // all-ones / zero: branch-free selects of the byte offset (a
+        const int64_t mg = gx ? -1 : 0;                               // branch here makes the compiler's vmcnt placement drain the ring)
+        GI[(slot + 2) % DW_RS] = load_idx(t + 2);                     // issued BEFORE this stage's data
+        const int64_t rofs = (int64_t)__builtin_amdgcn_ds_bpermute(bsrc, GI[slot]) * ldgb;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int64_t lin = gofs[j] + (int64_t)t * gstep + lofs, gat = rofs + gcol[j];
-            const int64_t o = in ? (gx ? gat : lin) : zofs + lofs;    // stages past the end of the split: the zero page
+            const int64_t o = ((((gat & mg) | (lin & ~mg))) & m) | ((zofs + lofs) & ~m);    // past the end of the split: the zero page
             rr[j] = *reinterpret_cast<const u32x4*>(gbase + o);
         }
     };
@@ -1224,7 +1229,7 @@ __global__ __launch_bounds__(DW_THREADS, 2) void dw_kernel_rs(const DwArgs a) {
     const u32x4 ones = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
 
 #pragma unroll
-    for (int j = 0; j < DW_RS; ++j) load(j, R[j]);
+    for (int j = 0; j < DW_RS; ++j) load(j, j, R[j]);
     store(0, R[0]);
     __syncthreads();
     const int np = (nsteps + DW_RS - 1) / DW_RS * DW_RS;
@@ -1232,7 +1237,7 @@ __global__ __launch_bounds__(DW_THREADS, 2) void dw_kernel_rs(const DwArgs a) {
 #pragma unroll
         for (int j = 0; j < DW_RS; ++j) {
             const int t = t0 + j;
-            load(t + DW_RS, R[j]);                           // R[j] held stage t, which is in LDS already
+            load(t + DW_RS, j, R[j]);                        // R[j] held stage t, which is in LDS already
             __builtin_amdgcn_sched_barrier(0);
             const char* st = smem + (t & 1) * DW_STAGE_BYTES;
             u32x4 xa[4], zb[4];

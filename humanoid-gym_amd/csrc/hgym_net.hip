@@ -827,11 +827,6 @@ struct NetRunner {
     // rows, same columns -- and every bias gradient of it is a column sum of dZ: its loss has no per-tile partial sums for them)
     // gb (mlp_fb_kernel<XB16> ran): the first-layer operands were never copied -- those products gather their rows by gb->idx from the
     // bf16 shadows
-    static constexpr int DW_GATHER_MAX_IDX_BYTES = 48 * 1024;      // two 80 KB workgroups per CU: 32 KB of stages + the split's row indices
-    bool dw_gather_fits(int B) const {
-        const int steps = (int)round_up(B, 64) / 32;
-        return (int64_t)ceil_div(steps, w.dw_splits) * 32 * 4 <= DW_GATHER_MAX_IDX_BYTES;
-    }
     int32_t fused_dw(int first, int count, int B, const ScalArgs* sc = nullptr, const HgymBatch* gb = nullptr) {
         const int Bp = (int)round_up(B, 64);
         DwArgs d;
@@ -854,7 +849,6 @@ struct NetRunner {
                     p.gidx = gb->idx;
                     p.ldg = shadow_ld(i == 1 ? 1 : 0);
                     p.CBx = (int)(p.ldg / 16);
-                    d.gather = 1;
                 }
                 p.N = y.N;
                 p.K = y.K;
@@ -879,13 +873,8 @@ struct NetRunner {
             d.sc = *sc;
             d.scal_bid = blocks++;
         }
-        const size_t lds = 2 * DW_STAGE_BYTES + (d.gather ? (size_t)d.steps_per_split * 32 * 4 : 0);
-        if (lds > 64 * 1024) {
-            const int32_t rc_lds = ensure_dynamic_lds(reinterpret_cast<const void*>(&dw_kernel_rs<3>), lds, "dw_kernel_rs");
-            if (rc_lds) return rc_lds;
-        }
         prof_begin(HGYM_PROF_DW, s);
-        hipLaunchKernelGGL(dw_kernel_rs<3>, dim3(blocks), dim3(DW_THREADS), lds, s, d);
+        hipLaunchKernelGGL(dw_kernel_rs<3>, dim3(blocks), dim3(DW_THREADS), 2 * DW_STAGE_BYTES, s, d);
         prof_end(HGYM_PROF_DW, s, fl);
         HG_CHECK_LAUNCH("dw_kernel_rs");
         return HGYM_OK;
@@ -916,12 +905,9 @@ struct NetRunner {
         const int B = b.B, A = cfg.num_actions;
         const int64_t critic_off = w.net[1].layer[0].w_off;
         const bool aux_fb = w.nnets > 2 && w.fused_aux;      // the auxiliary head as a third grid row of the same launches
-        // batch splits of the weight-gradient contraction: one per XCD up to ~100 k rows, two beyond (8192 envs per GPU: 122 880-row
-        // minibatches -- twice the slab traffic, which is then half as large a share, and a split's row indices fit LDS again)
-        w.dw_splits = B > 98304 ? 16 : 8;
         // bf16 shadows of the storage rows (HgymBatch.obs_bf16 / priv_bf16): gather 2 B per element, keep no operand copy
         static const bool no_shadow = getenv("HGYM_NO_SHADOW") != nullptr;       // A/B experiments only
-        const bool shadow = b.obs_bf16 && b.priv_bf16 && !no_shadow && dw_gather_fits(B);
+        const bool shadow = b.obs_bf16 && b.priv_bf16 && !no_shadow;
         const HgymBatch* gb = shadow ? &b : nullptr;
         if (part == 1) {
             int32_t rc1 = fused_dw(1, aux_fb ? 2 : 1, B, nullptr, gb);
