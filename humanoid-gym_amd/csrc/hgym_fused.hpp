@@ -434,10 +434,14 @@ struct FwdNoop {
 };
 
 template <int BM, int NW, int D, int G1, bool WIDE = false, bool XB16 = false, class Early = FwdNoop, class Mid = FwdNoop, class Put = FwdNoop,
-          class Extra = int, class Idle = FwdNoop, class Head = FwdNoop>
+          class Extra = int, class Idle = FwdNoop, class Head = FwdNoop, class L2Idle = FwdNoop>
 __device__ __forceinline__ void fwd_body(const FwdArgs& a, const FusedNet& n, bool is_actor, char* smem, Early&& hook_early = Early(),
                                          Mid&& hook_mid = Mid(), Put&& hook_put = Put(), const Extra& extra = Extra(),
-                                         Idle&& hook_idle = Idle(), Head&& hook_head = Head(), char* h2_lds = nullptr) {
+                                         Idle&& hook_idle = Idle(), Head&& hook_head = Head(), char* h2_lds = nullptr,
+                                         int* rowidx_lds = nullptr, L2Idle&& hook_l2idle = L2Idle()) {
+    // rowidx_lds (BM ints of LDS): receives the storage row of every tile row (a.idx gathered once, by the lanes that stage the
+    // input) for whoever needs it later in the tile; hook_l2idle(extra): runs on the wavefronts that have no strip in the third
+    // layer while the others compute it (the fused forward + backward kernel gathers its loss inputs there).
     constexpr int MB = BM / 16;
     constexpr int IT = BM * 32 / (NW * 64);           // staging items per thread per chunk (BM rows x 32 float4)
     constexpr int RPP = NW * 2;                       // rows covered per staging pass (32 lanes per row)
@@ -506,6 +510,7 @@ __device__ __forceinline__ void fwd_body(const FwdArgs& a, const FusedNet& n, bo
         m = m < a.M ? m : a.M - 1;
         const int64_t src = a.idx ? a.idx[m] : (int64_t)m;
         const char* srow = reinterpret_cast<const char*>(n.xb + src * n.ldxb + cb * 16 + hf * 8);
+        if (rowidx_lds && cb == 0 && hf == 0) rowidx_lds[row] = (int)src;
         const int loff = ((row >> 4) * 8 + cb) * 512 + (row & 15) * 32 + hf * 16;
         u32x4 stg;
         auto stage_load = [&](int c) { stg = ld_stream_u4<(HGYM_NT & 1) != 0>(srow + c * (FUSED_CHUNK * 2)); };
@@ -547,6 +552,7 @@ __device__ __forceinline__ void fwd_body(const FwdArgs& a, const FusedNet& n, bo
             const int64_t src = a.idx ? a.idx[m] : (int64_t)m;
             srow[u] = n.x + src * n.ldx;
             lrow[u] = row;
+            if (rowidx_lds && f4 == 0) rowidx_lds[row] = (int)src;
         }
         F4 stg[IT];
         // one unconditional 16-byte load per item: the address is clamped to the last full vector of the row.  stage_load
@@ -627,6 +633,7 @@ __device__ __forceinline__ void fwd_body(const FwdArgs& a, const FusedNet& n, bo
         if (wave < MB) wring_prime<1, 4>(r3, L3.Wf + lane, 0, L3.KB);
     };
     hidden_layer<GH, MB, NW, D, AHEAD>(r2, L2, bl + L0.N + L1.N, Q, L1.NB, PH2, train_h ? n.H[2] : nullptr, mbg0, wave, lane, prime3);
+    if (wave * GH >= L2.NB) hook_l2idle(extra);       // wavefronts without a strip in this layer
     __syncthreads();
     phase_stamp(a.dbg, 5);
     if (!AHEAD) prime3();
@@ -812,7 +819,14 @@ struct FbLoss {
 // LDS of the fused kernel behind the forward's P / Q / bias regions: the dZ3 tile (64 rows x 32 * layer[3].NBB bf16 columns), the
 // head waves' partial sums, and H2 (64 x layer[2].N bf16) -- the forward writes it there instead of over H0, so that all three
 // activations are resident for the dZ chain
-HG_HD int fb_lds_extra(const FusedNet& n) { return 64 * 64 * n.layer[3].NBB + 4 * 32 * 4 + 64 * n.layer[2].N * 2; }
+#ifndef HGYM_FB_PRE
+#define HGYM_FB_PRE 1      // 0: the head wavefronts gather their loss inputs themselves (A/B builds)
+#endif
+// ... and, behind H2, the storage row of each of the tile's 64 rows (256 B) and the loss inputs gathered through them: actor 64 x
+// [actions 12 | old mu 12 | old sigma 12 | advantage | old log-prob | pad 2] floats, critic 64 x [return | old value]
+constexpr int FB_LIN_ACTOR = 40;      // floats per row
+HG_HD int fb_lds_lin(const FusedNet& n) { return n.layer[3].N == 1 ? 64 * 2 * 4 : (n.layer[3].N <= 12 ? 64 * FB_LIN_ACTOR * 4 : 0); }
+HG_HD int fb_lds_extra(const FusedNet& n) { return 64 * 64 * n.layer[3].NBB + 4 * 32 * 4 + 64 * n.layer[2].N * 2 + 256 + fb_lds_lin(n); }
 
 template <int G1, bool AUX = false, bool XB16 = false>
 __device__ __forceinline__ void fb_body(const FwdArgs& a, const FbLoss& L, const FusedNet& n, bool is_actor, char* smem) {
@@ -827,7 +841,13 @@ __device__ __forceinline__ void fb_body(const FwdArgs& a, const FbLoss& L, const
     const int NBB3 = n.layer[3].NBB, CB3 = 2 * NBB3;      // the head gradient's column blocks of 16 (padded to the backward's k-steps of 32)
     float* red = reinterpret_cast<float*>(R0 + BM * 64 * NBB3);
     char* H2 = R0 + BM * 64 * NBB3 + 4 * 32 * 4;
+    int* rowidx = reinterpret_cast<int*>(H2 + BM * n.layer[2].N * 2);
+    float* lin = reinterpret_cast<float*>(rowidx + BM);
     const int A = a.A;
+    // The loss inputs of the tile's rows (scattered 48-byte rows and scalars of the storage) are gathered into LDS by the eight
+    // wavefronts that have no strip in the 128-wide third layer, while the other eight compute it: the head wavefronts used to
+    // start with two dependent round trips (a.idx[m], then the rows) -- 5 of an actor tile's 47 us.
+    const bool pre = HGYM_FB_PRE && !AUX && n.layer[2].NB <= 8 && (is_actor ? A == 12 : true);
     const float invB = 1.0f / (float)a.M;
     float aux_se = 0.0f;
     // auxiliary head: lane (r, q) of head wave hw, row m, outputs nb * 16 + 4q .. + 3 (called once per column block).
@@ -835,7 +855,7 @@ __device__ __forceinline__ void fb_body(const FwdArgs& a, const FbLoss& L, const
     auto head_aux = [&](int hw, int m, int nb, const float (&out)[4]) {
         const int No = n.layer[3].N;
         const bool valid = m < a.M;
-        const int64_t row = a.idx ? a.idx[valid ? m : a.M - 1] : (int64_t)(valid ? m : a.M - 1);
+        const int64_t row = rowidx[hw * 16 + r];
         const float* t = L.aux_target + row * L.aux_ldt + L.aux_off;
         const float gs = 2.0f * L.aux_coef / ((float)a.M * (float)No);
         float g[4];
@@ -863,18 +883,52 @@ __device__ __forceinline__ void fb_body(const FwdArgs& a, const FbLoss& L, const
             }
         }
     };
+    auto l2idle = [&](int) {
+        if (!pre) return;
+        const int j = tid - 8 * 64;                 // 0 .. 511 (wavefronts 8 .. 15)
+        if (j < 0) return;
+        if (is_actor) {
+            // round 1: (row, quad k): actions 0..2, old mu 3..5, old sigma 6..7; round 2: old sigma quad 2, advantage, old log-prob.
+            // Every load is issued before the first LDS write.
+            const int rw = j >> 3, k = j & 7;
+            const int64_t ri = rowidx[rw];
+            const float* base = k < 3 ? L.actions : (k < 6 ? L.old_mu : L.old_sigma);
+            const F4 v1 = *reinterpret_cast<const F4*>(base + ri * 12 + 4 * (k < 3 ? k : (k < 6 ? k - 3 : k - 6)));
+            // (unconditional loads, conditional stores: a conditionally initialised vector ends up in private memory)
+            const int rw2 = j & 63;
+            const int64_t ri2 = rowidx[rw2];
+            const F4 v2 = *reinterpret_cast<const F4*>(L.old_sigma + ri2 * 12 + 8);
+            const float s2 = (j < 128 ? L.advantages : L.logp)[ri2];
+            *reinterpret_cast<F4*>(lin + rw * FB_LIN_ACTOR + 4 * k) = v1;
+            if (j < 64) *reinterpret_cast<F4*>(lin + rw2 * FB_LIN_ACTOR + 32) = v2;
+            else if (j < 192) lin[rw2 * FB_LIN_ACTOR + (j < 128 ? 36 : 37)] = s2;
+        } else if (j < 128) {
+            const int rw = j & 63;
+            const int64_t ri = rowidx[rw];
+            lin[rw * 2 + (j >> 6)] = j < 64 ? L.returns[ri] : L.values[ri];
+        }
+    };
     auto head = [&](int hw, int m, int, const float (&out)[4]) {
         // lane (r, q) of head wave hw: row m, head outputs 4q .. 4q + 3.  ppo.py:128-168 forward scalars + the hand-written
         // backward of the loss w.r.t. mu, std and V (oracle/ppo_oracle.py: ppo_loss_and_grads), as in ppo_loss_kernel
         const bool valid = m < a.M;
-        const int64_t row = a.idx ? a.idx[valid ? m : a.M - 1] : (int64_t)(valid ? m : a.M - 1);
+        const int rl = hw * 16 + r;                 // row of the tile
+        const int64_t row = rowidx[rl];
         float g[4] = {0.f, 0.f, 0.f, 0.f};
         float part[11];
 #pragma unroll
         for (int k = 0; k < 11; ++k) part[k] = 0.0f;
         if (is_actor) {
             float act[4] = {0.f, 0.f, 0.f, 0.f}, mo[4] = {0.f, 0.f, 0.f, 0.f}, so[4] = {1.f, 1.f, 1.f, 1.f}, sg[4] = {1.f, 1.f, 1.f, 1.f};
-            if (4 * q + 3 < A) {
+            if (pre) {
+                if (q < 3) {
+                    const F4 qa = *reinterpret_cast<const F4*>(lin + rl * FB_LIN_ACTOR + 4 * q);
+                    const F4 qo = *reinterpret_cast<const F4*>(lin + rl * FB_LIN_ACTOR + 12 + 4 * q);
+                    const F4 qs = *reinterpret_cast<const F4*>(lin + rl * FB_LIN_ACTOR + 24 + 4 * q);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { act[e] = qa.v[e]; mo[e] = qo.v[e]; so[e] = qs.v[e]; }
+                }
+            } else if (4 * q + 3 < A) {
                 const F4 qa = *reinterpret_cast<const F4*>(L.actions + row * A + 4 * q);
                 const F4 qo = *reinterpret_cast<const F4*>(L.old_mu + row * A + 4 * q);
                 const F4 qs = *reinterpret_cast<const F4*>(L.old_sigma + row * A + 4 * q);
@@ -885,7 +939,7 @@ __device__ __forceinline__ void fb_body(const FwdArgs& a, const FbLoss& L, const
                 for (int e = 0; e < 4; ++e)
                     if (4 * q + e < A) { act[e] = L.actions[row * A + 4 * q + e]; mo[e] = L.old_mu[row * A + 4 * q + e]; so[e] = L.old_sigma[row * A + 4 * q + e]; }
             }
-            const float adv = L.advantages[row], lpold = L.logp[row];
+            const float adv = pre ? lin[rl * FB_LIN_ACTOR + 36] : L.advantages[row], lpold = pre ? lin[rl * FB_LIN_ACTOR + 37] : L.logp[row];
             float lp = 0.0f, ent = 0.0f, kl = 0.0f, diff[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -922,7 +976,7 @@ __device__ __forceinline__ void fb_body(const FwdArgs& a, const FbLoss& L, const
                     }
             }
         } else {
-            const float ret = L.returns[row], vold = L.values[row];
+            const float ret = pre ? lin[rl * 2] : L.returns[row], vold = pre ? lin[rl * 2 + 1] : L.values[row];
             const float v = out[0];
             const float vc = vold + clampf(v - vold, -L.clip, L.clip);
             const float l1 = (v - ret) * (v - ret), l2 = (vc - ret) * (vc - ret);
@@ -964,14 +1018,14 @@ __device__ __forceinline__ void fb_body(const FwdArgs& a, const FbLoss& L, const
         }
     };
     if constexpr (AUX) {
-        fwd_body<BM, NW, D, G1, true, XB16>(a, n, false, smem, FwdNoop(), FwdNoop(), FwdNoop(), 0, FwdNoop(), head_aux, H2);
+        fwd_body<BM, NW, D, G1, true, XB16>(a, n, false, smem, FwdNoop(), FwdNoop(), FwdNoop(), 0, FwdNoop(), head_aux, H2, rowidx);
         if (wave < MB) {
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) aux_se += __shfl_xor(aux_se, o, 64);
             if (lane == 0) red[wave * 32 + 29] = aux_se;
         }
     } else {
-        fwd_body<BM, NW, D, G1, false, XB16>(a, n, is_actor, smem, FwdNoop(), FwdNoop(), FwdNoop(), 0, FwdNoop(), head, H2);
+        fwd_body<BM, NW, D, G1, false, XB16>(a, n, is_actor, smem, FwdNoop(), FwdNoop(), FwdNoop(), 0, FwdNoop(), head, H2, rowidx, l2idle);
     }
     __syncthreads();          // dZ3 tile and the per-wave sums are in LDS; H0 sits in P, H1 in Q, H2 in its own buffer
     if (tid < 32) {

@@ -46,6 +46,9 @@
 #ifndef HGYM_RO_INTERLEAVE
 #define HGYM_RO_INTERLEAVE 1
 #endif
+#ifndef HGYM_RO_HIST_IDLE
+#define HGYM_RO_HIST_IDLE 1    // the older observation frames are stored by the six wavefronts idle during the head, under it (0: behind the tile)
+#endif
 #ifndef HGYM_RO_VARIANT
 #define HGYM_RO_VARIANT 0      // experiments only: 1 = policy tiles alone (no env work at all), 2 = env part without its early loads
 #endif
@@ -178,6 +181,11 @@ __global__ __launch_bounds__(RO_NT) void rollout_step_kernel(const FwdArgs f, co
 #if HGYM_RO_DRAWS_IDLE && HGYM_RO_VARIANT == 0 && !defined(HGYM_RO_NO_DRAWS)
         if (!draws_in) env_fill_draws<RO_E>(E, block, t - 128, RO_NT - 128, esm, csc0);
 #endif
+#if HGYM_RO_HIST_IDLE && HGYM_RO_VARIANT == 0
+        // these lanes' share of the 14 older frames (in registers since `mid`) -> the stacked rows of the next observation, while
+        // the two head wavefronts finish the tile: three quarters of that store phase leave the chain behind the tile
+        hist_store<15, HGYM_OBS_FRAME, RO_NIO>(E.out.obs, block * RO_E, RO_E, (int)(ring_step % 15), t, RO_NT, nullptr, E.cfg.clip_obs, hist_o);
+#endif
     };
     fwd_body<32, 8, 4, 2 * U, false>(f, f.net[0], true, smem, early, mid, put, e, idle);
     __syncthreads();                                // the tile's actions are in the env image; the policy buffers are dead
@@ -193,6 +201,9 @@ __global__ __launch_bounds__(RO_NT) void rollout_step_kernel(const FwdArgs f, co
     const EnvArgs& A = e;
     // the two older privileged frames (12 registers the policy tile could not spare): loaded here, stored behind the joints phase
     hist_load<3, HGYM_PRIV_FRAME, RO_NIP>(A.st.priv_ring, block * RO_E, RO_E, (int)(ring_step % 3), t, RO_NT, hist_p);
+#if HGYM_RO_HIST_IDLE && HGYM_RO_VARIANT == 0
+    if (t < 128)          // the head wavefronts' share; the others stored theirs under the head (idle hook)
+#endif
     hist_store<15, HGYM_OBS_FRAME, RO_NIO>(A.out.obs, block * RO_E, RO_E, (int)(ring_step % 15), t, RO_NT, nullptr, A.cfg.clip_obs, hist_o);
     stamp(1);
 #if HGYM_ENV_SPLIT

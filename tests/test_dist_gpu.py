@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, out_dir, backend="gloo"):
+def _worker(rank, world, port, out_dir, backend="gloo", num_envs=256, iters=4):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "humanoid-gym_amd"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -33,7 +33,7 @@ def _worker(rank, world, port, out_dir, backend="gloo"):
     PPO.precision = "bf16"
     from humanoid.envs import task_registry
     from humanoid.utils import get_args
-    args = get_args(["--task=humanoid_ppo", "--headless", "--num_envs", "256", "--seed", str(5 + rank), "--sim_device", dev,
+    args = get_args(["--task=humanoid_ppo", "--headless", "--num_envs", str(num_envs), "--seed", str(5 + rank), "--sim_device", dev,
                      "--rl_device", dev])
     env, _ = task_registry.make_env(name=args.task, args=args)
     runner, _ = task_registry.make_alg_runner(env=env, name=args.task, args=args, log_root=None)
@@ -41,7 +41,7 @@ def _worker(rank, world, port, out_dir, backend="gloo"):
     p_init = runner.alg.net.params.clone()
     friction, commands0, seed = env.env_frictions.clone().cpu(), env.commands.clone().cpu(), int(env._ncfg.seed)
     runner.alg.comm_timing = []
-    runner.learn(num_learning_iterations=4, init_at_random_ep_len=True)     # eager, capture + replay, replay, replay
+    runner.learn(num_learning_iterations=iters, init_at_random_ep_len=True)     # eager, capture + replay, replay, replay
     torch.cuda.synchronize()
     net = runner.alg.net
     torch.save(dict(p_init=p_init.cpu(), params=net.params.cpu(), lr=float(net.opt_state[0]), steps=float(net.opt_state[1]),
@@ -68,6 +68,24 @@ def test_two_ranks_one_gpu_stay_in_lockstep(tmp_path):
     assert not torch.equal(a["friction"], b["friction"]) and not torch.equal(a["commands0"], b["commands0"])
     # the gradient exchange ran as two buckets per minibatch (one event pair per minibatch: 4 iterations x 8)
     assert a["comm_events"] == 32 and 0 < a["split"] < a["P"]
+
+
+@pytest.mark.timeout(900)
+def test_eight_ranks_one_gpu_stay_in_lockstep(tmp_path):
+    """BASELINE configs[2]'s rank count (8 ranks, here 128 envs each sharing one GPU over gloo): after 3 iterations = 24 synchronised
+    Adam steps every rank holds bit-identical parameters and the same learning rate, from 8 different env shards; the 2 x 24
+    bucketed exchanges and the per-iteration advantage-statistics all-reduce complete on all ranks (no dead-lock with the
+    graph-captured rollout and the asynchronous iteration loop alive in 8 processes)."""
+    port = 30100 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(8, port, str(tmp_path), "gloo", 128, 3), nprocs=8, join=True)
+    r = [torch.load(os.path.join(str(tmp_path), "r%d.pt" % i)) for i in range(8)]
+    assert torch.isfinite(r[0]["params"]).all() and not torch.equal(r[0]["params"], r[0]["p_init"])
+    for i in range(1, 8):
+        assert torch.equal(r[i]["p_init"], r[0]["p_init"]) and torch.equal(r[i]["params"], r[0]["params"]), i
+        assert r[i]["lr"] == r[0]["lr"] and r[i]["steps"] == 24 and r[i]["graph"]
+        assert not torch.equal(r[i]["obs"], r[0]["obs"]) and r[i]["env_seed"] != r[0]["env_seed"]
+        assert r[i]["comm_events"] == 24
+    assert len({x["env_seed"] for x in r}) == 8
 
 
 @pytest.mark.timeout(600)
