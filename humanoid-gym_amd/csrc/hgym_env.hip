@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void env_step_kernel(const EnvArgs A) {
     constexpr int NIP = kPrefetch ? hist_ni<HCP, HGYM_PRIV_FRAME, EP, NTH>() : 0;
     float hist_o[NIO > 0 ? NIO : 1][4], hist_p[NIP > 0 ? NIP : 1][4];
     const StackGeom geom = stack_geom<H_T, HC_T, E_T>(A, blockIdx.x);
-    const bool stack_on = A.mode != MODE_RESET_ALL && !(A.ablate & 8);
+    const bool stack_on = A.mode != MODE_RESET_ALL && !(A.ablate & 8) && A.phase != 1;      // a derive launch writes no observations
 #if HGYM_ENV_STAGE_FIRST
     // the state / sim loads need nothing but the block index: issued first, they travel while the ring-step counter -- which the
     // history addresses wait for -- is still on its way; their LDS writes follow the history loads' issue
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void env_step_kernel(const EnvArgs A) {
             hist_store<HCP, HGYM_PRIV_FRAME, NIP>(A.out.priv_obs, geom.e0, geom.nE, (int)(ring_step % HCP), t - 64, NTH, nullptr, A.cfg.clip_obs,
                                                   hist_p);
         }
-    } else if (!(A.ablate & 8)) {
+    } else if (!(A.ablate & 8) && A.phase != 1) {
         env_step_stack_old<H_T, HC_T, E_T>(A, blockIdx.x, t - 64, blockDim.x - 64, ring_step);
     }
     __syncthreads();
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void env_step_kernel(const EnvArgs A) {
         __syncthreads();
     }
     if (!(A.ablate & 4)) env_stage_out<E_T>(A, blockIdx.x, t, blockDim.x, smem);
-    if (!(A.ablate & 8)) env_step_phase_b<H_T, HC_T, E_T>(A, blockIdx.x, t, blockDim.x, smem, csc0, ring_step, false);
+    if (!(A.ablate & 8) && A.phase != 1) env_step_phase_b<H_T, HC_T, E_T>(A, blockIdx.x, t, blockDim.x, smem, csc0, ring_step, false);
     // postponed finaliser (HgymEnvOut.defer_finalize): the sampling step the NEXT policy launch reads is bumped here -- no policy
     // kernel is running now, and the finaliser will be one of that launch's workgroups
     if (A.out.defer_finalize && blockIdx.x == 0 && t == 0 && A.out.t_rewards && A.out.t_step) A.out.t_step[0] += 1;
@@ -206,9 +206,20 @@ static void launch_measure_heights(const EnvArgs& A, hipStream_t s) {
 }
 
 static int32_t launch_step(const HgymEnvConfig* cfg, const HgymSimTensors* sim, const HgymEnvState* st, const HgymEnvOut* out,
-                           const HgymEnvNoise* noise, float* actions_in, int mode, int fused, hipStream_t s) {
+                           const HgymEnvNoise* noise, float* actions_in, int mode, int fused, hipStream_t s, int phase = 0) {
     int32_t rc = check_common(cfg, sim, st);
     if (rc) return rc;
+    HG_REQUIRE(cfg->num_custom_rewards >= 0 && cfg->num_custom_rewards <= HGYM_MAX_CUSTOM_REWARDS, HGYM_E_SHAPE, "num_custom_rewards=%d",
+               cfg->num_custom_rewards);
+    if (cfg->num_custom_rewards > 0) {
+        HG_REQUIRE(mode != MODE_STEP || phase != 0, HGYM_E_BADARG,
+                   "user-defined reward terms need the two-launch step (hgym_env_step_begin / hgym_env_step_end)");
+        HG_REQUIRE(st->custom_rew && st->custom_sums && st->custom_acc && out->extras_custom, HGYM_E_BADARG,
+                   "user-defined reward terms need custom_rew / custom_sums / custom_acc / extras_custom");
+        for (int j = 0; j < cfg->num_custom_rewards; ++j)
+            HG_REQUIRE(cfg->custom_reward_pos[j] >= 0 && cfg->custom_reward_pos[j] <= HGYM_NUM_REWARDS, HGYM_E_SHAPE, "custom_reward_pos[%d]=%d",
+                       j, cfg->custom_reward_pos[j]);
+    }
     HG_REQUIRE(sim && out, HGYM_E_BADARG, "null sim/out");
     HG_REQUIRE(out->obs && out->priv_obs && out->rew && out->reset && out->time_out && out->extras_time_outs && out->extras_episode,
                HGYM_E_BADARG, "null output buffer");
@@ -224,6 +235,7 @@ static int32_t launch_step(const HgymEnvConfig* cfg, const HgymSimTensors* sim, 
     A.actions_in = actions_in;
     A.origins_hbm = st->env_origins;
     A.mode = mode;
+    A.phase = phase;
     A.fused = fused;
     A.envs_per_block = pick_envs_per_block(cfg->num_envs);
     static const int ablate = getenv("HGYM_ENV_ABLATE") ? atoi(getenv("HGYM_ENV_ABLATE")) : 0;   // profiling experiments only
@@ -241,7 +253,7 @@ static int32_t launch_step(const HgymEnvConfig* cfg, const HgymSimTensors* sim, 
     const bool std_stack = cfg->frame_stack == 15 && cfg->c_frame_stack == 3;
     // the generic LeggedRobot options (HgymEnvConfig tail) have their own instantiation: off, none of their code is compiled in
     const bool generic = cfg->custom_origins || cfg->terrain_curriculum || cfg->num_height_points > 0 || cfg->command_curriculum ||
-                         !cfg->heading_command;
+                         !cfg->heading_command || phase != 0 || cfg->num_custom_rewards > 0;
     if (std_stack && A.envs_per_block == 16 && !generic && mode == MODE_STEP && HGYM_ENV_SPLIT)
         hipLaunchKernelGGL((env_step_kernel<15, 3, 16, false, true>), dim3(blocks), dim3(256), lds, s, A);
     else if (std_stack && A.envs_per_block == 16 && !generic)
@@ -255,10 +267,11 @@ static int32_t launch_step(const HgymEnvConfig* cfg, const HgymSimTensors* sim, 
         prof_end(HGYM_PROF_ENV_STEP, s, (double)cfg->num_envs * (4.0 * (245 + (H - 1) * 47 + (HC - 1) * 73 + H * 47 + HC * 73) + 6));
     }
     HG_CHECK_LAUNCH("env_step_kernel");
-    if (cfg->num_height_points > 0 && mode == MODE_STEP) {
+    if (cfg->num_height_points > 0 && mode == MODE_STEP && phase != 2) {     // (a derive launch samples them: the caller's terms may read them)
         launch_measure_heights(A, s);
         HG_CHECK_LAUNCH("measure_heights_kernel");
     }
+    if (phase == 1) return HGYM_OK;                           // the step is finished by hgym_env_step_end
     if (cfg->command_curriculum && mode != MODE_PRIME) {     // before the finaliser consumes the episode-sum accumulators
         hipLaunchKernelGGL(command_curriculum_kernel, dim3(1), dim3(cfg->num_envs > 256 ? 1024 : 256), 0, s, A);
         HG_CHECK_LAUNCH("command_curriculum_kernel");
@@ -284,7 +297,7 @@ int32_t rollout_env_args(const HgymEnvConfig* cfg, const HgymSimTensors* sim, co
     HG_REQUIRE(out->t_rewards && out->t_values && out->t_dones && out->t_step && out->defer_finalize, HGYM_E_BADARG,
                "the fused rollout step stores the transition itself: transition sink + defer_finalize required");
     const bool generic = cfg->custom_origins || cfg->terrain_curriculum || cfg->num_height_points > 0 || cfg->command_curriculum ||
-                         !cfg->heading_command;
+                         !cfg->heading_command || cfg->num_custom_rewards > 0;
     HG_REQUIRE(!generic && !cfg->use_ref_actions && cfg->frame_stack == 15 && cfg->c_frame_stack == 3, HGYM_E_UNSUPPORTED,
                "fused rollout step: XBot-L default options only");
     HG_REQUIRE(cfg->num_envs % 32 == 0, HGYM_E_UNSUPPORTED, "fused rollout step: num_envs must be a multiple of 32");
@@ -406,6 +419,17 @@ int32_t hgym_env_step_synth(const HgymEnvConfig* cfg, const HgymSimTensors* sim,
                             float* actions_in, void* stream) {
     HG_REQUIRE(actions_in, HGYM_E_BADARG, "null actions");
     return launch_step(cfg, sim, st, out, nullptr, actions_in, MODE_STEP, 1, (hipStream_t)stream);
+}
+
+int32_t hgym_env_step_begin(const HgymEnvConfig* cfg, const HgymSimTensors* sim, const HgymEnvState* st, const HgymEnvOut* out,
+                            const HgymEnvNoise* noise, float* actions_in, void* stream) {
+    return launch_step(cfg, sim, st, out, noise, actions_in, MODE_STEP, actions_in ? 1 : 0, (hipStream_t)stream, 1);
+}
+
+int32_t hgym_env_step_end(const HgymEnvConfig* cfg, const HgymSimTensors* sim, const HgymEnvState* st, const HgymEnvOut* out,
+                          const HgymEnvNoise* noise, void* stream) {
+    HG_REQUIRE(out && !out->defer_finalize, HGYM_E_UNSUPPORTED, "the two-launch step runs its finaliser itself (defer_finalize must be 0)");
+    return launch_step(cfg, sim, st, out, noise, nullptr, MODE_STEP, 0, (hipStream_t)stream, 2);
 }
 
 int32_t hgym_measure_heights(const HgymEnvConfig* cfg, const HgymEnvState* st, void* stream) {

@@ -29,6 +29,10 @@ struct EnvArgs {
     float* origins_hbm;       // st.env_origins as the caller gave it (the LDS shadow replaces st.env_origins by its staged copy)
     int64_t* reset_count;     // where resetting envs count themselves for the step finaliser; null: &st.counters[1]
     int mode;
+    int phase;                // user-defined reward terms (cfg.num_custom_rewards > 0) split the step in two launches: 1 = derive (action
+                              // processing, physics, derived state, commands, pushes, termination flags -- what the reference has
+                              // done when compute_reward starts), 2 = finish (the reward sum with the caller's terms merged in,
+                              // reset, observations, tail); 0 = the whole step in one launch
     int fused;                // 1: pre_physics + synthetic physics run inside the step kernel
     int envs_per_block;
     int ablate;               // debug/profiling only: bit0 skip stage-in, bit1 skip phase A, bit2 skip stage-out, bit3 skip phase B,
@@ -488,7 +492,20 @@ HG_HD StepFlags post_physics_env(const EnvArgs& A, const RngKey& rk, int64_t csc
     }
     const float friction0 = FG(S.friction, 0), body_mass0 = FG(S.body_mass, 0);
 
+    const int phase = kGeneric ? A.phase : 0;
+    if (mode == MODE_STEP && phase == 2) {
+        // finish launch: the derive launch left the incremented episode length, the derived state, the (possibly resampled)
+        // commands and the pushes in the state / sim tensors; the termination flags are re-derived from the same inputs below
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            blv[i] = FG(S.base_lin_vel, i);
+            bav[i] = FG(S.base_ang_vel, i);
+            grav[i] = FG(S.projected_gravity, i);
+            eul[i] = FG(S.base_euler, i);
+        }
+    }
     if (mode == MODE_STEP) {
+      if (phase != 2) {
         ep += 1;                                                     // legged_robot.py:128
         // derived state :132-136
         const float gvec[3] = {0.0f, 0.0f, -1.0f};
@@ -538,13 +555,14 @@ HG_HD StepFlags post_physics_env(const EnvArgs& A, const RngKey& rk, int64_t csc
             sset(A.sim.root, e, 11, root[11]);
             sset(A.sim.root, e, 12, root[12]);
         }
+      }
         // check_termination :156-161
         {
             const float bx = bxyz[0], by = bxyz[1], bz = bxyz[2];
             const float bn = sqrtf(bx * bx + by * by + bz * bz);
             time_out = ep > (int64_t)c.max_episode_length;
             reset = (bn > 1.0f) || time_out;
-
+          if (phase != 1) {
             // ---------------- compute_reward :217-235, 22 terms in alphabetical order ----------------
             const float s = sinf(kTwoPi * gait_phase(c, ep));
             float stance[2];
@@ -704,14 +722,29 @@ HG_HD StepFlags post_physics_env(const EnvArgs& A, const RngKey& rk, int64_t csc
             // 21 vel_mismatch_exp :396-406
             term[21] = (r_exp(-(blv[2] * blv[2]) * 10.0f) + r_exp(-r_sqrt(bav[0] * bav[0] + bav[1] * bav[1]) * 5.0f)) / 2.0f;
 
+            // user-defined terms (legged_robot.py:518-541 discovers `_reward_<name>` by name; the caller evaluated them between the
+            // derive and the finish launch, already times scale * dt): merged into the sum at their place in the alphabetical order
+            // -- custom term j comes right before built-in term custom_reward_pos[j] (22: after all of them)
+            const int ncust = (kGeneric && phase == 2) ? c.num_custom_rewards : 0;
+            auto add_custom = [&](int k) {
+                for (int j = 0; j < ncust; ++j)
+                    if (c.custom_reward_pos[j] == k) {
+                        const float t = S.custom_rew[(int64_t)j * c.num_envs + ge];
+                        rew += t;
+                        S.custom_sums[(int64_t)j * c.num_envs + ge] += t;
+                    }
+            };
 #pragma unroll
             for (int k = 0; k < HGYM_NUM_REWARDS; ++k) {
+                if (kGeneric && ncust > 0) add_custom(k);
                 const float t = term[k] * c.reward_scales[k];
                 rew += t;
                 esum[k] += t;
                 FG(S.episode_sums, k) = esum[k];
             }
+            if (kGeneric && ncust > 0) add_custom(HGYM_NUM_REWARDS);
             if (c.only_positive_rewards) rew = fmaxf(rew, 0.0f);
+          }
         }
     } else {
         // PRIME / RESET_ALL: reset_idx(all); derived velocities keep their current values
@@ -733,6 +766,22 @@ HG_HD StepFlags post_physics_env(const EnvArgs& A, const RngKey& rk, int64_t csc
         reset = 1;
     }
 
+    if (kGeneric && mode == MODE_STEP && phase == 1) {
+        // derive launch: leave what compute_reward (and the caller's reward terms) will read, touch nothing else
+        S.episode_length[e] = ep;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) FG(S.commands, i) = cmd[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            FG(S.base_lin_vel, i) = blv[i];
+            FG(S.base_ang_vel, i) = bav[i];
+            FG(S.projected_gravity, i) = grav[i];
+            FG(S.base_euler, i) = eul[i];
+        }
+        A.out.reset[e] = (uint8_t)reset;
+        A.out.time_out[e] = (uint8_t)time_out;
+        return fl;
+    }
     // ---------------- reset_idx :163-215 (+ humanoid_env.py:264-269), mask-driven ----------------
     if (reset) {
         fl.reset = 1;
@@ -800,6 +849,13 @@ HG_HD StepFlags post_physics_env(const EnvArgs& A, const RngKey& rk, int64_t csc
         for (int k = 0; k < HGYM_NUM_REWARDS; ++k) {
             hg_atomic_add(&S.episode_acc[k], esum[k]);
             FG(S.episode_sums, k) = 0.0f;
+        }
+        if (kGeneric && c.num_custom_rewards > 0 && S.custom_sums) {
+            for (int j = 0; j < c.num_custom_rewards; ++j) {
+                float* cs = S.custom_sums + (int64_t)j * c.num_envs + ge;
+                hg_atomic_add(&S.custom_acc[j], *cs);
+                *cs = 0.0f;
+            }
         }
         if (kSplit) {       // the reset orientation is cfg.base_init_state's for every env: evaluated once per block (env_step_phase_j)
 #pragma unroll

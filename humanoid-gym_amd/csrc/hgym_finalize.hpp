@@ -24,6 +24,8 @@ struct FinArgs {
     int64_t* reset_count;    // envs that reset in the step being finalised: &counters[1], or the step's own slot when the finaliser
                              // runs concurrently with the NEXT step's env phase (rollout_step_kernel)
     float* episode_acc;      // HgymEnvState::episode_acc (same remark)
+    int ncustom;             // user-defined reward terms (HgymEnvConfig::num_custom_rewards)
+    float* custom_acc;       // HgymEnvState::custom_acc
     HgymEnvOut out;
 };
 
@@ -35,6 +37,8 @@ HG_HD FinArgs make_fin_args(const HgymEnvConfig& cfg, const HgymEnvState& st, co
     f.counters = st.counters;
     f.reset_count = st.counters + 1;
     f.episode_acc = st.episode_acc;
+    f.ncustom = (st.custom_acc && out.extras_custom) ? cfg.num_custom_rewards : 0;
+    f.custom_acc = st.custom_acc;
     f.out = out;
     return f;
 }
@@ -45,6 +49,10 @@ HG_HD void fin_part1(const FinArgs& F, int t, int nthreads) {
         if (t < HGYM_NUM_REWARDS) {
             F.out.extras_episode[t] = F.episode_acc[t] / (float)cnt / F.episode_length_s;
             F.episode_acc[t] = 0.0f;
+        }
+        if (t < F.ncustom) {
+            F.out.extras_custom[t] = F.custom_acc[t] / (float)cnt / F.episode_length_s;
+            F.custom_acc[t] = 0.0f;
         }
         for (int i = t; i < F.N; i += nthreads) F.out.extras_time_outs[i] = F.out.time_out[i];
     }

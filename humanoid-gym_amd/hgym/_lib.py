@@ -16,6 +16,7 @@ NUM_REWARDS = 22
 OBS_FRAME = 47
 PRIV_FRAME = 73
 MAX_LAYERS = 8
+MAX_CUSTOM_REWARDS = 8
 F32, BF16 = 0, 1
 
 c_float_p = C.POINTER(C.c_float)
@@ -54,6 +55,8 @@ class EnvConfig(C.Structure):
         ("terrain_border", C.c_float), ("terrain_hscale", C.c_float), ("terrain_vscale", C.c_float),
         ("cmd_yaw_lo", C.c_float), ("cmd_yaw_span", C.c_float),
         ("command_curriculum", C.c_int32), ("max_curriculum", C.c_float),
+        # user-defined reward terms
+        ("num_custom_rewards", C.c_int32), ("custom_reward_pos", C.c_int32 * MAX_CUSTOM_REWARDS),
     ]
 
 
@@ -79,14 +82,16 @@ class EnvState(C.Structure):
                 [("obs_ring", c_float_p), ("priv_ring", c_float_p), ("episode_acc", c_float_p),
                  ("terrain_levels", c_i64_p), ("terrain_types", c_i64_p), ("terrain_origins", c_float_p),
                  ("height_samples", C.POINTER(C.c_int16)), ("height_points", c_float_p), ("height_pose", c_float_p),
-                 ("measured_heights", c_float_p), ("command_range_x", c_f64_p)])
+                 ("measured_heights", c_float_p), ("command_range_x", c_f64_p),
+                 ("custom_rew", c_float_p), ("custom_sums", c_float_p), ("custom_acc", c_float_p)])
 
 
 class EnvOut(C.Structure):
     _fields_ = [("obs", c_float_p), ("priv_obs", c_float_p), ("rew", c_float_p), ("reset", c_u8_p), ("time_out", c_u8_p),
                 ("extras_time_outs", c_u8_p), ("extras_episode", c_float_p),
                 ("t_values", c_float_p), ("t_rewards", c_float_p), ("t_dones", c_u8_p), ("t_step", c_i64_p),
-                ("t_gamma", C.c_float), ("defer_finalize", C.c_int32), ("log_cur", c_float_p), ("log_stats", c_float_p)]
+                ("t_gamma", C.c_float), ("defer_finalize", C.c_int32), ("log_cur", c_float_p), ("log_stats", c_float_p),
+                ("extras_custom", c_float_p)]
 
 
 class EnvNoise(C.Structure):
@@ -147,6 +152,8 @@ SYMBOLS = {
     "hgym_post_physics": (C.c_int32, [_P(EnvConfig), _P(SimTensors), _P(EnvState), _P(EnvOut), _P(EnvNoise), C.c_void_p]),
     "hgym_env_step_synth": (C.c_int32, [_P(EnvConfig), _P(SimTensors), _P(EnvState), _P(EnvOut), c_float_p, C.c_void_p]),
     "hgym_env_finalize": (C.c_int32, [_P(EnvConfig), _P(EnvState), _P(EnvOut), C.c_void_p]),
+    "hgym_env_step_begin": (C.c_int32, [_P(EnvConfig), _P(SimTensors), _P(EnvState), _P(EnvOut), _P(EnvNoise), c_float_p, C.c_void_p]),
+    "hgym_env_step_end": (C.c_int32, [_P(EnvConfig), _P(SimTensors), _P(EnvState), _P(EnvOut), _P(EnvNoise), C.c_void_p]),
     "hgym_measure_heights": (C.c_int32, [_P(EnvConfig), _P(EnvState), C.c_void_p]),
     "hgym_store_step": (C.c_int32, [C.c_int32, c_float_p, c_float_p, c_u8_p, c_u8_p, C.c_float, c_float_p, c_u8_p, C.c_void_p]),
     "hgym_randperm": (C.c_int32, [C.c_int64, C.c_uint64, C.c_uint64, c_i64_p, C.c_void_p]),

@@ -97,6 +97,7 @@ class EnvBuffers:
         self.terrain_levels = self.terrain_types = self.terrain_origins = None
         self.height_samples = self.height_points = self.height_pose = self.measured_heights = None
         self.command_range_x = None
+        self.custom_rew = self.custom_sums = self.custom_acc = self.extras_custom = None     # set_custom_rewards
 
     # ---- generic options --------------------------------------------------------
     def set_terrain(self, origins, levels, types, env_length, curriculum, height_samples=None, height_points=None, border_size=0.0,
@@ -130,6 +131,19 @@ class EnvBuffers:
         self.command_range_x = torch.tensor([float(lin_vel_x[0]), float(lin_vel_x[1])], dtype=torch.float64, device=self.device)
         self.cfg.command_curriculum = 1
         self.cfg.max_curriculum = float(max_curriculum)
+
+    def set_custom_rewards(self, positions):
+        """User-defined reward terms (HgymEnvConfig.num_custom_rewards): positions[j] = how many built-in terms precede custom term j
+        in the alphabetical order the reference sums in.  Allocates the (K, N) term / episode-sum buffers the caller fills between
+        hgym_env_step_begin and hgym_env_step_end."""
+        K = len(positions)
+        if K > L.MAX_CUSTOM_REWARDS:
+            raise NotImplementedError("at most %d user-defined reward terms" % L.MAX_CUSTOM_REWARDS)
+        self.cfg.num_custom_rewards = K
+        for j, p in enumerate(positions):
+            self.cfg.custom_reward_pos[j] = int(p)
+        z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=self.device)
+        self.custom_rew, self.custom_sums, self.custom_acc, self.extras_custom = z(max(K, 1), self.N), z(max(K, 1), self.N), z(max(K, 1)), z(max(K, 1))
 
     # ---- views with the reference's shapes -------------------------------------------------------
     def view(self, name):
@@ -205,6 +219,8 @@ class EnvBuffers:
             st.measured_heights = L.fptr(self.measured_heights)
         if self.command_range_x is not None:
             st.command_range_x = C.cast(self.command_range_x.data_ptr(), L.c_f64_p)
+        if self.custom_rew is not None:
+            st.custom_rew, st.custom_sums, st.custom_acc = L.fptr(self.custom_rew), L.fptr(self.custom_sums), L.fptr(self.custom_acc)
         return st
 
     def out_struct(self, obs=None, priv=None, sink=None, defer_finalize=False, alt=False):
@@ -221,6 +237,8 @@ class EnvBuffers:
         o.defer_finalize = 1 if defer_finalize else 0
         if self.log_sink:
             o.log_cur, o.log_stats = L.fptr(self.log_cur), L.fptr(self.log_stats)
+        if self.extras_custom is not None:
+            o.extras_custom = L.fptr(self.extras_custom)
         return o
 
     @staticmethod

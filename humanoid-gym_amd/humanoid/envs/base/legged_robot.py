@@ -278,20 +278,38 @@ class LeggedRobot(BaseTask):
         self._refresh_extras()
 
     def _prepare_reward_function(self):
-        """legged_robot.py:518-541: drop zero scales, multiply by dt once; the survivors must be the kernel's terms."""
+        """legged_robot.py:518-541: drop zero scales, multiply by dt once; every surviving name is a reward term.  The 22 XBot-L terms
+        are evaluated inside the env kernel.  Any OTHER name -- or one of the 22 that a task subclass overrides with a method of its
+        own -- must be a `_reward_<name>` method of this object (as in the reference, which finds them all by name): those are
+        evaluated in torch between the two launches of a split step (hgym_env_step_begin / hgym_env_step_end) and summed at their
+        place in the reference's alphabetical order.  What such a method sees is the state compute_reward starts from
+        (legged_robot.py:128-161 done); the four buffers two built-in terms update while the reference walks the list
+        (feet_air_time, last_contacts, feet_height, last_feet_z) are read in their PRE-reward state even by a term that sorts
+        after feet_air_time / feet_clearance."""
         for key in list(self.reward_scales.keys()):
             if self.reward_scales[key] == 0:
                 self.reward_scales.pop(key)
             else:
                 self.reward_scales[key] *= self.dt
-        unknown = [k for k in self.reward_scales if k not in KERNEL_REWARD_TERMS]
-        if unknown:
-            raise NotImplementedError("reward terms not built into the fused env kernel: %s" % unknown)
         self.reward_names = [k for k in self.reward_scales]
+        own = lambda name: getattr(type(self), "_reward_" + name, None) is not None      # LeggedRobot / XBotLFreeEnv define none themselves
+        custom = [k for k in self.reward_names if k not in KERNEL_REWARD_TERMS or own(k)]
+        if any(k in ("feet_air_time", "feet_clearance") for k in custom):
+            raise NotImplementedError("the two stateful terms (feet_air_time, feet_clearance) cannot be overridden")
+        self._custom_terms = []
+        for name in custom:
+            fn = getattr(self, "_reward_" + name)           # AttributeError for a scale without a method, as in the reference
+            self._custom_terms.append((name, fn, self.reward_scales[name]))
         for k, name in enumerate(KERNEL_REWARD_TERMS):
-            self._ncfg.reward_scales[k] = self.reward_scales.get(name, 0.0)
+            self._ncfg.reward_scales[k] = 0.0 if name in custom else self.reward_scales.get(name, 0.0)
         sums = self._buf.f["episode_sums"]
-        self.episode_sums = {name: sums[KERNEL_REWARD_TERMS.index(name)] for name in self.reward_names}
+        self.episode_sums = {name: sums[KERNEL_REWARD_TERMS.index(name)] for name in self.reward_names if name not in custom}
+        if custom:
+            # custom term j is summed right before the first built-in term that sorts at or after it
+            self._buf.set_custom_rewards([sum(1 for b in KERNEL_REWARD_TERMS if b < name) for name in custom])
+            self._st_s = self._buf.state_struct()
+            for j, name in enumerate(custom):
+                self.episode_sums[name] = self._buf.custom_sums[j]
         self._refresh_extras()
 
     # ------------------------------------------------------------------ runner-visible buffers
@@ -321,8 +339,9 @@ class LeggedRobot(BaseTask):
 
     def _refresh_extras(self):
         b = self._buf
-        self.extras["episode"] = {"rew_" + n: b.extras_episode[KERNEL_REWARD_TERMS.index(n)] for n in self.reward_names} \
-            if hasattr(self, "reward_names") else {}
+        cust = [c[0] for c in getattr(self, "_custom_terms", [])]
+        self.extras["episode"] = {"rew_" + n: (b.extras_custom[cust.index(n)] if n in cust else b.extras_episode[KERNEL_REWARD_TERMS.index(n)])
+                                  for n in self.reward_names} if hasattr(self, "reward_names") else {}
         if self.cfg.env.send_timeouts:
             self.extras["time_outs"] = b.extras_time_outs
         # curriculum info (legged_robot.py:203-207): live device scalars (the reference refreshes them on steps with a reset)
@@ -345,13 +364,15 @@ class LeggedRobot(BaseTask):
         defer_finalize: step() does not launch the finaliser at all; the caller collects it with take_pending_finalize() and
         hands it to the next policy launch (PPO.act(env_fin=...)) or to run_finalize() -- before the next step()."""
         self._sink = sink
-        self._defer = bool(defer_finalize) and sink is not None
+        # (a split step -- user-defined reward terms -- always runs its finaliser itself)
+        self._defer = bool(defer_finalize) and sink is not None and not getattr(self, "_custom_terms", None)
 
     def bind_log_sink(self, on):
         """Native extension: while on, the step finaliser keeps the runner's per-step logging book-keeping on the device
         (HgymEnvOut.log_*: running episode return / length per env, the last-100-episodes rings, the per-step sums of
         extras["episode"]); read with log_sink_read().  Only the kernel's own reward terms are covered."""
-        on = bool(on) and set(self.extras.get("episode", {})) == {"rew_" + n for n in self.reward_names}
+        on = (bool(on) and not getattr(self, "_custom_terms", None)
+              and set(self.extras.get("episode", {})) == {"rew_" + n for n in self.reward_names})
         self._buf.log_sink = on
         if on:
             self._buf.log_cur.zero_()
@@ -406,6 +427,7 @@ class LeggedRobot(BaseTask):
         # the fused launch never calls step(): a task class that overrides step() / post_physics_step() (a wrapper, extra
         # book-keeping around the step) must keep getting its own code, i.e. the act() + step() path
         own_step = type(self).step is LeggedRobot.step and type(self).post_physics_step is LeggedRobot.post_physics_step
+        own_step = own_step and not getattr(self, "_custom_terms", None)       # user-defined reward terms: the two-launch step
         return bool(own_step and not generic and not c.use_ref_actions and c.frame_stack == 15 and c.c_frame_stack == 3 and self.num_envs % 32 == 0
                     and nc.precision == self._L.BF16 and nc.actor_layers == 4 and nc.critic_layers == 4 and nc.actor_dims[1] == 512
                     and nc.critic_dims[1] == 768 and nc.num_actions == 12 and 2 * (self.num_envs // 32) <= max(cus, 1)
@@ -462,8 +484,11 @@ class LeggedRobot(BaseTask):
         if getattr(self, "_pending_fin", None) is not None:
             raise RuntimeError("the previous step's finaliser was postponed (bind_transition(defer_finalize=True)) and never run")
         obs, priv, out = self._next_out()
-        L.check(L.lib.hgym_env_step_synth(C.byref(self._ncfg), C.byref(self._sim_s), C.byref(self._st_s), C.byref(out),
-                                          L.fptr(a), self._stream()), "hgym_env_step_synth")
+        if self._custom_terms:
+            self._split_step(out, L.fptr(a))
+        else:
+            L.check(L.lib.hgym_env_step_synth(C.byref(self._ncfg), C.byref(self._sim_s), C.byref(self._st_s), C.byref(out),
+                                              L.fptr(a), self._stream()), "hgym_env_step_synth")
         if out.defer_finalize:
             self._pending_fin = (self._ncfg, self._st_s, out)
         if self._ncfg.use_ref_actions and a.data_ptr() != actions.data_ptr():
@@ -477,9 +502,23 @@ class LeggedRobot(BaseTask):
         """For an external simulator that has written root_states / dof / contact / rigid tensors itself."""
         L = self._L
         obs, priv, out = self._next_out()
-        L.check(L.lib.hgym_post_physics(C.byref(self._ncfg), C.byref(self._sim_s), C.byref(self._st_s), C.byref(out),
-                                        C.byref(self._noise_none), self._stream()), "hgym_post_physics")
+        if self._custom_terms:
+            self._split_step(out, None)
+        else:
+            L.check(L.lib.hgym_post_physics(C.byref(self._ncfg), C.byref(self._sim_s), C.byref(self._st_s), C.byref(out),
+                                            C.byref(self._noise_none), self._stream()), "hgym_post_physics")
         self.obs_buf, self.privileged_obs_buf = obs, priv
+
+    def _split_step(self, out, actions_ptr):
+        """One step as two launches with the user-defined reward terms evaluated in between (legged_robot.py:217-235 with terms the
+        kernel does not know): derive -> `_reward_<name>()` * scale for each -> finish."""
+        L = self._L
+        L.check(L.lib.hgym_env_step_begin(C.byref(self._ncfg), C.byref(self._sim_s), C.byref(self._st_s), C.byref(out),
+                                          C.byref(self._noise_none), actions_ptr, self._stream()), "hgym_env_step_begin")
+        for j, (name, fn, scale) in enumerate(self._custom_terms):
+            self._buf.custom_rew[j].copy_(fn() * scale)
+        L.check(L.lib.hgym_env_step_end(C.byref(self._ncfg), C.byref(self._sim_s), C.byref(self._st_s), C.byref(out),
+                                        C.byref(self._noise_none), self._stream()), "hgym_env_step_end")
 
     def reset_idx(self, env_ids):
         """Only the all-envs form exists on the device (per-env resets are mask-driven inside the step kernel)."""

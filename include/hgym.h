@@ -49,6 +49,7 @@ enum {
 #define HGYM_OBS_FRAME 47   /* num_single_obs,           envs/custom/humanoid_config.py:41 */
 #define HGYM_PRIV_FRAME 73  /* single_num_privileged_obs, envs/custom/humanoid_config.py:43 */
 #define HGYM_MAX_LAYERS 8
+#define HGYM_MAX_CUSTOM_REWARDS 8   /* user-defined reward terms per env (HgymEnvConfig.num_custom_rewards) */
 
 int32_t hgym_version(void);
 const char* hgym_last_error(void);
@@ -118,6 +119,13 @@ typedef struct HgymEnvConfig {
                                      tracking_lin_vel episode sum exceeds 80 % of its maximum, lin_vel_x widens by 0.5 each way
                                      up to +-max_curriculum (:179-180,422-431).  The live range is HgymEnvState.command_range_x. */
     float max_curriculum;
+    /* User-defined reward terms (legged_robot.py:518-541: every non-zero entry of cfg.rewards.scales names a method
+     * `_reward_<name>`, found by name).  The 22 XBot-L terms are built in; any OTHER name is evaluated by the caller between
+     * hgym_env_step_begin and hgym_env_step_end (what the reference has computed by the time compute_reward runs is then in the
+     * state) and handed in through HgymEnvState.custom_rew.  custom_reward_pos[j] = how many built-in terms precede custom
+     * term j in the alphabetical order the reference sums in (0 .. 22): the fp32 sum is formed in that merged order. */
+    int32_t num_custom_rewards;
+    int32_t custom_reward_pos[HGYM_MAX_CUSTOM_REWARDS];
 } HgymEnvConfig;
 
 /* fills *cfg with the XBot-L values (the reference defaults) for num_envs environments */
@@ -177,6 +185,10 @@ typedef struct HgymEnvState {
                                        samples the heights (before the reset overwrites them) */
     float* measured_heights;        /* (N, num_height_points) fp32 = LeggedRobot.measured_heights */
     double* command_range_x;        /* [2] device doubles: command_ranges["lin_vel_x"] = [lo, hi]; moved by the command curriculum */
+    /* user-defined reward terms (HgymEnvConfig.num_custom_rewards = K > 0; NULL otherwise) */
+    const float* custom_rew;        /* (K, N) this step's terms, already times scale * dt: written by the caller between begin and end */
+    float* custom_sums;             /* (K, N) their episode sums (episode_sums of the reference, legged_robot.py:225-227) */
+    float* custom_acc;              /* (K,)   sum over the envs resetting this step of their episode sums (-> HgymEnvOut.extras_custom) */
 } HgymEnvState;
 
 /* Outputs of one env step = the 5-tuple of VecEnv.step (algo/vec_env.py:50-51) plus the extras tensors. */
@@ -215,6 +227,7 @@ typedef struct HgymEnvOut {
      * The caller zero-fills both once and clears log_stats[0, 23) after reading it. */
     float* log_cur;
     float* log_stats;
+    float* extras_custom;      /* (K,) extras["episode"]["rew_<name>"] of the user-defined terms, same staleness rule as extras_episode */
 } HgymEnvOut;
 #define HGYM_LOG_STATS 256
 
@@ -263,6 +276,20 @@ int32_t hgym_post_physics(const HgymEnvConfig* cfg, const HgymSimTensors* sim, c
 /* Fast path: pre_physics + synth_physics + post_physics in ONE launch, then the step finaliser. */
 int32_t hgym_env_step_synth(const HgymEnvConfig* cfg, const HgymSimTensors* sim, const HgymEnvState* st,
                             const HgymEnvOut* out, float* actions_in, void* stream);
+
+/* One env step in TWO launches, for tasks with user-defined reward terms (HgymEnvConfig.num_custom_rewards > 0):
+ *   hgym_env_step_begin  action processing (+ synthetic physics when actions_in != NULL; NULL: an external simulator has written the
+ *                        sim tensors, as for hgym_post_physics), episode length + 1, derived state, command resampling, pushes,
+ *                        termination flags -> out->reset / out->time_out -- legged_robot.py:128-137,156-161: the state
+ *                        compute_reward (:142) starts from;
+ *   [the caller evaluates its `_reward_<name>` terms on that state and writes term * scale * dt into st->custom_rew]
+ *   hgym_env_step_end    compute_reward with the caller's terms merged in at their alphabetical positions, reset_idx,
+ *                        observations, tail, finaliser (:142-151).
+ * With num_custom_rewards == 0 the pair computes exactly what hgym_env_step_synth / hgym_post_physics do in one launch. */
+int32_t hgym_env_step_begin(const HgymEnvConfig* cfg, const HgymSimTensors* sim, const HgymEnvState* st, const HgymEnvOut* out,
+                            const HgymEnvNoise* noise, float* actions_in, void* stream);
+int32_t hgym_env_step_end(const HgymEnvConfig* cfg, const HgymSimTensors* sim, const HgymEnvState* st, const HgymEnvOut* out,
+                          const HgymEnvNoise* noise, void* stream);
 
 /* LeggedRobot._get_heights (legged_robot.py:761-795) for the poses the last env step left in st->height_pose ->
  * st->measured_heights.  The env-step entry points call it themselves when cfg->num_height_points > 0. */

@@ -131,8 +131,15 @@ class XBotEnvOracle:
 
     def __init__(self, n, frictions=None, body_mass=None, frame_stack=C.FRAME_STACK,
                  c_frame_stack=C.C_FRAME_STACK, use_ref_actions=False, terrain=None, command_curriculum=False, max_curriculum=1.0,
-                 heading_command=True):
+                 heading_command=True, extra_rewards=None):
         self.n = n
+        # user-defined reward terms, legged_robot.py:518-541: name -> (fn(oracle) -> (N,) raw value, scale).  Every non-zero scale
+        # names a `_reward_<name>` found by getattr; the terms are evaluated and summed in the order of the scales dict, which
+        # class_to_dict builds with dir(), i.e. alphabetically (helpers.py:41-56) -- so extra names interleave with the 22 built-in
+        # ones.  A name that IS one of the 22 replaces that term (a subclass overriding the method).
+        self.extra_rewards = dict(extra_rewards or {})
+        self.extra_sums = {k: torch.zeros(n) for k in self.extra_rewards}
+        self.extras_extra = None
         self.use_ref_actions = bool(use_ref_actions)      # cfg.env.use_ref_actions, humanoid_config.py:49 (False for XBot-L)
         # generic LeggedRobot options XBot-L leaves off
         self.terrain = terrain                            # TerrainSpec or None (plane)
@@ -434,6 +441,8 @@ class XBotEnvOracle:
         cnt = m.sum()
         self.extras_episode = (self.episode_sums * mc).sum(dim=0) / cnt / C.EPISODE_LENGTH_S
         self.episode_sums = torch.where(mc, torch.zeros_like(self.episode_sums), self.episode_sums)
+        self.extras_extra = {k: (v * m).sum() / cnt / C.EPISODE_LENGTH_S for k, v in self.extra_sums.items()}
+        self.extra_sums = {k: torch.where(m, torch.zeros_like(v), v) for k, v in self.extra_sums.items()}
         self.extras_time_outs = self.time_out.clone()
         self.base_euler = euler_xyz_wrapped(s.root[:, 3:7])
         g = quat_rotate_inverse(s.root[:, 3:7], self.gravity)
@@ -508,12 +517,24 @@ class XBotEnvOracle:
         self.reset = torch.any(torch.norm(s.contact[:, [C.BASE_BODY], :], dim=-1) > 1.0, dim=1)
         self.time_out = self.ep_len > C.MAX_EPISODE_LENGTH
         self.reset = self.reset | self.time_out
-        # reward :217-235
+        # reward :217-235.  The reference evaluates the terms one after the other in alphabetical order, and two built-in terms
+        # are stateful (feet_air_time: feet_air_time / last_contacts; feet_clearance: feet_height / last_feet_z): a user-defined
+        # term sorting before "feet_air_time" sees those four buffers as compute_reward finds them, one sorting after
+        # "feet_clearance" sees them updated.  (Names strictly between the two are not supported by this restatement.)
+        sc = lambda name: self.extra_rewards[name][0](self) * (self.extra_rewards[name][1] * C.DT)
+        assert not any("feet_air_time" <= n <= "feet_clearance" for n in self.extra_rewards)
+        extra = {n: sc(n) for n in self.extra_rewards if n < "feet_air_time"}
         raw = self._rewards()
+        extra.update({n: sc(n) for n in self.extra_rewards if n > "feet_clearance"})
         self.rew = torch.zeros(self.n)
         scales = torch.tensor(C.REWARD_SCALES_DT, dtype=torch.float64)
         self.reward_terms = torch.zeros(self.n, C.NUM_REWARDS)
-        for k in range(C.NUM_REWARDS):
+        for name in sorted(set(C.REWARD_NAMES) | set(extra)):
+            if name in extra:
+                self.rew = self.rew + extra[name]
+                self.extra_sums[name] = self.extra_sums[name] + extra[name]
+                continue
+            k = C.REWARD_NAMES.index(name)
             term = raw[:, k] * C.REWARD_SCALES_DT[k]
             self.rew = self.rew + term
             self.episode_sums[:, k] += term

@@ -17,7 +17,7 @@ char* last_error_buf() {
 using namespace hgym;
 
 static EnvArgs make_args(const HgymEnvConfig* cfg, const HgymSimTensors* sim, const HgymEnvState* st, const HgymEnvOut* out,
-                         const HgymEnvNoise* noise, float* actions_in, int mode, int fused, int epb) {
+                         const HgymEnvNoise* noise, float* actions_in, int mode, int fused, int epb, int phase = 0) {
     EnvArgs A;
     memset(&A, 0, sizeof(A));
     A.cfg = *cfg;
@@ -28,6 +28,7 @@ static EnvArgs make_args(const HgymEnvConfig* cfg, const HgymSimTensors* sim, co
     A.actions_in = actions_in;
     A.origins_hbm = st->env_origins;
     A.mode = mode;
+    A.phase = phase;
     A.fused = fused;
     A.envs_per_block = epb;
     set_body_offsets(A);
@@ -40,6 +41,48 @@ extern "C" {
 // env_step_kernel<15, 3, 16, false> and rollout_step_kernel), plain steps of the default options only
 int hc_env_step_ex(const HgymEnvConfig* cfg, const HgymSimTensors* sim, const HgymEnvState* st, const HgymEnvOut* out,
                    const HgymEnvNoise* noise, float* actions_in, int mode, int fused, int epb, int nthreads, int split);
+// phase 1 / 2: the derive / finish launches of the two-launch step (hgym_env_step_begin / hgym_env_step_end: user-defined reward terms)
+int hc_env_step_phase(const HgymEnvConfig* cfg, const HgymSimTensors* sim, const HgymEnvState* st, const HgymEnvOut* out,
+                      const HgymEnvNoise* noise, float* actions_in, int fused, int epb, int nthreads, int phase) {
+    const EnvArgs A = make_args(cfg, sim, st, out, noise, actions_in, MODE_STEP, phase == 2 ? 0 : fused, epb, phase);
+    const int N = cfg->num_envs;
+    const int blocks = (N + epb - 1) / epb;
+    const int64_t csc0 = st->counters[0], ring = st->counters[2];
+    std::vector<float> smem(step_smem_bytes(epb) / sizeof(float));
+    for (int b = 0; b < blocks; ++b) {
+        for (int t = 0; t < nthreads; ++t) env_stage_in<0>(A, b, t, nthreads, smem.data());
+        for (int t = 0; t < nthreads; ++t) env_fill_draws<0>(A, b, t, nthreads, smem.data(), csc0);
+        for (int t = 0; t < nthreads; ++t) env_reset_pose<0>(A, t, nthreads, smem.data());
+        for (int t = 0; t < nthreads; ++t) env_step_joints<0>(A, b, t, nthreads, smem.data());
+        for (int t = 0; t < nthreads; ++t) env_step_phase_a<0, true>(A, b, t, smem.data(), csc0);
+        if (phase == 2)
+            for (int t = 0; t < nthreads; ++t) {
+                if (cfg->frame_stack == 15 && cfg->c_frame_stack == 3) env_step_stack_old<15, 3, 0>(A, b, t, nthreads, ring);
+                else env_step_stack_old<0, 0, 0>(A, b, t, nthreads, ring);
+            }
+        for (int t = 0; t < nthreads; ++t) env_stage_out<0>(A, b, t, nthreads, smem.data());
+        if (phase == 2)
+            for (int t = 0; t < nthreads; ++t) {
+                if (cfg->frame_stack == 15 && cfg->c_frame_stack == 3) env_step_phase_b<15, 3, 0>(A, b, t, nthreads, smem.data(), csc0, ring);
+                else env_step_phase_b<0, 0, 0>(A, b, t, nthreads, smem.data(), csc0, ring);
+            }
+    }
+    if (cfg->num_height_points > 0 && phase == 1)
+        for (int e = 0; e < N; ++e)
+            for (int p = 0; p < cfg->num_height_points; ++p) measure_height_point(A, e, p);
+    if (phase == 1) return 0;
+    if (cfg->command_curriculum && command_curriculum_due(A, csc0 + 1)) {
+        double lo, hi;
+        command_curriculum_move(A, st->command_range_x[0], st->command_range_x[1], lo, hi);
+        st->command_range_x[0] = lo;
+        st->command_range_x[1] = hi;
+        const RngKey rk = make_rng_key(A, csc0);
+        for (int e = 0; e < N; ++e) command_curriculum_fix_env(A, rk, e, (float)lo, (float)(hi - lo), ring);
+    }
+    for (int t = 0; t < nthreads; ++t) env_finalize_part1(A, t, nthreads);
+    env_finalize_part2(A);
+    return 0;
+}
 int hc_env_step(const HgymEnvConfig* cfg, const HgymSimTensors* sim, const HgymEnvState* st, const HgymEnvOut* out,
                 const HgymEnvNoise* noise, float* actions_in, int mode, int fused, int epb, int nthreads) {
     return hc_env_step_ex(cfg, sim, st, out, noise, actions_in, mode, fused, epb, nthreads, 0);
