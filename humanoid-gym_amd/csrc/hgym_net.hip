@@ -814,6 +814,7 @@ struct NetRunner {
         // <= CUs, i.e. 4096 envs), 64-row tiles x 16 waves (depth 2) for the update and for larger rollouts; measured
         // alternatives (64 rows x 8 waves, 32-row tiles for the update, other depths) were equal or slower
         const int cus = device_cus() > 0 ? device_cus() : 256;
+        // (32-row tiles two per CU at 8192 rows: collection 5.32 vs 3.82 ms, profiles/r03_envs8192_policy_tiles_ab.txt)
         const int32_t rc = (train || nets * ceil_div(M, 32) > cus) ? launch_fwd<64, 16, 2>(a, nets) : launch_fwd<32, 8, 4>(a, nets);
         double fl = 0.0;
         for (int i = first; i < first + nets; ++i)
