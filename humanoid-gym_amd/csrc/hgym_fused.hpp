@@ -1218,33 +1218,42 @@ __global__ __launch_bounds__(DW_THREADS, 2) void dw_kernel_rs(const DwArgs a) {
     }
     const char* gbase = reinterpret_cast<const char*>(op ? P.X : P.Z);
     const int64_t gstep = (int64_t)2 * (op ? P.CBx : P.CBz) * 512;   // bytes per 32-row step
-    const int64_t zofs = a.zeros - gbase;
-    const int lofs = lane * 16;
+    const unsigned int lofs = lane * 16;
     // Gathered X operand (first-layer products on the bf16 shadow): the lane that holds bytes [16 l, 16 l + 16) of a piece holds
     // row (l & 31) >> 1 of the row block, block l >> 5 of the pair, half l & 1 -- in the row-major shadow that is 16 bytes of row
-    // gidx[m].  The 16 row indices of a stage are one 128-byte load (lane l: row l & 15, replicated over the wave) issued TWO stages
+    // gidx[m].  The 16 row indices of a stage are one 4-byte load per lane (row l & 15, replicated over the wave) issued TWO stages
     // ahead of the stage's data and in front of the data loads of the stage issued with it: a wave's loads return in order, so
     // when the index is needed only the two younger stages (and the next index) are behind it -- the data ring keeps its depth.
     // Every wave issues the index load (from the zero page when it has nothing to gather): one instruction stream, exact vmcnt.
+    //
+    // Addressing: every load is (wave-uniform 64-bit base in SGPRs, advanced by scalar arithmetic) + (32-bit per-lane byte offset),
+    // the saddr form of global_load.  With per-lane 64-bit addresses the step spent ~50 of its 126 instructions on v_mad_u64 /
+    // v_lshl_add_u64 / v_cndmask, in a kernel whose waves are issuing or issue-stalled 73 % of the time (PMC).
+    // (The shadow is < 4 GiB: fused_grad checks.)
     const bool gx = op && P.gidx != nullptr;                          // wave-uniform
-    const int64_t ldgb = P.ldg * 2;
+    const unsigned int ldgb = (unsigned int)(P.ldg * 2);
     const int irow = mbl * 16 + (lane & 15);                          // row of the 32-row step whose index this lane fetches
     const int bsrc = ((lane & 31) >> 1) * 4;                          // ds_bpermute address: the lane that holds this lane's row
-    int64_t gcol[4];
+    unsigned int vb[4];                                               // per-lane constant part of the byte offset
+    int64_t sofs[4];                                                  // wave-uniform part: the piece's offset in a linear operand
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         int cb = cbx0 + 2 * j;
         cb = cb + 1 < P.CBx ? cb : P.CBx - 2;
-        gcol[j] = ((int64_t)(cb + (lane >> 5)) * 16 + (lane & 1) * 8) * 2;
+        const unsigned int gcol = (unsigned int)(((cb + (lane >> 5)) * 16 + (lane & 1) * 8) * 2);
+        vb[j] = gx ? gcol : lofs;
+        sofs[j] = gx ? 0 : gofs[j];
     }
-    const int64_t* ibase = gx ? P.gidx : reinterpret_cast<const int64_t*>(a.zeros);
+    const int64_t sstep = gx ? 0 : gstep;
+    const int64_t zdelta = a.zeros - gbase;
+    const char* ibase = gx ? reinterpret_cast<const char*>(P.gidx) : a.zeros;
     const int mg0 = gx ? -1 : 0;
     auto load_idx = [&](int t) -> int {
         int mrow = (step0 + (t < nsteps ? t : nsteps - 1)) * 32 + irow;
         mrow = mrow < a.B ? mrow : a.B - 1;
         // the low word only (indices are < 2^31): the dead upper half of an 8-byte load is a register the allocator hands out
         // again at once, and overwriting it has to wait for the load -- i.e. for every older load of the ring
-        return reinterpret_cast<const int*>(ibase)[2 * ((mrow & mg0) | ((lane & 15) & ~mg0))];
+        return *reinterpret_cast<const int*>(ibase + ((unsigned int)((mrow & mg0) | ((lane & 15) & ~mg0)) << 3));
     };
     // index ring: slot t % DW_RS holds the indices of stage t (a compile-time slot in the unrolled loop: rotating two registers
     // instead costs a move of a just-loaded value, i.e. a wait that drains the data ring once per revolution)
@@ -1254,15 +1263,16 @@ __global__ __launch_bounds__(DW_THREADS, 2) void dw_kernel_rs(const DwArgs a) {
     GI[1] = load_idx(1);
     u32x4 R[DW_RS][4];
     auto load = [&](int t, int slot, u32x4 (&rr)[4]) {                // slot == t % DW_RS
-        const int64_t m = t < nsteps ? -1 : 0;                        // all-ones / zero: branch-free selects of the byte offset (a
-        const int64_t mg = gx ? -1 : 0;                               // branch here makes the compiler's vmcnt placement drain the ring)
+        const bool in = t < nsteps;                                   // wave-uniform: scalar selects below, never a branch
         GI[(slot + 2) % DW_RS] = load_idx(t + 2);                     // issued BEFORE this stage's data
-        const int64_t rofs = (int64_t)__builtin_amdgcn_ds_bpermute(bsrc, GI[slot]) * ldgb;
+        const unsigned int rmask = (gx && in) ? 0xffffffffu : 0u;
+        const unsigned int rterm = ((unsigned int)__builtin_amdgcn_ds_bpermute(bsrc, GI[slot]) * ldgb) & rmask;
+        const int64_t m = in ? -1 : 0;                                // (integer masks: a `?:` on the pointer becomes a branch)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int64_t lin = gofs[j] + (int64_t)t * gstep + lofs, gat = rofs + gcol[j];
-            const int64_t o = ((((gat & mg) | (lin & ~mg))) & m) | ((zofs + lofs) & ~m);    // past the end of the split: the zero page
-            rr[j] = *reinterpret_cast<const u32x4*>(gbase + o);
+            // (an offset from the operand's own pointer, not a pointer rebuilt from an integer: that one would be a FLAT access)
+            const int64_t so = ((sofs[j] + (int64_t)t * sstep) & m) | (zdelta & ~m);      // stages past the end of the split: the zero page
+            rr[j] = *reinterpret_cast<const u32x4*>(gbase + so + (vb[j] + rterm));
         }
     };
     auto store = [&](int buf, const u32x4 (&rr)[4]) {

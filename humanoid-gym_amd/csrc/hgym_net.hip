@@ -908,7 +908,8 @@ struct NetRunner {
         const bool aux_fb = w.nnets > 2 && w.fused_aux;      // the auxiliary head as a third grid row of the same launches
         // bf16 shadows of the storage rows (HgymBatch.obs_bf16 / priv_bf16): gather 2 B per element, keep no operand copy
         static const bool no_shadow = getenv("HGYM_NO_SHADOW") != nullptr;       // A/B experiments only
-        const bool shadow = b.obs_bf16 && b.priv_bf16 && !no_shadow;
+        const bool shadow = b.obs_bf16 && b.priv_bf16 && !no_shadow && b.num_rows > 0 &&
+                            b.num_rows * shadow_ld(0) * 2 < ((int64_t)1 << 32) && b.num_rows * shadow_ld(1) * 2 < ((int64_t)1 << 32);
         const HgymBatch* gb = shadow ? &b : nullptr;
         if (part == 1) {
             int32_t rc1 = fused_dw(1, aux_fb ? 2 : 1, B, nullptr, gb);

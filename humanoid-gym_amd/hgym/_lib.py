@@ -124,7 +124,7 @@ class Batch(C.Structure):
     _fields_ = [("obs", c_float_p), ("priv", c_float_p), ("actions", c_float_p), ("values", c_float_p),
                 ("advantages", c_float_p), ("returns", c_float_p), ("logp", c_float_p), ("mu", c_float_p),
                 ("sigma", c_float_p), ("idx", c_i64_p), ("B", C.c_int32),
-                ("obs_bf16", C.c_void_p), ("priv_bf16", C.c_void_p)]
+                ("obs_bf16", C.c_void_p), ("priv_bf16", C.c_void_p), ("num_rows", C.c_int64)]
 
 
 class ObsShadow(C.Structure):

@@ -174,4 +174,4 @@ def make_batch(obs, priv, actions, values, advantages, returns, logp, mu, sigma,
         assert obs_bf16.shape[0] == obs.shape[0] and priv_bf16.shape[0] == priv.shape[0]
         sb = (C.c_void_p(obs_bf16.data_ptr()), C.c_void_p(priv_bf16.data_ptr()))
     return L.Batch(L.fptr(obs), L.fptr(priv), L.fptr(actions), L.fptr(values), L.fptr(advantages), L.fptr(returns), L.fptr(logp),
-                   L.fptr(mu), L.fptr(sigma), L.i64ptr(idx), int(idx.numel()), sb[0], sb[1])
+                   L.fptr(mu), L.fptr(sigma), L.i64ptr(idx), int(idx.numel()), sb[0], sb[1], int(obs.shape[0]))

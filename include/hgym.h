@@ -477,6 +477,9 @@ typedef struct HgymBatch {
      * operand copy of the gathered rows is kept for the weight-gradient kernel). */
     const void* obs_bf16;
     const void* priv_bf16;
+    int64_t num_rows;        /* rows of the storage tensors (T*N), required (> 0) with the shadows: the weight-gradient kernel addresses a
+                                shadow with 32-bit byte offsets, so num_rows * hgym_net_shadow_ld(cfg, 0) * 2 must stay below 4 GiB (2.79 M
+                                rows for XBot-L) -- beyond that the fp32 rows are used */
 } HgymBatch;
 
 int32_t hgym_ppo_grad(const HgymNetConfig* cfg, const HgymPPOConfig* ppo, const HgymNet* net,
