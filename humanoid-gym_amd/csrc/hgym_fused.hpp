@@ -1123,13 +1123,31 @@ __device__ __forceinline__ void ppo_scalars_block(const ScalArgs& a, int tid, in
 }
 
 // ================================================================================================ weight gradients
-// dW[n][k] = sum_m Z[m][n] * X[m][k]  (Z = dZ_l, X = layer input), 128 x 128 output tiles, contraction split over blockIdx.y.
-#ifndef HGYM_DW_LOCKSTEP
-#define HGYM_DW_LOCKSTEP 0      // measured: no change (177.5 vs 177.8 us), the tiles of a split do not drift because of the bias MFMAs
-#endif
-constexpr int DW_THREADS = 256;
-constexpr int DW_STAGE_BYTES = 16384;     // 32 rows x (8 Z blocks + 8 X blocks) x 512 B
-constexpr int DW_MAX_PRODUCTS = 12;    // actor + critic + auxiliary head, four layers each
+// dW[n][k] = sum_m Z[m][n] * X[m][k]  (Z = dZ_l, X = layer input): tiles of 128 dZ columns x 256 input columns, eight wavefronts
+// (64 x 64 each), contraction split over blockIdx.y.
+//
+// How the kernel got its shape (all on B = 61 440, one box, profiles/r03_dw_ablation.txt):
+//  * Operand transport: every wave keeps DW_RS stages of its three 1-KiB pieces in registers (global_load_dwordx4) and passes one
+//    stage per step to the LDS ring with ds_write_b128; fragments are read with the transpose read.  (A first version DMA'd the
+//    pieces straight into LDS with global_load_lds: a piece costs the issuing wave 60-185 cycles (MI355X_MICROARCH.md, LDS-DMA
+//    issue cost) next to 20 MFMAs = 320 cycles, so the DMA issue set the pace -- 272 us per launch against 183 us.)
+//  * Round 2's kernel (128 x 128 tiles, four waves, two workgroups per CU, 189 us) took the same time with its LDS traffic
+//    (177.9 us) or three quarters of its MFMAs (186.1 us) removed, and 135 us when every load hit a page of zeros: the pace is set
+//    by the CU's fill path -- 16 KiB per 32-row step per tile, two tiles per CU -- and neither by MFMA nor LDS; not by HBM either:
+//    a quarter of the rows, written microseconds earlier and still in the Infinity Cache, is no faster per row, and register rings
+//    of 2..5 stages all measure the same.  A 128 x 256 tile moves 24 KiB per step for twice the products -- three quarters of the
+//    bytes per MFMA through L1 -- and 32 tiles x 8 splits is exactly one workgroup per CU: 189 -> 180 us.
+//  * On L1-resident operands, removing the LDS reads, the LDS writes or three quarters of the MFMAs each saved its own 20-30 us of
+//    the 135: a sum, not a maximum -- the waves leave every barrier in the same phase, two MFMA streams queue at each matrix
+//    pipe and then nobody uses it.  Hence the two wave groups half a step apart (below): 180 -> 174 us (zero-page floor 133 -> 120).
+//  * What remains above the floor is the fill path itself: +29 us when the operands come from L2 (the same two row blocks over and
+//    over), +24 us more from HBM.
+constexpr int DW_THREADS = 512;
+constexpr int DW_Z_BYTES = 8192;           // 32 rows x 8 Z blocks x 512 B
+constexpr int DW_STAGE_BYTES = 24576;      // + 32 rows x 16 X blocks
+constexpr int DW_LDS_STAGES = 3;
+constexpr int DW_TILE_N = 128, DW_TILE_K = 256;
+constexpr int DW_MAX_PRODUCTS = 12;        // actor + critic + auxiliary head, four layers each
 
 struct DwProduct {
     const __bf16* Z;      // block layout, CBz column blocks per row block
@@ -1153,7 +1171,7 @@ struct DwArgs {
     int steps_per_split;
     float* slabs;
     int64_t slab_stride;   // floats
-    const char* zeros;     // >= 1 KiB of zeros (workspace): source of the stages past the end of a split
+    const char* zeros;     // 4 KiB of zeros (workspace): source of the stages past the end of a split
     int B;                 // valid batch rows (gathered products clamp their row indices to it)
     int scal_bid;          // >= 0: this workgroup sums the minibatch's loss partials instead (ppo_scalars_block); -1: none
     ScalArgs sc;
@@ -1167,26 +1185,20 @@ __device__ __forceinline__ u32x4 tr_frag(const char* p0, const char* p1) {
     return __builtin_bit_cast(u32x4, pr);
 }
 
-// Operand transport: every wave keeps DW_RS stages of its four 1-KiB pieces in registers (global_load_dwordx4) and passes one
-// stage per step to a 2-stage LDS buffer with ds_write_b128; the fragments are then read with the transpose read.  (A first
-// version DMA'd the pieces straight into an LDS ring with global_load_lds: a piece costs the issuing wave 60-185 cycles
-// (MI355X_MICROARCH.md, LDS-DMA issue cost), four pieces per 32-row step next to 20 MFMAs = 320 cycles, so the DMA issue,
-// not memory, set the pace -- MFMA pipe 20 % busy, L2 at 7 TB/s, 272 us per launch against 183 us now.)  The steady-state
-// loop is branch-free -- stages past the end of the split are read from a page of zeros, so they add nothing -- which keeps
-// the compiler's vmcnt exact (two younger stages in flight).  Depths 2..5 measure the same; 3 is used.
-template <int DW_RS>
-__global__ __launch_bounds__(DW_THREADS, 2) void dw_kernel_rs(const DwArgs a) {
+template <int DW_RS>      // register stages in flight per wave
+__global__ __launch_bounds__(DW_THREADS, 1) void dw_kernel_rs(const DwArgs a) {
+    static_assert(DW_RS == 3, "ring indices below: three register stages over three LDS stages, unrolled by six");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wi = wave >> 1, wj = wave & 1;
+    const int wi = wave >> 1, wj = wave & 1;                  // 64-column strip of the X side (4), of the Z side (2)
     const int r = lane & 15, q = lane >> 4;
     const int bid = blockIdx.x;
-    if (bid == a.scal_bid) {      // the loss scalars ride in this launch: one workgroup, ~10 us beside 180 us of tiles
+    if (bid == a.scal_bid) {      // the loss scalars ride in this launch: one workgroup, ~10 us beside 170 us of tiles
         ppo_scalars_block(a.sc, tid, DW_THREADS);
         return;
     }
     // Block -> (tile, split).  Workgroups are dealt round-robin to the 8 XCDs (block b -> XCD b % 8), each with a private
-    // 4 MiB L2.  All tiles of one split stream the SAME batch rows, so a split is pinned to one XCD: its ~62 tiles run there
+    // 4 MiB L2.  All tiles of one split stream the SAME batch rows, so a split is pinned to one XCD: its 32 tiles run there
     // concurrently and every operand block is fetched from HBM once and re-read from that L2 by the other tiles.
     const int xcd = bid & 7, slot = bid >> 3;
     const int split = xcd + 8 * (slot / a.total_tiles);
@@ -1199,53 +1211,49 @@ __global__ __launch_bounds__(DW_THREADS, 2) void dw_kernel_rs(const DwArgs a) {
     const DwProduct& P = a.p[pi];
     const int tl = tile - P.tile0;
     const int tn = tl / P.tiles_k, tk = tl - tn * P.tiles_k;
-    const int cbz0 = tn * 8, cbx0 = tk * 8;
+    const int cbz0 = tn * 8, cbx0 = tk * 16;
     const int step0 = split * a.steps_per_split;
     int nsteps = a.steps_total - step0;
     nsteps = nsteps < a.steps_per_split ? nsteps : a.steps_per_split;
 
-    // wave w moves pieces 4w..4w+3 of every stage; piece = (operand, row block, block pair), 1 KiB, lane-linear.
-    // Piece addresses are kept as (wave-uniform base, lane offset) so that "past the end -> the zero page" is one scalar
-    // select per piece and never a branch around a load.
-    const int op = __builtin_amdgcn_readfirstlane(wave >> 1), mbl = __builtin_amdgcn_readfirstlane(wave & 1);
-    int64_t gofs[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int CB = op ? P.CBx : P.CBz;
-        int cb = (op ? cbx0 : cbz0) + 2 * j;
-        cb = cb + 1 < CB ? cb : CB - 2;                       // clamp surplus pairs onto valid blocks (results unused)
-        gofs[j] = ((int64_t)(2 * step0 + mbl) * CB + cb) * 512;
-    }
-    const char* gbase = reinterpret_cast<const char*>(op ? P.X : P.Z);
-    const int64_t gstep = (int64_t)2 * (op ? P.CBx : P.CBz) * 512;   // bytes per 32-row step
-    const unsigned int lofs = lane * 16;
-    // Gathered X operand (first-layer products on the bf16 shadow): the lane that holds bytes [16 l, 16 l + 16) of a piece holds
-    // row (l & 31) >> 1 of the row block, block l >> 5 of the pair, half l & 1 -- in the row-major shadow that is 16 bytes of row
-    // gidx[m].  The 16 row indices of a stage are one 4-byte load per lane (row l & 15, replicated over the wave) issued TWO stages
-    // ahead of the stage's data and in front of the data loads of the stage issued with it: a wave's loads return in order, so
-    // when the index is needed only the two younger stages (and the next index) are behind it -- the data ring keeps its depth.
-    // Every wave issues the index load (from the zero page when it has nothing to gather): one instruction stream, exact vmcnt.
+    // Wave w moves, of every 32-row stage, row block w & 1 of Z block pair w >> 1 and of X block pairs 2 (w >> 1), 2 (w >> 1) + 1
+    // (piece = two adjacent 16 x 16 blocks of one row block, 1 KiB, lane-linear).
     //
     // Addressing: every load is (wave-uniform 64-bit base in SGPRs, advanced by scalar arithmetic) + (32-bit per-lane byte offset),
-    // the saddr form of global_load.  With per-lane 64-bit addresses the step spent ~50 of its 126 instructions on v_mad_u64 /
-    // v_lshl_add_u64 / v_cndmask, in a kernel whose waves are issuing or issue-stalled 73 % of the time (PMC).
-    // (The shadow is < 4 GiB: fused_grad checks.)
-    const bool gx = op && P.gidx != nullptr;                          // wave-uniform
+    // the saddr form of global_load; per-lane 64-bit addresses cost ~50 of a step's 126 instructions.  "Past the end of the split ->
+    // the page of zeros" is a scalar select on that base, never a branch around a load (a conditional load makes the compiler's
+    // vmcnt conservative), and an OFFSET from the operand's own pointer (a pointer rebuilt from an integer becomes a FLAT access).
+    //
+    // Gathered X operand (first-layer products on the bf16 shadow, < 4 GiB: fused_grad checks): the lane that holds bytes
+    // [16 l, 16 l + 16) of a piece holds row (l & 31) >> 1 of the row block, block l >> 5 of the pair, half l & 1 -- in the row-major
+    // shadow that is 16 bytes of row gidx[m].  The 16 row indices of a stage are one 4-byte load per lane (row l & 15, replicated
+    // over the wave) issued TWO stages ahead of the stage's data and in front of the data loads issued with it: a wave's loads
+    // return in order, so when the index is needed only the younger stages are behind it and the data ring keeps its depth.  Every
+    // tile issues the index load (from the zero page when it has nothing to gather): one instruction stream, exact vmcnt.
+    const int mbl = __builtin_amdgcn_readfirstlane(wave & 1), pp = __builtin_amdgcn_readfirstlane(wave >> 1);
+    const char* zbase = reinterpret_cast<const char*>(P.Z);
+    const char* xbase = reinterpret_cast<const char*>(P.X);
+    const bool gx = P.gidx != nullptr;
+    const unsigned int lofs = lane * 16;
+    int cbz = cbz0 + 2 * pp;
+    cbz = cbz + 1 < P.CBz ? cbz : P.CBz - 2;                          // surplus pairs: clamped onto valid blocks (results unused)
+    const int64_t zofs = ((int64_t)(2 * step0 + mbl) * P.CBz + cbz) * 512;
+    const int64_t zstep = (int64_t)2 * P.CBz * 512;                   // bytes per 32-row step
     const unsigned int ldgb = (unsigned int)(P.ldg * 2);
     const int irow = mbl * 16 + (lane & 15);                          // row of the 32-row step whose index this lane fetches
     const int bsrc = ((lane & 31) >> 1) * 4;                          // ds_bpermute address: the lane that holds this lane's row
-    unsigned int vb[4];                                               // per-lane constant part of the byte offset
-    int64_t sofs[4];                                                  // wave-uniform part: the piece's offset in a linear operand
+    unsigned int vb[2];                                               // per-lane constant part of the byte offset
+    int64_t xofs[2];                                                  // wave-uniform part: the piece's offset in a linear operand
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        int cb = cbx0 + 2 * j;
+    for (int j = 0; j < 2; ++j) {
+        int cb = cbx0 + 2 * (2 * pp + j);
         cb = cb + 1 < P.CBx ? cb : P.CBx - 2;
         const unsigned int gcol = (unsigned int)(((cb + (lane >> 5)) * 16 + (lane & 1) * 8) * 2);
         vb[j] = gx ? gcol : lofs;
-        sofs[j] = gx ? 0 : gofs[j];
+        xofs[j] = gx ? 0 : ((int64_t)(2 * step0 + mbl) * P.CBx + cb) * 512;
     }
-    const int64_t sstep = gx ? 0 : gstep;
-    const int64_t zdelta = a.zeros - gbase;
+    const int64_t xstep = gx ? 0 : (int64_t)2 * P.CBx * 512;
+    const int64_t zdz = a.zeros - zbase, zdx = a.zeros - xbase;
     const char* ibase = gx ? reinterpret_cast<const char*>(P.gidx) : a.zeros;
     const int mg0 = gx ? -1 : 0;
     auto load_idx = [&](int t) -> int {
@@ -1255,30 +1263,30 @@ __global__ __launch_bounds__(DW_THREADS, 2) void dw_kernel_rs(const DwArgs a) {
         // again at once, and overwriting it has to wait for the load -- i.e. for every older load of the ring
         return *reinterpret_cast<const int*>(ibase + ((unsigned int)((mrow & mg0) | ((lane & 15) & ~mg0)) << 3));
     };
-    // index ring: slot t % DW_RS holds the indices of stage t (a compile-time slot in the unrolled loop: rotating two registers
+    // index ring: slot t % 3 holds the indices of stage t (a compile-time slot in the unrolled loop: rotating two registers
     // instead costs a move of a just-loaded value, i.e. a wait that drains the data ring once per revolution)
-    static_assert(DW_RS >= 3, "the index of stage t + 2 is loaded into the slot stage t - 1 has left");
-    int GI[DW_RS];
+    int GI[3];
     GI[0] = load_idx(0);
     GI[1] = load_idx(1);
-    u32x4 R[DW_RS][4];
-    auto load = [&](int t, int slot, u32x4 (&rr)[4]) {                // slot == t % DW_RS
-        const bool in = t < nsteps;                                   // wave-uniform: scalar selects below, never a branch
-        GI[(slot + 2) % DW_RS] = load_idx(t + 2);                     // issued BEFORE this stage's data
+    u32x4 R[DW_RS][3];
+    auto load = [&](int t, int slot3, u32x4 (&rr)[3]) {               // slot3 == t % 3
+        const bool in = t < nsteps;                                   // wave-uniform: scalar selects below
+        GI[(slot3 + 2) % 3] = load_idx(t + 2);                        // issued BEFORE this stage's data
         const unsigned int rmask = (gx && in) ? 0xffffffffu : 0u;
-        const unsigned int rterm = ((unsigned int)__builtin_amdgcn_ds_bpermute(bsrc, GI[slot]) * ldgb) & rmask;
+        const unsigned int rterm = ((unsigned int)__builtin_amdgcn_ds_bpermute(bsrc, GI[slot3]) * ldgb) & rmask;
         const int64_t m = in ? -1 : 0;                                // (integer masks: a `?:` on the pointer becomes a branch)
+        rr[0] = *reinterpret_cast<const u32x4*>(zbase + (((zofs + (int64_t)t * zstep) & m) | (zdz & ~m)) + lofs);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            // (an offset from the operand's own pointer, not a pointer rebuilt from an integer: that one would be a FLAT access)
-            const int64_t so = ((sofs[j] + (int64_t)t * sstep) & m) | (zdelta & ~m);      // stages past the end of the split: the zero page
-            rr[j] = *reinterpret_cast<const u32x4*>(gbase + so + (vb[j] + rterm));
-        }
+        for (int j = 0; j < 2; ++j)
+            rr[1 + j] = *reinterpret_cast<const u32x4*>(xbase + (((xofs[j] + (int64_t)t * xstep) & m) | (zdx & ~m)) + (vb[j] + rterm));
     };
-    auto store = [&](int buf, const u32x4 (&rr)[4]) {
-        char* dst = smem + buf * DW_STAGE_BYTES + wave * 4096 + lane * 16;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) *reinterpret_cast<u32x4*>(dst + j * 1024) = rr[j];
+    // LDS stage: [row block][8 Z blocks][512 B], then [row block][16 X blocks][512 B]
+    auto store = [&](int buf, const u32x4 (&rr)[3]) {
+        char* dz = smem + buf * DW_STAGE_BYTES + mbl * 4096 + pp * 1024 + lane * 16;
+        char* dx = smem + buf * DW_STAGE_BYTES + DW_Z_BYTES + mbl * 8192 + pp * 2048 + lane * 16;
+        *reinterpret_cast<u32x4*>(dz) = rr[0];
+        *reinterpret_cast<u32x4*>(dx) = rr[1];
+        *reinterpret_cast<u32x4*>(dx + 1024) = rr[2];
     };
 
     f32x4 acc[4][4];
@@ -1291,49 +1299,64 @@ __global__ __launch_bounds__(DW_THREADS, 2) void dw_kernel_rs(const DwArgs a) {
     }
     const bool do_bias = (P.b_off >= 0) && tk == 0 && wi == 0;
     const u32x4 ones = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
-
+    auto frags = [&](int stage, u32x4 (&xa)[4], u32x4 (&zb)[4]) {
+        const char* st = smem + stage * DW_STAGE_BYTES;
 #pragma unroll
-    for (int j = 0; j < DW_RS; ++j) load(j, j, R[j]);
-    store(0, R[0]);
-    __syncthreads();
-    const int np = (nsteps + DW_RS - 1) / DW_RS * DW_RS;
-    for (int t0 = 0; t0 < np; t0 += DW_RS) {
+        for (int i = 0; i < 4; ++i) {
+            const char* px = st + DW_Z_BYTES + (wi * 4 + i) * 512 + lane * 8;
+            xa[i] = tr_frag(px, px + 8192);
+            const char* pz = st + (wj * 4 + i) * 512 + lane * 8;
+            zb[i] = tr_frag(pz, pz + 4096);
+        }
+    };
+    auto mfmas = [&](const u32x4 (&xa)[4], const u32x4 (&zb)[4]) {
 #pragma unroll
-        for (int j = 0; j < DW_RS; ++j) {
-            const int t = t0 + j;
-            load(t + DW_RS, j, R[j]);                        // R[j] held stage t, which is in LDS already
-            __builtin_amdgcn_sched_barrier(0);
-            const char* st = smem + (t & 1) * DW_STAGE_BYTES;
-            u32x4 xa[4], zb[4];
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const char* px = st + 8192 + (wi * 4 + i) * 512 + lane * 8;
-                xa[i] = tr_frag(px, px + 4096);
-                const char* pz = st + (wj * 4 + i) * 512 + lane * 8;
-                zb[i] = tr_frag(pz, pz + 4096);
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) mma_frag<__bf16>(xa[i], zb[jj], acc[i][jj]);
-#if HGYM_DW_LOCKSTEP
-            // every tile issues the column-sum MFMAs (only the tiles that own a bias gradient keep the result): tiles of one split
-            // share their operand rows through the XCD's L2, and tiles that run a different instruction count per step drift apart
-            // until the slower ones find their rows evicted
-            (void)do_bias;
+            for (int jj = 0; jj < 4; ++jj) mma_frag<__bf16>(xa[i], zb[jj], acc[i][jj]);
+        if (do_bias) {      // column sums of Z (measured: making every tile issue them, to keep a split's tiles in step, changes nothing)
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) mma_frag<__bf16>(ones, zb[jj], accb[jj]);
-#else
-            if (do_bias) {
+        }
+    };
+
+    // Pipeline.  The LDS ring holds stages t, t + 1 (read) and t + 2 (being written), the register ring stages t + 2 .. t + 4; the
+    // MFMAs of step t run on fragments read during step t - 1.  A step is two half-steps with a barrier after each, and the
+    // wavefronts work in two groups half a step apart: while waves 0-3 (one per SIMD) issue the MFMAs of a step, waves 4-7 --
+    // their SIMD partners -- move data (global loads of stage t + 4, LDS writes of stage t + 2, transpose reads of step t + 1),
+    // and vice versa.  The lagging group enters one barrier late and the leading group leaves one barrier late: every wave
+    // executes the same number of barriers.  Stage t + 2 is written in half-steps 2t + 1 (leading) and 2t + 2 (lagging) and first
+    // read in half-step 2t + 3; its buffer was last read (stage t - 1) in half-step 2t - 2.  The steady-state loop is branch-free
+    // -- stages past the end of the split come from the page of zeros and add nothing.
+    u32x4 XA[2][4], ZB[2][4];
 #pragma unroll
-                for (int jj = 0; jj < 4; ++jj) mma_frag<__bf16>(ones, zb[jj], accb[jj]);
-            }
-#endif
+    for (int j = 0; j < DW_RS; ++j) load(j, j % 3, R[j]);
+    store(0, R[0]);
+    load(DW_RS, DW_RS % 3, R[0]);
+    store(1, R[1]);
+    __syncthreads();
+    frags(0, XA[0], ZB[0]);
+    const int np = (nsteps + 5) / 6 * 6;
+    const int lagw = __builtin_amdgcn_readfirstlane(wave >> 2);
+    if (lagw) __builtin_amdgcn_s_barrier();
+    for (int t0 = 0; t0 < np; t0 += 6) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int t = t0 + j;
+            __builtin_amdgcn_s_setprio(1);
+            mfmas(XA[j & 1], ZB[j & 1]);
+            __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
-            store((t + 1) & 1, R[(j + 1) % DW_RS]);           // stage t + 1, loaded two steps ago
+            __syncthreads();
+            load(t + 1 + DW_RS, (j + 1 + DW_RS) % 3, R[(j + 1) % DW_RS]);      // that slot held stage t + 1: in LDS since step t - 1
+            __builtin_amdgcn_sched_barrier(0);
+            store((j + 2) % 3, R[(j + 2) % DW_RS]);                            // stage t + 2, loaded two steps ago
+            frags((j + 1) % 3, XA[(j + 1) & 1], ZB[(j + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
             __syncthreads();
         }
     }
+    if (!lagw) __builtin_amdgcn_s_barrier();
 
     // lane holds dW[n = .. + r][k = .. + 4q + e]
     float* __restrict__ slab = a.slabs + (int64_t)split * a.slab_stride;

@@ -855,8 +855,8 @@ struct NetRunner {
                 p.K = y.K;
                 p.w_off = y.w_off;
                 p.b_off = (l < 3 || i == 2) ? y.b_off : -1;
-                p.tiles_n = ceil_div(y.N, 128);
-                p.tiles_k = ceil_div(y.K, 128);
+                p.tiles_n = ceil_div(y.N, DW_TILE_N);
+                p.tiles_k = ceil_div(y.K, DW_TILE_K);
                 p.tile0 = tile;
                 tile += p.tiles_n * p.tiles_k;
                 fl += 2.0 * (double)B * y.N * y.K;
@@ -874,8 +874,10 @@ struct NetRunner {
             d.sc = *sc;
             d.scal_bid = blocks++;
         }
+        const int32_t rc_lds = ensure_dynamic_lds(reinterpret_cast<const void*>(&dw_kernel_rs<3>), DW_LDS_STAGES * DW_STAGE_BYTES, "dw_kernel_rs");
+        if (rc_lds != HGYM_OK) return rc_lds;
         prof_begin(HGYM_PROF_DW, s);
-        hipLaunchKernelGGL(dw_kernel_rs<3>, dim3(blocks), dim3(DW_THREADS), 2 * DW_STAGE_BYTES, s, d);
+        hipLaunchKernelGGL(dw_kernel_rs<3>, dim3(blocks), dim3(DW_THREADS), DW_LDS_STAGES * DW_STAGE_BYTES, s, d);
         prof_end(HGYM_PROF_DW, s, fl);
         HG_CHECK_LAUNCH("dw_kernel_rs");
         return HGYM_OK;

@@ -51,8 +51,11 @@ if os.environ.get('HGYM_BU_SHADOW', '1') != '0' and net.shadow_ld(0) > 0:      #
 print("shadow:", bool(shadow))
 batch = make_batch(obs, priv, act, val, adv, ret, lp_o, mu_o, sg_o, idx, **shadow)
 names = {0: "gemm(all)", 3: "loss", 4: "mlp_fwd", 5: "mlp_bwd", 6: "dw", 7: "reduce", 8: "apply", 9: "policy"}
+CH = int(os.environ.get('HGYM_CHUNKS', '1'))      # timing experiment: the minibatch as CH back-to-back gradient calls over B / CH rows each
+chunks = [make_batch(obs, priv, act, val, adv, ret, lp_o, mu_o, sg_o, idx[c * (B // CH):(c + 1) * (B // CH)].contiguous(), **shadow) for c in range(CH)] if CH > 1 else [batch]
 def step():
-    net.ppo_grad(ppo, batch); net.ppo_apply(ppo)
+    for bt in chunks: net.ppo_grad(ppo, bt)
+    net.ppo_apply(ppo)
 t = timeit(step, 20)
 print("minibatch grad+apply: %.1f us" % t)
 L.lib.hgym_prof_enable(1)
