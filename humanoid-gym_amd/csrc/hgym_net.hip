@@ -549,7 +549,13 @@ __global__ void apply_prologue_kernel(const HgymPPOConfig p, const float* __rest
         else if (kl < (double)p.desired_kl / 2.0 && kl > 0.0) lr = fmin(p.lr_max, lr * 1.5);
         opt[0] = lr;
     }
-    opt[1] += 1.0;
+    const double t = opt[1] + 1.0;
+    opt[1] = t;
+    // Adam's bias corrections, once per step instead of two double-precision pow() per thread of adam_kernel (1.1 M threads): the
+    // same double arithmetic, rounded to the floats the update uses
+    const double bc1 = 1.0 - pow((double)p.beta1, t), bc2 = 1.0 - pow((double)p.beta2, t);
+    opt[11] = (double)(float)(opt[0] / bc1);      // step size
+    opt[12] = (double)(float)sqrt(bc2);
     if (p.world_size > 1 || !p.grad_norm_ready) opt[9] = 0.0;   // sqnorm_kernel follows (rank MEAN after an all-reduce / foreign gradients)
 }
 
@@ -577,10 +583,7 @@ __global__ __launch_bounds__(256) void adam_kernel(const SegTable tab, const Hgy
     float coef = p.max_grad_norm / (total + 1e-6f);
     coef = fminf(coef, 1.0f);
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) opt[6] = (double)total;
-    const double t = opt[1];
-    const double bc1 = 1.0 - pow((double)p.beta1, t), bc2 = 1.0 - pow((double)p.beta2, t);
-    const float step_size = (float)(opt[0] / bc1);
-    const float sqrt_bc2 = (float)sqrt(bc2);
+    const float step_size = (float)opt[11], sqrt_bc2 = (float)opt[12];      // apply_prologue_kernel: lr / (1 - beta1^t), sqrt(1 - beta2^t)
     auto adam1 = [&](int64_t q) -> float {            // one parameter: clip, moments, step; returns the new weight
         const float g = (grads[q] * inv_w) * coef;
         grads[q] = g;

@@ -369,7 +369,8 @@ int64_t hgym_net_workspace_bytes(const HgymNetConfig* net);
  * [2] sum of minibatch mean KL  [3] sum of surrogate losses  [4] sum of value losses  [5] sum of mean entropies
  * [6] gradient norm of the last step (before clipping)  [7] minibatches accumulated in [2..5]
  * [8] mean KL of the last minibatch (average it across ranks before hgym_ppo_apply when world_size > 1)
- * [9] internal  [10] sum of the auxiliary head's minibatch MSE losses  [11..15] internal.
+ * [9] internal  [10] sum of the auxiliary head's minibatch MSE losses  [11] Adam step size lr / (1 - beta1^t) and
+ * [12] sqrt(1 - beta2^t) of the current step (as floats; written by hgym_ppo_apply)  [13..15] internal.
  * workspace: hgym_net_workspace_bytes() bytes, 256-byte aligned, ZERO-FILLED once by the caller before first use
  * (padding rows/columns of the operand buffers rely on it). */
 typedef struct HgymNet {

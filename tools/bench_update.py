@@ -21,7 +21,7 @@ src = torch.empty(1 << 28, device=dev, dtype=torch.uint8); dst = torch.empty_lik
 uc = timeit(lambda: dst.copy_(src), 10)
 print("calib: matmul8192 bf16 %.0f us (%.0f TF/s)  copy256MB %.0f us (%.2f TB/s r+w)" % (us, 2 * 8192**3 / us / 1e6, uc, 2 * (1 << 28) / uc / 1e6))
 
-B = 61440
+B = int(os.environ.get('HGYM_B', 61440))      # minibatch rows (61 440 = XBot-L: 4096 envs x 60 steps / 4)
 S = int(os.environ.get('HGYM_S', B))      # storage rows the minibatch is drawn from (245760 = the real XBot-L storage)
 cfg = make_net_config(705, 219, 12, [512, 256, 128], [768, 256, 128], "bf16", B)
 net = NetBuffers(cfg, dev, learning_rate=1e-5)
