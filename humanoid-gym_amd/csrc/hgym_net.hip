@@ -497,9 +497,17 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const SegTable tab, i
         const int64_t base = sg.off + head;
         for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int z = 0; z < sg.splits; ++z) {
-                const float4 v = *reinterpret_cast<const float4*>(slabs + (int64_t)z * P + base + 4 * i);
-                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            if (sg.splits == 8) {      // the usual split count: all eight loads in flight, then the same ascending sum
+                float4 v[8];
+#pragma unroll
+                for (int z = 0; z < 8; ++z) v[z] = *reinterpret_cast<const float4*>(slabs + (int64_t)z * P + base + 4 * i);
+#pragma unroll
+                for (int z = 0; z < 8; ++z) { acc.x += v[z].x; acc.y += v[z].y; acc.z += v[z].z; acc.w += v[z].w; }
+            } else {
+                for (int z = 0; z < sg.splits; ++z) {
+                    const float4 v = *reinterpret_cast<const float4*>(slabs + (int64_t)z * P + base + 4 * i);
+                    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+                }
             }
             *reinterpret_cast<float4*>(grads + base + 4 * i) = acc;
             sq += (double)acc.x * (double)acc.x + (double)acc.y * (double)acc.y + (double)acc.z * (double)acc.z + (double)acc.w * (double)acc.w;
