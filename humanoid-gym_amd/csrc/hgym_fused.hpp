@@ -1080,9 +1080,19 @@ struct ScalArgs {
     float* grads_bv;
     float* kl_slot;
     double* opt;
+    double beta1, beta2;   // Adam's: beta^t of the step this gradient will be applied in is left in opt[13..15] (below)
 };
 __device__ __forceinline__ void ppo_scalars_block(const ScalArgs& a, int tid, int nthreads) {
     __shared__ double red[16][LOSS_PARTIALS + 1];
+    // beta1^t, beta2^t for hgym_ppo_apply's prologue: two double-precision pow() are ~6 us in that single-thread kernel, on the
+    // minibatch's critical path; here they run on two lanes of the last wavefront beside a launch that takes 170 us anyway.  Keyed
+    // by t (opt[13]): the prologue recomputes them if the step count is not the one assumed here.
+    if (tid >= nthreads - 2) {
+        const double t = a.opt[1] + 1.0;
+        const double pw = pow(tid == nthreads - 2 ? a.beta1 : a.beta2, t);
+        a.opt[tid == nthreads - 2 ? 14 : 15] = pw;
+        if (tid == nthreads - 2) a.opt[13] = t;
+    }
     const float* __restrict__ partials = a.partials;
     const int nblocks = a.nblocks, B = a.B, A = a.A;
     const int k = tid & (LOSS_PARTIALS - 1);

@@ -561,7 +561,8 @@ __global__ void apply_prologue_kernel(const HgymPPOConfig p, const float* __rest
     opt[1] = t;
     // Adam's bias corrections, once per step instead of two double-precision pow() per thread of adam_kernel (1.1 M threads): the
     // same double arithmetic, rounded to the floats the update uses
-    const double bc1 = 1.0 - pow((double)p.beta1, t), bc2 = 1.0 - pow((double)p.beta2, t);
+    const bool cached = opt[13] == t;             // ppo_scalars_block left beta^t of this step (same pow(), same arguments): kernel 8.1 -> 4.8 us
+    const double bc1 = 1.0 - (cached ? opt[14] : pow((double)p.beta1, t)), bc2 = 1.0 - (cached ? opt[15] : pow((double)p.beta2, t));
     opt[11] = (double)(float)(opt[0] / bc1);      // step size
     opt[12] = (double)(float)sqrt(bc2);
     if (p.world_size > 1 || !p.grad_norm_ready) opt[9] = 0.0;   // sqnorm_kernel follows (rank MEAN after an all-reduce / foreign gradients)
@@ -998,7 +999,8 @@ struct NetRunner {
         // the minibatch's loss scalars (per-tile partials -> opt_state, std / head-bias gradients, KL slot): one extra workgroup of
         // the weight-gradient launch that follows anyway (it needs nothing but the partials mlp_fb_kernel has just written)
         const ScalArgs sc = {tiles, B, A, aux_fb ? w.net[2].layer[3].N : 0, at<float>(w.partials), net.grads,
-                             net.grads + w.net[0].layer[3].b_off, net.grads + w.net[1].layer[3].b_off, net.grads + w.P, net.opt_state};
+                             net.grads + w.net[0].layer[3].b_off, net.grads + w.net[1].layer[3].b_off, net.grads + w.P, net.opt_state,
+                             (double)ppo.beta1, (double)ppo.beta2};
         if (part == 0) {
             const int32_t rc0 = fused_dw(0, 1, B, &sc, gb);
             return rc0 ? rc0 : reduce_range(0, critic_off);
@@ -1205,7 +1207,8 @@ struct NetRunner {
         hipLaunchKernelGGL((ppo_loss_kernel<T>), dim3(nblocks), dim3(256), 0, s, a);
         prof_end(HGYM_PROF_LOSS, s, (double)B * (4.0 * (5 * A + 6) + (double)sizeof(T) * (2 * A + 2)));
         HG_CHECK_LAUNCH("ppo_loss_kernel");
-        const ScalArgs sc = {nblocks, B, A, 0, at<float>(w.partials), net.grads, nullptr, nullptr, net.grads + w.P, net.opt_state};
+        const ScalArgs sc = {nblocks, B, A, 0, at<float>(w.partials), net.grads, nullptr, nullptr, net.grads + w.P, net.opt_state,
+                             (double)ppo.beta1, (double)ppo.beta2};
         hipLaunchKernelGGL(ppo_scalars_kernel, dim3(1), dim3(512), 0, s, sc);
         HG_CHECK_LAUNCH("ppo_scalars_kernel");
         cur_Mp = Bp;

@@ -370,7 +370,8 @@ int64_t hgym_net_workspace_bytes(const HgymNetConfig* net);
  * [6] gradient norm of the last step (before clipping)  [7] minibatches accumulated in [2..5]
  * [8] mean KL of the last minibatch (average it across ranks before hgym_ppo_apply when world_size > 1)
  * [9] internal  [10] sum of the auxiliary head's minibatch MSE losses  [11] Adam step size lr / (1 - beta1^t) and
- * [12] sqrt(1 - beta2^t) of the current step (as floats; written by hgym_ppo_apply)  [13..15] internal.
+ * [12] sqrt(1 - beta2^t) of the current step (as floats; written by hgym_ppo_apply)  [13..15] internal (beta^t of the next step, prepared
+ * by hgym_ppo_grad: Adam's betas must not change between a gradient call and the apply that follows it).
  * workspace: hgym_net_workspace_bytes() bytes, 256-byte aligned, ZERO-FILLED once by the caller before first use
  * (padding rows/columns of the operand buffers rely on it). */
 typedef struct HgymNet {
