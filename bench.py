@@ -346,11 +346,10 @@ def run_config(args, task, num_envs, rank, world, local, dist, steps, warmup, lo
         if world > 1 and runner.alg.comm_timing:
             ev = runner.alg.comm_timing
             exposed = [a_.elapsed_time(b_) * 1e3 for a_, b_ in ev]
-            res["comm"] = dict(collective="all_reduce(SUM) of [flat fp32 gradient | minibatch KL], 2 buckets (std+actor under the "
-                                          "critic's dW, then critic+KL)",
+            res["comm"] = dict(collective="all_reduce(SUM) of [flat fp32 gradient | minibatch KL], one bucket per minibatch",
                                backend=("RCCL (torch.distributed 'nccl')" if dist.get_backend() == "nccl" else
                                         "%s (ranks may share a GPU; host-staged, not representative of RCCL over xGMI)" % dist.get_backend()),
-                               bytes_per_minibatch=4 * (runner.alg.net.P + 1), minibatches_per_iter=len(ev) // 2,
+                               bytes_per_minibatch=4 * (runner.alg.net.P + 1), minibatches_per_iter=len(ev) // 2,      # (two eager profiling iterations)
                                exposed_us_per_minibatch=sum(exposed) / len(exposed), exposed_us_max=max(exposed),
                                exposed_ms_per_iter=sum(exposed) / 2 * 1e-3,
                                note="stream time between the last backward kernel and the start of hgym_ppo_apply (HIP events on the "

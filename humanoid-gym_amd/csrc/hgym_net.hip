@@ -915,7 +915,7 @@ struct NetRunner {
     }
 
     // part < 0: the whole minibatch gradient.  part 0 / 1: the two halves of hgym_ppo_grad_part -- 0 leaves std's and the actor's
-    // gradient final (the LARGER bucket: it travels under part 1's kernels), 1 the critic's, the auxiliary head's and the KL slot.
+    // gradient final, 1 the critic's, the auxiliary head's and the KL slot.
     int32_t fused_grad(const HgymPPOConfig& ppo, const HgymBatch& b, int part = -1) {
         const int B = b.B, A = cfg.num_actions;
         const int64_t critic_off = w.net[1].layer[0].w_off;
@@ -925,15 +925,10 @@ struct NetRunner {
         const bool shadow = b.obs_bf16 && b.priv_bf16 && !no_shadow && b.num_rows > 0 &&
                             b.num_rows * shadow_ld(0) * 2 < ((int64_t)1 << 32) && b.num_rows * shadow_ld(1) * 2 < ((int64_t)1 << 32);
         const HgymBatch* gb = shadow ? &b : nullptr;
-        if (part == 1) {
-            int32_t rc1 = fused_dw(1, aux_fb ? 2 : 1, B, nullptr, gb);
-            if (rc1) return rc1;
-            if (w.nnets > 2 && !aux_fb) {
-                rc1 = aux_grad(ppo, b);
-                if (rc1) return rc1;
-            }
-            return reduce_range(critic_off, w.P);
-        }
+        // In two parts (hgym_ppo_grad_part): part 0 runs everything up to and including ALL weight-gradient products and sums the
+        // slabs of [std | actor]; part 1 only sums the rest.  (Until round 3 part 1 also launched the critic's products on their own:
+        // two launches of 144 and 112 workgroups on 256 CUs, each as long as the full one -- 2 x 142 us against 178 us.)
+        if (part == 1) return reduce_range(critic_off, w.P);
         float* mu = at<float>(w.net[0].out_f32);
         float* val = at<float>(w.net[1].out_f32);
         const float* xs[3] = {b.obs, b.priv, b.obs};
@@ -1001,17 +996,13 @@ struct NetRunner {
         const ScalArgs sc = {tiles, B, A, aux_fb ? w.net[2].layer[3].N : 0, at<float>(w.partials), net.grads,
                              net.grads + w.net[0].layer[3].b_off, net.grads + w.net[1].layer[3].b_off, net.grads + w.P, net.opt_state,
                              (double)ppo.beta1, (double)ppo.beta2};
-        if (part == 0) {
-            const int32_t rc0 = fused_dw(0, 1, B, &sc, gb);
-            return rc0 ? rc0 : reduce_range(0, critic_off);
-        }
         rc = fused_dw(0, nets, B, &sc, gb);
         if (rc) return rc;
         if (w.nnets > 2 && !aux_fb) {
             const int32_t rca = aux_grad(ppo, b);
             if (rca) return rca;
         }
-        return reduce_range(0, w.P);
+        return part == 0 ? reduce_range(0, critic_off) : reduce_range(0, w.P);
     }
 
     int32_t act(int M, const float* obs, const float* priv, const float* z, uint64_t seed, const int64_t* step, float* actions, float* mu,

@@ -1,8 +1,8 @@
 """Data-parallel glue: envs shard across ranks with no data-path collective; the only exchanges are
-  * per minibatch: the in-place all-reduce (SUM) of [flat fp32 gradient (926 105) | minibatch mean KL], issued as TWO buckets
-    -- [std | actor] (the larger one) as soon as hgym_ppo_grad_part(0) has produced it, so that it travels under the critic's (and
-    the denoiser's) weight-gradient kernels, then [critic | auxiliary head | KL] -- the means are formed inside hgym_ppo_apply, so every rank clips the same
-    gradient and takes the same adaptive-KL learning-rate decision;
+  * per minibatch: ONE in-place all-reduce (SUM) of [flat fp32 gradient (926 105) | minibatch mean KL] between hgym_ppo_grad and
+    hgym_ppo_apply -- the means are formed inside hgym_ppo_apply, so every rank clips the same gradient and takes the same
+    adaptive-KL learning-rate decision.  Nothing of the minibatch can run under it (apply needs the result); rounds 1-2 bought an
+    overlap by splitting the weight-gradient launch, which cost more than the exchange (ppo.py, update);
   * per iteration: one all-reduce of (sum adv, sum adv^2, count) so advantages are normalised over the global batch.
 Backend: torch.distributed "nccl" (= RCCL over xGMI) on the GPUs; the same functions run over "gloo" in the CPU tests."""
 import os
@@ -32,7 +32,7 @@ def sum_grads_and_kl(grads_ext):
 
 
 def start_sum(t):
-    """Asynchronous in-place all-reduce (SUM) of one gradient bucket; returns a handle for `finish` (None on a single rank).
+    """Asynchronous in-place all-reduce (SUM) of the gradient vector (or a slice of it); returns a handle for `finish` (None on a single rank).
     With RCCL the collective runs on the process group's own stream, ordered after everything enqueued on the current
     stream so far -- kernels launched after this call overlap with it."""
     if active():

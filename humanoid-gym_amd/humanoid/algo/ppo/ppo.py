@@ -3,8 +3,7 @@
 act() = one hgym_policy_act call whose outputs land directly in the rollout-storage slot; process_env_step() =
 hgym_store_step (time-out bootstrap) ; compute_returns() = wavefront-scan GAE ; update() = for every minibatch
 hgym_ppo_grad (gather + forward + KL + loss + hand-written backward, all on the device, no host sync) ->
-[when torch.distributed is initialised: hgym_ppo_grad_part 0 / 1 with the RCCL all-reduce of the actor's gradient bucket
-running under the critic's weight-gradient kernels, then the critic's bucket (+ KL)] -> hgym_ppo_apply (adaptive-KL
+[when torch.distributed is initialised: one RCCL all-reduce of [flat gradient | minibatch KL]] -> hgym_ppo_apply (adaptive-KL
 learning rate, grad-norm clip, Adam, operand-shadow refresh).  The host reads the loss sums back once per update.
 """
 import os
@@ -248,22 +247,18 @@ class PPO:
             for i in range(self.num_mini_batches):
                 idx = perm[i * mb:(i + 1) * mb]
                 batch = hgym.make_batch(*cols, idx, **sh)
-                if not dist_utils.active():
-                    net.ppo_grad(self._ppo_cfg, batch)
-                else:
-                    # two buckets: [std | actor] (the larger one) is reduced across ranks while this rank's critic (and denoiser)
-                    # weight gradients are still being computed; [critic | aux | KL] follows; apply waits (stream-side) for both
-                    split = net.bucket_split
-                    net.ppo_grad_part(self._ppo_cfg, batch, 0)
-                    h0 = dist_utils.start_sum(net.grads_ext[:split])
-                    net.ppo_grad_part(self._ppo_cfg, batch, 1)
-                    h1 = dist_utils.start_sum(net.grads_ext[split:])
+                net.ppo_grad(self._ppo_cfg, batch)
+                if dist_utils.active():
+                    # ONE bucket, [flat gradient | KL]: nothing of this minibatch is left to run under the exchange (apply needs it),
+                    # and two buckets pay the collective's latency twice.  (Rounds 1-2 split the weight-gradient launch in two so that
+                    # the actor's bucket travelled under the critic's products: the two half-empty launches cost 106 us more per
+                    # minibatch than the one launch -- more than the exchange they hid; profiles/r03_grad_parts_ab.txt.)
+                    h = dist_utils.start_sum(net.grads_ext)
                     probe = self.comm_timing is not None
                     if probe:
                         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                         ev[0].record()
-                    dist_utils.finish(h0)
-                    dist_utils.finish(h1)
+                    dist_utils.finish(h)
                     if probe:
                         ev[1].record()
                         self.comm_timing.append(ev)

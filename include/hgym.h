@@ -487,18 +487,18 @@ typedef struct HgymBatch {
 int32_t hgym_ppo_grad(const HgymNetConfig* cfg, const HgymPPOConfig* ppo, const HgymNet* net,
                       const HgymBatch* batch, void* stream);
 
-/* hgym_ppo_grad in two halves, for the data-parallel update (one process per GPU; the reference is single-process, its
- * `--horovod` flag is dead: utils/helpers.py:207-212): the flat gradient is exchanged in two buckets so that the first
- * all-reduce runs under the second half's kernels.
- *   part 0: forward, loss, dZ chain (of every net, the auxiliary head included), then the weight gradients of the ACTOR: on return
- *           (stream order)
- *           grads[0 .. hgym_net_param_offset(cfg, 1)) -- std | actor, the larger bucket (527 256 of 926 106 floats) -- are final;
- *   part 1: the weight gradients of the CRITIC (and of the auxiliary head):
- *           grads[hgym_net_param_offset(cfg, 1) .. P] -- critic | auxiliary head | the KL slot -- are final.
+/* hgym_ppo_grad in two halves (one process per GPU; the reference is single-process, its `--horovod` flag is dead:
+ * utils/helpers.py:207-212), for a caller that wants to start exchanging the first gradient bucket a few microseconds early:
+ *   part 0: forward, loss, dZ chain and ALL weight-gradient products (of every net, the auxiliary head included), then the slab
+ *           sums of [std | actor]: on return (stream order) grads[0 .. hgym_net_param_offset(cfg, 1)) -- 527 256 of 926 106
+ *           floats -- are final;
+ *   part 1: the slab sums of the rest: grads[hgym_net_param_offset(cfg, 1) .. P] -- critic | auxiliary head | the KL slot.
+ * (Until round 3 part 1 also launched the critic's weight-gradient products on their own, so that the first bucket travelled
+ * under them: two launches of 144 and 112 workgroups on 256 CUs took 2 x 142 us against 178 us for the one launch, more than the
+ * exchange they hid.  PPO.update now calls hgym_ppo_grad and exchanges ONE bucket.)
  * part 0 followed by part 1 leaves net->grads exactly as hgym_ppo_grad does (bit-identical), and opt_state[9] (the squared norm
- * hgym_ppo_apply may reuse with grad_norm_ready) complete: part 0 zeroes it and adds its bucket's share, part 1 adds the rest --
- * so a single rank may follow the two halves with grad_norm_ready = 1 (what PPO.update does under HGYM_DIST_SINGLE).  Between
- * part 0 and part 1 it is partial; with world_size > 1 apply recomputes the norm of the rank mean regardless. */
+ * hgym_ppo_apply may reuse with grad_norm_ready) complete: part 0 zeroes it and adds its bucket's share, part 1 adds the rest.
+ * Between part 0 and part 1 it is partial; with world_size > 1 apply recomputes the norm of the rank mean regardless. */
 int32_t hgym_ppo_grad_part(const HgymNetConfig* cfg, const HgymPPOConfig* ppo, const HgymNet* net,
                            const HgymBatch* batch, int32_t part, void* stream);
 /* offset (floats) in the flat parameter / gradient vector of the first parameter of net `which` (0 actor, 1 critic, 2 auxiliary

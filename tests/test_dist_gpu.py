@@ -66,15 +66,15 @@ def test_two_ranks_one_gpu_stay_in_lockstep(tmp_path):
     # every rank owns an independent env stream: Philox key, frictions and the first command draws all differ (helpers.shard_seed)
     assert a["env_seed"] != b["env_seed"] and a["env_seed"] == 5
     assert not torch.equal(a["friction"], b["friction"]) and not torch.equal(a["commands0"], b["commands0"])
-    # the gradient exchange ran as two buckets per minibatch (one event pair per minibatch: 4 iterations x 8)
+    # the gradient exchange ran once per minibatch (one event pair each: 4 iterations x 8)
     assert a["comm_events"] == 32 and 0 < a["split"] < a["P"]
 
 
 @pytest.mark.timeout(900)
 def test_eight_ranks_one_gpu_stay_in_lockstep(tmp_path):
     """BASELINE configs[2]'s rank count (8 ranks, here 128 envs each sharing one GPU over gloo): after 3 iterations = 24 synchronised
-    Adam steps every rank holds bit-identical parameters and the same learning rate, from 8 different env shards; the 2 x 24
-    bucketed exchanges and the per-iteration advantage-statistics all-reduce complete on all ranks (no dead-lock with the
+    Adam steps every rank holds bit-identical parameters and the same learning rate, from 8 different env shards; the 24
+    gradient exchanges and the per-iteration advantage-statistics all-reduce complete on all ranks (no dead-lock with the
     graph-captured rollout and the asynchronous iteration loop alive in 8 processes)."""
     port = 30100 + (os.getpid() % 2000)
     mp.spawn(_worker, args=(8, port, str(tmp_path), "gloo", 128, 3), nprocs=8, join=True)

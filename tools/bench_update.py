@@ -53,8 +53,13 @@ batch = make_batch(obs, priv, act, val, adv, ret, lp_o, mu_o, sg_o, idx, **shado
 names = {0: "gemm(all)", 3: "loss", 4: "mlp_fwd", 5: "mlp_bwd", 6: "dw", 7: "reduce", 8: "apply", 9: "policy"}
 CH = int(os.environ.get('HGYM_CHUNKS', '1'))      # timing experiment: the minibatch as CH back-to-back gradient calls over B / CH rows each
 chunks = [make_batch(obs, priv, act, val, adv, ret, lp_o, mu_o, sg_o, idx[c * (B // CH):(c + 1) * (B // CH)].contiguous(), **shadow) for c in range(CH)] if CH > 1 else [batch]
+PARTS = os.environ.get('HGYM_PARTS') == '1'       # the data-parallel update's two gradient halves (hgym_ppo_grad_part 0, 1) on one rank
 def step():
-    for bt in chunks: net.ppo_grad(ppo, bt)
+    for bt in chunks:
+        if PARTS:
+            net.ppo_grad_part(ppo, bt, 0); net.ppo_grad_part(ppo, bt, 1)
+        else:
+            net.ppo_grad(ppo, bt)
     net.ppo_apply(ppo)
 t = timeit(step, 20)
 print("minibatch grad+apply: %.1f us" % t)
