@@ -17,6 +17,8 @@ def test_header_symbols_exported():
     for name in declared:
         assert hasattr(L.lib, name), name
     assert L.lib.hgym_version() == 4
+    import __graft_entry__ as G      # build()'s own check reads the header: the two can not drift apart again
+    assert G.header_version() == L.lib.hgym_version()
 
 
 def test_struct_layouts_match():
