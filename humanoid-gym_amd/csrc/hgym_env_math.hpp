@@ -1745,7 +1745,8 @@ HG_HD void stack_new(const EnvArgs& A, float* __restrict__ ring, const float* cl
 // row's last frame each receive F / 4 (+1) unaligned 16-byte stores per env instead of F 4-byte ones.  Same arithmetic per entry.
 template <bool kNoisy, int F>
 HG_HD void stack_new_vec(const EnvArgs& A, float* __restrict__ ring, const float* clean_all, const float* z_all, const float* noise_vec,
-                         float* __restrict__ dst, int e0, int nE, int H, int slot_new, int t, int nthreads) {
+                         float* __restrict__ dst, int e0, int nE, int H, int slot_new, int t, int nthreads, float* __restrict__ ahead = nullptr) {
+    // ahead (HgymEnvOut.obs_ahead): this step's frame is frame H - 2 of the rows after next
     constexpr int Q = (F + 3) / 4;
     const int row = H * F;
     const float lim = A.cfg.clip_obs;
@@ -1768,6 +1769,7 @@ HG_HD void stack_new_vec(const EnvArgs& A, float* __restrict__ ring, const float
         }
         st_stream4<(HGYM_ENV_NT & 4) != 0>(ring + ((int64_t)(e0 + le) * H + slot_new) * F + off, r);
         st_stream4<(HGYM_ENV_NT & 4) != 0>(dst + (int64_t)le * row + (H - 1) * F + off, o);
+        if (ahead) st_stream4<(HGYM_ENV_NT & 4) != 0>(ahead + (int64_t)le * row + (H - 2) * F + off, o);
     }
 }
 
@@ -1797,6 +1799,22 @@ HG_HD void stack_reset_fix(float* __restrict__ ring, const int* s_reset, float* 
     }
 }
 
+// The same for rows written one launch ahead (HgymEnvOut.obs_ahead): their frames 0 .. H-3 were copied from the ring before this
+// step knew which envs reset.
+HG_HD void stack_reset_ahead(float* __restrict__ dst, const int* s_reset, int nE, int H, int F, int t, int nthreads, int reset_count,
+                             const int* reset_list) {
+    if (reset_count == 0) return;
+    const int row = H * F, hrow = (H - 2) * F;
+    const int n = reset_count > 0 ? reset_count : nE;
+    for (int r = 0; r < n; ++r) {
+        int le = r;
+        if (reset_count > 0) le = reset_list[r];
+        else if (!s_reset[le]) continue;
+        float* dp = dst + (int64_t)le * row;
+        for (int i = t; i < hrow; i += nthreads) dp[i] = 0.0f;
+    }
+}
+
 // Register-prefetched form of the older-frames copy for the compiled-in geometry: the lanes of wavefronts 1..3 issue ALL
 // of the history loads at kernel entry, back to back, together with the state staging loads -- one memory round trip for
 // the whole step -- and store them, clipped, WHILE wavefront 0 runs the per-env scalar phase; the few envs that turn out
@@ -1805,18 +1823,24 @@ HG_HD void stack_reset_fix(float* __restrict__ ring, const int* s_reset, float* 
 // into 16-byte items; the last item of a segment is shifted back to END at the segment end (it overlaps its neighbour and
 // rewrites identical values), so every item is one unconditional unaligned 16-byte load and one 16-byte store: no
 // branches, nothing for the compiler to serialise.  Surplus item slots repeat the last item.
-template <int H, int F>
+// EXCL = 1: the H - 1 frames older than the one this step writes into ring slot slot_new.  EXCL = 2 (rows written one launch ahead,
+// HgymEnvOut.obs_ahead): the H - 2 frames that are older than the NEXT step's too -- slot slot_new + 1, the oldest, is left out as well.
+template <int H, int F, int EXCL = 1>
 struct HistGeom {
     static constexpr int kRow = H * F;
-    static constexpr int kSlots = ((H - 1) * F + 3) / 4 + 1;    // item slots per env row (covers any split into A and B)
+    static constexpr int kSlots = ((H - EXCL) * F + 3) / 4 + 1;    // item slots per env row (covers any split into A and B)
 };
-template <int H, int F, int E, int NT>
-HG_HD constexpr int hist_ni() { return H > 1 ? (E * HistGeom<H, F>::kSlots + NT - 1) / NT : 0; }
+template <int H, int F, int E, int NT, int EXCL = 1>
+HG_HD constexpr int hist_ni() { return H > EXCL ? (E * HistGeom<H, F, EXCL>::kSlots + NT - 1) / NT : 0; }
 
-// item slot j of an env row -> (ring offset, row offset); slot_new = ring slot that receives the newest frame
-template <int H, int F>
+// item slot j of an env row -> (ring offset, row offset); slot_new = ring slot that receives the newest frame.  In ring order the
+// frames kept are slots slot_new + EXCL .. slot_new + H - 1 (mod H): segment A up to the end of the ring, segment B from its start.
+template <int H, int F, int EXCL = 1>
 HG_HD void hist_slot(int slot_new, int j, int& src_off, int& dst_off) {
-    const int LA = (H - 1 - slot_new) * F, LB = slot_new * F;
+    const int a0 = slot_new + EXCL;
+    const int LA = a0 < H ? (H - a0) * F : 0;
+    const int LB = (H - EXCL) * F - LA;
+    const int sA = a0 * F, sB = a0 < H ? 0 : (a0 - H) * F;
     const int nA = (LA + 3) >> 2, nB = (LB + 3) >> 2;
     j = j < nA + nB - 1 ? j : nA + nB - 1;                       // surplus slots repeat the last item
     const bool inA = j < nA;
@@ -1824,34 +1848,34 @@ HG_HD void hist_slot(int slot_new, int j, int& src_off, int& dst_off) {
     const int L = inA ? LA : LB;
     int o = 4 * k;
     o = o < L - 4 ? o : L - 4;                                   // last item of a segment ends at the segment end
-    src_off = inA ? (slot_new + 1) * F + o : o;
+    src_off = (inA ? sA : sB) + o;
     dst_off = inA ? o : LA + o;
 }
-template <int H, int F, int NI>
+template <int H, int F, int NI, int EXCL = 1>
 HG_HD void hist_load(const float* __restrict__ ring, int e0, int nE, int slot_new, int t, int nthreads, float (&v)[NI > 0 ? NI : 1][4]) {
-    constexpr int S = HistGeom<H, F>::kSlots, ROW = HistGeom<H, F>::kRow;
+    constexpr int S = HistGeom<H, F, EXCL>::kSlots, ROW = HistGeom<H, F, EXCL>::kRow;
 #pragma unroll
     for (int u = 0; u < NI; ++u) {
         int i = t + u * nthreads;
         i = i < nE * S ? i : nE * S - 1;
         const int le = i / S;
         int so, d_o;
-        hist_slot<H, F>(slot_new, i - le * S, so, d_o);
+        hist_slot<H, F, EXCL>(slot_new, i - le * S, so, d_o);
         const EnvF4 q = ld_stream4<(HGYM_ENV_NT & 1) != 0>(ring + (int64_t)(e0 + le) * ROW + so);
         v[u][0] = q.v[0]; v[u][1] = q.v[1]; v[u][2] = q.v[2]; v[u][3] = q.v[3];
     }
 }
-template <int H, int F, int NI>
+template <int H, int F, int NI, int EXCL = 1>
 HG_HD void hist_store(float* __restrict__ dst, int e0, int nE, int slot_new, int t, int nthreads, const int* s_reset, float lim,
                       const float (&v)[NI > 0 ? NI : 1][4]) {
-    constexpr int S = HistGeom<H, F>::kSlots, ROW = HistGeom<H, F>::kRow;
+    constexpr int S = HistGeom<H, F, EXCL>::kSlots, ROW = HistGeom<H, F, EXCL>::kRow;
 #pragma unroll
     for (int u = 0; u < NI; ++u) {
         int i = t + u * nthreads;
         i = i < nE * S ? i : nE * S - 1;
         const int le = i / S;
         int so, d_o;
-        hist_slot<H, F>(slot_new, i - le * S, so, d_o);
+        hist_slot<H, F, EXCL>(slot_new, i - le * S, so, d_o);
         const bool rs = s_reset ? s_reset[le] != 0 : false;     // null: reset envs are fixed up later (stack_reset_fix)
         EnvF4 q;
 #pragma unroll
@@ -1889,9 +1913,10 @@ HG_HD void env_step_phase_b(const EnvArgs& A, int block, int t, int nthreads, fl
     }
     float* dobs = A.out.obs + (int64_t)e0 * H * HGYM_OBS_FRAME;
     float* dpriv = A.out.priv_obs + (int64_t)e0 * HC * HGYM_PRIV_FRAME;
+    float* dahead = (H_T > 0 && HC_T > 0 && A.out.obs_ahead) ? A.out.obs_ahead + (int64_t)e0 * H * HGYM_OBS_FRAME : nullptr;      // fused rollout step only
     if (H_T > 0 && HC_T > 0) {
         stack_new_vec<true, HGYM_OBS_FRAME>(A, A.st.obs_ring, smem + m.frame, smem + m.z_obs, smem + m.noise_vec, dobs, e0, nE, H,
-                                            (int)(ring_step % H), t, nthreads);
+                                            (int)(ring_step % H), t, nthreads, dahead);
         stack_new_vec<false, HGYM_PRIV_FRAME>(A, A.st.priv_ring, smem + m.priv, nullptr, nullptr, dpriv, e0, nE, HC, (int)(ring_step % HC), t,
                                               nthreads);
     } else {
@@ -1905,6 +1930,7 @@ HG_HD void env_step_phase_b(const EnvArgs& A, int block, int t, int nthreads, fl
     stack_reset_fix(A.st.obs_ring, s_reset, dobs, e0, nE, H, HGYM_OBS_FRAME, (int)(ring_step % H), t, nthreads, !old_rows_final, nreset, rlist);
     stack_reset_fix(A.st.priv_ring, s_reset, dpriv, e0, nE, HC, HGYM_PRIV_FRAME, (int)(ring_step % HC), t, nthreads, !old_rows_final, nreset,
                     rlist);
+    if (dahead) stack_reset_ahead(dahead, s_reset, nE, H, HGYM_OBS_FRAME, t, nthreads, nreset, rlist);
 }
 
 // Step finaliser (hgym_finalize.hpp) on an EnvArgs record.

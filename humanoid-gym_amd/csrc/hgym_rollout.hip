@@ -92,8 +92,14 @@ struct RolloutPP {
 
 constexpr int RO_NIO = hist_ni<15, HGYM_OBS_FRAME, RO_E, RO_NT>();
 constexpr int RO_NIP = hist_ni<3, HGYM_PRIV_FRAME, RO_E, RO_NT>();
+constexpr int RO_NIA = hist_ni<15, HGYM_OBS_FRAME, RO_E, RO_NT - 64, 2>();      // rows written one launch ahead: 13 frames, seven wavefronts
 
-template <bool FIN>
+// PRE (HgymEnvOut.obs_older_ready): the 14 older frames of this launch's stacked observation rows were written by the previous launch
+// (as its obs_ahead), so the copy ring -> rows -- 11 HBM loads per lane issued after the first layer, in front of the second layer's
+// weight ring in the in-order vmcnt queue, and their stores: 4.4 us of a 42 us launch -- is not in this kernel at all.  A launch
+// that is given obs_ahead writes the 13 frames it already knows of the rows after next on the seven wavefronts that idle during
+// the per-env phase, and this step's frame next to its own row's in the stack phase.
+template <bool FIN, bool PRE>
 __global__ __launch_bounds__(RO_NT) void rollout_step_kernel(const FwdArgs f, const EnvArgs e, const FinArgs fin, const RolloutPP pp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (FIN && blockIdx.y >= 2) {
@@ -172,7 +178,7 @@ __global__ __launch_bounds__(RO_NT) void rollout_step_kernel(const FwdArgs f, co
     };
     auto mid = [&](const EnvArgs& E) {
 #if HGYM_RO_VARIANT == 0 || HGYM_RO_VARIANT == 5
-        hist_load<15, HGYM_OBS_FRAME, RO_NIO>(E.st.obs_ring, block * RO_E, RO_E, (int)(ring_step % 15), t, RO_NT, hist_o);
+        if (!PRE) hist_load<15, HGYM_OBS_FRAME, RO_NIO>(E.st.obs_ring, block * RO_E, RO_E, (int)(ring_step % 15), t, RO_NT, hist_o);
 #endif
     };
     auto put = [&](int row, int j, float v) { esm[act_off + row * 12 + j] = v; };
@@ -184,7 +190,7 @@ __global__ __launch_bounds__(RO_NT) void rollout_step_kernel(const FwdArgs f, co
 #if HGYM_RO_HIST_IDLE && HGYM_RO_VARIANT == 0
         // these lanes' share of the 14 older frames (in registers since `mid`) -> the stacked rows of the next observation, while
         // the two head wavefronts finish the tile: three quarters of that store phase leave the chain behind the tile
-        hist_store<15, HGYM_OBS_FRAME, RO_NIO>(E.out.obs, block * RO_E, RO_E, (int)(ring_step % 15), t, RO_NT, nullptr, E.cfg.clip_obs, hist_o);
+        if (!PRE) hist_store<15, HGYM_OBS_FRAME, RO_NIO>(E.out.obs, block * RO_E, RO_E, (int)(ring_step % 15), t, RO_NT, nullptr, E.cfg.clip_obs, hist_o);
 #endif
     };
     fwd_body<32, 8, 4, 2 * U, false>(f, f.net[0], true, smem, early, mid, put, e, idle);
@@ -201,10 +207,12 @@ __global__ __launch_bounds__(RO_NT) void rollout_step_kernel(const FwdArgs f, co
     const EnvArgs& A = e;
     // the two older privileged frames (12 registers the policy tile could not spare): loaded here, stored behind the joints phase
     hist_load<3, HGYM_PRIV_FRAME, RO_NIP>(A.st.priv_ring, block * RO_E, RO_E, (int)(ring_step % 3), t, RO_NT, hist_p);
+    if (!PRE) {
 #if HGYM_RO_HIST_IDLE && HGYM_RO_VARIANT == 0
-    if (t < 128)          // the head wavefronts' share; the others stored theirs under the head (idle hook)
+        if (t < 128)          // the head wavefronts' share; the others stored theirs under the head (idle hook)
 #endif
-    hist_store<15, HGYM_OBS_FRAME, RO_NIO>(A.out.obs, block * RO_E, RO_E, (int)(ring_step % 15), t, RO_NT, nullptr, A.cfg.clip_obs, hist_o);
+            hist_store<15, HGYM_OBS_FRAME, RO_NIO>(A.out.obs, block * RO_E, RO_E, (int)(ring_step % 15), t, RO_NT, nullptr, A.cfg.clip_obs, hist_o);
+    }
     stamp(1);
 #if HGYM_ENV_SPLIT
     env_step_phase_j<RO_E>(A, block, t, RO_NT, esm);       // joints + per-joint reward products; synthetic-physics remainder on waves 6, 7
@@ -215,13 +223,24 @@ __global__ __launch_bounds__(RO_NT) void rollout_step_kernel(const FwdArgs f, co
                                            hist_p);
     __syncthreads();
     stamp(2);
+    // rows after next (obs_ahead): the 13 frames older than this step's and the next one's, from the ring as this launch found it
+    auto ahead = [&]() {
+        if (A.out.obs_ahead) {
+            float hist_a[RO_NIA][4];
+            hist_load<15, HGYM_OBS_FRAME, RO_NIA, 2>(A.st.obs_ring, block * RO_E, RO_E, (int)(ring_step % 15), t - 64, RO_NT - 64, hist_a);
+            hist_store<15, HGYM_OBS_FRAME, RO_NIA, 2>(A.out.obs_ahead, block * RO_E, RO_E, (int)(ring_step % 15), t - 64, RO_NT - 64, nullptr,
+                                                      A.cfg.clip_obs, hist_a);
+        }
+    };
 #if HGYM_ENV_SPLIT
     if (t < 64) env_step_phase_a<RO_E, false, true>(A, block, t, esm, csc0);
+    else ahead();
     __syncthreads();
     env_step_phase_f<RO_E>(A, block, t, RO_NT, esm);       // per-joint reset / reference pose / frame entries / last_* copies
     __syncthreads();
 #else
     if (t < 64) env_step_phase_a<RO_E, false>(A, block, t, esm, csc0);
+    else ahead();
     __syncthreads();
 #endif
     stamp(3);
@@ -318,15 +337,21 @@ int32_t hgym_rollout_step(const HgymNetConfig* cfg, const HgymNet* net, const Hg
     }
     f.dbg = phase_buffer((int64_t)(M / RO_E) * 3);
     const size_t lds = (size_t)pp.env_lds_off + step_smem_bytes(RO_E);
+    const bool pre = out->obs_older_ready != 0;
+    HG_REQUIRE(!pre || prev_out, HGYM_E_BADARG, "obs_older_ready on the first step of a rollout: no launch has written those frames");
+    HG_REQUIRE(!out->obs_ahead || out->obs_ahead != out->obs, HGYM_E_BADARG, "obs_ahead must be the rows AFTER obs");
     {
-        const void* fn = prev_out ? reinterpret_cast<const void*>(&rollout_step_kernel<true>) : reinterpret_cast<const void*>(&rollout_step_kernel<false>);
+        const void* fn = pre ? reinterpret_cast<const void*>(&rollout_step_kernel<true, true>)
+                             : (prev_out ? reinterpret_cast<const void*>(&rollout_step_kernel<true, false>)
+                                         : reinterpret_cast<const void*>(&rollout_step_kernel<false, false>));
         rc = ensure_dynamic_lds(fn, lds, "rollout_step_kernel");
         if (rc) return rc;
     }
     hipStream_t s = (hipStream_t)stream;
     prof_begin(HGYM_PROF_ROLLOUT, s);
-    if (prev_out) hipLaunchKernelGGL(rollout_step_kernel<true>, dim3(M / RO_E, 3), dim3(RO_NT), lds, s, f, e, fin, pp);
-    else hipLaunchKernelGGL(rollout_step_kernel<false>, dim3(M / RO_E, 2), dim3(RO_NT), lds, s, f, e, fin, pp);
+    if (pre) hipLaunchKernelGGL((rollout_step_kernel<true, true>), dim3(M / RO_E, 3), dim3(RO_NT), lds, s, f, e, fin, pp);
+    else if (prev_out) hipLaunchKernelGGL((rollout_step_kernel<true, false>), dim3(M / RO_E, 3), dim3(RO_NT), lds, s, f, e, fin, pp);
+    else hipLaunchKernelGGL((rollout_step_kernel<false, false>), dim3(M / RO_E, 2), dim3(RO_NT), lds, s, f, e, fin, pp);
     {   // algorithmic HBM bytes of the fused step: the env step's + the policy's input rows and outputs
         const double env_b = 4.0 * (245 + 14 * 47 + 2 * 73 + 15 * 47 + 3 * 73) + 6;
         const double pol_b = 4.0 * (cfg->num_obs + cfg->num_priv + 3 * cfg->num_actions + 2);

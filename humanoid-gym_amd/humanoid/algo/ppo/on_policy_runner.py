@@ -125,8 +125,10 @@ class OnPolicyRunner:
         def rollout(obs, critic_obs):
             if fuse_ok:
                 env.rollout_begin(alg._sample_step, self.num_steps_per_env)
-                for i in range(self.num_steps_per_env):
-                    alg.fused_rollout_step(env, i, obs, critic_obs, obs_all[i + 1], priv_all[i + 1])
+                T = self.num_steps_per_env
+                for i in range(T):
+                    # (the slot after next: its older frames are written by this launch, off the next one's critical path)
+                    alg.fused_rollout_step(env, i, obs, critic_obs, obs_all[i + 1], priv_all[i + 1], obs_all[i + 2] if i + 2 <= T else None)
                     obs, critic_obs = obs_all[i + 1], priv_all[i + 1]
                 env.rollout_end()
                 return obs, critic_obs

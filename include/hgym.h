@@ -28,10 +28,11 @@
 extern "C" {
 #endif
 
-#define HGYM_VERSION 4      /* 2: HgymEnvOut carries the logging sink; hgym_rollout_*, hgym_ppo_grad_part, hgym_net_param_offset
+#define HGYM_VERSION 5      /* 2: HgymEnvOut carries the logging sink; hgym_rollout_*, hgym_ppo_grad_part, hgym_net_param_offset
                              * 3: the rollout scratch block grows with the env count (HGYM_ROLLOUT_SCRATCH_BYTES(num_envs))
                              * 4: bf16 observation shadow: HgymObsShadow argument of the policy launches, HgymBatch.obs_bf16 /
-                             *    priv_bf16, hgym_net_shadow_ld */
+                             *    priv_bf16, hgym_net_shadow_ld
+                             * 5: HgymEnvOut.obs_ahead / obs_older_ready (hgym_rollout_step writes the older frames one launch ahead) */
 
 enum {
     HGYM_OK = 0,
@@ -228,6 +229,13 @@ typedef struct HgymEnvOut {
     float* log_cur;
     float* log_stats;
     float* extras_custom;      /* (K,) extras["episode"]["rew_<name>"] of the user-defined terms, same staleness rule as extras_episode */
+    /* hgym_rollout_step only (NULL / 0 everywhere else).  obs_ahead: rows of the observation AFTER `obs` ((N, frame_stack*47): the
+     * rollout storage's slot after next).  The launch then also writes their frames 0 .. frame_stack-2 -- the frame_stack-2 older
+     * frames it knows when it starts (during its per-env phase, on wavefronts that idle there) and this step's own frame -- so that
+     * the NEXT launch, called with obs = this pointer and obs_older_ready = 1, does not copy them on its critical path: between the
+     * first and second layer of the actor tile that copy costs 4.4 us of a 42 us launch.  The rows come out bit-identical. */
+    float* obs_ahead;
+    int32_t obs_older_ready;   /* 1: frames 0 .. frame_stack-2 of `obs` were written by the previous launch (its obs_ahead) */
 } HgymEnvOut;
 #define HGYM_LOG_STATS 256
 

@@ -130,7 +130,8 @@ def test_env_step_synth_internal_philox_vs_oracle_gpu(N, steps):
 
 
 @pytest.mark.gpu
-def test_rollout_step_env_part_vs_oracle_gpu(monkeypatch):
+@pytest.mark.parametrize("ahead", [True, False])
+def test_rollout_step_env_part_vs_oracle_gpu(monkeypatch, ahead):
     """hgym_rollout_step (actor tile + env step of the same 32 envs + critic tile + previous finaliser, ONE launch per vec-step),
     4096 envs, 24 steps: the policy's sampled actions (storage) are the oracle's inputs; the next observations the launch wrote
     into the storage slots, the rewards / dones its finaliser stored (time-out bootstrap included: ppo.py:107-108 on the
@@ -164,7 +165,9 @@ def test_rollout_step_env_part_vs_oracle_gpu(monkeypatch):
         env.rollout_begin(alg._sample_step, T)
         obs, pobs = obs_all[0], priv_all[0]
         for i in range(T):
-            alg.fused_rollout_step(env, i, obs, pobs, obs_all[i + 1], priv_all[i + 1])
+            # ahead: the launch also writes the older frames of the slot after next (HgymEnvOut.obs_ahead) and the next one skips
+            # its own copy -- the rows compared below are produced by a different launch, and must not differ
+            alg.fused_rollout_step(env, i, obs, pobs, obs_all[i + 1], priv_all[i + 1], obs_all[i + 2] if (ahead and i + 2 <= T) else None)
             obs, pobs = obs_all[i + 1], priv_all[i + 1]
         env.rollout_end()
     torch.cuda.synchronize()
