@@ -231,8 +231,8 @@ static int32_t launch_step(const HgymEnvConfig* cfg, const HgymSimTensors* sim, 
     A.sim = *sim;
     A.st = *st;
     A.out = *out;
-    A.out.obs_ahead = nullptr;        // the rows-ahead protocol exists in hgym_rollout_step only (a stand-alone step would write one
-    A.out.obs_older_ready = 0;        // frame of those rows and nothing else)
+    A.out.obs_ahead = A.out.priv_ahead = nullptr;      // the rows-ahead protocol exists in hgym_rollout_step only (a stand-alone step
+    A.out.obs_older_ready = 0;                          // would write one frame of those rows and nothing else)
     if (noise) A.noise = *noise;
     A.actions_in = actions_in;
     A.origins_hbm = st->env_origins;

@@ -1914,11 +1914,12 @@ HG_HD void env_step_phase_b(const EnvArgs& A, int block, int t, int nthreads, fl
     float* dobs = A.out.obs + (int64_t)e0 * H * HGYM_OBS_FRAME;
     float* dpriv = A.out.priv_obs + (int64_t)e0 * HC * HGYM_PRIV_FRAME;
     float* dahead = (H_T > 0 && HC_T > 0 && A.out.obs_ahead) ? A.out.obs_ahead + (int64_t)e0 * H * HGYM_OBS_FRAME : nullptr;      // fused rollout step only
+    float* pahead = (H_T > 0 && HC_T > 0 && A.out.priv_ahead) ? A.out.priv_ahead + (int64_t)e0 * HC * HGYM_PRIV_FRAME : nullptr;
     if (H_T > 0 && HC_T > 0) {
         stack_new_vec<true, HGYM_OBS_FRAME>(A, A.st.obs_ring, smem + m.frame, smem + m.z_obs, smem + m.noise_vec, dobs, e0, nE, H,
                                             (int)(ring_step % H), t, nthreads, dahead);
         stack_new_vec<false, HGYM_PRIV_FRAME>(A, A.st.priv_ring, smem + m.priv, nullptr, nullptr, dpriv, e0, nE, HC, (int)(ring_step % HC), t,
-                                              nthreads);
+                                              nthreads, pahead);
     } else {
         stack_new<true>(A, A.st.obs_ring, smem + m.frame, smem + m.z_obs, smem + m.noise_vec, dobs, e0, nE, H, HGYM_OBS_FRAME,
                         (int)(ring_step % H), t, nthreads);
@@ -1931,6 +1932,7 @@ HG_HD void env_step_phase_b(const EnvArgs& A, int block, int t, int nthreads, fl
     stack_reset_fix(A.st.priv_ring, s_reset, dpriv, e0, nE, HC, HGYM_PRIV_FRAME, (int)(ring_step % HC), t, nthreads, !old_rows_final, nreset,
                     rlist);
     if (dahead) stack_reset_ahead(dahead, s_reset, nE, H, HGYM_OBS_FRAME, t, nthreads, nreset, rlist);
+    if (pahead) stack_reset_ahead(pahead, s_reset, nE, HC, HGYM_PRIV_FRAME, t, nthreads, nreset, rlist);
 }
 
 // Step finaliser (hgym_finalize.hpp) on an EnvArgs record.

@@ -93,6 +93,7 @@ struct RolloutPP {
 constexpr int RO_NIO = hist_ni<15, HGYM_OBS_FRAME, RO_E, RO_NT>();
 constexpr int RO_NIP = hist_ni<3, HGYM_PRIV_FRAME, RO_E, RO_NT>();
 constexpr int RO_NIA = hist_ni<15, HGYM_OBS_FRAME, RO_E, RO_NT - 64, 2>();      // rows written one launch ahead: 13 frames, seven wavefronts
+constexpr int RO_NIAP = hist_ni<3, HGYM_PRIV_FRAME, RO_E, RO_NT - 64, 2>();      // ... and the one privileged frame
 
 // PRE (HgymEnvOut.obs_older_ready): the 14 older frames of this launch's stacked observation rows were written by the previous launch
 // (as its obs_ahead), so the copy ring -> rows -- 11 HBM loads per lane issued after the first layer, in front of the second layer's
@@ -206,7 +207,7 @@ __global__ __launch_bounds__(RO_NT) void rollout_step_kernel(const FwdArgs f, co
 #endif
     const EnvArgs& A = e;
     // the two older privileged frames (12 registers the policy tile could not spare): loaded here, stored behind the joints phase
-    hist_load<3, HGYM_PRIV_FRAME, RO_NIP>(A.st.priv_ring, block * RO_E, RO_E, (int)(ring_step % 3), t, RO_NT, hist_p);
+    if (!PRE) hist_load<3, HGYM_PRIV_FRAME, RO_NIP>(A.st.priv_ring, block * RO_E, RO_E, (int)(ring_step % 3), t, RO_NT, hist_p);
     if (!PRE) {
 #if HGYM_RO_HIST_IDLE && HGYM_RO_VARIANT == 0
         if (t < 128)          // the head wavefronts' share; the others stored theirs under the head (idle hook)
@@ -219,8 +220,9 @@ __global__ __launch_bounds__(RO_NT) void rollout_step_kernel(const FwdArgs f, co
 #else
     env_step_joints<RO_E>(A, block, t, RO_NT, esm);
 #endif
-    hist_store<3, HGYM_PRIV_FRAME, RO_NIP>(A.out.priv_obs, block * RO_E, RO_E, (int)(ring_step % 3), t, RO_NT, nullptr, A.cfg.clip_obs,
-                                           hist_p);
+    if (!PRE)
+        hist_store<3, HGYM_PRIV_FRAME, RO_NIP>(A.out.priv_obs, block * RO_E, RO_E, (int)(ring_step % 3), t, RO_NT, nullptr, A.cfg.clip_obs,
+                                               hist_p);
     __syncthreads();
     stamp(2);
     // rows after next (obs_ahead): the 13 frames older than this step's and the next one's, from the ring as this launch found it
@@ -228,8 +230,12 @@ __global__ __launch_bounds__(RO_NT) void rollout_step_kernel(const FwdArgs f, co
         if (A.out.obs_ahead) {
             float hist_a[RO_NIA][4];
             hist_load<15, HGYM_OBS_FRAME, RO_NIA, 2>(A.st.obs_ring, block * RO_E, RO_E, (int)(ring_step % 15), t - 64, RO_NT - 64, hist_a);
+            float hist_ap[RO_NIAP][4];
+            hist_load<3, HGYM_PRIV_FRAME, RO_NIAP, 2>(A.st.priv_ring, block * RO_E, RO_E, (int)(ring_step % 3), t - 64, RO_NT - 64, hist_ap);
             hist_store<15, HGYM_OBS_FRAME, RO_NIA, 2>(A.out.obs_ahead, block * RO_E, RO_E, (int)(ring_step % 15), t - 64, RO_NT - 64, nullptr,
                                                       A.cfg.clip_obs, hist_a);
+            hist_store<3, HGYM_PRIV_FRAME, RO_NIAP, 2>(A.out.priv_ahead, block * RO_E, RO_E, (int)(ring_step % 3), t - 64, RO_NT - 64, nullptr,
+                                                       A.cfg.clip_obs, hist_ap);
         }
     };
 #if HGYM_ENV_SPLIT
@@ -339,7 +345,9 @@ int32_t hgym_rollout_step(const HgymNetConfig* cfg, const HgymNet* net, const Hg
     const size_t lds = (size_t)pp.env_lds_off + step_smem_bytes(RO_E);
     const bool pre = out->obs_older_ready != 0;
     HG_REQUIRE(!pre || prev_out, HGYM_E_BADARG, "obs_older_ready on the first step of a rollout: no launch has written those frames");
-    HG_REQUIRE(!out->obs_ahead || out->obs_ahead != out->obs, HGYM_E_BADARG, "obs_ahead must be the rows AFTER obs");
+    HG_REQUIRE((out->obs_ahead != nullptr) == (out->priv_ahead != nullptr), HGYM_E_BADARG, "obs_ahead and priv_ahead: both or neither");
+    HG_REQUIRE(!out->obs_ahead || (out->obs_ahead != out->obs && out->priv_ahead != out->priv_obs), HGYM_E_BADARG,
+               "obs_ahead / priv_ahead must be the rows AFTER obs / priv_obs");
     {
         const void* fn = pre ? reinterpret_cast<const void*>(&rollout_step_kernel<true, true>)
                              : (prev_out ? reinterpret_cast<const void*>(&rollout_step_kernel<true, false>)

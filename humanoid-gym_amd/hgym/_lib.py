@@ -91,7 +91,7 @@ class EnvOut(C.Structure):
                 ("extras_time_outs", c_u8_p), ("extras_episode", c_float_p),
                 ("t_values", c_float_p), ("t_rewards", c_float_p), ("t_dones", c_u8_p), ("t_step", c_i64_p),
                 ("t_gamma", C.c_float), ("defer_finalize", C.c_int32), ("log_cur", c_float_p), ("log_stats", c_float_p),
-                ("extras_custom", c_float_p), ("obs_ahead", c_float_p), ("obs_older_ready", C.c_int32)]
+                ("extras_custom", c_float_p), ("obs_ahead", c_float_p), ("priv_ahead", c_float_p), ("obs_older_ready", C.c_int32)]
 
 
 class EnvNoise(C.Structure):

@@ -128,7 +128,8 @@ class OnPolicyRunner:
                 T = self.num_steps_per_env
                 for i in range(T):
                     # (the slot after next: its older frames are written by this launch, off the next one's critical path)
-                    alg.fused_rollout_step(env, i, obs, critic_obs, obs_all[i + 1], priv_all[i + 1], obs_all[i + 2] if i + 2 <= T else None)
+                    alg.fused_rollout_step(env, i, obs, critic_obs, obs_all[i + 1], priv_all[i + 1],
+                                           (obs_all[i + 2], priv_all[i + 2]) if i + 2 <= T else None)
                     obs, critic_obs = obs_all[i + 1], priv_all[i + 1]
                 env.rollout_end()
                 return obs, critic_obs

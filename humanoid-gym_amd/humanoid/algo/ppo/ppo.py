@@ -174,11 +174,11 @@ class PPO:
             self._sample_step += 1
         return t.actions
 
-    def fused_rollout_step(self, env, i, obs, critic_obs, next_obs, next_critic_obs, ahead_obs=None):
+    def fused_rollout_step(self, env, i, obs, critic_obs, next_obs, next_critic_obs, ahead=None):
         """act() + env.step() + process_env_step() of rollout step i as ONE launch (LeggedRobot.rollout_step): the policy's outputs
         land in storage slot i, the env writes the next observations into the slots handed in, the finaliser riding in the
-        following launch stores rewards / dones of slot i (time-out bootstrap included).  ahead_obs: the slot after next_obs, whose
-        older frames this launch may write ahead (LeggedRobot.rollout_step)."""
+        following launch stores rewards / dones of slot i (time-out bootstrap included).  ahead: (obs, critic_obs) of the slot after
+        next_obs, whose older frames this launch may write ahead (LeggedRobot.rollout_step)."""
         st, s = self.storage, self.storage.step
         if s >= st.num_transitions_per_env:
             raise AssertionError("Rollout buffer overflow")
@@ -186,7 +186,7 @@ class PPO:
         sink = dict(values=st.values[s], rewards=st.rewards[s], dones=st.dones[s], step=self._sample_step, gamma=self.gamma)
         sh = st.shadow_slot(s) if (obs.data_ptr() == st._obs_all[s].data_ptr() and critic_obs.data_ptr() == st._priv_all[s].data_ptr()) else None
         env.rollout_step(self.net, i, obs, critic_obs, next_obs, next_critic_obs, sink, self.actor_critic._sample_seed, out, shadow=sh,
-                         ahead_obs=ahead_obs)
+                         ahead=ahead)
         st.step += 1
 
     def transition_sink(self):

@@ -441,25 +441,28 @@ class LeggedRobot(BaseTask):
         self._L.check(self._L.lib.hgym_rollout_begin(C.byref(self._st_s), self._L.i64ptr(step_counter), C.c_void_p(self._buf.rollout_scratch.data_ptr()),
                                                      (self._ro_T - 1) & 1, self._stream()), "hgym_rollout_begin")
 
-    def rollout_step(self, net, i, obs, priv, next_obs, next_priv, sink, seed, out, shadow=None, ahead_obs=None):
+    def rollout_step(self, net, i, obs, priv, next_obs, next_priv, sink, seed, out, shadow=None, ahead=None):
         """Step i of the rollout begun with rollout_begin: actions / mu / sigma / logp / values of PPO.act into `out`, this env's
         step on those actions with the observations written to next_obs / next_priv, the transition sink of step i stored by
         the finaliser that rides in step i + 1 (or in rollout_end).  The last step uses the primary rew / reset / time_out
         buffers, so that they read as after a plain step() once the rollout is over.  shadow: optional (obs_bf16, priv_bf16)
-        storage-slot tensors receiving the bf16 of `obs` / `priv` (HgymObsShadow).  ahead_obs: the rows the NEXT step will write
-        its observations to (HgymEnvOut.obs_ahead): this launch writes their 14 older frames off its critical path, and the next
-        call -- recognised by its next_obs being this tensor -- skips the copy.  Same rows either way (HGYM_ROWS_AHEAD=0: never)."""
+        storage-slot tensors receiving the bf16 of `obs` / `priv` (HgymObsShadow).  ahead: (obs, priv) rows the NEXT step will write
+        its observations to (HgymEnvOut.obs_ahead / priv_ahead): this launch writes their older frames off its critical path, and the
+        next call -- recognised by its next_obs being that tensor -- skips the copy.  Same rows either way (HGYM_ROWS_AHEAD=0: never)."""
         sh = None if shadow is None else net.shadow_struct(*shadow)
         L = self._L
         parity = (self._ro_T - 1 - i) & 1
         o = self._buf.out_struct(next_obs, next_priv, sink, True, alt=bool(parity))
         if os.environ.get("HGYM_ROWS_AHEAD", "1") == "0":
-            ahead_obs = None
-        o.obs_older_ready = int(self._ro_prev is not None and self._ro_ahead is not None and self._ro_ahead == next_obs.data_ptr())
-        if ahead_obs is not None:
-            assert ahead_obs.is_contiguous() and ahead_obs.shape == next_obs.shape and ahead_obs.data_ptr() != next_obs.data_ptr()
-            o.obs_ahead = L.fptr(ahead_obs)
-        self._ro_ahead = None if ahead_obs is None else ahead_obs.data_ptr()
+            ahead = None
+        o.obs_older_ready = int(self._ro_prev is not None and self._ro_ahead is not None
+                                and self._ro_ahead == (next_obs.data_ptr(), next_priv.data_ptr()))
+        if ahead is not None:
+            a_obs, a_priv = ahead
+            assert a_obs.is_contiguous() and a_obs.shape == next_obs.shape and a_obs.data_ptr() != next_obs.data_ptr()
+            assert a_priv.is_contiguous() and a_priv.shape == next_priv.shape and a_priv.data_ptr() != next_priv.data_ptr()
+            o.obs_ahead, o.priv_ahead = L.fptr(a_obs), L.fptr(a_priv)
+        self._ro_ahead = None if ahead is None else (ahead[0].data_ptr(), ahead[1].data_ptr())
         prev = self._ro_prev
         L.check(L.lib.hgym_rollout_step(C.byref(net.cfg), C.byref(net.struct), C.byref(self._ncfg), C.byref(self._sim_s), C.byref(self._st_s),
                                         C.byref(o), C.byref(prev[0]) if prev is not None else None, L.fptr(obs), L.fptr(priv),

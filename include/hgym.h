@@ -235,7 +235,9 @@ typedef struct HgymEnvOut {
      * the NEXT launch, called with obs = this pointer and obs_older_ready = 1, does not copy them on its critical path: between the
      * first and second layer of the actor tile that copy costs 4.4 us of a 42 us launch.  The rows come out bit-identical. */
     float* obs_ahead;
-    int32_t obs_older_ready;   /* 1: frames 0 .. frame_stack-2 of `obs` were written by the previous launch (its obs_ahead) */
+    float* priv_ahead;         /* the same for priv_obs ((N, c_frame_stack*73)); both or neither */
+    int32_t obs_older_ready;   /* 1: frames 0 .. frame_stack-2 of `obs` (and 0 .. c_frame_stack-2 of `priv_obs`) were written by the
+                                  previous launch (as its obs_ahead / priv_ahead) */
 } HgymEnvOut;
 #define HGYM_LOG_STATS 256
 

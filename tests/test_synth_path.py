@@ -167,7 +167,8 @@ def test_rollout_step_env_part_vs_oracle_gpu(monkeypatch, ahead):
         for i in range(T):
             # ahead: the launch also writes the older frames of the slot after next (HgymEnvOut.obs_ahead) and the next one skips
             # its own copy -- the rows compared below are produced by a different launch, and must not differ
-            alg.fused_rollout_step(env, i, obs, pobs, obs_all[i + 1], priv_all[i + 1], obs_all[i + 2] if (ahead and i + 2 <= T) else None)
+            alg.fused_rollout_step(env, i, obs, pobs, obs_all[i + 1], priv_all[i + 1],
+                                   (obs_all[i + 2], priv_all[i + 2]) if (ahead and i + 2 <= T) else None)
             obs, pobs = obs_all[i + 1], priv_all[i + 1]
         env.rollout_end()
     torch.cuda.synchronize()

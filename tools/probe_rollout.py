@@ -28,7 +28,7 @@ env.rollout_begin(alg._sample_step, 4)
 acc = []
 for i in range(4):
     buf.zero_()
-    alg.fused_rollout_step(env, i, obs_all[i], priv_all[i], obs_all[i + 1], priv_all[i + 1], obs_all[i + 2])
+    alg.fused_rollout_step(env, i, obs_all[i], priv_all[i], obs_all[i + 1], priv_all[i + 1], (obs_all[i + 2], priv_all[i + 2]))
     torch.cuda.synchronize()
     acc.append(buf.clone())
 env.rollout_end()
