@@ -41,7 +41,7 @@ if os.environ.get('HGYM_IDX_SEQ'):
 if os.environ.get('HGYM_SORT'):
     idx = idx.sort().values.contiguous()      # same minibatch (as a set), ascending storage order
 if os.environ.get('HGYM_IDX0'):
-    idx = torch.randint(0, 64, (S,), device=dev)   # every gather hits L2: isolates the input-latency share of mlp_fwd
+    idx = torch.randint(0, 64, (B,), device=dev)   # every gather hits L2: isolates the input-latency share of mlp_fwd
 ppo = make_ppo_config(grad_norm_ready=True)      # what PPO.update passes on one rank
 shadow = {}
 if os.environ.get('HGYM_BU_SHADOW', '1') != '0' and net.shadow_ld(0) > 0:      # bf16 shadows of the storage rows (what the rollout leaves behind)

@@ -20,6 +20,8 @@ sg_o = torch.ones(S, 12, device=dev)
 val, adv, ret = torch.randn(S, device=dev), torch.randn(S, device=dev), torch.randn(S, device=dev)
 lp_o = -12.0 + torch.randn(S, device=dev)
 idx = torch.randperm(S, device=dev).contiguous()
+if os.environ.get('HGYM_IDX0'):
+    idx = torch.randint(0, 64, (S,), device=dev)      # every gather hits L2 / L1: the phases without the input rows' HBM latency
 ppo = make_ppo_config()
 shadow = {}
 if os.environ.get('HGYM_BU_SHADOW', '1') != '0' and net.shadow_ld(0) > 0:
