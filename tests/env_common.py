@@ -124,8 +124,13 @@ class EnvUnderTest:
     """Product-side buffers + the call sequence of one vec-step in parity mode (external noise, external sim frames)."""
 
     def __init__(self, backend, N, friction, body_mass, sim_layout="soa", frame_stack=15, c_frame_stack=3, use_ref_actions=False,
-                 terrain=None, command_curriculum=None, heading_command=True):
-        """terrain: an oracle TerrainSpec (its initial levels are copied); command_curriculum: max_curriculum or None."""
+                 terrain=None, command_curriculum=None, heading_command=True, rows_ahead=False):
+        """terrain: an oracle TerrainSpec (its initial levels are copied); command_curriculum: max_curriculum or None.
+        rows_ahead: the observation rows rotate through three buffers the way hgym_rollout_step's caller hands them in -- the step
+        writes its observations to one, the older frames of the NEXT step's rows to another (HgymEnvOut.obs_ahead / priv_ahead),
+        and from the second step on finds its own rows' older frames already written (obs_older_ready).  A buffer is filled with
+        NaN before it is handed in as `ahead`, so a frame nobody wrote would show in the comparison with the oracle."""
+        self.rows_ahead = bool(rows_ahead)
         from hgym import EnvBuffers, default_env_config
         self.be = backend
         self.cfg = default_env_config(N, frame_stack=frame_stack, c_frame_stack=c_frame_stack)
@@ -168,9 +173,25 @@ class EnvUnderTest:
         self.be.pd_torques(self.cfg, self.sim, self.st)
         self.be.sync()
         self.buf.load_sim(*frame)
+        if self.rows_ahead:
+            fp = lambda t: C.cast(t.data_ptr(), C.POINTER(C.c_float))
+            if not hasattr(self, "_rows"):
+                b = self.buf
+                self._rows = [(b.obs, b.priv_obs)] + [(torch.empty_like(b.obs), torch.empty_like(b.priv_obs)) for _ in range(2)]
+                self._k, self._ready = 0, False
+            nxt, ah = self._rows[(self._k + 1) % 3], self._rows[(self._k + 2) % 3]
+            if not self._ready:
+                nxt[0].fill_(float("nan")); nxt[1].fill_(float("nan"))
+            ah[0].fill_(float("nan")); ah[1].fill_(float("nan"))
+            self.out.obs, self.out.priv_obs = fp(nxt[0]), fp(nxt[1])
+            self.out.obs_ahead, self.out.priv_ahead = fp(ah[0]), fp(ah[1])
+            self.out.obs_older_ready = int(self._ready)
         self.be.step_call("post", self.cfg, self.sim, self.st, self.out,
                           self._noise(u_cmd=u_cmd, u_dof=u_dof, u_push=u_push, z_obs=z_obs, u_xy=u_xy, r_level=r_level))
         self.be.sync()
+        if self.rows_ahead:
+            self._k, self._ready = self._k + 1, True
+            self.buf.obs, self.buf.priv_obs = nxt
 
 
 def compare_state(env, o, tag, check_obs=True):
@@ -232,7 +253,7 @@ def random_terrain_spec(g, N, rows=5, cols=4, points=(7, 5)):
 
 
 def run_random_trace(backend, N, steps, seed, sim_layout="soa", frame_stack=15, c_frame_stack=3, check_every=1,
-                     use_ref_actions=False, generic=False, track_sum=40.0, heading_command=True):
+                     use_ref_actions=False, generic=False, track_sum=40.0, heading_command=True, rows_ahead=False):
     """Seeded random trace through product + oracle with identical inputs; returns event counts.
     generic: a terrain map (custom origins, terrain curriculum, height measurements) and the command curriculum are on; the
     common step counter is planted so that the command curriculum is examined inside the trace and `track_sum` (the planted
@@ -246,7 +267,7 @@ def run_random_trace(backend, N, steps, seed, sim_layout="soa", frame_stack=15, 
                       heading_command=heading_command)
     env = EnvUnderTest(backend, N, fr, bm, sim_layout=sim_layout, frame_stack=frame_stack, c_frame_stack=c_frame_stack,
                        use_ref_actions=use_ref_actions, terrain=spec, command_curriculum=1.5 if generic else None,
-                       heading_command=heading_command)
+                       heading_command=heading_command, rows_ahead=rows_ahead)
     u_dof, u_cmd3, z_obs = torch.rand(N, 12, generator=g), torch.rand(N, 3, generator=g), torch.randn(N, 47, generator=g)
     gen_draws = lambda: (torch.rand(N, 2, generator=g), torch.randint(0, spec.max_level, (N,), generator=g)) if generic else (None, None)
     u_xy, r_level = gen_draws()

@@ -109,13 +109,36 @@ int hc_env_step_ex(const HgymEnvConfig* cfg, const HgymSimTensors* sim, const Hg
             for (int t = 0; t < nthreads; ++t) env_step_joints<0>(A, b, t, nthreads, smem.data());
             for (int t = 0; t < nthreads; ++t) env_step_phase_a<0, true>(A, b, t, smem.data(), csc0);
         }
-        for (int t = 0; t < nthreads; ++t) {   // the device runs this on its idle wavefronts, concurrently with phase A
-            if (cfg->frame_stack == 15 && cfg->c_frame_stack == 3) env_step_stack_old<15, 3, 0>(A, b, t, nthreads, ring);
-            else env_step_stack_old<0, 0, 0>(A, b, t, nthreads, ring);
+        // The rows-ahead protocol of hgym_rollout_step (HgymEnvOut.obs_ahead / priv_ahead / obs_older_ready; XBot-L geometry): the
+        // frames this launch already finds in the ring go into the rows AFTER next through the device's item geometry
+        // (hist_slot<H, F, 2>) -- on the device by the wavefronts idle during phase A -- and a launch whose rows were prepared this
+        // way copies no older frames itself.
+        const bool xbot = cfg->frame_stack == 15 && cfg->c_frame_stack == 3;
+        if (xbot && mode == MODE_STEP && A.out.obs_ahead && A.out.priv_ahead) {
+            const StackGeom g = stack_geom<15, 3, 0>(A, b);
+            auto copy_ahead = [&](auto geom, const float* ring_base, float* dst_base, int H, int F, int slots) {
+                for (int le = 0; le < g.nE; ++le)
+                    for (int j = 0; j < slots; ++j) {
+                        int so, d_o;
+                        geom((int)(ring % H), j, so, d_o);
+                        for (int k = 0; k < 4; ++k)
+                            dst_base[(int64_t)(g.e0 + le) * H * F + d_o + k] =
+                                clampf(ring_base[(int64_t)(g.e0 + le) * H * F + so + k], -A.cfg.clip_obs, A.cfg.clip_obs);
+                    }
+            };
+            copy_ahead([](int s, int j, int& so, int& d_o) { hist_slot<15, HGYM_OBS_FRAME, 2>(s, j, so, d_o); }, A.st.obs_ring, A.out.obs_ahead,
+                       15, HGYM_OBS_FRAME, HistGeom<15, HGYM_OBS_FRAME, 2>::kSlots);
+            copy_ahead([](int s, int j, int& so, int& d_o) { hist_slot<3, HGYM_PRIV_FRAME, 2>(s, j, so, d_o); }, A.st.priv_ring, A.out.priv_ahead,
+                       3, HGYM_PRIV_FRAME, HistGeom<3, HGYM_PRIV_FRAME, 2>::kSlots);
         }
+        if (!(xbot && A.out.obs_older_ready))
+            for (int t = 0; t < nthreads; ++t) {   // the device runs this on its idle wavefronts, concurrently with phase A
+                if (xbot) env_step_stack_old<15, 3, 0>(A, b, t, nthreads, ring);
+                else env_step_stack_old<0, 0, 0>(A, b, t, nthreads, ring);
+            }
         for (int t = 0; t < nthreads; ++t) env_stage_out<0>(A, b, t, nthreads, smem.data());
         for (int t = 0; t < nthreads; ++t) {
-            if (cfg->frame_stack == 15 && cfg->c_frame_stack == 3) env_step_phase_b<15, 3, 0>(A, b, t, nthreads, smem.data(), csc0, ring);
+            if (xbot) env_step_phase_b<15, 3, 0>(A, b, t, nthreads, smem.data(), csc0, ring);
             else env_step_phase_b<0, 0, 0>(A, b, t, nthreads, smem.data(), csc0, ring);
         }
     }

@@ -73,6 +73,20 @@ def test_random_trace_host(N, layout, epb, nthreads, split):
     assert counts["push"] == 1 and counts["timeout"] >= 1 and counts["reset"] >= 3
 
 
+@pytest.mark.parametrize("split", [False, True])
+@pytest.mark.parametrize("N,epb,nthreads", [(37, 8, 64), (64, 32, 512), (5, 4, 32)])
+def test_rows_written_one_step_ahead_host(N, epb, nthreads, split):
+    """hgym_rollout_step's rows-ahead protocol (HgymEnvOut.obs_ahead / priv_ahead / obs_older_ready, header v5) on the kernel source:
+    every step writes the older frames of the rows AFTER next through the device's item geometry (hist_slot<H, F, 2>) plus its own frame,
+    and from the second step on copies no older frames into its own rows.  The stacked observations are compared with the oracle
+    after every step (a frame nobody wrote would be NaN), over time-outs / resets -- whose pre-written frames have to come out
+    zero -- a push and command resampling; 34 steps: the 15-slot ring goes round more than twice."""
+    be = EC.HostBackend(envs_per_block=epb, nthreads=nthreads, split=split)
+    counts, env, o = EC.run_random_trace(be, N, steps=34, seed=500 + N, rows_ahead=True)
+    assert counts["push"] == 1 and counts["timeout"] >= 1 and counts["reset"] >= 3
+    assert env._k == 34 and env._ready
+
+
 @pytest.mark.parametrize("track_sum,moves", [(40.0, 1), (5.0, 0)])
 def test_generic_options_random_trace_host(track_sum, moves):
     """Oracle vs kernel source with the terrain map, both curricula and the height measurements on; the command range widens
