@@ -43,7 +43,7 @@ import torch  # noqa: E402
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak
 REFERENCE_ROOT = "/root/reference"
-EXTRA_CONFIGS = ("envs8192", "logging", "dwl")
+EXTRA_CONFIGS = ("envs8192", "logging", "dwl", "fp32")
 
 
 def parse():
@@ -440,6 +440,21 @@ def main():
             elif c == "dwl":
                 r = run_config(args, "humanoid_dwl_ppo", 4096, 0, 1, local, None, k_steps, k_warm, want_roofline=False, quiet=True)
                 e = dict(name="dwl_head", logging=False, note="BASELINE configs[4] on one GPU; parity of the head is unpinned (no reference code)")
+            elif c == "fp32":
+                if args.precision == "f32":
+                    continue
+                # the headline workload at the REFERENCE's own arithmetic (fp32 end to end, actor_critic.py:53-80): context beside
+                # the bf16 headline BASELINE.json names; the generic layer-by-layer path (gemm_nt_kernel<float>), same env kernels
+                PPO.precision = "f32"
+                os.environ["HGYM_PRECISION"] = "f32"
+                try:
+                    r = run_config(args, "humanoid_ppo", 4096, 0, 1, local, None, k_steps, k_warm, want_roofline=False, quiet=True)
+                finally:
+                    PPO.precision = args.precision
+                    os.environ["HGYM_PRECISION"] = args.precision
+                e = dict(name="fp32", logging=False, dtype="f32",
+                         note="the headline workload with fp32 dense layers (f32-input MFMA, 157 TFLOP/s peak) -- the reference's own "
+                              "arithmetic; env / GAE / loss / Adam are fp32 in both")
             else:
                 continue
             if "checkpoint_ms_total" in r:

@@ -87,6 +87,7 @@ def test_fused_synthetic_step_host_vs_oracle(N, epb, nthreads, split):
         counts["reset"] += int(o.reset.sum())
         counts["timeout"] += int(o.time_out.sum())
         counts["push"] += int(info["pushed"])
+    SC.report("kernel source on the host (hc_env_step_ex, fused, split=%d) vs oracle, N=%d, 30 steps: %s" % (split, N, counts), flips[0])
     assert counts["push"] == 1 and counts["timeout"] >= 3 and counts["reset"] > counts["timeout"] - 1
     assert int(buf.counters[0]) == 397 + 30
 
@@ -125,7 +126,7 @@ def test_env_step_synth_internal_philox_vs_oracle_gpu(N, steps):
         counts["timeout"] += int(o.time_out.sum())
         counts["base_hit"] += int((o.reset & ~o.time_out).sum())
         counts["push"] += int(info["pushed"])
-    print("internal-Philox env step vs oracle, N=%d, %d steps: %s, low_speed threshold flips forgiven: %d" % (N, steps, counts, flips[0]))
+    SC.report("internal-Philox env step (hgym_env_step_synth) vs oracle, N=%d, %d steps: %s" % (N, steps, counts), flips[0])
     assert counts["push"] == 1 and counts["timeout"] >= 3 and counts["base_hit"] >= 3
 
 
@@ -199,6 +200,86 @@ def test_rollout_step_env_part_vs_oracle_gpu(monkeypatch, ahead):
     # the env state the rollout leaves behind (the last step used the primary rew / reset / time_out set)
     o.rew = buf.rew.cpu().clone() if flips[0] else o.rew
     EC.compare_state(SC.Holder(buf), o, "after the rollout", check_obs=False)
-    print("fused rollout step, env part vs oracle: %s, low_speed threshold flips forgiven: %d" % (counts, flips[0]))
+    SC.report("fused rollout step (hgym_rollout_step, rows ahead: %s), env part vs oracle, N=%d, %d steps: %s" % (ahead, N, T, counts), flips[0])
     assert counts["push"] == 1 and counts["timeout"] >= 3 and counts["reset"] > counts["timeout"] and counts["boot"] >= 3
     assert int(buf.counters[0]) == 390 + T and int(alg._sample_step) == T
+
+
+@pytest.mark.gpu
+def test_two_launch_rollout_8192_envs_vs_oracle_gpu(monkeypatch):
+    """BASELINE configs[3]'s TIMED rollout at its own size: 8192 envs take the two-launch path -- `hgym_policy_act_fin`
+    (64-row policy tiles, `mlp_fwd_kernel<64,16,2>`, the previous step's finaliser riding as one extra workgroup) then
+    `hgym_env_step_synth` with `defer_finalize`, internal Philox and the transition sink -- driven exactly as
+    OnPolicyRunner.learn's loop body drives it, 20 steps, against oracle/synth_env_oracle.py fed the stored actions: dones
+    bit-exact, next observations / privileged observations / bootstrapped rewards 1e-5.
+    Reference: /root/reference/humanoid/algo/ppo/on_policy_runner.py:129-141."""
+    from humanoid.algo import PPO
+    from humanoid.envs import task_registry
+    from humanoid.utils import get_args
+    PPO.precision = "bf16"
+    monkeypatch.setenv("HGYM_GRAPH", "0")
+    torch.manual_seed(98)
+    np.random.seed(98)
+    N, T = 8192, 20
+    args = get_args(["--task=humanoid_ppo", "--headless", "--num_envs", str(N), "--seed", "23"])
+    task_registry.train_cfgs[args.task].seed = 23
+    env, _ = task_registry.make_env(name=args.task, args=args)
+    runner, _ = task_registry.make_alg_runner(env=env, name=args.task, args=args, log_root=None)
+    alg, buf = runner.alg, env._buf
+    assert not env.rollout_fused_supported(alg.net)          # two 32-row tiles per CU do not fit one round: the runner's other branch
+    seed = int(env._ncfg.seed)
+    g = torch.Generator().manual_seed(5)
+    SC.plant(buf, None, g, csc=392)
+    torch.cuda.synchronize()
+    o = SC.oracle_from_buffers(buf)
+    st = alg.storage
+    obs_all, priv_all = st._obs_all, st._priv_all
+    obs_all[0].copy_(env.get_observations())
+    priv_all[0].copy_(env.get_privileged_observations())
+    alg.env_stores_transitions = True
+    try:
+        with torch.inference_mode():
+            obs, pobs, fin = obs_all[0], priv_all[0], None
+            for i in range(T):                                  # on_policy_runner.py (this repo): rollout(), the defer_ok branch
+                actions = alg.act(obs, pobs, env_fin=fin)
+                env.bind_outputs(obs_all[i + 1], priv_all[i + 1])
+                env.bind_transition(alg.transition_sink(), defer_finalize=True)
+                obs, pobs, rewards, dones, infos = env.step(actions)
+                fin = env.take_pending_finalize()
+                assert fin is not None
+                alg.process_env_step(rewards, dones, infos, stored=True)
+            env.run_finalize(fin)
+        torch.cuda.synchronize()
+    finally:
+        env.bind_outputs(None, None)
+        env.bind_transition(None)
+        alg.env_stores_transitions = False
+    flips = [0]
+    counts = dict(reset=0, timeout=0, push=0, boot=0)
+    for i in range(T):
+        a = st.actions[i].cpu()
+        obs_o, priv_o, rew_o, reset_o, info = S.synth_step(o, seed, a)
+        rew_dev_boot = st.rewards[i].view(-1).cpu()
+        boot = alg.gamma * (st.values[i].view(-1).cpu() * o.extras_time_outs.float())        # ppo.py:107-108
+        want = o.rew + boot
+        d = (rew_dev_boot - want).abs()
+        bad = (d > (EC.ATOL + EC.RTOL * want.abs())).nonzero().flatten().tolist()
+        for e in bad:                               # low_speed threshold flips (tests/synth_common.py): counted, re-synchronised
+            assert float(d[e]) <= SC.LOW_SPEED_QUANTUM, (i, e, float(d[e]))
+            o.rew[e] = rew_dev_boot[e] - boot[e]
+            o.episode_sums[e, K.REWARD_NAMES.index("low_speed")] += (rew_dev_boot[e] - want[e])
+        flips[0] += len(bad)
+        EC.exact(st.dones[i].view(-1), reset_o, "dones %d" % i)
+        EC.close(obs_all[i + 1], obs_o, "next obs %d" % i)
+        EC.close(priv_all[i + 1], priv_o, "next privileged obs %d" % i)
+        counts["reset"] += int(reset_o.sum())
+        counts["timeout"] += int(o.time_out.sum())
+        counts["push"] += int(info["pushed"])
+        counts["boot"] += int((boot != 0).sum())
+    assert flips[0] <= 2, flips
+    o.rew = buf.rew.cpu().clone() if flips[0] else o.rew
+    EC.compare_state(SC.Holder(buf), o, "after the two-launch rollout", check_obs=False)
+    SC.report("two-launch rollout (policy_act_fin<64-row tiles> + env_step_synth, deferred finaliser), N=8192, %d steps vs oracle: %s"
+              % (T, counts), flips[0])
+    assert counts["push"] == 1 and counts["timeout"] >= 3 and counts["reset"] > counts["timeout"] and counts["boot"] >= 3
+    assert int(buf.counters[0]) == 392 + T and int(alg._sample_step) == T
