@@ -217,7 +217,7 @@ static int32_t launch_step(const HgymEnvConfig* cfg, const HgymSimTensors* sim, 
         HG_REQUIRE(st->custom_rew && st->custom_sums && st->custom_acc && out->extras_custom, HGYM_E_BADARG,
                    "user-defined reward terms need custom_rew / custom_sums / custom_acc / extras_custom");
         for (int j = 0; j < cfg->num_custom_rewards; ++j)
-            HG_REQUIRE(cfg->custom_reward_pos[j] >= 0 && cfg->custom_reward_pos[j] <= HGYM_NUM_REWARDS, HGYM_E_SHAPE, "custom_reward_pos[%d]=%d",
+            HG_REQUIRE(cfg->custom_reward_pos[j] >= 0 && cfg->custom_reward_pos[j] <= HGYM_NUM_REWARDS + 1, HGYM_E_SHAPE, "custom_reward_pos[%d]=%d",
                        j, cfg->custom_reward_pos[j]);
     }
     HG_REQUIRE(sim && out, HGYM_E_BADARG, "null sim/out");

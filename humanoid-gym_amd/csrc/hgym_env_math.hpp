@@ -724,7 +724,7 @@ HG_HD StepFlags post_physics_env(const EnvArgs& A, const RngKey& rk, int64_t csc
 
             // user-defined terms (legged_robot.py:518-541 discovers `_reward_<name>` by name; the caller evaluated them between the
             // derive and the finish launch, already times scale * dt): merged into the sum at their place in the alphabetical order
-            // -- custom term j comes right before built-in term custom_reward_pos[j] (22: after all of them)
+            // -- custom term j comes right before built-in term custom_reward_pos[j] (22: after all of them; 23: after the clip)
             const int ncust = (kGeneric && phase == 2) ? c.num_custom_rewards : 0;
             auto add_custom = [&](int k) {
                 for (int j = 0; j < ncust; ++j)
@@ -744,6 +744,9 @@ HG_HD StepFlags post_physics_env(const EnvArgs& A, const RngKey& rk, int64_t csc
             }
             if (kGeneric && ncust > 0) add_custom(HGYM_NUM_REWARDS);
             if (c.only_positive_rewards) rew = fmaxf(rew, 0.0f);
+            // "termination" is not in the reference's function list: it is added AFTER the clip (legged_robot.py:229-235, :533-534);
+            // a user-defined `_reward_termination` arrives with custom_reward_pos = HGYM_NUM_REWARDS + 1
+            if (kGeneric && ncust > 0) add_custom(HGYM_NUM_REWARDS + 1);
           }
         }
     } else {

@@ -16,7 +16,7 @@ NUM_REWARDS = 22
 OBS_FRAME = 47
 PRIV_FRAME = 73
 MAX_LAYERS = 8
-MAX_CUSTOM_REWARDS = 8
+MAX_CUSTOM_REWARDS = 24
 F32, BF16 = 0, 1
 
 c_float_p = C.POINTER(C.c_float)

@@ -120,6 +120,8 @@ class PPO:
         dist_utils.broadcast_parameters(ac.parameters())   # identical initial parameters on every rank
         ac.bind(self.net)
         # bf16 shadows of the stored observation rows: the policy launches leave them behind, the update gathers from them
+        # (environment knobs are read ONCE, here: a captured rollout graph keeps whatever was active at capture)
+        self._check_shadow = os.environ.get("HGYM_CHECK_SHADOW", "0") == "1"
         if os.environ.get("HGYM_SHADOW", "1") != "0":
             self.storage.enable_shadow(self.net.shadow_ld(0), self.net.shadow_ld(1))
         self._ppo_cfg = hgym.make_ppo_config(self.clip_param, self.value_loss_coef, self.entropy_coef, self.max_grad_norm,
@@ -241,6 +243,8 @@ class PPO:
         cols = (obs, priv, fl(st.actions), st.values.view(-1), st.advantages.view(-1), st.returns.view(-1),
                 st.actions_log_prob.view(-1), fl(st.mu), fl(st.sigma))
         sh = st.shadows() if hasattr(st, "shadows") else None
+        if sh is not None and self._check_shadow:
+            st.check_shadows()
         sh = dict(obs_bf16=sh[0], priv_bf16=sh[1]) if sh is not None else {}
         net.opt_state[2:8] = 0.0               # the per-update sums [2..5], [7] (and the informational last norm [6]): one fill
         if self._ppo_cfg.aux_coef > 0.0:

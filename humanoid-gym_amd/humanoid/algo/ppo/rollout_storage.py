@@ -88,18 +88,35 @@ class RolloutStorage:
         if self.step >= self.num_transitions_per_env:
             raise AssertionError("Rollout buffer overflow")
         s = self.step
-        pairs = [(self.observations[s], transition.observations), (self.actions[s], transition.actions),
-                 (self.rewards[s], transition.rewards.view(-1, 1)), (self.dones[s], transition.dones.view(-1, 1)),
-                 (self.values[s], transition.values), (self.actions_log_prob[s], transition.actions_log_prob.view(-1, 1)),
-                 (self.mu[s], transition.action_mean), (self.sigma[s], transition.action_sigma)]
+        # (name, destination, source, does the slot's bf16 shadow describe this column?)
+        pairs = [("observations", self.observations[s], transition.observations, True), ("actions", self.actions[s], transition.actions, False),
+                 ("rewards", self.rewards[s], transition.rewards.view(-1, 1), False), ("dones", self.dones[s], transition.dones.view(-1, 1), False),
+                 ("values", self.values[s], transition.values, False),
+                 ("actions_log_prob", self.actions_log_prob[s], transition.actions_log_prob.view(-1, 1), False),
+                 ("mu", self.mu[s], transition.action_mean, False), ("sigma", self.sigma[s], transition.action_sigma, False)]
         if self.privileged_observations is not None:
-            pairs.append((self.privileged_observations[s], transition.critic_observations))
-        for k, (dst, src) in enumerate(pairs):
+            pairs.append(("privileged_observations", self.privileged_observations[s], transition.critic_observations, True))
+        for name, dst, src, shadowed in pairs:
             if not self._same(dst, src):          # producers that already wrote the slot are not copied again
                 dst.copy_(src)
-                if k == 0 or k == 8:              # observations copied in from elsewhere: the slot's bf16 shadow does not describe them
+                if shadowed:                      # observations copied in from elsewhere: the slot's bf16 shadow does not describe them
                     self.shadow_valid[s] = False
         self.step += 1
+
+    def check_shadows(self, rows=64):
+        """Debug aid (HGYM_CHECK_SHADOW=1: PPO.update calls it before gathering from the shadows): a few rows of every slot of the
+        bf16 shadows against bfloat16(fp32 rows) -- catches a caller that wrote `observations[s]` directly behind the policy launch,
+        which the validity flags cannot see."""
+        sh = self.shadows()
+        if sh is None:
+            return
+        T, N = self.num_transitions_per_env, self.num_envs
+        idx = torch.randint(0, T * N, (rows,), device=self.device)
+        for name, full, bf in (("observations", self.observations, sh[0]), ("privileged_observations", self.privileged_observations, sh[1])):
+            want = full.flatten(0, 1)[idx].to(torch.bfloat16)
+            got = bf[idx][:, :want.shape[1]]
+            if not torch.equal(want, got):
+                raise AssertionError("bf16 shadow of %s is stale: a storage slot was written behind the policy launch that shadowed it" % name)
 
     def clear(self):
         self._obs_all[0].copy_(self._obs_all[self.num_transitions_per_env])

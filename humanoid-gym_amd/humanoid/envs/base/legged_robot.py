@@ -244,6 +244,8 @@ class LeggedRobot(BaseTask):
         self._outs = [(b.obs, b.priv_obs), (z(N, self.num_obs), z(N, self.num_privileged_obs))]
         self._flip = 0
         self._bound_out = None
+        # A/B knob, read once (a captured rollout graph keeps the protocol active at capture; OnPolicyRunner's graph key includes it)
+        self._rows_ahead = os.environ.get("HGYM_ROWS_AHEAD", "1") != "0"
         self._sim_s, self._st_s = b.sim_struct(), b.state_struct()
         self._noise_none = b.noise_struct()
         self.common_step_counter_buf = b.counters
@@ -306,8 +308,10 @@ class LeggedRobot(BaseTask):
         sums = self._buf.f["episode_sums"]
         self.episode_sums = {name: sums[KERNEL_REWARD_TERMS.index(name)] for name in self.reward_names if name not in custom}
         if custom:
-            # custom term j is summed right before the first built-in term that sorts at or after it
-            self._buf.set_custom_rewards([sum(1 for b in KERNEL_REWARD_TERMS if b < name) for name in custom])
+            # custom term j is summed right before the first built-in term that sorts at or after it; `termination` is not in the
+            # reference's function list at all: it is added after the only-positive clip (legged_robot.py:229-235, :533-534)
+            self._buf.set_custom_rewards([len(KERNEL_REWARD_TERMS) + 1 if name == "termination" else
+                                          sum(1 for b in KERNEL_REWARD_TERMS if b < name) for name in custom])
             self._st_s = self._buf.state_struct()
             for j, name in enumerate(custom):
                 self.episode_sums[name] = self._buf.custom_sums[j]
@@ -409,8 +413,8 @@ class LeggedRobot(BaseTask):
         `iteration` learning iterations has it, so that a resumed run continues the env's draw streams instead of replaying them
         from step 0.  The reference's checkpoint carries no generator state either (on_policy_runner.py:274-281); the counter is
         a function of the iteration number.  The history ring position is left alone."""
-        if not hasattr(self, "_seek_base"):
-            self._seek_base = int(self._buf.counters[0])       # the freshly constructed + reset env (= iteration 0)
+        if not hasattr(self, "_seek_base"):                    # no reset() yet: this IS the fresh env
+            self._seek_base = int(self._buf.counters[0])
         self._buf.counters[0] = self._seek_base + int(iteration) * int(steps_per_iteration)
 
     # ------------------------------------------------------------------ fused rollout step (native extension)
@@ -453,7 +457,7 @@ class LeggedRobot(BaseTask):
         L = self._L
         parity = (self._ro_T - 1 - i) & 1
         o = self._buf.out_struct(next_obs, next_priv, sink, True, alt=bool(parity))
-        if os.environ.get("HGYM_ROWS_AHEAD", "1") == "0":
+        if not self._rows_ahead:
             ahead = None
         o.obs_older_ready = int(self._ro_prev is not None and self._ro_ahead is not None
                                 and self._ro_ahead == (next_obs.data_ptr(), next_priv.data_ptr()))
@@ -548,6 +552,10 @@ class LeggedRobot(BaseTask):
         """legged_robot.py:112-117: reset every env, then one zero-action step."""
         self.reset_idx(torch.arange(self.num_envs, device=self.device))
         obs, privileged_obs, _, _, _ = self.step(torch.zeros(self.num_envs, self.num_actions, device=self.device))
+        if not hasattr(self, "_seek_base"):
+            # iteration 0 of seek(): the counter right after the FIRST reset (OnPolicyRunner.__init__ calls it), recorded here and not
+            # lazily in seek() -- a load() after learn() would otherwise take the already-advanced counter for the base
+            self._seek_base = int(self._buf.counters[0])
         return obs, privileged_obs
 
     def _prime(self):

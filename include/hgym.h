@@ -50,7 +50,8 @@ enum {
 #define HGYM_OBS_FRAME 47   /* num_single_obs,           envs/custom/humanoid_config.py:41 */
 #define HGYM_PRIV_FRAME 73  /* single_num_privileged_obs, envs/custom/humanoid_config.py:43 */
 #define HGYM_MAX_LAYERS 8
-#define HGYM_MAX_CUSTOM_REWARDS 8   /* user-defined reward terms per env (HgymEnvConfig.num_custom_rewards) */
+#define HGYM_MAX_CUSTOM_REWARDS 24  /* user-defined reward terms per env (HgymEnvConfig.num_custom_rewards): room for a task class that
+                                      * defines every one of its terms itself, the reference's way */
 
 int32_t hgym_version(void);
 const char* hgym_last_error(void);
@@ -124,7 +125,9 @@ typedef struct HgymEnvConfig {
      * `_reward_<name>`, found by name).  The 22 XBot-L terms are built in; any OTHER name is evaluated by the caller between
      * hgym_env_step_begin and hgym_env_step_end (what the reference has computed by the time compute_reward runs is then in the
      * state) and handed in through HgymEnvState.custom_rew.  custom_reward_pos[j] = how many built-in terms precede custom
-     * term j in the alphabetical order the reference sums in (0 .. 22): the fp32 sum is formed in that merged order. */
+     * term j in the alphabetical order the reference sums in (0 .. 22): the fp32 sum is formed in that merged order.
+     * 23 (= HGYM_NUM_REWARDS + 1): the term is added AFTER the only_positive_rewards clip -- the reference's `termination`
+     * (legged_robot.py:229-235; it is skipped in the function list, :533-534). */
     int32_t num_custom_rewards;
     int32_t custom_reward_pos[HGYM_MAX_CUSTOM_REWARDS];
 } HgymEnvConfig;

@@ -530,6 +530,8 @@ class XBotEnvOracle:
         scales = torch.tensor(C.REWARD_SCALES_DT, dtype=torch.float64)
         self.reward_terms = torch.zeros(self.n, C.NUM_REWARDS)
         for name in sorted(set(C.REWARD_NAMES) | set(extra)):
+            if name == "termination":      # legged_robot.py:533-534: not in the function list; added after the clip (:229-235)
+                continue
             if name in extra:
                 self.rew = self.rew + extra[name]
                 self.extra_sums[name] = self.extra_sums[name] + extra[name]
@@ -540,6 +542,9 @@ class XBotEnvOracle:
             self.episode_sums[:, k] += term
             self.reward_terms[:, k] = term
         self.rew = torch.clip(self.rew, min=0.0)
+        if "termination" in extra:         # legged_robot.py:231-235
+            self.rew = self.rew + extra["termination"]
+            self.extra_sums["termination"] = self.extra_sums["termination"] + extra["termination"]
         any_reset = self._reset_masked(self.reset.clone(), u_dof, u_cmd[:, 3:6], u_xy, r_level)
         frame, priv_frame = self._observe(z_obs)
         self.last_last_actions = self.last_actions.clone()

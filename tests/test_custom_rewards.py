@@ -22,6 +22,8 @@ TERMS = {
     "heading_err": (-0.5, lambda o: torch.abs(o.commands[:, 2]), lambda b: torch.abs(b.view("commands")[:, 2])),
     "torques": (dict(K.REWARD_SCALES_RAW)["torques"], lambda o: torch.sum(torch.abs(o.torques), dim=1),
                 lambda b: torch.sum(torch.abs(b.view("torques")), dim=1)),
+    # `termination` is summed AFTER the only-positive clip (legged_robot.py:229-235): position HGYM_NUM_REWARDS + 1
+    "termination": (-2.0, lambda o: (o.reset & ~o.time_out).float(), lambda b: (b.reset & ~b.time_out).float()),
     "zz_dof": (-0.01, lambda o: torch.sum(torch.square(o.sim.dof_pos), dim=1), lambda b: torch.sum(torch.square(b.dof_pos_view()), dim=1)),
 }
 NAMES = sorted(TERMS)
@@ -59,7 +61,7 @@ def run_custom_trace(be, N, steps, seed):
     env = EC.EnvUnderTest(be, N, fr, bm)
     b, cfg = env.buf, env.cfg
     kernel_names = list(K.REWARD_NAMES)
-    b.set_custom_rewards([sum(1 for x in kernel_names if x < n) for n in NAMES])
+    b.set_custom_rewards([len(kernel_names) + 1 if n == "termination" else sum(1 for x in kernel_names if x < n) for n in NAMES])
     cfg.reward_scales[kernel_names.index("torques")] = 0.0          # overridden: the kernel's own term is switched off
     env.sim, env.st, env.out = b.sim_struct(), b.state_struct(), b.out_struct()
     sp = SplitStepBackend(be)
@@ -121,7 +123,7 @@ def test_single_launch_entry_points_refuse_custom_terms_host():
     here: the configuration fields exist and default to none)."""
     from hgym import default_env_config
     cfg = default_env_config(8)
-    assert cfg.num_custom_rewards == 0 and list(cfg.custom_reward_pos) == [0] * 8
+    assert cfg.num_custom_rewards == 0 and list(cfg.custom_reward_pos) == [0] * 24
 
 
 # ------------------------------------------------------------------------------------------------ GPU
