@@ -113,6 +113,45 @@ __device__ __forceinline__ u32x4 ld_stream_u4(const char* p) {
 }
 __device__ __forceinline__ float bf16_bits_to_f32(unsigned int lo16) { return __builtin_bit_cast(float, lo16 << 16); }
 
+// Epilogue stores, 16 bytes per lane.  An MFMA epilogue lane (r = lane & 15, q = lane >> 4) holds 4 consecutive bf16 columns of row r of a
+// 16 x 16 block: 8 bytes at r * 32 + q * 8, so the natural store is one dwordx2 per block -- and the update's tiles turned out to be
+// paced by store ISSUE (round 4: without its H / dZ stores mlp_fb2_kernel ran 271 instead of 440 us on a slow-class box; MI355X_MICROARCH.md:
+// a dwordx2 store tail moves ~7 B/clk/CU, dwordx4 twice that).  For TWO blocks A and B (same lane offsets), v_permlane16_swap_b32 exchanges
+// the odd 16-lane rows of A's register with the even rows of B's: afterwards a lane with q even holds columns 8 (q / 2) .. + 7 of row r of
+// block A (its own 8 bytes and its right neighbour's), a lane with q odd the same of block B -- one dwordx4 per lane for the pair, same
+// bytes, same addresses, half the store instructions.  HGYM_WIDE_ST=0 restores the dwordx2 form (A/B builds).
+#ifndef HGYM_WIDE_ST
+#define HGYM_WIDE_ST 1
+#endif
+#ifndef HGYM_WIDE_OLD
+#define HGYM_WIDE_OLD 0      // the 16-wave kernels of this file run at their 128-register cap: the pairing spills there (20 B of private segment)
+#endif
+template <bool NT>
+__device__ __forceinline__ void st_stream_u4(char* p, u32x4 v) {
+    if (NT) __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(p));
+    else *reinterpret_cast<u32x4*>(p) = v;
+}
+// pa / pb: block A / B base + this lane's r * 32 + q * 8; oka / okb: whether block A / B is stored at all (wave-uniform)
+template <bool NT, bool WIDE = true>
+__device__ __forceinline__ void st_pair(char* pa, char* pb, u32x2 a, u32x2 b, bool oka, bool okb, int q) {
+    if constexpr (!WIDE) {
+        if (oka) st_stream_u2<NT>(pa, a);
+        if (okb) st_stream_u2<NT>(pb, b);
+        return;
+    }
+#if HGYM_WIDE_ST
+    const auto s0 = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false);
+    const auto s1 = __builtin_amdgcn_permlane16_swap(a[1], b[1], false, false);
+    const u32x4 v = {s0[0], s1[0], s0[1], s1[1]};
+    const bool odd = q & 1;
+    char* p = odd ? pb - 8 : pa;
+    if (odd ? okb : oka) st_stream_u4<NT>(p, v);
+#else
+    if (oka) st_stream_u2<NT>(pa, a);
+    if (okb) st_stream_u2<NT>(pb, b);
+#endif
+}
+
 // ---- weight stream ------------------------------------------------------------------------------------------------------
 // The weight fragments of one output strip (G n-blocks) stream from L2 into a register ring of D k-steps per wavefront:
 // slot t % D holds k-step t, and the slot is re-loaded with k-step t + D as soon as its MFMAs have been issued, so D - 1
@@ -323,17 +362,25 @@ __device__ __forceinline__ void epilogue_elu_t(f32x4 (&acc)[MB][G], const float*
                                                __bf16* __restrict__ Hg, int64_t mbg0, int lane) {
     const int r = lane & 15, q = lane >> 4;
     const int loff = r * 32 + q * 8;
+    static_assert(MB % 2 == 0, "row blocks are stored in pairs");
 #pragma unroll
     for (int g = 0; g < G; ++g) {
         const F4 b = *reinterpret_cast<const F4*>(bias + (nb0 + g) * 16 + 4 * q);
 #pragma unroll
-        for (int i = 0; i < MB; ++i) {
-            float v[4];
+        for (int i = 0; i < MB; i += 2) {
+            u32x2 pk[2];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = elu_bf(acc[i][g][e] + b.v[e]);
-            const u32x2 pk = pack_bf16x4(v[0], v[1], v[2], v[3]);
-            *reinterpret_cast<u32x2*>(out_lds + (i * CBo + nb0 + g) * 512 + loff) = pk;
-            if (STORE) st_stream_u2<(HGYM_NT & 2) != 0>(reinterpret_cast<char*>(Hg) + ((mbg0 + i) * CBo + nb0 + g) * 512 + loff, pk);
+            for (int h = 0; h < 2; ++h) {
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = elu_bf(acc[i + h][g][e] + b.v[e]);
+                pk[h] = pack_bf16x4(v[0], v[1], v[2], v[3]);
+                *reinterpret_cast<u32x2*>(out_lds + ((i + h) * CBo + nb0 + g) * 512 + loff) = pk[h];
+            }
+            if (STORE) {
+                char* pa = reinterpret_cast<char*>(Hg) + ((mbg0 + i) * CBo + nb0 + g) * 512 + loff;
+                st_pair<(HGYM_NT & 2) != 0, HGYM_WIDE_OLD != 0>(pa, pa + (int64_t)CBo * 512, pk[0], pk[1], true, true, q);
+            }
         }
     }
 }
@@ -772,19 +819,25 @@ __device__ __forceinline__ void bwd_step(WRing<GR, D>& R, const u32x4* __restric
                 if (HLDS) aux[i][g] = *reinterpret_cast<const u32x2*>(H_lds + (i * NBo + nb0 + g) * 512 + loff);
                 else aux[i][g] = ld_stream_u2<(HGYM_NT & 4) != 0>(reinterpret_cast<const char*>(Hg) + ((mbg0 + i) * NBo + nb0 + g) * 512 + loff);
             }
+        static_assert(MB % 2 == 0, "row blocks are stored in pairs");
 #pragma unroll
-        for (int i = 0; i < MB; ++i)
+        for (int i = 0; i < MB; i += 2)
 #pragma unroll
             for (int g = 0; g < G; ++g) {
-                const unsigned int w0 = aux[i][g][0], w1 = aux[i][g][1];
-                const float y[4] = {bf16_bits_to_f32(w0 & 0xffffu), bf16_bits_to_f32(w0 >> 16), bf16_bits_to_f32(w1 & 0xffffu),
-                                    bf16_bits_to_f32(w1 >> 16)};
-                float d[4];
+                u32x2 pk[2];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) d[e] = acc[i][g][e] * ((y[e] > 0.0f) ? 1.0f : (y[e] + 1.0f));   // elu'(z) from y = elu(z)
-                const u32x2 pk = pack_bf16x4(d[0], d[1], d[2], d[3]);
-                if (out_lds) *reinterpret_cast<u32x2*>(out_lds + (i * NBo + nb0 + g) * 512 + loff) = pk;
-                st_stream_u2<(HGYM_NT & 4) != 0>(reinterpret_cast<char*>(dZg) + ((mbg0 + i) * NBo + nb0 + g) * 512 + loff, pk);
+                for (int h = 0; h < 2; ++h) {
+                    const unsigned int w0 = aux[i + h][g][0], w1 = aux[i + h][g][1];
+                    const float y[4] = {bf16_bits_to_f32(w0 & 0xffffu), bf16_bits_to_f32(w0 >> 16), bf16_bits_to_f32(w1 & 0xffffu),
+                                        bf16_bits_to_f32(w1 >> 16)};
+                    float d[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) d[e] = acc[i + h][g][e] * ((y[e] > 0.0f) ? 1.0f : (y[e] + 1.0f));   // elu'(z) from y = elu(z)
+                    pk[h] = pack_bf16x4(d[0], d[1], d[2], d[3]);
+                    if (out_lds) *reinterpret_cast<u32x2*>(out_lds + ((i + h) * NBo + nb0 + g) * 512 + loff) = pk[h];
+                }
+                char* pa = reinterpret_cast<char*>(dZg) + ((mbg0 + i) * NBo + nb0 + g) * 512 + loff;
+                st_pair<(HGYM_NT & 4) != 0, HGYM_WIDE_OLD != 0>(pa, pa + (int64_t)NBo * 512, pk[0], pk[1], true, true, q);
             }
     }
     if (AHEAD && !primed) prime_next();
@@ -1081,6 +1134,9 @@ struct ScalArgs {
     float* kl_slot;
     double* opt;
     double beta1, beta2;   // Adam's: beta^t of the step this gradient will be applied in is left in opt[13..15] (below)
+    int group;             // 0 / 1: `partials` holds one row per loss workgroup; 4: one row per 16-row block (mlp_fb2_kernel), four
+                           // consecutive rows are added first, ((p0 + p1) + p2) + p3 in fp32 -- the sum mlp_fb_kernel's 64-row tile forms
+                           // over its four head waves -- and nblocks counts those groups
 };
 __device__ __forceinline__ void ppo_scalars_block(const ScalArgs& a, int tid, int nthreads) {
     __shared__ double red[16][LOSS_PARTIALS + 1];
@@ -1101,12 +1157,25 @@ __device__ __forceinline__ void ppo_scalars_block(const ScalArgs& a, int tid, in
         // latency-bound once the fused forward + backward kernel started handing in one partial row per 64-row tile (960 rows)
         double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
         int b = part;
-        for (; b + 48 < nblocks; b += 64) {
-            const float v0 = partials[(int64_t)b * LOSS_PARTIALS + k], v1 = partials[(int64_t)(b + 16) * LOSS_PARTIALS + k];
-            const float v2 = partials[(int64_t)(b + 32) * LOSS_PARTIALS + k], v3 = partials[(int64_t)(b + 48) * LOSS_PARTIALS + k];
-            s0 += (double)v0; s1 += (double)v1; s2 += (double)v2; s3 += (double)v3;
+        if (a.group == 4) {
+            auto ld = [&](int g) -> float {
+                const float* p = partials + (int64_t)g * 4 * LOSS_PARTIALS + k;
+                const float p0 = p[0], p1 = p[LOSS_PARTIALS], p2 = p[2 * LOSS_PARTIALS], p3 = p[3 * LOSS_PARTIALS];
+                return ((p0 + p1) + p2) + p3;
+            };
+            for (; b + 48 < nblocks; b += 64) {
+                const float v0 = ld(b), v1 = ld(b + 16), v2 = ld(b + 32), v3 = ld(b + 48);
+                s0 += (double)v0; s1 += (double)v1; s2 += (double)v2; s3 += (double)v3;
+            }
+            for (; b < nblocks; b += 16) s0 += (double)ld(b);
+        } else {
+            for (; b + 48 < nblocks; b += 64) {
+                const float v0 = partials[(int64_t)b * LOSS_PARTIALS + k], v1 = partials[(int64_t)(b + 16) * LOSS_PARTIALS + k];
+                const float v2 = partials[(int64_t)(b + 32) * LOSS_PARTIALS + k], v3 = partials[(int64_t)(b + 48) * LOSS_PARTIALS + k];
+                s0 += (double)v0; s1 += (double)v1; s2 += (double)v2; s3 += (double)v3;
+            }
+            for (; b < nblocks; b += 16) s0 += (double)partials[(int64_t)b * LOSS_PARTIALS + k];
         }
-        for (; b < nblocks; b += 16) s0 += (double)partials[(int64_t)b * LOSS_PARTIALS + k];
         red[part][k] = (s0 + s1) + (s2 + s3);
     }
     __syncthreads();

@@ -16,6 +16,7 @@
 
 #include "hgym_gemm.hpp"
 #include "hgym_fused.hpp"
+#include "hgym_fb2.hpp"
 
 namespace hgym {
 
@@ -936,11 +937,37 @@ struct NetRunner {
         float* outs[3] = {mu, val, nullptr};
         const int64_t ldos[3] = {A, 1, 0};
         const int Bp = (int)round_up(B, 64);
-        const int tiles = Bp / 64;
         const int nets = aux_fb ? 3 : 2;
+        // 128-row tiles (hgym_fb2.hpp), OPT-IN (HGYM_FB2=1): measured equal to slightly slower than the 64-row kernel on every box of
+        // round 4 (282-340 vs 289-340 us per launch; profiles/r04_fb2_128row_tiles_negative_result.txt) -- the launch is paced by its
+        // 0.5 GB of H / dZ stores, not by the L2 -> CU weight stream the taller tile halves.  Shapes it carries: shadow rows, actor +
+        // critic only, 256 / 128 wide second / third layers, 12 actions; a wide input needs a first width of <= 512 (full-width
+        // accumulators), a narrow one any multiple of 256.  Results are bit-identical to mlp_fb_kernel's (tests/test_fused_gpu.py).
+        const char* fb2_env = getenv("HGYM_FB2");                                // read per call: tests flip it
+        const bool no_fb2 = !(fb2_env && fb2_env[0] == '1');
+        bool fb2 = shadow && !no_fb2 && nets == 2 && A == 12;
+        for (int i = 0; i < 2 && fb2; ++i) {
+            const NetLayout& n = w.net[i];
+            const int N0 = n.layer[0].N;
+            fb2 = n.layer[1].N == 256 && n.layer[2].N == 128 && n.layer[3].N <= 16 && N0 % 256 == 0 && N0 <= 768 &&
+                  (n.layer[0].KBf > 8 ? N0 <= 512 : true);
+        }
+        Fb2Sched sch = {0, 0};
+        if (fb2) {
+            // tiles of 7 or 8 row blocks: as many tiles per net as a whole number of rounds over the CUs when that keeps them >= 6 high
+            const int cus = device_cus() > 0 ? device_cus() : 256;
+            sch.nb = Bp / 16;
+            sch.T = ceil_div(sch.nb, 8);
+            const int Tr = (int)round_up(sch.T, cus);
+            if (sch.T > cus && sch.nb / Tr >= 6) sch.T = Tr;
+        }
+        const int tiles = fb2 ? sch.T : Bp / 64;
+        if (fb2) HG_REQUIRE(sch.nb <= MAX_LOSS_BLOCKS, HGYM_E_UNSUPPORTED, "minibatch %d too large for the loss partial buffer", B);
         HG_REQUIRE(tiles <= MAX_LOSS_BLOCKS, HGYM_E_UNSUPPORTED, "minibatch %d too large for the loss partial buffer", B);
         HG_REQUIRE(B <= w.maxM, HGYM_E_SHAPE, "minibatch %d exceeds max_batch %lld", B, (long long)w.maxM);
         int32_t rc = HGYM_OK;
+        const char* only = getenv("HGYM_GRAD_ONLY");      // timing experiments (tools/probe_overlap.py): "fb" / "dw" run just that launch
+        if (!(only && only[0] == 'd'))
         {   // forward + PPO loss + dZ chain of both nets: ONE launch (hgym_fused.hpp: mlp_fb_kernel)
             FwdArgs fa = make_fwd_args(0, nets, B, xs, ldxs, b.idx, outs, ldos, true, nullptr, nullptr);
             fa.net[2].X0 = nullptr;       // the head's first-layer operand for the weight gradient is the actor's copy (fused_dw)
@@ -969,6 +996,25 @@ struct NetRunner {
             fl.aux_ldt = cfg.num_priv;
             fl.aux_off = cfg.aux_target_offset;
             fl.aux_coef = ppo.aux_coef;
+            if (fb2) {
+                size_t lds2 = 0;
+                for (int i = 0; i < nets; ++i) lds2 = std::max(lds2, (size_t)fb2_lds_bytes(fa.net[i]));
+                HG_REQUIRE(lds2 <= 160 * 1024, HGYM_E_UNSUPPORTED, "mlp_fb2_kernel needs %zu bytes of LDS", lds2);
+                const int32_t rc2 = ensure_dynamic_lds(reinterpret_cast<const void*>(&mlp_fb2_kernel), lds2, "mlp_fb2_kernel");
+                if (rc2) return rc2;
+                FwdArgs fb = fa;
+                fb.nets = nets;
+                fb.dbg = phase_buffer((int64_t)tiles * nets);
+                prof_begin(HGYM_PROF_MLP_FWD, s);
+                hipLaunchKernelGGL(mlp_fb2_kernel, dim3(tiles, nets), dim3(FB2_NW * 64), lds2, s, fb, fl, sch);
+                double flops = 0.0;
+                for (int i = 0; i < nets; ++i) {
+                    for (int l = 0; l < 4; ++l) flops += 2.0 * (double)B * w.net[i].layer[l].N * w.net[i].layer[l].K;
+                    for (int l = 1; l < 4; ++l) flops += 2.0 * (double)B * w.net[i].layer[l].K * w.net[i].layer[l].N;
+                }
+                prof_end(HGYM_PROF_MLP_FWD, s, flops);
+                HG_CHECK_LAUNCH("mlp_fb2_kernel");
+            } else {
             size_t lds = 0;
             for (int i = 0; i < nets; ++i)
                 lds = std::max(lds, (size_t)fused_lds_p(fa.net[i], 64) + (size_t)fused_lds_q(fa.net[i], 64) + (size_t)fused_lds_bias(fa.net[i]) +
@@ -990,14 +1036,18 @@ struct NetRunner {
             }
             prof_end(HGYM_PROF_MLP_FWD, s, flops);
             HG_CHECK_LAUNCH("mlp_fb_kernel");
+            }
         }
         // the minibatch's loss scalars (per-tile partials -> opt_state, std / head-bias gradients, KL slot): one extra workgroup of
         // the weight-gradient launch that follows anyway (it needs nothing but the partials mlp_fb_kernel has just written)
-        const ScalArgs sc = {tiles, B, A, aux_fb ? w.net[2].layer[3].N : 0, at<float>(w.partials), net.grads,
+        // (mlp_fb2_kernel hands in one partial row per 16-row block; four of them are one 64-row tile's sum)
+        const ScalArgs sc = {fb2 ? Bp / 64 : tiles, B, A, aux_fb ? w.net[2].layer[3].N : 0, at<float>(w.partials), net.grads,
                              net.grads + w.net[0].layer[3].b_off, net.grads + w.net[1].layer[3].b_off, net.grads + w.P, net.opt_state,
-                             (double)ppo.beta1, (double)ppo.beta2};
+                             (double)ppo.beta1, (double)ppo.beta2, fb2 ? 4 : 1};
+        if (only && only[0] == 'f') return HGYM_OK;
         rc = fused_dw(0, nets, B, &sc, gb);
         if (rc) return rc;
+        if (only && only[0] == 'd') return HGYM_OK;
         if (w.nnets > 2 && !aux_fb) {
             const int32_t rca = aux_grad(ppo, b);
             if (rca) return rca;
@@ -1199,7 +1249,7 @@ struct NetRunner {
         prof_end(HGYM_PROF_LOSS, s, (double)B * (4.0 * (5 * A + 6) + (double)sizeof(T) * (2 * A + 2)));
         HG_CHECK_LAUNCH("ppo_loss_kernel");
         const ScalArgs sc = {nblocks, B, A, 0, at<float>(w.partials), net.grads, nullptr, nullptr, net.grads + w.P, net.opt_state,
-                             (double)ppo.beta1, (double)ppo.beta2};
+                             (double)ppo.beta1, (double)ppo.beta2, 1};
         hipLaunchKernelGGL(ppo_scalars_kernel, dim3(1), dim3(512), 0, s, sc);
         HG_CHECK_LAUNCH("ppo_scalars_kernel");
         cur_Mp = Bp;
