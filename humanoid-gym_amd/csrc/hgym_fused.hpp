@@ -441,6 +441,75 @@ __device__ __forceinline__ void phase_stamp(long long* dbg, int slot) {
 // (<= 2 ulp of log for sigma in [1e-3, 1e3]; the log-probability is compared with the reference at 1e-5 relative).
 __device__ __forceinline__ float log_sigma(float s) { return __fmul_rn(__builtin_amdgcn_logf(s), 0.6931471805599453f); }
 
+// ---- the actor's first layer carried ACROSS launches of the rollout (round 4) ----------------------------------------------------
+// An observation row is a stack of frames: the row of step t + 1 is the row of step t shifted by one frame (47 columns) plus the
+// frame step t produces, so columns [0, 640) of the NEXT row -- 20 of the first layer's 24 k-steps -- are known when launch t starts.
+// Launch t's critic workgroup of the tile (idle from ~16 us of the ~40 us launch on) forms those 20 k-steps of the actor's first
+// layer for the next row (`l0_partial_ahead`) and leaves the fp32 accumulators in the caller's scratch; launch t + 1's actor tile
+// (`fwd_body<.., PART>`) starts from them and runs the last 128-column chunk only: the same fragments, the same k order, the same
+// accumulator chain -- the pre-activations are bit-identical -- and 8 of the first layer's 9.5 us leave the launch's critical path.
+// Rows whose env was reset in between have zero older frames: their partial sums are dropped (0 + the chunk's products, as the
+// reference computes on a zero history).
+struct L0Part {
+    const float* acc;        // [tile][wave][MB * G1][64 lanes][4]: pre-activations over k-steps [0, kb0) left by the previous launch
+    const uint8_t* reset;    // (M,) the previous step's reset flags
+    int kb0;                 // first k-step still to do here (a multiple of 4: whole 128-column chunks)
+};
+struct L0Ahead {
+    float* acc_out;          // the same layout, for the NEXT launch (null: nothing to do)
+    __bf16* xs_next;         // bf16 shadow rows of the next step's observation: columns [0, 32 kb0) are written here (null: no shadow)
+    int64_t ldxs;
+    int shift;               // columns a row shifts by per step (one frame)
+    int kb0;                 // k-steps formed ahead
+};
+
+// by ALL 8 wavefronts of a 32-row workgroup whose own tile is finished (the caller has synchronised): rows m0 .. m0 + 31 of net n's fp32
+// input, columns [shift, shift + 32 kb0) -> bf16 (the rounding fwd_body's staging applies) -> LDS block layout -> k-steps [0, kb0) of
+// the first layer with fwd_body<32, 8, 4, G1>'s wave -> strip mapping -> acc_out.  kb0 % 4 == 0.
+template <int G1>
+__device__ __forceinline__ void l0_partial_ahead(const FusedNet& n, const L0Ahead& ah, int M, char* smem) {
+    constexpr int BM = 32, NW = 8, MB = 2, D = 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.x * BM;
+    const FusedLayer& L0 = n.layer[0];
+    const int CB = 2 * ah.kb0, groups = 8 * ah.kb0;          // column blocks of 16 / groups of 4 columns per row
+    const int nb0 = wave * G1;
+    WRing<G1, D> r0;
+    const u32x4* wl0 = L0.Wf + (int64_t)nb0 * L0.KB * 64 + lane;
+    wring_prime<G1, D>(r0, wl0, L0.KB * 64, ah.kb0);
+    constexpr int IPR = 5;                                       // items per lane per round: (row, 4 consecutive new columns)
+    for (int j0 = 0; j0 < BM * groups; j0 += NW * 64 * IPR) {
+        F4 v[IPR];
+        int row[IPR], c4[IPR];
+#pragma unroll
+        for (int u = 0; u < IPR; ++u) {
+            int j = j0 + u * NW * 64 + tid;
+            j = j < BM * groups ? j : BM * groups - 1;
+            row[u] = j / groups;
+            c4[u] = (j - row[u] * groups) * 4;
+            int m = m0 + row[u];
+            m = m < M ? m : M - 1;
+            v[u] = *reinterpret_cast<const F4*>(n.x + (int64_t)m * n.ldx + ah.shift + c4[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < IPR; ++u) {
+            const u32x2 pk = pack_bf16x4(v[u].v[0], v[u].v[1], v[u].v[2], v[u].v[3]);
+            *reinterpret_cast<u32x2*>(smem + ((row[u] >> 4) * CB + (c4[u] >> 4)) * 512 + (row[u] & 15) * 32 + ((c4[u] >> 2) & 3) * 8) = pk;
+            if (ah.xs_next && m0 + row[u] < M && j0 + u * NW * 64 + tid < BM * groups)
+                st_stream_u2<(HGYM_NT & 2) != 0>(reinterpret_cast<char*>(ah.xs_next + (int64_t)(m0 + row[u]) * ah.ldxs + c4[u]), pk);
+        }
+    }
+    __syncthreads();
+    f32x4 acc[MB][G1];
+    zero_acc<G1, MB>(acc);
+    mma_stream<G1, MB, D, 1>(r0, wl0, L0.KB * 64, ah.kb0, smem, CB, lane, acc);
+    f32x4* dst = reinterpret_cast<f32x4*>(ah.acc_out) + ((int64_t)(blockIdx.x * NW + wave) * (MB * G1)) * 64 + lane;
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int g = 0; g < G1; ++g) dst[(i * G1 + g) * 64] = acc[i][g];
+}
+
 struct FwdArgs {
     long long* dbg;
     FusedNet net[3];           // 0 actor, 1 critic, 2 auxiliary head
@@ -480,12 +549,15 @@ struct FwdNoop {
     __device__ __forceinline__ void operator()(int, int, int, const float (&)[4]) const {}
 };
 
-template <int BM, int NW, int D, int G1, bool WIDE = false, bool XB16 = false, class Early = FwdNoop, class Mid = FwdNoop, class Put = FwdNoop,
-          class Extra = int, class Idle = FwdNoop, class Head = FwdNoop, class L2Idle = FwdNoop>
+template <int BM, int NW, int D, int G1, bool WIDE = false, bool XB16 = false, bool PART = false, class Early = FwdNoop, class Mid = FwdNoop,
+          class Put = FwdNoop, class Extra = int, class Idle = FwdNoop, class Head = FwdNoop, class L2Idle = FwdNoop>
 __device__ __forceinline__ void fwd_body(const FwdArgs& a, const FusedNet& n, bool is_actor, char* smem, Early&& hook_early = Early(),
                                          Mid&& hook_mid = Mid(), Put&& hook_put = Put(), const Extra& extra = Extra(),
                                          Idle&& hook_idle = Idle(), Head&& hook_head = Head(), char* h2_lds = nullptr,
-                                         int* rowidx_lds = nullptr, L2Idle&& hook_l2idle = L2Idle()) {
+                                         int* rowidx_lds = nullptr, L2Idle&& hook_l2idle = L2Idle(), const L0Part* part = nullptr) {
+    // PART (the rollout's actor tile, hgym_rollout.hip): the first layer starts from the partial sums *part and runs chunks
+    // [part->kb0 / 4, NC) only (struct L0Part above)
+    static_assert(!PART || !XB16, "the carried first layer exists for fp32 input rows only");
     // rowidx_lds (BM ints of LDS): receives the storage row of every tile row (a.idx gathered once, by the lanes that stage the
     // input) for whoever needs it later in the tile; hook_l2idle(extra): runs on the wavefronts that have no strip in the third
     // layer while the others compute it (the fused forward + backward kernel gathers its loss inputs there).
@@ -642,25 +714,49 @@ __device__ __forceinline__ void fwd_body(const FwdArgs& a, const FusedNet& n, bo
         };
         const int nb0 = wave * G1;
         f32x4 acc[MB][G1];
-        zero_acc<G1, MB>(acc);
+        const int c0 = PART ? part->kb0 / 4 : 0;                // first chunk this launch runs; k-steps and LDS buffers count from it
+        bool drop[MB];
+        if constexpr (PART) {
+            const f32x4* src = reinterpret_cast<const f32x4*>(part->acc) + ((int64_t)(blockIdx.x * NW + wave) * (MB * G1)) * 64 + lane;
+#pragma unroll
+            for (int i = 0; i < MB; ++i)
+#pragma unroll
+                for (int g = 0; g < G1; ++g) acc[i][g] = src[(i * G1 + g) * 64];
+#pragma unroll
+            for (int i = 0; i < MB; ++i) {                      // lane (r, q) holds row i * 16 + r of the tile
+                int m = m0 + i * 16 + r;
+                m = m < a.M ? m : a.M - 1;
+                drop[i] = part->reset[m] != 0;
+            }
+        } else {
+            zero_acc<G1, MB>(acc);
+        }
         WRing<G1, D> r0;
-        const u32x4* wl0 = L0.Wf + (int64_t)nb0 * L0.KB * 64 + lane;
+        const u32x4* wl0 = L0.Wf + (int64_t)nb0 * L0.KB * 64 + lane + (int64_t)c0 * 4 * 64;
         phase_stamp(a.dbg, 0);
-        wring_prime<G1, D>(r0, wl0, L0.KB * 64, L0.KB);
-        stage_load(0);
+        wring_prime<G1, D>(r0, wl0, L0.KB * 64, L0.KB - c0 * 4);
+        stage_load(c0);
         hook_early(extra);
-        stage_write(0, 0);
+        stage_write(c0, 0);
         bias_to_lds();
+        if constexpr (PART) {
+#pragma unroll
+            for (int i = 0; i < MB; ++i)
+#pragma unroll
+                for (int g = 0; g < G1; ++g)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[i][g][e] = drop[i] ? 0.0f : acc[i][g][e];
+        }
         __syncthreads();
         phase_stamp(a.dbg, 1);
         // steady state: no condition inside the body (see mma_stream); the last chunk is peeled
-        for (int c = 0; c + 1 < NC; ++c) {
+        for (int c = c0; c + 1 < NC; ++c) {
             stage_load(c + 1);
-            mma_chunk<G1, MB, D, false, XBF>(r0, wl0, L0.KB * 64, c * 4, Q + (c & 1) * (BM * FUSED_CHUNK * 2), 8, lane, acc);
-            stage_write(c + 1, (c + 1) & 1);
+            mma_chunk<G1, MB, D, false, XBF>(r0, wl0, L0.KB * 64, (c - c0) * 4, Q + ((c - c0) & 1) * (BM * FUSED_CHUNK * 2), 8, lane, acc);
+            stage_write(c + 1, (c + 1 - c0) & 1);
             __syncthreads();
         }
-        mma_chunk<G1, MB, D, true, XBF>(r0, wl0, L0.KB * 64, (NC - 1) * 4, Q + ((NC - 1) & 1) * (BM * FUSED_CHUNK * 2), 8, lane, acc);
+        mma_chunk<G1, MB, D, true, XBF>(r0, wl0, L0.KB * 64, (NC - 1 - c0) * 4, Q + ((NC - 1 - c0) & 1) * (BM * FUSED_CHUNK * 2), 8, lane, acc);
         phase_stamp(a.dbg, 2);
         if (AHEAD) prime1();
         epilogue_elu<G1, MB>(acc, bl, nb0, P, L0.NB, train_h ? n.H[0] : nullptr, mbg0, lane);

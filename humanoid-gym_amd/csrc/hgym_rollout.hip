@@ -88,6 +88,10 @@ struct RolloutPP {
     const float* draws_in;
     float* draws_out;
     int draws_len;             // floats per tile
+    // The actor's first layer carried across launches (hgym_fused.hpp: L0Part / L0Ahead): l0.acc = what the previous launch's critic
+    // workgroups left for this step (PART instantiation), ah.acc_out = where this launch's leave the next step's (null: not).
+    L0Part l0;
+    L0Ahead ah;
 };
 
 constexpr int RO_NIO = hist_ni<15, HGYM_OBS_FRAME, RO_E, RO_NT>();
@@ -100,7 +104,7 @@ constexpr int RO_NIAP = hist_ni<3, HGYM_PRIV_FRAME, RO_E, RO_NT - 64, 2>();     
 // weight ring in the in-order vmcnt queue, and their stores: 4.4 us of a 42 us launch -- is not in this kernel at all.  A launch
 // that is given obs_ahead writes the 13 frames it already knows of the rows after next on the seven wavefronts that idle during
 // the per-env phase, and this step's frame next to its own row's in the stack phase.
-template <bool FIN, bool PRE>
+template <bool FIN, bool PRE, bool PART = false>
 __global__ __launch_bounds__(RO_NT) void rollout_step_kernel(const FwdArgs f, const EnvArgs e, const FinArgs fin, const RolloutPP pp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (FIN && blockIdx.y >= 2) {
@@ -125,6 +129,11 @@ __global__ __launch_bounds__(RO_NT) void rollout_step_kernel(const FwdArgs f, co
             env_fill_draws<RO_E>(e, (int)blockIdx.x, (int)threadIdx.x, RO_NT, base, pp.in[0] + 1);
         }
 #endif
+        if (pp.ah.acc_out) {     // k-steps [0, kb0) of the ACTOR's first layer for the next step's rows of this tile
+            __syncthreads();     // (the head wavefronts of this tile may still read its LDS)
+            l0_partial_ahead<2 * U>(f.net[0], pp.ah, f.M, smem);
+        }
+        phase_stamp(f.dbg, 7);
         return;
     }
     const int t = threadIdx.x, block = blockIdx.x;
@@ -194,7 +203,17 @@ __global__ __launch_bounds__(RO_NT) void rollout_step_kernel(const FwdArgs f, co
         if (!PRE) hist_store<15, HGYM_OBS_FRAME, RO_NIO>(E.out.obs, block * RO_E, RO_E, (int)(ring_step % 15), t, RO_NT, nullptr, E.cfg.clip_obs, hist_o);
 #endif
     };
-    fwd_body<32, 8, 4, 2 * U, false>(f, f.net[0], true, smem, early, mid, put, e, idle);
+    fwd_body<32, 8, 4, 2 * U, false, false, PART>(f, f.net[0], true, smem, early, mid, put, e, idle, FwdNoop(), nullptr, nullptr, FwdNoop(), &pp.l0);
+    if (PART && f.net[0].xs) {
+        // rows of this tile whose env was reset by the previous step: columns [0, 32 kb0) of their bf16 shadow were written ahead from
+        // the un-reset history -- the row's older frames are zero now (the launch that reset them zeroed the fp32 row)
+        const int pieces = 4 * pp.l0.kb0;           // 16-byte pieces per row
+        for (int j = t; j < RO_E * pieces; j += RO_NT) {
+            const int row = j / pieces, pc = j - row * pieces;
+            const int m = block * RO_E + row;
+            if (m < f.M && pp.l0.reset[m]) *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(f.net[0].xs + (int64_t)m * f.net[0].ldxs) + pc * 16) = (u32x4){0u, 0u, 0u, 0u};
+        }
+    }
     __syncthreads();                                // the tile's actions are in the env image; the policy buffers are dead
     // phase clock of the env part (hgym_prof_phase_buffer): the slots of grid row 2, which stamps nothing itself
     long long* dbg = f.dbg ? f.dbg + (int64_t)2 * gridDim.x * 8 + (int64_t)block * 8 : nullptr;
@@ -341,15 +360,50 @@ int32_t hgym_rollout_step(const HgymNetConfig* cfg, const HgymNet* net, const Hg
         pp.draws_in = prev_out ? tables + parity * per_parity : nullptr;       // the first step of a rollout draws its own
         pp.draws_out = tables + (parity ^ 1) * per_parity;
     }
+    memset(&pp.l0, 0, sizeof(pp.l0));
+    memset(&pp.ah, 0, sizeof(pp.ah));
+    const bool part = out->l0_ready != nullptr;
+    {   // first layer of the actor carried across launches (HgymEnvOut.l0_ahead / l0_ready)
+        // k-steps formed ahead: whole 128-column chunks, at most 20 (640 of the 658 columns of the 14 older frames).  12 by default:
+        // the critic workgroup pays for every k-step it takes over at the same L2 -> CU fill rate, and with all 20 it becomes the
+        // launch's longest workgroup (profiles/r04_l0_ahead_ab.txt: collection 2.33 -> 2.27 ms with 12, 2.30 with 20, 2.34 with 8).
+        // HGYM_L0_KB0 tunes the split (A/B runs).
+        static const int KB0_AHEAD = [] {
+            const char* e = getenv("HGYM_L0_KB0");
+            const int v = e ? atoi(e) : 12;
+            return (v >= 4 && v <= 20 && v % 4 == 0) ? v : 12;
+        }();
+        HG_REQUIRE(!part || prev_out, HGYM_E_BADARG, "l0_ready on the first step of a rollout: no launch has left partial sums");
+        HG_REQUIRE(!(part || out->l0_ahead) || (f.net[0].layer[0].KB == 24 && f.net[0].layer[0].N == 512 && HGYM_OBS_FRAME * 14 >= 32 * KB0_AHEAD),
+                   HGYM_E_UNSUPPORTED, "the carried first layer is built for XBot-L's 15 x 47 -> 512 actor input");
+        HG_REQUIRE(!out->l0_ahead || (((uintptr_t)out->l0_ahead & 15) == 0 && out->l0_ahead != out->l0_ready), HGYM_E_BADARG,
+                   "l0_ahead must be 16-byte aligned and distinct from l0_ready");
+        HG_REQUIRE(!out->obs_bf16_ahead || (out->l0_ahead && out->ld_obs_bf16_ahead >= 768 && out->ld_obs_bf16_ahead % 8 == 0 &&
+                                           ((uintptr_t)out->obs_bf16_ahead & 15) == 0), HGYM_E_BADARG, "obs_bf16_ahead: needs l0_ahead, ld >= 768 (multiple of 8), 16-byte aligned");
+        if (part) {
+            pp.l0.acc = out->l0_ready;
+            pp.l0.reset = prev_out->reset;
+            pp.l0.kb0 = KB0_AHEAD;
+        }
+        if (out->l0_ahead) {
+            pp.ah.acc_out = out->l0_ahead;
+            pp.ah.xs_next = (__bf16*)out->obs_bf16_ahead;
+            pp.ah.ldxs = out->ld_obs_bf16_ahead;
+            pp.ah.shift = HGYM_OBS_FRAME;
+            pp.ah.kb0 = KB0_AHEAD;
+        }
+    }
     f.dbg = phase_buffer((int64_t)(M / RO_E) * 3);
     const size_t lds = (size_t)pp.env_lds_off + step_smem_bytes(RO_E);
     const bool pre = out->obs_older_ready != 0;
     HG_REQUIRE(!pre || prev_out, HGYM_E_BADARG, "obs_older_ready on the first step of a rollout: no launch has written those frames");
+    HG_REQUIRE(!part || pre, HGYM_E_UNSUPPORTED, "l0_ready is built together with obs_older_ready (the steady-state launch)");
     HG_REQUIRE((out->obs_ahead != nullptr) == (out->priv_ahead != nullptr), HGYM_E_BADARG, "obs_ahead and priv_ahead: both or neither");
     HG_REQUIRE(!out->obs_ahead || (out->obs_ahead != out->obs && out->priv_ahead != out->priv_obs), HGYM_E_BADARG,
                "obs_ahead / priv_ahead must be the rows AFTER obs / priv_obs");
     {
-        const void* fn = pre ? reinterpret_cast<const void*>(&rollout_step_kernel<true, true>)
+        const void* fn = part ? reinterpret_cast<const void*>(&rollout_step_kernel<true, true, true>)
+                       : pre ? reinterpret_cast<const void*>(&rollout_step_kernel<true, true>)
                              : (prev_out ? reinterpret_cast<const void*>(&rollout_step_kernel<true, false>)
                                          : reinterpret_cast<const void*>(&rollout_step_kernel<false, false>));
         rc = ensure_dynamic_lds(fn, lds, "rollout_step_kernel");
@@ -357,7 +411,8 @@ int32_t hgym_rollout_step(const HgymNetConfig* cfg, const HgymNet* net, const Hg
     }
     hipStream_t s = (hipStream_t)stream;
     prof_begin(HGYM_PROF_ROLLOUT, s);
-    if (pre) hipLaunchKernelGGL((rollout_step_kernel<true, true>), dim3(M / RO_E, 3), dim3(RO_NT), lds, s, f, e, fin, pp);
+    if (part) hipLaunchKernelGGL((rollout_step_kernel<true, true, true>), dim3(M / RO_E, 3), dim3(RO_NT), lds, s, f, e, fin, pp);
+    else if (pre) hipLaunchKernelGGL((rollout_step_kernel<true, true>), dim3(M / RO_E, 3), dim3(RO_NT), lds, s, f, e, fin, pp);
     else if (prev_out) hipLaunchKernelGGL((rollout_step_kernel<true, false>), dim3(M / RO_E, 3), dim3(RO_NT), lds, s, f, e, fin, pp);
     else hipLaunchKernelGGL((rollout_step_kernel<false, false>), dim3(M / RO_E, 2), dim3(RO_NT), lds, s, f, e, fin, pp);
     {   // algorithmic HBM bytes of the fused step: the env step's + the policy's input rows and outputs

@@ -91,7 +91,8 @@ class EnvOut(C.Structure):
                 ("extras_time_outs", c_u8_p), ("extras_episode", c_float_p),
                 ("t_values", c_float_p), ("t_rewards", c_float_p), ("t_dones", c_u8_p), ("t_step", c_i64_p),
                 ("t_gamma", C.c_float), ("defer_finalize", C.c_int32), ("log_cur", c_float_p), ("log_stats", c_float_p),
-                ("extras_custom", c_float_p), ("obs_ahead", c_float_p), ("priv_ahead", c_float_p), ("obs_older_ready", C.c_int32)]
+                ("extras_custom", c_float_p), ("obs_ahead", c_float_p), ("priv_ahead", c_float_p), ("obs_older_ready", C.c_int32),
+                ("l0_ahead", c_float_p), ("l0_ready", c_float_p), ("obs_bf16_ahead", C.c_void_p), ("ld_obs_bf16_ahead", C.c_int64)]
 
 
 class EnvNoise(C.Structure):

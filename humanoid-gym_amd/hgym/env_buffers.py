@@ -68,6 +68,7 @@ class EnvBuffers:
         # second rew / reset / time_out set for the alternate steps, and the library's scratch block (zero-filled once)
         self.rew_alt, self.reset_alt, self.time_out_alt = z(N), torch.zeros(N, dtype=torch.bool, device=dev), z(N, dtype=torch.bool)
         self.rollout_scratch = torch.zeros(L.rollout_scratch_bytes(N), dtype=torch.uint8, device=dev)
+        self._l0_partial = None      # (2, N, 512) fp32: the actor's first-layer partial sums handed from launch to launch (l0_partial())
         # logging sink of the step finaliser (HgymEnvOut.log_*): per-env running episode return / length, and the statistics block
         self.log_cur = z(2, N)
         self.log_stats = z(L.LOG_STATS)
@@ -240,6 +241,13 @@ class EnvBuffers:
         if self.extras_custom is not None:
             o.extras_custom = L.fptr(self.extras_custom)
         return o
+
+    def l0_partial(self, k):
+        """Buffer k (0 / 1) of the actor's first-layer partial pre-activations carried from one fused rollout launch to the next
+        (HgymEnvOut.l0_ahead / l0_ready): (N, 512) fp32, allocated on first use."""
+        if self._l0_partial is None:
+            self._l0_partial = torch.zeros(2, self.N, 512, dtype=torch.float32, device=self.device)
+        return self._l0_partial[k]
 
     @staticmethod
     def noise_struct(u_delay=None, z_act=None, u_cmd=None, u_dof=None, u_push=None, z_obs=None, u_xy=None, r_level=None):

@@ -178,7 +178,7 @@ class OnPolicyRunner:
         # must re-capture, as the eager reference would simply see it
         gkey = (id(env), id(alg.storage), log_on, log_sink, sink_ok, defer_ok, fuse_ok, getattr(alg, "gamma", None),
                 env.native_config_digest() if hasattr(env, "native_config_digest") else None,
-                getattr(env, "_rows_ahead", None), getattr(alg.storage, "_obs_bf16", None) is not None)
+                getattr(env, "_rows_ahead", None), getattr(env, "_l0_ahead", None), getattr(alg.storage, "_obs_bf16", None) is not None)
         tot_iter = self.current_learning_iteration + num_learning_iterations
         try:
             for it in range(self.current_learning_iteration, tot_iter):

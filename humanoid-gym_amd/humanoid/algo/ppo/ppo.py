@@ -187,8 +187,12 @@ class PPO:
         out = dict(actions=st.actions[s], mu=st.mu[s], sigma=st.sigma[s], logp=st.actions_log_prob[s].view(-1), values=st.values[s])
         sink = dict(values=st.values[s], rewards=st.rewards[s], dones=st.dones[s], step=self._sample_step, gamma=self.gamma)
         sh = st.shadow_slot(s) if (obs.data_ptr() == st._obs_all[s].data_ptr() and critic_obs.data_ptr() == st._priv_all[s].data_ptr()) else None
+        # the bf16 shadow of the NEXT slot's observation rows: this launch writes the columns it already knows (the carried first layer)
+        sh_next = None
+        if (sh is not None and s + 1 < st.num_transitions_per_env and next_obs.data_ptr() == st._obs_all[s + 1].data_ptr()):
+            sh_next = st._obs_bf16[s + 1]
         env.rollout_step(self.net, i, obs, critic_obs, next_obs, next_critic_obs, sink, self.actor_critic._sample_seed, out, shadow=sh,
-                         ahead=ahead)
+                         ahead=ahead, shadow_next=sh_next)
         st.step += 1
 
     def transition_sink(self):

@@ -246,6 +246,7 @@ class LeggedRobot(BaseTask):
         self._bound_out = None
         # A/B knob, read once (a captured rollout graph keeps the protocol active at capture; OnPolicyRunner's graph key includes it)
         self._rows_ahead = os.environ.get("HGYM_ROWS_AHEAD", "1") != "0"
+        self._l0_ahead = os.environ.get("HGYM_L0_AHEAD", "1") != "0"      # the actor's first layer carried across launches (rollout_step)
         self._sim_s, self._st_s = b.sim_struct(), b.state_struct()
         self._noise_none = b.noise_struct()
         self.common_step_counter_buf = b.counters
@@ -441,18 +442,22 @@ class LeggedRobot(BaseTask):
     def rollout_begin(self, step_counter, num_steps):
         if getattr(self, "_pending_fin", None) is not None:
             raise RuntimeError("a postponed step finaliser is pending; run it before a fused rollout")
-        self._ro_T, self._ro_prev, self._ro_ahead = int(num_steps), None, None
+        self._ro_T, self._ro_prev, self._ro_ahead, self._ro_l0 = int(num_steps), None, None, None
         self._L.check(self._L.lib.hgym_rollout_begin(C.byref(self._st_s), self._L.i64ptr(step_counter), C.c_void_p(self._buf.rollout_scratch.data_ptr()),
                                                      (self._ro_T - 1) & 1, self._stream()), "hgym_rollout_begin")
 
-    def rollout_step(self, net, i, obs, priv, next_obs, next_priv, sink, seed, out, shadow=None, ahead=None):
+    def rollout_step(self, net, i, obs, priv, next_obs, next_priv, sink, seed, out, shadow=None, ahead=None, shadow_next=None):
         """Step i of the rollout begun with rollout_begin: actions / mu / sigma / logp / values of PPO.act into `out`, this env's
         step on those actions with the observations written to next_obs / next_priv, the transition sink of step i stored by
         the finaliser that rides in step i + 1 (or in rollout_end).  The last step uses the primary rew / reset / time_out
         buffers, so that they read as after a plain step() once the rollout is over.  shadow: optional (obs_bf16, priv_bf16)
         storage-slot tensors receiving the bf16 of `obs` / `priv` (HgymObsShadow).  ahead: (obs, priv) rows the NEXT step will write
         its observations to (HgymEnvOut.obs_ahead / priv_ahead): this launch writes their older frames off its critical path, and the
-        next call -- recognised by its next_obs being that tensor -- skips the copy.  Same rows either way (HGYM_ROWS_AHEAD=0: never)."""
+        next call -- recognised by its next_obs being that tensor -- skips the copy.  Same rows either way (HGYM_ROWS_AHEAD=0: never).
+        shadow_next: the bf16 shadow tensor of next_obs (the NEXT call's shadow[0]), or None.  With `ahead` given there is a next
+        launch: this one also forms 20 of the 24 k-steps of the actor's first layer for next_obs (HgymEnvOut.l0_ahead; the rows are
+        this call's rows shifted by a frame) and writes columns [0, 640) of shadow_next; the next call -- recognised by its obs being
+        this call's next_obs -- starts from those sums (l0_ready).  Bit-identical outputs (HGYM_L0_AHEAD=0: never)."""
         sh = None if shadow is None else net.shadow_struct(*shadow)
         L = self._L
         parity = (self._ro_T - 1 - i) & 1
@@ -467,6 +472,20 @@ class LeggedRobot(BaseTask):
             assert a_priv.is_contiguous() and a_priv.shape == next_priv.shape and a_priv.data_ptr() != next_priv.data_ptr()
             o.obs_ahead, o.priv_ahead = L.fptr(a_obs), L.fptr(a_priv)
         self._ro_ahead = None if ahead is None else (ahead[0].data_ptr(), ahead[1].data_ptr())
+        # the carried first layer rides with the rows-ahead protocol (the steady-state launch): ready if the previous launch formed the
+        # sums for exactly these rows, with the same shadow arrangement
+        l0 = self._ro_l0
+        if (l0 is not None and o.obs_older_ready and l0[0] == obs.data_ptr()
+                and l0[2] == (None if shadow is None else shadow[0].data_ptr())):
+            o.l0_ready = L.fptr(self._buf.l0_partial(l0[1]))
+        self._ro_l0 = None
+        if self._l0_ahead and ahead is not None and (shadow is None) == (shadow_next is None):
+            k = i & 1
+            o.l0_ahead = L.fptr(self._buf.l0_partial(k))
+            if shadow_next is not None:
+                assert shadow_next.dtype == torch.bfloat16 and shadow_next.is_contiguous() and shadow_next.shape[0] == self.num_envs
+                o.obs_bf16_ahead, o.ld_obs_bf16_ahead = C.c_void_p(shadow_next.data_ptr()), shadow_next.shape[-1]
+            self._ro_l0 = (next_obs.data_ptr(), k, None if shadow_next is None else shadow_next.data_ptr())
         prev = self._ro_prev
         L.check(L.lib.hgym_rollout_step(C.byref(net.cfg), C.byref(net.struct), C.byref(self._ncfg), C.byref(self._sim_s), C.byref(self._st_s),
                                         C.byref(o), C.byref(prev[0]) if prev is not None else None, L.fptr(obs), L.fptr(priv),

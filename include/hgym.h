@@ -28,11 +28,13 @@
 extern "C" {
 #endif
 
-#define HGYM_VERSION 5      /* 2: HgymEnvOut carries the logging sink; hgym_rollout_*, hgym_ppo_grad_part, hgym_net_param_offset
+#define HGYM_VERSION 6      /* 2: HgymEnvOut carries the logging sink; hgym_rollout_*, hgym_ppo_grad_part, hgym_net_param_offset
                              * 3: the rollout scratch block grows with the env count (HGYM_ROLLOUT_SCRATCH_BYTES(num_envs))
                              * 4: bf16 observation shadow: HgymObsShadow argument of the policy launches, HgymBatch.obs_bf16 /
                              *    priv_bf16, hgym_net_shadow_ld
-                             * 5: HgymEnvOut.obs_ahead / obs_older_ready (hgym_rollout_step writes the older frames one launch ahead) */
+                             * 5: HgymEnvOut.obs_ahead / obs_older_ready (hgym_rollout_step writes the older frames one launch ahead)
+                             * 6: HgymEnvOut.l0_ahead / l0_ready / obs_bf16_ahead (the actor's first layer carried across the launches of a rollout);
+                             *    HGYM_MAX_CUSTOM_REWARDS 8 -> 24, custom_reward_pos = 23: after the clip (`termination`) */
 
 enum {
     HGYM_OK = 0,
@@ -241,6 +243,19 @@ typedef struct HgymEnvOut {
     float* priv_ahead;         /* the same for priv_obs ((N, c_frame_stack*73)); both or neither */
     int32_t obs_older_ready;   /* 1: frames 0 .. frame_stack-2 of `obs` (and 0 .. c_frame_stack-2 of `priv_obs`) were written by the
                                   previous launch (as its obs_ahead / priv_ahead) */
+    /* hgym_rollout_step only, header v6 (NULL / 0 everywhere else): the actor's FIRST LAYER carried across launches.  The next row is
+     * this row shifted by one frame plus the frame this step produces, so up to 20 of the first layer's 24 k-steps (columns [0, 640)
+     * of the next row; 12 are taken by default) can be formed while this launch runs: its critic workgroups, idle for the second half of the launch, do that and
+     * leave the fp32 partial pre-activations in l0_ahead ((num_envs, 512) floats, caller-owned, 16-byte aligned); the NEXT launch,
+     * called with l0_ready = that buffer (and obs_older_ready = 1), starts its actor tile from them and reads only the remaining
+     * columns of its rows.  Same fragments, same k order, same accumulator chain: bit-identical outputs.  Partial sums of rows whose
+     * env was reset in between are dropped (their older frames are zero).  obs_bf16_ahead (optional, with l0_ahead): the bf16 shadow
+     * rows of the NEXT step's observation (HgymObsShadow.obs of the next call): the columns formed ahead are written by this launch,
+     * the next launch writes the rest and zeroes the former in reset rows. */
+    float* l0_ahead;
+    const float* l0_ready;
+    void* obs_bf16_ahead;
+    int64_t ld_obs_bf16_ahead;
 } HgymEnvOut;
 #define HGYM_LOG_STATS 256
 

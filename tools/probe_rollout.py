@@ -48,6 +48,8 @@ for i, b in enumerate(acc[1:], 1):
         segs = [(d[:, k + 1] - d[:, k]).mean().item() for k in range(len(names))]
         print("step %d %-28s block mean %.1f us: " % (i, tag, (d[:, len(names)] - d[:, 0]).mean().item()) +
               ", ".join("%s %.1f" % (n, s) for n, s in zip(names, segs)))
+    print("step %d critic workgroup start -> its end (tile + next step's draws + the actor's first-layer partial sums ahead): mean %.1f us, max %.1f us" % (
+        i, (t[1][:, 7] - t[1][:, 0]).mean().item(), (t[1][:, 7] - t[1][:, 0]).max().item()))
     print("step %d actor end -> env start (barrier behind the head: the slowest wavefront's head / draws): mean %.1f us" % (i, (t[2][:, 0] - t[0][:, 6]).mean().item()))
     print("step %d actor start -> env end: mean %.1f us, grid span %.1f us" % (
         i, (t[2][:, 5] - t[0][:, 0]).mean().item(), (t[2][:, 5].max() - t[0][:, 0].min()).item()))
