@@ -335,7 +335,13 @@ def run_config(args, task, num_envs, rank, world, local, dist, steps, warmup, lo
             L.lib.hgym_prof_enable(1)
         runner.alg.comm_timing = [] if world > 1 else None
         with (contextlib.redirect_stdout(io.StringIO()) if log_root is not None else contextlib.nullcontext()):
-            runner.learn(num_learning_iterations=2, init_at_random_ep_len=False)
+            # two eager iterations; with several ranks the second one runs the OTHER gradient exchange (the direct kernel over peer
+            # mappings vs the collective) when the peer-mapped buffer exists, so that the line carries both
+            runner.learn(num_learning_iterations=1, init_at_random_ep_len=False)
+            both = world > 1 and getattr(runner.alg, "_comm", None) is not None
+            runner.alg.comm_flip = both
+            runner.learn(num_learning_iterations=1, init_at_random_ep_len=False)
+            runner.alg.comm_flip = False
         torch.cuda.synchronize()
         os.environ["HGYM_GRAPH"] = "1"
         if rank == 0:
@@ -345,15 +351,39 @@ def run_config(args, task, num_envs, rank, world, local, dist, steps, warmup, lo
             L.lib.hgym_prof_enable(0)
         if world > 1 and runner.alg.comm_timing:
             ev = runner.alg.comm_timing
-            exposed = [a_.elapsed_time(b_) * 1e3 for a_, b_ in ev]
-            res["comm"] = dict(collective="all_reduce(SUM) of [flat fp32 gradient | minibatch KL], one bucket per minibatch",
-                               backend=("RCCL (torch.distributed 'nccl')" if dist.get_backend() == "nccl" else
-                                        "%s (ranks may share a GPU; host-staged, not representative of RCCL over xGMI)" % dist.get_backend()),
-                               bytes_per_minibatch=4 * (runner.alg.net.P + 1), minibatches_per_iter=len(ev) // 2,      # (two eager profiling iterations)
-                               exposed_us_per_minibatch=sum(exposed) / len(exposed), exposed_us_max=max(exposed),
-                               exposed_ms_per_iter=sum(exposed) / 2 * 1e-3,
-                               note="stream time between the last backward kernel and the start of hgym_ppo_apply (HIP events on the "
-                                    "compute stream, eager profiling iterations, rank 0); includes waiting for the slowest rank")
+            nmb = runner.alg.num_learning_epochs * runner.alg.num_mini_batches
+            # what 0.9 weak-scaling efficiency leaves for the exchange: T_N <= T_1 / 0.9 with T_1 ~ this run's iteration minus its exposed waits
+            p2p_on = bool(getattr(runner.alg, "_comm_p2p", False))
+            names = {"p2p": "direct reduce-scatter + all-gather kernel over hipIpc peer mappings of the ranks' gradient buffers (HGYM_COMM=p2p)",
+                     "collective": ("RCCL all-reduce (torch.distributed 'nccl')" if dist.get_backend() == "nccl" else
+                                    "%s all-reduce (ranks may share a GPU; host-staged, not representative of RCCL over xGMI)" % dist.get_backend())}
+            per = {}
+            for tag in ("p2p", "collective"):
+                xs = [a_.elapsed_time(b_) * 1e3 for a_, b_, t_ in ev if t_ == tag]
+                if xs:
+                    per[tag] = dict(backend=names[tag], minibatches_timed=len(xs), exposed_us_per_minibatch=sum(xs) / len(xs), exposed_us_max=max(xs))
+            used = "p2p" if p2p_on else "collective"
+            exposed_used = per[used]["exposed_us_per_minibatch"] if used in per else 0.0
+            t1_ms = max(res["ms_per_step"] - exposed_used * nmb * 1e-3, 1e-6)
+            budget = t1_ms * (1.0 / 0.9 - 1.0) / nmb * 1e3
+            comm = dict(collective="SUM of [flat fp32 gradient | minibatch KL], one exchange per minibatch, fully exposed by construction",
+                        used_in_timed_run=used, bytes_per_minibatch=4 * (runner.alg.net.P + 1), minibatches_per_iter=nmb,
+                        exposed_us_per_minibatch=exposed_used, exposed_us_max=per[used]["exposed_us_max"] if used in per else 0.0,
+                        exposed_ms_per_iter=exposed_used * nmb * 1e-3, backend=names[used],
+                        budget_us_per_minibatch_for_0p9_weak_scaling=budget, within_budget=bool(exposed_used <= budget),
+                        backends=per,
+                        note="stream time between the last backward kernel and the start of hgym_ppo_apply (HIP events on the compute stream, "
+                             "one eager profiling iteration per backend, rank 0); includes waiting for the slowest rank.  budget = what an "
+                             "efficiency of 0.9 leaves per minibatch: (iteration - exposed) x (1 / 0.9 - 1) / minibatches")
+            c = getattr(runner.alg, "_comm", None)
+            if c is not None:
+                try:
+                    w_us, x_us = c.check()
+                    comm["p2p_last_call"] = dict(wait_for_slowest_rank_us=w_us, exchange_us=x_us,
+                                                 note="the direct kernel's own 100 MHz timestamps: start -> every rank arrived (rank skew), -> every shard delivered")
+                except Exception as e:      # noqa: BLE001
+                    comm["p2p_error"] = str(e)
+            res["comm"] = comm
         runner.alg.comm_timing = None
     del runner, env
     torch.cuda.empty_cache()

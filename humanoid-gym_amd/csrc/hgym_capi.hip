@@ -67,7 +67,7 @@ int64_t hgym_sizeof(const char* name) {
     if (!name) return -1;
 #define HG_SZ(T) if (!strcmp(name, #T)) return (int64_t)sizeof(T)
     HG_SZ(HgymEnvConfig); HG_SZ(HgymStrided); HG_SZ(HgymSimTensors); HG_SZ(HgymEnvState); HG_SZ(HgymEnvOut);
-    HG_SZ(HgymEnvNoise); HG_SZ(HgymNetConfig); HG_SZ(HgymPPOConfig); HG_SZ(HgymNet); HG_SZ(HgymBatch); HG_SZ(HgymObsShadow);
+    HG_SZ(HgymEnvNoise); HG_SZ(HgymNetConfig); HG_SZ(HgymPPOConfig); HG_SZ(HgymNet); HG_SZ(HgymBatch); HG_SZ(HgymObsShadow); HG_SZ(HgymComm);
 #undef HG_SZ
     return -1;
 }

@@ -1,0 +1,206 @@
+// hgym_comm.hip -- the data-parallel update's gradient exchange as ONE direct kernel over peer mappings (opt-in: HGYM_COMM=p2p;
+// the default stays torch.distributed's all-reduce = RCCL, as north_star names it).
+//
+// Why.  The exchange is fully exposed by construction (the norm clip and the KL-adaptive learning rate need
+// the whole averaged gradient before Adam can start, and the next minibatch's forward needs Adam's result), so at 6 ms per
+// iteration a weak-scaling efficiency of 0.9 leaves <= 88 us per minibatch for collective + rank skew.  The payload is small --
+// [flat gradient | KL] = 926 106 floats = 3.7 MB -- and MI355X's xGMI is a fully connected mesh of point-to-point links
+// (7 x ~153 GB/s per GPU): a ring collective is bound by per-link latency x 2 (N - 1) hops, a DIRECT reduce-scatter + all-gather
+// moves (N - 1) / N of the payload once each way over N - 1 links in parallel: 7 x 463 KB per phase at N = 8, ~3 us of wire time
+// per link and phase, two flag round trips.
+//
+// Protocol (rank r of W, call number seq = 1, 2, ...; every rank's buffer is mapped into every rank's address space through
+// hipIpcMemHandles exchanged once, fine-grained memory so that peer writes are visible without cache maintenance):
+//   A  the previous kernel on the stream has written my gradient into MY buffer.  Workgroup 0 stores seq into slot A[r] of every
+//      rank's flag block; every workgroup waits until its own flag block shows A[q] >= seq for all q: all gradients are complete.
+//   RS my shard = elements [r S, (r + 1) S) (S = count / W rounded up to 4).  For each 16-byte piece of it: load the piece from all W
+//      buffers, add them in RANK ORDER q = 0 .. W - 1 (fp32, the same association on every rank -- and each element is summed by
+//      exactly one rank, so all ranks end with bit-identical vectors), store the sum into all W buffers.
+//   B  every workgroup release-fences and bumps a local counter; the last one stores seq into slot B[r] of every rank's flag block.
+//      Workgroup 0 waits for B[q] >= seq for all q before it exits: when my kernel completes, every shard of my buffer holds its
+//      final sum and no peer still reads my gradient -- the next kernel on the stream (hgym_ppo_apply) may read and overwrite it.
+// Every wait is BOUNDED (~2 s): on expiry the kernel writes status[0] = 1 and returns instead of hanging the device; the host
+// checks the status word where it synchronises anyway (hgym_comm_status).
+//
+// Timestamps (100 MHz wall clock) of the last call are left in status[8 ..]: kernel start, phase A complete, phase B complete --
+// "A - start" is how long this rank waited for the slowest rank (the skew), "B - A" the exchange itself.
+#include "hgym_common.hpp"
+
+namespace hgym {
+
+constexpr int COMM_THREADS = 256;
+constexpr int COMM_BLOCKS = 64;
+constexpr uint32_t COMM_SPINS = 4u << 20;       // x ~0.5 us per poll (s_sleep): ~2 s
+
+struct CommArgs {
+    float* data[HGYM_COMM_MAX_RANKS];
+    uint32_t* flags[HGYM_COMM_MAX_RANKS];        // per rank: [0, 8) phase A arrivals, [8, 16) phase B arrivals, [16] local done counter
+    long long* status;                           // MY status block: [0] error flag, [8 ..] timestamps
+    int world, rank;
+    int64_t count;                               // floats (a multiple of 4)
+    int64_t shard;                               // floats per shard (a multiple of 4)
+    uint32_t seq;
+};
+
+__device__ __forceinline__ uint32_t ld_sys(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ void st_sys(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+
+// lanes 0 .. world - 1 of the calling wave each watch one slot; returns false on time-out (wave-uniform result)
+__device__ __forceinline__ bool wait_slots(const uint32_t* slots, int world, uint32_t seq, int lane) {
+    bool ok = true;
+    if (lane < world) {
+        uint32_t spins = 0;
+        // (seq - flag) as a signed distance: correct across the 32-bit wrap of the call counter
+        while ((int32_t)(ld_sys(slots + lane) - seq) < 0) {
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > COMM_SPINS) { ok = false; break; }
+        }
+    }
+    return __all(ok);
+}
+
+__global__ __launch_bounds__(COMM_THREADS) void p2p_allreduce_kernel(const CommArgs c) {
+    const int t = threadIdx.x, lane = t & 63;
+    __shared__ int s_ok;
+    uint32_t* myf = c.flags[c.rank];
+    if (blockIdx.x == 0 && t == 0) c.status[8] = (long long)__builtin_amdgcn_s_memrealtime();
+    // ---- A: my gradient is complete (written by the previous kernel on this stream); tell everyone, wait for everyone
+    if (blockIdx.x == 0 && t < c.world) st_sys(c.flags[t] + c.rank, c.seq);
+    if (t < 64) {
+        const bool ok = wait_slots(myf, c.world, c.seq, lane);
+        if (t == 0) s_ok = ok ? 1 : 0;
+    }
+    __syncthreads();
+    if (!s_ok) {
+        if (t == 0) c.status[0] = 1;
+        return;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    if (blockIdx.x == 0 && t == 0) c.status[9] = (long long)__builtin_amdgcn_s_memrealtime();
+    // ---- RS + AG: my shard, summed in rank order, written to every buffer
+    const int64_t lo = (int64_t)c.rank * c.shard;
+    int64_t hi = lo + c.shard;
+    hi = hi < c.count ? hi : c.count;
+    typedef __attribute__((ext_vector_type(4))) float f4;
+    for (int64_t i = lo + ((int64_t)blockIdx.x * COMM_THREADS + t) * 4; i < hi; i += (int64_t)gridDim.x * COMM_THREADS * 4) {
+        f4 v[HGYM_COMM_MAX_RANKS];
+#pragma unroll
+        for (int q = 0; q < HGYM_COMM_MAX_RANKS; ++q)
+            if (q < c.world) v[q] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(c.data[q] + i));
+        f4 s = v[0];
+#pragma unroll
+        for (int q = 1; q < HGYM_COMM_MAX_RANKS; ++q)
+            if (q < c.world) s += v[q];
+#pragma unroll
+        for (int q = 0; q < HGYM_COMM_MAX_RANKS; ++q)
+            if (q < c.world) __builtin_nontemporal_store(s, reinterpret_cast<f4*>(c.data[q] + i));
+    }
+    // ---- B: all my stores are out (release, system scope) -> the last workgroup tells everyone; workgroup 0 waits for everyone
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    __syncthreads();
+    __shared__ int s_last;
+    if (t == 0) {
+        const uint32_t done = __hip_atomic_fetch_add(myf + 16, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (done == (uint32_t)c.seq * gridDim.x - 1u) ? 1 : 0;        // the counter is never reset: call seq ends at seq * blocks
+    }
+    __syncthreads();
+    if (s_last) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "");
+        if (t < c.world) st_sys(c.flags[t] + 8 + c.rank, c.seq);
+    }
+    if (blockIdx.x == 0) {
+        if (t < 64) {
+            const bool ok = wait_slots(myf + 8, c.world, c.seq, lane);
+            if (t == 0) {
+                if (!ok) c.status[0] = 1;
+                c.status[10] = (long long)__builtin_amdgcn_s_memrealtime();
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    }
+}
+
+}  // namespace hgym
+
+using namespace hgym;
+
+extern "C" {
+
+int32_t hgym_comm_alloc(int64_t bytes, void** dev_ptr) {
+    HG_REQUIRE(bytes > 0 && dev_ptr, HGYM_E_BADARG, "bytes=%lld", (long long)bytes);
+    void* p = nullptr;
+    // fine-grained: device-coherent, not cached in the writer's L2 -- what a peer stores is what the next local kernel loads
+    if (hipExtMallocWithFlags(&p, (size_t)bytes, hipDeviceMallocFinegrained) != hipSuccess) {
+        (void)hipGetLastError();
+        HG_FAIL(HGYM_E_LAUNCH, "hipExtMallocWithFlags(%lld bytes, fine-grained) failed", (long long)bytes);
+    }
+    if (hipMemset(p, 0, (size_t)bytes) != hipSuccess) HG_FAIL(HGYM_E_LAUNCH, "hipMemset failed");
+    if (hipDeviceSynchronize() != hipSuccess) HG_FAIL(HGYM_E_LAUNCH, "hipDeviceSynchronize failed");
+    *dev_ptr = p;
+    return HGYM_OK;
+}
+
+int32_t hgym_comm_free(void* dev_ptr) {
+    if (dev_ptr && hipFree(dev_ptr) != hipSuccess) HG_FAIL(HGYM_E_LAUNCH, "hipFree failed");
+    return HGYM_OK;
+}
+
+int32_t hgym_comm_ipc_export(void* dev_ptr, void* handle_out) {
+    HG_REQUIRE(dev_ptr && handle_out, HGYM_E_BADARG, "null pointer");
+    static_assert(sizeof(hipIpcMemHandle_t) <= HGYM_IPC_HANDLE_BYTES, "handle does not fit");
+    hipIpcMemHandle_t h;
+    if (hipIpcGetMemHandle(&h, dev_ptr) != hipSuccess) {
+        (void)hipGetLastError();
+        HG_FAIL(HGYM_E_LAUNCH, "hipIpcGetMemHandle failed (HSA_ENABLE_IPC_MODE_LEGACY=0 is required on this driver)");
+    }
+    memset(handle_out, 0, HGYM_IPC_HANDLE_BYTES);
+    memcpy(handle_out, &h, sizeof(h));
+    return HGYM_OK;
+}
+
+int32_t hgym_comm_ipc_open(const void* handle, void** dev_ptr) {
+    HG_REQUIRE(handle && dev_ptr, HGYM_E_BADARG, "null pointer");
+    hipIpcMemHandle_t h;
+    memcpy(&h, handle, sizeof(h));
+    void* p = nullptr;
+    if (hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess) != hipSuccess) {
+        (void)hipGetLastError();
+        HG_FAIL(HGYM_E_LAUNCH, "hipIpcOpenMemHandle failed");
+    }
+    *dev_ptr = p;
+    return HGYM_OK;
+}
+
+int32_t hgym_comm_ipc_close(void* dev_ptr) {
+    if (dev_ptr && hipIpcCloseMemHandle(dev_ptr) != hipSuccess) {
+        (void)hipGetLastError();
+        HG_FAIL(HGYM_E_LAUNCH, "hipIpcCloseMemHandle failed");
+    }
+    return HGYM_OK;
+}
+
+int32_t hgym_comm_allreduce(const HgymComm* c, uint32_t seq, void* stream) {
+    HG_REQUIRE(c && c->world >= 1 && c->world <= HGYM_COMM_MAX_RANKS && c->rank >= 0 && c->rank < c->world, HGYM_E_BADARG, "bad communicator");
+    HG_REQUIRE(c->count > 0 && c->count % 4 == 0 && c->status && seq != 0, HGYM_E_BADARG, "count=%lld (a positive multiple of 4), seq=%u (>= 1)",
+               (long long)c->count, seq);
+    CommArgs a;
+    memset(&a, 0, sizeof(a));
+    for (int q = 0; q < c->world; ++q) {
+        HG_REQUIRE(c->data[q] && c->flags[q] && ((uintptr_t)c->data[q] & 15) == 0, HGYM_E_BADARG, "rank %d: null / unaligned buffer", q);
+        a.data[q] = c->data[q];
+        a.flags[q] = c->flags[q];
+    }
+    a.status = (long long*)c->status;
+    a.world = c->world;
+    a.rank = c->rank;
+    a.count = c->count;
+    a.shard = round_up(ceil_div(c->count, c->world), 4);
+    a.seq = seq;
+    prof_begin(HGYM_PROF_COMM, (hipStream_t)stream);
+    hipLaunchKernelGGL(p2p_allreduce_kernel, dim3(COMM_BLOCKS), dim3(COMM_THREADS), 0, (hipStream_t)stream, a);
+    prof_end(HGYM_PROF_COMM, (hipStream_t)stream, (double)c->count * 4.0 * 2.0 * (c->world - 1) / c->world);
+    HG_CHECK_LAUNCH("p2p_allreduce_kernel");
+    return HGYM_OK;
+}
+
+}  // extern "C"

@@ -121,6 +121,11 @@ class Net(C.Structure):
                 ("opt_state", c_f64_p), ("workspace", C.c_void_p)]
 
 
+class Comm(C.Structure):
+    _fields_ = [("world", C.c_int32), ("rank", C.c_int32), ("data", c_float_p * 8), ("flags", C.POINTER(C.c_uint32) * 8),
+                ("count", C.c_int64), ("status", c_i64_p)]
+
+
 class Batch(C.Structure):
     _fields_ = [("obs", c_float_p), ("priv", c_float_p), ("actions", c_float_p), ("values", c_float_p),
                 ("advantages", c_float_p), ("returns", c_float_p), ("logp", c_float_p), ("mu", c_float_p),
@@ -140,6 +145,12 @@ STRUCTS = dict(HgymEnvConfig=EnvConfig, HgymStrided=Strided, HgymSimTensors=SimT
 # every symbol include/hgym.h declares: name -> (restype, argtypes)
 _P = C.POINTER
 SYMBOLS = {
+    "hgym_comm_alloc": (C.c_int32, [C.c_int64, C.POINTER(C.c_void_p)]),
+    "hgym_comm_free": (C.c_int32, [C.c_void_p]),
+    "hgym_comm_ipc_export": (C.c_int32, [C.c_void_p, C.c_void_p]),
+    "hgym_comm_ipc_open": (C.c_int32, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "hgym_comm_ipc_close": (C.c_int32, [C.c_void_p]),
+    "hgym_comm_allreduce": (C.c_int32, [_P(Comm), C.c_uint32, C.c_void_p]),
     "hgym_version": (C.c_int32, []),
     "hgym_last_error": (C.c_char_p, []),
     "hgym_device_cus": (C.c_int32, []),
@@ -184,7 +195,7 @@ SYMBOLS = {
     "hgym_prof_phase_buffer": (C.c_int32, [C.c_void_p, C.c_int64]),
     "hgym_prof_summary": (C.c_int32, [C.c_int32, _P(C.c_int64), _P(C.c_double), _P(C.c_double)]),
 }
-PROF_GEMM, PROF_ENV_STEP, PROF_GAE, PROF_LOSS, PROF_MLP_FWD, PROF_MLP_BWD, PROF_DW, PROF_REDUCE, PROF_APPLY, PROF_POLICY, PROF_ROLLOUT = range(11)
+PROF_GEMM, PROF_ENV_STEP, PROF_GAE, PROF_LOSS, PROF_MLP_FWD, PROF_MLP_BWD, PROF_DW, PROF_REDUCE, PROF_APPLY, PROF_POLICY, PROF_ROLLOUT, PROF_COMM = range(12)
 ROLLOUT_SCRATCH_HEADER_BYTES = 512
 ROLLOUT_DRAW_BYTES_PER_ENV = 1000
 

@@ -48,7 +48,9 @@ class NetBuffers:
     """Flat fp32 master parameters (state_dict order), Adam state, optimiser scalars and the zero-filled
     workspace; exposes per-tensor views named like the reference's ActorCritic.state_dict()."""
 
-    def __init__(self, cfg, device, learning_rate=1e-5):
+    def __init__(self, cfg, device, learning_rate=1e-5, grads_ext=None):
+        """grads_ext: optional caller-owned (>= P + 1,) fp32 tensor to hold [gradient | KL] (the data-parallel update's direct exchange
+        keeps it in peer-mapped memory: dist_utils.P2PComm)."""
         self.cfg = cfg
         self.device = torch.device(device)
         self.P = int(L.lib.hgym_net_param_count(C.byref(cfg)))
@@ -57,7 +59,10 @@ class NetBuffers:
             raise L.HgymError("bad net config: %s" % L.lib.hgym_last_error().decode())
         z = lambda n, dt=torch.float32: torch.zeros(n, dtype=dt, device=self.device)
         self.params, self.adam_m, self.adam_v = z(self.P), z(self.P), z(self.P)
-        self.grads_ext = z(self.P + 1)          # flat gradient + the minibatch KL slot: what the ranks all-reduce, in one piece
+        if grads_ext is not None:
+            assert grads_ext.dtype == torch.float32 and grads_ext.is_contiguous() and grads_ext.numel() >= self.P + 1
+            grads_ext.zero_()
+        self.grads_ext = grads_ext[:self.P + 1] if grads_ext is not None else z(self.P + 1)      # flat gradient + the minibatch KL slot: what the ranks all-reduce, in one piece
         self.grads = self.grads_ext[:self.P]
         self.opt_state = z(16, torch.float64)
         self.opt_state[0] = learning_rate

@@ -116,7 +116,12 @@ class PPO:
         cfg = hgym.make_net_config(ac.num_actor_obs, ac.num_critic_obs, ac.num_actions, ac.actor_hidden_dims, ac.critic_hidden_dims,
                                    self.precision, max(mb, num_envs), aux_hidden=aux, aux_out=getattr(ac, "denoiser_targets", 0),
                                    aux_target_offset=ac.num_critic_obs - getattr(ac, "denoiser_targets", 0))
-        self.net = hgym.NetBuffers(cfg, self.device, learning_rate=self._lr0)
+        # data-parallel update with the direct exchange (HGYM_COMM=p2p): the gradient vector lives in peer-mapped memory
+        import ctypes as C
+        self._comm = dist_utils.make_comm(int(hgym._lib.lib.hgym_net_param_count(C.byref(cfg))) + 1, self.device)
+        self._comm_p2p = self._comm is not None and dist_utils.comm_backend() == "p2p"
+        self.comm_flip = False      # bench.py: use the OTHER exchange for the next update() (timing both in its profiling iterations)
+        self.net = hgym.NetBuffers(cfg, self.device, learning_rate=self._lr0, grads_ext=None if self._comm is None else self._comm.data)
         dist_utils.broadcast_parameters(ac.parameters())   # identical initial parameters on every rank
         ac.bind(self.net)
         # bf16 shadows of the stored observation rows: the policy launches leave them behind, the update gathers from them
@@ -263,15 +268,22 @@ class PPO:
                     # and two buckets pay the collective's latency twice.  (Rounds 1-2 split the weight-gradient launch in two so that
                     # the actor's bucket travelled under the critic's products: the two half-empty launches cost 106 us more per
                     # minibatch than the one launch -- more than the exchange they hid; profiles/r03_grad_parts_ab.txt.)
-                    h = dist_utils.start_sum(net.grads_ext)
                     probe = self.comm_timing is not None
-                    if probe:
-                        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-                        ev[0].record()
-                    dist_utils.finish(h)
+                    if self._comm is not None and (self._comm_p2p != bool(self.comm_flip)):
+                        # HGYM_COMM=p2p: one kernel on this stream (reduce-scatter + all-gather over the peer mappings)
+                        if probe:
+                            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                            ev[0].record()
+                        self._comm.allreduce()
+                    else:
+                        h = dist_utils.start_sum(net.grads_ext)
+                        if probe:
+                            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                            ev[0].record()
+                        dist_utils.finish(h)
                     if probe:
                         ev[1].record()
-                        self.comm_timing.append(ev)
+                        self.comm_timing.append(ev + ("p2p" if (self._comm is not None and self._comm_p2p != bool(self.comm_flip)) else "collective",))
                 net.ppo_apply(self._ppo_cfg)
         st.clear()
         if not sync:

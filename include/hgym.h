@@ -538,6 +538,34 @@ int64_t hgym_net_param_offset(const HgymNetConfig* cfg, int32_t which);
  * compute-precision shadows, bumps opt_state. */
 int32_t hgym_ppo_apply(const HgymNetConfig* cfg, const HgymPPOConfig* ppo, const HgymNet* net, void* stream);
 
+/* ---- direct gradient exchange over peer mappings (header v6; opt-in alternative to the RCCL all-reduce of the data-parallel update:
+ * reference has nothing here, /root/reference/humanoid/utils/helpers.py:207-212 is a dead flag).  One process per GPU.  Every rank
+ * allocates ONE fine-grained buffer with hgym_comm_alloc, exports its handle (hgym_comm_ipc_export, 64 bytes, exchanged by the
+ * caller over whatever it has -- torch.distributed's all_gather_object here), opens the peers' (hgym_comm_ipc_open) and fills an
+ * HgymComm: data[q] = rank q's payload (count floats, count % 4 == 0; data[rank] is the caller's own -- the flat [gradient | KL] vector
+ * lives there, HgymNet.grads points into it), flags[q] = rank q's flag block (HGYM_COMM_FLAG_WORDS zero-filled uint32), status = 16
+ * int64 of the caller's own buffer.  hgym_comm_allreduce(seq = 1, 2, 3, ... -- the same sequence on every rank) enqueues ONE kernel that
+ * leaves the rank-ordered fp32 SUM in every rank's data (bit-identical on all ranks): arrival flags, each rank sums its 1 / world shard
+ * from all buffers and stores the result into all buffers, completion flags.  Waits are bounded (~2 s): on expiry status[0] = 1 and
+ * the payload is garbage (hgym_comm_status reads it; call it where the host synchronises anyway).  status[8 .. 10] = 100 MHz
+ * timestamps of the last call: start, every rank arrived, every shard delivered. */
+#define HGYM_COMM_MAX_RANKS 8
+#define HGYM_IPC_HANDLE_BYTES 64
+#define HGYM_COMM_FLAG_WORDS 32
+typedef struct HgymComm {
+    int32_t world, rank;
+    float* data[HGYM_COMM_MAX_RANKS];
+    uint32_t* flags[HGYM_COMM_MAX_RANKS];
+    int64_t count;
+    int64_t* status;
+} HgymComm;
+int32_t hgym_comm_alloc(int64_t bytes, void** dev_ptr);
+int32_t hgym_comm_free(void* dev_ptr);
+int32_t hgym_comm_ipc_export(void* dev_ptr, void* handle_out);
+int32_t hgym_comm_ipc_open(const void* handle, void** dev_ptr);
+int32_t hgym_comm_ipc_close(void* dev_ptr);
+int32_t hgym_comm_allreduce(const HgymComm* comm, uint32_t seq, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Measurement hooks (bench.py's roofline leg).  PROCESS-GLOBAL state, unlike the rest of this interface: one event list and one
  * phase buffer per process, not per device or per stream, and not thread-safe -- enable them from one thread, for one device at
@@ -557,7 +585,8 @@ enum {
     HGYM_PROF_APPLY = 8,     /* grad-norm + clip + Adam */
     HGYM_PROF_POLICY = 9,    /* fused forward, rollout / inference (32-row tiles, sampling epilogue) */
     HGYM_PROF_ROLLOUT = 10,  /* fused rollout step (policy + env step + previous finaliser); work = algorithmic HBM bytes */
-    HGYM_PROF_CLASSES = 11
+    HGYM_PROF_COMM = 11,     /* hgym_comm_allreduce (the direct gradient exchange); work = bytes this rank moves over its links */
+    HGYM_PROF_CLASSES = 12
 };
 int32_t hgym_prof_enable(int32_t on);  /* 1: start collecting (clears previous events), 0: stop */
 int32_t hgym_prof_summary(int32_t cls, int64_t* launches, double* total_ms, double* work);

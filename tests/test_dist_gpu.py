@@ -15,12 +15,13 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, out_dir, backend="gloo", num_envs=256, iters=4):
+def _worker(rank, world, port, out_dir, backend="gloo", num_envs=256, iters=4, comm="rccl"):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "humanoid-gym_amd"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ["HGYM_COMM"] = comm
     if backend == "nccl":            # RCCL: one device per rank
         torch.cuda.set_device(rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
@@ -44,9 +45,19 @@ def _worker(rank, world, port, out_dir, backend="gloo", num_envs=256, iters=4):
     runner.learn(num_learning_iterations=iters, init_at_random_ep_len=True)     # eager, capture + replay, replay, replay
     torch.cuda.synchronize()
     net = runner.alg.net
+    p2p = None
+    # the gradient vector lives in the peer-mapped buffer whenever one could be built (also when the exchange itself is the collective)
+    assert runner.alg._comm_p2p == (comm == "p2p")
+    if runner.alg._comm is not None:
+        assert net.grads_ext.data_ptr() == runner.alg._comm.data.data_ptr()
+        t = runner.alg._comm.check()            # raises if any bounded wait expired; (wait for the slowest rank, exchange) of the last call, us
+        p2p = t if comm == "p2p" else None
+        runner.alg._comm.close()
+    else:
+        assert comm != "p2p"
     torch.save(dict(p_init=p_init.cpu(), params=net.params.cpu(), lr=float(net.opt_state[0]), steps=float(net.opt_state[1]),
                     obs=runner.alg.storage._obs_all[1].cpu(), graph=runner._graph is not None, friction=friction, commands0=commands0,
-                    env_seed=seed, comm_events=len(runner.alg.comm_timing), split=net.bucket_split, P=net.P),
+                    env_seed=seed, comm_events=len(runner.alg.comm_timing), split=net.bucket_split, P=net.P, p2p=p2p),
                os.path.join(out_dir, "r%d.pt" % rank))
     dist.barrier()
     dist.destroy_process_group()
@@ -86,6 +97,93 @@ def test_eight_ranks_one_gpu_stay_in_lockstep(tmp_path):
         assert not torch.equal(r[i]["obs"], r[0]["obs"]) and r[i]["env_seed"] != r[0]["env_seed"]
         assert r[i]["comm_events"] == 24
     assert len({x["env_seed"] for x in r}) == 8
+
+
+def _p2p_unit_worker(rank, world, port, out_dir, count, calls):
+    """hgym_comm_allreduce on its own: every rank's vector is a function of (rank, call), so each rank can form the expected
+    rank-ordered fp32 sum itself."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "humanoid-gym_amd"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ["HGYM_COMM"] = "p2p"
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from humanoid.algo.ppo import dist_utils
+    assert dist_utils.comm_backend() == "p2p"
+    comm = dist_utils.P2PComm(count, "cuda:0")
+    dist.barrier()                               # (PPO goes through make_comm, whose success all-reduce is this rendezvous)
+    assert comm.count % 4 == 0 and comm.count >= count
+
+    def vec(r, k):
+        g = torch.Generator().manual_seed(1000 * k + r)
+        return (torch.randn(comm.count, generator=g) * (1.0 + r)).cuda()
+    worst = 0.0
+    times = []
+    for k in range(calls):
+        comm.data.copy_(vec(rank, k))
+        if k % 2 == 1:                           # uneven arrival: odd ranks dawdle on odd calls (the kernel waits for the slowest rank)
+            torch.cuda.synchronize()
+            if rank % 2 == 1:
+                import time
+                time.sleep(0.05)
+        comm.allreduce()
+        times.append(comm.check())
+        want = vec(0, k)
+        for q in range(1, world):
+            want = want + vec(q, k)               # rank order, fp32: what the kernel forms
+        assert torch.equal(comm.data, want), (rank, k, float((comm.data - want).abs().max()))
+        worst = max(worst, float((comm.data - want).abs().max()))
+    torch.save(dict(times=times, last=comm.data.cpu()), os.path.join(out_dir, "u%d.pt" % rank))
+    comm.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_p2p_allreduce_kernel_sums_in_rank_order(tmp_path, world):
+    """The direct gradient exchange (csrc/hgym_comm.hip, HGYM_COMM=p2p): `world` processes share cuda:0, their buffers are mapped into
+    each other through hipIpcMemHandles, 6 calls on the flat-gradient size (926 106 floats) with uneven arrival: every rank ends
+    with the rank-ordered fp32 sum, bit for bit, the same on all ranks; no bounded wait expires.  The reference has no multi-GPU
+    path to match (/root/reference/humanoid/utils/helpers.py:207-212 is a dead flag)."""
+    port = 30500 + (os.getpid() % 2000) + world
+    mp.spawn(_p2p_unit_worker, args=(world, port, str(tmp_path), 926106, 6), nprocs=world, join=True)
+    r = [torch.load(os.path.join(str(tmp_path), "u%d.pt" % i)) for i in range(world)]
+    for i in range(1, world):
+        assert torch.equal(r[i]["last"], r[0]["last"]), i
+    print("p2p all-reduce, %d ranks on one GPU, 3.7 MB: (wait for the slowest rank, exchange) us per call on rank 0: %s"
+          % (world, ["%.0f / %.0f" % t for t in r[0]["times"]]))
+
+
+@pytest.mark.timeout(900)
+def test_two_ranks_one_gpu_p2p_exchange_equals_collective(tmp_path):
+    """The whole data-parallel run (graph-captured rollout, asynchronous iterations, 32 synchronised Adam steps) with the direct
+    exchange in place of the all-reduce: for two ranks a + b = b + a exactly, so the parameters must equal the gloo run's bit for bit."""
+    port = 30900 + (os.getpid() % 2000)
+    os.makedirs(str(tmp_path / "p2p"))
+    os.makedirs(str(tmp_path / "coll"))
+    mp.spawn(_worker, args=(2, port, str(tmp_path / "p2p"), "gloo", 256, 4, "p2p"), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port + 1, str(tmp_path / "coll"), "gloo", 256, 4, "rccl"), nprocs=2, join=True)
+    a, b = (torch.load(os.path.join(str(tmp_path / "p2p"), "r%d.pt" % i)) for i in range(2))
+    c = torch.load(os.path.join(str(tmp_path / "coll"), "r0.pt"))
+    assert torch.equal(a["params"], b["params"]) and a["lr"] == b["lr"] and a["steps"] == 32 and a["comm_events"] == 32
+    assert torch.isfinite(a["params"]).all() and not torch.equal(a["params"], a["p_init"])
+    assert torch.equal(a["params"], c["params"]) and a["lr"] == c["lr"]
+    assert a["p2p"] is not None and c["p2p"] is None
+
+
+@pytest.mark.timeout(900)
+def test_eight_ranks_one_gpu_p2p_exchange_stays_in_lockstep(tmp_path):
+    """BASELINE configs[2]'s rank count over the direct exchange: 8 processes share one GPU, 24 exchanges; bit-identical parameters."""
+    port = 31300 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(8, port, str(tmp_path), "gloo", 128, 3, "p2p"), nprocs=8, join=True)
+    r = [torch.load(os.path.join(str(tmp_path), "r%d.pt" % i)) for i in range(8)]
+    assert torch.isfinite(r[0]["params"]).all() and not torch.equal(r[0]["params"], r[0]["p_init"])
+    for i in range(1, 8):
+        assert torch.equal(r[i]["params"], r[0]["params"]) and r[i]["lr"] == r[0]["lr"] and r[i]["steps"] == 24, i
+        assert r[i]["comm_events"] == 24 and r[i]["p2p"] is not None
 
 
 @pytest.mark.timeout(600)
