@@ -254,7 +254,7 @@ def _roofline(L, runner, elapsed_per_iter_ms, precision, n_profiled_iters, traff
         (L.PROF_MLP_BWD, "mlp_bwd_kernel", "mfma"), (L.PROF_DW, "dw_kernel", "mfma"), (L.PROF_GEMM, "gemm_nt_kernel", "mfma"),
         (L.PROF_LOSS, "ppo_loss_kernel", "hbm"), (L.PROF_REDUCE, "reduce_slabs_kernel", "hbm"),
         (L.PROF_APPLY, "sqnorm+adam_kernel", "hbm"), (L.PROF_GAE, "gae_kernel", "hbm")]
-    traffic, source = {}, None
+    traffic, source, counters = {}, None, {}
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")     # HBM bytes per launch from rocprofv3 --pmc passes
     if pmc is not None and traffic_ok:
         traffic = pmc.get("kernels", {})
@@ -263,6 +263,7 @@ def _roofline(L, runner, elapsed_per_iter_ms, precision, n_profiled_iters, traff
     elif os.path.exists(tpath) and traffic_ok:     # the counters were collected on the headline workload: they say nothing about another size
         tj = json.load(open(tpath))
         traffic = tj.get("kernels", {})
+        counters = tj.get("counters", {})
         # NOT a measurement of this run: a committed file, quoted with where it came from so that the reader can tell
         source = dict(kind="committed file, not measured in this run", path="profiles/pmc_traffic.json", **tj.get("provenance", {}))
     ks = []
@@ -276,6 +277,9 @@ def _roofline(L, runner, elapsed_per_iter_ms, precision, n_profiled_iters, traff
         ks.append(dict(kernel=name, bound=bound, launches_per_iter=n // n_profiled_iters, avg_launch_us=ms / n * 1e3, achieved=ach,
                        peak=peak, unit=unit, frac=ach / peak, share_of_iteration=ms / n_profiled_iters / elapsed_per_iter_ms,
                        traffic=tr, traffic_source=source if tr else None,
+                       # rocprofv3 SQ / TCC passes (tools/gpu_counters.sh), same provenance as `traffic`: MFMA-pipe occupancy
+                       # (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs)) and L2 hit rate of this kernel
+                       mfma_busy=counters.get(name, {}).get("mfma_busy"), l2_hit=counters.get(name, {}).get("l2_hit"),
                        # counter traffic per launch over this run's launch time, as a fraction of the HBM peak: how close the kernel
                        # is to being bound by the bytes it actually moves, whatever its algorithmic bound says
                        traffic_frac_of_hbm_peak=(tr / (ms / n * 1e-3) / 1e9 / HBM_PEAK_GBS) if tr else None))
@@ -400,6 +404,7 @@ def _roofline_obj(ks, pick=None):
     rest = [k for k in ks if k is not dom]
     return dict(bound=dom["bound"], achieved=dom["achieved"], peak=dom["peak"], unit=dom["unit"], frac=dom["frac"],
                 traffic=dom["traffic"], traffic_source=dom.get("traffic_source"), traffic_frac_of_hbm_peak=dom.get("traffic_frac_of_hbm_peak"),
+                mfma_busy=dom.get("mfma_busy"), l2_hit=dom.get("l2_hit"),
                 kernel=dom["kernel"], launches_per_iter=dom["launches_per_iter"],
                 avg_launch_us=dom["avg_launch_us"], share_of_iteration=dom["share_of_iteration"], kernels=rest)
 

@@ -416,9 +416,14 @@ int32_t hgym_rollout_step(const HgymNetConfig* cfg, const HgymNet* net, const Hg
     else if (prev_out) hipLaunchKernelGGL((rollout_step_kernel<true, false>), dim3(M / RO_E, 3), dim3(RO_NT), lds, s, f, e, fin, pp);
     else hipLaunchKernelGGL((rollout_step_kernel<false, false>), dim3(M / RO_E, 2), dim3(RO_NT), lds, s, f, e, fin, pp);
     {   // algorithmic HBM bytes of the fused step: the env step's + the policy's input rows and outputs
+        // + the policy's weights, read once per launch (3 704 420 B / N per env-step in fp32 terms; here the bf16 forward
+        // fragments the tiles actually stream, padded layout) -- until round 4 this term was left out (0.149 -> 0.155 at N = 4096)
         const double env_b = 4.0 * (245 + 14 * 47 + 2 * 73 + 15 * 47 + 3 * 73) + 6;
         const double pol_b = 4.0 * (cfg->num_obs + cfg->num_priv + 3 * cfg->num_actions + 2);
-        prof_end(HGYM_PROF_ROLLOUT, s, (double)M * (env_b + pol_b));
+        double w_b = 0.0;
+        for (int n = 0; n < 2; ++n)
+            for (int l = 0; l < 4; ++l) w_b += (double)f.net[n].layer[l].NB * f.net[n].layer[l].KB * 1024.0;
+        prof_end(HGYM_PROF_ROLLOUT, s, (double)M * (env_b + pol_b) + w_b);
     }
     HG_CHECK_LAUNCH("rollout_step_kernel");
     return HGYM_OK;
