@@ -280,7 +280,7 @@ class OnPolicyRunner:
                         self._log_flush(pending, num_learning_iterations)
                     pending = dict(it=it, ev=ev, snap=snap)
                     if it % self.save_interval == 0:
-                        self.save(os.path.join(self.log_dir, "model_{}.pt".format(it)))
+                        self.save(os.path.join(self.log_dir, "model_{}.pt".format(it)), wait=False)
                     continue
                 else:
                     self.last_collection_time, self.last_learn_time = collection_time, learn_time
@@ -299,7 +299,7 @@ class OnPolicyRunner:
                         done_stats.zero_()
                     self.log(locals())
                     if it % self.save_interval == 0:
-                        self.save(os.path.join(self.log_dir, "model_{}.pt".format(it)))
+                        self.save(os.path.join(self.log_dir, "model_{}.pt".format(it)), wait=False)
                 if self._graph is None or ep_infos is not self._graph["ep_infos"]:
                     ep_infos.clear()
         finally:
@@ -323,7 +323,7 @@ class OnPolicyRunner:
             self.last_learn_time = sum(b.elapsed_time(c) for _, b, c in marks) * 1e-3 / len(marks)
         self.current_learning_iteration += num_learning_iterations
         if self.log_dir is not None:
-            self.save(os.path.join(self.log_dir, "model_{}.pt".format(self.current_learning_iteration)))
+            self.save(os.path.join(self.log_dir, "model_{}.pt".format(self.current_learning_iteration)), wait=False)
             self.wait_for_saves()           # as in the reference, every checkpoint of this call is on disk when learn() returns
 
     # ------------------------------------------------------------------
@@ -418,8 +418,9 @@ class OnPolicyRunner:
         """Drop the captured rollout; the next learn() iteration runs eagerly and the one after re-captures."""
         self._graph, self._graph_warm = None, False
 
-    def save(self, path, infos=None):
-        """on_policy_runner.py:274-281 (same dict, same keys).  On the device path the tensors are first copied to pinned host memory
+    def save(self, path, infos=None, wait=True):
+        """on_policy_runner.py:274-281 (same dict, same keys).  wait=True (the reference's semantics, and what a direct caller gets): the
+        file is on disk when the call returns; learn() passes wait=False for its own checkpoints and waits once, before it returns.  On the device path the tensors are first copied to pinned host memory
         stream-side (behind whatever the update has enqueued -- the host does not wait) and pickled + written by a background
         thread, so a checkpoint inside a training run costs the training thread ~0.1 ms instead of a device sync + 6-15 ms;
         `wait_for_saves()` (called by learn() before it returns, by load(), and at interpreter exit) waits for the files.
@@ -475,6 +476,8 @@ class OnPolicyRunner:
                 finally:
                     buf["busy"].set()
             _WRITER.submit(job)
+            if wait:
+                _WRITER.wait()
         self.save_time_s = getattr(self, "save_time_s", 0.0) + (time.time() - t0)     # host time the TRAINING thread spent in checkpoints (bench.py reports it)
 
     def wait_for_saves(self):
