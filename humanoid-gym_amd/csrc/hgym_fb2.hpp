@@ -512,24 +512,21 @@ __device__ __forceinline__ void fb2_body(const FwdArgs& a, const FbLoss& L, cons
     phase_stamp(a.dbg, 7);
 }
 
-// grid (T tiles, nets); 512 threads; one workgroup per CU (154.5 KB of LDS).  Nets: 0 actor, 1 critic.
+// grid (T tiles, nets); 512 threads; one workgroup per CU (153.5 KB of LDS).  Nets: 0 actor, 1 critic.
+// ONE instantiation per (actor shape, critic shape) pair, and only XBot-L's is built: a first version dispatched over all five bodies
+// inside one kernel -- 281 KB of code -- and its mere PRESENCE in the code object (never launched) made multi-process runs on one GPU
+// abort at random with HSA_STATUS_ERROR_ILLEGAL_INSTRUCTION (tests/test_dist_gpu.py, 8 ranks: 0 / 6 failures without it, 3-4 / 6 with
+// it, 0 / 6 with a single-body build; bisected in round 4).  Every other kernel of the library is < 130 KB; so is this one now.
+template <int NCH_A, bool STREAM_A, int NCH_C, bool STREAM_C>
 __global__ __launch_bounds__(FB2_NW * 64) void mlp_fb2_kernel(const FwdArgs a, const FbLoss L, const Fb2Sched sch) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int which = a.net0 + blockIdx.y;
     const FusedNet& n = a.net[which];
-    const int nch0 = n.layer[0].N / 256;
-    const bool stream = n.layer[0].KB > 8;
-#ifndef FB2_ONLY
-#define FB2_ONLY 31
-#endif
-    if (stream) {
-        if (nch0 == 2 && (FB2_ONLY & 1)) fb2_body<2, true>(a, L, sch, n, which == 0, smem);
-        else if (nch0 == 1 && (FB2_ONLY & 2)) fb2_body<1, true>(a, L, sch, n, which == 0, smem);
-    } else {
-        if (nch0 == 3 && (FB2_ONLY & 4)) fb2_body<3, false>(a, L, sch, n, which == 0, smem);
-        else if (nch0 == 2 && (FB2_ONLY & 8)) fb2_body<2, false>(a, L, sch, n, which == 0, smem);
-        else if (nch0 == 1 && (FB2_ONLY & 16)) fb2_body<1, false>(a, L, sch, n, which == 0, smem);
-    }
+    if (which == 0) fb2_body<NCH_A, STREAM_A>(a, L, sch, n, true, smem);
+    else fb2_body<NCH_C, STREAM_C>(a, L, sch, n, false, smem);
 }
+// the shapes the one instantiation serves: (first hidden width / 256, input wider than two 128-column chunks) of actor and critic
+constexpr int FB2_NCH_A = 2, FB2_NCH_C = 3;
+constexpr bool FB2_STREAM_A = true, FB2_STREAM_C = false;
 
 }  // namespace hgym

@@ -16,7 +16,11 @@
 
 #include "hgym_gemm.hpp"
 #include "hgym_fused.hpp"
+#ifndef HGYM_NO_FB2_KERNEL
 #include "hgym_fb2.hpp"
+#else
+namespace hgym { struct Fb2Sched { int nb, T; }; }
+#endif
 
 namespace hgym {
 
@@ -941,17 +945,22 @@ struct NetRunner {
         // 128-row tiles (hgym_fb2.hpp), OPT-IN (HGYM_FB2=1): measured equal to slightly slower than the 64-row kernel on every box of
         // round 4 (282-340 vs 289-340 us per launch; profiles/r04_fb2_128row_tiles_negative_result.txt) -- the launch is paced by its
         // 0.5 GB of H / dZ stores, not by the L2 -> CU weight stream the taller tile halves.  Shapes it carries: shadow rows, actor +
-        // critic only, 256 / 128 wide second / third layers, 12 actions; a wide input needs a first width of <= 512 (full-width
-        // accumulators), a narrow one any multiple of 256.  Results are bit-identical to mlp_fb_kernel's (tests/test_fused_gpu.py).
+        // critic only, XBot-L's widths (the kernel is instantiated for one shape pair: hgym_fb2.hpp says why), 12 actions.  Results are
+        // bit-identical to mlp_fb_kernel's (tests/test_fused_gpu.py).
         const char* fb2_env = getenv("HGYM_FB2");                                // read per call: tests flip it
         const bool no_fb2 = !(fb2_env && fb2_env[0] == '1');
+#ifdef HGYM_NO_FB2_KERNEL
+        bool fb2 = false && no_fb2;
+#else
         bool fb2 = shadow && !no_fb2 && nets == 2 && A == 12;
-        for (int i = 0; i < 2 && fb2; ++i) {
+#endif
+#ifndef HGYM_NO_FB2_KERNEL
+        for (int i = 0; i < 2 && fb2; ++i) {      // the one (actor, critic) shape pair the kernel is instantiated for: XBot-L's
             const NetLayout& n = w.net[i];
-            const int N0 = n.layer[0].N;
-            fb2 = n.layer[1].N == 256 && n.layer[2].N == 128 && n.layer[3].N <= 16 && N0 % 256 == 0 && N0 <= 768 &&
-                  (n.layer[0].KBf > 8 ? N0 <= 512 : true);
+            fb2 = n.layer[1].N == 256 && n.layer[2].N == 128 && n.layer[3].N <= 16 &&
+                  n.layer[0].N == 256 * (i == 0 ? FB2_NCH_A : FB2_NCH_C) && (n.layer[0].KBf > 8) == (i == 0 ? FB2_STREAM_A : FB2_STREAM_C);
         }
+#endif
         Fb2Sched sch = {0, 0};
         if (fb2) {
             // tiles of 7 or 8 row blocks: as many tiles per net as a whole number of rounds over the CUs when that keeps them >= 6 high
@@ -996,17 +1005,19 @@ struct NetRunner {
             fl.aux_ldt = cfg.num_priv;
             fl.aux_off = cfg.aux_target_offset;
             fl.aux_coef = ppo.aux_coef;
+#ifndef HGYM_NO_FB2_KERNEL
             if (fb2) {
                 size_t lds2 = 0;
                 for (int i = 0; i < nets; ++i) lds2 = std::max(lds2, (size_t)fb2_lds_bytes(fa.net[i]));
                 HG_REQUIRE(lds2 <= 160 * 1024, HGYM_E_UNSUPPORTED, "mlp_fb2_kernel needs %zu bytes of LDS", lds2);
-                const int32_t rc2 = ensure_dynamic_lds(reinterpret_cast<const void*>(&mlp_fb2_kernel), lds2, "mlp_fb2_kernel");
+                auto* const fb2k = &mlp_fb2_kernel<FB2_NCH_A, FB2_STREAM_A, FB2_NCH_C, FB2_STREAM_C>;
+                const int32_t rc2 = ensure_dynamic_lds(reinterpret_cast<const void*>(fb2k), lds2, "mlp_fb2_kernel");
                 if (rc2) return rc2;
                 FwdArgs fb = fa;
                 fb.nets = nets;
                 fb.dbg = phase_buffer((int64_t)tiles * nets);
                 prof_begin(HGYM_PROF_MLP_FWD, s);
-                hipLaunchKernelGGL(mlp_fb2_kernel, dim3(tiles, nets), dim3(FB2_NW * 64), lds2, s, fb, fl, sch);
+                hipLaunchKernelGGL(fb2k, dim3(tiles, nets), dim3(FB2_NW * 64), lds2, s, fb, fl, sch);
                 double flops = 0.0;
                 for (int i = 0; i < nets; ++i) {
                     for (int l = 0; l < 4; ++l) flops += 2.0 * (double)B * w.net[i].layer[l].N * w.net[i].layer[l].K;
@@ -1014,7 +1025,9 @@ struct NetRunner {
                 }
                 prof_end(HGYM_PROF_MLP_FWD, s, flops);
                 HG_CHECK_LAUNCH("mlp_fb2_kernel");
-            } else {
+            } else
+#endif
+            {
             size_t lds = 0;
             for (int i = 0; i < nets; ++i)
                 lds = std::max(lds, (size_t)fused_lds_p(fa.net[i], 64) + (size_t)fused_lds_q(fa.net[i], 64) + (size_t)fused_lds_bias(fa.net[i]) +

@@ -67,10 +67,11 @@ def comm_backend():
 
 
 def make_comm(count, device):
-    """The peer-mapped gradient buffer of the data-parallel update, or None.  Built whenever there are 2..8 ranks (HGYM_COMM=off: never)
-    -- also when the exchange itself stays with RCCL, so that `bench.py --gpus N` can time both in its profiling iterations; if any rank
-    cannot allocate / export / map (no IPC on this driver, ranks on different hosts), EVERY rank falls back to a plain tensor."""
-    if not active() or world_size() > 8 or os.environ.get("HGYM_COMM", "rccl").lower() == "off":
+    """The peer-mapped gradient buffer of the data-parallel update, or None.  Built only on request (HGYM_COMM=p2p, or HGYM_COMM=both:
+    the exchange stays with the collective but the buffers exist, so that `bench.py --gpus N` can time the direct kernel as well in its
+    profiling iterations) -- the default data-parallel path allocates nothing new.  If any rank cannot allocate / export / map (no IPC
+    on this driver, ranks on different hosts), EVERY rank falls back to a plain tensor (HGYM_COMM=p2p: raises instead)."""
+    if not active() or world_size() > 8 or os.environ.get("HGYM_COMM", "rccl").lower() not in ("p2p", "both"):
         return None
     comm, err = None, None
     try:

@@ -46,8 +46,8 @@ def _worker(rank, world, port, out_dir, backend="gloo", num_envs=256, iters=4, c
     torch.cuda.synchronize()
     net = runner.alg.net
     p2p = None
-    # the gradient vector lives in the peer-mapped buffer whenever one could be built (also when the exchange itself is the collective)
-    assert runner.alg._comm_p2p == (comm == "p2p")
+    # the gradient vector lives in the peer-mapped buffer only on request (HGYM_COMM=p2p / both)
+    assert runner.alg._comm_p2p == (comm == "p2p") and (runner.alg._comm is not None) == (comm in ("p2p", "both"))
     if runner.alg._comm is not None:
         assert net.grads_ext.data_ptr() == runner.alg._comm.data.data_ptr()
         t = runner.alg._comm.check()            # raises if any bounded wait expired; (wait for the slowest rank, exchange) of the last call, us
