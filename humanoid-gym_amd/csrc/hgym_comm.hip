@@ -19,7 +19,7 @@
 //   B  every workgroup release-fences and bumps a local counter; the last one stores seq into slot B[r] of every rank's flag block.
 //      Workgroup 0 waits for B[q] >= seq for all q before it exits: when my kernel completes, every shard of my buffer holds its
 //      final sum and no peer still reads my gradient -- the next kernel on the stream (hgym_ppo_apply) may read and overwrite it.
-// Every wait is BOUNDED (~2 s): on expiry the kernel writes status[0] = 1 and returns instead of hanging the device; the host
+// Every wait is BOUNDED (15 s of wall clock): on expiry the kernel writes status[0] = 1 and returns instead of hanging the device; the host
 // checks the status word where it synchronises anyway (hgym_comm_status).
 //
 // Timestamps (100 MHz wall clock) of the last call are left in status[8 ..]: kernel start, phase A complete, phase B complete --
@@ -30,7 +30,7 @@ namespace hgym {
 
 constexpr int COMM_THREADS = 256;
 constexpr int COMM_BLOCKS = 64;
-constexpr uint32_t COMM_SPINS = 4u << 20;       // x ~0.5 us per poll (s_sleep): ~2 s
+constexpr long long COMM_WAIT_TICKS = 1500000000ll;      // bounded wait: 15 s of the 100 MHz wall clock (s_memrealtime)
 
 struct CommArgs {
     float* data[HGYM_COMM_MAX_RANKS];
@@ -50,10 +50,14 @@ __device__ __forceinline__ bool wait_slots(const uint32_t* slots, int world, uin
     bool ok = true;
     if (lane < world) {
         uint32_t spins = 0;
+        const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
         // (seq - flag) as a signed distance: correct across the 32-bit wrap of the call counter
         while ((int32_t)(ld_sys(slots + lane) - seq) < 0) {
-            __builtin_amdgcn_s_sleep(8);
-            if (++spins > COMM_SPINS) { ok = false; break; }
+            // back off after the first ~thousand polls: a rank that is late by milliseconds (another process's kernels on a shared
+            // GPU, a host hiccup) should not be polled at full rate
+            if (++spins < 1024u) __builtin_amdgcn_s_sleep(8);
+            else __builtin_amdgcn_s_sleep(127);
+            if ((spins & 255u) == 0u && (long long)__builtin_amdgcn_s_memrealtime() - t0 > COMM_WAIT_TICKS) { ok = false; break; }
         }
     }
     return __all(ok);

@@ -87,6 +87,10 @@ def make_comm(count, device):
     return comm
 
 
+class CommTimeout(RuntimeError):
+    """A bounded wait of the direct exchange expired: some rank's kernel never ran beside this one's (P2PComm.check)."""
+
+
 class _DevMem:
     """A raw device allocation presented to torch through __cuda_array_interface__ (the memory is owned by P2PComm)."""
 
@@ -155,7 +159,7 @@ class P2PComm:
         torch.cuda.synchronize(self.device)
         s = self.status.cpu()
         if int(s[0]) != 0:
-            raise RuntimeError("hgym_comm_allreduce: a rank did not arrive within the kernel's bounded wait (rank %d, call %d)" % (self.rank, self.seq))
+            raise CommTimeout("hgym_comm_allreduce: a rank did not arrive within the kernel's bounded wait (rank %d, call %d)" % (self.rank, self.seq))
         return (int(s[9]) - int(s[8])) * 0.01, (int(s[10]) - int(s[9])) * 0.01
 
     def close(self):

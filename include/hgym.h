@@ -546,7 +546,7 @@ int32_t hgym_ppo_apply(const HgymNetConfig* cfg, const HgymPPOConfig* ppo, const
  * lives there, HgymNet.grads points into it), flags[q] = rank q's flag block (HGYM_COMM_FLAG_WORDS zero-filled uint32), status = 16
  * int64 of the caller's own buffer.  hgym_comm_allreduce(seq = 1, 2, 3, ... -- the same sequence on every rank) enqueues ONE kernel that
  * leaves the rank-ordered fp32 SUM in every rank's data (bit-identical on all ranks): arrival flags, each rank sums its 1 / world shard
- * from all buffers and stores the result into all buffers, completion flags.  Waits are bounded (~2 s): on expiry status[0] = 1 and
+ * from all buffers and stores the result into all buffers, completion flags.  Waits are bounded (15 s): on expiry status[0] = 1 and
  * the payload is garbage (hgym_comm_status reads it; call it where the host synchronises anyway).  status[8 .. 10] = 100 MHz
  * timestamps of the last call: start, every rank arrived, every shard delivered. */
 #define HGYM_COMM_MAX_RANKS 8
