@@ -424,10 +424,12 @@ class OnPolicyRunner:
         stream-side (behind whatever the update has enqueued -- the host does not wait) and pickled + written by a background
         thread, so a checkpoint inside a training run costs the training thread ~0.1 ms instead of a device sync + 6-15 ms;
         `wait_for_saves()` (called by learn() before it returns, by load(), and at interpreter exit) waits for the files.
-        HGYM_ASYNC_SAVE=0: the synchronous torch.save."""
+        OPT-IN (HGYM_ASYNC_SAVE=1): it pays for runs that checkpoint often; in bench.py's 6-iteration logging window the only
+        checkpoint is the last one, which learn() has to wait for anyway, and the writer thread's wake-up made that wait 5-75 ms
+        instead of a steady 5 ms (tools/probe_logging.py, profiles/r04_async_checkpoint_ab.txt).  Default: the synchronous torch.save."""
         t0 = time.time()
         net = getattr(self.alg, "net", None)
-        if (net is None or not str(self.device).startswith("cuda") or os.environ.get("HGYM_ASYNC_SAVE", "1") == "0"
+        if (net is None or not str(self.device).startswith("cuda") or os.environ.get("HGYM_ASYNC_SAVE", "0") != "1"
                 or not hasattr(self.alg.actor_critic, "_net")):
             torch.save({"model_state_dict": self.alg.actor_critic.state_dict(),
                         "optimizer_state_dict": self.alg.optimizer.state_dict(),
