@@ -1230,6 +1230,13 @@ struct ScalArgs {
     float* kl_slot;
     double* opt;
     double beta1, beta2;   // Adam's: beta^t of the step this gradient will be applied in is left in opt[13..15] (below)
+    // hgym_ppo_apply's single-thread prologue (adaptive-KL learning rate, Adam step count, bias corrections) done HERE, beside the
+    // weight-gradient launch, when the caller has promised that exactly this gradient is applied next on one rank
+    // (HgymPPOConfig.grad_norm_ready): it needs nothing but the minibatch KL this block has just formed, and as a launch of its own it
+    // sat alone on the critical path between the slab sum and Adam (4.7 us + a launch boundary, eight times per iteration)
+    int do_prologue, adaptive_lr;
+    float desired_kl;
+    double lr_min, lr_max;
     int group;             // 0 / 1: `partials` holds one row per loss workgroup; 4: one row per 16-row block (mlp_fb2_kernel), four
                            // consecutive rows are added first, ((p0 + p1) + p2) + p3 in fp32 -- the sum mlp_fb_kernel's 64-row tile forms
                            // over its four head waves -- and nblocks counts those groups
@@ -1289,6 +1296,20 @@ __device__ __forceinline__ void ppo_scalars_block(const ScalArgs& a, int tid, in
             opt[7] += 1.0;
             opt[9] = 0.0;                     // squared gradient norm: accumulated by reduce_slabs_kernel later in this call
             a.kl_slot[0] = (float)(t / B);    // grads[P]: travels with the gradient in the ranks' one all-reduce
+            if (a.do_prologue) {              // apply_prologue_kernel's arithmetic (hgym_net.hip), one rank: ppo.py:140-148 in python doubles
+                double lr = opt[0];
+                if (a.adaptive_lr) {
+                    const double kl = t / B;
+                    if (kl > (double)a.desired_kl * 2.0) lr = fmax(a.lr_min, lr / 1.5);
+                    else if (kl < (double)a.desired_kl / 2.0 && kl > 0.0) lr = fmin(a.lr_max, lr * 1.5);
+                    opt[0] = lr;
+                }
+                const double ts = opt[1] + 1.0;           // (= opt[13]: the two lanes above prepared beta^ts before the barrier)
+                opt[1] = ts;
+                const double bc1 = 1.0 - opt[14], bc2 = 1.0 - opt[15];
+                opt[11] = (double)(float)(lr / bc1);      // step size
+                opt[12] = (double)(float)sqrt(bc2);
+            }
         }
         if (q >= 4 && q < 16 && q - 4 < A) a.grads_std[q - 4] = (float)t;
         if (q >= 16 && q < 28 && q - 16 < A && a.grads_bmu) a.grads_bmu[q - 16] = (float)t;

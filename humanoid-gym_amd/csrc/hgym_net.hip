@@ -1056,7 +1056,8 @@ struct NetRunner {
         // (mlp_fb2_kernel hands in one partial row per 16-row block; four of them are one 64-row tile's sum)
         const ScalArgs sc = {fb2 ? Bp / 64 : tiles, B, A, aux_fb ? w.net[2].layer[3].N : 0, at<float>(w.partials), net.grads,
                              net.grads + w.net[0].layer[3].b_off, net.grads + w.net[1].layer[3].b_off, net.grads + w.P, net.opt_state,
-                             (double)ppo.beta1, (double)ppo.beta2, fb2 ? 4 : 1};
+                             (double)ppo.beta1, (double)ppo.beta2, prologue_in_grad(ppo) ? 1 : 0, ppo.adaptive_lr, ppo.desired_kl, ppo.lr_min,
+                             ppo.lr_max, fb2 ? 4 : 1};
         if (only && only[0] == 'f') return HGYM_OK;
         rc = fused_dw(0, nets, B, &sc, gb);
         if (rc) return rc;
@@ -1262,7 +1263,7 @@ struct NetRunner {
         prof_end(HGYM_PROF_LOSS, s, (double)B * (4.0 * (5 * A + 6) + (double)sizeof(T) * (2 * A + 2)));
         HG_CHECK_LAUNCH("ppo_loss_kernel");
         const ScalArgs sc = {nblocks, B, A, 0, at<float>(w.partials), net.grads, nullptr, nullptr, net.grads + w.P, net.opt_state,
-                             (double)ppo.beta1, (double)ppo.beta2, 1};
+                             (double)ppo.beta1, (double)ppo.beta2, 0, 0, 0.0f, 0.0, 0.0, 1};
         hipLaunchKernelGGL(ppo_scalars_kernel, dim3(1), dim3(512), 0, s, sc);
         HG_CHECK_LAUNCH("ppo_scalars_kernel");
         cur_Mp = Bp;
@@ -1280,10 +1281,18 @@ struct NetRunner {
         return HGYM_OK;
     }
 
+    // The fused path on one rank with grad_norm_ready: the loss-scalar workgroup that rides in the weight-gradient launch has already taken
+    // the learning-rate decision and prepared Adam's step scalars (ScalArgs::do_prologue); hgym_ppo_apply then starts with Adam.
+#ifndef HGYM_PROLOGUE_IN_GRAD
+#define HGYM_PROLOGUE_IN_GRAD 1      // 0: apply_prologue_kernel as its own launch everywhere (A/B builds)
+#endif
+    bool prologue_in_grad(const HgymPPOConfig& ppo) const { return HGYM_PROLOGUE_IN_GRAD && w.fused && ppo.world_size <= 1 && ppo.grad_norm_ready != 0; }
+
     int32_t apply(const HgymPPOConfig& ppo) {
         prof_begin(HGYM_PROF_APPLY, s);
         const float inv_w = ppo.world_size > 1 ? (float)(1.0 / (double)ppo.world_size) : 1.0f;
-        hipLaunchKernelGGL(apply_prologue_kernel, dim3(1), dim3(64), 0, s, ppo, net.grads + w.P, inv_w, net.opt_state);
+        if (!prologue_in_grad(ppo))
+            hipLaunchKernelGGL(apply_prologue_kernel, dim3(1), dim3(64), 0, s, ppo, net.grads + w.P, inv_w, net.opt_state);
         if (ppo.world_size > 1 || !ppo.grad_norm_ready)        // else: reduce_slabs_kernel left the squared norm in opt[9]
             hipLaunchKernelGGL(sqnorm_kernel, dim3(256), dim3(256), 0, s, w.P, net.grads, inv_w, net.opt_state);
         const SegTable tab = segments(false);

@@ -383,7 +383,10 @@ typedef struct HgymPPOConfig {
     float aux_coef;                 /* weight of the auxiliary head's MSE in the total loss (0 with aux_layers = 0) */
     int32_t grad_norm_ready;        /* 1: net->grads is exactly what the preceding hgym_ppo_grad left (one rank, nothing touched it),
                                        so its squared norm is already in opt_state[9] and apply skips its own pass over the
-                                       gradient; 0 (or world_size > 1): apply computes the norm itself */
+                                       gradient; 0 (or world_size > 1): apply computes the norm itself.  The flag is a PROMISE that every
+                                       hgym_ppo_grad is followed by exactly one hgym_ppo_apply with the same configuration: on the fused
+                                       bf16 path hgym_ppo_grad then also takes the adaptive-KL learning-rate decision and advances Adam's
+                                       step count (the work of apply's prologue, done beside the weight-gradient launch) */
 } HgymPPOConfig;
 
 /* Sizes (bytes) of the caller-allocated blocks, as functions of the configuration. */
