@@ -368,11 +368,9 @@ int32_t hgym_rollout_step(const HgymNetConfig* cfg, const HgymNet* net, const Hg
         // the critic workgroup pays for every k-step it takes over at the same L2 -> CU fill rate, and with all 20 it becomes the
         // launch's longest workgroup (profiles/r04_l0_ahead_ab.txt: collection 2.33 -> 2.27 ms with 12, 2.30 with 20, 2.34 with 8).
         // HGYM_L0_KB0 tunes the split (A/B runs).
-        static const int KB0_AHEAD = [] {
-            const char* e = getenv("HGYM_L0_KB0");
-            const int v = e ? atoi(e) : 12;
-            return (v >= 4 && v <= 20 && v % 4 == 0) ? v : 12;
-        }();
+        const char* kb0_env = getenv("HGYM_L0_KB0");          // (read per call: the tests run several splits in one process)
+        const int kb0_v = kb0_env ? atoi(kb0_env) : 12;
+        const int KB0_AHEAD = (kb0_v >= 4 && kb0_v <= 20 && kb0_v % 4 == 0) ? kb0_v : 12;
         HG_REQUIRE(!part || prev_out, HGYM_E_BADARG, "l0_ready on the first step of a rollout: no launch has left partial sums");
         HG_REQUIRE(!(part || out->l0_ahead) || (f.net[0].layer[0].KB == 24 && f.net[0].layer[0].N == 512 && HGYM_OBS_FRAME * 14 >= 32 * KB0_AHEAD),
                    HGYM_E_UNSUPPORTED, "the carried first layer is built for XBot-L's 15 x 47 -> 512 actor input");

@@ -440,6 +440,41 @@ def test_update_from_the_bf16_shadow_equals_update_from_fp32_rows(S, B):
     assert torch.equal(net.grads_ext, want)
 
 
+@pytest.mark.parametrize("kb0", ["12", "20", "4"])
+def test_first_layer_carried_across_launches_changes_nothing(monkeypatch, kb0):
+    """HgymEnvOut.l0_ahead / l0_ready (csrc/hgym_fused.hpp: L0Part / l0_partial_ahead): the critic workgroups of launch t form kb0 of the 24
+    k-steps of the ACTOR's first layer for the rows of step t + 1 (step t's rows shifted by one frame), launch t + 1's actor tile starts
+    from those fp32 partial sums, reads only the remaining columns, and drops the sums of rows whose env was reset in between.  Three
+    learning iterations (eager, capture + replay, replay; 1024 envs x 60 steps) with the hand-over and
+    without it (HGYM_L0_AHEAD=0) from the same seeds: rollout storage (observations, actions, log-probs, values, rewards, dones), the
+    bf16 shadows and the parameters must be BIT-identical -- same fragments, same k order, same accumulator chain.
+    Reference: /root/reference/humanoid/algo/ppo/actor_critic.py:53-80 (the actor's first Linear), on_policy_runner.py:129-141."""
+    from humanoid.algo import PPO
+    PPO.precision = "bf16"
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("HGYM_L0_AHEAD", mode)
+        monkeypatch.setenv("HGYM_L0_KB0", kb0)
+        torch.manual_seed(11)
+        np.random.seed(11)
+        r = _runner(1024, 31)
+        assert r.env._l0_ahead == (mode == "1")
+        r.learn(num_learning_iterations=3, init_at_random_ep_len=True)
+        torch.cuda.synchronize()
+        st = r.alg.storage
+        used = r.env._buf._l0_partial is not None and bool((r.env._buf._l0_partial != 0).any())
+        assert used == (mode == "1")                  # the hand-over buffers were really written (or never allocated)
+        outs[mode] = dict(params=r.alg.net.params.clone(), obs=st._obs_all.clone(), act=st.actions.clone(), logp=st.actions_log_prob.clone(),
+                          val=st.values.clone(), rew=st.rewards.clone(), dones=st.dones.clone(), sh=st._obs_bf16.clone(),
+                          resets=int(st.dones.sum()))
+        del r
+    a, b = outs["1"], outs["0"]
+    assert a["resets"] == b["resets"] and a["resets"] >= 10
+    for k in ("obs", "act", "logp", "val", "rew", "dones", "sh", "params"):
+        assert torch.equal(a[k], b[k]), k
+    assert torch.isfinite(a["params"]).all()
+
+
 @pytest.mark.parametrize("S,B", [(700, 333), (5000, 4096), (61440, 61440)])
 def test_update_on_128_row_tiles_equals_update_on_64_row_tiles(monkeypatch, S, B):
     """`mlp_fb2_kernel` (csrc/hgym_fb2.hpp: 128-row tiles, eight 256-register wavefronts, H0 never resident, tiles of 7 or 8 row
