@@ -24,6 +24,41 @@ EXTRA = {
 }
 
 
+# Every kernel must stay inside the 128 KiB short-branch range (s_cbranch reaches +-32 K dwords): round 4 found a 281 KB kernel whose mere
+# presence in the code object made multi-process runs on one GPU abort at random.  -save-temps=obj leaves the linked
+# device code object of each translation unit next to its .o; its symbol table gives every kernel's size.
+KERNEL_CODE_LIMIT = 128 * 1024
+READELF = os.environ.get("LLVM_READELF", "/opt/rocm/lib/llvm/bin/llvm-readelf")
+
+
+def kernel_sizes(objdir):
+    """{kernel symbol: bytes of code} over the device code objects in objdir (the *-gfx950.out files -save-temps left)."""
+    sizes = {}
+    for f in sorted(os.listdir(objdir)):
+        if not f.endswith("-hip-amdgcn-amd-amdhsa-%s.out" % ARCH):
+            continue
+        out = subprocess.run([READELF, "-s", "-W", os.path.join(objdir, f)], capture_output=True, text=True).stdout
+        for line in out.splitlines():
+            p = line.split()
+            if len(p) >= 8 and p[3] == "FUNC" and p[6] != "UND":
+                sizes[p[7]] = max(sizes.get(p[7], 0), int(p[2]))
+    return sizes
+
+
+def check_kernel_sizes(objdir, verbose=True):
+    import json
+    sizes = kernel_sizes(objdir)
+    if not sizes:
+        return sizes
+    json.dump(dict(limit=KERNEL_CODE_LIMIT, kernels=dict(sorted(sizes.items(), key=lambda kv: -kv[1]))), open(os.path.join(objdir, "kernel_sizes.json"), "w"), indent=1)
+    worst = max(sizes.items(), key=lambda kv: kv[1])
+    if verbose:
+        print("largest kernel: %d bytes of code (%s), limit %d" % (worst[1], worst[0][:60], KERNEL_CODE_LIMIT), flush=True)
+    if worst[1] >= KERNEL_CODE_LIMIT:
+        raise RuntimeError("kernel %s is %d bytes of code (>= %d): split it (see the comment in build.py)" % (worst[0], worst[1], KERNEL_CODE_LIMIT))
+    return sizes
+
+
 def _newer(src, dst, deps):
     if not os.path.exists(dst):
         return True
@@ -42,11 +77,16 @@ def build(force=False, verbose=True):
         obj = os.path.join(OBJDIR, f.replace(".hip", ".o"))
         objs.append(obj)
         if force or _newer(src, obj, headers):
-            cmd = [HIPCC] + COMMON + EXTRA.get(f, []) + ["-c", src, "-o", obj]
+            cmd = [HIPCC] + COMMON + EXTRA.get(f, []) + ["-save-temps=obj", "-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)
+            for t in os.listdir(OBJDIR):        # keep the device code object (.out) for the size check, drop the bulky intermediates
+                if t.startswith(f.replace(".hip", "")) and t.endswith((".hipi", ".bc", ".s", ".hipfb", ".resolution.txt")) or t.endswith("-host-x86_64-unknown-linux-gnu.o"):
+                    os.remove(os.path.join(OBJDIR, t))
             rebuilt = True
+    if rebuilt or not os.path.exists(os.path.join(OBJDIR, "kernel_sizes.json")):
+        check_kernel_sizes(OBJDIR, verbose)
     if rebuilt or not os.path.exists(LIB):
         cmd = [HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
         if verbose:

@@ -1033,15 +1033,17 @@ struct NetRunner {
                 lds = std::max(lds, (size_t)fused_lds_p(fa.net[i], 64) + (size_t)fused_lds_q(fa.net[i], 64) + (size_t)fused_lds_bias(fa.net[i]) +
                                         (size_t)fb_lds_extra(fa.net[i]));
             HG_REQUIRE(lds <= 160 * 1024, HGYM_E_UNSUPPORTED, "mlp_fb_kernel needs %zu bytes of LDS", lds);
-            const int32_t rc_lds = shadow ? ensure_dynamic_lds(reinterpret_cast<const void*>(&mlp_fb_kernel<true>), lds, "mlp_fb_kernel<shadow>")
-                                          : ensure_dynamic_lds(reinterpret_cast<const void*>(&mlp_fb_kernel<false>), lds, "mlp_fb_kernel");
+            // four instantiations: input rows from the bf16 shadow or the fp32 storage x with / without the auxiliary head's grid row
+            void (*const fbk)(const FwdArgs, const FbLoss) =
+                nets > 2 ? (shadow ? &mlp_fb_kernel<true, true> : &mlp_fb_kernel<false, true>)
+                         : (shadow ? &mlp_fb_kernel<true, false> : &mlp_fb_kernel<false, false>);
+            const int32_t rc_lds = ensure_dynamic_lds(reinterpret_cast<const void*>(fbk), lds, shadow ? "mlp_fb_kernel<shadow>" : "mlp_fb_kernel");
             if (rc_lds) return rc_lds;
             FwdArgs fb = fa;
             fb.nets = nets;
             fb.dbg = phase_buffer((int64_t)tiles * nets);
             prof_begin(HGYM_PROF_MLP_FWD, s);
-            if (shadow) hipLaunchKernelGGL(mlp_fb_kernel<true>, dim3(tiles, nets), dim3(1024), lds, s, fb, fl);
-            else hipLaunchKernelGGL(mlp_fb_kernel<false>, dim3(tiles, nets), dim3(1024), lds, s, fb, fl);
+            hipLaunchKernelGGL(fbk, dim3(tiles, nets), dim3(1024), lds, s, fb, fl);
             double flops = 0.0;
             for (int i = 0; i < nets; ++i) {
                 for (int l = 0; l < 4; ++l) flops += 2.0 * (double)B * w.net[i].layer[l].N * w.net[i].layer[l].K;

@@ -48,3 +48,31 @@ def test_errors_are_reported_not_swallowed():
     from hgym import _lib as L
     rc = L.lib.hgym_gae(0, 0, None, None, None, None, 0.9, 0.9, None, None, None, None)
     assert rc == -2 and b"T=0" in L.lib.hgym_last_error()
+
+
+def test_every_kernel_stays_inside_the_short_branch_range():
+    """Round 4's bug: a 281 KB kernel in the code object -- never launched -- made multi-process runs on one GPU abort at random with
+    HSA_STATUS_ERROR_ILLEGAL_INSTRUCTION.  build.py records every kernel's code size from the device code
+    objects it links (lib/obj/kernel_sizes.json) and refuses to build past 128 KiB; this test keeps the record honest."""
+    import importlib.util
+    import json
+    pkg = os.path.join(ROOT, "humanoid-gym_amd")
+    spec = importlib.util.spec_from_file_location("hgym_build", os.path.join(pkg, "build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    path = os.path.join(pkg, "lib", "obj", "kernel_sizes.json")
+    if not os.path.exists(path):
+        sizes = mod.check_kernel_sizes(os.path.join(pkg, "lib", "obj"), verbose=False)
+        if not sizes:
+            import pytest
+            pytest.skip("the library was built elsewhere (no device code objects beside it)")
+    d = json.load(open(path))
+    assert d["limit"] == mod.KERNEL_CODE_LIMIT == 128 * 1024
+    names = list(d["kernels"])
+    assert any("rollout_step_kernel" in k for k in names) and any("mlp_fb_kernel" in k for k in names) and any("dw_kernel_rs" in k for k in names)
+    worst = max(d["kernels"].items(), key=lambda kv: kv[1])
+    assert worst[1] < d["limit"], worst
+    # the kernels of every default run keep a margin: only the auxiliary-head instantiations come close to the limit
+    for k, v in d["kernels"].items():
+        if "mlp_fb_kernelILb1ELb0E" in k or "mlp_fb_kernelILb0ELb0E" in k or "rollout_step_kernel" in k or "dw_kernel_rs" in k:
+            assert v < 112 * 1024, (k, v)
