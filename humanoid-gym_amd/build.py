@@ -24,10 +24,13 @@ EXTRA = {
 }
 
 
-# Every kernel must stay inside the 128 KiB short-branch range (s_cbranch reaches +-32 K dwords): round 4 found a 281 KB kernel whose mere
-# presence in the code object made multi-process runs on one GPU abort at random.  -save-temps=obj leaves the linked
-# device code object of each translation unit next to its .o; its symbol table gives every kernel's size.
+# Round 4 found that a device code object beyond ~1 MiB in the library makes runs of eight processes on one GPU abort at random with
+# HSA_STATUS_ERROR_ILLEGAL_INSTRUCTION, whether or not anything of it is launched (csrc/hgym_fb2.hip has the bisection: 0.87 - 0.99 MB fine,
+# 1.15 / 1.19 MB not).  -save-temps=obj leaves the linked device code object of each translation unit next to its .o: every one must stay
+# below CODE_OBJECT_LIMIT, and every kernel inside the 128 KiB short-branch range (s_cbranch reaches +-32 K dwords) -- a big kernel belongs
+# in a translation unit of its own.
 KERNEL_CODE_LIMIT = 128 * 1024
+CODE_OBJECT_LIMIT = 960 * 1024
 READELF = os.environ.get("LLVM_READELF", "/opt/rocm/lib/llvm/bin/llvm-readelf")
 
 
@@ -50,7 +53,14 @@ def check_kernel_sizes(objdir, verbose=True):
     sizes = kernel_sizes(objdir)
     if not sizes:
         return sizes
-    json.dump(dict(limit=KERNEL_CODE_LIMIT, kernels=dict(sorted(sizes.items(), key=lambda kv: -kv[1]))), open(os.path.join(objdir, "kernel_sizes.json"), "w"), indent=1)
+    objects = {f: os.path.getsize(os.path.join(objdir, f)) for f in sorted(os.listdir(objdir)) if f.endswith("-hip-amdgcn-amd-amdhsa-%s.out" % ARCH)}
+    json.dump(dict(limit=KERNEL_CODE_LIMIT, code_object_limit=CODE_OBJECT_LIMIT, code_objects=objects,
+                   kernels=dict(sorted(sizes.items(), key=lambda kv: -kv[1]))), open(os.path.join(objdir, "kernel_sizes.json"), "w"), indent=1)
+    big = max(objects.items(), key=lambda kv: kv[1])
+    if verbose:
+        print("largest device code object: %d bytes (%s), limit %d" % (big[1], big[0], CODE_OBJECT_LIMIT), flush=True)
+    if big[1] >= CODE_OBJECT_LIMIT:
+        raise RuntimeError("device code object %s is %d bytes (>= %d): move kernels into another translation unit (see build.py)" % (big[0], big[1], CODE_OBJECT_LIMIT))
     worst = max(sizes.items(), key=lambda kv: kv[1])
     if verbose:
         print("largest kernel: %d bytes of code (%s), limit %d" % (worst[1], worst[0][:60], KERNEL_CODE_LIMIT), flush=True)

@@ -29,7 +29,9 @@
 // ppo_scalars_block exactly as the 64-row kernel groups its head waves, so the loss scalars and the std / head-bias gradients are
 // bit-identical too (tests/test_fused_gpu.py: the shadow path, which takes this kernel, against the fp32-row path, which does not).
 #pragma once
-#include "hgym_fused.hpp"
+#include <algorithm>
+
+#include "hgym_fb2_api.hpp"
 #pragma clang fp contract(fast)
 
 namespace hgym {
@@ -54,11 +56,6 @@ HG_HD int fb2_lds_bytes(const FusedNet& n) {
     const int lin = n.layer[3].N == 1 ? FB2_BM * 2 * 4 : FB2_BM * FB2_LIN_ACTOR * 4;
     return FB2_P_BYTES + fused_lds_bias(n) + FB2_BM * 4 + lin;
 }
-
-struct Fb2Sched {
-    int nb;      // row blocks of 16 in the (64-padded) batch
-    int T;       // tiles per net: tile i owns row blocks [i * nb / T, (i + 1) * nb / T), at most 8 of them
-};
 
 // bias + ELU -> bf16 -> LDS block layout (column block cbl0 + g of a matrix with CBl column blocks) and, for the row blocks this
 // tile owns, the same blocks in HBM (column block cbg0 + g of CBg)
@@ -513,10 +510,9 @@ __device__ __forceinline__ void fb2_body(const FwdArgs& a, const FbLoss& L, cons
 }
 
 // grid (T tiles, nets); 512 threads; one workgroup per CU (153.5 KB of LDS).  Nets: 0 actor, 1 critic.
-// ONE instantiation per (actor shape, critic shape) pair, and only XBot-L's is built: a first version dispatched over all five bodies
-// inside one kernel -- 281 KB of code -- and its mere PRESENCE in the code object (never launched) made multi-process runs on one GPU
-// abort at random with HSA_STATUS_ERROR_ILLEGAL_INSTRUCTION (tests/test_dist_gpu.py, 8 ranks: 0 / 6 failures without it, 3-4 / 6 with
-// it, 0 / 6 with a single-body build; bisected in round 4).  Every other kernel of the library is < 130 KB; so is this one now.
+// ONE instantiation per (actor shape, critic shape) pair, and only XBot-L's is built (hgym_fb2_api.hpp): a first version dispatched over
+// all five bodies inside one kernel -- 281 KB of code inside hgym_net's code object -- and its mere PRESENCE (never launched) made
+// multi-process runs on one GPU abort at random (hgym_fb2.hip has the story: the limit is the size of a device code object).
 template <int NCH_A, bool STREAM_A, int NCH_C, bool STREAM_C>
 __global__ __launch_bounds__(FB2_NW * 64) void mlp_fb2_kernel(const FwdArgs a, const FbLoss L, const Fb2Sched sch) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -525,8 +521,5 @@ __global__ __launch_bounds__(FB2_NW * 64) void mlp_fb2_kernel(const FwdArgs a, c
     if (which == 0) fb2_body<NCH_A, STREAM_A>(a, L, sch, n, true, smem);
     else fb2_body<NCH_C, STREAM_C>(a, L, sch, n, false, smem);
 }
-// the shapes the one instantiation serves: (first hidden width / 256, input wider than two 128-column chunks) of actor and critic
-constexpr int FB2_NCH_A = 2, FB2_NCH_C = 3;
-constexpr bool FB2_STREAM_A = true, FB2_STREAM_C = false;
 
 }  // namespace hgym

@@ -1198,20 +1198,15 @@ __device__ __forceinline__ void fb_body(const FwdArgs& a, const FbLoss& L, const
     phase_stamp(a.dbg, 7);
 }
 
-// XB16: every net of the launch gathers its input rows from the bf16 shadow (FusedNet::xb) instead of the fp32 storage rows.
-// WITH_AUX: the launch has a third grid row, the auxiliary head's tile (its body is compiled into that instantiation only: with it the
-// kernel is 127-130 KB of code, and kernels beyond the 128 KB short-branch range turned out to be a hazard -- hgym_fb2.hpp, DESIGN.md
-// section 7 round 4; the actor + critic launch of every default run stays ~25 KB below it).
-template <bool XB16 = false, bool WITH_AUX = false>
+// XB16: every net of the launch gathers its input rows from the bf16 shadow (FusedNet::xb) instead of the fp32 storage rows
+template <bool XB16 = false>
 __global__ __launch_bounds__(1024) void mlp_fb_kernel(const FwdArgs a, const FbLoss L) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int which = a.net0 + blockIdx.y;
     const FusedNet& n = a.net[which];
     const int g1 = n.layer[0].NB / 16;     // first hidden width 256 / 512 / 768
     if (which == 2) {                      // the auxiliary head (wide head, first hidden width 512 only): MSE instead of the PPO loss
-        if constexpr (WITH_AUX) {
-            if (g1 == 2) fb_body<2, true, XB16>(a, L, n, false, smem);
-        }
+        if (g1 == 2) fb_body<2, true, XB16>(a, L, n, false, smem);
         return;
     }
     if (g1 == 2) fb_body<2, false, XB16>(a, L, n, which == 0, smem);

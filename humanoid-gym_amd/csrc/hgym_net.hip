@@ -16,11 +16,7 @@
 
 #include "hgym_gemm.hpp"
 #include "hgym_fused.hpp"
-#ifndef HGYM_NO_FB2_KERNEL
-#include "hgym_fb2.hpp"
-#else
-namespace hgym { struct Fb2Sched { int nb, T; }; }
-#endif
+#include "hgym_fb2_api.hpp"      // mlp_fb2_kernel lives in a translation unit of its own (hgym_fb2.hip): see the note there
 
 namespace hgym {
 
@@ -949,18 +945,12 @@ struct NetRunner {
         // bit-identical to mlp_fb_kernel's (tests/test_fused_gpu.py).
         const char* fb2_env = getenv("HGYM_FB2");                                // read per call: tests flip it
         const bool no_fb2 = !(fb2_env && fb2_env[0] == '1');
-#ifdef HGYM_NO_FB2_KERNEL
-        bool fb2 = false && no_fb2;
-#else
         bool fb2 = shadow && !no_fb2 && nets == 2 && A == 12;
-#endif
-#ifndef HGYM_NO_FB2_KERNEL
         for (int i = 0; i < 2 && fb2; ++i) {      // the one (actor, critic) shape pair the kernel is instantiated for: XBot-L's
             const NetLayout& n = w.net[i];
             fb2 = n.layer[1].N == 256 && n.layer[2].N == 128 && n.layer[3].N <= 16 &&
                   n.layer[0].N == 256 * (i == 0 ? FB2_NCH_A : FB2_NCH_C) && (n.layer[0].KBf > 8) == (i == 0 ? FB2_STREAM_A : FB2_STREAM_C);
         }
-#endif
         Fb2Sched sch = {0, 0};
         if (fb2) {
             // tiles of 7 or 8 row blocks: as many tiles per net as a whole number of rounds over the CUs when that keeps them >= 6 high
@@ -1005,45 +995,34 @@ struct NetRunner {
             fl.aux_ldt = cfg.num_priv;
             fl.aux_off = cfg.aux_target_offset;
             fl.aux_coef = ppo.aux_coef;
-#ifndef HGYM_NO_FB2_KERNEL
             if (fb2) {
-                size_t lds2 = 0;
-                for (int i = 0; i < nets; ++i) lds2 = std::max(lds2, (size_t)fb2_lds_bytes(fa.net[i]));
-                HG_REQUIRE(lds2 <= 160 * 1024, HGYM_E_UNSUPPORTED, "mlp_fb2_kernel needs %zu bytes of LDS", lds2);
-                auto* const fb2k = &mlp_fb2_kernel<FB2_NCH_A, FB2_STREAM_A, FB2_NCH_C, FB2_STREAM_C>;
-                const int32_t rc2 = ensure_dynamic_lds(reinterpret_cast<const void*>(fb2k), lds2, "mlp_fb2_kernel");
-                if (rc2) return rc2;
                 FwdArgs fb = fa;
                 fb.nets = nets;
                 fb.dbg = phase_buffer((int64_t)tiles * nets);
                 prof_begin(HGYM_PROF_MLP_FWD, s);
-                hipLaunchKernelGGL(fb2k, dim3(tiles, nets), dim3(FB2_NW * 64), lds2, s, fb, fl, sch);
+                const int32_t rc2 = launch_fb2(fb, fl, sch, tiles, nets, s);
+                if (rc2) return rc2;
                 double flops = 0.0;
                 for (int i = 0; i < nets; ++i) {
                     for (int l = 0; l < 4; ++l) flops += 2.0 * (double)B * w.net[i].layer[l].N * w.net[i].layer[l].K;
                     for (int l = 1; l < 4; ++l) flops += 2.0 * (double)B * w.net[i].layer[l].K * w.net[i].layer[l].N;
                 }
                 prof_end(HGYM_PROF_MLP_FWD, s, flops);
-                HG_CHECK_LAUNCH("mlp_fb2_kernel");
-            } else
-#endif
-            {
+            } else {
             size_t lds = 0;
             for (int i = 0; i < nets; ++i)
                 lds = std::max(lds, (size_t)fused_lds_p(fa.net[i], 64) + (size_t)fused_lds_q(fa.net[i], 64) + (size_t)fused_lds_bias(fa.net[i]) +
                                         (size_t)fb_lds_extra(fa.net[i]));
             HG_REQUIRE(lds <= 160 * 1024, HGYM_E_UNSUPPORTED, "mlp_fb_kernel needs %zu bytes of LDS", lds);
-            // four instantiations: input rows from the bf16 shadow or the fp32 storage x with / without the auxiliary head's grid row
-            void (*const fbk)(const FwdArgs, const FbLoss) =
-                nets > 2 ? (shadow ? &mlp_fb_kernel<true, true> : &mlp_fb_kernel<false, true>)
-                         : (shadow ? &mlp_fb_kernel<true, false> : &mlp_fb_kernel<false, false>);
-            const int32_t rc_lds = ensure_dynamic_lds(reinterpret_cast<const void*>(fbk), lds, shadow ? "mlp_fb_kernel<shadow>" : "mlp_fb_kernel");
+            const int32_t rc_lds = shadow ? ensure_dynamic_lds(reinterpret_cast<const void*>(&mlp_fb_kernel<true>), lds, "mlp_fb_kernel<shadow>")
+                                          : ensure_dynamic_lds(reinterpret_cast<const void*>(&mlp_fb_kernel<false>), lds, "mlp_fb_kernel");
             if (rc_lds) return rc_lds;
             FwdArgs fb = fa;
             fb.nets = nets;
             fb.dbg = phase_buffer((int64_t)tiles * nets);
             prof_begin(HGYM_PROF_MLP_FWD, s);
-            hipLaunchKernelGGL(fbk, dim3(tiles, nets), dim3(1024), lds, s, fb, fl);
+            if (shadow) hipLaunchKernelGGL(mlp_fb_kernel<true>, dim3(tiles, nets), dim3(1024), lds, s, fb, fl);
+            else hipLaunchKernelGGL(mlp_fb_kernel<false>, dim3(tiles, nets), dim3(1024), lds, s, fb, fl);
             double flops = 0.0;
             for (int i = 0; i < nets; ++i) {
                 for (int l = 0; l < 4; ++l) flops += 2.0 * (double)B * w.net[i].layer[l].N * w.net[i].layer[l].K;

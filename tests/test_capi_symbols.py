@@ -50,10 +50,11 @@ def test_errors_are_reported_not_swallowed():
     assert rc == -2 and b"T=0" in L.lib.hgym_last_error()
 
 
-def test_every_kernel_stays_inside_the_short_branch_range():
-    """Round 4's bug: a 281 KB kernel in the code object -- never launched -- made multi-process runs on one GPU abort at random with
-    HSA_STATUS_ERROR_ILLEGAL_INSTRUCTION.  build.py records every kernel's code size from the device code
-    objects it links (lib/obj/kernel_sizes.json) and refuses to build past 128 KiB; this test keeps the record honest."""
+def test_code_objects_and_kernels_stay_below_their_size_limits():
+    """Round 4's bug: with a device code object beyond ~1 MiB in the library -- the first mlp_fb2_kernel, 281 KB, compiled into hgym_net's --
+    runs of eight processes on one GPU aborted at random with HSA_STATUS_ERROR_ILLEGAL_INSTRUCTION, launched or not (csrc/hgym_fb2.hip has
+    the bisection).  build.py records the size of every device code object and of every kernel it links (lib/obj/kernel_sizes.json) and
+    refuses to build past 960 KiB per code object / 128 KiB per kernel; this test keeps the record honest."""
     import importlib.util
     import json
     pkg = os.path.join(ROOT, "humanoid-gym_amd")
@@ -67,12 +68,9 @@ def test_every_kernel_stays_inside_the_short_branch_range():
             import pytest
             pytest.skip("the library was built elsewhere (no device code objects beside it)")
     d = json.load(open(path))
-    assert d["limit"] == mod.KERNEL_CODE_LIMIT == 128 * 1024
+    assert d["limit"] == mod.KERNEL_CODE_LIMIT == 128 * 1024 and d["code_object_limit"] == mod.CODE_OBJECT_LIMIT == 960 * 1024
     names = list(d["kernels"])
     assert any("rollout_step_kernel" in k for k in names) and any("mlp_fb_kernel" in k for k in names) and any("dw_kernel_rs" in k for k in names)
-    worst = max(d["kernels"].items(), key=lambda kv: kv[1])
-    assert worst[1] < d["limit"], worst
-    # the kernels of every default run keep a margin: only the auxiliary-head instantiations come close to the limit
-    for k, v in d["kernels"].items():
-        if "mlp_fb_kernelILb1ELb0E" in k or "mlp_fb_kernelILb0ELb0E" in k or "rollout_step_kernel" in k or "dw_kernel_rs" in k:
-            assert v < 112 * 1024, (k, v)
+    assert max(d["kernels"].values()) < d["limit"], max(d["kernels"].items(), key=lambda kv: kv[1])
+    assert len(d["code_objects"]) >= 6 and any(f.startswith("hgym_fb2-") for f in d["code_objects"])       # the 128-row kernel has its own
+    assert max(d["code_objects"].values()) < d["code_object_limit"], d["code_objects"]
