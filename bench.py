@@ -57,9 +57,11 @@ def parse():
                    help="humanoid_ppo = BASELINE configs[1] (the headline); humanoid_dwl_ppo adds the denoising head (configs[4])")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-roofline", action="store_true")
-    p.add_argument("--pmc", action="store_true",
-                   help="collect roofline.traffic IN THIS RUN: two extra rocprofv3 passes (--kernel-trace --pmc FETCH_SIZE, then WRITE_SIZE) "
-                        "over a short run of the same workload; without it the committed profiles/pmc_traffic.json is quoted, with its provenance")
+    p.add_argument("--pmc", action="store_true", help="(default at --gpus 1 since round 4; kept for old command lines)")
+    p.add_argument("--no-pmc", action="store_true",
+                   help="do NOT collect roofline.traffic in this run.  By default (one GPU, roofline on) two extra rocprofv3 passes (--kernel-trace "
+                        "--pmc FETCH_SIZE, then WRITE_SIZE; counters + kernel-trace only) run over a short run of the same workload, ~40 s each, "
+                        "300 s limit; if they fail or are switched off the committed profiles/pmc_traffic.json is quoted, with its provenance")
     p.add_argument("--configs", default=",".join(EXTRA_CONFIGS),
                    help="extra single-GPU configurations reported under \"configs\" (N=1 only); \"\" or none: skip")
     return p.parse_args()
@@ -227,9 +229,13 @@ def collect_pmc_traffic():
     csvs = {}
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         d = os.path.join(tmp, ctr)
-        r = subprocess.run([rp, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "t", "--", sys.executable,
-                            os.path.join(ROOT, "tools", "traffic_run.py")], cwd=tmp, env=dict(os.environ, TMPDIR=tmp),
-                           capture_output=True, text=True, timeout=900)
+        try:
+            r = subprocess.run([rp, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "t", "--", sys.executable,
+                                os.path.join(ROOT, "tools", "traffic_run.py")], cwd=tmp, env=dict(os.environ, TMPDIR=tmp),
+                               capture_output=True, text=True, timeout=300)
+        except subprocess.TimeoutExpired:
+            sys.stderr.write("--pmc: %s pass exceeded its 300 s limit; quoting the committed file instead\n" % ctr)
+            return None
         found = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
         if r.returncode != 0 or not found:
             sys.stderr.write("--pmc: %s pass failed (rc %d): %s\n" % (ctr, r.returncode, r.stderr[-300:]))
@@ -450,7 +456,9 @@ def main():
     PPO.precision = args.precision
 
     args.pmc_result = None
-    if args.pmc and world == 1 and not args.no_roofline and not os.environ.get("HGYM_BENCH_CHILD"):
+    want_pmc = (args.pmc or not args.no_pmc) and os.environ.get("HGYM_BENCH_PMC", "1") != "0"
+    if (want_pmc and world == 1 and not args.no_roofline and not os.environ.get("HGYM_BENCH_CHILD") and args.task == "humanoid_ppo"
+            and args.num_envs == 4096 and args.precision == "bf16"):
         os.environ["HGYM_BENCH_CHILD"] = "1"            # tools/traffic_run.py runs this file again: not recursively
         args.pmc_result = collect_pmc_traffic()
         del os.environ["HGYM_BENCH_CHILD"]

@@ -1,5 +1,6 @@
 #!/bin/bash
 # usage: tools/gpu_pmc_bench.sh <tag> <counters...>  -- one PMC pass (kernel-trace + counters only) over a short bench.py run (in-situ kernels)
+export HGYM_BENCH_PMC=0   # (bench.py collects PMC traffic itself by default: not under another profiler)
 tag=$1; shift
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out

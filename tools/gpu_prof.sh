@@ -1,5 +1,6 @@
 #!/bin/bash
 # usage: tools/gpu_prof.sh <tag> "<bench args>"  -- rocprofv3 kernel trace + stats of one short bench run, per-(kernel, grid) summary
+export HGYM_BENCH_PMC=0   # (bench.py collects PMC traffic itself by default: not under another profiler)
 tag=$1; bargs=$2
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out

@@ -1,5 +1,6 @@
 #!/bin/bash
 # usage: tools/gpu_round.sh <tag>  -- GPU tests + smoke + default bench + rocprofv3 kernel-trace stats of the same bench command
+export HGYM_BENCH_PMC=0   # (bench.py collects PMC traffic itself by default: not under another profiler)
 tag=$1
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out
@@ -13,7 +14,7 @@ timeout 600 python bench.py > gpurun_out/${tag}_bench.txt 2>&1
 echo "bench exit $?" >> gpurun_out/${tag}_bench.txt
 tail -2 gpurun_out/${tag}_bench.txt | cut -c1-1500
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$tag -o $tag -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --configs none > $R/gpurun_out/${tag}_rocprof.txt 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$tag -o $tag -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-pmc --configs none > $R/gpurun_out/${tag}_rocprof.txt 2>&1
 echo "rocprof exit $?" >> $R/gpurun_out/${tag}_rocprof.txt
 cd $R
 f=$(find gpurun_out/prof_$tag -name "*kernel_stats.csv" | head -1)
