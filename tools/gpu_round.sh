@@ -1,6 +1,5 @@
 #!/bin/bash
 # usage: tools/gpu_round.sh <tag>  -- GPU tests + smoke + default bench + rocprofv3 kernel-trace stats of the same bench command
-export HGYM_BENCH_PMC=0   # (bench.py collects PMC traffic itself by default: not under another profiler)
 tag=$1
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out
