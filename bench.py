@@ -262,8 +262,11 @@ def _roofline(L, runner, elapsed_per_iter_ms, precision, n_profiled_iters, traff
         (L.PROF_APPLY, "sqnorm+adam_kernel", "hbm"), (L.PROF_GAE, "gae_kernel", "hbm")]
     traffic, source, counters = {}, None, {}
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")     # HBM bytes per launch from rocprofv3 --pmc passes
+    if os.path.exists(tpath) and traffic_ok:        # SQ / TCC counter passes are not repeated in the run: quoted from the committed file
+        counters = json.load(open(tpath)).get("counters", {})
     if pmc is not None and traffic_ok:
         traffic = pmc.get("kernels", {})
+        counters = pmc.get("counters", counters)
         source = dict(kind="measured in this run", how="rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE, separate passes (bench.py --pmc)",
                       fetch_calibration=pmc.get("fetch_calibration"))
     elif os.path.exists(tpath) and traffic_ok:     # the counters were collected on the headline workload: they say nothing about another size
@@ -286,6 +289,8 @@ def _roofline(L, runner, elapsed_per_iter_ms, precision, n_profiled_iters, traff
                        # rocprofv3 SQ / TCC passes (tools/gpu_counters.sh), same provenance as `traffic`: MFMA-pipe occupancy
                        # (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs)) and L2 hit rate of this kernel
                        mfma_busy=counters.get(name, {}).get("mfma_busy"), l2_hit=counters.get(name, {}).get("l2_hit"),
+                       counters_source=("profiles/pmc_traffic.json (rocprofv3 SQ / TCC passes, tools/gpu_counters.sh; committed file, not "
+                                        "measured in this run)" if counters.get(name) else None),
                        # counter traffic per launch over this run's launch time, as a fraction of the HBM peak: how close the kernel
                        # is to being bound by the bytes it actually moves, whatever its algorithmic bound says
                        traffic_frac_of_hbm_peak=(tr / (ms / n * 1e-3) / 1e9 / HBM_PEAK_GBS) if tr else None))
