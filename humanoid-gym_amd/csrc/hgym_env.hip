@@ -67,28 +67,34 @@ __global__ __launch_bounds__(256) void env_step_kernel(const EnvArgs A) {
     // for each of the 12 joints runs one (env, joint) pair per lane before (phase J) and after (phase F) a shorter chain, and
     // the synthetic physics' per-env remainder runs on two otherwise idle wavefronts of phase J.
     const bool split = HGYM_ENV_SPLIT && !kGeneric && E_T > 0 && (kStep || A.mode == MODE_STEP);
-    if (split) env_step_phase_j<E_T>(A, blockIdx.x, t, blockDim.x, smem);
+    constexpr bool kW3 = HGYM_ENV_SPLIT && HGYM_ENV_WAVES3 && !kGeneric && E_T > 0 && kStep;     // the chain on three wavefronts
+    if (split) env_step_phase_j<E_T, kW3>(A, blockIdx.x, t, blockDim.x, smem);
     else if (!(A.ablate & 128)) env_step_joints<E_T>(A, blockIdx.x, t, blockDim.x, smem);
     __syncthreads();
-    // wavefront 0 runs the per-env scalar chains (one lane per env); the other wavefronts meanwhile move the older frames of
-    // the observation history, which depend on nothing this step computes (reset envs are fixed up in phase B)
-    if (t < 64) {
-        if (!(A.ablate & 2)) {
-            if (split) env_step_phase_a<E_T, kGeneric, true>(A, blockIdx.x, t, smem, csc0);
-            else env_step_phase_a<E_T, kGeneric>(A, blockIdx.x, t, smem, csc0);
+    // wavefront 0 (kW3: wavefronts 0-2) runs the per-env scalar chains (one lane per env); the other wavefronts meanwhile move the
+    // older frames of the observation history, which depend on nothing this step computes (reset envs are fixed up in phase B) --
+    // their stores are issued first
+    if (t >= 64) {
+        if (kPrefetch) {
+            if (stack_on) {
+                hist_store<HP, HGYM_OBS_FRAME, NIO>(A.out.obs, geom.e0, geom.nE, (int)(ring_step % HP), t - 64, NTH, nullptr, A.cfg.clip_obs, hist_o);
+                hist_store<HCP, HGYM_PRIV_FRAME, NIP>(A.out.priv_obs, geom.e0, geom.nE, (int)(ring_step % HCP), t - 64, NTH, nullptr, A.cfg.clip_obs,
+                                                      hist_p);
+            }
+        } else if (!(A.ablate & 8) && A.phase != 1) {
+            env_step_stack_old<H_T, HC_T, E_T>(A, blockIdx.x, t - 64, blockDim.x - 64, ring_step);
         }
-    } else if (kPrefetch) {
-        if (stack_on) {
-            hist_store<HP, HGYM_OBS_FRAME, NIO>(A.out.obs, geom.e0, geom.nE, (int)(ring_step % HP), t - 64, NTH, nullptr, A.cfg.clip_obs, hist_o);
-            hist_store<HCP, HGYM_PRIV_FRAME, NIP>(A.out.priv_obs, geom.e0, geom.nE, (int)(ring_step % HCP), t - 64, NTH, nullptr, A.cfg.clip_obs,
-                                                  hist_p);
-        }
-    } else if (!(A.ablate & 8) && A.phase != 1) {
-        env_step_stack_old<H_T, HC_T, E_T>(A, blockIdx.x, t - 64, blockDim.x - 64, ring_step);
+    }
+    if (kW3) {
+        if (t < 192 && !(A.ablate & 2)) env_step_phase_a3<E_T>(A, blockIdx.x, t, blockDim.x, smem, csc0);
+    } else if (t < 64 && !(A.ablate & 2)) {
+        if (split) env_step_phase_a<E_T, kGeneric, true>(A, blockIdx.x, t, smem, csc0);
+        else env_step_phase_a<E_T, kGeneric>(A, blockIdx.x, t, smem, csc0);
     }
     __syncthreads();
     if (split) {
         env_step_phase_f<E_T>(A, blockIdx.x, t, blockDim.x, smem);
+        if (kW3 && !(A.ablate & 2)) env_step_reward_sum<E_T>(A, blockIdx.x, t, blockDim.x, smem);
         __syncthreads();
     }
     if (!(A.ablate & 4)) env_stage_out<E_T>(A, blockIdx.x, t, blockDim.x, smem);

@@ -403,9 +403,31 @@ HG_HD void joint_terms(const HgymEnvConfig& c, int j, float a, float la, float l
 // per-joint part of the reset, the reference pose, the per-joint frame entries and the last_* write-back after it
 // (env_step_phase_f, which takes this step's reset flag and gait-clock sine from `cscal`).  Same arithmetic, same order.
 constexpr int kJointTerms = 8;     // per-joint products: d1^2, d2^2, |a| (term 0), jd^2 (4), acc^2 (5), qd^2 (6), tq^2 (17), (q - ref)^2 (13)
-template <bool kGeneric, bool kSplit = false>
+// ROLE (split chain only): the chain is one wavefront issuing ~2 500 instructions once; three wavefronts of the workgroup can share it.
+//   ROLE_ALL    everything (one wavefront, the form above);
+//   ROLE_MAIN   everything but the reward terms and the state only they touch: derived state, commands, push, termination, reset,
+//               frames, write-back;
+//   ROLE_REW_A / ROLE_REW_B   the derived quantities their terms need (re-derived from a SNAPSHOT of root state / commands / episode
+//               length / last root velocity taken before the phase: ROLE_MAIN rewrites those while the three run) and their share of
+//               the 22 terms, left times their scale in `tscr` [22][N]; B owns the stateful terms 7 / 8 and their four state fields.
+// env_step_reward_sum then forms the reward and the episode sums in the reference's order.  No wavefront reads what another writes
+// during the phase; tests/hostcheck runs the three roles in both orders.
+#ifndef HGYM_ENV_WAVES3
+#define HGYM_ENV_WAVES3 1      // the split per-env chain of the compiled-in fast kernels on three wavefronts; 0: on one
+#endif
+constexpr int ROLE_ALL = 0, ROLE_MAIN = 1, ROLE_REW_A = 2, ROLE_REW_B = 3;
+HG_HD constexpr bool term_in_role(int k, int role) {
+    // A: the terms of the base velocities / orientation / commands (they need the quaternion prefix); B: feet, gait clock, joint sums
+    const bool a = k == 1 || k == 15 || k == 16 || k == 18 || k == 19 || k == 20 || k == 21;
+    return role == ROLE_ALL || (role == ROLE_REW_A && a) || (role == ROLE_REW_B && !a);
+}
+template <bool kGeneric, bool kSplit = false, int ROLE = ROLE_ALL>
 HG_HD StepFlags post_physics_env(const EnvArgs& A, const RngKey& rk, int64_t csc, int e, int N, float* frame47,
-                                 float* priv73, const float* jpart = nullptr, float* cscal = nullptr, const float* reset_pose = nullptr) {
+                                 float* priv73, const float* jpart = nullptr, float* cscal = nullptr, const float* reset_pose = nullptr,
+                                 float* tscr = nullptr) {
+    static_assert(ROLE == ROLE_ALL || (kSplit && !kGeneric), "the three-wavefront form exists for the split XBot-L chain only");
+    constexpr bool kMain = ROLE == ROLE_ALL || ROLE == ROLE_MAIN;      // state write-back, reset, frames
+    constexpr bool kFeet = ROLE == ROLE_ALL || ROLE == ROLE_REW_B;     // owner of last_contacts / feet_air_time / feet_height / last_feet_z
     const HgymEnvConfig& c = A.cfg;
     const HgymEnvState& S = A.st;
     const int mode = A.mode;
@@ -456,7 +478,7 @@ HG_HD StepFlags post_physics_env(const EnvArgs& A, const RngKey& rk, int64_t csc
 #pragma unroll
     for (int k = 0; k < kJointTerms; ++k) {
         jsum[k] = 0.0f;
-        if (kSplit) {
+        if (kSplit && kFeet) {
 #pragma unroll
             for (int j = 0; j < 12; ++j) jsum[k] += jpart[(k * 12 + j) * N + e];
         }
@@ -536,8 +558,10 @@ HG_HD StepFlags post_physics_env(const EnvArgs& A, const RngKey& rk, int64_t csc
         if (c.push_robots && (csc % c.push_interval == 0)) {          // humanoid_env.py:83-98
             const float px = c.push_vel_span * nz_uniform(A.noise.u_push, 5, 0, rk, e, ge, SLOT_PUSH, 0) + c.push_vel_lo;
             const float py = c.push_vel_span * nz_uniform(A.noise.u_push, 5, 1, rk, e, ge, SLOT_PUSH, 1) + c.push_vel_lo;
-            FG(S.push_force, 0) = px;
-            FG(S.push_force, 1) = py;
+            if (kMain) {
+                FG(S.push_force, 0) = px;
+                FG(S.push_force, 1) = py;
+            }
             pf[0] = px;
             pf[1] = py;
             root[7] = px;
@@ -545,15 +569,17 @@ HG_HD StepFlags post_physics_env(const EnvArgs& A, const RngKey& rk, int64_t csc
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 const float t = c.push_ang_span * nz_uniform(A.noise.u_push, 5, 2 + i, rk, e, ge, SLOT_PUSH, 2 + i) + c.push_ang_lo;
-                FG(S.push_torque, i) = t;
+                if (kMain) FG(S.push_torque, i) = t;
                 pt[i] = t;
                 root[10 + i] = t;
             }
-            sset(A.sim.root, e, 7, root[7]);
-            sset(A.sim.root, e, 8, root[8]);
-            sset(A.sim.root, e, 10, root[10]);
-            sset(A.sim.root, e, 11, root[11]);
-            sset(A.sim.root, e, 12, root[12]);
+            if (kMain) {
+                sset(A.sim.root, e, 7, root[7]);
+                sset(A.sim.root, e, 8, root[8]);
+                sset(A.sim.root, e, 10, root[10]);
+                sset(A.sim.root, e, 11, root[11]);
+                sset(A.sim.root, e, 12, root[12]);
+            }
         }
       }
         // check_termination :156-161
@@ -562,7 +588,7 @@ HG_HD StepFlags post_physics_env(const EnvArgs& A, const RngKey& rk, int64_t csc
             const float bn = sqrtf(bx * bx + by * by + bz * bz);
             time_out = ep > (int64_t)c.max_episode_length;
             reset = (bn > 1.0f) || time_out;
-          if (phase != 1) {
+          if (phase != 1 && ROLE != ROLE_MAIN) {
             // ---------------- compute_reward :217-235, 22 terms in alphabetical order ----------------
             const float s = sinf(kTwoPi * gait_phase(c, ep));
             float stance[2];
@@ -642,19 +668,20 @@ HG_HD StepFlags post_physics_env(const EnvArgs& A, const RngKey& rk, int64_t csc
                 for (int f = 0; f < 2; ++f) {
                     const float lc = lcon[f];
                     const int filt = (contact[f] > 0.5f) || (stance[f] > 0.5f) || (lc > 0.5f);
-                    FG(S.last_contacts, f) = contact[f];
+                    if (kFeet) FG(S.last_contacts, f) = contact[f];
                     float air = fat[f];
                     const int first = (air > 0.0f) && filt;
                     air += c.dt;
                     r7 += clampf(air, 0.0f, 0.5f) * (first ? 1.0f : 0.0f);
-                    FG(S.feet_air_time, f) = air * (filt ? 0.0f : 1.0f);
+                    // (ROLE_REW_B: reset_idx's feet_air_time = 0 lands here, ROLE_MAIN does not touch the field)
+                    if (kFeet) FG(S.feet_air_time, f) = (ROLE == ROLE_REW_B && reset) ? 0.0f : air * (filt ? 0.0f : 1.0f);
 
                     const float z = fpos[f][2] - 0.05f;
                     float fh = fhs[f] + (z - lfz[f]);
-                    FG(S.last_feet_z, f) = z;
+                    if (kFeet) FG(S.last_feet_z, f) = z;
                     const float swing = 1.0f - stance[f];
                     r8 += ((fabsf(fh - c.target_feet_height) < 0.01f) ? 1.0f : 0.0f) * swing;
-                    FG(S.feet_height, f) = fh * (contact[f] > 0.5f ? 0.0f : 1.0f);
+                    if (kFeet) FG(S.feet_height, f) = fh * (contact[f] > 0.5f ? 0.0f : 1.0f);
                 }
                 term[7] = r7;
                 term[8] = r8;
@@ -725,6 +752,12 @@ HG_HD StepFlags post_physics_env(const EnvArgs& A, const RngKey& rk, int64_t csc
             // user-defined terms (legged_robot.py:518-541 discovers `_reward_<name>` by name; the caller evaluated them between the
             // derive and the finish launch, already times scale * dt): merged into the sum at their place in the alphabetical order
             // -- custom term j comes right before built-in term custom_reward_pos[j] (22: after all of them; 23: after the clip)
+            if (ROLE == ROLE_REW_A || ROLE == ROLE_REW_B) {     // this wavefront's terms, times their scale: env_step_reward_sum adds them up
+#pragma unroll
+                for (int k = 0; k < HGYM_NUM_REWARDS; ++k)
+                    if (term_in_role(k, ROLE)) tscr[k * N + e] = term[k] * c.reward_scales[k];
+                return fl;
+            }
             const int ncust = (kGeneric && phase == 2) ? c.num_custom_rewards : 0;
             auto add_custom = [&](int k) {
                 for (int j = 0; j < ncust; ++j)
@@ -843,13 +876,16 @@ HG_HD StepFlags post_physics_env(const EnvArgs& A, const RngKey& rk, int64_t csc
             cmd_x_range<kGeneric>(A, x_lo, x_span);       // a command-curriculum move this step is applied by command_curriculum_fix
             resample_commands(c, x_lo, x_span, cmd, u, !kGeneric || c.heading_command);
         }
-        FG(S.feet_air_time, 0) = 0.0f;
-        FG(S.feet_air_time, 1) = 0.0f;
+        if (ROLE == ROLE_ALL) {        // (three-wavefront form: ROLE_REW_B zeroes the field it owns)
+            FG(S.feet_air_time, 0) = 0.0f;
+            FG(S.feet_air_time, 1) = 0.0f;
+        }
         ep = 0;
         // extras["episode"]: mean over resetting envs, finished by the step finaliser
         hg_atomic_inc(A.reset_count ? A.reset_count : &S.counters[1]);
 #pragma unroll
         for (int k = 0; k < HGYM_NUM_REWARDS; ++k) {
+            if (ROLE != ROLE_ALL) break;          // env_step_reward_sum, once the terms of this step are in
             hg_atomic_add(&S.episode_acc[k], esum[k]);
             FG(S.episode_sums, k) = 0.0f;
         }
@@ -950,7 +986,7 @@ HG_HD StepFlags post_physics_env(const EnvArgs& A, const RngKey& rk, int64_t csc
         }
 #pragma unroll
         for (int i = 0; i < 6; ++i) FG(S.last_root_vel, i) = root[7 + i];
-        A.out.rew[e] = rew;
+        if (ROLE == ROLE_ALL) A.out.rew[e] = rew;
         A.out.reset[e] = (uint8_t)reset;
         A.out.time_out[e] = (uint8_t)time_out;
     } else {
@@ -1040,10 +1076,13 @@ HG_HD float* state_comp_row(const EnvArgs& A, int comp, int N) {
     return *state_field_ptr(S, f) + (int64_t)comp * N;
 }
 
+// snapshot rows of the three-wavefront chain: root state 0..12, commands 13..16, last root velocity 17..22, (23 unused), episode length
+// (int64[E]) from row 24
+constexpr int kSnapRoot = 0, kSnapCmd = 13, kSnapLrv = 17, kSnapEp = 24, kSnapComps = 26;
 // LDS carve (float offsets) for a block of E envs
 struct LdsMap {
     int state, root, dof_pos, dof_vel, contact, rigid, actions_in, u_delay, z_act, u_cmd, u_dof, u_push, z_obs, phys, frame, priv, rew,
-        noise_vec, ep_len, flags, reset_i, reset_cnt, reset_list, reset_pose, jpart, cscal, total;
+        noise_vec, ep_len, flags, reset_i, reset_cnt, reset_list, reset_pose, jpart, cscal, terms, snap, total;
 };
 HG_HD LdsMap lds_map(int E) {
     LdsMap m;
@@ -1075,6 +1114,9 @@ HG_HD LdsMap lds_map(int E) {
     m.reset_pose = o; o += 8;              // euler angles [0..2] and projected gravity [3..5] of the reset orientation (split chain)
     m.jpart = o;      o += kJointTerms * 12 * E;   // [8][12][E] per-joint reward products (split per-env chain)
     m.cscal = o;      o += E;              // [E] gait-clock sine of the new observation (split per-env chain -> per-joint lanes)
+    m.terms = o;      o += HGYM_NUM_REWARDS * E;   // [22][E] reward terms times their scale (three-wavefront chain -> env_step_reward_sum)
+    o = (o + 1) & ~1;
+    m.snap = o;       o += kSnapComps * E;   // the reward wavefronts' inputs that ROLE_MAIN rewrites during the phase (env_snapshot)
     m.total = o;
     return m;
 }
@@ -1432,6 +1474,8 @@ HG_HD void env_step_joints(const EnvArgs& A, int block, int t, int nthreads, flo
 constexpr int kStateOffLastActions = 4 + 12;
 constexpr int kStateOffLastLastActions = 4 + 12 * 2;
 constexpr int kStateOffLastDofVel = 4 + 12 * 3;
+constexpr int kStateOffLastRootVel = 4 + 12 * 4;
+constexpr int kStateOffEpisodeSums = 4 + 12 * 4 + 6 + 12 + 2 * 4 + 12 + 3 * 2;     // = 96
 
 // the per-joint reward products, one (env, joint) pair per lane, same item mapping as env_step_joints (a lane reads what it has
 // just written there: no barrier in between): jpart[(k * 12 + j) * E + le]
@@ -1457,7 +1501,9 @@ HG_HD void env_step_joint_terms(const EnvArgs& A, int block, int t, int nthreads
 // everything between the draws and the per-env chain: action filter + joint integration (fused backend), the per-joint reward
 // products, and -- on the last two wavefronts, next to the joint lanes -- the two halves of the synthetic physics' per-env
 // remainder (with a single wavefront, as in the host emulation, they simply follow)
-template <int E_T>
+// kSnap: the three-wavefront chain follows -- the same two wavefronts leave the snapshot its reward roles read (each lane its own
+// env: the root lane after it has moved the root state)
+template <int E_T, bool kSnap = false>
 HG_HD void env_step_phase_j(const EnvArgs& A, int block, int t, int nthreads, float* smem) {
     const int E = E_T > 0 ? E_T : A.envs_per_block;
     const int N = A.cfg.num_envs, e0 = block * E;
@@ -1466,13 +1512,31 @@ HG_HD void env_step_phase_j(const EnvArgs& A, int block, int t, int nthreads, fl
     env_step_joint_terms<E_T>(A, block, t, nthreads, smem);
     const LdsMap m = lds_map(E);
     const int nw = nthreads >= 64 ? nthreads / 64 : 1;
-    if (A.mode == MODE_STEP && A.fused && !(A.ablate & 16)) {
+    const bool synth = A.mode == MODE_STEP && A.fused && !(A.ablate & 16);
+    if (synth || kSnap) {
         const int w_root = nw - 1, w_feet = nw >= 2 ? nw - 2 : nw - 1;
         const int lr = t - 64 * w_root, lf = t - 64 * w_feet;
-        if ((lr >= 0 && lr < nE) || (lf >= 0 && lf < nE)) {
-            const EnvArgs S = make_shadow(A, smem, block, E);
-            if (lr >= 0 && lr < nE) synth_root_env(S, smem + m.phys + lr * kPhysDraws, lr, E);
-            if (lf >= 0 && lf < nE) synth_feet_env(S, smem + m.phys + lf * kPhysDraws, lf, E);
+        const bool r_ok = lr >= 0 && lr < nE, f_ok = lf >= 0 && lf < nE;
+        if (r_ok || f_ok) {
+            if (synth) {
+                const EnvArgs S = make_shadow(A, smem, block, E);
+                if (r_ok) synth_root_env(S, smem + m.phys + lr * kPhysDraws, lr, E);
+                if (f_ok) synth_feet_env(S, smem + m.phys + lf * kPhysDraws, lf, E);
+            }
+            if (kSnap) {
+                float* sn = smem + m.snap;
+                if (r_ok) {
+#pragma unroll
+                    for (int i = 0; i < 13; ++i) sn[(kSnapRoot + i) * E + lr] = smem[m.root + i * E + lr];
+                }
+                if (f_ok) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) sn[(kSnapCmd + i) * E + lf] = smem[m.state + i * E + lf];
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) sn[(kSnapLrv + i) * E + lf] = smem[m.state + (kStateOffLastRootVel + i) * E + lf];
+                    reinterpret_cast<int64_t*>(sn + kSnapEp * E)[lf] = reinterpret_cast<const int64_t*>(smem + m.ep_len)[lf];
+                }
+            }
         }
     }
 }
@@ -1546,6 +1610,70 @@ HG_HD void env_step_phase_a(const EnvArgs& A, int block, int t, float* smem, int
                                                 smem + m.jpart, smem + m.cscal, smem + m.reset_pose);
     reinterpret_cast<int*>(smem + m.reset_i)[t] = fl.reset;
     if (fl.reset) reinterpret_cast<int*>(smem + m.reset_list)[hg_atomic_inc_int(reinterpret_cast<int*>(smem + m.reset_cnt))] = t;
+}
+
+// The three-wavefront form of the split chain (post_physics_env's ROLE): lanes [0, W) run ROLE_MAIN, [W, 2 W) ROLE_REW_A, [2 W, 3 W)
+// ROLE_REW_B, one env per lane, W = 64 on the device (a wavefront each, on three SIMDs of the CU).  Needs env_step_phase_j<.., true>
+// before it (the snapshot) and env_step_reward_sum after the barrier behind it.
+template <int E_T>
+HG_HD void env_step_phase_a3(const EnvArgs& A, int block, int t, int nthreads, float* smem, int64_t csc0) {
+    const int E = E_T > 0 ? E_T : A.envs_per_block;
+    const int N = A.cfg.num_envs, e0 = block * E;
+    const int nE = (E < N - e0) ? E : (N - e0);
+    const int W = nthreads >= 192 ? 64 : nthreads / 3;        // (the host emulation's small launches: nthreads >= 3 nE)
+    const int role = t / (W > 0 ? W : 1), le = t - role * W;
+    if (role > 2 || le >= nE) return;
+    const LdsMap m = lds_map(E);
+    const RngKey rk = make_rng_key(A, csc0);
+    if (role == 0) {
+        const EnvArgs S = make_shadow(A, smem, block, E);
+        const StepFlags fl = post_physics_env<false, true, ROLE_MAIN>(S, rk, csc0 + 1, le, E, smem + m.frame + le * HGYM_OBS_FRAME,
+                                                                     smem + m.priv + le * HGYM_PRIV_FRAME, smem + m.jpart, smem + m.cscal,
+                                                                     smem + m.reset_pose, nullptr);
+        reinterpret_cast<int*>(smem + m.reset_i)[le] = fl.reset;
+        if (fl.reset) reinterpret_cast<int*>(smem + m.reset_list)[hg_atomic_inc_int(reinterpret_cast<int*>(smem + m.reset_cnt))] = le;
+        return;
+    }
+    EnvArgs S = make_shadow(A, smem, block, E);     // ... with what ROLE_MAIN rewrites re-aimed at the snapshot
+    float* sn = smem + m.snap;
+    S.sim.root = HgymStrided{sn + kSnapRoot * E, 1, E};
+    S.st.commands = sn + kSnapCmd * E;
+    S.st.last_root_vel = sn + kSnapLrv * E;
+    S.st.episode_length = reinterpret_cast<int64_t*>(sn + kSnapEp * E);
+    if (role == 1)
+        post_physics_env<false, true, ROLE_REW_A>(S, rk, csc0 + 1, le, E, nullptr, nullptr, smem + m.jpart, nullptr, nullptr, smem + m.terms);
+    else
+        post_physics_env<false, true, ROLE_REW_B>(S, rk, csc0 + 1, le, E, nullptr, nullptr, smem + m.jpart, nullptr, nullptr, smem + m.terms);
+}
+
+// compute_reward's sum (legged_robot.py:217-235) and reset_idx's episode sums (:197-204) for the three-wavefront chain, one env per
+// lane of the LAST wavefront (env_step_phase_f, next to it, occupies the first ones): the same additions in the same order as
+// post_physics_env<.., ROLE_ALL>
+template <int E_T>
+HG_HD void env_step_reward_sum(const EnvArgs& A, int block, int t, int nthreads, float* smem) {
+    const int E = E_T > 0 ? E_T : A.envs_per_block;
+    const int N = A.cfg.num_envs, e0 = block * E;
+    const int nE = (E < N - e0) ? E : (N - e0);
+    const int le = t - (nthreads >= 128 ? nthreads - 64 : 0);
+    if (le < 0 || le >= nE) return;
+    const LdsMap m = lds_map(E);
+    const int reset = reinterpret_cast<const int*>(smem + m.reset_i)[le];
+    float* es = smem + m.state + kStateOffEpisodeSums * E + le;
+    const float* ts = smem + m.terms + le;
+    float rew = 0.0f;
+#pragma unroll
+    for (int k = 0; k < HGYM_NUM_REWARDS; ++k) {
+        const float tk = ts[k * E];
+        rew += tk;
+        float sum = es[k * E] + tk;
+        if (reset) {
+            hg_atomic_add(&A.st.episode_acc[k], sum);
+            sum = 0.0f;
+        }
+        es[k * E] = sum;
+    }
+    if (A.cfg.only_positive_rewards) rew = fmaxf(rew, 0.0f);
+    smem[m.rew + le] = rew;
 }
 
 template <int E_T>

@@ -96,8 +96,10 @@ struct RolloutPP {
 
 constexpr int RO_NIO = hist_ni<15, HGYM_OBS_FRAME, RO_E, RO_NT>();
 constexpr int RO_NIP = hist_ni<3, HGYM_PRIV_FRAME, RO_E, RO_NT>();
-constexpr int RO_NIA = hist_ni<15, HGYM_OBS_FRAME, RO_E, RO_NT - 64, 2>();      // rows written one launch ahead: 13 frames, seven wavefronts
-constexpr int RO_NIAP = hist_ni<3, HGYM_PRIV_FRAME, RO_E, RO_NT - 64, 2>();      // ... and the one privileged frame
+constexpr bool RO_W3 = HGYM_ENV_SPLIT && HGYM_ENV_WAVES3;
+constexpr int RO_CHAIN = RO_W3 ? 192 : 64;     // lanes of the per-env chain; the others write the rows after next meanwhile
+constexpr int RO_NIA = hist_ni<15, HGYM_OBS_FRAME, RO_E, RO_NT - RO_CHAIN, 2>();      // rows written one launch ahead: 13 frames
+constexpr int RO_NIAP = hist_ni<3, HGYM_PRIV_FRAME, RO_E, RO_NT - RO_CHAIN, 2>();      // ... and the one privileged frame
 
 // PRE (HgymEnvOut.obs_older_ready): the 14 older frames of this launch's stacked observation rows were written by the previous launch
 // (as its obs_ahead), so the copy ring -> rows -- 11 HBM loads per lane issued after the first layer, in front of the second layer's
@@ -235,7 +237,7 @@ __global__ __launch_bounds__(RO_NT) void rollout_step_kernel(const FwdArgs f, co
     }
     stamp(1);
 #if HGYM_ENV_SPLIT
-    env_step_phase_j<RO_E>(A, block, t, RO_NT, esm);       // joints + per-joint reward products; synthetic-physics remainder on waves 6, 7
+    env_step_phase_j<RO_E, RO_W3>(A, block, t, RO_NT, esm);       // joints + per-joint reward products; synthetic-physics remainder on waves 6, 7
 #else
     env_step_joints<RO_E>(A, block, t, RO_NT, esm);
 #endif
@@ -248,20 +250,23 @@ __global__ __launch_bounds__(RO_NT) void rollout_step_kernel(const FwdArgs f, co
     auto ahead = [&]() {
         if (A.out.obs_ahead) {
             float hist_a[RO_NIA][4];
-            hist_load<15, HGYM_OBS_FRAME, RO_NIA, 2>(A.st.obs_ring, block * RO_E, RO_E, (int)(ring_step % 15), t - 64, RO_NT - 64, hist_a);
+            hist_load<15, HGYM_OBS_FRAME, RO_NIA, 2>(A.st.obs_ring, block * RO_E, RO_E, (int)(ring_step % 15), t - RO_CHAIN, RO_NT - RO_CHAIN, hist_a);
             float hist_ap[RO_NIAP][4];
-            hist_load<3, HGYM_PRIV_FRAME, RO_NIAP, 2>(A.st.priv_ring, block * RO_E, RO_E, (int)(ring_step % 3), t - 64, RO_NT - 64, hist_ap);
-            hist_store<15, HGYM_OBS_FRAME, RO_NIA, 2>(A.out.obs_ahead, block * RO_E, RO_E, (int)(ring_step % 15), t - 64, RO_NT - 64, nullptr,
+            hist_load<3, HGYM_PRIV_FRAME, RO_NIAP, 2>(A.st.priv_ring, block * RO_E, RO_E, (int)(ring_step % 3), t - RO_CHAIN, RO_NT - RO_CHAIN, hist_ap);
+            hist_store<15, HGYM_OBS_FRAME, RO_NIA, 2>(A.out.obs_ahead, block * RO_E, RO_E, (int)(ring_step % 15), t - RO_CHAIN, RO_NT - RO_CHAIN, nullptr,
                                                       A.cfg.clip_obs, hist_a);
-            hist_store<3, HGYM_PRIV_FRAME, RO_NIAP, 2>(A.out.priv_ahead, block * RO_E, RO_E, (int)(ring_step % 3), t - 64, RO_NT - 64, nullptr,
+            hist_store<3, HGYM_PRIV_FRAME, RO_NIAP, 2>(A.out.priv_ahead, block * RO_E, RO_E, (int)(ring_step % 3), t - RO_CHAIN, RO_NT - RO_CHAIN, nullptr,
                                                        A.cfg.clip_obs, hist_ap);
         }
     };
 #if HGYM_ENV_SPLIT
-    if (t < 64) env_step_phase_a<RO_E, false, true>(A, block, t, esm, csc0);
-    else ahead();
+    if (t < RO_CHAIN) {
+        if (RO_W3) env_step_phase_a3<RO_E>(A, block, t, RO_NT, esm, csc0);
+        else env_step_phase_a<RO_E, false, true>(A, block, t, esm, csc0);
+    } else ahead();
     __syncthreads();
     env_step_phase_f<RO_E>(A, block, t, RO_NT, esm);       // per-joint reset / reference pose / frame entries / last_* copies
+    if (RO_W3) env_step_reward_sum<RO_E>(A, block, t, RO_NT, esm);   // (the last wavefront: phase F has the first six)
     __syncthreads();
 #else
     if (t < 64) env_step_phase_a<RO_E, false>(A, block, t, esm, csc0);

@@ -87,11 +87,13 @@ class HostBackend:
 
     def __init__(self, envs_per_block=8, nthreads=64, split=False):
         """split: the phase sequence of the XBot-L fast kernels (per-joint work on (env, joint) lanes around a shorter per-env
-        chain: env_step_phase_j / _a<split> / _f) instead of the monolithic per-env chain; default options only."""
+        chain: env_step_phase_j / _a<split> / _f) instead of the monolithic per-env chain; default options only.  2 / 3: that chain on
+        three wavefronts (env_step_phase_a3 + env_step_reward_sum, what the device runs by default), its roles emulated in ascending /
+        descending lane order -- a role reading what another one writes during the phase would make the two differ."""
         sys.path.insert(0, os.path.join(ROOT, "tests", "hostcheck"))
         import build_hostcheck
         self.lib = C.CDLL(build_hostcheck.build())
-        self.epb, self.nthreads, self.split = envs_per_block, nthreads, int(bool(split))
+        self.epb, self.nthreads, self.split = envs_per_block, nthreads, int(split)
 
     def step_call(self, mode, cfg, sim, st, out, noise):
         m = {"post": 0, "prime": 1, "reset_all": 2}[mode]

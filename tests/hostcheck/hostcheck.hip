@@ -37,7 +37,7 @@ static EnvArgs make_args(const HgymEnvConfig* cfg, const HgymSimTensors* sim, co
 
 extern "C" {
 
-// split != 0: the phase sequence of the XBot-L fast kernels (per-joint work on (env, joint) lanes around a shorter per-env chain;
+// split != 0 (1: chain on one wavefront, 2 / 3: on three, see below): the phase sequence of the XBot-L fast kernels (per-joint work on (env, joint) lanes around a shorter per-env chain;
 // env_step_kernel<15, 3, 16, false> and rollout_step_kernel), plain steps of the default options only
 int hc_env_step_ex(const HgymEnvConfig* cfg, const HgymSimTensors* sim, const HgymEnvState* st, const HgymEnvOut* out,
                    const HgymEnvNoise* noise, float* actions_in, int mode, int fused, int epb, int nthreads, int split);
@@ -101,7 +101,17 @@ int hc_env_step_ex(const HgymEnvConfig* cfg, const HgymSimTensors* sim, const Hg
         const bool generic = cfg->custom_origins || cfg->terrain_curriculum || cfg->num_height_points > 0 || cfg->command_curriculum ||
                              !cfg->heading_command;
         const bool sp = split && mode == MODE_STEP && !generic;       // as launch_step picks the instantiation
-        if (sp) {
+        if (sp && split >= 2) {
+            // the chain on three wavefronts (main / reward terms A / reward terms B): no role may read what another writes during the
+            // phase, so the order the emulation runs them in must not matter -- split = 2: lanes ascending, split = 3: descending
+            for (int t = 0; t < nthreads; ++t) env_step_phase_j<0, true>(A, b, t, nthreads, smem.data());
+            if (split == 2)
+                for (int t = 0; t < nthreads; ++t) env_step_phase_a3<0>(A, b, t, nthreads, smem.data(), csc0);
+            else
+                for (int t = nthreads - 1; t >= 0; --t) env_step_phase_a3<0>(A, b, t, nthreads, smem.data(), csc0);
+            for (int t = 0; t < nthreads; ++t) env_step_phase_f<0>(A, b, t, nthreads, smem.data());
+            for (int t = 0; t < nthreads; ++t) env_step_reward_sum<0>(A, b, t, nthreads, smem.data());
+        } else if (sp) {
             for (int t = 0; t < nthreads; ++t) env_step_phase_j<0>(A, b, t, nthreads, smem.data());
             for (int t = 0; t < nthreads; ++t) env_step_phase_a<0, false, true>(A, b, t, smem.data(), csc0);
             for (int t = 0; t < nthreads; ++t) env_step_phase_f<0>(A, b, t, nthreads, smem.data());

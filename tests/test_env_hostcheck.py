@@ -12,11 +12,11 @@ import env_common as EC
 T = lambda a: torch.from_numpy(np.asarray(a))
 
 
-@pytest.fixture(scope="module", params=["chain", "split"])
+@pytest.fixture(scope="module", params=["chain", "split", "split3", "split3r"])
 def host(request):
     """chain: the monolithic per-env chain; split: the phase sequence of the XBot-L fast kernels (per-joint work on (env, joint)
     lanes before and after a shorter chain).  Traces with generic options fall back to the chain inside the kernel source."""
-    return EC.HostBackend(envs_per_block=8, nthreads=64, split=request.param == "split")
+    return EC.HostBackend(envs_per_block=8, nthreads=64, split={"chain": 0, "split": 1, "split3": 2, "split3r": 3}[request.param])
 
 
 @pytest.mark.parametrize("name", ["env_trace.npz", "env_trace_refact.npz", "env_trace_yawrate.npz"])
@@ -65,7 +65,7 @@ def test_generic_options_golden_trace_host(host, golden_dir):
     EC.run_generic_golden(host, golden_dir)
 
 
-@pytest.mark.parametrize("split", [False, True])
+@pytest.mark.parametrize("split", [0, 1, 2, 3])
 @pytest.mark.parametrize("N,layout,epb,nthreads", [(37, "soa", 8, 64), (64, "aos", 16, 256), (5, "soa", 4, 32)])
 def test_random_trace_host(N, layout, epb, nthreads, split):
     be = EC.HostBackend(envs_per_block=epb, nthreads=nthreads, split=split)
@@ -73,7 +73,7 @@ def test_random_trace_host(N, layout, epb, nthreads, split):
     assert counts["push"] == 1 and counts["timeout"] >= 1 and counts["reset"] >= 3
 
 
-@pytest.mark.parametrize("split", [False, True])
+@pytest.mark.parametrize("split", [0, 1, 2, 3])
 @pytest.mark.parametrize("N,epb,nthreads", [(37, 8, 64), (64, 32, 512), (5, 4, 32)])
 def test_rows_written_one_step_ahead_host(N, epb, nthreads, split):
     """hgym_rollout_step's rows-ahead protocol (HgymEnvOut.obs_ahead / priv_ahead / obs_older_ready, header v5) on the kernel source:

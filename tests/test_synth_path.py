@@ -53,13 +53,13 @@ def test_oracle_draw_layout_matches_kernel_source_streams():
     assert not np.array_equal(S.env_draws(seed, step, np.array([env]), mode_step=False)["u_dof"].numpy(), d["u_dof"].numpy())
 
 
-@pytest.mark.parametrize("split", [0, 1])
+@pytest.mark.parametrize("split", [0, 1, 2, 3])
 @pytest.mark.parametrize("N,epb,nthreads", [(96, 8, 64), (37, 16, 256)])
 def test_fused_synthetic_step_host_vs_oracle(N, epb, nthreads, split):
     """hc_env_step_ex(fused = 1, no noise tables): stage-in, env_fill_draws, joints + synthetic physics, per-env chain, history
     -- the kernel source on the host -- against the oracle on the same Philox stream, 30 steps."""
     from hgym import EnvBuffers, default_env_config
-    be = EC.HostBackend(envs_per_block=epb, nthreads=nthreads, split=bool(split))
+    be = EC.HostBackend(envs_per_block=epb, nthreads=nthreads, split=split)
     seed = 0xC0FFEE1234
     g = torch.Generator().manual_seed(N)
     cfg = default_env_config(N, seed=seed)
