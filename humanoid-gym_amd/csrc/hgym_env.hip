@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void env_step_kernel(const EnvArgs A) {
     if (split) env_step_phase_j<E_T, kW3>(A, blockIdx.x, t, blockDim.x, smem);
     else if (!(A.ablate & 128)) env_step_joints<E_T>(A, blockIdx.x, t, blockDim.x, smem);
     __syncthreads();
-    // wavefront 0 (kW3: wavefronts 0-2) runs the per-env scalar chains (one lane per env); the other wavefronts meanwhile move the
+    // wavefront 0 (kW3: all four) runs the per-env scalar chains (one lane per env); the other wavefronts meanwhile move the
     // older frames of the observation history, which depend on nothing this step computes (reset envs are fixed up in phase B) --
     // their stores are issued first
     if (t >= 64) {
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void env_step_kernel(const EnvArgs A) {
         }
     }
     if (kW3) {
-        if (t < 192 && !(A.ablate & 2)) env_step_phase_a3<E_T>(A, blockIdx.x, t, blockDim.x, smem, csc0);
+        if (t < 64 * kChainRoles && !(A.ablate & 2)) env_step_phase_a3<E_T>(A, blockIdx.x, t, blockDim.x, smem, csc0);
     } else if (t < 64 && !(A.ablate & 2)) {
         if (split) env_step_phase_a<E_T, kGeneric, true>(A, blockIdx.x, t, smem, csc0);
         else env_step_phase_a<E_T, kGeneric>(A, blockIdx.x, t, smem, csc0);

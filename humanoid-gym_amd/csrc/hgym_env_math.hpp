@@ -403,19 +403,21 @@ HG_HD void joint_terms(const HgymEnvConfig& c, int j, float a, float la, float l
 // per-joint part of the reset, the reference pose, the per-joint frame entries and the last_* write-back after it
 // (env_step_phase_f, which takes this step's reset flag and gait-clock sine from `cscal`).  Same arithmetic, same order.
 constexpr int kJointTerms = 8;     // per-joint products: d1^2, d2^2, |a| (term 0), jd^2 (4), acc^2 (5), qd^2 (6), tq^2 (17), (q - ref)^2 (13)
-// ROLE (split chain only): the chain is one wavefront issuing ~2 500 instructions once; three wavefronts of the workgroup can share it.
+// ROLE (split chain only): the chain is ONE wavefront issuing ~2 500 instructions once, and a lone wavefront issues one instruction
+// (of any kind) per four cycles; four wavefronts of the workgroup -- on the CU's four SIMDs -- can share it.
 //   ROLE_ALL    everything (one wavefront, the form above);
-//   ROLE_MAIN   everything but the reward terms and the state only they touch: derived state, commands, push, termination, reset,
-//               frames, write-back;
+//   ROLE_MAIN   the state: derived state, commands, push, termination, reset, write-back -- no reward terms, no frames;
 //   ROLE_REW_A / ROLE_REW_B   the derived quantities their terms need (re-derived from a SNAPSHOT of root state / commands / episode
-//               length / last root velocity taken before the phase: ROLE_MAIN rewrites those while the three run) and their share of
-//               the 22 terms, left times their scale in `tscr` [22][N]; B owns the stateful terms 7 / 8 and their four state fields.
+//               length / last root velocity taken before the phase: ROLE_MAIN rewrites those while the others run) and their share of
+//               the 22 terms, left times their scale in `tscr` [22][N]; B owns the stateful terms 7 / 8 and their four state fields;
+//   ROLE_FRAMES the same re-derivation, the values a reset changes, and the non-joint entries of the two clean observation frames.
 // env_step_reward_sum then forms the reward and the episode sums in the reference's order.  No wavefront reads what another writes
-// during the phase; tests/hostcheck runs the three roles in both orders.
+// during the phase; tests/hostcheck runs the roles in both orders.
 #ifndef HGYM_ENV_WAVES3
-#define HGYM_ENV_WAVES3 1      // the split per-env chain of the compiled-in fast kernels on three wavefronts; 0: on one
+#define HGYM_ENV_WAVES3 1      // the split per-env chain of the compiled-in fast kernels on four wavefronts (the name is older); 0: on one
 #endif
-constexpr int ROLE_ALL = 0, ROLE_MAIN = 1, ROLE_REW_A = 2, ROLE_REW_B = 3;
+constexpr int ROLE_ALL = 0, ROLE_MAIN = 1, ROLE_REW_A = 2, ROLE_REW_B = 3, ROLE_FRAMES = 4;
+constexpr int kChainRoles = 4;       // wavefronts of env_step_phase_a3
 HG_HD constexpr bool term_in_role(int k, int role) {
     // A: the terms of the base velocities / orientation / commands (they need the quaternion prefix); B: feet, gait clock, joint sums
     const bool a = k == 1 || k == 15 || k == 16 || k == 18 || k == 19 || k == 20 || k == 21;
@@ -426,7 +428,8 @@ HG_HD StepFlags post_physics_env(const EnvArgs& A, const RngKey& rk, int64_t csc
                                  float* priv73, const float* jpart = nullptr, float* cscal = nullptr, const float* reset_pose = nullptr,
                                  float* tscr = nullptr) {
     static_assert(ROLE == ROLE_ALL || (kSplit && !kGeneric), "the three-wavefront form exists for the split XBot-L chain only");
-    constexpr bool kMain = ROLE == ROLE_ALL || ROLE == ROLE_MAIN;      // state write-back, reset, frames
+    constexpr bool kMain = ROLE == ROLE_ALL || ROLE == ROLE_MAIN;      // state write-back, reset
+    constexpr bool kFrames = ROLE == ROLE_ALL || ROLE == ROLE_FRAMES;  // the clean observation frames
     constexpr bool kFeet = ROLE == ROLE_ALL || ROLE == ROLE_REW_B;     // owner of last_contacts / feet_air_time / feet_height / last_feet_z
     const HgymEnvConfig& c = A.cfg;
     const HgymEnvState& S = A.st;
@@ -588,7 +591,7 @@ HG_HD StepFlags post_physics_env(const EnvArgs& A, const RngKey& rk, int64_t csc
             const float bn = sqrtf(bx * bx + by * by + bz * bz);
             time_out = ep > (int64_t)c.max_episode_length;
             reset = (bn > 1.0f) || time_out;
-          if (phase != 1 && ROLE != ROLE_MAIN) {
+          if (phase != 1 && ROLE != ROLE_MAIN && ROLE != ROLE_FRAMES) {
             // ---------------- compute_reward :217-235, 22 terms in alphabetical order ----------------
             const float s = sinf(kTwoPi * gait_phase(c, ep));
             float stance[2];
@@ -819,7 +822,7 @@ HG_HD StepFlags post_physics_env(const EnvArgs& A, const RngKey& rk, int64_t csc
         return fl;
     }
     // ---------------- reset_idx :163-215 (+ humanoid_env.py:264-269), mask-driven ----------------
-    if (reset) {
+    if (reset) {      // (ROLE_FRAMES: only the values its frames read -- commands, episode length, euler angles)
         fl.reset = 1;
 #pragma unroll
         for (int j = 0; j < 12; ++j) {
@@ -867,7 +870,9 @@ HG_HD StepFlags post_physics_env(const EnvArgs& A, const RngKey& rk, int64_t csc
             root[1] += 2.0f * (A.noise.u_xy ? A.noise.u_xy[(int64_t)ge * 2 + 1] : uniform_at(rk, (uint32_t)ge, SLOT_TERRAIN, 1)) + -1.0f;
         }
 #pragma unroll
-        for (int i = 0; i < 13; ++i) sset(A.sim.root, e, i, root[i]);
+        for (int i = 0; i < 13; ++i) {
+            if (kMain) sset(A.sim.root, e, i, root[i]);
+        }
         {
             const float u[3] = {nz_uniform(A.noise.u_cmd, 6, 3, rk, e, ge, SLOT_CMD_RESET, 0),
                                 nz_uniform(A.noise.u_cmd, 6, 4, rk, e, ge, SLOT_CMD_RESET, 1),
@@ -882,7 +887,7 @@ HG_HD StepFlags post_physics_env(const EnvArgs& A, const RngKey& rk, int64_t csc
         }
         ep = 0;
         // extras["episode"]: mean over resetting envs, finished by the step finaliser
-        hg_atomic_inc(A.reset_count ? A.reset_count : &S.counters[1]);
+        if (kMain) hg_atomic_inc(A.reset_count ? A.reset_count : &S.counters[1]);
 #pragma unroll
         for (int k = 0; k < HGYM_NUM_REWARDS; ++k) {
             if (ROLE != ROLE_ALL) break;          // env_step_reward_sum, once the terms of this step are in
@@ -909,7 +914,7 @@ HG_HD StepFlags post_physics_env(const EnvArgs& A, const RngKey& rk, int64_t csc
         }
     }
 
-    if (mode != MODE_RESET_ALL) {
+    if (mode != MODE_RESET_ALL && kFrames) {
         // ---------------- compute_observations humanoid_env.py:200-244 (clean frames) ----------------
         const float phase = gait_phase(c, ep);
         const float s = sinf(kTwoPi * phase);
@@ -964,6 +969,7 @@ HG_HD StepFlags post_physics_env(const EnvArgs& A, const RngKey& rk, int64_t csc
         priv73[72] = contact[1];
     }
 
+    if (ROLE == ROLE_FRAMES) return fl;
     // ---------------- write-back + tail of post_physics_step :147-151 ----------------
     S.episode_length[e] = ep;
 #pragma unroll
@@ -1612,17 +1618,17 @@ HG_HD void env_step_phase_a(const EnvArgs& A, int block, int t, float* smem, int
     if (fl.reset) reinterpret_cast<int*>(smem + m.reset_list)[hg_atomic_inc_int(reinterpret_cast<int*>(smem + m.reset_cnt))] = t;
 }
 
-// The three-wavefront form of the split chain (post_physics_env's ROLE): lanes [0, W) run ROLE_MAIN, [W, 2 W) ROLE_REW_A, [2 W, 3 W)
-// ROLE_REW_B, one env per lane, W = 64 on the device (a wavefront each, on three SIMDs of the CU).  Needs env_step_phase_j<.., true>
+// The four-wavefront form of the split chain (post_physics_env's ROLE): lanes [0, W) run ROLE_MAIN, [W, 2 W) ROLE_REW_A, [2 W, 3 W)
+// ROLE_REW_B, [3 W, 4 W) ROLE_FRAMES, one env per lane, W = 64 on the device (a wavefront each, on the four SIMDs of the CU).  Needs env_step_phase_j<.., true>
 // before it (the snapshot) and env_step_reward_sum after the barrier behind it.
 template <int E_T>
 HG_HD void env_step_phase_a3(const EnvArgs& A, int block, int t, int nthreads, float* smem, int64_t csc0) {
     const int E = E_T > 0 ? E_T : A.envs_per_block;
     const int N = A.cfg.num_envs, e0 = block * E;
     const int nE = (E < N - e0) ? E : (N - e0);
-    const int W = nthreads >= 192 ? 64 : nthreads / 3;        // (the host emulation's small launches: nthreads >= 3 nE)
+    const int W = nthreads >= 64 * kChainRoles ? 64 : nthreads / kChainRoles;        // (the host emulation's small launches: nthreads >= 4 nE)
     const int role = t / (W > 0 ? W : 1), le = t - role * W;
-    if (role > 2 || le >= nE) return;
+    if (role >= kChainRoles || le >= nE) return;
     const LdsMap m = lds_map(E);
     const RngKey rk = make_rng_key(A, csc0);
     if (role == 0) {
@@ -1642,8 +1648,11 @@ HG_HD void env_step_phase_a3(const EnvArgs& A, int block, int t, int nthreads, f
     S.st.episode_length = reinterpret_cast<int64_t*>(sn + kSnapEp * E);
     if (role == 1)
         post_physics_env<false, true, ROLE_REW_A>(S, rk, csc0 + 1, le, E, nullptr, nullptr, smem + m.jpart, nullptr, nullptr, smem + m.terms);
-    else
+    else if (role == 2)
         post_physics_env<false, true, ROLE_REW_B>(S, rk, csc0 + 1, le, E, nullptr, nullptr, smem + m.jpart, nullptr, nullptr, smem + m.terms);
+    else
+        post_physics_env<false, true, ROLE_FRAMES>(S, rk, csc0 + 1, le, E, smem + m.frame + le * HGYM_OBS_FRAME, smem + m.priv + le * HGYM_PRIV_FRAME,
+                                                   smem + m.jpart, smem + m.cscal, smem + m.reset_pose, nullptr);
 }
 
 // compute_reward's sum (legged_robot.py:217-235) and reset_idx's episode sums (:197-204) for the three-wavefront chain, one env per
@@ -1660,20 +1669,30 @@ HG_HD void env_step_reward_sum(const EnvArgs& A, int block, int t, int nthreads,
     const int reset = reinterpret_cast<const int*>(smem + m.reset_i)[le];
     float* es = smem + m.state + kStateOffEpisodeSums * E + le;
     const float* ts = smem + m.terms + le;
+    // every load before the first store or atomic (untyped float pointers: a load behind one would wait for it -- 22 LDS round trips)
+    float tk[HGYM_NUM_REWARDS], sum[HGYM_NUM_REWARDS];
+#pragma unroll
+    for (int k = 0; k < HGYM_NUM_REWARDS; ++k) {
+        tk[k] = ts[k * E];
+        sum[k] = es[k * E];
+    }
     float rew = 0.0f;
 #pragma unroll
     for (int k = 0; k < HGYM_NUM_REWARDS; ++k) {
-        const float tk = ts[k * E];
-        rew += tk;
-        float sum = es[k * E] + tk;
-        if (reset) {
-            hg_atomic_add(&A.st.episode_acc[k], sum);
-            sum = 0.0f;
-        }
-        es[k * E] = sum;
+        rew += tk[k];
+        sum[k] += tk[k];
     }
     if (A.cfg.only_positive_rewards) rew = fmaxf(rew, 0.0f);
     smem[m.rew + le] = rew;
+    if (reset) {
+#pragma unroll
+        for (int k = 0; k < HGYM_NUM_REWARDS; ++k) {
+            hg_atomic_add(&A.st.episode_acc[k], sum[k]);
+            sum[k] = 0.0f;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < HGYM_NUM_REWARDS; ++k) es[k * E] = sum[k];
 }
 
 template <int E_T>

@@ -96,8 +96,14 @@ struct RolloutPP {
 
 constexpr int RO_NIO = hist_ni<15, HGYM_OBS_FRAME, RO_E, RO_NT>();
 constexpr int RO_NIP = hist_ni<3, HGYM_PRIV_FRAME, RO_E, RO_NT>();
+#ifndef HGYM_W3_PROBE
+#define HGYM_W3_PROBE 0
+#endif
 constexpr bool RO_W3 = HGYM_ENV_SPLIT && HGYM_ENV_WAVES3;
-constexpr int RO_CHAIN = RO_W3 ? 192 : 64;     // lanes of the per-env chain; the others write the rows after next meanwhile
+constexpr int RO_CHAIN = RO_W3 ? 64 * kChainRoles : 64;     // lanes of the per-env chain; the others fetch the rows after next meanwhile
+#ifndef HGYM_RO_AHEAD_LATE
+#define HGYM_RO_AHEAD_LATE 1   // the rows after next are STORED as the launch's last instructions (nothing waits for them there); 0: right behind their loads
+#endif
 constexpr int RO_NIA = hist_ni<15, HGYM_OBS_FRAME, RO_E, RO_NT - RO_CHAIN, 2>();      // rows written one launch ahead: 13 frames
 constexpr int RO_NIAP = hist_ni<3, HGYM_PRIV_FRAME, RO_E, RO_NT - RO_CHAIN, 2>();      // ... and the one privileged frame
 
@@ -235,7 +241,12 @@ __global__ __launch_bounds__(RO_NT) void rollout_step_kernel(const FwdArgs f, co
 #endif
             hist_store<15, HGYM_OBS_FRAME, RO_NIO>(A.out.obs, block * RO_E, RO_E, (int)(ring_step % 15), t, RO_NT, nullptr, A.cfg.clip_obs, hist_o);
     }
+#if HGYM_W3_PROBE     // tools/probe_w3.py: slot 1 = the SIMD every wavefront of the workgroup runs on (4 bits each), 4..7 = ends of the chain's roles
+    if (dbg && (t & 63) == 0) atomicAdd(reinterpret_cast<unsigned long long*>(dbg + 1),
+                                        (unsigned long long)__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4) << (4 * (t >> 6)));
+#else
     stamp(1);
+#endif
 #if HGYM_ENV_SPLIT
     env_step_phase_j<RO_E, RO_W3>(A, block, t, RO_NT, esm);       // joints + per-joint reward products; synthetic-physics remainder on waves 6, 7
 #else
@@ -247,23 +258,34 @@ __global__ __launch_bounds__(RO_NT) void rollout_step_kernel(const FwdArgs f, co
     __syncthreads();
     stamp(2);
     // rows after next (obs_ahead): the 13 frames older than this step's and the next one's, from the ring as this launch found it
-    auto ahead = [&]() {
+    // The stores wait for nothing this launch computes except the reset flags, and a barrier waits for every store issued before it
+    // (one counter for loads and stores): with HGYM_RO_AHEAD_LATE they are the launch's last instructions -- reset envs' frames go out
+    // as zeros there, as phase B's stack_reset_ahead would have left them.
+    float hist_a[RO_NIA][4], hist_ap[RO_NIAP][4];
+    auto ahead_load = [&]() {       // (unconditional: the ring always exists; a launch without rows after next drops them)
+        hist_load<15, HGYM_OBS_FRAME, RO_NIA, 2>(A.st.obs_ring, block * RO_E, RO_E, (int)(ring_step % 15), t - RO_CHAIN, RO_NT - RO_CHAIN, hist_a);
+        hist_load<3, HGYM_PRIV_FRAME, RO_NIAP, 2>(A.st.priv_ring, block * RO_E, RO_E, (int)(ring_step % 3), t - RO_CHAIN, RO_NT - RO_CHAIN, hist_ap);
+    };
+    auto ahead_store = [&](const int* s_reset) {
         if (A.out.obs_ahead) {
-            float hist_a[RO_NIA][4];
-            hist_load<15, HGYM_OBS_FRAME, RO_NIA, 2>(A.st.obs_ring, block * RO_E, RO_E, (int)(ring_step % 15), t - RO_CHAIN, RO_NT - RO_CHAIN, hist_a);
-            float hist_ap[RO_NIAP][4];
-            hist_load<3, HGYM_PRIV_FRAME, RO_NIAP, 2>(A.st.priv_ring, block * RO_E, RO_E, (int)(ring_step % 3), t - RO_CHAIN, RO_NT - RO_CHAIN, hist_ap);
-            hist_store<15, HGYM_OBS_FRAME, RO_NIA, 2>(A.out.obs_ahead, block * RO_E, RO_E, (int)(ring_step % 15), t - RO_CHAIN, RO_NT - RO_CHAIN, nullptr,
+            hist_store<15, HGYM_OBS_FRAME, RO_NIA, 2>(A.out.obs_ahead, block * RO_E, RO_E, (int)(ring_step % 15), t - RO_CHAIN, RO_NT - RO_CHAIN, s_reset,
                                                       A.cfg.clip_obs, hist_a);
-            hist_store<3, HGYM_PRIV_FRAME, RO_NIAP, 2>(A.out.priv_ahead, block * RO_E, RO_E, (int)(ring_step % 3), t - RO_CHAIN, RO_NT - RO_CHAIN, nullptr,
+            hist_store<3, HGYM_PRIV_FRAME, RO_NIAP, 2>(A.out.priv_ahead, block * RO_E, RO_E, (int)(ring_step % 3), t - RO_CHAIN, RO_NT - RO_CHAIN, s_reset,
                                                        A.cfg.clip_obs, hist_ap);
         }
+    };
+    auto ahead = [&]() {
+        ahead_load();
+        if (!HGYM_RO_AHEAD_LATE) ahead_store(nullptr);
     };
 #if HGYM_ENV_SPLIT
     if (t < RO_CHAIN) {
         if (RO_W3) env_step_phase_a3<RO_E>(A, block, t, RO_NT, esm, csc0);
         else env_step_phase_a<RO_E, false, true>(A, block, t, esm, csc0);
     } else ahead();
+#if HGYM_W3_PROBE
+    if (dbg && (t & 63) == 0 && t <= 256) dbg[t < 256 ? 4 + (t >> 6) : 0] = (long long)__builtin_amdgcn_s_memrealtime();     // wavefronts 0-3 -> slots 4-7, wavefront 4 -> slot 0
+#endif
     __syncthreads();
     env_step_phase_f<RO_E>(A, block, t, RO_NT, esm);       // per-joint reset / reference pose / frame entries / last_* copies
     if (RO_W3) env_step_reward_sum<RO_E>(A, block, t, RO_NT, esm);   // (the last wavefront: phase F has the first six)
@@ -275,9 +297,14 @@ __global__ __launch_bounds__(RO_NT) void rollout_step_kernel(const FwdArgs f, co
 #endif
     stamp(3);
     env_stage_out<RO_E>(A, block, t, RO_NT, esm);
+#if !HGYM_W3_PROBE
     stamp(4);
+#endif
     env_step_phase_b<15, 3, RO_E>(A, block, t, RO_NT, esm, csc0, ring_step, false);
+#if !HGYM_W3_PROBE
     stamp(5);
+#endif
+    if (HGYM_RO_AHEAD_LATE && t >= RO_CHAIN) ahead_store(reinterpret_cast<const int*>(esm + lds_map(RO_E).reset_i));
     if (block == 0 && t == 0) {
         pp.out[0] = csc0 + 1;
         pp.out[1] = ring_step + 1;

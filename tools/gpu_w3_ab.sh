@@ -1,9 +1,13 @@
 #!/bin/bash
-# same-call A/B of the per-env chain on three wavefronts (default) against one (variant w1 = build.py --variant w1 -DHGYM_ENV_WAVES3=0):
+# same-call A/B of the per-env chain on four wavefronts (default) against one (variant w1 = build.py --variant w1 -DHGYM_ENV_WAVES3=0;
+# probe variants w3p / w3pe / w1p: -DHGYM_W3_PROBE=1, + -DHGYM_RO_AHEAD_LATE=0, + -DHGYM_ENV_WAVES3=0):
 # whole bench twice each, the rollout launch's phase clock under both, then the GPU test suite under the default library
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
 mkdir -p $O
+for v in w3p w3pe w1p; do echo "== $v"; HGYM_LIB=$R/humanoid-gym_amd/lib/variants/$v/libhgym_hip.so timeout 250 python tools/probe_w3.py 2>&1 | grep "^step"; done > $O/w3_probe.txt 2>&1
+cat $O/w3_probe.txt
+rm -f $O/w3_phase.txt
 bash tools/gpu_bench_ab.sh base w1
 for v in base w1; do
   if [ "$v" == "base" ]; then L=$R/humanoid-gym_amd/lib/libhgym_hip.so; else L=$R/humanoid-gym_amd/lib/variants/$v/libhgym_hip.so; fi
