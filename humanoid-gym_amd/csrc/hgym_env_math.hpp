@@ -1646,9 +1646,20 @@ HG_HD void env_step_phase_a3(const EnvArgs& A, int block, int t, int nthreads, f
     S.st.commands = sn + kSnapCmd * E;
     S.st.last_root_vel = sn + kSnapLrv * E;
     S.st.episode_length = reinterpret_cast<int64_t*>(sn + kSnapEp * E);
-    if (role == 1)
+    if (role == 1) {
+#if defined(HGYM_W3_PROBE) && HGYM_W3_PROBE
+        // probe: role A (pure: it only writes its terms) repeated -- a second pass through the SAME code costs its instruction issue but
+        // no instruction fetch misses
+#pragma unroll 1
+        for (int rep = (A.ablate >> 8) & 7; rep > 0; --rep) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm volatile("" ::: "memory");        // nothing of the pass may be hoisted out of the loop
+#endif
+            post_physics_env<false, true, ROLE_REW_A>(S, rk, csc0 + 1, le, E, nullptr, nullptr, smem + m.jpart, nullptr, nullptr, smem + m.terms);
+        }
+#endif
         post_physics_env<false, true, ROLE_REW_A>(S, rk, csc0 + 1, le, E, nullptr, nullptr, smem + m.jpart, nullptr, nullptr, smem + m.terms);
-    else if (role == 2)
+    } else if (role == 2)
         post_physics_env<false, true, ROLE_REW_B>(S, rk, csc0 + 1, le, E, nullptr, nullptr, smem + m.jpart, nullptr, nullptr, smem + m.terms);
     else
         post_physics_env<false, true, ROLE_FRAMES>(S, rk, csc0 + 1, le, E, smem + m.frame + le * HGYM_OBS_FRAME, smem + m.priv + le * HGYM_PRIV_FRAME,
@@ -1695,14 +1706,78 @@ HG_HD void env_step_reward_sum(const EnvArgs& A, int block, int t, int nthreads,
     for (int k = 0; k < HGYM_NUM_REWARDS; ++k) es[k * E] = sum[k];
 }
 
+// Fast stage-out, the mirror of the fast stage-in (contiguous state, SoA sim tensors, full block of a compiled-in size): every tensor
+// is a list of 16-byte items (4 envs of one component row) with an ARITHMETIC item -> (tensor row, LDS row) mapping.  The general
+// form below reaches the same rows through component tables and per-field pointers, which the compiler turns into dependent loads
+// from memory in front of the stores; this phase is executed by every wavefront of the workgroup and is paced by instruction issue.
+// The five sim tensors take consecutive lane ranges, so that a wavefront runs the code of the one or two it has items of.
+template <int E_T>
+HG_HD bool env_stage_out_fast(const EnvArgs& A, int block, int t, int nthreads, float* smem) {
+    if (E_T <= 0 || (E_T & 3) != 0) return false;
+    constexpr int E = E_T > 0 ? E_T : 4, Q = E / 4;
+    const int N = A.cfg.num_envs, e0 = block * E;
+    if (N - e0 < E || !A.state_contig || A.sim.root.env_stride != 1 || A.sim.dof_pos.env_stride != 1 || A.sim.dof_vel.env_stride != 1 ||
+        A.sim.contact.env_stride != 1 || A.sim.rigid.env_stride != 1)
+        return false;
+    const LdsMap m = lds_map(E);
+    auto put = [&](float* g, const float* l) { *reinterpret_cast<EnvF4*>(g) = *reinterpret_cast<const EnvF4*>(l); };
+    for (int i = t; i < kMutableComps * Q; i += nthreads) {
+        const int c = i / Q, qd = i - c * Q;
+        put(A.st.commands + (int64_t)c * N + e0 + 4 * qd, smem + m.state + c * E + 4 * qd);
+    }
+    auto first = [&](int lane0) {        // first item of the lane in a tensor whose items start at lane `lane0`
+        const int i = t - lane0;
+        return i < 0 ? i + nthreads : i;
+    };
+    int lane0 = 0;
+    for (int i = first(lane0); i < 13 * Q; i += nthreads) {
+        const int k = i / Q, qd = i - k * Q;
+        put(A.sim.root.base + (int64_t)k * A.sim.root.comp_stride + e0 + 4 * qd, smem + m.root + k * E + 4 * qd);
+    }
+    lane0 = (lane0 + 13 * Q) % nthreads;
+    for (int i = first(lane0); i < 12 * Q; i += nthreads) {
+        const int k = i / Q, qd = i - k * Q;
+        put(A.sim.dof_pos.base + (int64_t)k * A.sim.dof_pos.comp_stride + e0 + 4 * qd, smem + m.dof_pos + k * E + 4 * qd);
+    }
+    lane0 = (lane0 + 12 * Q) % nthreads;
+    for (int i = first(lane0); i < 12 * Q; i += nthreads) {
+        const int k = i / Q, qd = i - k * Q;
+        put(A.sim.dof_vel.base + (int64_t)k * A.sim.dof_vel.comp_stride + e0 + 4 * qd, smem + m.dof_vel + k * E + 4 * qd);
+    }
+    if (!(A.mode == MODE_STEP && A.fused)) return true;       // the synthetic physics wrote contacts / rigid bodies
+    lane0 = (lane0 + 12 * Q) % nthreads;
+    const int cc0 = A.contact_comp[0], cc1 = A.contact_comp[1], cc2 = A.contact_comp[2];
+    for (int i = first(lane0); i < 9 * Q; i += nthreads) {
+        const int k = i / Q, qd = i - k * Q;
+        const int comp = (k < 3 ? cc0 : (k < 6 ? cc1 : cc2)) + k % 3;
+        put(A.sim.contact.base + (int64_t)comp * A.sim.contact.comp_stride + e0 + 4 * qd, smem + m.contact + k * E + 4 * qd);
+    }
+    lane0 = (lane0 + 9 * Q) % nthreads;
+    const int rc0 = A.rigid_comp[0], rc1 = A.rigid_comp[1], rc2 = A.rigid_comp[2], rc3 = A.rigid_comp[3];
+    for (int i = first(lane0); i < 14 * Q; i += nthreads) {      // feet {x, y, z, vx, vy}, knees {x, y}
+        const int k = i / Q, qd = i - k * Q;
+        const int body = k < 10 ? k / 5 : 2 + (k - 10) / 2;
+        const int c5 = k % 5;
+        const int comp = k < 10 ? (c5 < 3 ? c5 : c5 + 4) : (k - 10) % 2;
+        const int base = body == 0 ? rc0 : (body == 1 ? rc1 : (body == 2 ? rc2 : rc3));
+        put(A.sim.rigid.base + (int64_t)(base + comp) * A.sim.rigid.comp_stride + e0 + 4 * qd, smem + m.rigid + (body * 13 + comp) * E + 4 * qd);
+    }
+    return true;
+}
+
 template <int E_T>
 HG_HD void env_stage_out(const EnvArgs& A, int block, int t, int nthreads, float* smem) {
     const int E = E_T > 0 ? E_T : A.envs_per_block;
     const int N = A.cfg.num_envs, e0 = block * E;
     const int nE = (E < N - e0) ? E : (N - e0);
     const LdsMap m = lds_map(E);
-    copy_comp_rows<false>(nullptr, A, 0, kMutableComps, smem + m.state, E, e0, nE, N, t, nthreads);
-    stage_sim<false>(A, m, smem, E, e0, nE, t, nthreads, A.mode == MODE_STEP && A.fused);   // the synthetic physics wrote contacts / rigid bodies
+#ifndef HGYM_STAGE_OUT_FAST
+#define HGYM_STAGE_OUT_FAST 1
+#endif
+    if (!(HGYM_STAGE_OUT_FAST && env_stage_out_fast<E_T>(A, block, t, nthreads, smem))) {
+        copy_comp_rows<false>(nullptr, A, 0, kMutableComps, smem + m.state, E, e0, nE, N, t, nthreads);
+        stage_sim<false>(A, m, smem, E, e0, nE, t, nthreads, A.mode == MODE_STEP && A.fused);   // the synthetic physics wrote contacts / rigid bodies
+    }
     if (A.cfg.use_ref_actions && A.mode == MODE_STEP && A.fused && A.actions_in)       // the in-place `actions += ref_action`
         for (int i = t; i < nE * 12; i += nthreads) A.actions_in[(int64_t)e0 * 12 + i] = smem[m.actions_in + i];
     const uint8_t* fl = reinterpret_cast<const uint8_t*>(smem + m.flags);

@@ -367,6 +367,9 @@ int32_t hgym_rollout_step(const HgymNetConfig* cfg, const HgymNet* net, const Hg
     int32_t rc = rollout_fwd_args(cfg, net, M, obs, priv, seed, &scr->pp[parity][2], actions, mu, sigma, logp, values, &f, &lds_pol, shadow);
     if (rc) return rc;
     rc = rollout_env_args(env_cfg, sim, st, out, actions, &e);
+#if HGYM_W3_PROBE
+    if (rc == HGYM_OK && getenv("HGYM_W3_REPS")) e.ablate = atoi(getenv("HGYM_W3_REPS")) << 8;      // tools/probe_w3.py
+#endif
     if (rc) return rc;
     HG_REQUIRE(out->t_values == values, HGYM_E_BADARG, "the transition sink must take this launch's values");
     e.reset_count = &scr->reset_cnt[parity];

@@ -32,6 +32,12 @@ static EnvArgs make_args(const HgymEnvConfig* cfg, const HgymSimTensors* sim, co
     A.fused = fused;
     A.envs_per_block = epb;
     set_body_offsets(A);
+    {   // as launch_step: the fast staging paths when the state fields are one contiguous [136][N] allocation
+        bool contig = true;
+        float* const* f = &st->commands;
+        for (int i = 0; i + 1 < kNumStateFields; ++i) contig = contig && (f[i + 1] == f[i] + (int64_t)state_field_comps(i) * cfg->num_envs);
+        A.state_contig = contig ? 1 : 0;
+    }
     return A;
 }
 
@@ -146,7 +152,12 @@ int hc_env_step_ex(const HgymEnvConfig* cfg, const HgymSimTensors* sim, const Hg
                 if (xbot) env_step_stack_old<15, 3, 0>(A, b, t, nthreads, ring);
                 else env_step_stack_old<0, 0, 0>(A, b, t, nthreads, ring);
             }
-        for (int t = 0; t < nthreads; ++t) env_stage_out<0>(A, b, t, nthreads, smem.data());
+        // (the block sizes the device compiles in take their instantiation: its fast path -- env_stage_out_fast -- where the layout allows)
+        for (int t = 0; t < nthreads; ++t) {
+            if (epb == 16) env_stage_out<16>(A, b, t, nthreads, smem.data());
+            else if (epb == 32) env_stage_out<32>(A, b, t, nthreads, smem.data());
+            else env_stage_out<0>(A, b, t, nthreads, smem.data());
+        }
         for (int t = 0; t < nthreads; ++t) {
             if (xbot) env_step_phase_b<15, 3, 0>(A, b, t, nthreads, smem.data(), csc0, ring);
             else env_step_phase_b<0, 0, 0>(A, b, t, nthreads, smem.data(), csc0, ring);
