@@ -181,15 +181,31 @@ HG_HD void pre_physics_env(const EnvArgs& A, const RngKey& rk, int e, int N) {
 }
 
 // legged_robot.py:340-356
-HG_HD float pd_torque(const HgymEnvConfig& c, int j, float a, float q, float qd) {
-    const float t = c.p_gains[j] * (a * c.action_scale + c.default_dof_pos[j] - q) - c.d_gains[j] * qd;
-    return clampf(t, -c.torque_limits[j], c.torque_limits[j]);
+// The six per-joint constant arrays of the configuration as ONE block of 72 floats (p_gains, d_gains, torque_limits, default_dof_pos,
+// dof_lower, dof_upper).  Code that indexes them with a lane-varying joint takes the block as a pointer `jc`: the workgroup kernels
+// pass their LDS copy (LdsMap::jcfg, filled by the stage-in) -- indexing the kernel ARGUMENT by a lane-varying j is a load from
+// memory with a full round trip in front of the arithmetic, once per phase that does it.
+constexpr int kJcP = 0, kJcD = 12, kJcTq = 24, kJcDef = 36, kJcLo = 48, kJcHi = 60, kJointConsts = 72;
+static_assert(offsetof(HgymEnvConfig, d_gains) == offsetof(HgymEnvConfig, p_gains) + 48 &&
+              offsetof(HgymEnvConfig, torque_limits) == offsetof(HgymEnvConfig, p_gains) + 96 &&
+              offsetof(HgymEnvConfig, default_dof_pos) == offsetof(HgymEnvConfig, p_gains) + 144 &&
+              offsetof(HgymEnvConfig, dof_lower) == offsetof(HgymEnvConfig, p_gains) + 192 &&
+              offsetof(HgymEnvConfig, dof_upper) == offsetof(HgymEnvConfig, p_gains) + 240, "the per-joint constants are one block");
+HG_HD const float* joint_consts(const HgymEnvConfig& c) { return reinterpret_cast<const float*>(&c) + offsetof(HgymEnvConfig, p_gains) / 4; }
+#ifndef HGYM_JCFG_LDS
+#define HGYM_JCFG_LDS 1        // 0 (A/B runs): the workgroup kernels index the kernel argument
+#endif
+#define HGYM_JC(A, smem, m) (HGYM_JCFG_LDS ? (const float*)((smem) + (m).jcfg) : joint_consts((A).cfg))
+
+HG_HD float pd_torque(const HgymEnvConfig& c, const float* jc, int j, float a, float q, float qd) {
+    const float t = jc[kJcP + j] * (a * c.action_scale + jc[kJcDef + j] - q) - jc[kJcD + j] * qd;
+    return clampf(t, -jc[kJcTq + j], jc[kJcTq + j]);
 }
 
 HG_HD void pd_torques_env(const EnvArgs& A, int e, int N) {
 #pragma unroll
     for (int j = 0; j < 12; ++j)
-        FG(A.st.torques, j) = pd_torque(A.cfg, j, FG(A.st.actions, j), sget(A.sim.dof_pos, e, j), sget(A.sim.dof_vel, e, j));
+        FG(A.st.torques, j) = pd_torque(A.cfg, joint_consts(A.cfg), j, FG(A.st.actions, j), sget(A.sim.dof_pos, e, j), sget(A.sim.dof_vel, e, j));
 }
 
 // ------------------------------------------------------------------------------------------------ synthetic physics
@@ -217,19 +233,20 @@ HG_HD void phys_draw_call(const RngKey& rk, uint32_t ue, int c, float* tab) {
 }
 
 // `decimation` PD + semi-implicit Euler substeps of one unit-inertia joint; t = the last torque evaluation
-HG_HD void integrate_joint(const HgymEnvConfig& c, int j, float a, float& q, float& qd, float& t) {
+HG_HD void integrate_joint(const HgymEnvConfig& c, const float* jc, int j, float a, float& q, float& qd, float& t) {
     t = 0.0f;
+    const float lo = jc[kJcLo + j], hi = jc[kJcHi + j];
     for (int s = 0; s < c.decimation; ++s) {
-        t = pd_torque(c, j, a, q, qd);
+        t = pd_torque(c, jc, j, a, q, qd);
         qd = qd + c.sim_dt * t;
         q = q + c.sim_dt * qd;
-        if (q < c.dof_lower[j]) { q = c.dof_lower[j]; qd = 0.0f; }
-        if (q > c.dof_upper[j]) { q = c.dof_upper[j]; qd = 0.0f; }
+        if (q < lo) { q = lo; qd = 0.0f; }
+        if (q > hi) { q = hi; qd = 0.0f; }
     }
 }
 HG_HD void synth_joint(const EnvArgs& A, int e, int N, int j) {
     float q = sget(A.sim.dof_pos, e, j), qd = sget(A.sim.dof_vel, e, j), t;
-    integrate_joint(A.cfg, j, FG(A.st.actions, j), q, qd, t);
+    integrate_joint(A.cfg, joint_consts(A.cfg), j, FG(A.st.actions, j), q, qd, t);
     // the reference evaluates the torque before each substep; the last evaluation is what rewards see
     FG(A.st.torques, j) = t;
     sset(A.sim.dof_pos, e, j, q);
@@ -373,14 +390,14 @@ struct StepFlags {
 // 4 default_joint_pos :362-372, 5 dof_acc :516-521, 6 dof_vel :509-514, 17 torques :502-507, 13 joint_pos :272-280), joint j:
 // a = this step's action, la / lla = the previous two, ldv = last joint velocity, tq = torque, rdp = reference pose of the
 // previous step.
-HG_HD void joint_terms(const HgymEnvConfig& c, int j, float a, float la, float lla, float ldv, float q, float qd, float tq, float rdp,
-                       float (&o)[8]) {
+HG_HD void joint_terms(const HgymEnvConfig& c, const float* jc, int j, float a, float la, float lla, float ldv, float q, float qd, float tq,
+                       float rdp, float (&o)[8]) {
     const float d1 = la - a;
     o[0] = d1 * d1;
     const float d2 = a + lla - 2.0f * la;
     o[1] = d2 * d2;
     o[2] = fabsf(a);
-    const float jd = q - c.default_dof_pos[j];
+    const float jd = q - jc[kJcDef + j];
     o[3] = jd * jd;
     const float ac = (ldv - qd) / c.dt;
     o[4] = ac * ac;
@@ -606,7 +623,7 @@ HG_HD StepFlags post_physics_env(const EnvArgs& A, const RngKey& rk, int64_t csc
 #pragma unroll
                     for (int j = 0; j < 12; ++j) {
                         float jt[kJointTerms];
-                        joint_terms(c, j, act[j], la[j], lla[j], ldv[j], q[j], qd[j], tqv[j], rdp[j], jt);
+                        joint_terms(c, joint_consts(c), j, act[j], la[j], lla[j], ldv[j], q[j], qd[j], tqv[j], rdp[j], jt);
                         t1 += jt[0];
                         t2 += jt[1];
                         t3 += jt[2];
@@ -1088,7 +1105,7 @@ constexpr int kSnapRoot = 0, kSnapCmd = 13, kSnapLrv = 17, kSnapEp = 24, kSnapCo
 // LDS carve (float offsets) for a block of E envs
 struct LdsMap {
     int state, root, dof_pos, dof_vel, contact, rigid, actions_in, u_delay, z_act, u_cmd, u_dof, u_push, z_obs, phys, frame, priv, rew,
-        noise_vec, ep_len, flags, reset_i, reset_cnt, reset_list, reset_pose, jpart, cscal, terms, snap, total;
+        noise_vec, jcfg, ep_len, flags, reset_i, reset_cnt, reset_list, reset_pose, jpart, cscal, terms, snap, total;
 };
 HG_HD LdsMap lds_map(int E) {
     LdsMap m;
@@ -1111,6 +1128,7 @@ HG_HD LdsMap lds_map(int E) {
     m.priv = o;       o += HGYM_PRIV_FRAME * E;
     m.rew = o;        o += E;
     m.noise_vec = o;  o += 48;             // obs_noise[47] (a lane-varying index must not go through the kernel argument)
+    m.jcfg = o;       o += kJointConsts;   // the six per-joint constant arrays (joint_consts), for the same reason
     o = (o + 1) & ~1;
     m.ep_len = o;     o += 2 * E;          // int64[E]
     m.flags = o;      o += (2 * E + 3) / 4;  // uint8 reset[E], time_out[E]
@@ -1351,6 +1369,7 @@ HG_HD void env_stage_in_store(const EnvArgs& A, int block, int t, int nthreads, 
     copy_rows_in(A.noise.u_push, smem + m.u_push, 5, e0, nE, t, nthreads);
     copy_rows_in(A.noise.z_obs, smem + m.z_obs, HGYM_OBS_FRAME, e0, nE, t, nthreads);
     for (int i = t; i < HGYM_OBS_FRAME; i += nthreads) smem[m.noise_vec + i] = A.cfg.obs_noise[i];
+    for (int i = t; i < kJointConsts; i += nthreads) smem[m.jcfg + i] = joint_consts(A.cfg)[i];
     if (t == 0) reinterpret_cast<int*>(smem + m.reset_cnt)[0] = 0;
 }
 template <int E_T>
@@ -1469,7 +1488,7 @@ HG_HD void env_step_joints(const EnvArgs& A, int block, int t, int nthreads, flo
         const float a = filter_action(A.cfg, a_in, *act, smem[m.u_delay + le], smem[m.z_act + le * 12 + j]);
         *act = a;
         float q = smem[m.dof_pos + j * E + le], qd = smem[m.dof_vel + j * E + le], tq;
-        integrate_joint(A.cfg, j, a, q, qd, tq);
+        integrate_joint(A.cfg, HGYM_JC(A, smem, m), j, a, q, qd, tq);
         smem[m.state + (kStateOffTorques + j) * E + le] = tq;
         smem[m.dof_pos + j * E + le] = q;
         smem[m.dof_vel + j * E + le] = qd;
@@ -1496,7 +1515,7 @@ HG_HD void env_step_joint_terms(const EnvArgs& A, int block, int t, int nthreads
         const int j = i / E, le = i - j * E;
         if (le >= nE) continue;
         float jt[kJointTerms];
-        joint_terms(A.cfg, j, st[(kStateOffActions + j) * E + le], st[(kStateOffLastActions + j) * E + le],
+        joint_terms(A.cfg, HGYM_JC(A, smem, m), j, st[(kStateOffActions + j) * E + le], st[(kStateOffLastActions + j) * E + le],
                     st[(kStateOffLastLastActions + j) * E + le], st[(kStateOffLastDofVel + j) * E + le], smem[m.dof_pos + j * E + le],
                     smem[m.dof_vel + j * E + le], st[(kStateOffTorques + j) * E + le], st[(kStateOffRefPos + j) * E + le], jt);
 #pragma unroll
@@ -1567,7 +1586,7 @@ HG_HD void env_step_phase_f(const EnvArgs& A, int block, int t, int nthreads, fl
         float q = smem[m.dof_pos + j * E + le], qd = smem[m.dof_vel + j * E + le];
         float act = st[(kStateOffActions + j) * E + le];
         const float la = st[(kStateOffLastActions + j) * E + le];
-        const float dflt = c.default_dof_pos[j];
+        const float dflt = HGYM_JC(A, smem, m)[kJcDef + j];
         if (reset) {
             q = dflt + (c.dof_reset_span * smem[m.u_dof + le * 12 + j] + c.dof_reset_lo);
             qd = 0.0f;
@@ -2122,7 +2141,7 @@ HG_HD void env_step_stack_old(const EnvArgs& A, int block, int t, int nthreads, 
 
 template <int H_T, int HC_T, int E_T>
 HG_HD void env_step_phase_b(const EnvArgs& A, int block, int t, int nthreads, float* smem, int64_t csc0, int64_t ring_step,
-                            bool old_rows_final = false) {
+                            bool old_rows_final = false, bool ahead_rows_fixed = false) {
     const StackGeom g = stack_geom<H_T, HC_T, E_T>(A, block);
     const int H = g.H, HC = g.HC, e0 = g.e0, nE = g.nE;
     const LdsMap m = lds_map(g.E);
@@ -2156,8 +2175,28 @@ HG_HD void env_step_phase_b(const EnvArgs& A, int block, int t, int nthreads, fl
     stack_reset_fix(A.st.obs_ring, s_reset, dobs, e0, nE, H, HGYM_OBS_FRAME, (int)(ring_step % H), t, nthreads, !old_rows_final, nreset, rlist);
     stack_reset_fix(A.st.priv_ring, s_reset, dpriv, e0, nE, HC, HGYM_PRIV_FRAME, (int)(ring_step % HC), t, nthreads, !old_rows_final, nreset,
                     rlist);
-    if (dahead) stack_reset_ahead(dahead, s_reset, nE, H, HGYM_OBS_FRAME, t, nthreads, nreset, rlist);
-    if (pahead) stack_reset_ahead(pahead, s_reset, nE, HC, HGYM_PRIV_FRAME, t, nthreads, nreset, rlist);
+    // (ahead_rows_fixed: the caller has zeroed the reset envs' older frames of the rows after next itself -- hist_zero_reset, from the
+    // lanes that stored them)
+    if (dahead && !ahead_rows_fixed) stack_reset_ahead(dahead, s_reset, nE, H, HGYM_OBS_FRAME, t, nthreads, nreset, rlist);
+    if (pahead && !ahead_rows_fixed) stack_reset_ahead(pahead, s_reset, nE, HC, HGYM_PRIV_FRAME, t, nthreads, nreset, rlist);
+}
+
+// hist_store's items of the envs that reset, as zeros -- issued by the SAME lanes that stored the (pre-reset) frames there, so the
+// two stores to an address leave one wavefront in program order (no barrier between them has to wait for the first to be acknowledged)
+template <int H, int F, int NI, int EXCL = 1>
+HG_HD void hist_zero_reset(float* __restrict__ dst, int e0, int nE, int slot_new, int t, int nthreads, const int* s_reset) {
+    constexpr int S = HistGeom<H, F, EXCL>::kSlots, ROW = HistGeom<H, F, EXCL>::kRow;
+    const EnvF4 z = {{0.0f, 0.0f, 0.0f, 0.0f}};
+#pragma unroll
+    for (int u = 0; u < NI; ++u) {
+        int i = t + u * nthreads;
+        i = i < nE * S ? i : nE * S - 1;
+        const int le = i / S;
+        if (!s_reset[le]) continue;
+        int so, d_o;
+        hist_slot<H, F, EXCL>(slot_new, i - le * S, so, d_o);
+        st_stream4<(HGYM_ENV_NT & 2) != 0>(dst + (int64_t)(e0 + le) * ROW + d_o, z);
+    }
 }
 
 // Step finaliser (hgym_finalize.hpp) on an EnvArgs record.

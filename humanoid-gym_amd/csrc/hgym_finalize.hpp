@@ -137,13 +137,103 @@ __device__ __forceinline__ void fin_log(const FinArgs& F, int t, int nthreads) {
     }
 }
 
+// fin_part1 + fin_store in ONE memory round trip (N a multiple of 8, 16-byte aligned columns; otherwise returns false and nothing is
+// touched).  The two functions above are loops of load -> store over byte pointers: every load waits for the store before it (a
+// uint8_t store may alias anything), 8 + 8 dependent round trips for 4096 envs on 512 lanes -- 8 us of a single workgroup that
+// rides behind the critic tiles of the rollout launch and ended that launch.  Here a lane owns 8 consecutive envs, issues every
+// load it needs (the reset count, its 8 time-out / reset / stale time-out bytes, its 8 values and rewards) before its first store,
+// and thread t still refreshes exactly the elements it reads back (no barrier).  Same arithmetic, same roundings.
+__device__ __forceinline__ bool fin_fused(const FinArgs& F, int t, int nthreads) {
+#pragma clang fp contract(off)
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    typedef unsigned long long u64;
+    const HgymEnvOut& O = F.out;
+    auto al = [](const void* p, int a) { return ((uintptr_t)p & (uintptr_t)(a - 1)) == 0; };
+    const bool sink = O.t_rewards != nullptr;
+    if ((F.N & 7) != 0 || !al(O.time_out, 8) || !al(O.extras_time_outs, 8) ||
+        (sink && (!al(O.reset, 8) || !al(O.t_dones, 8) || !al(O.t_values, 16) || !al(O.rew, 16) || !al(O.t_rewards, 16))))
+        return false;
+    const int G = F.N >> 3;
+    const int64_t cnt = F.reset_count[0];
+    float acc = 0.0f, cacc = 0.0f;
+    if (t < HGYM_NUM_REWARDS) acc = F.episode_acc[t];
+    if (t < F.ncustom) cacc = F.custom_acc[t];
+    for (int g0 = 0; g0 < G; g0 += nthreads) {          // (4096 envs on 512 lanes: one trip)
+        const int g = g0 + t;
+        if (g >= G) break;
+        const u64 to_new = reinterpret_cast<const u64*>(O.time_out)[g];
+        const u64 to_old = reinterpret_cast<const u64*>(O.extras_time_outs)[g];
+        u64 rs = 0;
+        f4 v0 = {0.0f, 0.0f, 0.0f, 0.0f}, v1 = v0, r0 = v0, r1 = v0;
+        if (sink) {
+            rs = reinterpret_cast<const u64*>(O.reset)[g];
+            v0 = reinterpret_cast<const f4*>(O.t_values)[2 * g];
+            v1 = reinterpret_cast<const f4*>(O.t_values)[2 * g + 1];
+            r0 = reinterpret_cast<const f4*>(O.rew)[2 * g];
+            r1 = reinterpret_cast<const f4*>(O.rew)[2 * g + 1];
+        }
+        const u64 to = cnt > 0 ? to_new : to_old;
+        if (cnt > 0) reinterpret_cast<u64*>(O.extras_time_outs)[g] = to_new;
+        if (sink) {
+            f4 o0, o1;
+            u64 dn = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float tof = (float)(((to >> (8 * k)) & 0xffull) != 0);
+                const float boot = (k < 4 ? v0[k & 3] : v1[k & 3]) * tof;
+                const float gb = O.t_gamma * boot;
+                const float r = (k < 4 ? r0[k & 3] : r1[k & 3]) + gb;
+                if (k < 4) o0[k & 3] = r;
+                else o1[k & 3] = r;
+                dn |= (u64)(((rs >> (8 * k)) & 0xffull) != 0) << (8 * k);
+            }
+            reinterpret_cast<f4*>(O.t_rewards)[2 * g] = o0;
+            reinterpret_cast<f4*>(O.t_rewards)[2 * g + 1] = o1;
+            reinterpret_cast<u64*>(O.t_dones)[g] = dn;
+        }
+    }
+    if (cnt > 0) {
+        if (t < HGYM_NUM_REWARDS) {
+            O.extras_episode[t] = acc / (float)cnt / F.episode_length_s;
+            F.episode_acc[t] = 0.0f;
+        }
+        if (t < F.ncustom) {
+            O.extras_custom[t] = cacc / (float)cnt / F.episode_length_s;
+            F.custom_acc[t] = 0.0f;
+        }
+    }
+    return true;
+}
+
 // all of it, for one workgroup of `nthreads` lanes
+#ifndef HGYM_FIN_FUSED
+#define HGYM_FIN_FUSED 1
+#endif
 __device__ __forceinline__ void fin_block(const FinArgs& F, int t, int nthreads) {
-    fin_part1(F, t, nthreads);
-    __syncthreads();
-    fin_store(F, t, nthreads);
+    // fin_part2's counters travel with the first loads (nothing in between writes them): no round trip of their own at the end
+    const bool bump_step = F.out.t_rewards && F.out.t_step && !F.out.defer_finalize;
+    int64_t c0 = 0, c2 = 0, ts = 0;
+    if (HGYM_FIN_FUSED && t == 0) {
+        c0 = F.counters[0];
+        c2 = F.counters[2];
+        if (bump_step) ts = F.out.t_step[0];
+    }
+    if (!(HGYM_FIN_FUSED && fin_fused(F, t, nthreads))) {
+        fin_part1(F, t, nthreads);
+        __syncthreads();
+        fin_store(F, t, nthreads);
+    }
     fin_log(F, t, nthreads);
-    if (t == 0) fin_part2(F);
+    if (t == 0) {
+        if (HGYM_FIN_FUSED) {       // = fin_part2
+            if (bump_step) F.out.t_step[0] = ts + 1;
+            F.reset_count[0] = 0;
+            if (F.mode == FIN_MODE_STEP) F.counters[0] = c0 + 1;
+            if (F.mode != FIN_MODE_RESET_ALL) F.counters[2] = c2 + 1;
+        } else {
+            fin_part2(F);
+        }
+    }
 }
 
 }  // namespace hgym

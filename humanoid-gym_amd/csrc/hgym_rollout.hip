@@ -99,10 +99,26 @@ constexpr int RO_NIP = hist_ni<3, HGYM_PRIV_FRAME, RO_E, RO_NT>();
 #ifndef HGYM_W3_PROBE
 #define HGYM_W3_PROBE 0
 #endif
+#ifndef HGYM_RO_LDS_BARRIER
+#define HGYM_RO_LDS_BARRIER 0   // 1: the barriers behind the per-env phase and behind phase F order LDS traffic only (ro_lds_barrier)
+#endif
+// __syncthreads() also waits for every global-memory operation the wavefront has in flight (one counter for loads and stores), i.e.
+// for the acknowledgement of the rows-after-next stores issued during the per-env phase.  A barrier that waits for the LDS operations
+// only lets those stores retire behind the following phases -- and was measured SLOWER (collection 2.38 vs 2.29 ms, same call): what
+// a workgroup does not wait for in the middle it waits for at its end, where nothing overlaps it (as HGYM_RO_AHEAD_LATE).  Kept as a
+// switch for that measurement.  With it, a later store of ANOTHER wavefront to the same address must not rely on the barrier (reset
+// envs' frames of the rows after next: hist_zero_reset, from the lanes that stored them).
+__device__ __forceinline__ void ro_lds_barrier() {
+#if HGYM_RO_LDS_BARRIER
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#else
+    __syncthreads();
+#endif
+}
 constexpr bool RO_W3 = HGYM_ENV_SPLIT && HGYM_ENV_WAVES3;
 constexpr int RO_CHAIN = RO_W3 ? 64 * kChainRoles : 64;     // lanes of the per-env chain; the others fetch the rows after next meanwhile
 #ifndef HGYM_RO_AHEAD_LATE
-#define HGYM_RO_AHEAD_LATE 1   // the rows after next are STORED as the launch's last instructions (nothing waits for them there); 0: right behind their loads
+#define HGYM_RO_AHEAD_LATE 0   // 1: the rows after next are STORED as the launch's last instructions (shorter per-env phase, but the workgroup then ends with their acknowledgement: measured +0.05 ms per rollout)
 #endif
 constexpr int RO_NIA = hist_ni<15, HGYM_OBS_FRAME, RO_E, RO_NT - RO_CHAIN, 2>();      // rows written one launch ahead: 13 frames
 constexpr int RO_NIAP = hist_ni<3, HGYM_PRIV_FRAME, RO_E, RO_NT - RO_CHAIN, 2>();      // ... and the one privileged frame
@@ -116,7 +132,13 @@ template <bool FIN, bool PRE, bool PART = false>
 __global__ __launch_bounds__(RO_NT) void rollout_step_kernel(const FwdArgs f, const EnvArgs e, const FinArgs fin, const RolloutPP pp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (FIN && blockIdx.y >= 2) {
-        if (blockIdx.x == 0) fin_block(fin, threadIdx.x, RO_NT);
+        // (phase clock: slot 6 of the env row = when this workgroup of the third grid row started, slot 7 of block 0 = the finaliser's end)
+        long long* d2 = f.dbg ? f.dbg + ((int64_t)2 * gridDim.x + blockIdx.x) * 8 : nullptr;
+        if (d2 && threadIdx.x == 0) d2[6] = (long long)__builtin_amdgcn_s_memrealtime();
+        if (blockIdx.x == 0) {
+            fin_block(fin, threadIdx.x, RO_NT);
+            if (d2 && threadIdx.x == 0) d2[7] = (long long)__builtin_amdgcn_s_memrealtime();
+        }
         return;
     }
     constexpr int U = 16 / 8;                       // n-blocks per wave per 256 first-layer columns (mlp_fwd_kernel)
@@ -286,10 +308,16 @@ __global__ __launch_bounds__(RO_NT) void rollout_step_kernel(const FwdArgs f, co
 #if HGYM_W3_PROBE
     if (dbg && (t & 63) == 0 && t <= 256) dbg[t < 256 ? 4 + (t >> 6) : 0] = (long long)__builtin_amdgcn_s_memrealtime();     // wavefronts 0-3 -> slots 4-7, wavefront 4 -> slot 0
 #endif
-    __syncthreads();
+    ro_lds_barrier();
+    if (HGYM_RO_LDS_BARRIER && !HGYM_RO_AHEAD_LATE && t >= RO_CHAIN && A.out.obs_ahead &&
+        reinterpret_cast<const int*>(esm + lds_map(RO_E).reset_cnt)[0] > 0) {       // (phase B's stack_reset_ahead, from the lanes that own the items)
+        const int* s_reset = reinterpret_cast<const int*>(esm + lds_map(RO_E).reset_i);
+        hist_zero_reset<15, HGYM_OBS_FRAME, RO_NIA, 2>(A.out.obs_ahead, block * RO_E, RO_E, (int)(ring_step % 15), t - RO_CHAIN, RO_NT - RO_CHAIN, s_reset);
+        hist_zero_reset<3, HGYM_PRIV_FRAME, RO_NIAP, 2>(A.out.priv_ahead, block * RO_E, RO_E, (int)(ring_step % 3), t - RO_CHAIN, RO_NT - RO_CHAIN, s_reset);
+    }
     env_step_phase_f<RO_E>(A, block, t, RO_NT, esm);       // per-joint reset / reference pose / frame entries / last_* copies
     if (RO_W3) env_step_reward_sum<RO_E>(A, block, t, RO_NT, esm);   // (the last wavefront: phase F has the first six)
-    __syncthreads();
+    ro_lds_barrier();
 #else
     if (t < 64) env_step_phase_a<RO_E, false>(A, block, t, esm, csc0);
     else ahead();
@@ -300,7 +328,7 @@ __global__ __launch_bounds__(RO_NT) void rollout_step_kernel(const FwdArgs f, co
 #if !HGYM_W3_PROBE
     stamp(4);
 #endif
-    env_step_phase_b<15, 3, RO_E>(A, block, t, RO_NT, esm, csc0, ring_step, false);
+    env_step_phase_b<15, 3, RO_E>(A, block, t, RO_NT, esm, csc0, ring_step, false, HGYM_RO_LDS_BARRIER && !HGYM_RO_AHEAD_LATE);
 #if !HGYM_W3_PROBE
     stamp(5);
 #endif

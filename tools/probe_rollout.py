@@ -24,19 +24,29 @@ L.check(L.lib.hgym_prof_phase_buffer(C.c_void_p(buf.data_ptr()), buf.numel()))
 alg, st = runner.alg, runner.alg.storage
 obs_all, priv_all = st._obs_all, st._priv_all
 alg.env_stores_transitions = True
-env.rollout_begin(alg._sample_step, 4)
+# HGYM_PROBE_BURST=K: K launches back to back without a host synchronisation in between (as the captured graph runs them: every
+# launch finds the caches the way the previous one left them), the phase clock of the LAST one; default: 4 launches, a
+# synchronisation behind each
+BURST = int(os.environ.get("HGYM_PROBE_BURST", "0"))
+NS = BURST if BURST > 0 else 4
+env.rollout_begin(alg._sample_step, NS)
 acc = []
-for i in range(4):
-    buf.zero_()
+for i in range(NS):
+    if BURST == 0:
+        buf.zero_()
     alg.fused_rollout_step(env, i, obs_all[i], priv_all[i], obs_all[i + 1], priv_all[i + 1], (obs_all[i + 2], priv_all[i + 2]))
-    torch.cuda.synchronize()
-    acc.append(buf.clone())
+    if BURST == 0:
+        torch.cuda.synchronize()
+        acc.append(buf.clone())
+torch.cuda.synchronize()
+if BURST > 0:
+    acc = [None, buf.clone()]
 env.rollout_end()
 st.step = 0
 L.check(L.lib.hgym_prof_phase_buffer(None, 0))
 FWD = ["input0+draws", "layer0 k-loop", "epilogue0+sync", "layer1+sync", "layer2+sync", "head"]
 ENV = ["hist stores", "joints+sync", "per-env chain+sync", "stage-out", "phase B"]
-for i, b in enumerate(acc[1:], 1):
+for i, b in enumerate(acc[1:], NS - 1 if BURST > 0 else 1):
     t = b.view(3, nb, 8).cpu().double() * 0.01
     if os.environ.get("HGYM_RO_INTERLEAVE", "1") != "0":     # the default build: tile b's actor sits in grid row b & 1, its critic in the other
         odd = (torch.arange(nb) & 1).bool()
@@ -54,6 +64,9 @@ for i, b in enumerate(acc[1:], 1):
     print("step %d actor start -> env end: mean %.1f us, grid span %.1f us" % (
         i, (t[2][:, 5] - t[0][:, 0]).mean().item(), (t[2][:, 5].max() - t[0][:, 0].min()).item()))
     t0 = t[0][:, 0].min()
+    r2 = t[2][:, 6] - t0
+    print("step %d   third grid row (the finaliser's + 127 empty workgroups) start offsets: min %.1f p50 %.1f max %.1f | finaliser start %.1f end %.1f | last env end %.1f | last critic end %.1f" % (
+        i, r2.min().item(), r2.median().item(), r2.max().item(), r2[0].item(), (t[2][0, 7] - t0).item(), (t[2][:, 5] - t0).max().item(), (t[1][:, 7] - t0).max().item()))
     q = lambda x: "min %.1f p50 %.1f p90 %.1f max %.1f" % (x.min().item(), x.median().item(), x.quantile(0.9).item(), x.max().item())
     print("step %d   actor start offsets: %s | critic start offsets: %s" % (i, q(t[0][:, 0] - t0), q(t[1][:, 0] - t0)))
     print("step %d   actor+env durations: %s | env end offsets: %s" % (i, q(t[2][:, 5] - t[0][:, 0]), q(t[2][:, 5] - t0)))
