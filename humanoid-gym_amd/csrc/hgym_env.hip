@@ -67,7 +67,10 @@ __global__ __launch_bounds__(256) void env_step_kernel(const EnvArgs A) {
     // for each of the 12 joints runs one (env, joint) pair per lane before (phase J) and after (phase F) a shorter chain, and
     // the synthetic physics' per-env remainder runs on two otherwise idle wavefronts of phase J.
     const bool split = HGYM_ENV_SPLIT && !kGeneric && E_T > 0 && (kStep || A.mode == MODE_STEP);
-    constexpr bool kW3 = HGYM_ENV_SPLIT && HGYM_ENV_WAVES3 && !kGeneric && E_T > 0 && kStep;     // the chain on three wavefronts
+#ifndef HGYM_ENV_KERNEL_WAVES
+#define HGYM_ENV_KERNEL_WAVES 1    // this kernel's per-env chain on one wavefront (its other three store the observation history meanwhile); 4: on all four
+#endif
+    constexpr bool kW3 = HGYM_ENV_SPLIT && HGYM_ENV_WAVES3 && HGYM_ENV_KERNEL_WAVES == 4 && !kGeneric && E_T > 0 && kStep;
     if (split) env_step_phase_j<E_T, kW3>(A, blockIdx.x, t, blockDim.x, smem);
     else if (!(A.ablate & 128)) env_step_joints<E_T>(A, blockIdx.x, t, blockDim.x, smem);
     __syncthreads();

@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage: tools/gpu_bench_ab.sh <variant> ...  -- same-box A/B of the WHOLE bench (bench.py, no CPU baseline) per library variant
 # ("base" = the default library; others from `build.py --variant`), two interleaved repetitions; prints value, ms/iter,
-# collection and update ms.  HGYM_AB_TESTS=1 then runs the full GPU test suite under the default library.
+# collection and update ms.  HGYM_AB_BENCH_ARGS: extra bench.py arguments (e.g. --num-envs 8192).  HGYM_AB_TESTS=1 then runs the full GPU test suite under the default library.
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
 mkdir -p $O
@@ -10,7 +10,7 @@ out=$O/benchab_$(echo "$@" | tr ' ' '_').txt
 : > $out
 for rep in 1 2; do
   for v in "$@"; do
-    HGYM_LIB=$(lib $v) timeout 300 python bench.py --no-cpu-baseline --no-roofline --configs none --steps 20 2>&1 | tail -1 > $O/_line.json
+    HGYM_LIB=$(lib $v) timeout 300 python bench.py --no-cpu-baseline --no-roofline --configs none --steps 20 $HGYM_AB_BENCH_ARGS 2>&1 | tail -1 > $O/_line.json
     python - "$v" "$rep" $O/_line.json >> $out <<'P'
 import json, sys
 try:
