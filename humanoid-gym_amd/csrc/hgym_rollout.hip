@@ -92,6 +92,7 @@ struct RolloutPP {
     // workgroups left for this step (PART instantiation), ah.acc_out = where this launch's leave the next step's (null: not).
     L0Part l0;
     L0Ahead ah;
+    const uint8_t* prev_reset;   // reset flags of the previous step (prev_out->reset; null: first step of a rollout), see HGYM_RO_AHEAD_CRITIC
 };
 
 constexpr int RO_NIO = hist_ni<15, HGYM_OBS_FRAME, RO_E, RO_NT>();
@@ -115,6 +116,17 @@ __device__ __forceinline__ void ro_lds_barrier() {
     __syncthreads();
 #endif
 }
+#ifndef HGYM_RO_AHEAD_CRITIC
+#define HGYM_RO_AHEAD_CRITIC 1
+#endif
+// HGYM_RO_AHEAD_CRITIC: the rows after next (obs_ahead / priv_ahead: 13 + 1 older frames per env, ring -> rows, 78 KB per tile) are copied
+// by the tile's CRITIC workgroup at its start, not by the idle wavefronts of the actor workgroup's per-env phase -- in a run of launches
+// that phase waited 7 us for the copy's loads and acknowledged stores, against 4.5 us for its own arithmetic, and the critic workgroup
+// ends ~3 us before the actor's.  The copy reads pre-reset history for an env that resets in THIS step; nobody reads those rows before
+// the next launch, which zeroes them (prev_reset) -- the kernel boundary orders the two workgroups' stores to the same addresses.
+constexpr bool RO_AHC = HGYM_RO_AHEAD_CRITIC != 0;
+constexpr int RO_NIA_C = hist_ni<15, HGYM_OBS_FRAME, RO_E, RO_NT, 2>();
+constexpr int RO_NIAP_C = hist_ni<3, HGYM_PRIV_FRAME, RO_E, RO_NT, 2>();
 constexpr bool RO_W3 = HGYM_ENV_SPLIT && HGYM_ENV_WAVES3;
 constexpr int RO_CHAIN = RO_W3 ? 64 * kChainRoles : 64;     // lanes of the per-env chain; the others fetch the rows after next meanwhile
 #ifndef HGYM_RO_AHEAD_LATE
@@ -153,12 +165,26 @@ __global__ __launch_bounds__(RO_NT) void rollout_step_kernel(const FwdArgs f, co
         // one instantiation only (first hidden layer 768 wide, rollout_fwd_args checks): with the three-way dispatch of
         // mlp_fwd_kernel next to the actor + env branch the compiler keeps a private-memory copy of the whole 3 KB argument
         fwd_body<32, 8, 4, 3 * U>(f, f.net[1], false, smem);
+        // rows after next of this tile (HGYM_RO_AHEAD_CRITIC): loads issued here, behind the tile, where the launch's first rush on memory is
+        // over; they travel while the draws are computed; the stores' acknowledgements are waited for under the first-layer weights below
+        float ha[RO_AHC ? RO_NIA_C : 1][4], hp[RO_AHC ? RO_NIAP_C : 1][4];
+        const int ring_s = (int)pp.in[1];
+        if (RO_AHC) {       // (unconditional: the ring always exists; a launch without rows after next drops them)
+            hist_load<15, HGYM_OBS_FRAME, RO_NIA_C, 2>(e.st.obs_ring, (int)blockIdx.x * RO_E, RO_E, ring_s % 15, (int)threadIdx.x, RO_NT, ha);
+            hist_load<3, HGYM_PRIV_FRAME, RO_NIAP_C, 2>(e.st.priv_ring, (int)blockIdx.x * RO_E, RO_E, ring_s % 3, (int)threadIdx.x, RO_NT, hp);
+        }
 #if HGYM_RO_DRAWS_AHEAD
         if (pp.draws_out) {      // next step's draw tables of this tile (step counter + 1), written where the LDS tables would be
             float* base = pp.draws_out + (int64_t)blockIdx.x * pp.draws_len - lds_map(RO_E).u_delay;
             env_fill_draws<RO_E>(e, (int)blockIdx.x, (int)threadIdx.x, RO_NT, base, pp.in[0] + 1);
         }
 #endif
+        if (RO_AHC && e.out.obs_ahead) {
+            hist_store<15, HGYM_OBS_FRAME, RO_NIA_C, 2>(e.out.obs_ahead, (int)blockIdx.x * RO_E, RO_E, ring_s % 15, (int)threadIdx.x, RO_NT, nullptr,
+                                                        e.cfg.clip_obs, ha);
+            hist_store<3, HGYM_PRIV_FRAME, RO_NIAP_C, 2>(e.out.priv_ahead, (int)blockIdx.x * RO_E, RO_E, ring_s % 3, (int)threadIdx.x, RO_NT, nullptr,
+                                                         e.cfg.clip_obs, hp);
+        }
         if (pp.ah.acc_out) {     // k-steps [0, kb0) of the ACTOR's first layer for the next step's rows of this tile
             __syncthreads();     // (the head wavefronts of this tile may still read its LDS)
             l0_partial_ahead<2 * U>(f.net[0], pp.ah, f.M, smem);
@@ -297,6 +323,7 @@ __global__ __launch_bounds__(RO_NT) void rollout_step_kernel(const FwdArgs f, co
         }
     };
     auto ahead = [&]() {
+        if (RO_AHC) return;          // the critic workgroup of the tile has done it
         ahead_load();
         if (!HGYM_RO_AHEAD_LATE) ahead_store(nullptr);
     };
@@ -309,7 +336,7 @@ __global__ __launch_bounds__(RO_NT) void rollout_step_kernel(const FwdArgs f, co
     if (dbg && (t & 63) == 0 && t <= 256) dbg[t < 256 ? 4 + (t >> 6) : 0] = (long long)__builtin_amdgcn_s_memrealtime();     // wavefronts 0-3 -> slots 4-7, wavefront 4 -> slot 0
 #endif
     ro_lds_barrier();
-    if (HGYM_RO_LDS_BARRIER && !HGYM_RO_AHEAD_LATE && t >= RO_CHAIN && A.out.obs_ahead &&
+    if (HGYM_RO_LDS_BARRIER && !HGYM_RO_AHEAD_LATE && !RO_AHC && t >= RO_CHAIN && A.out.obs_ahead &&
         reinterpret_cast<const int*>(esm + lds_map(RO_E).reset_cnt)[0] > 0) {       // (phase B's stack_reset_ahead, from the lanes that own the items)
         const int* s_reset = reinterpret_cast<const int*>(esm + lds_map(RO_E).reset_i);
         hist_zero_reset<15, HGYM_OBS_FRAME, RO_NIA, 2>(A.out.obs_ahead, block * RO_E, RO_E, (int)(ring_step % 15), t - RO_CHAIN, RO_NT - RO_CHAIN, s_reset);
@@ -328,11 +355,24 @@ __global__ __launch_bounds__(RO_NT) void rollout_step_kernel(const FwdArgs f, co
 #if !HGYM_W3_PROBE
     stamp(4);
 #endif
-    env_step_phase_b<15, 3, RO_E>(A, block, t, RO_NT, esm, csc0, ring_step, false, HGYM_RO_LDS_BARRIER && !HGYM_RO_AHEAD_LATE);
+    env_step_phase_b<15, 3, RO_E>(A, block, t, RO_NT, esm, csc0, ring_step, false, RO_AHC || (HGYM_RO_LDS_BARRIER && !HGYM_RO_AHEAD_LATE));
+    if (RO_AHC && PRE && pp.prev_reset) {
+        // this launch's next-observation rows were pre-written by the previous launch from the history as IT found it: an env the previous
+        // step reset has zero older frames (13 of 15, 1 of 3) -- every wavefront reads the tile's 32 flags, loops over the set ones
+        const int lane = t & 63;
+        const unsigned long long mask = __ballot(lane < RO_E && pp.prev_reset[block * RO_E + (lane & (RO_E - 1))] != 0);
+        for (unsigned long long mm = mask; mm; mm &= mm - 1) {
+            const int le = __builtin_ctzll(mm);
+            float* dobs = A.out.obs + (int64_t)(block * RO_E + le) * 15 * HGYM_OBS_FRAME;
+            float* dpriv = A.out.priv_obs + (int64_t)(block * RO_E + le) * 3 * HGYM_PRIV_FRAME;
+            for (int i = t; i < 13 * HGYM_OBS_FRAME; i += RO_NT) dobs[i] = 0.0f;
+            for (int i = t; i < HGYM_PRIV_FRAME; i += RO_NT) dpriv[i] = 0.0f;
+        }
+    }
 #if !HGYM_W3_PROBE
     stamp(5);
 #endif
-    if (HGYM_RO_AHEAD_LATE && t >= RO_CHAIN) ahead_store(reinterpret_cast<const int*>(esm + lds_map(RO_E).reset_i));
+    if (HGYM_RO_AHEAD_LATE && !RO_AHC && t >= RO_CHAIN) ahead_store(reinterpret_cast<const int*>(esm + lds_map(RO_E).reset_i));
     if (block == 0 && t == 0) {
         pp.out[0] = csc0 + 1;
         pp.out[1] = ring_step + 1;
@@ -391,6 +431,7 @@ int32_t hgym_rollout_step(const HgymNetConfig* cfg, const HgymNet* net, const Hg
     FinArgs fin;
     RolloutPP pp;
     memset(&fin, 0, sizeof(fin));
+    pp.prev_reset = nullptr;
     size_t lds_pol = 0;
     int32_t rc = rollout_fwd_args(cfg, net, M, obs, priv, seed, &scr->pp[parity][2], actions, mu, sigma, logp, values, &f, &lds_pol, shadow);
     if (rc) return rc;
@@ -408,6 +449,7 @@ int32_t hgym_rollout_step(const HgymNetConfig* cfg, const HgymNet* net, const Hg
         HG_REQUIRE(prev_out->time_out && prev_out->extras_time_outs && prev_out->extras_episode && prev_out->rew && prev_out->reset,
                    HGYM_E_BADARG, "null finaliser buffer");
         fin = parity_fin(*env_cfg, *st, *prev_out, scr, parity ^ 1);
+        pp.prev_reset = prev_out->reset;
     }
     pp.in = scr->pp[parity];
     pp.out = scr->pp[parity ^ 1];
