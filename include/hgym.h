@@ -236,9 +236,12 @@ typedef struct HgymEnvOut {
     float* extras_custom;      /* (K,) extras["episode"]["rew_<name>"] of the user-defined terms, same staleness rule as extras_episode */
     /* hgym_rollout_step only (NULL / 0 everywhere else).  obs_ahead: rows of the observation AFTER `obs` ((N, frame_stack*47): the
      * rollout storage's slot after next).  The launch then also writes their frames 0 .. frame_stack-2 -- the frame_stack-2 older
-     * frames it knows when it starts (during its per-env phase, on wavefronts that idle there) and this step's own frame -- so that
+     * frames it knows when it starts (copied by the tile's critic workgroup behind its tile) and this step's own frame -- so that
      * the NEXT launch, called with obs = this pointer and obs_older_ready = 1, does not copy them on its critical path: between the
-     * first and second layer of the actor tile that copy costs 4.4 us of a 42 us launch.  The rows come out bit-identical. */
+     * first and second layer of the actor tile that copy costs 4.4 us of a 42 us launch.  The rows come out bit-identical.
+     * For an env that resets in THIS step the copied frames are pre-reset history: the next call (obs_older_ready = 1, prev_out = this
+     * call's out -- both already required) zeroes them before anybody reads the rows; a next call WITHOUT obs_older_ready writes all
+     * older frames itself.  Do not read obs_ahead / priv_ahead rows between the two calls. */
     float* obs_ahead;
     float* priv_ahead;         /* the same for priv_obs ((N, c_frame_stack*73)); both or neither */
     int32_t obs_older_ready;   /* 1: frames 0 .. frame_stack-2 of `obs` (and 0 .. c_frame_stack-2 of `priv_obs`) were written by the
