@@ -167,7 +167,7 @@ __global__ __launch_bounds__(RO_NT) void rollout_step_kernel(const FwdArgs f, co
         fwd_body<32, 8, 4, 3 * U>(f, f.net[1], false, smem);
         // rows after next of this tile (HGYM_RO_AHEAD_CRITIC): loads issued here, behind the tile, where the launch's first rush on memory is
         // over; they travel while the draws are computed; the stores' acknowledgements are waited for under the first-layer weights below
-        float ha[RO_AHC ? RO_NIA_C : 1][4], hp[RO_AHC ? RO_NIAP_C : 1][4];
+        float ha[RO_NIA_C][4], hp[RO_NIAP_C][4];
         const int ring_s = (int)pp.in[1];
         if (RO_AHC) {       // (unconditional: the ring always exists; a launch without rows after next drops them)
             hist_load<15, HGYM_OBS_FRAME, RO_NIA_C, 2>(e.st.obs_ring, (int)blockIdx.x * RO_E, RO_E, ring_s % 15, (int)threadIdx.x, RO_NT, ha);
