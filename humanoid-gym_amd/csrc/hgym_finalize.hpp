@@ -143,7 +143,7 @@ __device__ __forceinline__ void fin_log(const FinArgs& F, int t, int nthreads) {
 // rides behind the critic tiles of the rollout launch and ended that launch.  Here a lane owns 8 consecutive envs, issues every
 // load it needs (the reset count, its 8 time-out / reset / stale time-out bytes, its 8 values and rewards) before its first store,
 // and thread t still refreshes exactly the elements it reads back (no barrier).  Same arithmetic, same roundings.
-__device__ __forceinline__ bool fin_fused(const FinArgs& F, int t, int nthreads) {
+HG_HD bool fin_fused(const FinArgs& F, int t, int nthreads) {      // (host-compilable: tests/hostcheck runs it against fin_part1 + fin_store)
 #pragma clang fp contract(off)
     typedef float f4 __attribute__((ext_vector_type(4)));
     typedef unsigned long long u64;

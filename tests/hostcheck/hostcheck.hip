@@ -179,6 +179,20 @@ int hc_env_step_ex(const HgymEnvConfig* cfg, const HgymSimTensors* sim, const Hg
     return 0;
 }
 
+// The finaliser's two forms on the same inputs: fused != 0 runs fin_fused (one pass, a lane owns 8 envs, packed loads / stores) for
+// every lane, otherwise fin_part1 then fin_store as the general path does.  Returns 1 if the fused form declined (N % 8, alignment).
+int hc_finalize_forms(const HgymEnvConfig* cfg, const HgymEnvState* st, const HgymEnvOut* out, int nthreads, int fused) {
+    const FinArgs F = make_fin_args(*cfg, *st, *out, FIN_MODE_STEP);
+    if (fused) {
+        for (int t = 0; t < nthreads; ++t)
+            if (!fin_fused(F, t, nthreads)) return 1;
+        return 0;
+    }
+    for (int t = 0; t < nthreads; ++t) fin_part1(F, t, nthreads);
+    for (int t = 0; t < nthreads; ++t) fin_store(F, t, nthreads);
+    return 0;
+}
+
 int hc_pre_physics(const HgymEnvConfig* cfg, const HgymEnvState* st, float* actions_in, const HgymEnvNoise* noise) {
     const EnvArgs A = make_args(cfg, nullptr, st, nullptr, noise, actions_in, MODE_STEP, 0, 4);
     const RngKey rk = make_rng_key(A, st->counters[0]);

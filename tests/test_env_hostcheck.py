@@ -3,6 +3,7 @@ against the golden trace recorded from the reference.  Catches arithmetic / inde
 without a GPU; the `-m gpu` twin of this file (test_env_gpu.py) runs the real kernels."""
 import os
 
+import ctypes as C
 import numpy as np
 import pytest
 import torch
@@ -139,3 +140,44 @@ def test_reset_all_then_step_host():
     o.pre_physics(a, nz[0], nz[1]); o.pd_torques(); o.sim.load(*frame); o.post_physics(*nz[2:])
     env.step(a, frame, *nz)
     EC.compare_state(env, o, "step after reset_all")
+
+
+@pytest.mark.parametrize("N,nthreads,resets", [(4096, 512, 7), (4096, 1024, 0), (40, 64, 3), (8, 256, 1), (37, 64, 2)])
+def test_finaliser_one_pass_form_equals_the_general_one_host(N, nthreads, resets):
+    """csrc/hgym_finalize.hpp: fin_fused (a lane owns 8 consecutive envs, every load before its first store, 64- / 128-bit accesses; what the
+    device runs when N % 8 == 0) against fin_part1 + fin_store on the same inputs: refreshed extras["time_outs"] (only when an env reset),
+    extras["episode"], the emptied accumulators and the transition sink's bootstrapped rewards / dones -- bit for bit.  N = 37: declines."""
+    from hgym import EnvBuffers, default_env_config
+    be = EC.HostBackend(envs_per_block=8, nthreads=64)
+    g = torch.Generator().manual_seed(N + nthreads)
+    outs = []
+    for fused in (0, 1):
+        cfg = default_env_config(N, seed=1)
+        buf = EnvBuffers(cfg, "cpu")
+        gg = torch.Generator().manual_seed(N * 7 + 1)
+        buf.rew.copy_(torch.randn(N, generator=gg))
+        buf.reset.copy_(torch.rand(N, generator=gg) < 0.3)
+        buf.time_out.copy_(torch.rand(N, generator=gg) < 0.4)
+        buf.extras_time_outs.copy_(torch.rand(N, generator=gg) < 0.5)
+        buf.episode_acc.copy_(torch.randn(24, generator=gg))
+        buf.counters[1] = resets
+        sink = dict(values=torch.randn(N, generator=gg), rewards=torch.full((N,), float("nan")), dones=torch.zeros(N, dtype=torch.bool),
+                    step=torch.zeros(1, dtype=torch.int64), gamma=0.994)
+        st, out = buf.state_struct(), buf.out_struct(sink=sink)
+        rc = be.lib.hc_finalize_forms(C.byref(cfg), C.byref(st), C.byref(out), nthreads, fused)
+        if fused and N % 8:
+            assert rc == 1          # declined, nothing touched
+            assert torch.isnan(sink["rewards"]).all()
+            return
+        assert rc == 0
+        outs.append((buf.extras_time_outs.clone(), buf.extras_episode.clone(), buf.episode_acc.clone(), sink["rewards"].clone(), sink["dones"].clone(),
+                     buf.time_out.clone(), buf.reset.clone(), buf.rew.clone(), sink["values"].clone()))
+    a, b = outs
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    eto, eep, acc, rw, dn, to, rs, rew, val = a
+    assert torch.equal(dn, rs)
+    if resets > 0:
+        assert torch.equal(eto, to) and bool((acc[:22] == 0).all())
+    boot = val * eto.float()
+    assert torch.equal(rw, rew + torch.tensor(0.994, dtype=torch.float32) * boot)
