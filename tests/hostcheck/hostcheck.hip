@@ -100,6 +100,10 @@ int hc_env_step_ex(const HgymEnvConfig* cfg, const HgymSimTensors* sim, const Hg
     const int blocks = (N + epb - 1) / epb;
     const int64_t csc0 = st->counters[0], ring = st->counters[2];
     std::vector<float> smem(step_smem_bytes(epb) / sizeof(float));
+    // the previous step's reset flags, as hgym_rollout_step is handed them (prev_out->reset): the rows-ahead protocol below zeroes the
+    // frames that step copied ahead for an env it then reset in the NEXT call, as the device does since round 4 (HGYM_RO_AHEAD_CRITIC)
+    std::vector<uint8_t> prev_reset(N, 0);
+    if (A.out.reset && mode == MODE_STEP) memcpy(prev_reset.data(), A.out.reset, N);
     for (int b = 0; b < blocks; ++b) {
         for (int t = 0; t < nthreads; ++t) env_stage_in<0>(A, b, t, nthreads, smem.data());
         for (int t = 0; t < nthreads; ++t) env_fill_draws<0>(A, b, t, nthreads, smem.data(), csc0);
@@ -158,9 +162,19 @@ int hc_env_step_ex(const HgymEnvConfig* cfg, const HgymSimTensors* sim, const Hg
             else if (epb == 32) env_stage_out<32>(A, b, t, nthreads, smem.data());
             else env_stage_out<0>(A, b, t, nthreads, smem.data());
         }
+        const bool ahead = xbot && mode == MODE_STEP && A.out.obs_ahead && A.out.priv_ahead;
         for (int t = 0; t < nthreads; ++t) {
-            if (xbot) env_step_phase_b<15, 3, 0>(A, b, t, nthreads, smem.data(), csc0, ring);
+            // (rows ahead: this step does NOT zero what it copied ahead for the envs it resets -- on the device another workgroup copied it)
+            if (xbot) env_step_phase_b<15, 3, 0>(A, b, t, nthreads, smem.data(), csc0, ring, false, ahead);
             else env_step_phase_b<0, 0, 0>(A, b, t, nthreads, smem.data(), csc0, ring);
+        }
+        if (xbot && mode == MODE_STEP && A.out.obs_older_ready) {      // ... the next step does, for ITS next-observation rows
+            const StackGeom g = stack_geom<15, 3, 0>(A, b);
+            for (int le = 0; le < g.nE; ++le)
+                if (prev_reset[g.e0 + le]) {
+                    for (int i = 0; i < 13 * HGYM_OBS_FRAME; ++i) A.out.obs[(int64_t)(g.e0 + le) * 15 * HGYM_OBS_FRAME + i] = 0.0f;
+                    for (int i = 0; i < HGYM_PRIV_FRAME; ++i) A.out.priv_obs[(int64_t)(g.e0 + le) * 3 * HGYM_PRIV_FRAME + i] = 0.0f;
+                }
         }
     }
     if (cfg->num_height_points > 0 && mode == MODE_STEP)
