@@ -100,6 +100,9 @@ constexpr int RO_NIP = hist_ni<3, HGYM_PRIV_FRAME, RO_E, RO_NT>();
 #ifndef HGYM_W3_PROBE
 #define HGYM_W3_PROBE 0
 #endif
+#ifndef HGYM_HWID_PROBE
+#define HGYM_HWID_PROBE 0
+#endif
 #ifndef HGYM_RO_LDS_BARRIER
 #define HGYM_RO_LDS_BARRIER 0   // 1: the barriers behind the per-env phase and behind phase F order LDS traffic only (ro_lds_barrier)
 #endif
@@ -289,7 +292,9 @@ __global__ __launch_bounds__(RO_NT) void rollout_step_kernel(const FwdArgs f, co
 #endif
             hist_store<15, HGYM_OBS_FRAME, RO_NIO>(A.out.obs, block * RO_E, RO_E, (int)(ring_step % 15), t, RO_NT, nullptr, A.cfg.clip_obs, hist_o);
     }
-#if HGYM_W3_PROBE     // tools/probe_w3.py: slot 1 = the SIMD every wavefront of the workgroup runs on (4 bits each), 4..7 = ends of the chain's roles
+#if HGYM_HWID_PROBE   // tools/probe_placement.py: slot 1 = where the workgroup runs: XCC_ID (bits 32..35) | HW_ID (se / sh / cu / simd / wave fields, bits 0..31)
+    if (dbg && t == 0) dbg[1] = ((long long)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15) << 32) | (long long)(unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+#elif HGYM_W3_PROBE     // tools/probe_w3.py: slot 1 = the SIMD every wavefront of the workgroup runs on (4 bits each), 4..7 = ends of the chain's roles
     if (dbg && (t & 63) == 0) atomicAdd(reinterpret_cast<unsigned long long*>(dbg + 1),
                                         (unsigned long long)__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4) << (4 * (t >> 6)));
 #else
