@@ -34,7 +34,9 @@ extern "C" {
                              *    priv_bf16, hgym_net_shadow_ld
                              * 5: HgymEnvOut.obs_ahead / obs_older_ready (hgym_rollout_step writes the older frames one launch ahead)
                              * 6: HgymEnvOut.l0_ahead / l0_ready / obs_bf16_ahead (the actor's first layer carried across the launches of a rollout);
-                             *    HGYM_MAX_CUSTOM_REWARDS 8 -> 24, custom_reward_pos = 23: after the clip (`termination`) */
+                             *    HGYM_MAX_CUSTOM_REWARDS 8 -> 24, custom_reward_pos = 23: after the clip (`termination`);
+                             *    (same version, later: frames written into obs_ahead / priv_ahead for an env that resets in the same step are
+                             *    zeroed by the NEXT hgym_rollout_step call -- see HgymEnvOut.obs_ahead; layouts and call sequence unchanged) */
 
 enum {
     HGYM_OK = 0,
