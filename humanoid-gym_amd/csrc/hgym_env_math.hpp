@@ -444,7 +444,7 @@ template <bool kGeneric, bool kSplit = false, int ROLE = ROLE_ALL>
 HG_HD StepFlags post_physics_env(const EnvArgs& A, const RngKey& rk, int64_t csc, int e, int N, float* frame47,
                                  float* priv73, const float* jpart = nullptr, float* cscal = nullptr, const float* reset_pose = nullptr,
                                  float* tscr = nullptr) {
-    static_assert(ROLE == ROLE_ALL || (kSplit && !kGeneric), "the three-wavefront form exists for the split XBot-L chain only");
+    static_assert(ROLE == ROLE_ALL || (kSplit && !kGeneric), "the chain by roles exists for the split XBot-L chain only");
     constexpr bool kMain = ROLE == ROLE_ALL || ROLE == ROLE_MAIN;      // state write-back, reset
     constexpr bool kFrames = ROLE == ROLE_ALL || ROLE == ROLE_FRAMES;  // the clean observation frames
     constexpr bool kFeet = ROLE == ROLE_ALL || ROLE == ROLE_REW_B;     // owner of last_contacts / feet_air_time / feet_height / last_feet_z
@@ -898,7 +898,7 @@ HG_HD StepFlags post_physics_env(const EnvArgs& A, const RngKey& rk, int64_t csc
             cmd_x_range<kGeneric>(A, x_lo, x_span);       // a command-curriculum move this step is applied by command_curriculum_fix
             resample_commands(c, x_lo, x_span, cmd, u, !kGeneric || c.heading_command);
         }
-        if (ROLE == ROLE_ALL) {        // (three-wavefront form: ROLE_REW_B zeroes the field it owns)
+        if (ROLE == ROLE_ALL) {        // (chain by roles: ROLE_REW_B zeroes the field it owns)
             FG(S.feet_air_time, 0) = 0.0f;
             FG(S.feet_air_time, 1) = 0.0f;
         }
@@ -1099,7 +1099,7 @@ HG_HD float* state_comp_row(const EnvArgs& A, int comp, int N) {
     return *state_field_ptr(S, f) + (int64_t)comp * N;
 }
 
-// snapshot rows of the three-wavefront chain: root state 0..12, commands 13..16, last root velocity 17..22, (23 unused), episode length
+// snapshot rows of the chain by roles: root state 0..12, commands 13..16, last root velocity 17..22, (23 unused), episode length
 // (int64[E]) from row 24
 constexpr int kSnapRoot = 0, kSnapCmd = 13, kSnapLrv = 17, kSnapEp = 24, kSnapComps = 26;
 // LDS carve (float offsets) for a block of E envs
@@ -1138,7 +1138,7 @@ HG_HD LdsMap lds_map(int E) {
     m.reset_pose = o; o += 8;              // euler angles [0..2] and projected gravity [3..5] of the reset orientation (split chain)
     m.jpart = o;      o += kJointTerms * 12 * E;   // [8][12][E] per-joint reward products (split per-env chain)
     m.cscal = o;      o += E;              // [E] gait-clock sine of the new observation (split per-env chain -> per-joint lanes)
-    m.terms = o;      o += HGYM_NUM_REWARDS * E;   // [22][E] reward terms times their scale (three-wavefront chain -> env_step_reward_sum)
+    m.terms = o;      o += HGYM_NUM_REWARDS * E;   // [22][E] reward terms times their scale (chain by roles -> env_step_reward_sum)
     o = (o + 1) & ~1;
     m.snap = o;       o += kSnapComps * E;   // the reward wavefronts' inputs that ROLE_MAIN rewrites during the phase (env_snapshot)
     m.total = o;
@@ -1526,7 +1526,7 @@ HG_HD void env_step_joint_terms(const EnvArgs& A, int block, int t, int nthreads
 // everything between the draws and the per-env chain: action filter + joint integration (fused backend), the per-joint reward
 // products, and -- on the last two wavefronts, next to the joint lanes -- the two halves of the synthetic physics' per-env
 // remainder (with a single wavefront, as in the host emulation, they simply follow)
-// kSnap: the three-wavefront chain follows -- the same two wavefronts leave the snapshot its reward roles read (each lane its own
+// kSnap: the chain by roles follows -- the same two wavefronts leave the snapshot its reward and frame roles read (each lane its own
 // env: the root lane after it has moved the root state)
 template <int E_T, bool kSnap = false>
 HG_HD void env_step_phase_j(const EnvArgs& A, int block, int t, int nthreads, float* smem) {
@@ -1685,7 +1685,7 @@ HG_HD void env_step_phase_a3(const EnvArgs& A, int block, int t, int nthreads, f
                                                    smem + m.jpart, smem + m.cscal, smem + m.reset_pose, nullptr);
 }
 
-// compute_reward's sum (legged_robot.py:217-235) and reset_idx's episode sums (:197-204) for the three-wavefront chain, one env per
+// compute_reward's sum (legged_robot.py:217-235) and reset_idx's episode sums (:197-204) for the chain by roles, one env per
 // lane of the LAST wavefront (env_step_phase_f, next to it, occupies the first ones): the same additions in the same order as
 // post_physics_env<.., ROLE_ALL>
 template <int E_T>

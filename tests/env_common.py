@@ -88,7 +88,7 @@ class HostBackend:
     def __init__(self, envs_per_block=8, nthreads=64, split=False):
         """split: the phase sequence of the XBot-L fast kernels (per-joint work on (env, joint) lanes around a shorter per-env
         chain: env_step_phase_j / _a<split> / _f) instead of the monolithic per-env chain; default options only.  2 / 3: that chain on
-        three wavefronts (env_step_phase_a3 + env_step_reward_sum, what the device runs by default), its roles emulated in ascending /
+        four wavefronts by role (env_step_phase_a3 + env_step_reward_sum, what the fused rollout launch runs), its roles emulated in ascending /
         descending lane order -- a role reading what another one writes during the phase would make the two differ."""
         sys.path.insert(0, os.path.join(ROOT, "tests", "hostcheck"))
         import build_hostcheck

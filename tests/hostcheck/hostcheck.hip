@@ -112,7 +112,7 @@ int hc_env_step_ex(const HgymEnvConfig* cfg, const HgymSimTensors* sim, const Hg
                              !cfg->heading_command;
         const bool sp = split && mode == MODE_STEP && !generic;       // as launch_step picks the instantiation
         if (sp && split >= 2) {
-            // the chain on three wavefronts (main / reward terms A / reward terms B): no role may read what another writes during the
+            // the chain on four wavefronts (state / reward terms A / reward terms B / frames): no role may read what another writes during the
             // phase, so the order the emulation runs them in must not matter -- split = 2: lanes ascending, split = 3: descending
             for (int t = 0; t < nthreads; ++t) env_step_phase_j<0, true>(A, b, t, nthreads, smem.data());
             if (split == 2)
