@@ -58,3 +58,15 @@ def test_defaults_are_the_single_gpu_headline(monkeypatch):
     assert (a.gpus, a.num_envs, a.precision, a.task) == (1, 4096, "bf16", "humanoid_ppo")
     assert a.steps >= 1 and a.warmup >= 0
     assert b.HBM_PEAK_GBS == 8000.0 and b.MFMA_BF16_PEAK_TFLOPS == 2500.0
+
+
+def test_measurement_scripts_compile():
+    """tools/*.py and the shell scripts that drive them only ever run on the GPU box: at least every Python file parses here, and every
+    script a shell driver names exists."""
+    import glob, py_compile, re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for f in glob.glob(os.path.join(root, "tools", "*.py")) + [os.path.join(root, "bench.py"), os.path.join(root, "__graft_entry__.py")]:
+        py_compile.compile(f, doraise=True)
+    for sh in glob.glob(os.path.join(root, "tools", "*.sh")):
+        for name in re.findall(r"tools/([A-Za-z0-9_]+\.(?:py|sh))", open(sh).read()):
+            assert os.path.exists(os.path.join(root, "tools", name)), "%s names tools/%s" % (os.path.basename(sh), name)
