@@ -1735,14 +1735,28 @@ HG_HD bool env_stage_out_fast(const EnvArgs& A, int block, int t, int nthreads, 
     if (E_T <= 0 || (E_T & 3) != 0) return false;
     constexpr int E = E_T > 0 ? E_T : 4, Q = E / 4;
     const int N = A.cfg.num_envs, e0 = block * E;
-    if (N - e0 < E || !A.state_contig || A.sim.root.env_stride != 1 || A.sim.dof_pos.env_stride != 1 || A.sim.dof_vel.env_stride != 1 ||
-        A.sim.contact.env_stride != 1 || A.sim.rigid.env_stride != 1)
-        return false;
+    // every field of the (1.7 KB) kernel argument this phase needs, read up front and the layout test without short-circuits: read where
+    // they are used they are a dozen scalar loads each waited for on its own, in a phase all wavefronts execute
+    const int64_t es0 = A.sim.root.env_stride, es1 = A.sim.dof_pos.env_stride, es2 = A.sim.dof_vel.env_stride, es3 = A.sim.contact.env_stride,
+                  es4 = A.sim.rigid.env_stride;
+    const int64_t cs0 = A.sim.root.comp_stride, cs1 = A.sim.dof_pos.comp_stride, cs2 = A.sim.dof_vel.comp_stride, cs3 = A.sim.contact.comp_stride,
+                  cs4 = A.sim.rigid.comp_stride;
+    float* const b0 = A.sim.root.base;
+    float* const b1 = A.sim.dof_pos.base;
+    float* const b2 = A.sim.dof_vel.base;
+    float* const b3 = A.sim.contact.base;
+    float* const b4 = A.sim.rigid.base;
+    float* const bs = A.st.commands;
+    const int contig = A.state_contig, mode = A.mode, fused = A.fused;
+    const int cc0 = A.contact_comp[0], cc1 = A.contact_comp[1], cc2 = A.contact_comp[2];
+    const int rc0 = A.rigid_comp[0], rc1 = A.rigid_comp[1], rc2 = A.rigid_comp[2], rc3 = A.rigid_comp[3];
+    const bool ok = (N - e0 >= E) & (contig != 0) & (es0 == 1) & (es1 == 1) & (es2 == 1) & (es3 == 1) & (es4 == 1);
+    if (!ok) return false;
     const LdsMap m = lds_map(E);
     auto put = [&](float* g, const float* l) { *reinterpret_cast<EnvF4*>(g) = *reinterpret_cast<const EnvF4*>(l); };
     for (int i = t; i < kMutableComps * Q; i += nthreads) {
         const int c = i / Q, qd = i - c * Q;
-        put(A.st.commands + (int64_t)c * N + e0 + 4 * qd, smem + m.state + c * E + 4 * qd);
+        put(bs + (int64_t)c * N + e0 + 4 * qd, smem + m.state + c * E + 4 * qd);
     }
     auto first = [&](int lane0) {        // first item of the lane in a tensor whose items start at lane `lane0`
         const int i = t - lane0;
@@ -1751,35 +1765,33 @@ HG_HD bool env_stage_out_fast(const EnvArgs& A, int block, int t, int nthreads, 
     int lane0 = 0;
     for (int i = first(lane0); i < 13 * Q; i += nthreads) {
         const int k = i / Q, qd = i - k * Q;
-        put(A.sim.root.base + (int64_t)k * A.sim.root.comp_stride + e0 + 4 * qd, smem + m.root + k * E + 4 * qd);
+        put(b0 + (int64_t)k * cs0 + e0 + 4 * qd, smem + m.root + k * E + 4 * qd);
     }
     lane0 = (lane0 + 13 * Q) % nthreads;
     for (int i = first(lane0); i < 12 * Q; i += nthreads) {
         const int k = i / Q, qd = i - k * Q;
-        put(A.sim.dof_pos.base + (int64_t)k * A.sim.dof_pos.comp_stride + e0 + 4 * qd, smem + m.dof_pos + k * E + 4 * qd);
+        put(b1 + (int64_t)k * cs1 + e0 + 4 * qd, smem + m.dof_pos + k * E + 4 * qd);
     }
     lane0 = (lane0 + 12 * Q) % nthreads;
     for (int i = first(lane0); i < 12 * Q; i += nthreads) {
         const int k = i / Q, qd = i - k * Q;
-        put(A.sim.dof_vel.base + (int64_t)k * A.sim.dof_vel.comp_stride + e0 + 4 * qd, smem + m.dof_vel + k * E + 4 * qd);
+        put(b2 + (int64_t)k * cs2 + e0 + 4 * qd, smem + m.dof_vel + k * E + 4 * qd);
     }
-    if (!(A.mode == MODE_STEP && A.fused)) return true;       // the synthetic physics wrote contacts / rigid bodies
+    if (!(mode == MODE_STEP && fused)) return true;       // the synthetic physics wrote contacts / rigid bodies
     lane0 = (lane0 + 12 * Q) % nthreads;
-    const int cc0 = A.contact_comp[0], cc1 = A.contact_comp[1], cc2 = A.contact_comp[2];
     for (int i = first(lane0); i < 9 * Q; i += nthreads) {
         const int k = i / Q, qd = i - k * Q;
         const int comp = (k < 3 ? cc0 : (k < 6 ? cc1 : cc2)) + k % 3;
-        put(A.sim.contact.base + (int64_t)comp * A.sim.contact.comp_stride + e0 + 4 * qd, smem + m.contact + k * E + 4 * qd);
+        put(b3 + (int64_t)comp * cs3 + e0 + 4 * qd, smem + m.contact + k * E + 4 * qd);
     }
     lane0 = (lane0 + 9 * Q) % nthreads;
-    const int rc0 = A.rigid_comp[0], rc1 = A.rigid_comp[1], rc2 = A.rigid_comp[2], rc3 = A.rigid_comp[3];
     for (int i = first(lane0); i < 14 * Q; i += nthreads) {      // feet {x, y, z, vx, vy}, knees {x, y}
         const int k = i / Q, qd = i - k * Q;
         const int body = k < 10 ? k / 5 : 2 + (k - 10) / 2;
         const int c5 = k % 5;
         const int comp = k < 10 ? (c5 < 3 ? c5 : c5 + 4) : (k - 10) % 2;
         const int base = body == 0 ? rc0 : (body == 1 ? rc1 : (body == 2 ? rc2 : rc3));
-        put(A.sim.rigid.base + (int64_t)(base + comp) * A.sim.rigid.comp_stride + e0 + 4 * qd, smem + m.rigid + (body * 13 + comp) * E + 4 * qd);
+        put(b4 + (int64_t)(base + comp) * cs4 + e0 + 4 * qd, smem + m.rigid + (body * 13 + comp) * E + 4 * qd);
     }
     return true;
 }

@@ -283,6 +283,9 @@ __global__ __launch_bounds__(RO_NT) void rollout_step_kernel(const FwdArgs f, co
 #if HGYM_RO_VARIANT == 1
     return;
 #endif
+    // (HGYM_RO_AHEAD_CRITIC) did the previous step reset this lane's env of the tile?  Loaded HERE, consumed behind phase B: read there it
+    // is a memory round trip at the very end of the workgroup
+    const bool prev_rs = RO_AHC && PRE && pp.prev_reset && (t & 63) < RO_E && pp.prev_reset[block * RO_E + (t & (RO_E - 1))] != 0;
     const EnvArgs& A = e;
     // the two older privileged frames (12 registers the policy tile could not spare): loaded here, stored behind the joints phase
     if (!PRE) hist_load<3, HGYM_PRIV_FRAME, RO_NIP>(A.st.priv_ring, block * RO_E, RO_E, (int)(ring_step % 3), t, RO_NT, hist_p);
@@ -364,8 +367,7 @@ __global__ __launch_bounds__(RO_NT) void rollout_step_kernel(const FwdArgs f, co
     if (RO_AHC && PRE && pp.prev_reset) {
         // this launch's next-observation rows were pre-written by the previous launch from the history as IT found it: an env the previous
         // step reset has zero older frames (13 of 15, 1 of 3) -- every wavefront reads the tile's 32 flags, loops over the set ones
-        const int lane = t & 63;
-        const unsigned long long mask = __ballot(lane < RO_E && pp.prev_reset[block * RO_E + (lane & (RO_E - 1))] != 0);
+        const unsigned long long mask = __ballot(prev_rs);
         for (unsigned long long mm = mask; mm; mm &= mm - 1) {
             const int le = __builtin_ctzll(mm);
             float* dobs = A.out.obs + (int64_t)(block * RO_E + le) * 15 * HGYM_OBS_FRAME;
