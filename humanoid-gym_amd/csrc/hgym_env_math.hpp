@@ -1292,13 +1292,15 @@ HG_HD bool env_stage_fast(const EnvArgs& A, int block, int nthreads) {
            A.sim.root.env_stride == 1 && A.sim.dof_pos.env_stride == 1 && A.sim.dof_vel.env_stride == 1 &&
            A.sim.contact.env_stride == 1 && A.sim.rigid.env_stride == 1;
 }
-template <int E_T>
+// kAssume (hgym_rollout_step, whose host side refuses every other layout: rollout_env_args): the fast layout is a fact of the launch, the general
+// paths of the staging phases -- never taken there -- are not compiled into it
+template <int E_T, bool kAssume = false>
 HG_HD void env_stage_in_load(const EnvArgs& A, int block, int t, int nthreads, StageRegs<E_T>& R) {
     const int E = E_T > 0 ? E_T : A.envs_per_block;
     const int N = A.cfg.num_envs, e0 = block * E;
     constexpr int EE = StageRegs<E_T>::EE, Q = StageRegs<E_T>::Q, NS = StageRegs<E_T>::NS;
-    R.fast = env_stage_fast<E_T>(A, block, nthreads) ? 1 : 0;
-    if (!R.fast) return;
+    R.fast = kAssume ? 1 : (env_stage_fast<E_T>(A, block, nthreads) ? 1 : 0);
+    if (!kAssume && !R.fast) return;
     auto cl = [](int i, int n) { return i < n ? i : n - 1; };
 #pragma unroll
     for (int u = 0; u < NS; ++u) {
@@ -1327,14 +1329,14 @@ HG_HD void env_stage_in_load(const EnvArgs& A, int block, int t, int nthreads, S
     stage_ld(R.r_act, A.actions_in ? A.actions_in + (int64_t)e0 * 12 + 4 * ia
                                                             : reinterpret_cast<const float*>(A.st.episode_length + e0) + 4 * ie);
 }
-template <int E_T>
+template <int E_T, bool kAssume = false>
 HG_HD void env_stage_in_store(const EnvArgs& A, int block, int t, int nthreads, float* smem, const StageRegs<E_T>& R) {
     const int E = E_T > 0 ? E_T : A.envs_per_block;
     const int N = A.cfg.num_envs, e0 = block * E;
-    const int nE = (E < N - e0) ? E : (N - e0);
+    const int nE = kAssume ? E : ((E < N - e0) ? E : (N - e0));
     const LdsMap m = lds_map(E);
     constexpr int EE = StageRegs<E_T>::EE, Q = StageRegs<E_T>::Q, NS = StageRegs<E_T>::NS;
-    if (R.fast) {
+    if (kAssume || R.fast) {
         auto cl = [](int i, int n) { return i < n ? i : n - 1; };
         const int i13 = cl(t, 13 * Q), i12 = cl(t, 12 * Q), i9 = cl(t, 9 * Q), i14 = cl(t, 14 * Q);
         const int k9 = i9 / Q, k14 = i14 / Q;
@@ -1372,11 +1374,11 @@ HG_HD void env_stage_in_store(const EnvArgs& A, int block, int t, int nthreads, 
     for (int i = t; i < kJointConsts; i += nthreads) smem[m.jcfg + i] = joint_consts(A.cfg)[i];
     if (t == 0) reinterpret_cast<int*>(smem + m.reset_cnt)[0] = 0;
 }
-template <int E_T>
+template <int E_T, bool kAssume = false>
 HG_HD void env_stage_in(const EnvArgs& A, int block, int t, int nthreads, float* smem) {
     StageRegs<E_T> R;
-    env_stage_in_load<E_T>(A, block, t, nthreads, R);
-    env_stage_in_store<E_T>(A, block, t, nthreads, smem, R);
+    env_stage_in_load<E_T, kAssume>(A, block, t, nthreads, R);
+    env_stage_in_store<E_T, kAssume>(A, block, t, nthreads, smem, R);
 }
 
 // Random draws not supplied by the caller, one Philox call per work item, into the LDS tables (row-major per env,
@@ -1730,7 +1732,7 @@ HG_HD void env_step_reward_sum(const EnvArgs& A, int block, int t, int nthreads,
 // form below reaches the same rows through component tables and per-field pointers, which the compiler turns into dependent loads
 // from memory in front of the stores; this phase is executed by every wavefront of the workgroup and is paced by instruction issue.
 // The five sim tensors take consecutive lane ranges, so that a wavefront runs the code of the one or two it has items of.
-template <int E_T>
+template <int E_T, bool kAssume = false>
 HG_HD bool env_stage_out_fast(const EnvArgs& A, int block, int t, int nthreads, float* smem) {
     if (E_T <= 0 || (E_T & 3) != 0) return false;
     constexpr int E = E_T > 0 ? E_T : 4, Q = E / 4;
@@ -1751,7 +1753,7 @@ HG_HD bool env_stage_out_fast(const EnvArgs& A, int block, int t, int nthreads, 
     const int cc0 = A.contact_comp[0], cc1 = A.contact_comp[1], cc2 = A.contact_comp[2];
     const int rc0 = A.rigid_comp[0], rc1 = A.rigid_comp[1], rc2 = A.rigid_comp[2], rc3 = A.rigid_comp[3];
     const bool ok = (N - e0 >= E) & (contig != 0) & (es0 == 1) & (es1 == 1) & (es2 == 1) & (es3 == 1) & (es4 == 1);
-    if (!ok) return false;
+    if (!kAssume && !ok) return false;
     const LdsMap m = lds_map(E);
     auto put = [&](float* g, const float* l) { *reinterpret_cast<EnvF4*>(g) = *reinterpret_cast<const EnvF4*>(l); };
     for (int i = t; i < kMutableComps * Q; i += nthreads) {
@@ -1796,16 +1798,18 @@ HG_HD bool env_stage_out_fast(const EnvArgs& A, int block, int t, int nthreads, 
     return true;
 }
 
-template <int E_T>
+template <int E_T, bool kAssume = false>
 HG_HD void env_stage_out(const EnvArgs& A, int block, int t, int nthreads, float* smem) {
     const int E = E_T > 0 ? E_T : A.envs_per_block;
     const int N = A.cfg.num_envs, e0 = block * E;
-    const int nE = (E < N - e0) ? E : (N - e0);
+    const int nE = kAssume ? E : ((E < N - e0) ? E : (N - e0));
     const LdsMap m = lds_map(E);
 #ifndef HGYM_STAGE_OUT_FAST
 #define HGYM_STAGE_OUT_FAST 1
 #endif
-    if (!(HGYM_STAGE_OUT_FAST && env_stage_out_fast<E_T>(A, block, t, nthreads, smem))) {
+    if (kAssume) {
+        env_stage_out_fast<E_T, true>(A, block, t, nthreads, smem);
+    } else if (!(HGYM_STAGE_OUT_FAST && env_stage_out_fast<E_T>(A, block, t, nthreads, smem))) {
         copy_comp_rows<false>(nullptr, A, 0, kMutableComps, smem + m.state, E, e0, nE, N, t, nthreads);
         stage_sim<false>(A, m, smem, E, e0, nE, t, nthreads, A.mode == MODE_STEP && A.fused);   // the synthetic physics wrote contacts / rigid bodies
     }

@@ -119,6 +119,10 @@ __device__ __forceinline__ void ro_lds_barrier() {
     __syncthreads();
 #endif
 }
+#ifndef HGYM_RO_ASSUME_FAST
+#define HGYM_RO_ASSUME_FAST 0   // 1: the staging phases' general paths (never taken in this launch: rollout_env_args refuses every layout but the fast
+#endif                          //    one) are compiled out of it -- prepared at the end of round 4, not yet run on a GPU
+constexpr bool RO_AF = HGYM_RO_ASSUME_FAST != 0;
 #ifndef HGYM_RO_AHEAD_CRITIC
 #define HGYM_RO_AHEAD_CRITIC 1
 #endif
@@ -211,7 +215,7 @@ __global__ __launch_bounds__(RO_NT) void rollout_step_kernel(const FwdArgs f, co
 #if HGYM_RO_VARIANT == 3
         env_fill_draws<RO_E>(E, block, t, RO_NT, esm, csc0);
 #elif HGYM_RO_VARIANT == 4
-        if (t < 256) env_stage_in<RO_E>(E, block, t, 256, esm);
+        if (t < 256) env_stage_in<RO_E, RO_AF>(E, block, t, 256, esm);
 #endif
 #if HGYM_RO_VARIANT == 0
         env_reset_pose<RO_E>(E, t, RO_NT, esm);                       // one lane, under the tile's first loads
@@ -227,7 +231,7 @@ __global__ __launch_bounds__(RO_NT) void rollout_step_kernel(const FwdArgs f, co
             const int i = t + u * RO_NT;
             stage_ld(dq[u], dsrc + 4 * (i < dmax ? i : dmax));
         }
-        if (t < 256) env_stage_in<RO_E>(E, block, t, 256, esm);      // travels with the tile's own first loads
+        if (t < 256) env_stage_in<RO_E, RO_AF>(E, block, t, 256, esm);      // travels with the tile's own first loads
         if (draws_in) {
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
@@ -239,9 +243,9 @@ __global__ __launch_bounds__(RO_NT) void rollout_step_kernel(const FwdArgs f, co
         // issue the state / sim loads, compute the draws under them, then write the loaded quads to the env image
         StageRegs<RO_E> R;
         R.fast = 0;
-        if (t < 256) env_stage_in_load<RO_E>(E, block, t, 256, R);
+        if (t < 256) env_stage_in_load<RO_E, RO_AF>(E, block, t, 256, R);
         env_fill_draws<RO_E>(E, block, t, RO_NT, esm, csc0);
-        if (t < 256) env_stage_in_store<RO_E>(E, block, t, 256, esm, R);
+        if (t < 256) env_stage_in_store<RO_E, RO_AF>(E, block, t, 256, esm, R);
 #endif
 #endif
     };
@@ -359,7 +363,7 @@ __global__ __launch_bounds__(RO_NT) void rollout_step_kernel(const FwdArgs f, co
     __syncthreads();
 #endif
     stamp(3);
-    env_stage_out<RO_E>(A, block, t, RO_NT, esm);
+    env_stage_out<RO_E, RO_AF>(A, block, t, RO_NT, esm);
 #if !HGYM_W3_PROBE
     stamp(4);
 #endif
