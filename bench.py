@@ -369,7 +369,7 @@ def run_config(args, task, num_envs, rank, world, local, dist, steps, warmup, lo
             nmb = runner.alg.num_learning_epochs * runner.alg.num_mini_batches
             # what 0.9 weak-scaling efficiency leaves for the exchange: T_N <= T_1 / 0.9 with T_1 ~ this run's iteration minus its exposed waits
             p2p_on = bool(getattr(runner.alg, "_comm_p2p", False))
-            names = {"p2p": "direct reduce-scatter + all-gather kernel over hipIpc peer mappings of the ranks' gradient buffers (HGYM_COMM=p2p)",
+            names = {"p2p": "direct reduce-scatter + all-gather kernel over hipIpc peer mappings of the ranks' gradient buffers (HGYM_COMM=auto picked it / p2p)",
                      "collective": ("RCCL all-reduce (torch.distributed 'nccl')" if dist.get_backend() == "nccl" else
                                     "%s all-reduce (ranks may share a GPU; host-staged, not representative of RCCL over xGMI)" % dist.get_backend())}
             per = {}
@@ -381,8 +381,10 @@ def run_config(args, task, num_envs, rank, world, local, dist, steps, warmup, lo
             exposed_used = per[used]["exposed_us_per_minibatch"] if used in per else 0.0
             t1_ms = max(res["ms_per_step"] - exposed_used * nmb * 1e-3, 1e-6)
             budget = t1_ms * (1.0 / 0.9 - 1.0) / nmb * 1e3
+            rep = getattr(runner.alg, "comm_report", {}) or {}
             comm = dict(collective="SUM of [flat fp32 gradient | minibatch KL], one exchange per minibatch, fully exposed by construction",
-                        used_in_timed_run=used, bytes_per_minibatch=4 * (runner.alg.net.P + 1), minibatches_per_iter=nmb,
+                        mode=rep.get("mode"), used_in_timed_run=used, fallback_reason=rep.get("fallback_reason"), startup_probe=rep.get("probe"),
+                        host_placement=getattr(args, "host_placement", None), bytes_per_minibatch=4 * (runner.alg.net.P + 1), minibatches_per_iter=nmb,
                         exposed_us_per_minibatch=exposed_used, exposed_us_max=per[used]["exposed_us_max"] if used in per else 0.0,
                         exposed_ms_per_iter=exposed_used * nmb * 1e-3, backend=names[used],
                         budget_us_per_minibatch_for_0p9_weak_scaling=budget, within_budget=bool(exposed_used <= budget),
@@ -418,6 +420,26 @@ def _roofline_obj(ks, pick=None):
                 mfma_busy=dom.get("mfma_busy"), l2_hit=dom.get("l2_hit"),
                 kernel=dom["kernel"], launches_per_iter=dom["launches_per_iter"],
                 avg_launch_us=dom["avg_launch_us"], share_of_iteration=dom["share_of_iteration"], kernels=rest)
+
+
+def place_rank_on_host(local, world):
+    """N > 1: eight Python launch threads on one host are the rank-skew source SURVEY 8(e) warns about.  Each rank gets its own block
+    of the cores this process may run on (no migration across ranks' blocks, no two launch threads on one core) and one intra-op
+    thread (the hot path is on the GPU; torch's CPU pool only adds wake-ups).  HGYM_PIN=0 leaves the affinity alone."""
+    torch.set_num_threads(1)
+    if os.environ.get("HGYM_PIN", "1") == "0" or not hasattr(os, "sched_setaffinity"):
+        return dict(threads=1, pinned=False)
+    try:
+        cores = sorted(os.sched_getaffinity(0))
+        per = len(cores) // max(world, 1)
+        if per < 2:
+            return dict(threads=1, pinned=False, note="fewer than 2 cores per rank")
+        per = min(per, 16)
+        mine = cores[local * per:(local + 1) * per]
+        os.sched_setaffinity(0, mine)
+        return dict(threads=1, pinned=True, cores=[mine[0], mine[-1]], cores_per_rank=per)
+    except OSError as e:
+        return dict(threads=1, pinned=False, note=str(e))
 
 
 def spawn_ranks(args):
@@ -456,6 +478,7 @@ def main():
         else:
             dist.init_process_group(backend)
     assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
+    args.host_placement = place_rank_on_host(local, world) if world > 1 else None
     os.environ["HGYM_PRECISION"] = args.precision
     from humanoid.algo import PPO
     PPO.precision = args.precision
@@ -537,6 +560,28 @@ def main():
             out["configs"] = extra
         if not args.no_cpu_baseline and world == 1:      # the CPU baseline leg belongs to the N=1 run only
             out["cpu_baseline"] = cpu_baseline(N, T)
+        # The line ENDS with a compact block (< 1.5 KB): a reader that keeps only the tail of the line (the driver's record keeps 2 000
+        # bytes) still has the headline's split, the three big kernels and the baselines.  Everything in it repeats a field above.
+        summ = dict(value=head["value"], n_gpus=world, ms_per_step=head["ms_per_step"], collection_ms=head["collection_ms"],
+                    ppo_update_ms=head["ppo_update_ms"])
+        if head.get("kernels"):
+            big = {}
+            for k in head["kernels"]:
+                if k["kernel"] in ("mlp_fb_kernel", "dw_kernel", "rollout_step_kernel", "env_step_kernel", "mlp_fwd_kernel<32>"):
+                    big[k["kernel"]] = dict(us=round(k["avg_launch_us"], 2), n=k["launches_per_iter"], frac=round(k["frac"], 4), bound=k["bound"],
+                                            traffic_MB=None if not k.get("traffic") else round(k["traffic"] / 1e6, 1),
+                                            share=round(k["share_of_iteration"], 3))
+            summ["kernels"] = big
+        if out.get("cpu_baseline"):
+            summ["cpu_baseline"] = dict(value=out["cpu_baseline"]["value"], cores=out["cpu_baseline"]["cores"], kind=out["cpu_baseline"]["kind"])
+        if extra:
+            summ["configs"] = {e["name"]: dict(value=round(e["value"]), collection_ms=round(e["collection_ms"], 3),
+                                               ppo_update_ms=round(e["ppo_update_ms"], 3)) for e in extra}
+        if head.get("comm"):
+            c = head["comm"]
+            summ["comm"] = dict(used=c.get("used_in_timed_run"), fallback_reason=c.get("fallback_reason"),
+                                exposed_us_per_minibatch=c.get("exposed_us_per_minibatch"), within_budget=c.get("within_budget"))
+        out["summary"] = summ
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

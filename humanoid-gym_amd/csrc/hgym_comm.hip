@@ -1,5 +1,7 @@
-// hgym_comm.hip -- the data-parallel update's gradient exchange as ONE direct kernel over peer mappings (opt-in: HGYM_COMM=p2p;
-// the default stays torch.distributed's all-reduce = RCCL, as north_star names it).
+// hgym_comm.hip -- the data-parallel update's gradient exchange as ONE direct kernel over peer mappings.  Round 5: HGYM_COMM=auto (the
+// default for 2..8 ranks on one host) builds the mappings, checks and times this kernel against torch.distributed's all-reduce (= RCCL)
+// once at start-up and uses the faster one; any set-up failure, wrong sum or expired wait falls back to the collective on every rank
+// (humanoid/algo/ppo/dist_utils.py).
 //
 // Why.  The exchange is fully exposed by construction (the norm clip and the KL-adaptive learning rate need
 // the whole averaged gradient before Adam can start, and the next minibatch's forward needs Adam's result), so at 6 ms per
@@ -19,8 +21,11 @@
 //   B  every workgroup release-fences and bumps a local counter; the last one stores seq into slot B[r] of every rank's flag block.
 //      Workgroup 0 waits for B[q] >= seq for all q before it exits: when my kernel completes, every shard of my buffer holds its
 //      final sum and no peer still reads my gradient -- the next kernel on the stream (hgym_ppo_apply) may read and overwrite it.
-// Every wait is BOUNDED (15 s of wall clock): on expiry the kernel writes status[0] = 1 and returns instead of hanging the device; the host
-// checks the status word where it synchronises anyway (hgym_comm_status).
+// Every wait is BOUNDED (HgymComm.wait_ticks of the 100 MHz wall clock; 0 = 15 s): on expiry the kernel writes status[0] = 1 (sticky) and
+// status[1] = seq, skips the sum and STILL runs phase B's book-keeping -- the local done counter counts one call and is reset by the call's
+// last workgroup, so a communicator that has seen a time-out stays usable (the payload of that call is garbage; the caller decides:
+// dist_utils falls back to the collective during its start-up probe and raises CommTimeout in training).  The host reads the status
+// word where it synchronises anyway (hgym_comm_status).
 //
 // Timestamps (100 MHz wall clock) of the last call are left in status[8 ..]: kernel start, phase A complete, phase B complete --
 // "A - start" is how long this rank waited for the slowest rank (the skew), "B - A" the exchange itself.
@@ -40,13 +45,14 @@ struct CommArgs {
     int64_t count;                               // floats (a multiple of 4)
     int64_t shard;                               // floats per shard (a multiple of 4)
     uint32_t seq;
+    long long wait_ticks;                        // bound of every wait, 100 MHz ticks
 };
 
 __device__ __forceinline__ uint32_t ld_sys(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 __device__ __forceinline__ void st_sys(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 
 // lanes 0 .. world - 1 of the calling wave each watch one slot; returns false on time-out (wave-uniform result)
-__device__ __forceinline__ bool wait_slots(const uint32_t* slots, int world, uint32_t seq, int lane) {
+__device__ __forceinline__ bool wait_slots(const uint32_t* slots, int world, uint32_t seq, int lane, long long ticks) {
     bool ok = true;
     if (lane < world) {
         uint32_t spins = 0;
@@ -57,7 +63,7 @@ __device__ __forceinline__ bool wait_slots(const uint32_t* slots, int world, uin
             // GPU, a host hiccup) should not be polled at full rate
             if (++spins < 1024u) __builtin_amdgcn_s_sleep(8);
             else __builtin_amdgcn_s_sleep(127);
-            if ((spins & 255u) == 0u && (long long)__builtin_amdgcn_s_memrealtime() - t0 > COMM_WAIT_TICKS) { ok = false; break; }
+            if ((spins & 255u) == 0u && (long long)__builtin_amdgcn_s_memrealtime() - t0 > ticks) { ok = false; break; }
         }
     }
     return __all(ok);
@@ -71,41 +77,47 @@ __global__ __launch_bounds__(COMM_THREADS) void p2p_allreduce_kernel(const CommA
     // ---- A: my gradient is complete (written by the previous kernel on this stream); tell everyone, wait for everyone
     if (blockIdx.x == 0 && t < c.world) st_sys(c.flags[t] + c.rank, c.seq);
     if (t < 64) {
-        const bool ok = wait_slots(myf, c.world, c.seq, lane);
+        const bool ok = wait_slots(myf, c.world, c.seq, lane, c.wait_ticks);
         if (t == 0) s_ok = ok ? 1 : 0;
     }
     __syncthreads();
-    if (!s_ok) {
-        if (t == 0) c.status[0] = 1;
-        return;
+    const bool arrived = s_ok != 0;            // (workgroup-uniform)
+    if (!arrived && t == 0) {
+        c.status[0] = 1;
+        c.status[1] = (long long)c.seq;
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
-    if (blockIdx.x == 0 && t == 0) c.status[9] = (long long)__builtin_amdgcn_s_memrealtime();
-    // ---- RS + AG: my shard, summed in rank order, written to every buffer
-    const int64_t lo = (int64_t)c.rank * c.shard;
-    int64_t hi = lo + c.shard;
-    hi = hi < c.count ? hi : c.count;
-    typedef __attribute__((ext_vector_type(4))) float f4;
-    for (int64_t i = lo + ((int64_t)blockIdx.x * COMM_THREADS + t) * 4; i < hi; i += (int64_t)gridDim.x * COMM_THREADS * 4) {
-        f4 v[HGYM_COMM_MAX_RANKS];
+    if (arrived) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+        if (blockIdx.x == 0 && t == 0) c.status[9] = (long long)__builtin_amdgcn_s_memrealtime();
+        // ---- RS + AG: my shard, summed in rank order, written to every buffer
+        const int64_t lo = (int64_t)c.rank * c.shard;
+        int64_t hi = lo + c.shard;
+        hi = hi < c.count ? hi : c.count;
+        typedef __attribute__((ext_vector_type(4))) float f4;
+        for (int64_t i = lo + ((int64_t)blockIdx.x * COMM_THREADS + t) * 4; i < hi; i += (int64_t)gridDim.x * COMM_THREADS * 4) {
+            f4 v[HGYM_COMM_MAX_RANKS];
 #pragma unroll
-        for (int q = 0; q < HGYM_COMM_MAX_RANKS; ++q)
-            if (q < c.world) v[q] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(c.data[q] + i));
-        f4 s = v[0];
+            for (int q = 0; q < HGYM_COMM_MAX_RANKS; ++q)
+                if (q < c.world) v[q] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(c.data[q] + i));
+            f4 s = v[0];
 #pragma unroll
-        for (int q = 1; q < HGYM_COMM_MAX_RANKS; ++q)
-            if (q < c.world) s += v[q];
+            for (int q = 1; q < HGYM_COMM_MAX_RANKS; ++q)
+                if (q < c.world) s += v[q];
 #pragma unroll
-        for (int q = 0; q < HGYM_COMM_MAX_RANKS; ++q)
-            if (q < c.world) __builtin_nontemporal_store(s, reinterpret_cast<f4*>(c.data[q] + i));
+            for (int q = 0; q < HGYM_COMM_MAX_RANKS; ++q)
+                if (q < c.world) __builtin_nontemporal_store(s, reinterpret_cast<f4*>(c.data[q] + i));
+        }
     }
-    // ---- B: all my stores are out (release, system scope) -> the last workgroup tells everyone; workgroup 0 waits for everyone
+    // ---- B: all my stores are out (release, system scope) -> the last workgroup tells everyone; workgroup 0 waits for everyone.
+    // A workgroup whose phase-A wait expired takes part too (it has nothing to release): the done counter counts THIS call's workgroups
+    // and the last one resets it, so the next call elects its last workgroup whatever happened in this one.
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
     __syncthreads();
     __shared__ int s_last;
     if (t == 0) {
         const uint32_t done = __hip_atomic_fetch_add(myf + 16, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = (done == (uint32_t)c.seq * gridDim.x - 1u) ? 1 : 0;        // the counter is never reset: call seq ends at seq * blocks
+        s_last = (done == gridDim.x - 1u) ? 1 : 0;
+        if (s_last) __hip_atomic_store(myf + 16, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // every workgroup of this call has counted
     }
     __syncthreads();
     if (s_last) {
@@ -114,9 +126,13 @@ __global__ __launch_bounds__(COMM_THREADS) void p2p_allreduce_kernel(const CommA
     }
     if (blockIdx.x == 0) {
         if (t < 64) {
-            const bool ok = wait_slots(myf + 8, c.world, c.seq, lane);
+            // (after an expired phase-A wait the peers' completion flags cannot be expected either: no second bounded wait)
+            const bool ok = arrived ? wait_slots(myf + 8, c.world, c.seq, lane, c.wait_ticks) : false;
             if (t == 0) {
-                if (!ok) c.status[0] = 1;
+                if (!ok) {
+                    c.status[0] = 1;
+                    c.status[1] = (long long)c.seq;
+                }
                 c.status[10] = (long long)__builtin_amdgcn_s_memrealtime();
             }
         }
@@ -200,10 +216,26 @@ int32_t hgym_comm_allreduce(const HgymComm* c, uint32_t seq, void* stream) {
     a.count = c->count;
     a.shard = round_up(ceil_div(c->count, c->world), 4);
     a.seq = seq;
+    a.wait_ticks = c->wait_ticks > 0 ? (long long)c->wait_ticks : COMM_WAIT_TICKS;
     prof_begin(HGYM_PROF_COMM, (hipStream_t)stream);
     hipLaunchKernelGGL(p2p_allreduce_kernel, dim3(COMM_BLOCKS), dim3(COMM_THREADS), 0, (hipStream_t)stream, a);
     prof_end(HGYM_PROF_COMM, (hipStream_t)stream, (double)c->count * 4.0 * 2.0 * (c->world - 1) / c->world);
     HG_CHECK_LAUNCH("p2p_allreduce_kernel");
+    return HGYM_OK;
+}
+
+int32_t hgym_comm_status(const HgymComm* c, int64_t* host16, void* stream) {
+    HG_REQUIRE(c && c->status && host16, HGYM_E_BADARG, "null pointer");
+    // waits for `stream` (the caller synchronises here anyway: the end of an update, a log read-back) and hands back the 16 status words:
+    // [0] != 0: a bounded wait of some call expired (sticky), [1] the call number it was, [8 .. 10] the last call's timestamps
+    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) {
+        (void)hipGetLastError();
+        HG_FAIL(HGYM_E_LAUNCH, "hipStreamSynchronize failed");
+    }
+    if (hipMemcpy(host16, c->status, 16 * sizeof(int64_t), hipMemcpyDeviceToHost) != hipSuccess) {
+        (void)hipGetLastError();
+        HG_FAIL(HGYM_E_LAUNCH, "hipMemcpy of the status block failed");
+    }
     return HGYM_OK;
 }
 

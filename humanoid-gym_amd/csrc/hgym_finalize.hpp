@@ -224,6 +224,9 @@ __device__ __forceinline__ void fin_block(const FinArgs& F, int t, int nthreads)
         fin_store(F, t, nthreads);
     }
     fin_log(F, t, nthreads);
+    // every lane of the workgroup has loaded reset_count[0] (fin_fused's / fin_part1's first load) before thread 0 zeroes it: without
+    // this barrier a late wavefront of a 512 / 1024-lane workgroup could read 0 and keep the stale time-out bytes
+    __syncthreads();
     if (t == 0) {
         if (HGYM_FIN_FUSED) {       // = fin_part2
             if (bump_step) F.out.t_step[0] = ts + 1;

@@ -123,7 +123,7 @@ class Net(C.Structure):
 
 class Comm(C.Structure):
     _fields_ = [("world", C.c_int32), ("rank", C.c_int32), ("data", c_float_p * 8), ("flags", C.POINTER(C.c_uint32) * 8),
-                ("count", C.c_int64), ("status", c_i64_p)]
+                ("count", C.c_int64), ("status", c_i64_p), ("wait_ticks", C.c_int64)]
 
 
 class Batch(C.Structure):
@@ -140,7 +140,7 @@ class ObsShadow(C.Structure):
 
 STRUCTS = dict(HgymEnvConfig=EnvConfig, HgymStrided=Strided, HgymSimTensors=SimTensors, HgymEnvState=EnvState,
                HgymEnvOut=EnvOut, HgymEnvNoise=EnvNoise, HgymNetConfig=NetConfig, HgymPPOConfig=PPOConfig,
-               HgymNet=Net, HgymBatch=Batch, HgymObsShadow=ObsShadow)
+               HgymNet=Net, HgymBatch=Batch, HgymObsShadow=ObsShadow, HgymComm=Comm)
 
 # every symbol include/hgym.h declares: name -> (restype, argtypes)
 _P = C.POINTER
@@ -151,6 +151,7 @@ SYMBOLS = {
     "hgym_comm_ipc_open": (C.c_int32, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "hgym_comm_ipc_close": (C.c_int32, [C.c_void_p]),
     "hgym_comm_allreduce": (C.c_int32, [_P(Comm), C.c_uint32, C.c_void_p]),
+    "hgym_comm_status": (C.c_int32, [_P(Comm), c_i64_p, C.c_void_p]),
     "hgym_version": (C.c_int32, []),
     "hgym_last_error": (C.c_char_p, []),
     "hgym_device_cus": (C.c_int32, []),

@@ -5,9 +5,20 @@
     overlap by splitting the weight-gradient launch, which cost more than the exchange (ppo.py, update);
   * per iteration: one all-reduce of (sum adv, sum adv^2, count) so advantages are normalised over the global batch.
 Backend: torch.distributed "nccl" (= RCCL over xGMI) on the GPUs; the same functions run over "gloo" in the CPU tests.
-HGYM_COMM=p2p (opt-in) replaces the per-minibatch all-reduce by ONE direct kernel over peer mappings of the ranks' gradient buffers
-(P2PComm below, csrc/hgym_comm.hip): a reduce-scatter + all-gather over the fully connected xGMI mesh instead of a ring."""
+
+The per-minibatch exchange has two implementations: the collective above, and ONE direct kernel over peer mappings of the ranks'
+gradient buffers (P2PComm below, csrc/hgym_comm.hip: reduce-scatter + all-gather over the fully connected xGMI mesh instead of a
+ring).  HGYM_COMM selects:
+  auto (default)  2..8 ranks on one host: build the peer mappings, CHECK the direct kernel's sum on a known pattern, TIME both
+                  exchanges (PROBE_CALLS calls each, every wait of the probe bounded by PROBE_WAIT_S), agree on the decision over all
+                  ranks and use the faster one.  Any failure on any rank -- allocation, IPC export / open, a wrong sum, an expired
+                  wait -- makes EVERY rank fall back to the collective; `comm_report()` says what was used and why.
+  p2p             the direct kernel, unconditionally (a set-up failure raises)
+  rccl            the collective, nothing else is allocated
+  both            the collective in training, but the peer-mapped buffer exists (bench.py times the other exchange as well)
+HGYM_COMM_FAIL_INJECT=alloc|map|timeout|sum[:rank] makes that step fail on one rank (default: the last) -- how the fallback is tested."""
 import os
+import socket
 
 import torch
 import torch.distributed as dist
@@ -61,30 +72,136 @@ def broadcast_parameters(params):
             dist.broadcast(p.data, src=0)
 
 
+PROBE_CALLS = 20
+PROBE_WAIT_S = 2.0
+_REPORT = {}
+
+
+def comm_mode():
+    m = os.environ.get("HGYM_COMM", "auto").lower()
+    return m if m in ("auto", "p2p", "rccl", "both") else "auto"
+
+
+def comm_report():
+    """What make_comm decided: mode, used ("p2p" / "collective"), fallback_reason (None when the direct exchange is in use or was
+    never asked for), probe (per-backend microseconds per call, max over ranks) -- bench.py prints it under "comm"."""
+    return dict(_REPORT)
+
+
 def comm_backend():
-    """"p2p": the direct exchange (HGYM_COMM=p2p, at most 8 ranks); "rccl": torch.distributed's all-reduce (default)."""
-    return "p2p" if (active() and os.environ.get("HGYM_COMM", "rccl").lower() == "p2p" and world_size() <= 8) else "rccl"
+    """"p2p": the update's per-minibatch exchange is the direct kernel; "rccl": torch.distributed's all-reduce."""
+    return "p2p" if _REPORT.get("used") == "p2p" else "rccl"
+
+
+def _inject(step):
+    spec = os.environ.get("HGYM_COMM_FAIL_INJECT", "")
+    if not spec:
+        return False
+    what, _, r = spec.partition(":")
+    rank = int(r) if r else world_size() - 1
+    return what == step and dist.get_rank() == rank
+
+
+def _agree(ok, note=None):
+    """Every rank contributes (ok, note); returns (all ok, first failure note).  An object gather: it also carries the reason."""
+    got = [None] * world_size()
+    dist.all_gather_object(got, (bool(ok), None if note is None else str(note)))
+    bad = [(q, n) for q, (o, n) in enumerate(got) if not o]
+    return (not bad), (None if not bad else "rank %d: %s" % bad[0])
 
 
 def make_comm(count, device):
-    """The peer-mapped gradient buffer of the data-parallel update, or None.  Built only on request (HGYM_COMM=p2p, or HGYM_COMM=both:
-    the exchange stays with the collective but the buffers exist, so that `bench.py --gpus N` can time the direct kernel as well in its
-    profiling iterations) -- the default data-parallel path allocates nothing new.  If any rank cannot allocate / export / map (no IPC
-    on this driver, ranks on different hosts), EVERY rank falls back to a plain tensor (HGYM_COMM=p2p: raises instead)."""
-    if not active() or world_size() > 8 or os.environ.get("HGYM_COMM", "rccl").lower() not in ("p2p", "both"):
+    """The peer-mapped gradient buffer of the data-parallel update when the direct exchange is going to be used (or, HGYM_COMM=both,
+    timed), else None -- the caller then keeps its gradient in a plain tensor and exchanges it with the collective.  Every rank takes
+    the same decision: each step that can fail locally is followed by an agreement over all ranks BEFORE the next collective call, so
+    a failure on some ranks never leaves the others inside a different collective."""
+    mode = comm_mode()
+    _REPORT.clear()
+    _REPORT.update(mode=mode, used="collective", fallback_reason=None, probe=None)
+    if not active():
         return None
+    W = world_size()
+    if mode == "rccl":
+        return None
+
+    def give_up(reason, comm=None, torn=True):
+        if torn:
+            _teardown(comm)         # EVERY rank runs the same barriers, whether or not its own set-up got anywhere
+        if mode == "p2p":
+            raise RuntimeError("HGYM_COMM=p2p: the direct gradient exchange could not be set up on every rank (%s)" % reason)
+        _REPORT["fallback_reason"] = reason
+        return None
+
+    if W > HGYM_COMM_MAX_RANKS:
+        return give_up("%d ranks (the direct exchange serves at most %d)" % (W, HGYM_COMM_MAX_RANKS), torn=False)
+    hosts = [None] * W
+    dist.all_gather_object(hosts, socket.gethostname())
+    if len(set(hosts)) > 1:
+        return give_up("ranks on %d hosts (peer mappings are intra-node)" % len(set(hosts)), torn=False)
+    # ---- 1: local allocation + export
     comm, err = None, None
     try:
+        if _inject("alloc"):
+            raise RuntimeError("injected allocation failure (HGYM_COMM_FAIL_INJECT)")
         comm = P2PComm(count, device)
     except Exception as e:          # noqa: BLE001 -- whatever went wrong, the collective path still works
         err = e
-    ok = torch.tensor([0.0 if comm is None else 1.0], device=device)
-    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-    if float(ok) < 1.0:
-        if comm_backend() == "p2p":
-            raise RuntimeError("HGYM_COMM=p2p: the peer-mapped gradient buffers could not be set up on every rank (%r)" % (err,))
-        return None
+    ok, why = _agree(comm is not None, err)
+    if not ok:
+        return give_up("allocation / IPC export failed (%s)" % why, comm)
+    # ---- 2: exchange the handles, map the peers
+    handles = [None] * W
+    dist.all_gather_object(handles, comm.handle())
+    try:
+        if _inject("map"):
+            raise RuntimeError("injected mapping failure (HGYM_COMM_FAIL_INJECT)")
+        comm.connect(handles)
+    except Exception as e:          # noqa: BLE001
+        err = e
+    ok, why = _agree(comm.connected, err)
+    if not ok:
+        return give_up("hipIpcOpenMemHandle failed (%s)" % why, comm)
+    if mode == "both":
+        return comm
+    # ---- 3: first contact: a known pattern through the direct kernel ...
+    try:
+        ok_local, note = comm.probe_verify(device)
+    except Exception as e:          # noqa: BLE001
+        ok_local, note = False, "raised %r" % (e,)
+    ok, why = _agree(ok_local, note)
+    if not ok:
+        return give_up("first direct exchange failed (%s)" % why, comm)
+    # ---- 4: ... then both exchanges timed (the same calls on every rank: nothing in here returns early)
+    try:
+        probe = comm.probe_time(device)
+    except Exception as e:          # noqa: BLE001
+        probe = dict(error="raised %r" % (e,))
+    got = [None] * W
+    dist.all_gather_object(got, probe)
+    bad = [(q, g["error"]) for q, g in enumerate(got) if g.get("error")]
+    if bad:
+        return give_up("timing the direct exchange failed (rank %d: %s)" % bad[0], comm)
+    p2p_us = max(g["p2p_us"] for g in got)
+    coll_us = max(g["collective_us"] for g in got)
+    _REPORT["probe"] = dict(p2p_us_per_call=p2p_us, collective_us_per_call=coll_us, calls=PROBE_CALLS,
+                            note="isolated exchanges of the real payload at start-up, max over ranks of each rank's mean (HIP events)")
+    if mode == "auto" and not (p2p_us < coll_us):
+        return give_up("the collective was faster in the start-up probe (%.1f vs %.1f us per call)" % (coll_us, p2p_us), comm)
+    _REPORT["used"] = "p2p"
     return comm
+
+
+def _teardown(comm):
+    """Collective: every rank calls it, with its own P2PComm or None.  Nobody unmaps a buffer a peer's kernel may still touch, nobody
+    frees a buffer a peer still has mapped."""
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    dist.barrier()
+    if comm is not None:
+        comm._unmap()
+    dist.barrier()
+    if comm is not None:
+        comm._free()
 
 
 class CommTimeout(RuntimeError):
@@ -98,11 +215,15 @@ class _DevMem:
         self.__cuda_array_interface__ = dict(shape=(int(n),), typestr=typestr, data=(int(ptr), False), version=3)
 
 
+HGYM_COMM_MAX_RANKS = 8
+
+
 class P2PComm:
     """The ranks' [gradient | KL] vectors in fine-grained device memory, each mapped into every rank (hipIpcMemHandle exchanged once
     through torch.distributed), and hgym_comm_allreduce over them: ONE kernel per minibatch on the compute stream, between
     hgym_ppo_grad and hgym_ppo_apply.  `data` (count floats) IS the rank's gradient vector: NetBuffers is constructed on it.
-    Sum in rank order, formed once per element and stored into every rank's buffer: bit-identical on all ranks."""
+    Sum in rank order, formed once per element and stored into every rank's buffer: bit-identical on all ranks.
+    Construction is local (allocate + export); `connect(handles)` maps the peers; `close()` undoes whatever has been done."""
 
     def __init__(self, count, device):
         import ctypes as C
@@ -111,62 +232,153 @@ class P2PComm:
         self.world, self.rank = world_size(), dist.get_rank()
         self.count = (int(count) + 3) // 4 * 4
         self.device = torch.device(device)
-        flag_off = (self.count * 4 + 255) // 256 * 256
-        stat_off = flag_off + 256
-        self.nbytes = stat_off + 256
+        self._flag_off = (self.count * 4 + 255) // 256 * 256
+        self._stat_off = self._flag_off + 256
+        self.nbytes = self._stat_off + 256
+        self._base, self._peer, self.connected, self.seq = None, [None] * self.world, False, 0
         base = C.c_void_p()
         with torch.cuda.device(self.device):
             L.check(L.lib.hgym_comm_alloc(self.nbytes, C.byref(base)), "hgym_comm_alloc")
-            handle = (C.c_ubyte * 64)()
-            L.check(L.lib.hgym_comm_ipc_export(base, handle), "hgym_comm_ipc_export")
-            handles = [None] * self.world
-            dist.all_gather_object(handles, (bytes(handle), os.getpid()))
-            self._base, self._peer = base.value, [None] * self.world
-            for q, (h, pid) in enumerate(handles):
+            self._base = base.value
+            self._handle = (C.c_ubyte * 64)()
+            L.check(L.lib.hgym_comm_ipc_export(base, self._handle), "hgym_comm_ipc_export")
+        self.data = torch.as_tensor(_DevMem(self._base, self.count, "<f4"), device=self.device)
+        self.status = torch.as_tensor(_DevMem(self._base + self._stat_off, 16, "<i8"), device=self.device)
+
+    def handle(self):
+        return (bytes(self._handle), os.getpid(), self.device.index if self.device.index is not None else torch.cuda.current_device())
+
+    def connect(self, handles):
+        """handles[q] = rank q's handle(): open every peer's buffer and fill the HgymComm.  (The agreement that follows in make_comm is
+        the rendezvous: every rank has opened every buffer before anyone's first kernel stores into them.)"""
+        L, C = self._L, self._C
+        with torch.cuda.device(self.device):
+            mine = handles[self.rank][2]
+            for q, (h, pid, dev) in enumerate(handles):
                 if q == self.rank:
                     self._peer[q] = self._base
                     continue
                 if pid == os.getpid():
                     raise RuntimeError("P2PComm: two ranks in one process")
+                # (ranks that see all devices of the node and differ by index: ask the runtime before touching peer memory -- a kernel
+                # that dereferences an inaccessible mapping is a memory fault, not an error code)
+                if dev != mine and max(dev, mine) < torch.cuda.device_count() and not torch.cuda.can_device_access_peer(mine, dev):
+                    raise RuntimeError("device %d cannot access device %d (rank %d)" % (mine, dev, q))
                 ptr = C.c_void_p()
                 hb = (C.c_ubyte * 64).from_buffer_copy(h)
                 L.check(L.lib.hgym_comm_ipc_open(hb, C.byref(ptr)), "hgym_comm_ipc_open")
                 self._peer[q] = ptr.value
-        self.data = torch.as_tensor(_DevMem(self._base, self.count, "<f4"), device=self.device)
-        self.status = torch.as_tensor(_DevMem(self._base + stat_off, 16, "<i8"), device=self.device)
-        self._keep = (self.data, self.status)
         c = L.Comm()
         c.world, c.rank, c.count = self.world, self.rank, self.count
         for q in range(self.world):
             c.data[q] = C.cast(C.c_void_p(self._peer[q]), L.c_float_p)
-            c.flags[q] = C.cast(C.c_void_p(self._peer[q] + flag_off), C.POINTER(C.c_uint32))
-        c.status = C.cast(C.c_void_p(self._base + stat_off), L.c_i64_p)
+            c.flags[q] = C.cast(C.c_void_p(self._peer[q] + self._flag_off), C.POINTER(C.c_uint32))
+        c.status = C.cast(C.c_void_p(self._base + self._stat_off), L.c_i64_p)
+        c.wait_ticks = 0
         self.struct = c
-        self.seq = 0
-        # (make_comm's all-reduce of the success flag is the rendezvous: every rank has opened every buffer before anyone's first
-        # kernel stores into them)
+        self.connected = True
+
+    def set_wait(self, seconds):
+        """Bound of every wait inside the kernel (None: the library's default, 15 s)."""
+        self.struct.wait_ticks = 0 if seconds is None else max(1, int(seconds * 1e8))
 
     def allreduce(self):
         """In-place SUM over the ranks of `data`, enqueued on the current stream (the same call sequence on every rank)."""
         self.seq += 1
         L, C = self._L, self._C
-        L.check(L.lib.hgym_comm_allreduce(C.byref(self.struct), self.seq & 0xFFFFFFFF or 1,
-                                          C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)), "hgym_comm_allreduce")
+        seq32 = (self.seq - 1) % 0xFFFFFFFF + 1          # 1 .. 2^32 - 1, never 0 (a zero-filled flag block means "call 0 has arrived")
+        L.check(L.lib.hgym_comm_allreduce(C.byref(self.struct), seq32, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)),
+                "hgym_comm_allreduce")
+
+    def read_status(self):
+        """Synchronises the current stream; the 16 status words as a list of ints."""
+        L, C = self._L, self._C
+        host = (C.c_int64 * 16)()
+        L.check(L.lib.hgym_comm_status(C.byref(self.struct), host, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)),
+                "hgym_comm_status")
+        return list(host)
+
+    def raise_if_expired(self, words):
+        if int(words[0]) != 0:
+            raise CommTimeout("hgym_comm_allreduce: a rank did not arrive within the kernel's bounded wait (rank %d, first at call %d of %d); "
+                              "the gradient of that minibatch is garbage and the replicas have diverged" % (self.rank, int(words[1]), self.seq))
 
     def check(self):
         """Synchronises; raises if a bounded wait of any call so far expired (a rank never arrived).  Returns the last call's
         (wait for the slowest rank, exchange) in microseconds -- the kernel's own 100 MHz timestamps."""
-        torch.cuda.synchronize(self.device)
-        s = self.status.cpu()
-        if int(s[0]) != 0:
-            raise CommTimeout("hgym_comm_allreduce: a rank did not arrive within the kernel's bounded wait (rank %d, call %d)" % (self.rank, self.seq))
-        return (int(s[9]) - int(s[8])) * 0.01, (int(s[10]) - int(s[9])) * 0.01
+        s = self.read_status()
+        self.raise_if_expired(s)
+        return (s[9] - s[8]) * 0.01, (s[10] - s[9]) * 0.01
 
-    def close(self):
+    def probe_verify(self, device):
+        """First contact, local part (make_comm agrees on the result over all ranks): (ok, note).  A known pattern through the direct
+        kernel -- rank q contributes (q + 1) x [1 .. 7 repeating], the sum is W (W + 1) / 2 x the pattern, exact in fp32.  The wait is
+        bounded by PROBE_WAIT_S."""
+        W, n = self.world, self.count
+        self.set_wait(PROBE_WAIT_S)
+        pat = (torch.arange(n, device=device, dtype=torch.float32) % 7.0) + 1.0
+        self.data.copy_(pat * float(self.rank + 1))
+        torch.cuda.synchronize(device)
+        dist.barrier()
+        skip = _inject("timeout")
+        if skip:
+            self.seq += 1                     # this rank's kernel never runs: the peers' waits expire
+        else:
+            self.allreduce()
+        s = self.read_status()
+        if s[0] != 0:
+            return False, "a bounded wait (%.1f s) expired" % PROBE_WAIT_S
+        want = pat * float(W * (W + 1) // 2)
+        if _inject("sum"):
+            want = want + 1.0
+        if not skip and not torch.equal(self.data, want):
+            return False, "wrong sum in %d of %d elements" % (int((self.data != want).sum()), n)
+        return True, None
+
+    def probe_time(self, device):
+        """PROBE_CALLS calls of each exchange on the real payload size between barriers, HIP-event timed: dict(p2p_us, collective_us),
+        or dict(error) -- never returns before every collective call of the sequence has been made."""
+        scratch = torch.zeros(self.count, device=device, dtype=torch.float32)
+        self.data.zero_()
+        self.set_wait(0.5)
+
+        def timed(fn):
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize(device)
+            dist.barrier()
+            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(PROBE_CALLS)]
+            for a, b in ev:
+                a.record()
+                fn()
+                b.record()
+            torch.cuda.synchronize(device)
+            return sum(a.elapsed_time(b) for a, b in ev) / len(ev) * 1e3
+
+        t_p2p = timed(self.allreduce)
+        s = self.read_status()
+        t_coll = timed(lambda: finish(start_sum(scratch)))
+        self.data.zero_()
+        torch.cuda.synchronize(device)
+        self.set_wait(None)
+        if s[0] != 0:
+            return dict(error="a bounded wait expired while timing the direct exchange")
+        return dict(p2p_us=t_p2p, collective_us=t_coll)
+
+    def _unmap(self):
         L, C = self._L, self._C
-        torch.cuda.synchronize(self.device)
-        dist.barrier()               # nobody unmaps a buffer a peer's kernel may still touch
         for q, p in enumerate(self._peer):
             if q != self.rank and p:
                 L.lib.hgym_comm_ipc_close(C.c_void_p(p))
-        self._peer = []
+        self._peer = [None] * self.world
+        self.connected = False
+
+    def _free(self):
+        self.data = self.status = None
+        if self._base:
+            self._L.lib.hgym_comm_free(self._C.c_void_p(self._base))
+            self._base = None
+
+    def close(self):
+        """Unmap the peers and free the buffer.  Collective: every rank calls it (barriers inside)."""
+        _teardown(self)

@@ -319,6 +319,8 @@ class OnPolicyRunner:
                 env.bind_log_sink(False)
         if marks:                               # mean device time per iteration of this call (HIP events, one sync)
             torch.cuda.synchronize()
+            if hasattr(alg, "check_comm"):
+                alg.check_comm()                # the asynchronous loop read nothing back: the exchange's status word, once per call
             self.last_collection_time = sum(a.elapsed_time(b) for a, b, _ in marks) * 1e-3 / len(marks)
             self.last_learn_time = sum(b.elapsed_time(c) for _, b, c in marks) * 1e-3 / len(marks)
         self.current_learning_iteration += num_learning_iterations
@@ -339,10 +341,11 @@ class OnPolicyRunner:
         pin["opt"][slot].copy_(alg.net.opt_state, non_blocking=True)
         pin["ls"][slot].copy_(env._buf.log_stats, non_blocking=True)
         pin["std"][slot].copy_(alg.actor_critic.std.detach().mean().reshape(1), non_blocking=True)
+        comm_words = alg.comm_status_snapshot(slot) if hasattr(alg, "comm_status_snapshot") else None
         env._buf.log_stats[:23].zero_()
         done = torch.cuda.Event()
         done.record()
-        return dict(slot=slot, done=done, aux=alg._ppo_cfg.aux_coef > 0.0)
+        return dict(slot=slot, done=done, aux=alg._ppo_cfg.aux_coef > 0.0, comm=comm_words)
 
     def _log_flush(self, pending, num_learning_iterations):
         """Print / record the log block of a finished iteration from its host snapshot (no device access: the device is busy with
@@ -350,6 +353,8 @@ class OnPolicyRunner:
         from humanoid.envs.base.legged_robot import KERNEL_REWARD_TERMS
         snap, ev = pending["snap"], pending["ev"]
         snap["done"].synchronize()
+        if snap.get("comm") is not None:       # N > 1 with the direct gradient exchange: an expired wait must not go unnoticed
+            self.alg.check_comm(snap["comm"].tolist())
         pin, slot = self._log_pin, snap["slot"]
         o, ls = pin["opt"][slot], pin["ls"][slot]
         n = max(float(o[7]), 1.0)

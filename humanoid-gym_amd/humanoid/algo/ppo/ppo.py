@@ -116,10 +116,14 @@ class PPO:
         cfg = hgym.make_net_config(ac.num_actor_obs, ac.num_critic_obs, ac.num_actions, ac.actor_hidden_dims, ac.critic_hidden_dims,
                                    self.precision, max(mb, num_envs), aux_hidden=aux, aux_out=getattr(ac, "denoiser_targets", 0),
                                    aux_target_offset=ac.num_critic_obs - getattr(ac, "denoiser_targets", 0))
-        # data-parallel update with the direct exchange (HGYM_COMM=p2p): the gradient vector lives in peer-mapped memory
+        # data-parallel update: the exchange is chosen here, once (HGYM_COMM=auto: the direct kernel over peer mappings is set up,
+        # checked and timed against the collective, and used when it is faster; any failure falls back on every rank -- dist_utils).
+        # With the direct exchange the gradient vector lives in peer-mapped memory.
         import ctypes as C
         self._comm = dist_utils.make_comm(int(hgym._lib.lib.hgym_net_param_count(C.byref(cfg))) + 1, self.device)
         self._comm_p2p = self._comm is not None and dist_utils.comm_backend() == "p2p"
+        self._comm_pin = None
+        self.comm_report = dist_utils.comm_report()     # mode, used, fallback_reason, probe timings (bench.py prints it)
         self.comm_flip = False      # bench.py: use the OTHER exchange for the next update() (timing both in its profiling iterations)
         self.net = hgym.NetBuffers(cfg, self.device, learning_rate=self._lr0, grads_ext=None if self._comm is None else self._comm.data)
         dist_utils.broadcast_parameters(ac.parameters())   # identical initial parameters on every rank
@@ -152,6 +156,24 @@ class PPO:
         LeggedRobot.seek, which the runner calls next to this.)"""
         self._sample_step.fill_(int(iteration) * int(steps_per_iteration))
         self._perm_draws = int(iteration)
+
+    def check_comm(self, words=None):
+        """The direct exchange's status word, read where the host synchronises anyway (the end of a synchronous update, the end of
+        learn(), the asynchronous log's snapshot): raises dist_utils.CommTimeout if a bounded wait of any call expired -- that
+        minibatch's gradient was garbage and the replicas have diverged, so training must not go on silently.  words: a host copy
+        of the status block taken earlier (comm_status_snapshot); None: synchronise and read it now."""
+        if self._comm is None or not self._comm_p2p:
+            return
+        self._comm.raise_if_expired(self._comm.read_status() if words is None else words)
+
+    def comm_status_snapshot(self, slot):
+        """Stream-ordered device -> pinned-host copy of the status block (no host wait); the caller reads it after its own event."""
+        if self._comm is None or not self._comm_p2p:
+            return None
+        if self._comm_pin is None:
+            self._comm_pin = [torch.zeros(16, dtype=torch.int64).pin_memory() for _ in range(2)]
+        self._comm_pin[slot].copy_(self._comm.status, non_blocking=True)
+        return self._comm_pin[slot]
 
     def test_mode(self):
         self.actor_critic.eval()
@@ -289,6 +311,7 @@ class PPO:
         if not sync:
             return None, None
         o = net.opt_state.cpu()                # the one host read-back of the update
+        self.check_comm()                      # (the stream is idle now: reading the exchange's status costs one small copy)
         n = max(float(o[7]), 1.0)
         self.last_denoise_loss = float(o[10]) / n if self._ppo_cfg.aux_coef > 0.0 else None
         return float(o[4]) / n, float(o[3]) / n

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define HGYM_VERSION 6      /* 2: HgymEnvOut carries the logging sink; hgym_rollout_*, hgym_ppo_grad_part, hgym_net_param_offset
+#define HGYM_VERSION 7      /* 2: HgymEnvOut carries the logging sink; hgym_rollout_*, hgym_ppo_grad_part, hgym_net_param_offset
                              * 3: the rollout scratch block grows with the env count (HGYM_ROLLOUT_SCRATCH_BYTES(num_envs))
                              * 4: bf16 observation shadow: HgymObsShadow argument of the policy launches, HgymBatch.obs_bf16 /
                              *    priv_bf16, hgym_net_shadow_ld
@@ -36,7 +36,9 @@ extern "C" {
                              * 6: HgymEnvOut.l0_ahead / l0_ready / obs_bf16_ahead (the actor's first layer carried across the launches of a rollout);
                              *    HGYM_MAX_CUSTOM_REWARDS 8 -> 24, custom_reward_pos = 23: after the clip (`termination`);
                              *    (same version, later: frames written into obs_ahead / priv_ahead for an env that resets in the same step are
-                             *    zeroed by the NEXT hgym_rollout_step call -- see HgymEnvOut.obs_ahead; layouts and call sequence unchanged) */
+                             *    zeroed by the NEXT hgym_rollout_step call -- see HgymEnvOut.obs_ahead; layouts and call sequence unchanged)
+                             * 7: HgymComm.wait_ticks (bound of the direct exchange's waits) + hgym_comm_status; a communicator stays usable
+                             *    after an expired wait (the done counter is per call) */
 
 enum {
     HGYM_OK = 0,
@@ -546,7 +548,8 @@ int64_t hgym_net_param_offset(const HgymNetConfig* cfg, int32_t which);
  * compute-precision shadows, bumps opt_state. */
 int32_t hgym_ppo_apply(const HgymNetConfig* cfg, const HgymPPOConfig* ppo, const HgymNet* net, void* stream);
 
-/* ---- direct gradient exchange over peer mappings (header v6; opt-in alternative to the RCCL all-reduce of the data-parallel update:
+/* ---- direct gradient exchange over peer mappings (header v6 / v7; the alternative to the RCCL all-reduce of the data-parallel update
+ * that HGYM_COMM=auto probes and picks at start-up:
  * reference has nothing here, /root/reference/humanoid/utils/helpers.py:207-212 is a dead flag).  One process per GPU.  Every rank
  * allocates ONE fine-grained buffer with hgym_comm_alloc, exports its handle (hgym_comm_ipc_export, 64 bytes, exchanged by the
  * caller over whatever it has -- torch.distributed's all_gather_object here), opens the peers' (hgym_comm_ipc_open) and fills an
@@ -554,9 +557,11 @@ int32_t hgym_ppo_apply(const HgymNetConfig* cfg, const HgymPPOConfig* ppo, const
  * lives there, HgymNet.grads points into it), flags[q] = rank q's flag block (HGYM_COMM_FLAG_WORDS zero-filled uint32), status = 16
  * int64 of the caller's own buffer.  hgym_comm_allreduce(seq = 1, 2, 3, ... -- the same sequence on every rank) enqueues ONE kernel that
  * leaves the rank-ordered fp32 SUM in every rank's data (bit-identical on all ranks): arrival flags, each rank sums its 1 / world shard
- * from all buffers and stores the result into all buffers, completion flags.  Waits are bounded (15 s): on expiry status[0] = 1 and
- * the payload is garbage (hgym_comm_status reads it; call it where the host synchronises anyway).  status[8 .. 10] = 100 MHz
- * timestamps of the last call: start, every rank arrived, every shard delivered. */
+ * from all buffers and stores the result into all buffers, completion flags.  Waits are bounded (wait_ticks of the 100 MHz wall clock,
+ * 0 = 15 s): on expiry status[0] = 1 (sticky until the caller clears it), status[1] = the seq of the call, that call's payload is
+ * garbage and the communicator stays usable for later calls.  hgym_comm_status synchronises `stream` and copies the 16 status words
+ * to the host: call it where the host synchronises anyway.  status[8 .. 10] = 100 MHz timestamps of the last call: start, every
+ * rank arrived, every shard delivered. */
 #define HGYM_COMM_MAX_RANKS 8
 #define HGYM_IPC_HANDLE_BYTES 64
 #define HGYM_COMM_FLAG_WORDS 32
@@ -566,6 +571,7 @@ typedef struct HgymComm {
     uint32_t* flags[HGYM_COMM_MAX_RANKS];
     int64_t count;
     int64_t* status;
+    int64_t wait_ticks;     /* v7: bound of every wait inside hgym_comm_allreduce, 100 MHz ticks; 0 = the default (15 s) */
 } HgymComm;
 int32_t hgym_comm_alloc(int64_t bytes, void** dev_ptr);
 int32_t hgym_comm_free(void* dev_ptr);
@@ -573,6 +579,7 @@ int32_t hgym_comm_ipc_export(void* dev_ptr, void* handle_out);
 int32_t hgym_comm_ipc_open(const void* handle, void** dev_ptr);
 int32_t hgym_comm_ipc_close(void* dev_ptr);
 int32_t hgym_comm_allreduce(const HgymComm* comm, uint32_t seq, void* stream);
+int32_t hgym_comm_status(const HgymComm* comm, int64_t* host16, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Measurement hooks (bench.py's roofline leg).  PROCESS-GLOBAL state, unlike the rest of this interface: one event list and one

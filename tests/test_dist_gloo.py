@@ -42,6 +42,50 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
+def _comm_worker(rank, world, port, out_dir, mode):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "humanoid-gym_amd"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["HGYM_COMM"] = mode
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from humanoid.algo.ppo import dist_utils as D
+    err = None
+    try:
+        comm = D.make_comm(1001, "cuda:0")
+    except RuntimeError as e:
+        comm, err = None, str(e)
+    # whatever make_comm did, every rank is in step again: a collective issued now must complete
+    t = torch.tensor([float(rank + 1)])
+    dist.all_reduce(t)
+    torch.save(dict(none=comm is None, report=D.comm_report(), err=err, total=float(t)), os.path.join(out_dir, "c%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+def test_make_comm_falls_back_on_every_rank_when_no_rank_can_allocate(tmp_path):
+    """HGYM_COMM=auto on a host WITHOUT a GPU: the direct exchange's allocation fails on every rank (hgym_comm_alloc needs a device), so
+    make_comm must come back with None on every rank, name the reason, and leave the ranks in step (the next collective completes) --
+    ADVICE r04: a set-up failure must never leave some ranks inside a different collective.  HGYM_COMM=p2p raises instead; rccl does
+    not try."""
+    import pytest
+    if torch.cuda.is_available():
+        pytest.skip("this is the no-device case; tests/test_dist_gpu.py injects the failures on a GPU")
+    port = 29650 + (os.getpid() % 2000)
+    for k, mode in enumerate(("auto", "p2p", "rccl", "both")):
+        d = tmp_path / mode
+        os.makedirs(str(d))
+        mp.spawn(_comm_worker, args=(2, port + k, str(d), mode), nprocs=2, join=True)
+        r = [torch.load(os.path.join(str(d), "c%d.pt" % i)) for i in range(2)]
+        for x in r:
+            assert x["none"] and x["total"] == 3.0 and x["report"]["mode"] == mode and x["report"]["used"] == "collective", (mode, x)
+            if mode == "rccl":
+                assert x["report"]["fallback_reason"] is None and x["err"] is None
+            elif mode == "p2p":
+                assert x["err"] and "could not be set up" in x["err"]
+            else:
+                assert "allocation" in x["report"]["fallback_reason"] and x["err"] is None, x
+
+
 def test_two_rank_exchanges(tmp_path):
     port = 29500 + (os.getpid() % 2000)
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)

@@ -31,13 +31,14 @@ def _all_done_or_timed_out(out_dir, world, prefix, limit_s=60.0):
     return False
 
 
-def _worker(rank, world, port, out_dir, backend="gloo", num_envs=256, iters=4, comm="rccl"):
+def _worker(rank, world, port, out_dir, backend="gloo", num_envs=256, iters=4, comm="rccl", inject=""):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "humanoid-gym_amd"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     os.environ["HGYM_COMM"] = comm
+    os.environ["HGYM_COMM_FAIL_INJECT"] = inject
     if backend == "nccl":            # RCCL: one device per rank
         torch.cuda.set_device(rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
@@ -62,8 +63,16 @@ def _worker(rank, world, port, out_dir, backend="gloo", num_envs=256, iters=4, c
     torch.cuda.synchronize()
     net = runner.alg.net
     p2p = None
-    # the gradient vector lives in the peer-mapped buffer only on request (HGYM_COMM=p2p / both)
-    assert runner.alg._comm_p2p == (comm == "p2p") and (runner.alg._comm is not None) == (comm in ("p2p", "both"))
+    # the gradient vector lives in the peer-mapped buffer when the direct exchange is in use (HGYM_COMM=p2p, or auto when its start-up
+    # probe picked it: always over gloo, whose all-reduce is host-staged) or asked for beside the collective (both)
+    rep = dict(runner.alg.comm_report)
+    want_p2p = comm == "p2p" or (comm == "auto" and not inject)
+    assert runner.alg._comm_p2p == want_p2p and (runner.alg._comm is not None) == (want_p2p or comm == "both"), rep
+    assert rep["mode"] == comm and rep["used"] == ("p2p" if want_p2p else "collective"), rep
+    if comm == "auto":
+        assert (rep["fallback_reason"] is None) == (not inject), rep
+        if not inject:
+            assert rep["probe"]["p2p_us_per_call"] < rep["probe"]["collective_us_per_call"], rep
     if runner.alg._comm is not None:
         assert net.grads_ext.data_ptr() == runner.alg._comm.data.data_ptr()
         try:
@@ -73,15 +82,15 @@ def _worker(rank, world, port, out_dir, backend="gloo", num_envs=256, iters=4, c
                 raise
             open(os.path.join(out_dir, "timeout%d" % rank), "w").write(str(e))
             os._exit(0)
-        p2p = t if comm == "p2p" else None
+        p2p = t if want_p2p else None
     else:
-        assert comm != "p2p"
+        assert not want_p2p
     torch.save(dict(p_init=p_init.cpu(), params=net.params.cpu(), lr=float(net.opt_state[0]), steps=float(net.opt_state[1]),
                     obs=runner.alg.storage._obs_all[1].cpu(), graph=runner._graph is not None, friction=friction, commands0=commands0,
-                    env_seed=seed, comm_events=len(runner.alg.comm_timing), split=net.bucket_split, P=net.P, p2p=p2p),
+                    env_seed=seed, comm_events=len(runner.alg.comm_timing), split=net.bucket_split, P=net.P, p2p=p2p, report=rep),
                os.path.join(out_dir, "r%d.pt.tmp" % rank))
     os.replace(os.path.join(out_dir, "r%d.pt.tmp" % rank), os.path.join(out_dir, "r%d.pt" % rank))
-    if comm == "p2p" and not _all_done_or_timed_out(out_dir, world, "r"):
+    if want_p2p and not _all_done_or_timed_out(out_dir, world, "r"):
         os._exit(0)
     if runner.alg._comm is not None:
         runner.alg._comm.close()
@@ -137,9 +146,12 @@ def _p2p_unit_worker(rank, world, port, out_dir, count, calls):
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from humanoid.algo.ppo import dist_utils
-    assert dist_utils.comm_backend() == "p2p"
-    comm = dist_utils.P2PComm(count, "cuda:0")
-    dist.barrier()                               # (PPO goes through make_comm, whose success all-reduce is this rendezvous)
+    assert dist_utils.comm_mode() == "p2p"
+    comm = dist_utils.P2PComm(count, "cuda:0")   # (PPO goes through make_comm: the same steps, each followed by an agreement over all ranks)
+    handles = [None] * world
+    dist.all_gather_object(handles, comm.handle())
+    comm.connect(handles)
+    dist.barrier()                               # every rank has mapped every buffer before anyone's first kernel stores into them
     assert comm.count % 4 == 0 and comm.count >= count
 
     def vec(r, k):
@@ -222,6 +234,33 @@ def test_two_ranks_one_gpu_p2p_exchange_equals_collective(tmp_path):
     assert torch.isfinite(a["params"]).all() and not torch.equal(a["params"], a["p_init"])
     assert torch.equal(a["params"], c["params"]) and a["lr"] == c["lr"]
     assert a["p2p"] is not None and c["p2p"] is None
+
+
+@pytest.mark.timeout(900)
+def test_auto_picks_the_direct_exchange_and_falls_back_on_injected_failures(tmp_path):
+    """HGYM_COMM=auto (the default for N > 1): two ranks on one GPU over gloo.  Without a fault the start-up probe
+    checks the direct kernel's sum, times both exchanges and picks the direct one (gloo's all-reduce is host-staged).  With an injected
+    fault on rank 1 -- the allocation, the peer mapping, a rank whose first kernel never runs (the peers' bounded waits expire after
+    2 s), a wrong sum -- EVERY rank falls back to the collective, says why, and trains on.  For two ranks a + b = b + a exactly, so all
+    five runs must end with the same parameters, bit for bit, on both ranks."""
+    port = 31700 + (os.getpid() % 2000)
+    runs = [("auto", ""), ("auto", "alloc"), ("auto", "map"), ("auto", "timeout"), ("auto", "sum")]
+    res = []
+    for k, (comm, inject) in enumerate(runs):
+        d = tmp_path / ("run%d" % k)
+        os.makedirs(str(d))
+        mp.spawn(_worker, args=(2, port + k, str(d), "gloo", 256, 2, comm, inject), nprocs=2, join=True)
+        a, b = (torch.load(os.path.join(str(d), "r%d.pt" % i)) for i in range(2))
+        assert torch.equal(a["params"], b["params"]) and a["lr"] == b["lr"] and a["steps"] == 16, (comm, inject)
+        assert a["report"]["used"] == b["report"]["used"] == ("collective" if inject else "p2p"), (inject, a["report"], b["report"])
+        if inject:
+            assert a["report"]["fallback_reason"] and b["report"]["fallback_reason"], (inject, a["report"])
+        res.append(a)
+    words = dict(alloc="allocation", map="hipIpcOpenMemHandle", timeout="bounded wait", sum="wrong sum")
+    for (comm, inject), r in zip(runs[1:], res[1:]):
+        assert words[inject] in r["report"]["fallback_reason"], (inject, r["report"])
+        assert torch.equal(r["params"], res[0]["params"]) and r["lr"] == res[0]["lr"], inject
+    print("HGYM_COMM=auto start-up probe, 2 ranks on one GPU over gloo: %s" % (res[0]["report"]["probe"],))
 
 
 @pytest.mark.timeout(900)
@@ -315,4 +354,9 @@ def test_bench_spawns_its_own_ranks(tmp_path):
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
     assert out["config"]["envs_per_gpu"] == 512 and "cpu_baseline" not in out and "configs" not in out
     assert out["comm"]["minibatches_per_iter"] == 8 and out["comm"]["exposed_us_per_minibatch"] >= 0
+    assert out["comm"]["mode"] == "auto" and out["comm"]["used_in_timed_run"] in ("p2p", "collective")
+    assert (out["comm"]["fallback_reason"] is None) == (out["comm"]["used_in_timed_run"] == "p2p"), out["comm"]
     assert out["roofline"]["frac"] > 0
+    # the line ends with the compact block: the last 2 000 bytes (what the driver's record keeps) carry the headline's split
+    tail = lines[0][-2000:]
+    assert '"summary"' in tail and '"collection_ms"' in tail and '"ppo_update_ms"' in tail and '"rollout_step_kernel"' in tail, tail
