@@ -137,6 +137,98 @@ __device__ __forceinline__ void fin_log(const FinArgs& F, int t, int nthreads) {
     }
 }
 
+// fin_log in ONE memory round trip (round 5; N a multiple of 8, 16-byte aligned columns: otherwise false, nothing touched).  The loop above
+// walks the envs in rows of `nthreads` with two barriers and a dependent load -> scan -> store chain per row: 8 rows for 4096 envs on 512
+// lanes, ~9 us of the ONE workgroup that rides in the third grid row of the next rollout launch -- and that workgroup starts late (it
+// needs a compute unit one of the launch's 256 tiles has left), so with the log sink bound every launch of the rollout ended ~6.7 us later
+// (BENCH_r04 configs[logging_on]: collection 2.59 vs 2.19 ms).  Here a lane owns 8 CONSECUTIVE envs, issues every load it needs up front
+// and the workgroup scans the per-lane counts once: same ring order (ascending env index), same values, same roundings.
+__device__ __forceinline__ bool fin_log_fused(const FinArgs& F, int t, int nthreads) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    typedef unsigned long long u64;
+    const HgymEnvOut& O = F.out;
+    float* LS = O.log_stats;
+    if (!LS) return true;
+    float* cur = O.log_cur;
+    auto al = [](const void* p, int a) { return ((uintptr_t)p & (uintptr_t)(a - 1)) == 0; };
+    if ((F.N & 7) != 0 || !al(O.reset, 8) || !al(O.rew, 16) || !al(cur, 16)) return false;
+    __shared__ int s_wave[32];
+    __shared__ int s_head;
+    if (t < HGYM_NUM_REWARDS) LS[t] += O.extras_episode[t];      // (thread t refreshed extras_episode[t] itself: no barrier)
+    if (t == 0) {
+        LS[22] += 1.0f;
+        s_head = (int)LS[24];
+    }
+    const int lane = t & 63, wave = t >> 6, nw = (nthreads + 63) >> 6;
+    const int G = F.N >> 3;
+    int appended = 0;
+    for (int g0 = 0; g0 < G; g0 += nthreads) {
+        const int g = g0 + t;
+        const bool in = g < G;
+        u64 rs = 0;
+        f4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+        f4 c[2] = {z, z}, l[2] = {z, z}, rw[2] = {z, z};
+        if (in) {
+            rs = reinterpret_cast<const u64*>(O.reset)[g];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                c[h] = reinterpret_cast<const f4*>(cur)[2 * g + h];
+                l[h] = reinterpret_cast<const f4*>(cur + F.N)[2 * g + h];
+                rw[h] = reinterpret_cast<const f4*>(O.rew)[2 * g + h];
+            }
+        }
+        int cnt = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            c[k >> 2][k & 3] = c[k >> 2][k & 3] + rw[k >> 2][k & 3];
+            l[k >> 2][k & 3] = l[k >> 2][k & 3] + 1.0f;
+            cnt += (int)(((rs >> (8 * k)) & 0xffull) != 0);
+        }
+        int incl = cnt;                                        // inclusive scan of the lanes' counts over the wavefront ...
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int v = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += v;
+        }
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        int off = incl - cnt, total = 0;                       // ... and over the workgroup
+        for (int w = 0; w < nw; ++w) {
+            const int cw = s_wave[w];
+            if (w < wave) off += cw;
+            total += cw;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (((rs >> (8 * k)) & 0xffull) != 0) {
+                if (off >= total - 100) {                      // more than 100 in one trip: only the last 100 can survive (distinct slots)
+                    const int pos = (s_head + appended + off) % 100;
+                    LS[32 + pos] = c[k >> 2][k & 3];
+                    LS[132 + pos] = l[k >> 2][k & 3];
+                }
+                ++off;
+                c[k >> 2][k & 3] = 0.0f;
+                l[k >> 2][k & 3] = 0.0f;
+            }
+        }
+        if (in) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                reinterpret_cast<f4*>(cur)[2 * g + h] = c[h];
+                reinterpret_cast<f4*>(cur + F.N)[2 * g + h] = l[h];
+            }
+        }
+        appended += total;
+        __syncthreads();
+    }
+    if (t == 0) {
+        LS[24] = (float)((s_head + appended) % 100);
+        const float filled = LS[25] + (float)appended;
+        LS[25] = filled > 100.0f ? 100.0f : filled;
+    }
+    return true;
+}
+
 // fin_part1 + fin_store in ONE memory round trip (N a multiple of 8, 16-byte aligned columns; otherwise returns false and nothing is
 // touched).  The two functions above are loops of load -> store over byte pointers: every load waits for the store before it (a
 // uint8_t store may alias anything), 8 + 8 dependent round trips for 4096 envs on 512 lanes -- 8 us of a single workgroup that
@@ -223,7 +315,7 @@ __device__ __forceinline__ void fin_block(const FinArgs& F, int t, int nthreads)
         __syncthreads();
         fin_store(F, t, nthreads);
     }
-    fin_log(F, t, nthreads);
+    if (!(HGYM_FIN_FUSED && fin_log_fused(F, t, nthreads))) fin_log(F, t, nthreads);
     // every lane of the workgroup has loaded reset_count[0] (fin_fused's / fin_part1's first load) before thread 0 zeroes it: without
     // this barrier a late wavefront of a 512 / 1024-lane workgroup could read 0 and keep the stale time-out bytes
     __syncthreads();
