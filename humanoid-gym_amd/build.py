@@ -25,7 +25,7 @@ EXTRA = {
 
 
 # Round 4 found that a device code object beyond ~1 MiB in the library makes runs of eight processes on one GPU abort at random with
-# HSA_STATUS_ERROR_ILLEGAL_INSTRUCTION, whether or not anything of it is launched (csrc/hgym_fb2.hip has the bisection: 0.87 - 0.99 MB fine,
+# HSA_STATUS_ERROR_ILLEGAL_INSTRUCTION, whether or not anything of it is launched (csrc/experiments/hgym_fb2.hip has the bisection: 0.87 - 0.99 MB fine,
 # 1.15 / 1.19 MB not).  -save-temps=obj leaves the linked device code object of each translation unit next to its .o: every one must stay
 # below CODE_OBJECT_LIMIT, and every kernel inside the 128 KiB short-branch range (s_cbranch reaches +-32 K dwords) -- a big kernel belongs
 # in a translation unit of its own.
@@ -83,6 +83,10 @@ def build(force=False, verbose=True):
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".h"))]
     headers.append(os.path.join(os.path.dirname(HERE), "include", "hgym.h"))
     srcs = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+    stems = {f[:-4] for f in srcs}
+    for t in os.listdir(OBJDIR):        # objects / code objects of sources that no longer exist (a kernel moved out of the library) must not be size-checked
+        if t.endswith((".o", ".out")) and t.split("-hip-amdgcn")[0].split(".")[0] not in stems:
+            os.remove(os.path.join(OBJDIR, t))
     objs, rebuilt = [], False
     for f in srcs:
         src = os.path.join(CSRC, f)

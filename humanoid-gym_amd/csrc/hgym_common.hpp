@@ -99,13 +99,10 @@ HG_HD U4 rng4(const RngKey& k, uint32_t env, uint32_t slot) {
 // the policy step and the noise-table fill of the env step sit on the rollout's latency chain.  These are draws of the
 // built-in generator (nothing in the reference to match bit for bit); the host emulation keeps libm and agrees to ~1e-6.
 // HGYM_FAST_NORMALS=0 restores libm on the device.
-#ifndef HGYM_FAST_NORMALS
-#define HGYM_FAST_NORMALS 1
-#endif
 HG_HD void box_muller(uint32_t a, uint32_t b, float& z0, float& z1) {
     const float u1 = 1.0f - u01(a);
     const float u2 = u01(b);
-#if defined(__HIP_DEVICE_COMPILE__) && HGYM_FAST_NORMALS
+#if defined(__HIP_DEVICE_COMPILE__)
     const float r = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));     // -2 ln 2 * log2(u1)
     z0 = r * __builtin_amdgcn_cosf(u2);
     z1 = r * __builtin_amdgcn_sinf(u2);

@@ -17,12 +17,6 @@
 
 #include "hgym_env_math.hpp"
 
-#ifndef HGYM_ENV_SPLIT
-#define HGYM_ENV_SPLIT 1
-#endif
-#ifndef HGYM_ENV_STAGE_FIRST
-#define HGYM_ENV_STAGE_FIRST 0   // measured (fast-class box, same call): 3.386 ms collection with 1, 3.304 with 0 -- the history loads are better issued first
-#endif
 
 namespace hgym {
 
@@ -43,38 +37,25 @@ __global__ __launch_bounds__(256) void env_step_kernel(const EnvArgs A) {
     constexpr int NIP = kPrefetch ? hist_ni<HCP, HGYM_PRIV_FRAME, EP, NTH>() : 0;
     float hist_o[NIO > 0 ? NIO : 1][4], hist_p[NIP > 0 ? NIP : 1][4];
     const StackGeom geom = stack_geom<H_T, HC_T, E_T>(A, blockIdx.x);
-    const bool stack_on = A.mode != MODE_RESET_ALL && !(A.ablate & 8) && A.phase != 1;      // a derive launch writes no observations
-#if HGYM_ENV_STAGE_FIRST
-    // the state / sim loads need nothing but the block index: issued first, they travel while the ring-step counter -- which the
-    // history addresses wait for -- is still on its way; their LDS writes follow the history loads' issue
-    StageRegs<E_T> stage;
-    stage.fast = 0;
-    if (!(A.ablate & 1)) env_stage_in_load<E_T>(A, blockIdx.x, t, blockDim.x, stage);
-#endif
+    const bool stack_on = A.mode != MODE_RESET_ALL && A.phase != 1;      // a derive launch writes no observations
     if (kPrefetch && stack_on && t >= 64) {
         hist_load<HP, HGYM_OBS_FRAME, NIO>(A.st.obs_ring, geom.e0, geom.nE, (int)(ring_step % HP), t - 64, NTH, hist_o);
         hist_load<HCP, HGYM_PRIV_FRAME, NIP>(A.st.priv_ring, geom.e0, geom.nE, (int)(ring_step % HCP), t - 64, NTH, hist_p);
     }
-#if HGYM_ENV_STAGE_FIRST
-    if (!(A.ablate & 1)) env_stage_in_store<E_T>(A, blockIdx.x, t, blockDim.x, smem, stage);
-#else
-    if (!(A.ablate & 1)) env_stage_in<E_T>(A, blockIdx.x, t, blockDim.x, smem);
-#endif
-    if (!(A.ablate & 64)) env_fill_draws<E_T>(A, blockIdx.x, t, blockDim.x, smem, csc0);
+    env_stage_in<E_T>(A, blockIdx.x, t, blockDim.x, smem);
+    env_fill_draws<E_T>(A, blockIdx.x, t, blockDim.x, smem, csc0);
     env_reset_pose<E_T>(A, t, blockDim.x, smem);
     __syncthreads();
-    // The XBot-L instantiation splits the per-env chain of a plain step (HGYM_ENV_SPLIT): what is the same few instructions
+    // The XBot-L instantiation splits the per-env chain of a plain step: what is the same few instructions
     // for each of the 12 joints runs one (env, joint) pair per lane before (phase J) and after (phase F) a shorter chain, and
     // the synthetic physics' per-env remainder runs on two otherwise idle wavefronts of phase J.
-    const bool split = HGYM_ENV_SPLIT && !kGeneric && E_T > 0 && (kStep || A.mode == MODE_STEP);
-#ifndef HGYM_ENV_KERNEL_WAVES
-#define HGYM_ENV_KERNEL_WAVES 1    // this kernel's per-env chain on one wavefront (its other three store the observation history meanwhile); 4: on all four
-#endif
-    constexpr bool kW3 = HGYM_ENV_SPLIT && HGYM_ENV_WAVES3 && HGYM_ENV_KERNEL_WAVES == 4 && !kGeneric && E_T > 0 && kStep;
-    if (split) env_step_phase_j<E_T, kW3>(A, blockIdx.x, t, blockDim.x, smem);
-    else if (!(A.ablate & 128)) env_step_joints<E_T>(A, blockIdx.x, t, blockDim.x, smem);
+    const bool split = !kGeneric && E_T > 0 && (kStep || A.mode == MODE_STEP);
+    // (this kernel keeps the chain on ONE wavefront -- its other three store the observation history meanwhile; the fused rollout
+    // launch runs it on four by role, hgym_rollout.hip)
+    if (split) env_step_phase_j<E_T, false>(A, blockIdx.x, t, blockDim.x, smem);
+    else env_step_joints<E_T>(A, blockIdx.x, t, blockDim.x, smem);
     __syncthreads();
-    // wavefront 0 (kW3: all four) runs the per-env scalar chains (one lane per env); the other wavefronts meanwhile move the
+    // wavefront 0 runs the per-env scalar chains (one lane per env); the other wavefronts meanwhile move the
     // older frames of the observation history, which depend on nothing this step computes (reset envs are fixed up in phase B) --
     // their stores are issued first
     if (t >= 64) {
@@ -84,24 +65,21 @@ __global__ __launch_bounds__(256) void env_step_kernel(const EnvArgs A) {
                 hist_store<HCP, HGYM_PRIV_FRAME, NIP>(A.out.priv_obs, geom.e0, geom.nE, (int)(ring_step % HCP), t - 64, NTH, nullptr, A.cfg.clip_obs,
                                                       hist_p);
             }
-        } else if (!(A.ablate & 8) && A.phase != 1) {
+        } else if (A.phase != 1) {
             env_step_stack_old<H_T, HC_T, E_T>(A, blockIdx.x, t - 64, blockDim.x - 64, ring_step);
         }
     }
-    if (kW3) {
-        if (t < 64 * kChainRoles && !(A.ablate & 2)) env_step_phase_a3<E_T>(A, blockIdx.x, t, blockDim.x, smem, csc0);
-    } else if (t < 64 && !(A.ablate & 2)) {
+    if (t < 64) {
         if (split) env_step_phase_a<E_T, kGeneric, true>(A, blockIdx.x, t, smem, csc0);
         else env_step_phase_a<E_T, kGeneric>(A, blockIdx.x, t, smem, csc0);
     }
     __syncthreads();
     if (split) {
         env_step_phase_f<E_T>(A, blockIdx.x, t, blockDim.x, smem);
-        if (kW3 && !(A.ablate & 2)) env_step_reward_sum<E_T>(A, blockIdx.x, t, blockDim.x, smem);
         __syncthreads();
     }
-    if (!(A.ablate & 4)) env_stage_out<E_T>(A, blockIdx.x, t, blockDim.x, smem);
-    if (!(A.ablate & 8) && A.phase != 1) env_step_phase_b<H_T, HC_T, E_T>(A, blockIdx.x, t, blockDim.x, smem, csc0, ring_step, false);
+    env_stage_out<E_T>(A, blockIdx.x, t, blockDim.x, smem);
+    if (A.phase != 1) env_step_phase_b<H_T, HC_T, E_T>(A, blockIdx.x, t, blockDim.x, smem, csc0, ring_step, false);
     // postponed finaliser (HgymEnvOut.defer_finalize): the sampling step the NEXT policy launch reads is bumped here -- no policy
     // kernel is running now, and the finaliser will be one of that launch's workgroups
     if (A.out.defer_finalize && blockIdx.x == 0 && t == 0 && A.out.t_rewards && A.out.t_step) A.out.t_step[0] += 1;
@@ -249,8 +227,6 @@ static int32_t launch_step(const HgymEnvConfig* cfg, const HgymSimTensors* sim, 
     A.phase = phase;
     A.fused = fused;
     A.envs_per_block = pick_envs_per_block(cfg->num_envs);
-    static const int ablate = getenv("HGYM_ENV_ABLATE") ? atoi(getenv("HGYM_ENV_ABLATE")) : 0;   // profiling experiments only
-    A.ablate = ablate;
     set_body_offsets(A);
     {   // fast staging when the state fields are one contiguous [136][N] allocation
         bool contig = true;
@@ -265,7 +241,7 @@ static int32_t launch_step(const HgymEnvConfig* cfg, const HgymSimTensors* sim, 
     // the generic LeggedRobot options (HgymEnvConfig tail) have their own instantiation: off, none of their code is compiled in
     const bool generic = cfg->custom_origins || cfg->terrain_curriculum || cfg->num_height_points > 0 || cfg->command_curriculum ||
                          !cfg->heading_command || phase != 0 || cfg->num_custom_rewards > 0;
-    if (std_stack && A.envs_per_block == 16 && !generic && mode == MODE_STEP && HGYM_ENV_SPLIT)
+    if (std_stack && A.envs_per_block == 16 && !generic && mode == MODE_STEP)
         hipLaunchKernelGGL((env_step_kernel<15, 3, 16, false, true>), dim3(blocks), dim3(256), lds, s, A);
     else if (std_stack && A.envs_per_block == 16 && !generic)
         hipLaunchKernelGGL((env_step_kernel<15, 3, 16, false>), dim3(blocks), dim3(256), lds, s, A);

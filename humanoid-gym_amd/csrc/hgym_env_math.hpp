@@ -35,8 +35,6 @@ struct EnvArgs {
                               // reset, observations, tail); 0 = the whole step in one launch
     int fused;                // 1: pre_physics + synthetic physics run inside the step kernel
     int envs_per_block;
-    int ablate;               // debug/profiling only: bit0 skip stage-in, bit1 skip phase A, bit2 skip stage-out, bit3 skip phase B,
-                              // bit4 skip pre_physics+synthetic physics, bit5 skip the per-env post-physics arithmetic
     int state_contig;         // 1: the 22 [C][N] state fields are adjacent in memory, in HgymEnvState order
     int env_base;             // global id of env index 0 of the state arrays (0, or the block's first env for an LDS shadow)
     int contact_comp[3];      // component offset of the xyz triple of {base, foot L, foot R} in sim.contact
@@ -192,10 +190,7 @@ static_assert(offsetof(HgymEnvConfig, d_gains) == offsetof(HgymEnvConfig, p_gain
               offsetof(HgymEnvConfig, dof_lower) == offsetof(HgymEnvConfig, p_gains) + 192 &&
               offsetof(HgymEnvConfig, dof_upper) == offsetof(HgymEnvConfig, p_gains) + 240, "the per-joint constants are one block");
 HG_HD const float* joint_consts(const HgymEnvConfig& c) { return reinterpret_cast<const float*>(&c) + offsetof(HgymEnvConfig, p_gains) / 4; }
-#ifndef HGYM_JCFG_LDS
-#define HGYM_JCFG_LDS 1        // 0 (A/B runs): the workgroup kernels index the kernel argument
-#endif
-#define HGYM_JC(A, smem, m) (HGYM_JCFG_LDS ? (const float*)((smem) + (m).jcfg) : joint_consts((A).cfg))
+#define HGYM_JC(A, smem, m) ((const float*)((smem) + (m).jcfg))
 
 HG_HD float pd_torque(const HgymEnvConfig& c, const float* jc, int j, float a, float q, float qd) {
     const float t = jc[kJcP + j] * (a * c.action_scale + jc[kJcDef + j] - q) - jc[kJcD + j] * qd;
@@ -357,18 +352,15 @@ HG_HD void resample_commands(const HgymEnvConfig& c, float x_lo, float x_span, f
 // <= |x| * 1e-7 relative, i.e. < 2e-6 for the arguments that do not underflow) instead of libm's ~15 / ~10 instruction
 // sequences -- 16 exponentials and 6 roots sit on the single-wave per-env chain of the step kernel.  Nothing thresholded
 // (masks, termination, the command dead-band) goes through these.  The host emulation keeps libm.  HGYM_ENV_FAST=0: libm.
-#ifndef HGYM_ENV_FAST
-#define HGYM_ENV_FAST 1
-#endif
 HG_HD float r_exp(float x) {
-#if defined(__HIP_DEVICE_COMPILE__) && HGYM_ENV_FAST
+#if defined(__HIP_DEVICE_COMPILE__)
     return __builtin_amdgcn_exp2f(x * 1.4426950408889634f);
 #else
     return expf(x);
 #endif
 }
 HG_HD float r_sqrt(float x) {
-#if defined(__HIP_DEVICE_COMPILE__) && HGYM_ENV_FAST
+#if defined(__HIP_DEVICE_COMPILE__)
     return __builtin_amdgcn_sqrtf(x);
 #else
     return sqrtf(x);
@@ -430,9 +422,6 @@ constexpr int kJointTerms = 8;     // per-joint products: d1^2, d2^2, |a| (term 
 //   ROLE_FRAMES the same re-derivation, the values a reset changes, and the non-joint entries of the two clean observation frames.
 // env_step_reward_sum then forms the reward and the episode sums in the reference's order.  No wavefront reads what another writes
 // during the phase; tests/hostcheck runs the roles in both orders.
-#ifndef HGYM_ENV_WAVES3
-#define HGYM_ENV_WAVES3 1      // the split per-env chain of the compiled-in fast kernels on four wavefronts (the name is older); 0: on one
-#endif
 constexpr int ROLE_ALL = 0, ROLE_MAIN = 1, ROLE_REW_A = 2, ROLE_REW_B = 3, ROLE_FRAMES = 4;
 constexpr int kChainRoles = 4;       // wavefronts of env_step_phase_a3
 HG_HD constexpr bool term_in_role(int k, int role) {
@@ -1048,10 +1037,8 @@ struct __attribute__((packed, aligned(4))) EnvF4 {
 };
 // The observation history (14 + 2 older frames per env read, the stacked rows and the ring slot written) is touched once per
 // step: with the non-temporal hint it does not push the policy's weight fragments -- which every actor / critic tile of the XCD
-// re-reads at the next launch -- out of the 4 MB L2 (HGYM_ENV_NT=0: plain accesses).
-#ifndef HGYM_ENV_NT
-#define HGYM_ENV_NT 7      // bit 0: loads of the older frames, bit 1: their stores into the stacked rows, bit 2: newest frame (ring slot + row)
-#endif
+// re-reads at the next launch -- out of the 4 MB L2.
+constexpr int kEnvNT = 7;      // bit 0: loads of the older frames, bit 1: their stores into the stacked rows, bit 2: newest frame (ring slot + row)
 typedef float envf4_nt __attribute__((ext_vector_type(4), aligned(4)));
 template <bool NT = true>
 HG_HD EnvF4 ld_stream4(const float* p) {
@@ -1474,7 +1461,7 @@ HG_HD void env_step_joints(const EnvArgs& A, int block, int t, int nthreads, flo
     const int E = E_T > 0 ? E_T : A.envs_per_block;
     const int N = A.cfg.num_envs, e0 = block * E;
     const int nE = (E < N - e0) ? E : (N - e0);
-    if (!(A.mode == MODE_STEP && A.fused) || (A.ablate & 16)) return;
+    if (!(A.mode == MODE_STEP && A.fused)) return;
     const LdsMap m = lds_map(E);
     // works on the LDS image directly (no shadow struct): the per-joint constants are indexed by a lane-varying j and
     // must be read from the kernel argument itself, not from a per-lane copy of it
@@ -1535,11 +1522,11 @@ HG_HD void env_step_phase_j(const EnvArgs& A, int block, int t, int nthreads, fl
     const int E = E_T > 0 ? E_T : A.envs_per_block;
     const int N = A.cfg.num_envs, e0 = block * E;
     const int nE = (E < N - e0) ? E : (N - e0);
-    if (!(A.ablate & 128)) env_step_joints<E_T>(A, block, t, nthreads, smem);
+    env_step_joints<E_T>(A, block, t, nthreads, smem);
     env_step_joint_terms<E_T>(A, block, t, nthreads, smem);
     const LdsMap m = lds_map(E);
     const int nw = nthreads >= 64 ? nthreads / 64 : 1;
-    const bool synth = A.mode == MODE_STEP && A.fused && !(A.ablate & 16);
+    const bool synth = A.mode == MODE_STEP && A.fused;
     if (synth || kSnap) {
         const int w_root = nw - 1, w_feet = nw >= 2 ? nw - 2 : nw - 1;
         const int lr = t - 64 * w_root, lf = t - 64 * w_feet;
@@ -1629,12 +1616,9 @@ HG_HD void env_step_phase_a(const EnvArgs& A, int block, int t, float* smem, int
     const LdsMap m = lds_map(E);
     const EnvArgs S = make_shadow(A, smem, block, E);
     const RngKey rk = make_rng_key(A, csc0);
-    if (!kSplit && A.mode == MODE_STEP && A.fused && !(A.ablate & 16)) synth_rest_env(S, smem + m.phys + t * kPhysDraws, t, E);
-    StepFlags fl;
-    fl.reset = 0;
-    if (!(A.ablate & 32))
-        fl = post_physics_env<kGeneric, kSplit>(S, rk, csc0 + 1, t, E, smem + m.frame + t * HGYM_OBS_FRAME, smem + m.priv + t * HGYM_PRIV_FRAME,
-                                                smem + m.jpart, smem + m.cscal, smem + m.reset_pose);
+    if (!kSplit && A.mode == MODE_STEP && A.fused) synth_rest_env(S, smem + m.phys + t * kPhysDraws, t, E);
+    const StepFlags fl = post_physics_env<kGeneric, kSplit>(S, rk, csc0 + 1, t, E, smem + m.frame + t * HGYM_OBS_FRAME, smem + m.priv + t * HGYM_PRIV_FRAME,
+                                                            smem + m.jpart, smem + m.cscal, smem + m.reset_pose);
     reinterpret_cast<int*>(smem + m.reset_i)[t] = fl.reset;
     if (fl.reset) reinterpret_cast<int*>(smem + m.reset_list)[hg_atomic_inc_int(reinterpret_cast<int*>(smem + m.reset_cnt))] = t;
 }
@@ -1668,17 +1652,6 @@ HG_HD void env_step_phase_a3(const EnvArgs& A, int block, int t, int nthreads, f
     S.st.last_root_vel = sn + kSnapLrv * E;
     S.st.episode_length = reinterpret_cast<int64_t*>(sn + kSnapEp * E);
     if (role == 1) {
-#if defined(HGYM_W3_PROBE) && HGYM_W3_PROBE
-        // probe: role A (pure: it only writes its terms) repeated -- a second pass through the SAME code costs its instruction issue but
-        // no instruction fetch misses
-#pragma unroll 1
-        for (int rep = (A.ablate >> 8) & 7; rep > 0; --rep) {
-#if defined(__HIP_DEVICE_COMPILE__)
-            asm volatile("" ::: "memory");        // nothing of the pass may be hoisted out of the loop
-#endif
-            post_physics_env<false, true, ROLE_REW_A>(S, rk, csc0 + 1, le, E, nullptr, nullptr, smem + m.jpart, nullptr, nullptr, smem + m.terms);
-        }
-#endif
         post_physics_env<false, true, ROLE_REW_A>(S, rk, csc0 + 1, le, E, nullptr, nullptr, smem + m.jpart, nullptr, nullptr, smem + m.terms);
     } else if (role == 2)
         post_physics_env<false, true, ROLE_REW_B>(S, rk, csc0 + 1, le, E, nullptr, nullptr, smem + m.jpart, nullptr, nullptr, smem + m.terms);
@@ -1804,12 +1777,9 @@ HG_HD void env_stage_out(const EnvArgs& A, int block, int t, int nthreads, float
     const int N = A.cfg.num_envs, e0 = block * E;
     const int nE = kAssume ? E : ((E < N - e0) ? E : (N - e0));
     const LdsMap m = lds_map(E);
-#ifndef HGYM_STAGE_OUT_FAST
-#define HGYM_STAGE_OUT_FAST 1
-#endif
     if (kAssume) {
         env_stage_out_fast<E_T, true>(A, block, t, nthreads, smem);
-    } else if (!(HGYM_STAGE_OUT_FAST && env_stage_out_fast<E_T>(A, block, t, nthreads, smem))) {
+    } else if (!env_stage_out_fast<E_T>(A, block, t, nthreads, smem)) {
         copy_comp_rows<false>(nullptr, A, 0, kMutableComps, smem + m.state, E, e0, nE, N, t, nthreads);
         stage_sim<false>(A, m, smem, E, e0, nE, t, nthreads, A.mode == MODE_STEP && A.fused);   // the synthetic physics wrote contacts / rigid bodies
     }
@@ -2027,9 +1997,9 @@ HG_HD void stack_new_vec(const EnvArgs& A, float* __restrict__ ring, const float
             r.v[k] = v;
             o.v[k] = clampf(v, -lim, lim);
         }
-        st_stream4<(HGYM_ENV_NT & 4) != 0>(ring + ((int64_t)(e0 + le) * H + slot_new) * F + off, r);
-        st_stream4<(HGYM_ENV_NT & 4) != 0>(dst + (int64_t)le * row + (H - 1) * F + off, o);
-        if (ahead) st_stream4<(HGYM_ENV_NT & 4) != 0>(ahead + (int64_t)le * row + (H - 2) * F + off, o);
+        st_stream4<(kEnvNT & 4) != 0>(ring + ((int64_t)(e0 + le) * H + slot_new) * F + off, r);
+        st_stream4<(kEnvNT & 4) != 0>(dst + (int64_t)le * row + (H - 1) * F + off, o);
+        if (ahead) st_stream4<(kEnvNT & 4) != 0>(ahead + (int64_t)le * row + (H - 2) * F + off, o);
     }
 }
 
@@ -2121,7 +2091,7 @@ HG_HD void hist_load(const float* __restrict__ ring, int e0, int nE, int slot_ne
         const int le = i / S;
         int so, d_o;
         hist_slot<H, F, EXCL>(slot_new, i - le * S, so, d_o);
-        const EnvF4 q = ld_stream4<(HGYM_ENV_NT & 1) != 0>(ring + (int64_t)(e0 + le) * ROW + so);
+        const EnvF4 q = ld_stream4<(kEnvNT & 1) != 0>(ring + (int64_t)(e0 + le) * ROW + so);
         v[u][0] = q.v[0]; v[u][1] = q.v[1]; v[u][2] = q.v[2]; v[u][3] = q.v[3];
     }
 }
@@ -2140,7 +2110,7 @@ HG_HD void hist_store(float* __restrict__ dst, int e0, int nE, int slot_new, int
         EnvF4 q;
 #pragma unroll
         for (int k = 0; k < 4; ++k) q.v[k] = rs ? 0.0f : clampf(v[u][k], -lim, lim);
-        st_stream4<(HGYM_ENV_NT & 2) != 0>(dst + (int64_t)(e0 + le) * ROW + d_o, q);
+        st_stream4<(kEnvNT & 2) != 0>(dst + (int64_t)(e0 + le) * ROW + d_o, q);
     }
 }
 
@@ -2191,28 +2161,10 @@ HG_HD void env_step_phase_b(const EnvArgs& A, int block, int t, int nthreads, fl
     stack_reset_fix(A.st.obs_ring, s_reset, dobs, e0, nE, H, HGYM_OBS_FRAME, (int)(ring_step % H), t, nthreads, !old_rows_final, nreset, rlist);
     stack_reset_fix(A.st.priv_ring, s_reset, dpriv, e0, nE, HC, HGYM_PRIV_FRAME, (int)(ring_step % HC), t, nthreads, !old_rows_final, nreset,
                     rlist);
-    // (ahead_rows_fixed: the caller has zeroed the reset envs' older frames of the rows after next itself -- hist_zero_reset, from the
-    // lanes that stored them)
+    // (ahead_rows_fixed: the reset envs' older frames of the rows after next are zeroed elsewhere -- by the next launch, for the
+    // fused rollout launch: the kernel boundary orders the two stores)
     if (dahead && !ahead_rows_fixed) stack_reset_ahead(dahead, s_reset, nE, H, HGYM_OBS_FRAME, t, nthreads, nreset, rlist);
     if (pahead && !ahead_rows_fixed) stack_reset_ahead(pahead, s_reset, nE, HC, HGYM_PRIV_FRAME, t, nthreads, nreset, rlist);
-}
-
-// hist_store's items of the envs that reset, as zeros -- issued by the SAME lanes that stored the (pre-reset) frames there, so the
-// two stores to an address leave one wavefront in program order (no barrier between them has to wait for the first to be acknowledged)
-template <int H, int F, int NI, int EXCL = 1>
-HG_HD void hist_zero_reset(float* __restrict__ dst, int e0, int nE, int slot_new, int t, int nthreads, const int* s_reset) {
-    constexpr int S = HistGeom<H, F, EXCL>::kSlots, ROW = HistGeom<H, F, EXCL>::kRow;
-    const EnvF4 z = {{0.0f, 0.0f, 0.0f, 0.0f}};
-#pragma unroll
-    for (int u = 0; u < NI; ++u) {
-        int i = t + u * nthreads;
-        i = i < nE * S ? i : nE * S - 1;
-        const int le = i / S;
-        if (!s_reset[le]) continue;
-        int so, d_o;
-        hist_slot<H, F, EXCL>(slot_new, i - le * S, so, d_o);
-        st_stream4<(HGYM_ENV_NT & 2) != 0>(dst + (int64_t)(e0 + le) * ROW + d_o, z);
-    }
 }
 
 // Step finaliser (hgym_finalize.hpp) on an EnvArgs record.

@@ -298,36 +298,30 @@ HG_HD bool fin_fused(const FinArgs& F, int t, int nthreads) {      // (host-comp
 }
 
 // all of it, for one workgroup of `nthreads` lanes
-#ifndef HGYM_FIN_FUSED
-#define HGYM_FIN_FUSED 1
-#endif
 __device__ __forceinline__ void fin_block(const FinArgs& F, int t, int nthreads) {
     // fin_part2's counters travel with the first loads (nothing in between writes them): no round trip of their own at the end
     const bool bump_step = F.out.t_rewards && F.out.t_step && !F.out.defer_finalize;
     int64_t c0 = 0, c2 = 0, ts = 0;
-    if (HGYM_FIN_FUSED && t == 0) {
+    if (t == 0) {
         c0 = F.counters[0];
         c2 = F.counters[2];
         if (bump_step) ts = F.out.t_step[0];
     }
-    if (!(HGYM_FIN_FUSED && fin_fused(F, t, nthreads))) {
+    if (!fin_fused(F, t, nthreads)) {
         fin_part1(F, t, nthreads);
         __syncthreads();
         fin_store(F, t, nthreads);
     }
-    if (!(HGYM_FIN_FUSED && fin_log_fused(F, t, nthreads))) fin_log(F, t, nthreads);
+    if (!fin_log_fused(F, t, nthreads)) fin_log(F, t, nthreads);
     // every lane of the workgroup has loaded reset_count[0] (fin_fused's / fin_part1's first load) before thread 0 zeroes it: without
     // this barrier a late wavefront of a 512 / 1024-lane workgroup could read 0 and keep the stale time-out bytes
     __syncthreads();
     if (t == 0) {
-        if (HGYM_FIN_FUSED) {       // = fin_part2
-            if (bump_step) F.out.t_step[0] = ts + 1;
-            F.reset_count[0] = 0;
-            if (F.mode == FIN_MODE_STEP) F.counters[0] = c0 + 1;
-            if (F.mode != FIN_MODE_RESET_ALL) F.counters[2] = c2 + 1;
-        } else {
-            fin_part2(F);
-        }
+        // = fin_part2, on the values loaded above
+        if (bump_step) F.out.t_step[0] = ts + 1;
+        F.reset_count[0] = 0;
+        if (F.mode == FIN_MODE_STEP) F.counters[0] = c0 + 1;
+        if (F.mode != FIN_MODE_RESET_ALL) F.counters[2] = c2 + 1;
     }
 }
 

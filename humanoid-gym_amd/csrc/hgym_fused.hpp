@@ -84,12 +84,10 @@ __device__ __forceinline__ u32x2 pack_bf16x4(float a, float b, float c, float d)
     return __builtin_bit_cast(u32x2, v);
 }
 // Streaming accesses (data touched once per launch) carry the non-temporal hint so that they do not push the weight
-// fragments, which every workgroup re-reads, out of the XCD's L2: HGYM_NT bit 0 = input gather loads, bit 1 = X0 / H stores
+// fragments, which every workgroup re-reads, out of the XCD's L2: kFusedNT bit 0 = input gather loads, bit 1 = X0 / H stores
 // of the forward, bit 2 = H loads / dZ stores of the dZ chain.  Same-box A/B per minibatch (B = 61 440, storage 245 760 rows):
 // forward 265.6 -> 257.6..262.8 us (bit 0 alone 255), dZ chain 134.4 -> 127.5 us, dW (reads what those wrote) 185 -> 181 us.
-#ifndef HGYM_NT
-#define HGYM_NT 7
-#endif
+constexpr int kFusedNT = 7;
 typedef f32x4 f32x4_u4 __attribute__((aligned(4)));
 template <bool NT>
 __device__ __forceinline__ F4 ld_stream_f4(const float* p) {
@@ -120,12 +118,6 @@ __device__ __forceinline__ float bf16_bits_to_f32(unsigned int lo16) { return __
 // the odd 16-lane rows of A's register with the even rows of B's: afterwards a lane with q even holds columns 8 (q / 2) .. + 7 of row r of
 // block A (its own 8 bytes and its right neighbour's), a lane with q odd the same of block B -- one dwordx4 per lane for the pair, same
 // bytes, same addresses, half the store instructions.  HGYM_WIDE_ST=0 restores the dwordx2 form (A/B builds).
-#ifndef HGYM_WIDE_ST
-#define HGYM_WIDE_ST 1
-#endif
-#ifndef HGYM_WIDE_OLD
-#define HGYM_WIDE_OLD 0      // the 16-wave kernels of this file run at their 128-register cap: the pairing spills there (20 B of private segment)
-#endif
 template <bool NT>
 __device__ __forceinline__ void st_stream_u4(char* p, u32x4 v) {
     if (NT) __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(p));
@@ -139,17 +131,12 @@ __device__ __forceinline__ void st_pair(char* pa, char* pb, u32x2 a, u32x2 b, bo
         if (okb) st_stream_u2<NT>(pb, b);
         return;
     }
-#if HGYM_WIDE_ST
     const auto s0 = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false);
     const auto s1 = __builtin_amdgcn_permlane16_swap(a[1], b[1], false, false);
     const u32x4 v = {s0[0], s1[0], s0[1], s1[1]};
     const bool odd = q & 1;
     char* p = odd ? pb - 8 : pa;
     if (odd ? okb : oka) st_stream_u4<NT>(p, v);
-#else
-    if (oka) st_stream_u2<NT>(pa, a);
-    if (okb) st_stream_u2<NT>(pb, b);
-#endif
 }
 
 // ---- weight stream ------------------------------------------------------------------------------------------------------
@@ -345,15 +332,8 @@ __device__ __forceinline__ void mma_chunk(WRing<GR, D>& R, const u32x4* __restri
 // instructions per element (argument split, ldexp, two range selects) and the epilogues were VALU-bound on them; the result
 // is rounded to bf16 (2^-8 relative) right after, against this form's <= 1e-6 relative error for |z| <= 18.
 // HGYM_ELU_FAST=0 restores elu_f.
-#ifndef HGYM_ELU_FAST
-#define HGYM_ELU_FAST 1
-#endif
 __device__ __forceinline__ float elu_bf(float z) {
-#if HGYM_ELU_FAST
     return z > 0.0f ? z : (__builtin_amdgcn_exp2f(z * 1.4426950408889634f) - 1.0f);
-#else
-    return elu_f(z);
-#endif
 }
 
 // bias + ELU, bf16, -> LDS block layout (next layer's input) and, when Hg != null, the same blocks in HBM
@@ -379,7 +359,7 @@ __device__ __forceinline__ void epilogue_elu_t(f32x4 (&acc)[MB][G], const float*
             }
             if (STORE) {
                 char* pa = reinterpret_cast<char*>(Hg) + ((mbg0 + i) * CBo + nb0 + g) * 512 + loff;
-                st_pair<(HGYM_NT & 2) != 0, HGYM_WIDE_OLD != 0>(pa, pa + (int64_t)CBo * 512, pk[0], pk[1], true, true, q);
+                st_pair<(kFusedNT & 2) != 0, false>(pa, pa + (int64_t)CBo * 512, pk[0], pk[1], true, true, q);
             }
         }
     }
@@ -496,7 +476,7 @@ __device__ __forceinline__ void l0_partial_ahead(const FusedNet& n, const L0Ahea
             const u32x2 pk = pack_bf16x4(v[u].v[0], v[u].v[1], v[u].v[2], v[u].v[3]);
             *reinterpret_cast<u32x2*>(smem + ((row[u] >> 4) * CB + (c4[u] >> 4)) * 512 + (row[u] & 15) * 32 + ((c4[u] >> 2) & 3) * 8) = pk;
             if (ah.xs_next && m0 + row[u] < M && j0 + u * NW * 64 + tid < BM * groups)
-                st_stream_u2<(HGYM_NT & 2) != 0>(reinterpret_cast<char*>(ah.xs_next + (int64_t)(m0 + row[u]) * ah.ldxs + c4[u]), pk);
+                st_stream_u2<(kFusedNT & 2) != 0>(reinterpret_cast<char*>(ah.xs_next + (int64_t)(m0 + row[u]) * ah.ldxs + c4[u]), pk);
         }
     }
     __syncthreads();
@@ -632,7 +612,7 @@ __device__ __forceinline__ void fwd_body(const FwdArgs& a, const FusedNet& n, bo
         if (rowidx_lds && cb == 0 && hf == 0) rowidx_lds[row] = (int)src;
         const int loff = ((row >> 4) * 8 + cb) * 512 + (row & 15) * 32 + hf * 16;
         u32x4 stg;
-        auto stage_load = [&](int c) { stg = ld_stream_u4<(HGYM_NT & 1) != 0>(srow + c * (FUSED_CHUNK * 2)); };
+        auto stage_load = [&](int c) { stg = ld_stream_u4<(kFusedNT & 1) != 0>(srow + c * (FUSED_CHUNK * 2)); };
         auto stage_write = [&](int buf) { *reinterpret_cast<u32x4*>(Q + buf * (BM * FUSED_CHUNK * 2) + loff) = stg; };
         const int nb0 = wave * G1;
         f32x4 acc[MB][G1];
@@ -682,7 +662,7 @@ __device__ __forceinline__ void fwd_body(const FwdArgs& a, const FusedNet& n, bo
             const int col = c * FUSED_CHUNK + f4 * 4;
             const int cc = col < L0.K - 4 ? col : L0.K - 4;
 #pragma unroll
-            for (int u = 0; u < IT; ++u) stg[u] = ld_stream_f4<(HGYM_NT & 1) != 0>(srow[u] + cc);
+            for (int u = 0; u < IT; ++u) stg[u] = ld_stream_f4<(kFusedNT & 1) != 0>(srow[u] + cc);
         };
         auto stage_write = [&](int c, int buf) {
             char* dst = Q + buf * (BM * FUSED_CHUNK * 2);
@@ -706,10 +686,10 @@ __device__ __forceinline__ void fwd_body(const FwdArgs& a, const FusedNet& n, bo
                 const int inblk = (lrow[u] & 15) * 32 + (f4 & 3) * 8;
                 *reinterpret_cast<u32x2*>(dst + ((lrow[u] >> 4) * 8 + (f4 >> 2)) * 512 + inblk) = pk;
                 if (train)
-                    st_stream_u2<(HGYM_NT & 2) != 0>(reinterpret_cast<char*>(n.X0) +
+                    st_stream_u2<(kFusedNT & 2) != 0>(reinterpret_cast<char*>(n.X0) +
                                                      ((mbg0 + (lrow[u] >> 4)) * CB0 + c * 8 + (f4 >> 2)) * 512 + inblk, pk);
                 if (n.xs && m0 + lrow[u] < a.M)      // row m of the bf16 shadow (pad columns receive the zeros formed above)
-                    st_stream_u2<(HGYM_NT & 2) != 0>(reinterpret_cast<char*>(n.xs + (int64_t)(m0 + lrow[u]) * n.ldxs + col), pk);
+                    st_stream_u2<(kFusedNT & 2) != 0>(reinterpret_cast<char*>(n.xs + (int64_t)(m0 + lrow[u]) * n.ldxs + col), pk);
             }
         };
         const int nb0 = wave * G1;
@@ -913,7 +893,7 @@ __device__ __forceinline__ void bwd_step(WRing<GR, D>& R, const u32x4* __restric
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 if (HLDS) aux[i][g] = *reinterpret_cast<const u32x2*>(H_lds + (i * NBo + nb0 + g) * 512 + loff);
-                else aux[i][g] = ld_stream_u2<(HGYM_NT & 4) != 0>(reinterpret_cast<const char*>(Hg) + ((mbg0 + i) * NBo + nb0 + g) * 512 + loff);
+                else aux[i][g] = ld_stream_u2<(kFusedNT & 4) != 0>(reinterpret_cast<const char*>(Hg) + ((mbg0 + i) * NBo + nb0 + g) * 512 + loff);
             }
         static_assert(MB % 2 == 0, "row blocks are stored in pairs");
 #pragma unroll
@@ -933,7 +913,7 @@ __device__ __forceinline__ void bwd_step(WRing<GR, D>& R, const u32x4* __restric
                     if (out_lds) *reinterpret_cast<u32x2*>(out_lds + ((i + h) * NBo + nb0 + g) * 512 + loff) = pk[h];
                 }
                 char* pa = reinterpret_cast<char*>(dZg) + ((mbg0 + i) * NBo + nb0 + g) * 512 + loff;
-                st_pair<(HGYM_NT & 4) != 0, HGYM_WIDE_OLD != 0>(pa, pa + (int64_t)NBo * 512, pk[0], pk[1], true, true, q);
+                st_pair<(kFusedNT & 4) != 0, false>(pa, pa + (int64_t)NBo * 512, pk[0], pk[1], true, true, q);
             }
     }
     if (AHEAD && !primed) prime_next();
@@ -968,9 +948,6 @@ struct FbLoss {
 // LDS of the fused kernel behind the forward's P / Q / bias regions: the dZ3 tile (64 rows x 32 * layer[3].NBB bf16 columns), the
 // head waves' partial sums, and H2 (64 x layer[2].N bf16) -- the forward writes it there instead of over H0, so that all three
 // activations are resident for the dZ chain
-#ifndef HGYM_FB_PRE
-#define HGYM_FB_PRE 1      // 0: the head wavefronts gather their loss inputs themselves (A/B builds)
-#endif
 // ... and, behind H2, the storage row of each of the tile's 64 rows (256 B) and the loss inputs gathered through them: actor 64 x
 // [actions 12 | old mu 12 | old sigma 12 | advantage | old log-prob | pad 2] floats, critic 64 x [return | old value]
 constexpr int FB_LIN_ACTOR = 40;      // floats per row
@@ -996,7 +973,7 @@ __device__ __forceinline__ void fb_body(const FwdArgs& a, const FbLoss& L, const
     // The loss inputs of the tile's rows (scattered 48-byte rows and scalars of the storage) are gathered into LDS by the eight
     // wavefronts that have no strip in the 128-wide third layer, while the other eight compute it: the head wavefronts used to
     // start with two dependent round trips (a.idx[m], then the rows) -- 5 of an actor tile's 47 us.
-    const bool pre = HGYM_FB_PRE && !AUX && n.layer[2].NB <= 8 && (is_actor ? A == 12 : true);
+    const bool pre = !AUX && n.layer[2].NB <= 8 && (is_actor ? A == 12 : true);
     const float invB = 1.0f / (float)a.M;
     float aux_se = 0.0f;
     // auxiliary head: lane (r, q) of head wave hw, row m, outputs nb * 16 + 4q .. + 3 (called once per column block).

@@ -16,9 +16,11 @@
 
 #include "hgym_gemm.hpp"
 #include "hgym_fused.hpp"
-#include "hgym_fb2_api.hpp"      // mlp_fb2_kernel lives in a translation unit of its own (hgym_fb2.hip): see the note there
 
 namespace hgym {
+
+// hgym_update.hip
+int32_t launch_mlp_fb(const FwdArgs& fb, const FbLoss& fl, bool shadow, int tiles, int nets, size_t lds, hipStream_t s);
 
 // ------------------------------------------------------------------------------------------------ layouts
 struct LayerLayout {
@@ -793,8 +795,7 @@ struct NetRunner {
         a.M = M;
         a.idx = idx;
         if (fin) a.fin = *fin;
-        static const int fwd_ablate = getenv("HGYM_FWD_ABLATE") ? atoi(getenv("HGYM_FWD_ABLATE")) : 0;   // profiling only: 1 no X0 stores, 2 no H stores
-        a.train = train ? (3 & ~fwd_ablate) : 0;
+        a.train = train ? 3 : 0;
         a.A = cfg.num_actions;
         a.std_ = net.params;
         if (smp) {
@@ -938,35 +939,12 @@ struct NetRunner {
         const int64_t ldos[3] = {A, 1, 0};
         const int Bp = (int)round_up(B, 64);
         const int nets = aux_fb ? 3 : 2;
-        // 128-row tiles (hgym_fb2.hpp), OPT-IN (HGYM_FB2=1): measured equal to slightly slower than the 64-row kernel on every box of
-        // round 4 (282-340 vs 289-340 us per launch; profiles/r04_fb2_128row_tiles_negative_result.txt) -- the launch is paced by its
-        // 0.5 GB of H / dZ stores, not by the L2 -> CU weight stream the taller tile halves.  Shapes it carries: shadow rows, actor +
-        // critic only, XBot-L's widths (the kernel is instantiated for one shape pair: hgym_fb2.hpp says why), 12 actions.  Results are
-        // bit-identical to mlp_fb_kernel's (tests/test_fused_gpu.py).
-        const char* fb2_env = getenv("HGYM_FB2");                                // read per call: tests flip it
-        const bool no_fb2 = !(fb2_env && fb2_env[0] == '1');
-        bool fb2 = shadow && !no_fb2 && nets == 2 && A == 12;
-        for (int i = 0; i < 2 && fb2; ++i) {      // the one (actor, critic) shape pair the kernel is instantiated for: XBot-L's
-            const NetLayout& n = w.net[i];
-            fb2 = n.layer[1].N == 256 && n.layer[2].N == 128 && n.layer[3].N <= 16 &&
-                  n.layer[0].N == 256 * (i == 0 ? FB2_NCH_A : FB2_NCH_C) && (n.layer[0].KBf > 8) == (i == 0 ? FB2_STREAM_A : FB2_STREAM_C);
-        }
-        Fb2Sched sch = {0, 0};
-        if (fb2) {
-            // tiles of 7 or 8 row blocks: as many tiles per net as a whole number of rounds over the CUs when that keeps them >= 6 high
-            const int cus = device_cus() > 0 ? device_cus() : 256;
-            sch.nb = Bp / 16;
-            sch.T = ceil_div(sch.nb, 8);
-            const int Tr = (int)round_up(sch.T, cus);
-            if (sch.T > cus && sch.nb / Tr >= 6) sch.T = Tr;
-        }
-        const int tiles = fb2 ? sch.T : Bp / 64;
-        if (fb2) HG_REQUIRE(sch.nb <= MAX_LOSS_BLOCKS, HGYM_E_UNSUPPORTED, "minibatch %d too large for the loss partial buffer", B);
+        // (128-row tiles on eight 256-register wavefronts -- round 4's mlp_fb2_kernel -- measured equal to slightly slower:
+        // profiles/r04_fb2_128row_tiles_negative_result.txt; its source is kept under csrc/experiments/, outside the library.)
+        const int tiles = Bp / 64;
         HG_REQUIRE(tiles <= MAX_LOSS_BLOCKS, HGYM_E_UNSUPPORTED, "minibatch %d too large for the loss partial buffer", B);
         HG_REQUIRE(B <= w.maxM, HGYM_E_SHAPE, "minibatch %d exceeds max_batch %lld", B, (long long)w.maxM);
         int32_t rc = HGYM_OK;
-        const char* only = getenv("HGYM_GRAD_ONLY");      // timing experiments (tools/probe_overlap.py): "fb" / "dw" run just that launch
-        if (!(only && only[0] == 'd'))
         {   // forward + PPO loss + dZ chain of both nets: ONE launch (hgym_fused.hpp: mlp_fb_kernel)
             FwdArgs fa = make_fwd_args(0, nets, B, xs, ldxs, b.idx, outs, ldos, true, nullptr, nullptr);
             fa.net[2].X0 = nullptr;       // the head's first-layer operand for the weight gradient is the actor's copy (fused_dw)
@@ -995,34 +973,17 @@ struct NetRunner {
             fl.aux_ldt = cfg.num_priv;
             fl.aux_off = cfg.aux_target_offset;
             fl.aux_coef = ppo.aux_coef;
-            if (fb2) {
-                FwdArgs fb = fa;
-                fb.nets = nets;
-                fb.dbg = phase_buffer((int64_t)tiles * nets);
-                prof_begin(HGYM_PROF_MLP_FWD, s);
-                const int32_t rc2 = launch_fb2(fb, fl, sch, tiles, nets, s);
-                if (rc2) return rc2;
-                double flops = 0.0;
-                for (int i = 0; i < nets; ++i) {
-                    for (int l = 0; l < 4; ++l) flops += 2.0 * (double)B * w.net[i].layer[l].N * w.net[i].layer[l].K;
-                    for (int l = 1; l < 4; ++l) flops += 2.0 * (double)B * w.net[i].layer[l].K * w.net[i].layer[l].N;
-                }
-                prof_end(HGYM_PROF_MLP_FWD, s, flops);
-            } else {
             size_t lds = 0;
             for (int i = 0; i < nets; ++i)
                 lds = std::max(lds, (size_t)fused_lds_p(fa.net[i], 64) + (size_t)fused_lds_q(fa.net[i], 64) + (size_t)fused_lds_bias(fa.net[i]) +
                                         (size_t)fb_lds_extra(fa.net[i]));
             HG_REQUIRE(lds <= 160 * 1024, HGYM_E_UNSUPPORTED, "mlp_fb_kernel needs %zu bytes of LDS", lds);
-            const int32_t rc_lds = shadow ? ensure_dynamic_lds(reinterpret_cast<const void*>(&mlp_fb_kernel<true>), lds, "mlp_fb_kernel<shadow>")
-                                          : ensure_dynamic_lds(reinterpret_cast<const void*>(&mlp_fb_kernel<false>), lds, "mlp_fb_kernel");
-            if (rc_lds) return rc_lds;
             FwdArgs fb = fa;
             fb.nets = nets;
             fb.dbg = phase_buffer((int64_t)tiles * nets);
             prof_begin(HGYM_PROF_MLP_FWD, s);
-            if (shadow) hipLaunchKernelGGL(mlp_fb_kernel<true>, dim3(tiles, nets), dim3(1024), lds, s, fb, fl);
-            else hipLaunchKernelGGL(mlp_fb_kernel<false>, dim3(tiles, nets), dim3(1024), lds, s, fb, fl);
+            const int32_t rc_fb = launch_mlp_fb(fb, fl, shadow, tiles, nets, lds, s);      // (hgym_update.hip: the kernel's own code object)
+            if (rc_fb) return rc_fb;
             double flops = 0.0;
             for (int i = 0; i < nets; ++i) {
                 for (int l = 0; l < 4; ++l) flops += 2.0 * (double)B * w.net[i].layer[l].N * w.net[i].layer[l].K;
@@ -1030,19 +991,15 @@ struct NetRunner {
             }
             prof_end(HGYM_PROF_MLP_FWD, s, flops);
             HG_CHECK_LAUNCH("mlp_fb_kernel");
-            }
         }
         // the minibatch's loss scalars (per-tile partials -> opt_state, std / head-bias gradients, KL slot): one extra workgroup of
         // the weight-gradient launch that follows anyway (it needs nothing but the partials mlp_fb_kernel has just written)
-        // (mlp_fb2_kernel hands in one partial row per 16-row block; four of them are one 64-row tile's sum)
-        const ScalArgs sc = {fb2 ? Bp / 64 : tiles, B, A, aux_fb ? w.net[2].layer[3].N : 0, at<float>(w.partials), net.grads,
+        const ScalArgs sc = {tiles, B, A, aux_fb ? w.net[2].layer[3].N : 0, at<float>(w.partials), net.grads,
                              net.grads + w.net[0].layer[3].b_off, net.grads + w.net[1].layer[3].b_off, net.grads + w.P, net.opt_state,
                              (double)ppo.beta1, (double)ppo.beta2, prologue_in_grad(ppo) ? 1 : 0, ppo.adaptive_lr, ppo.desired_kl, ppo.lr_min,
-                             ppo.lr_max, fb2 ? 4 : 1};
-        if (only && only[0] == 'f') return HGYM_OK;
+                             ppo.lr_max, 1};
         rc = fused_dw(0, nets, B, &sc, gb);
         if (rc) return rc;
-        if (only && only[0] == 'd') return HGYM_OK;
         if (w.nnets > 2 && !aux_fb) {
             const int32_t rca = aux_grad(ppo, b);
             if (rca) return rca;
@@ -1264,10 +1221,7 @@ struct NetRunner {
 
     // The fused path on one rank with grad_norm_ready: the loss-scalar workgroup that rides in the weight-gradient launch has already taken
     // the learning-rate decision and prepared Adam's step scalars (ScalArgs::do_prologue); hgym_ppo_apply then starts with Adam.
-#ifndef HGYM_PROLOGUE_IN_GRAD
-#define HGYM_PROLOGUE_IN_GRAD 1      // 0: apply_prologue_kernel as its own launch everywhere (A/B builds)
-#endif
-    bool prologue_in_grad(const HgymPPOConfig& ppo) const { return HGYM_PROLOGUE_IN_GRAD && w.fused && ppo.world_size <= 1 && ppo.grad_norm_ready != 0; }
+    bool prologue_in_grad(const HgymPPOConfig& ppo) const { return w.fused && ppo.world_size <= 1 && ppo.grad_norm_ready != 0; }
 
     int32_t apply(const HgymPPOConfig& ppo) {
         prof_begin(HGYM_PROF_APPLY, s);

@@ -34,24 +34,6 @@
 #include "hgym_env_math.hpp"
 #include "hgym_fused.hpp"
 
-#ifndef HGYM_ENV_SPLIT
-#ifndef HGYM_RO_DRAWS_AHEAD
-#define HGYM_RO_DRAWS_AHEAD 1    // the next step's env draws computed by the critic workgroups of this launch (0: every launch draws its own)
-#endif
-#define HGYM_ENV_SPLIT 1       // the split per-env chain (hgym_env_math.hpp: env_step_phase_j / _a<split> / _f); 0: the monolithic one
-#endif
-#ifndef HGYM_RO_DRAWS_IDLE
-#define HGYM_RO_DRAWS_IDLE 1
-#endif
-#ifndef HGYM_RO_INTERLEAVE
-#define HGYM_RO_INTERLEAVE 1
-#endif
-#ifndef HGYM_RO_HIST_IDLE
-#define HGYM_RO_HIST_IDLE 1    // the older observation frames are stored by the six wavefronts idle during the head, under it (0: behind the tile)
-#endif
-#ifndef HGYM_RO_VARIANT
-#define HGYM_RO_VARIANT 0      // experiments only: 1 = policy tiles alone (no env work at all), 2 = env part without its early loads
-#endif
 
 namespace hgym {
 
@@ -92,55 +74,24 @@ struct RolloutPP {
     // workgroups left for this step (PART instantiation), ah.acc_out = where this launch's leave the next step's (null: not).
     L0Part l0;
     L0Ahead ah;
-    const uint8_t* prev_reset;   // reset flags of the previous step (prev_out->reset; null: first step of a rollout), see HGYM_RO_AHEAD_CRITIC
+    const uint8_t* prev_reset;   // reset flags of the previous step (prev_out->reset; null: first step of a rollout), see the rows-after-next note below
 };
 
 constexpr int RO_NIO = hist_ni<15, HGYM_OBS_FRAME, RO_E, RO_NT>();
 constexpr int RO_NIP = hist_ni<3, HGYM_PRIV_FRAME, RO_E, RO_NT>();
-#ifndef HGYM_W3_PROBE
-#define HGYM_W3_PROBE 0
-#endif
-#ifndef HGYM_HWID_PROBE
-#define HGYM_HWID_PROBE 0
-#endif
-#ifndef HGYM_RO_LDS_BARRIER
-#define HGYM_RO_LDS_BARRIER 0   // 1: the barriers behind the per-env phase and behind phase F order LDS traffic only (ro_lds_barrier)
-#endif
-// __syncthreads() also waits for every global-memory operation the wavefront has in flight (one counter for loads and stores), i.e.
-// for the acknowledgement of the rows-after-next stores issued during the per-env phase.  A barrier that waits for the LDS operations
-// only lets those stores retire behind the following phases -- and was measured SLOWER (collection 2.38 vs 2.29 ms, same call): what
-// a workgroup does not wait for in the middle it waits for at its end, where nothing overlaps it (as HGYM_RO_AHEAD_LATE).  Kept as a
-// switch for that measurement.  With it, a later store of ANOTHER wavefront to the same address must not rely on the barrier (reset
-// envs' frames of the rows after next: hist_zero_reset, from the lanes that stored them).
-__device__ __forceinline__ void ro_lds_barrier() {
-#if HGYM_RO_LDS_BARRIER
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#else
-    __syncthreads();
-#endif
-}
-#ifndef HGYM_RO_ASSUME_FAST
-#define HGYM_RO_ASSUME_FAST 0   // 1: the staging phases' general paths (never taken in this launch: rollout_env_args refuses every layout but the fast
-#endif                          //    one) are compiled out of it -- prepared at the end of round 4, not yet run on a GPU
-constexpr bool RO_AF = HGYM_RO_ASSUME_FAST != 0;
-#ifndef HGYM_RO_AHEAD_CRITIC
-#define HGYM_RO_AHEAD_CRITIC 1
-#endif
-// HGYM_RO_AHEAD_CRITIC: the rows after next (obs_ahead / priv_ahead: 13 + 1 older frames per env, ring -> rows, 78 KB per tile) are copied
-// by the tile's CRITIC workgroup at its start, not by the idle wavefronts of the actor workgroup's per-env phase -- in a run of launches
-// that phase waited 7 us for the copy's loads and acknowledged stores, against 4.5 us for its own arithmetic, and the critic workgroup
-// ends ~3 us before the actor's.  The copy reads pre-reset history for an env that resets in THIS step; nobody reads those rows before
-// the next launch, which zeroes them (prev_reset) -- the kernel boundary orders the two workgroups' stores to the same addresses.
-constexpr bool RO_AHC = HGYM_RO_AHEAD_CRITIC != 0;
+// The rows after next (obs_ahead / priv_ahead: 13 + 1 older frames per env, ring -> rows, 78 KB per tile) are copied by the tile's CRITIC
+// workgroup at its start, not by the idle wavefronts of the actor workgroup's per-env phase -- in a run of launches that phase waited
+// 7 us for the copy's loads and acknowledged stores, against 4.5 us for its own arithmetic, and the critic workgroup ends ~3 us before
+// the actor's.  The copy reads pre-reset history for an env that resets in THIS step; nobody reads those rows before the next launch,
+// which zeroes them (prev_reset) -- the kernel boundary orders the two workgroups' stores to the same addresses.  (Measured and dropped:
+// the copy on the actor workgroup's idle wavefronts, its stores as the launch's last instructions, LDS-only barriers around the per-env
+// phase -- profiles/r04_rollout_env_part_findings.txt.)
+// The staging phases (env_stage_in / env_stage_out) are instantiated for the one layout this launch accepts (rollout_env_args refuses
+// every other): their general paths are compiled out -- 122 -> 108 KB of code, collection 2.99 -> 2.96 ms in a same-call A/B
+// (profiles/r05a_bench_ab_base_rofast_dw32.txt).
 constexpr int RO_NIA_C = hist_ni<15, HGYM_OBS_FRAME, RO_E, RO_NT, 2>();
 constexpr int RO_NIAP_C = hist_ni<3, HGYM_PRIV_FRAME, RO_E, RO_NT, 2>();
-constexpr bool RO_W3 = HGYM_ENV_SPLIT && HGYM_ENV_WAVES3;
-constexpr int RO_CHAIN = RO_W3 ? 64 * kChainRoles : 64;     // lanes of the per-env chain; the others fetch the rows after next meanwhile
-#ifndef HGYM_RO_AHEAD_LATE
-#define HGYM_RO_AHEAD_LATE 0   // 1: the rows after next are STORED as the launch's last instructions (shorter per-env phase, but the workgroup then ends with their acknowledgement: measured +0.05 ms per rollout)
-#endif
-constexpr int RO_NIA = hist_ni<15, HGYM_OBS_FRAME, RO_E, RO_NT - RO_CHAIN, 2>();      // rows written one launch ahead: 13 frames
-constexpr int RO_NIAP = hist_ni<3, HGYM_PRIV_FRAME, RO_E, RO_NT - RO_CHAIN, 2>();      // ... and the one privileged frame
+constexpr int RO_CHAIN = 64 * kChainRoles;     // lanes of the per-env chain: four wavefronts by role (env_step_phase_a3)
 
 // PRE (HgymEnvOut.obs_older_ready): the 14 older frames of this launch's stacked observation rows were written by the previous launch
 // (as its obs_ahead), so the copy ring -> rows -- 11 HBM loads per lane issued after the first layer, in front of the second layer's
@@ -161,13 +112,9 @@ __global__ __launch_bounds__(RO_NT) void rollout_step_kernel(const FwdArgs f, co
         return;
     }
     constexpr int U = 16 / 8;                       // n-blocks per wave per 256 first-layer columns (mlp_fwd_kernel)
-#if HGYM_RO_INTERLEAVE
     // actor and critic workgroups alternate in dispatch order (tile b: row 0 holds its actor when b is even, its critic when b
     // is odd), so that the long actor + env workgroups are spread evenly over neighbouring compute units
     const bool critic_wg = ((blockIdx.x + blockIdx.y) & 1) != 0;
-#else
-    const bool critic_wg = blockIdx.y == 1;
-#endif
     if (critic_wg) {                                // critic tile
         // one instantiation only (first hidden layer 768 wide, rollout_fwd_args checks): with the three-way dispatch of
         // mlp_fwd_kernel next to the actor + env branch the compiler keeps a private-memory copy of the whole 3 KB argument
@@ -176,17 +123,14 @@ __global__ __launch_bounds__(RO_NT) void rollout_step_kernel(const FwdArgs f, co
         // over; they travel while the draws are computed; the stores' acknowledgements are waited for under the first-layer weights below
         float ha[RO_NIA_C][4], hp[RO_NIAP_C][4];
         const int ring_s = (int)pp.in[1];
-        if (RO_AHC) {       // (unconditional: the ring always exists; a launch without rows after next drops them)
-            hist_load<15, HGYM_OBS_FRAME, RO_NIA_C, 2>(e.st.obs_ring, (int)blockIdx.x * RO_E, RO_E, ring_s % 15, (int)threadIdx.x, RO_NT, ha);
-            hist_load<3, HGYM_PRIV_FRAME, RO_NIAP_C, 2>(e.st.priv_ring, (int)blockIdx.x * RO_E, RO_E, ring_s % 3, (int)threadIdx.x, RO_NT, hp);
-        }
-#if HGYM_RO_DRAWS_AHEAD
+        // (unconditional: the ring always exists; a launch without rows after next drops them)
+        hist_load<15, HGYM_OBS_FRAME, RO_NIA_C, 2>(e.st.obs_ring, (int)blockIdx.x * RO_E, RO_E, ring_s % 15, (int)threadIdx.x, RO_NT, ha);
+        hist_load<3, HGYM_PRIV_FRAME, RO_NIAP_C, 2>(e.st.priv_ring, (int)blockIdx.x * RO_E, RO_E, ring_s % 3, (int)threadIdx.x, RO_NT, hp);
         if (pp.draws_out) {      // next step's draw tables of this tile (step counter + 1), written where the LDS tables would be
             float* base = pp.draws_out + (int64_t)blockIdx.x * pp.draws_len - lds_map(RO_E).u_delay;
             env_fill_draws<RO_E>(e, (int)blockIdx.x, (int)threadIdx.x, RO_NT, base, pp.in[0] + 1);
         }
-#endif
-        if (RO_AHC && e.out.obs_ahead) {
+        if (e.out.obs_ahead) {
             hist_store<15, HGYM_OBS_FRAME, RO_NIA_C, 2>(e.out.obs_ahead, (int)blockIdx.x * RO_E, RO_E, ring_s % 15, (int)threadIdx.x, RO_NT, nullptr,
                                                         e.cfg.clip_obs, ha);
             hist_store<3, HGYM_PRIV_FRAME, RO_NIAP_C, 2>(e.out.priv_ahead, (int)blockIdx.x * RO_E, RO_E, ring_s % 3, (int)threadIdx.x, RO_NT, nullptr,
@@ -204,22 +148,10 @@ __global__ __launch_bounds__(RO_NT) void rollout_step_kernel(const FwdArgs f, co
     float* esm = reinterpret_cast<float*>(smem + pp.env_lds_off);
     float hist_o[RO_NIO][4], hist_p[RO_NIP][4];
     const int act_off = lds_map(RO_E).actions_in;
-#if HGYM_RO_DRAWS_AHEAD
     const float* const draws_in = pp.draws_in ? pp.draws_in + (int64_t)block * pp.draws_len : nullptr;
     const int draws_len = pp.draws_len;
-#else
-    const float* const draws_in = nullptr;
-    const int draws_len = 0;
-#endif
     auto early = [&](const EnvArgs& E) {
-#if HGYM_RO_VARIANT == 3
-        env_fill_draws<RO_E>(E, block, t, RO_NT, esm, csc0);
-#elif HGYM_RO_VARIANT == 4
-        if (t < 256) env_stage_in<RO_E, RO_AF>(E, block, t, 256, esm);
-#endif
-#if HGYM_RO_VARIANT == 0
         env_reset_pose<RO_E>(E, t, RO_NT, esm);                       // one lane, under the tile's first loads
-#if HGYM_RO_DRAWS_IDLE
         // this step's draw tables, computed during the previous launch: a plain copy that travels with the tile's first loads
         // (plain float quads and unconditional clamped loads: a packed-struct array behind a condition is kept in private memory)
         float dq[2][4];
@@ -231,7 +163,7 @@ __global__ __launch_bounds__(RO_NT) void rollout_step_kernel(const FwdArgs f, co
             const int i = t + u * RO_NT;
             stage_ld(dq[u], dsrc + 4 * (i < dmax ? i : dmax));
         }
-        if (t < 256) env_stage_in<RO_E, RO_AF>(E, block, t, 256, esm);      // travels with the tile's own first loads
+        if (t < 256) env_stage_in<RO_E, true>(E, block, t, 256, esm);      // travels with the tile's own first loads
         if (draws_in) {
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
@@ -239,32 +171,17 @@ __global__ __launch_bounds__(RO_NT) void rollout_step_kernel(const FwdArgs f, co
                 if (i < dq4) stage_st(esm + dq_off + 4 * i, dq[u]);
             }
         }
-#else
-        // issue the state / sim loads, compute the draws under them, then write the loaded quads to the env image
-        StageRegs<RO_E> R;
-        R.fast = 0;
-        if (t < 256) env_stage_in_load<RO_E, RO_AF>(E, block, t, 256, R);
-        env_fill_draws<RO_E>(E, block, t, RO_NT, esm, csc0);
-        if (t < 256) env_stage_in_store<RO_E, RO_AF>(E, block, t, 256, esm, R);
-#endif
-#endif
     };
     auto mid = [&](const EnvArgs& E) {
-#if HGYM_RO_VARIANT == 0 || HGYM_RO_VARIANT == 5
         if (!PRE) hist_load<15, HGYM_OBS_FRAME, RO_NIO>(E.st.obs_ring, block * RO_E, RO_E, (int)(ring_step % 15), t, RO_NT, hist_o);
-#endif
     };
     auto put = [&](int row, int j, float v) { esm[act_off + row * 12 + j] = v; };
     // the env step's Philox draws: on the six wavefronts that have no head block, while the other two compute the head
     auto idle = [&](const EnvArgs& E) {
-#if HGYM_RO_DRAWS_IDLE && HGYM_RO_VARIANT == 0 && !defined(HGYM_RO_NO_DRAWS)
         if (!draws_in) env_fill_draws<RO_E>(E, block, t - 128, RO_NT - 128, esm, csc0);
-#endif
-#if HGYM_RO_HIST_IDLE && HGYM_RO_VARIANT == 0
         // these lanes' share of the 14 older frames (in registers since `mid`) -> the stacked rows of the next observation, while
         // the two head wavefronts finish the tile: three quarters of that store phase leave the chain behind the tile
         if (!PRE) hist_store<15, HGYM_OBS_FRAME, RO_NIO>(E.out.obs, block * RO_E, RO_E, (int)(ring_step % 15), t, RO_NT, nullptr, E.cfg.clip_obs, hist_o);
-#endif
     };
     fwd_body<32, 8, 4, 2 * U, false, false, PART>(f, f.net[0], true, smem, early, mid, put, e, idle, FwdNoop(), nullptr, nullptr, FwdNoop(), &pp.l0);
     if (PART && f.net[0].xs) {
@@ -284,91 +201,33 @@ __global__ __launch_bounds__(RO_NT) void rollout_step_kernel(const FwdArgs f, co
         if (dbg && t == 0) dbg[slot] = (long long)__builtin_amdgcn_s_memrealtime();
     };
     stamp(0);
-#if HGYM_RO_VARIANT == 1
-    return;
-#endif
-    // (HGYM_RO_AHEAD_CRITIC) did the previous step reset this lane's env of the tile?  Loaded HERE, consumed behind phase B: read there it
+    // did the previous step reset this lane's env of the tile?  Loaded HERE, consumed behind phase B: read there it
     // is a memory round trip at the very end of the workgroup
-    const bool prev_rs = RO_AHC && PRE && pp.prev_reset && (t & 63) < RO_E && pp.prev_reset[block * RO_E + (t & (RO_E - 1))] != 0;
+    const bool prev_rs = PRE && pp.prev_reset && (t & 63) < RO_E && pp.prev_reset[block * RO_E + (t & (RO_E - 1))] != 0;
     const EnvArgs& A = e;
     // the two older privileged frames (12 registers the policy tile could not spare): loaded here, stored behind the joints phase
     if (!PRE) hist_load<3, HGYM_PRIV_FRAME, RO_NIP>(A.st.priv_ring, block * RO_E, RO_E, (int)(ring_step % 3), t, RO_NT, hist_p);
     if (!PRE) {
-#if HGYM_RO_HIST_IDLE && HGYM_RO_VARIANT == 0
         if (t < 128)          // the head wavefronts' share; the others stored theirs under the head (idle hook)
-#endif
             hist_store<15, HGYM_OBS_FRAME, RO_NIO>(A.out.obs, block * RO_E, RO_E, (int)(ring_step % 15), t, RO_NT, nullptr, A.cfg.clip_obs, hist_o);
     }
-#if HGYM_HWID_PROBE   // tools/probe_placement.py: slot 1 = where the workgroup runs: XCC_ID (bits 32..35) | HW_ID (se / sh / cu / simd / wave fields, bits 0..31)
-    if (dbg && t == 0) dbg[1] = ((long long)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15) << 32) | (long long)(unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
-#elif HGYM_W3_PROBE     // tools/probe_w3.py: slot 1 = the SIMD every wavefront of the workgroup runs on (4 bits each), 4..7 = ends of the chain's roles
-    if (dbg && (t & 63) == 0) atomicAdd(reinterpret_cast<unsigned long long*>(dbg + 1),
-                                        (unsigned long long)__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4) << (4 * (t >> 6)));
-#else
     stamp(1);
-#endif
-#if HGYM_ENV_SPLIT
-    env_step_phase_j<RO_E, RO_W3>(A, block, t, RO_NT, esm);       // joints + per-joint reward products; synthetic-physics remainder on waves 6, 7
-#else
-    env_step_joints<RO_E>(A, block, t, RO_NT, esm);
-#endif
+    env_step_phase_j<RO_E, true>(A, block, t, RO_NT, esm);       // joints + per-joint reward products; synthetic-physics remainder on waves 6, 7
     if (!PRE)
         hist_store<3, HGYM_PRIV_FRAME, RO_NIP>(A.out.priv_obs, block * RO_E, RO_E, (int)(ring_step % 3), t, RO_NT, nullptr, A.cfg.clip_obs,
                                                hist_p);
     __syncthreads();
     stamp(2);
-    // rows after next (obs_ahead): the 13 frames older than this step's and the next one's, from the ring as this launch found it
-    // The stores wait for nothing this launch computes except the reset flags, and a barrier waits for every store issued before it
-    // (one counter for loads and stores): with HGYM_RO_AHEAD_LATE they are the launch's last instructions -- reset envs' frames go out
-    // as zeros there, as phase B's stack_reset_ahead would have left them.
-    float hist_a[RO_NIA][4], hist_ap[RO_NIAP][4];
-    auto ahead_load = [&]() {       // (unconditional: the ring always exists; a launch without rows after next drops them)
-        hist_load<15, HGYM_OBS_FRAME, RO_NIA, 2>(A.st.obs_ring, block * RO_E, RO_E, (int)(ring_step % 15), t - RO_CHAIN, RO_NT - RO_CHAIN, hist_a);
-        hist_load<3, HGYM_PRIV_FRAME, RO_NIAP, 2>(A.st.priv_ring, block * RO_E, RO_E, (int)(ring_step % 3), t - RO_CHAIN, RO_NT - RO_CHAIN, hist_ap);
-    };
-    auto ahead_store = [&](const int* s_reset) {
-        if (A.out.obs_ahead) {
-            hist_store<15, HGYM_OBS_FRAME, RO_NIA, 2>(A.out.obs_ahead, block * RO_E, RO_E, (int)(ring_step % 15), t - RO_CHAIN, RO_NT - RO_CHAIN, s_reset,
-                                                      A.cfg.clip_obs, hist_a);
-            hist_store<3, HGYM_PRIV_FRAME, RO_NIAP, 2>(A.out.priv_ahead, block * RO_E, RO_E, (int)(ring_step % 3), t - RO_CHAIN, RO_NT - RO_CHAIN, s_reset,
-                                                       A.cfg.clip_obs, hist_ap);
-        }
-    };
-    auto ahead = [&]() {
-        if (RO_AHC) return;          // the critic workgroup of the tile has done it
-        ahead_load();
-        if (!HGYM_RO_AHEAD_LATE) ahead_store(nullptr);
-    };
-#if HGYM_ENV_SPLIT
-    if (t < RO_CHAIN) {
-        if (RO_W3) env_step_phase_a3<RO_E>(A, block, t, RO_NT, esm, csc0);
-        else env_step_phase_a<RO_E, false, true>(A, block, t, esm, csc0);
-    } else ahead();
-#if HGYM_W3_PROBE
-    if (dbg && (t & 63) == 0 && t <= 256) dbg[t < 256 ? 4 + (t >> 6) : 0] = (long long)__builtin_amdgcn_s_memrealtime();     // wavefronts 0-3 -> slots 4-7, wavefront 4 -> slot 0
-#endif
-    ro_lds_barrier();
-    if (HGYM_RO_LDS_BARRIER && !HGYM_RO_AHEAD_LATE && !RO_AHC && t >= RO_CHAIN && A.out.obs_ahead &&
-        reinterpret_cast<const int*>(esm + lds_map(RO_E).reset_cnt)[0] > 0) {       // (phase B's stack_reset_ahead, from the lanes that own the items)
-        const int* s_reset = reinterpret_cast<const int*>(esm + lds_map(RO_E).reset_i);
-        hist_zero_reset<15, HGYM_OBS_FRAME, RO_NIA, 2>(A.out.obs_ahead, block * RO_E, RO_E, (int)(ring_step % 15), t - RO_CHAIN, RO_NT - RO_CHAIN, s_reset);
-        hist_zero_reset<3, HGYM_PRIV_FRAME, RO_NIAP, 2>(A.out.priv_ahead, block * RO_E, RO_E, (int)(ring_step % 3), t - RO_CHAIN, RO_NT - RO_CHAIN, s_reset);
-    }
-    env_step_phase_f<RO_E>(A, block, t, RO_NT, esm);       // per-joint reset / reference pose / frame entries / last_* copies
-    if (RO_W3) env_step_reward_sum<RO_E>(A, block, t, RO_NT, esm);   // (the last wavefront: phase F has the first six)
-    ro_lds_barrier();
-#else
-    if (t < 64) env_step_phase_a<RO_E, false>(A, block, t, esm, csc0);
-    else ahead();
+    if (t < RO_CHAIN) env_step_phase_a3<RO_E>(A, block, t, RO_NT, esm, csc0);      // the per-env chain, four wavefronts by role
     __syncthreads();
-#endif
+    env_step_phase_f<RO_E>(A, block, t, RO_NT, esm);       // per-joint reset / reference pose / frame entries / last_* copies
+    env_step_reward_sum<RO_E>(A, block, t, RO_NT, esm);   // (the last wavefront: phase F has the first six)
+    __syncthreads();
     stamp(3);
-    env_stage_out<RO_E, RO_AF>(A, block, t, RO_NT, esm);
-#if !HGYM_W3_PROBE
+    env_stage_out<RO_E, true>(A, block, t, RO_NT, esm);
     stamp(4);
-#endif
-    env_step_phase_b<15, 3, RO_E>(A, block, t, RO_NT, esm, csc0, ring_step, false, RO_AHC || (HGYM_RO_LDS_BARRIER && !HGYM_RO_AHEAD_LATE));
-    if (RO_AHC && PRE && pp.prev_reset) {
+    env_step_phase_b<15, 3, RO_E>(A, block, t, RO_NT, esm, csc0, ring_step, false, true);
+    if (PRE && pp.prev_reset) {
         // this launch's next-observation rows were pre-written by the previous launch from the history as IT found it: an env the previous
         // step reset has zero older frames (13 of 15, 1 of 3) -- every wavefront reads the tile's 32 flags, loops over the set ones
         const unsigned long long mask = __ballot(prev_rs);
@@ -380,10 +239,7 @@ __global__ __launch_bounds__(RO_NT) void rollout_step_kernel(const FwdArgs f, co
             for (int i = t; i < HGYM_PRIV_FRAME; i += RO_NT) dpriv[i] = 0.0f;
         }
     }
-#if !HGYM_W3_PROBE
     stamp(5);
-#endif
-    if (HGYM_RO_AHEAD_LATE && !RO_AHC && t >= RO_CHAIN) ahead_store(reinterpret_cast<const int*>(esm + lds_map(RO_E).reset_i));
     if (block == 0 && t == 0) {
         pp.out[0] = csc0 + 1;
         pp.out[1] = ring_step + 1;
@@ -447,9 +303,6 @@ int32_t hgym_rollout_step(const HgymNetConfig* cfg, const HgymNet* net, const Hg
     int32_t rc = rollout_fwd_args(cfg, net, M, obs, priv, seed, &scr->pp[parity][2], actions, mu, sigma, logp, values, &f, &lds_pol, shadow);
     if (rc) return rc;
     rc = rollout_env_args(env_cfg, sim, st, out, actions, &e);
-#if HGYM_W3_PROBE
-    if (rc == HGYM_OK && getenv("HGYM_W3_REPS")) e.ablate = atoi(getenv("HGYM_W3_REPS")) << 8;      // tools/probe_w3.py
-#endif
     if (rc) return rc;
     HG_REQUIRE(out->t_values == values, HGYM_E_BADARG, "the transition sink must take this launch's values");
     e.reset_count = &scr->reset_cnt[parity];

@@ -475,51 +475,6 @@ def test_first_layer_carried_across_launches_changes_nothing(monkeypatch, kb0):
     assert torch.isfinite(a["params"]).all()
 
 
-@pytest.mark.parametrize("S,B", [(700, 333), (5000, 4096), (61440, 61440)])
-def test_update_on_128_row_tiles_equals_update_on_64_row_tiles(monkeypatch, S, B):
-    """`mlp_fb2_kernel` (csrc/hgym_fb2.hpp: 128-row tiles, eight 256-register wavefronts, H0 never resident, tiles of 7 or 8 row
-    blocks; opt-in with HGYM_FB2=1 -- measured no faster, profiles/r04_fb2_128row_tiles_negative_result.txt) against `mlp_fb_kernel`:
-    every product sums over k in the same order and the per-row-block loss partials are grouped as the 64-row tile groups its head
-    waves, so the whole gradient is BIT-identical; only the KL statistic may differ in its last fp32 bit (the two kernels' KL
-    expressions are contracted into different fused multiply-adds by the compiler).  Reference: /root/reference/humanoid/algo/ppo/ppo.py:128-171."""
-    from hgym import make_ppo_config, make_batch
-    g = torch.Generator().manual_seed(7 * S + B)
-    p = P.Params.random(705, 219, 12, K.ACTOR_HIDDEN, K.CRITIC_HIDDEN, g)
-    net = _net("bf16", max(B, 512))
-    net.load_state_dict(dict(zip(NAMES, p.tensors())))
-    dev = "cuda"
-    gd = torch.Generator(device=dev).manual_seed(S)
-    obs, priv = torch.randn(S, 705, device=dev, generator=gd).clamp_(-18, 18), torch.randn(S, 219, device=dev, generator=gd).clamp_(-18, 18)
-    act, mu_o = torch.randn(S, 12, device=dev, generator=gd), torch.randn(S, 12, device=dev, generator=gd) * 0.3
-    sg_o = torch.rand(S, 12, device=dev, generator=gd) * 0.5 + 0.75
-    val, adv, ret = (torch.randn(S, device=dev, generator=gd) for _ in range(3))
-    lp_o = -12.0 + torch.randn(S, device=dev, generator=gd)
-    idx = torch.randperm(S, device=dev, generator=gd)[:B].contiguous()
-    so = torch.zeros(S, 768, dtype=torch.bfloat16, device=dev)
-    sp = torch.zeros(S, 256, dtype=torch.bfloat16, device=dev)
-    so[:, :705] = obs.to(torch.bfloat16)
-    sp[:, :219] = priv.to(torch.bfloat16)
-    batch = make_batch(obs, priv, act, val, adv, ret, lp_o, mu_o, sg_o, idx, obs_bf16=so, priv_bf16=sp)
-    res = {}
-    for mode in ("64", "128", "128 again"):
-        if mode == "64":
-            monkeypatch.delenv("HGYM_FB2", raising=False)
-        else:
-            monkeypatch.setenv("HGYM_FB2", "1")
-        net.grads_ext.zero_()
-        net.opt_state[2:10] = 0.0
-        net.ppo_grad(make_ppo_config(), batch)
-        torch.cuda.synchronize()
-        res[mode] = (net.grads_ext.clone(), net.opt_state.clone())
-    for mode in ("128", "128 again"):
-        assert torch.equal(res[mode][0][:-1], res["64"][0][:-1]), mode                      # every gradient tensor, bit for bit
-        np.testing.assert_allclose(float(res[mode][0][-1]), float(res["64"][0][-1]), rtol=1e-6)          # the KL slot
-        o, w = res[mode][1], res["64"][1]
-        assert torch.equal(o[3:8], w[3:8])                                                  # surrogate / value / entropy sums, counters
-        np.testing.assert_allclose(o[[2, 8]].cpu().numpy(), w[[2, 8]].cpu().numpy(), rtol=1e-6)
-        np.testing.assert_allclose(float(o[9]), float(w[9]), rtol=1e-12)
-
-
 def test_runner_update_reads_the_shadow_the_rollout_wrote(monkeypatch):
     """End to end: two learning iterations with the shadow (default) and without (HGYM_SHADOW=0) from the same seeds end in
     bit-identical parameters, and the shadow slots hold the bf16 of the stored observation rows."""

@@ -9,7 +9,7 @@ import csv, json, re, sys
 from collections import defaultdict
 
 NAMES = {"rollout_step_kernel<true, true, true": "rollout_step_kernel", "rollout_step_kernelILb1ELb1ELb1": "rollout_step_kernel",
-         "mlp_fb_kernel": "mlp_fb_kernel", "mlp_fb2_kernel": "mlp_fb2_kernel", "env_step_kernel": "env_step_kernel",
+         "mlp_fb_kernel": "mlp_fb_kernel", "env_step_kernel": "env_step_kernel",
          "dw_kernel": "dw_kernel", "reduce_slabs_kernel": "reduce_slabs_kernel", "adam_kernel": "sqnorm+adam_kernel", "gae_kernel": "gae_kernel",
          "mlp_fwd_kernelILi32": "mlp_fwd_kernel<32>", "mlp_fwd_kernel<32": "mlp_fwd_kernel<32>"}
 XCDS, SIMDS = 8, 1024

@@ -61,4 +61,4 @@ if __name__ == "__main__":
         for M in (256, 1024, 2048, 4096, 8192, 16384):
             print("policy_act M=%5d: %.1f us" % (M, policy_time(M)), flush=True)
     if what == "env4096":
-        print("env_step(+finalize) N=4096 ablate=%s: %.1f us" % (os.environ.get("HGYM_ENV_ABLATE", "0"), env_time(4096)), flush=True)
+        print("env_step(+finalize) N=4096: %.1f us" % env_time(4096), flush=True)
