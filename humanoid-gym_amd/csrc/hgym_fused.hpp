@@ -1223,7 +1223,10 @@ __device__ __forceinline__ void ppo_scalars_block(const ScalArgs& a, int tid, in
     // beta1^t, beta2^t for hgym_ppo_apply's prologue: two double-precision pow() are ~6 us in that single-thread kernel, on the
     // minibatch's critical path; here they run on two lanes of the last wavefront beside a launch that takes 170 us anyway.  Keyed
     // by t (opt[13]): the prologue recomputes them if the step count is not the one assumed here.
-    if (tid >= nthreads - 2) {
+    // opt[13] is also the "prologue done, not applied yet" marker: == opt[1] (> 0) after a prologue taken here or in apply_prologue_kernel,
+    // -1 once adam_kernel has applied the step.  A second gradient call before the apply finds the marker set and leaves the step's
+    // learning-rate decision, step count and powers alone (the update then is the reference's: one optimiser step per apply).
+    if (tid >= nthreads - 2 && !(a.opt[13] == a.opt[1] && a.opt[1] > 0.0)) {
         const double t = a.opt[1] + 1.0;
         const double pw = pow(tid == nthreads - 2 ? a.beta1 : a.beta2, t);
         a.opt[tid == nthreads - 2 ? 14 : 15] = pw;
@@ -1273,7 +1276,7 @@ __device__ __forceinline__ void ppo_scalars_block(const ScalArgs& a, int tid, in
             opt[7] += 1.0;
             opt[9] = 0.0;                     // squared gradient norm: accumulated by reduce_slabs_kernel later in this call
             a.kl_slot[0] = (float)(t / B);    // grads[P]: travels with the gradient in the ranks' one all-reduce
-            if (a.do_prologue) {              // apply_prologue_kernel's arithmetic (hgym_net.hip), one rank: ppo.py:140-148 in python doubles
+            if (a.do_prologue && !(opt[13] == opt[1] && opt[1] > 0.0)) {      // apply_prologue_kernel's arithmetic (hgym_net.hip), one rank: ppo.py:140-148 in python doubles
                 double lr = opt[0];
                 if (a.adaptive_lr) {
                     const double kl = t / B;

@@ -553,6 +553,10 @@ __global__ __launch_bounds__(256) void sqnorm_kernel(int64_t P, const float* __r
 __global__ void apply_prologue_kernel(const HgymPPOConfig p, const float* __restrict__ kl_slot, float inv_w, double* __restrict__ opt) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     if (p.world_size > 1) opt[8] = (double)(kl_slot[0] * inv_w);     // mean over ranks of the minibatch KL: same LR branch everywhere
+    if (opt[13] == opt[1] && opt[1] > 0.0) {     // the gradient call already took this step's prologue (marker: ppo_scalars_block) and the
+        if (p.world_size > 1 || !p.grad_norm_ready) opt[9] = 0.0;     // caller applies with another configuration: not a second time
+        return;
+    }
     if (p.adaptive_lr) {
         const double kl = opt[8];
         double lr = opt[0];
@@ -568,6 +572,7 @@ __global__ void apply_prologue_kernel(const HgymPPOConfig p, const float* __rest
     const double bc1 = 1.0 - (cached ? opt[14] : pow((double)p.beta1, t)), bc2 = 1.0 - (cached ? opt[15] : pow((double)p.beta2, t));
     opt[11] = (double)(float)(opt[0] / bc1);      // step size
     opt[12] = (double)(float)sqrt(bc2);
+    opt[13] = t;                                  // marker: this step's prologue is done (adam_kernel clears it)
     if (p.world_size > 1 || !p.grad_norm_ready) opt[9] = 0.0;   // sqnorm_kernel follows (rank MEAN after an all-reduce / foreign gradients)
 }
 
@@ -594,7 +599,10 @@ __global__ __launch_bounds__(256) void adam_kernel(const SegTable tab, const Hgy
     const float total = (float)sqrt(opt[9]);
     float coef = p.max_grad_norm / (total + 1e-6f);
     coef = fminf(coef, 1.0f);
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) opt[6] = (double)total;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        opt[6] = (double)total;
+        opt[13] = -1.0;                           // the step whose prologue was pending is being applied (nobody reads opt[13] in this launch)
+    }
     const float step_size = (float)opt[11], sqrt_bc2 = (float)opt[12];      // apply_prologue_kernel: lr / (1 - beta1^t), sqrt(1 - beta2^t)
     auto adam1 = [&](int64_t q) -> float {            // one parameter: clip, moments, step; returns the new weight
         const float g = (grads[q] * inv_w) * coef;

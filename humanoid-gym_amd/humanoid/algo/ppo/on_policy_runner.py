@@ -462,8 +462,12 @@ class OnPolicyRunner:
             layout = [(k, (v.data_ptr() - base) // 4, tuple(v.shape)) for k, v in self.alg.actor_critic.state_dict().items()]
             opt_layout = [((v.data_ptr() - base) // 4, tuple(v.shape)) for v in net.views.values()]
             # (alg.optimizer.param_groups reads the learning rate from the device: a host sync; the snapshot carries it instead)
-            it, group = self.current_learning_iteration, dict(lr=None, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False)
-            assert all(0 <= o and o + int(torch.Size(shp).numel()) <= net.P for _, o, shp in layout), "a parameter outside the flat vector"
+            it, group = self.current_learning_iteration, dict(lr=None, **type(self.alg.optimizer).HYPER)
+            # every state_dict entry must be an fp32 view INTO the flat vector (the cut below is by offset and shape only)
+            for (k, o, shp), v in zip(layout, self.alg.actor_critic.state_dict().values()):
+                n = int(torch.Size(shp).numel())
+                assert v.dtype == torch.float32 and v.numel() == n and v.is_contiguous(), "%s is not an fp32 view of the flat parameter vector" % k
+                assert 0 <= o and o + n <= net.P and (v.data_ptr() - base) % 4 == 0, "%s lies outside the flat parameter vector" % k
 
             def job():
                 try:

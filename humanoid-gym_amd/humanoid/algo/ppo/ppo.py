@@ -20,12 +20,16 @@ class _DeviceAdam:
     """What `alg.optimizer` exposes to OnPolicyRunner.save/load: torch.optim.Adam-shaped state dicts backed by the
     flat exp_avg / exp_avg_sq vectors the HIP Adam kernel updates."""
 
+    # the hyper-parameters the HIP Adam kernel runs with (hgym.make_ppo_config); ONE definition for param_groups and for the
+    # runner's background checkpoint writer, which must not read the learning rate from the device (a host sync)
+    HYPER = dict(betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False)
+
     def __init__(self, ppo):
         self._ppo = ppo
 
     @property
     def param_groups(self):
-        return [dict(lr=self._ppo.learning_rate, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False)]
+        return [dict(lr=self._ppo.learning_rate, **self.HYPER)]
 
     def state_dict(self):
         net = self._ppo.net

@@ -393,7 +393,10 @@ typedef struct HgymPPOConfig {
                                        gradient; 0 (or world_size > 1): apply computes the norm itself.  The flag is a PROMISE that every
                                        hgym_ppo_grad is followed by exactly one hgym_ppo_apply with the same configuration: on the fused
                                        bf16 path hgym_ppo_grad then also takes the adaptive-KL learning-rate decision and advances Adam's
-                                       step count (the work of apply's prologue, done beside the weight-gradient launch) */
+                                       step count (the work of apply's prologue, done beside the weight-gradient launch).  A marker in
+                                       opt_state[13] keeps the two honest: a second hgym_ppo_grad before the apply does not advance the step
+                                       again, and an apply under another configuration does not repeat a prologue already taken.  (Not
+                                       covered: a gradient call WITHOUT the flag followed by an apply WITH it -- no prologue runs.) */
 } HgymPPOConfig;
 
 /* Sizes (bytes) of the caller-allocated blocks, as functions of the configuration. */
@@ -408,8 +411,8 @@ int64_t hgym_net_workspace_bytes(const HgymNetConfig* net);
  * [6] gradient norm of the last step (before clipping)  [7] minibatches accumulated in [2..5]
  * [8] mean KL of the last minibatch (average it across ranks before hgym_ppo_apply when world_size > 1)
  * [9] internal  [10] sum of the auxiliary head's minibatch MSE losses  [11] Adam step size lr / (1 - beta1^t) and
- * [12] sqrt(1 - beta2^t) of the current step (as floats; written by hgym_ppo_apply)  [13..15] internal (beta^t of the next step, prepared
- * by hgym_ppo_grad: Adam's betas must not change between a gradient call and the apply that follows it).
+ * [12] sqrt(1 - beta2^t) of the current step (as floats; written by hgym_ppo_apply)  [13..15] internal (the step whose beta^t lie in [14..15] / the
+ * "prologue done, not applied" marker: Adam's betas must not change between a gradient call and the apply that follows it).
  * workspace: hgym_net_workspace_bytes() bytes, 256-byte aligned, ZERO-FILLED once by the caller before first use
  * (padding rows/columns of the operand buffers rely on it). */
 typedef struct HgymNet {

@@ -337,6 +337,44 @@ def test_apply_can_reuse_the_norm_left_by_grad(precision):
     np.testing.assert_allclose(b.params.cpu().numpy(), a.params.cpu().numpy(), rtol=1e-7, atol=1e-9)
 
 
+def test_prologue_marker_keeps_grad_and_apply_in_step():
+    """with grad_norm_ready on the fused one-rank path hgym_ppo_grad itself takes the adaptive-KL learning-rate decision and
+    advances Adam's step count.  The marker in opt_state[13] keeps misuse from double-counting: (a) the normal sequence, (b) TWO gradient
+    calls before one apply, (c) an apply under a configuration without the flag -- each must end with one optimiser step, one
+    learning-rate decision and the same parameters (c: to the rounding of the norm it recomputes)."""
+    from hgym import NetBuffers, make_net_config, make_ppo_config, make_batch
+    S = B = 1000
+    res = {}
+    for mode in ("normal", "grad twice", "apply without the flag"):
+        torch.manual_seed(11)
+        cfg = make_net_config(705, 219, 12, [512, 256, 128], [768, 256, 128], "bf16", B)
+        net = NetBuffers(cfg, "cuda", learning_rate=1e-3)
+        for k, v in net.views.items():
+            v.copy_(torch.randn(v.shape, device="cuda") * (0.05 if v.dim() > 1 else 0.01))
+        net.views["std"].fill_(1.0)
+        net.sync_shadow()
+        g = torch.Generator(device="cuda").manual_seed(5)
+        r = lambda *s: torch.randn(*s, device="cuda", generator=g)
+        cols = (r(S, 705), r(S, 219), r(S, 12), r(S), r(S), r(S), r(S) - 12.0, r(S, 12) * 0.3, torch.ones(S, 12, device="cuda"))
+        idx = torch.randperm(S, device="cuda", generator=g).contiguous()
+        ready = make_ppo_config(grad_norm_ready=True, desired_kl=0.01, adaptive=True)
+        plain = make_ppo_config(grad_norm_ready=False, desired_kl=0.01, adaptive=True)
+        for step in range(2):           # two optimiser steps: the marker must also be CLEARED by the apply
+            net.ppo_grad(ready, make_batch(*cols, idx))
+            if mode == "grad twice":
+                net.ppo_grad(ready, make_batch(*cols, idx))
+            net.ppo_apply(plain if mode == "apply without the flag" else ready)
+        torch.cuda.synchronize()
+        res[mode] = (net.params.clone(), net.opt_state.clone())
+    lr0, steps0 = float(res["normal"][1][0]), float(res["normal"][1][1])
+    assert steps0 == 2.0 and lr0 != 1e-3
+    for mode in ("grad twice", "apply without the flag"):
+        o = res[mode][1]
+        assert float(o[1]) == 2.0 and float(o[0]) == lr0, (mode, o)
+        np.testing.assert_allclose(res[mode][0].cpu().numpy(), res["normal"][0].cpu().numpy(), rtol=1e-6, atol=1e-8, err_msg=mode)
+    assert float(res["normal"][1][13]) == -1.0                  # applied: nothing pending
+
+
 @pytest.mark.parametrize("precision", ["f32", "bf16"])
 def test_grad_in_two_parts_is_the_whole_gradient(precision):
     """hgym_ppo_grad_part 0 then 1 (the data-parallel update's two gradient buckets) leaves net.grads and the KL slot exactly

@@ -93,6 +93,34 @@ def test_training_iterations_and_checkpoint(tmp_path):
     assert err < 3e-2, err
 
 
+def test_background_checkpoint_equals_the_synchronous_one(tmp_path, monkeypatch):
+    """HGYM_ASYNC_SAVE=1 (pinned-host snapshot + writer thread, OnPolicyRunner.save) must write what the default torch.save path
+    writes: same keys, same parameter tensors, same Adam moments / step / param-group hyper-parameters, same learning rate (ADVICE r04:
+    the writer rebuilds the dict from flat offsets -- a drift between the two would be silent)."""
+    from humanoid.algo import PPO
+    PPO.precision = "bf16"
+    env, args, reg = _make(256)
+    runner, _ = reg.make_alg_runner(env=env, name=args.task, args=args, log_root=None)
+    runner.learn(num_learning_iterations=2, init_at_random_ep_len=True)
+    torch.cuda.synchronize()
+    monkeypatch.setenv("HGYM_ASYNC_SAVE", "0")
+    runner.save(str(tmp_path / "sync.pt"))
+    monkeypatch.setenv("HGYM_ASYNC_SAVE", "1")
+    runner.save(str(tmp_path / "async.pt"))          # wait=True: on disk when the call returns
+    a = torch.load(str(tmp_path / "sync.pt"), map_location="cpu")
+    b = torch.load(str(tmp_path / "async.pt"), map_location="cpu")
+    assert set(a) == set(b) and a["iter"] == b["iter"] == 2
+    assert list(a["model_state_dict"]) == list(b["model_state_dict"])
+    for k in a["model_state_dict"]:
+        assert torch.equal(a["model_state_dict"][k], b["model_state_dict"][k]), k
+    oa, ob = a["optimizer_state_dict"], b["optimizer_state_dict"]
+    assert oa["param_groups"] == ob["param_groups"], (oa["param_groups"], ob["param_groups"])
+    assert sorted(oa["state"]) == sorted(ob["state"])
+    for i in oa["state"]:
+        for f in ("step", "exp_avg", "exp_avg_sq"):
+            assert torch.equal(oa["state"][i][f], ob["state"][i][f]), (i, f)
+
+
 def test_f32_runner_matches_torch_module():
     """fp32 parity mode: the bound nn.Module (plain torch on the same parameters) and the HIP forward agree to 1e-5."""
     from humanoid.algo import PPO

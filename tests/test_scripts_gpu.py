@@ -36,7 +36,12 @@ def test_train_play_sim2sim_command_lines(task, exp, golden_dir):
         out = _run(os.path.join(SCRIPTS, "play.py"), "--task=" + task, "--headless", "--experiment_name", exp)
         pol = os.path.join(logs, "exported", "policies", "policy_1.pt")
         assert os.path.exists(pol) and "Exported policy as jit script" in out
+        # the reference's play loop (scripts/play.py:136-158): twelve states of one robot logged per step, per-episode rewards, the summary
+        assert "Average rewards per second" in out and "Total number of episodes" in out
+        assert "contact_forces_z" in out or os.path.exists(os.path.join(ROOT, "play_states.png"))      # plot_states: the keys, or the figure
         out = _run(os.path.join(SCRIPTS, "sim2sim.py"), "--load_model", pol, "--replay", os.path.join(golden_dir, "sim2sim_trace.npz"))
         assert "replayed 60 policy steps" in out
     finally:
         shutil.rmtree(logs, ignore_errors=True)
+        if os.path.exists(os.path.join(ROOT, "play_states.png")):
+            os.remove(os.path.join(ROOT, "play_states.png"))
