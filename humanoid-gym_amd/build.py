@@ -24,11 +24,12 @@ EXTRA = {
 }
 
 
-# Round 4 found that a device code object beyond ~1 MiB in the library makes runs of eight processes on one GPU abort at random with
-# HSA_STATUS_ERROR_ILLEGAL_INSTRUCTION, whether or not anything of it is launched (csrc/experiments/hgym_fb2.hip has the bisection: 0.87 - 0.99 MB fine,
-# 1.15 / 1.19 MB not).  -save-temps=obj leaves the linked device code object of each translation unit next to its .o: every one must stay
-# below CODE_OBJECT_LIMIT, and every kernel inside the 128 KiB short-branch range (s_cbranch reaches +-32 K dwords) -- a big kernel belongs
-# in a translation unit of its own.
+# Round 4: with hgym_net's device code object at 1.15 / 1.19 MB, runs of eight processes on one GPU aborted at random with
+# HSA_STATUS_ERROR_ILLEGAL_INSTRUCTION (0.87 - 0.99 MB: never; csrc/experiments/hgym_fb2.hip has the bisection).  Round 5's reproducer -- 1.1 MiB of
+# never-launched padding kernels as one extra code object -- passed 13 of 13 such runs (profiles/r05_code_object_abort_repro.txt): size alone is not
+# the trigger, a LAUNCHED kernel inside a > 1 MiB code object probably is.  The guard stays: every code object below CODE_OBJECT_LIMIT (-save-temps=obj
+# leaves the linked device code object of each translation unit next to its .o), every kernel inside the 128 KiB short-branch range (s_cbranch reaches
+# +-32 K dwords) -- a big kernel belongs in a translation unit of its own (hgym_update.hip).
 KERNEL_CODE_LIMIT = 128 * 1024
 CODE_OBJECT_LIMIT = 960 * 1024
 READELF = os.environ.get("LLVM_READELF", "/opt/rocm/lib/llvm/bin/llvm-readelf")

@@ -211,7 +211,8 @@ static int32_t launch_step(const HgymEnvConfig* cfg, const HgymSimTensors* sim, 
     HG_REQUIRE(out->obs && out->priv_obs && out->rew && out->reset && out->time_out && out->extras_time_outs && out->extras_episode,
                HGYM_E_BADARG, "null output buffer");
     HG_REQUIRE(st->obs_ring && st->priv_ring && st->episode_acc, HGYM_E_BADARG, "null ring/episode_acc");
-    HG_REQUIRE(!out->t_rewards || (out->t_values && out->t_dones), HGYM_E_BADARG, "transition sink needs t_values and t_dones");
+    HG_REQUIRE(!out->t_rewards || ((out->t_values || out->t_time_outs) && out->t_dones), HGYM_E_BADARG,
+               "transition sink needs t_values (or, deferred values, t_time_outs) and t_dones");
     EnvArgs A;
     memset(&A, 0, sizeof(A));
     A.cfg = *cfg;
@@ -281,8 +282,8 @@ int32_t rollout_env_args(const HgymEnvConfig* cfg, const HgymSimTensors* sim, co
     HG_REQUIRE(out->obs && out->priv_obs && out->rew && out->reset && out->time_out && out->extras_time_outs && out->extras_episode,
                HGYM_E_BADARG, "null output buffer");
     HG_REQUIRE(st->obs_ring && st->priv_ring && st->episode_acc, HGYM_E_BADARG, "null ring/episode_acc");
-    HG_REQUIRE(out->t_rewards && out->t_values && out->t_dones && out->t_step && out->defer_finalize, HGYM_E_BADARG,
-               "the fused rollout step stores the transition itself: transition sink + defer_finalize required");
+    HG_REQUIRE(out->t_rewards && (out->t_values || out->t_time_outs) && out->t_dones && out->t_step && out->defer_finalize, HGYM_E_BADARG,
+               "the fused rollout step stores the transition itself: transition sink (immediate: t_values; deferred: t_time_outs) + defer_finalize required");
     const bool generic = cfg->custom_origins || cfg->terrain_curriculum || cfg->num_height_points > 0 || cfg->command_curriculum ||
                          !cfg->heading_command || cfg->num_custom_rewards > 0;
     HG_REQUIRE(!generic && !cfg->use_ref_actions && cfg->frame_stack == 15 && cfg->c_frame_stack == 3, HGYM_E_UNSUPPORTED,

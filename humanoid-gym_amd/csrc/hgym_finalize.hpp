@@ -61,6 +61,14 @@ HG_HD void fin_part1(const FinArgs& F, int t, int nthreads) {
 HG_HD void fin_store(const FinArgs& F, int t, int nthreads) {
 #pragma clang fp contract(off)      // rew + gamma * (V * to) as three fp32 roundings, in every translation unit
     if (!F.out.t_rewards) return;
+    if (F.out.t_time_outs) {        // deferred values: raw reward + the flags of the bootstrap (hgym_gae_bootstrap applies it)
+        for (int i = t; i < F.N; i += nthreads) {
+            F.out.t_time_outs[i] = F.out.extras_time_outs[i] != 0;
+            F.out.t_rewards[i] = F.out.rew[i];
+            F.out.t_dones[i] = F.out.reset[i] != 0;
+        }
+        return;
+    }
     for (int i = t; i < F.N; i += nthreads) {
         const float to = (float)(F.out.extras_time_outs[i] != 0);
         const float boot = F.out.t_values[i] * to;
@@ -242,8 +250,10 @@ HG_HD bool fin_fused(const FinArgs& F, int t, int nthreads) {      // (host-comp
     const HgymEnvOut& O = F.out;
     auto al = [](const void* p, int a) { return ((uintptr_t)p & (uintptr_t)(a - 1)) == 0; };
     const bool sink = O.t_rewards != nullptr;
+    const bool deferred = sink && O.t_time_outs != nullptr;       // raw reward + bootstrap flags instead of the bootstrapped reward
     if ((F.N & 7) != 0 || !al(O.time_out, 8) || !al(O.extras_time_outs, 8) ||
-        (sink && (!al(O.reset, 8) || !al(O.t_dones, 8) || !al(O.t_values, 16) || !al(O.rew, 16) || !al(O.t_rewards, 16))))
+        (sink && (!al(O.reset, 8) || !al(O.t_dones, 8) || !al(O.rew, 16) || !al(O.t_rewards, 16))) ||
+        (sink && !deferred && !al(O.t_values, 16)) || (deferred && !al(O.t_time_outs, 8)))
         return false;
     const int G = F.N >> 3;
     const int64_t cnt = F.reset_count[0];
@@ -259,8 +269,10 @@ HG_HD bool fin_fused(const FinArgs& F, int t, int nthreads) {      // (host-comp
         f4 v0 = {0.0f, 0.0f, 0.0f, 0.0f}, v1 = v0, r0 = v0, r1 = v0;
         if (sink) {
             rs = reinterpret_cast<const u64*>(O.reset)[g];
-            v0 = reinterpret_cast<const f4*>(O.t_values)[2 * g];
-            v1 = reinterpret_cast<const f4*>(O.t_values)[2 * g + 1];
+            if (!deferred) {
+                v0 = reinterpret_cast<const f4*>(O.t_values)[2 * g];
+                v1 = reinterpret_cast<const f4*>(O.t_values)[2 * g + 1];
+            }
             r0 = reinterpret_cast<const f4*>(O.rew)[2 * g];
             r1 = reinterpret_cast<const f4*>(O.rew)[2 * g + 1];
         }
@@ -268,17 +280,21 @@ HG_HD bool fin_fused(const FinArgs& F, int t, int nthreads) {      // (host-comp
         if (cnt > 0) reinterpret_cast<u64*>(O.extras_time_outs)[g] = to_new;
         if (sink) {
             f4 o0, o1;
-            u64 dn = 0;
+            u64 dn = 0, tn = 0;
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                const float tof = (float)(((to >> (8 * k)) & 0xffull) != 0);
+                const bool tob = ((to >> (8 * k)) & 0xffull) != 0;
+                const float tof = (float)tob;
                 const float boot = (k < 4 ? v0[k & 3] : v1[k & 3]) * tof;
                 const float gb = O.t_gamma * boot;
-                const float r = (k < 4 ? r0[k & 3] : r1[k & 3]) + gb;
+                const float raw = k < 4 ? r0[k & 3] : r1[k & 3];
+                const float r = deferred ? raw : raw + gb;
                 if (k < 4) o0[k & 3] = r;
                 else o1[k & 3] = r;
                 dn |= (u64)(((rs >> (8 * k)) & 0xffull) != 0) << (8 * k);
+                tn |= (u64)tob << (8 * k);
             }
+            if (deferred) reinterpret_cast<u64*>(O.t_time_outs)[g] = tn;
             reinterpret_cast<f4*>(O.t_rewards)[2 * g] = o0;
             reinterpret_cast<f4*>(O.t_rewards)[2 * g + 1] = o1;
             reinterpret_cast<u64*>(O.t_dones)[g] = dn;

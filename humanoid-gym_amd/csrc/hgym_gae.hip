@@ -14,8 +14,13 @@ namespace hgym {
 constexpr int GAE_ENVS = 16;   // envs per workgroup (4 per wavefront)
 constexpr int GAE_PAD = 17;    // LDS row stride (odd: conflict-free column reads)
 
-__global__ __launch_bounds__(256) void gae_kernel(int T, int N, const float* __restrict__ rewards,
+// BOOT (hgym_gae_bootstrap): `rewards` holds raw rewards; r_t + gamma * (V_t * time_outs_t) -- PPO.process_env_step's bootstrap
+// (ppo.py:107-108) in store_step_kernel's three fp32 roundings (this file is built with -ffp-contract=off) -- is formed while the
+// tile is staged, used by the scan and written back, so the storage column ends up as the per-step path leaves it.
+template <bool BOOT>
+__global__ __launch_bounds__(256) void gae_kernel(int T, int N, float* __restrict__ rewards,
                                                   const float* __restrict__ values, const uint8_t* __restrict__ dones,
+                                                  const uint8_t* __restrict__ time_outs,
                                                   const float* __restrict__ last_values, float gamma, float lam,
                                                   float* __restrict__ returns, float* __restrict__ advantages,
                                                   double* __restrict__ stats) {
@@ -40,9 +45,17 @@ __global__ __launch_bounds__(256) void gae_kernel(int T, int N, const float* __r
             if (el < nE) {
                 const int tg = t0 + t;
                 if (t < nT) {
-                    s_r[t][el] = rewards[(int64_t)tg * N + e0 + el];
-                    s_d[t][el] = (float)dones[(int64_t)tg * N + e0 + el];
-                    s_v[t][el] = values[(int64_t)tg * N + e0 + el];
+                    const int64_t gi = (int64_t)tg * N + e0 + el;
+                    const float v = values[gi];
+                    float r = rewards[gi];
+                    if (BOOT) {
+                        const float to = (float)(time_outs[gi] != 0);
+                        r = r + gamma * (v * to);
+                        rewards[gi] = r;
+                    }
+                    s_r[t][el] = r;
+                    s_d[t][el] = (float)dones[gi];
+                    s_v[t][el] = v;
                 } else if (t == nT) {
                     s_v[t][el] = (tg >= T) ? last_values[e0 + el] : values[(int64_t)tg * N + e0 + el];
                 }
@@ -206,10 +219,23 @@ int32_t hgym_gae(int32_t T, int32_t n, const float* rewards, const float* values
     HG_REQUIRE(rewards && values && dones && last_values && returns && advantages && stats, HGYM_E_BADARG, "null pointer");
     hipLaunchKernelGGL(zero_stats_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, stats);
     prof_begin(HGYM_PROF_GAE, (hipStream_t)stream);
-    hipLaunchKernelGGL(gae_kernel, dim3(ceil_div(n, GAE_ENVS)), dim3(256), 0, (hipStream_t)stream, T, n, rewards, values, dones,
-                       last_values, gamma, lam, returns, advantages, stats);
+    hipLaunchKernelGGL(gae_kernel<false>, dim3(ceil_div(n, GAE_ENVS)), dim3(256), 0, (hipStream_t)stream, T, n, const_cast<float*>(rewards), values,
+                       dones, nullptr, last_values, gamma, lam, returns, advantages, stats);
     prof_end(HGYM_PROF_GAE, (hipStream_t)stream, (double)T * n * 17.0);   // r,V f32 + done u8 read, ret, adv f32 written
     HG_CHECK_LAUNCH("gae_kernel");
+    return HGYM_OK;
+}
+
+int32_t hgym_gae_bootstrap(int32_t T, int32_t n, float* rewards, const float* values, const uint8_t* dones, const uint8_t* time_outs,
+                           const float* last_values, float gamma, float lam, float* returns, float* advantages, double* stats, void* stream) {
+    HG_REQUIRE(T > 0 && n > 0, HGYM_E_SHAPE, "T=%d n=%d", T, n);
+    HG_REQUIRE(rewards && values && dones && time_outs && last_values && returns && advantages && stats, HGYM_E_BADARG, "null pointer");
+    hipLaunchKernelGGL(zero_stats_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, stats);
+    prof_begin(HGYM_PROF_GAE, (hipStream_t)stream);
+    hipLaunchKernelGGL(gae_kernel<true>, dim3(ceil_div(n, GAE_ENVS)), dim3(256), 0, (hipStream_t)stream, T, n, rewards, values, dones, time_outs,
+                       last_values, gamma, lam, returns, advantages, stats);
+    prof_end(HGYM_PROF_GAE, (hipStream_t)stream, (double)T * n * 22.0);   // + the time-out byte read, the bootstrapped reward written back
+    HG_CHECK_LAUNCH("gae_kernel<bootstrap>");
     return HGYM_OK;
 }
 

@@ -1040,6 +1040,33 @@ struct NetRunner {
         return HGYM_OK;
     }
 
+    // the critic over M rows in pieces of at most max_batch (a multiple of 64 rows each: whole tiles); fused path: 64-row tiles, the
+    // shadow's priv rows written by the tiles that read them
+    int32_t critic_values(int64_t M, const float* priv, float* values, const HgymObsShadow* sh) {
+        const int64_t piece = std::max<int64_t>(64, w.maxM / 64 * 64);
+        for (int64_t m0 = 0; m0 < M; m0 += piece) {
+            const int m = (int)std::min<int64_t>(piece, M - m0);
+            const float* x = priv + m0 * cfg.num_priv;
+            int32_t rc;
+            if (w.fused) {
+                const float* xs[3] = {nullptr, x, nullptr};
+                const int64_t ldxs[3] = {0, cfg.num_priv, 0};
+                float* outs[3] = {nullptr, values + m0, nullptr};
+                const int64_t ldos[3] = {0, 1, 0};
+                HgymObsShadow s1 = {nullptr, 0, nullptr, 0};
+                if (sh && sh->priv) {
+                    s1.priv = (char*)sh->priv + m0 * sh->ld_priv * 2;
+                    s1.ld_priv = sh->ld_priv;
+                }
+                rc = fused_forward(1, 1, m, xs, ldxs, nullptr, outs, ldos, false, nullptr, nullptr, (sh && sh->priv) ? &s1 : nullptr);
+            } else {
+                rc = forward(1, m, x, cfg.num_priv, nullptr, values + m0, 1, false);
+            }
+            if (rc) return rc;
+        }
+        return HGYM_OK;
+    }
+
     int32_t forward(int which, int M, const float* x, int64_t ldx, const int64_t* idx, float* y_out, int64_t ld_out, bool train) {
         if (w.fused && (which < 2 || w.fused_aux)) {
             const float* xs[3] = {x, x, x};
@@ -1343,6 +1370,16 @@ int32_t hgym_mlp_forward(const HgymNetConfig* cfg, const HgymNet* net, int32_t w
     HG_REQUIRE(x && y, HGYM_E_BADARG, "null x / y");
     const int nout = which == 0 ? cfg->num_actions : (which == 1 ? 1 : cfg->aux_dims[cfg->aux_layers]);
     HG_DISPATCH(cfg, net, w, stream, forward(which, M, x, ldx, nullptr, y, nout, false));
+}
+
+int32_t hgym_critic_values(const HgymNetConfig* cfg, const HgymNet* net, int64_t M, const float* priv, float* values,
+                           const HgymObsShadow* shadow, void* stream) {
+    WsLayout w;
+    const int32_t rc = check_net(cfg, net, &w);
+    if (rc) return rc;
+    HG_REQUIRE(M > 0 && priv && values, HGYM_E_BADARG, "M=%lld, null priv / values", (long long)M);
+    HG_REQUIRE(!shadow || !shadow->priv || w.fused, HGYM_E_UNSUPPORTED, "the observation shadow exists on the fused bf16 path only");
+    HG_DISPATCH(cfg, net, w, stream, critic_values(M, priv, values, shadow));
 }
 
 int64_t hgym_net_shadow_ld(const HgymNetConfig* cfg, int32_t which) {

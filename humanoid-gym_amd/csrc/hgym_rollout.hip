@@ -98,10 +98,14 @@ constexpr int RO_CHAIN = 64 * kChainRoles;     // lanes of the per-env chain: fo
 // weight ring in the in-order vmcnt queue, and their stores: 4.4 us of a 42 us launch -- is not in this kernel at all.  A launch
 // that is given obs_ahead writes the 13 frames it already knows of the rows after next on the seven wavefronts that idle during
 // the per-env phase, and this step's frame next to its own row's in the stack phase.
-template <bool FIN, bool PRE, bool PART = false>
+// NOCRITIC (hgym_rollout_step with values = NULL, header v7): no critic tiles -- grid rows = the actor + env workgroups and the
+// finaliser; the critic runs once over the stored rows after the rollout (hgym_critic_values).  With PRE = PART = false the actor
+// workgroup draws its own random numbers and copies its own history rows, as in the first launch of a rollout.
+template <bool FIN, bool PRE, bool PART = false, bool NOCRITIC = false>
 __global__ __launch_bounds__(RO_NT) void rollout_step_kernel(const FwdArgs f, const EnvArgs e, const FinArgs fin, const RolloutPP pp) {
+    static_assert(!NOCRITIC || (!PRE && !PART), "rows ahead and the carried first layer are the critic workgroups' side jobs");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    if (FIN && blockIdx.y >= 2) {
+    if (FIN && blockIdx.y >= (NOCRITIC ? 1 : 2)) {
         // (phase clock: slot 6 of the env row = when this workgroup of the third grid row started, slot 7 of block 0 = the finaliser's end)
         long long* d2 = f.dbg ? f.dbg + ((int64_t)2 * gridDim.x + blockIdx.x) * 8 : nullptr;
         if (d2 && threadIdx.x == 0) d2[6] = (long long)__builtin_amdgcn_s_memrealtime();
@@ -114,7 +118,7 @@ __global__ __launch_bounds__(RO_NT) void rollout_step_kernel(const FwdArgs f, co
     constexpr int U = 16 / 8;                       // n-blocks per wave per 256 first-layer columns (mlp_fwd_kernel)
     // actor and critic workgroups alternate in dispatch order (tile b: row 0 holds its actor when b is even, its critic when b
     // is odd), so that the long actor + env workgroups are spread evenly over neighbouring compute units
-    const bool critic_wg = ((blockIdx.x + blockIdx.y) & 1) != 0;
+    const bool critic_wg = !NOCRITIC && ((blockIdx.x + blockIdx.y) & 1) != 0;
     if (critic_wg) {                                // critic tile
         // one instantiation only (first hidden layer 768 wide, rollout_fwd_args checks): with the three-way dispatch of
         // mlp_fwd_kernel next to the actor + env branch the compiler keeps a private-memory copy of the whole 3 KB argument
@@ -284,7 +288,8 @@ int32_t hgym_rollout_step(const HgymNetConfig* cfg, const HgymNet* net, const Hg
                           uint64_t seed, float* actions, float* mu, float* sigma, float* logp, float* values, void* scratch,
                           int32_t parity, const HgymObsShadow* shadow, void* stream) {
     HG_REQUIRE(cfg && net && env_cfg && sim && st && out && scratch, HGYM_E_BADARG, "null argument");
-    HG_REQUIRE(obs && priv && actions && mu && sigma && logp && values, HGYM_E_BADARG, "null policy buffer");
+    const bool nocritic = values == nullptr;      // deferred values (header v7): hgym_critic_values runs after the rollout
+    HG_REQUIRE(obs && actions && mu && sigma && logp && (nocritic || priv), HGYM_E_BADARG, "null policy buffer");
     HG_REQUIRE(parity == 0 || parity == 1, HGYM_E_BADARG, "parity=%d", parity);
     // what the kernel compiles in (the header's "Supported:" list): the actor epilogue writes 12 actions per row into the env image
     // and the env part produces 15 x 47 / 3 x 73 wide rows, which the policy tiles read with these leading dimensions
@@ -305,6 +310,12 @@ int32_t hgym_rollout_step(const HgymNetConfig* cfg, const HgymNet* net, const Hg
     rc = rollout_env_args(env_cfg, sim, st, out, actions, &e);
     if (rc) return rc;
     HG_REQUIRE(out->t_values == values, HGYM_E_BADARG, "the transition sink must take this launch's values");
+    if (nocritic) {
+        HG_REQUIRE(out->t_rewards && out->t_time_outs && (!prev_out || (prev_out->t_time_outs && !prev_out->t_values)), HGYM_E_BADARG,
+                   "values = NULL: the transition sinks must be of the deferred kind (t_values NULL, t_time_outs set)");
+        HG_REQUIRE(!out->obs_ahead && !out->priv_ahead && !out->obs_older_ready && !out->l0_ahead && !out->l0_ready && !out->obs_bf16_ahead,
+                   HGYM_E_BADARG, "values = NULL: rows ahead / the carried first layer are the critic workgroups' side jobs");
+    }
     e.reset_count = &scr->reset_cnt[parity];
     e.st.episode_acc = scr->acc[parity];
     if (prev_out) {
@@ -326,8 +337,8 @@ int32_t hgym_rollout_step(const HgymNetConfig* cfg, const HgymNet* net, const Hg
                    HGYM_E_UNSUPPORTED, "draw tables of %d floats per tile do not fit the scratch layout", pp.draws_len);
         float* tables = reinterpret_cast<float*>(reinterpret_cast<char*>(scratch) + HGYM_ROLLOUT_SCRATCH_HEADER_BYTES);
         const int64_t per_parity = (int64_t)(M / RO_E) * pp.draws_len;
-        pp.draws_in = prev_out ? tables + parity * per_parity : nullptr;       // the first step of a rollout draws its own
-        pp.draws_out = tables + (parity ^ 1) * per_parity;
+        pp.draws_in = (prev_out && !nocritic) ? tables + parity * per_parity : nullptr;       // the first step of a rollout draws its own
+        pp.draws_out = nocritic ? nullptr : tables + (parity ^ 1) * per_parity;
     }
     memset(&pp.l0, 0, sizeof(pp.l0));
     memset(&pp.ah, 0, sizeof(pp.ah));
@@ -369,7 +380,9 @@ int32_t hgym_rollout_step(const HgymNetConfig* cfg, const HgymNet* net, const Hg
     HG_REQUIRE(!out->obs_ahead || (out->obs_ahead != out->obs && out->priv_ahead != out->priv_obs), HGYM_E_BADARG,
                "obs_ahead / priv_ahead must be the rows AFTER obs / priv_obs");
     {
-        const void* fn = part ? reinterpret_cast<const void*>(&rollout_step_kernel<true, true, true>)
+        const void* fn = nocritic ? (prev_out ? reinterpret_cast<const void*>(&rollout_step_kernel<true, false, false, true>)
+                                              : reinterpret_cast<const void*>(&rollout_step_kernel<false, false, false, true>))
+                       : part ? reinterpret_cast<const void*>(&rollout_step_kernel<true, true, true>)
                        : pre ? reinterpret_cast<const void*>(&rollout_step_kernel<true, true>)
                              : (prev_out ? reinterpret_cast<const void*>(&rollout_step_kernel<true, false>)
                                          : reinterpret_cast<const void*>(&rollout_step_kernel<false, false>));
@@ -378,7 +391,9 @@ int32_t hgym_rollout_step(const HgymNetConfig* cfg, const HgymNet* net, const Hg
     }
     hipStream_t s = (hipStream_t)stream;
     prof_begin(HGYM_PROF_ROLLOUT, s);
-    if (part) hipLaunchKernelGGL((rollout_step_kernel<true, true, true>), dim3(M / RO_E, 3), dim3(RO_NT), lds, s, f, e, fin, pp);
+    if (nocritic && prev_out) hipLaunchKernelGGL((rollout_step_kernel<true, false, false, true>), dim3(M / RO_E, 2), dim3(RO_NT), lds, s, f, e, fin, pp);
+    else if (nocritic) hipLaunchKernelGGL((rollout_step_kernel<false, false, false, true>), dim3(M / RO_E, 1), dim3(RO_NT), lds, s, f, e, fin, pp);
+    else if (part) hipLaunchKernelGGL((rollout_step_kernel<true, true, true>), dim3(M / RO_E, 3), dim3(RO_NT), lds, s, f, e, fin, pp);
     else if (pre) hipLaunchKernelGGL((rollout_step_kernel<true, true>), dim3(M / RO_E, 3), dim3(RO_NT), lds, s, f, e, fin, pp);
     else if (prev_out) hipLaunchKernelGGL((rollout_step_kernel<true, false>), dim3(M / RO_E, 3), dim3(RO_NT), lds, s, f, e, fin, pp);
     else hipLaunchKernelGGL((rollout_step_kernel<false, false>), dim3(M / RO_E, 2), dim3(RO_NT), lds, s, f, e, fin, pp);
@@ -388,9 +403,10 @@ int32_t hgym_rollout_step(const HgymNetConfig* cfg, const HgymNet* net, const Hg
         const double env_b = 4.0 * (245 + 14 * 47 + 2 * 73 + 15 * 47 + 3 * 73) + 6;
         const double pol_b = 4.0 * (cfg->num_obs + cfg->num_priv + 3 * cfg->num_actions + 2);
         double w_b = 0.0;
-        for (int n = 0; n < 2; ++n)
+        for (int n = 0; n < (nocritic ? 1 : 2); ++n)
             for (int l = 0; l < 4; ++l) w_b += (double)f.net[n].layer[l].NB * f.net[n].layer[l].KB * 1024.0;
-        prof_end(HGYM_PROF_ROLLOUT, s, (double)M * (env_b + pol_b) + w_b);
+        // (deferred values: the critic's input rows, its value and its weights are hgym_critic_values' bytes, not this launch's)
+        prof_end(HGYM_PROF_ROLLOUT, s, (double)M * (env_b + pol_b - (nocritic ? 4.0 * (cfg->num_priv + 1) : 0.0)) + w_b);
     }
     HG_CHECK_LAUNCH("rollout_step_kernel");
     return HGYM_OK;

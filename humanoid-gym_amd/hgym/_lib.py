@@ -92,7 +92,8 @@ class EnvOut(C.Structure):
                 ("t_values", c_float_p), ("t_rewards", c_float_p), ("t_dones", c_u8_p), ("t_step", c_i64_p),
                 ("t_gamma", C.c_float), ("defer_finalize", C.c_int32), ("log_cur", c_float_p), ("log_stats", c_float_p),
                 ("extras_custom", c_float_p), ("obs_ahead", c_float_p), ("priv_ahead", c_float_p), ("obs_older_ready", C.c_int32),
-                ("l0_ahead", c_float_p), ("l0_ready", c_float_p), ("obs_bf16_ahead", C.c_void_p), ("ld_obs_bf16_ahead", C.c_int64)]
+                ("l0_ahead", c_float_p), ("l0_ready", c_float_p), ("obs_bf16_ahead", C.c_void_p), ("ld_obs_bf16_ahead", C.c_int64),
+                ("t_time_outs", c_u8_p)]
 
 
 class EnvNoise(C.Structure):
@@ -173,6 +174,9 @@ SYMBOLS = {
     "hgym_gae": (C.c_int32, [C.c_int32, C.c_int32, c_float_p, c_float_p, c_u8_p, c_float_p, C.c_float, C.c_float,
                              c_float_p, c_float_p, c_f64_p, C.c_void_p]),
     "hgym_adv_normalize": (C.c_int32, [C.c_int64, c_float_p, c_f64_p, C.c_void_p]),
+    "hgym_gae_bootstrap": (C.c_int32, [C.c_int32, C.c_int32, c_float_p, c_float_p, c_u8_p, c_u8_p, c_float_p, C.c_float, C.c_float,
+                                       c_float_p, c_float_p, c_f64_p, C.c_void_p]),
+    "hgym_critic_values": (C.c_int32, [_P(NetConfig), _P(Net), C.c_int64, c_float_p, c_float_p, _P(ObsShadow), C.c_void_p]),
     "hgym_net_param_count": (C.c_int64, [_P(NetConfig)]),
     "hgym_net_workspace_bytes": (C.c_int64, [_P(NetConfig)]),
     "hgym_net_sync_shadow": (C.c_int32, [_P(NetConfig), _P(Net), C.c_void_p]),

@@ -225,7 +225,8 @@ class EnvBuffers:
         return st
 
     def out_struct(self, obs=None, priv=None, sink=None, defer_finalize=False, alt=False):
-        """sink: optional dict(values, rewards, dones, step, gamma) -- HgymEnvOut's transition sink (caller keeps the tensors alive).
+        """sink: optional dict(values, rewards, dones, step, gamma) -- HgymEnvOut's transition sink (caller keeps the tensors alive);
+        with values = None and a `time_outs` slot it is the deferred-values kind (HgymEnvOut.t_time_outs).
         defer_finalize: the env-step call does not launch the step finaliser (see HgymEnvOut.defer_finalize).
         alt: the alternate rew / reset / time_out set (fused rollout step)."""
         rew, reset, time_out = (self.rew_alt, self.reset_alt, self.time_out_alt) if alt else (self.rew, self.reset, self.time_out)
@@ -234,6 +235,8 @@ class EnvBuffers:
                      L.fptr(self.extras_episode))
         if sink is not None:
             o.t_values, o.t_rewards = L.fptr(sink["values"]), L.fptr(sink["rewards"])
+            if sink["values"] is None:
+                o.t_time_outs = L.u8ptr(sink["time_outs"])
             o.t_dones, o.t_step, o.t_gamma = L.u8ptr(sink["dones"]), L.i64ptr(sink.get("step")), float(sink["gamma"])
         o.defer_finalize = 1 if defer_finalize else 0
         if self.log_sink:

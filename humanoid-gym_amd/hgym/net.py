@@ -122,9 +122,20 @@ class NetBuffers:
         return int(L.lib.hgym_net_shadow_ld(C.byref(self.cfg), int(which)))
 
     def shadow_struct(self, obs_bf16, priv_bf16):
-        """HgymObsShadow over two (M, ld) torch.bfloat16 tensors (the caller keeps them alive)."""
-        assert obs_bf16.dtype == torch.bfloat16 and priv_bf16.dtype == torch.bfloat16 and obs_bf16.is_contiguous() and priv_bf16.is_contiguous()
-        return L.ObsShadow(C.c_void_p(obs_bf16.data_ptr()), obs_bf16.shape[-1], C.c_void_p(priv_bf16.data_ptr()), priv_bf16.shape[-1])
+        """HgymObsShadow over two (M, ld) torch.bfloat16 tensors (the caller keeps them alive); either may be None (that member is
+        not written by the launch)."""
+        for t in (obs_bf16, priv_bf16):
+            assert t is None or (t.dtype == torch.bfloat16 and t.is_contiguous())
+        p = lambda t: (None, 0) if t is None else (C.c_void_p(t.data_ptr()), t.shape[-1])
+        return L.ObsShadow(*p(obs_bf16), *p(priv_bf16))
+
+    def critic_values(self, priv, values, priv_bf16=None):
+        """hgym_critic_values: V of every row of `priv` ((M, num_priv) fp32, contiguous) into `values` ((M,) or (M, 1) fp32); priv_bf16:
+        optional (M, ld) bfloat16 shadow rows to fill.  M may exceed the configuration's max_batch."""
+        assert priv.is_contiguous() and values.is_contiguous() and priv.dtype == torch.float32 and values.numel() == priv.shape[0]
+        sh = None if priv_bf16 is None else C.byref(self.shadow_struct(None, priv_bf16))
+        L.check(L.lib.hgym_critic_values(C.byref(self.cfg), C.byref(self.struct), int(priv.shape[0]), L.fptr(priv), L.fptr(values), sh,
+                                         C.c_void_p(torch.cuda.current_stream().cuda_stream)), "hgym_critic_values")
 
     def act(self, obs, priv, z=None, seed=0, step_counter=None, out=None, env_fin=None, shadow=None):
         """env_fin: optional (HgymEnvConfig, HgymEnvState, HgymEnvOut) of an env step whose finaliser was postponed

@@ -163,19 +163,29 @@ class OnPolicyRunner:
 
         # ... and with the synthetic-physics backend the whole loop body -- act, env.step, process_env_step -- is ONE launch per
         # vec-step (hgym_rollout_step): the env step of a 32-env slice runs right behind the actor tile of the same slice
-        fuse_ok = (defer_ok and hasattr(env, "rollout_fused_supported") and hasattr(alg, "fused_rollout_step")
-                   and os.environ.get("HGYM_FUSE_ROLLOUT", "1") != "0" and env.rollout_fused_supported(alg.net))
+        fuse_mode = (env.rollout_fused_mode(alg.net) if (defer_ok and hasattr(env, "rollout_fused_mode") and hasattr(alg, "fused_rollout_step")
+                                                         and os.environ.get("HGYM_FUSE_ROLLOUT", "1") != "0") else None)
+        fuse_ok = fuse_mode is not None
+        # "deferred": more than half a chip of envs (8192 per MI355X, BASELINE configs[3]) -- the launch has no critic tiles, the critic
+        # runs once over the stored rows behind the last step (nothing inside the rollout needs V(s_t) but the time-out bootstrap,
+        # which compute_returns then applies: ppo.py:107-108)
+        deferred = fuse_mode == "deferred" and hasattr(alg, "deferred_values")
 
         def rollout(obs, critic_obs):
             if fuse_ok:
                 env.rollout_begin(alg._sample_step, self.num_steps_per_env)
                 T = self.num_steps_per_env
                 for i in range(T):
-                    # (the slot after next: its older frames are written by this launch, off the next one's critical path)
-                    alg.fused_rollout_step(env, i, obs, critic_obs, obs_all[i + 1], priv_all[i + 1],
-                                           (obs_all[i + 2], priv_all[i + 2]) if i + 2 <= T else None)
+                    if deferred:
+                        alg.fused_rollout_step(env, i, obs, critic_obs, obs_all[i + 1], priv_all[i + 1], deferred=True)
+                    else:
+                        # (the slot after next: its older frames are written by this launch, off the next one's critical path)
+                        alg.fused_rollout_step(env, i, obs, critic_obs, obs_all[i + 1], priv_all[i + 1],
+                                               (obs_all[i + 2], priv_all[i + 2]) if i + 2 <= T else None)
                     obs, critic_obs = obs_all[i + 1], priv_all[i + 1]
                 env.rollout_end()
+                if deferred:
+                    alg.deferred_values()       # part of the collection (and of the captured graph): V of all T + 1 slots in one pass
                 return obs, critic_obs
             fin = None
             for i in range(self.num_steps_per_env):
@@ -220,7 +230,7 @@ class OnPolicyRunner:
         # the captured launches hold HgymEnvConfig and the sink's gamma BY VALUE: a change between learn() calls (reward scales,
         # command ranges, push / noise settings written into the env's native config, alg.gamma -- what a curriculum script does)
         # must re-capture, as the eager reference would simply see it
-        gkey = (id(env), id(alg.storage), log_on, log_sink, sink_ok, defer_ok, fuse_ok, getattr(alg, "gamma", None),
+        gkey = (id(env), id(alg.storage), log_on, log_sink, sink_ok, defer_ok, fuse_mode, getattr(alg, "gamma", None),
                 env.native_config_digest() if hasattr(env, "native_config_digest") else None,
                 getattr(env, "_rows_ahead", None), getattr(env, "_l0_ahead", None), getattr(alg.storage, "_obs_bf16", None) is not None)
         tot_iter = self.current_learning_iteration + num_learning_iterations
@@ -235,6 +245,8 @@ class OnPolicyRunner:
                     if use_graph and g is not None and g["key"] == gkey:
                         g["graph"].replay()
                         alg.storage.step = self.num_steps_per_env
+                        if deferred:
+                            alg._deferred_ready = True              # (the captured rollout ends with deferred_values' launches)
                         alg.storage.shadow_valid = list(g["shadow_valid"])     # the replayed launches wrote the same shadow slots
                         obs, critic_obs = g["out"]
                         ep_infos = g["ep_infos"]

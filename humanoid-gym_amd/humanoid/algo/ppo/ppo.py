@@ -207,14 +207,26 @@ class PPO:
             self._sample_step += 1
         return t.actions
 
-    def fused_rollout_step(self, env, i, obs, critic_obs, next_obs, next_critic_obs, ahead=None):
+    def fused_rollout_step(self, env, i, obs, critic_obs, next_obs, next_critic_obs, ahead=None, deferred=False):
         """act() + env.step() + process_env_step() of rollout step i as ONE launch (LeggedRobot.rollout_step): the policy's outputs
         land in storage slot i, the env writes the next observations into the slots handed in, the finaliser riding in the
         following launch stores rewards / dones of slot i (time-out bootstrap included).  ahead: (obs, critic_obs) of the slot after
-        next_obs, whose older frames this launch may write ahead (LeggedRobot.rollout_step)."""
+        next_obs, whose older frames this launch may write ahead (LeggedRobot.rollout_step).
+        deferred: the launch has no critic tiles; slot i receives the RAW reward and the bootstrap's time-out flags, and
+        deferred_values() -- once, after the last step -- fills storage.values and applies the bootstrap in compute_returns."""
         st, s = self.storage, self.storage.step
         if s >= st.num_transitions_per_env:
             raise AssertionError("Rollout buffer overflow")
+        if deferred:
+            st.enable_deferred_values()
+            out = dict(actions=st.actions[s], mu=st.mu[s], sigma=st.sigma[s], logp=st.actions_log_prob[s].view(-1), values=None)
+            sink = dict(values=None, rewards=st.rewards[s], dones=st.dones[s], time_outs=st.time_outs[s], step=self._sample_step, gamma=self.gamma)
+            own = obs.data_ptr() == st._obs_all[s].data_ptr() and critic_obs.data_ptr() == st._priv_all[s].data_ptr()
+            sh = (st._obs_bf16[s], None) if (own and st._obs_bf16 is not None) else None      # (the priv shadow: deferred_values)
+            self._deferred_shadow = bool(own and st._obs_bf16 is not None and (s == 0 or getattr(self, "_deferred_shadow", False)))
+            env.rollout_step(self.net, i, obs, critic_obs, next_obs, next_critic_obs, sink, self.actor_critic._sample_seed, out, shadow=sh)
+            st.step += 1
+            return
         out = dict(actions=st.actions[s], mu=st.mu[s], sigma=st.sigma[s], logp=st.actions_log_prob[s].view(-1), values=st.values[s])
         sink = dict(values=st.values[s], rewards=st.rewards[s], dones=st.dones[s], step=self._sample_step, gamma=self.gamma)
         sh = st.shadow_slot(s) if (obs.data_ptr() == st._obs_all[s].data_ptr() and critic_obs.data_ptr() == st._priv_all[s].data_ptr()) else None
@@ -253,7 +265,27 @@ class PPO:
         self.transition.clear()
         self.actor_critic.reset(dones)
 
+    def deferred_values(self):
+        """After a rollout of fused_rollout_step(deferred=True) launches: ActorCritic.evaluate over EVERY stored privileged row in one
+        pass (the T slots -> storage.values, the bootstrap observation in slot T -> storage.last_values), 64-row tiles at the update's
+        efficiency instead of T + 1 latency-bound launches; the tiles also leave the bf16 shadow of the rows they read.  The
+        reference evaluates V(s_t) inside PPO.act (ppo.py:96, on_policy_runner.py:129) -- same weights (they do not change during
+        collection), same rows, same kernel arithmetic."""
+        st = self.storage
+        T, N = st.num_transitions_per_env, st.num_envs
+        shadow = st._priv_bf16.flatten(0, 1) if (st._priv_bf16 is not None and getattr(self, "_deferred_shadow", False)) else None
+        self.net.critic_values(st._priv_all[:T].flatten(0, 1), st.values.view(-1), shadow)
+        self.net.critic_values(st._priv_all[T], st.last_values.view(-1))
+        if shadow is not None:
+            st.shadow_valid = [True] * T
+        self._deferred_ready = True
+
     def compute_returns(self, last_critic_obs):
+        if getattr(self, "_deferred_ready", False):       # deferred_values() has evaluated the bootstrap observation with the rest
+            self._deferred_ready = False
+            self.storage.compute_returns(self.storage.last_values, self.gamma, self.lam, stats_hook=dist_utils.allreduce_adv_stats,
+                                         time_outs=self.storage.time_outs)
+            return
         last_values = self.actor_critic.evaluate(last_critic_obs)
         self.storage.compute_returns(last_values, self.gamma, self.lam, stats_hook=dist_utils.allreduce_adv_stats)
 

@@ -56,6 +56,8 @@ class RolloutStorage:
         # read by the update instead of the fp32 rows
         self._obs_bf16 = self._priv_bf16 = None
         self.shadow_valid = [False] * T
+        # deferred values (enable_deferred_values): the bootstrap flags of every step + the value of the bootstrap observation
+        self.time_outs = self.last_values = None
 
     def enable_shadow(self, ld_obs, ld_priv):
         """Native extension: allocate (T, N, ld) bfloat16 copies of `observations` / `privileged_observations` (ld = the widths
@@ -66,6 +68,14 @@ class RolloutStorage:
         self._obs_bf16 = torch.zeros(T, N, int(ld_obs), dtype=torch.bfloat16, device=self.device)
         self._priv_bf16 = torch.zeros(T, N, int(ld_priv), dtype=torch.bfloat16, device=self.device)
         return True
+
+    def enable_deferred_values(self):
+        """Native extension: columns for a rollout whose critic runs ONCE after collection (PPO.deferred_values): time_outs (T, N, 1)
+        uint8 = the stale-by-design extras["time_outs"] the per-step bootstrap would have used (ppo.py:107-108), last_values (N, 1)."""
+        if self.time_outs is None:
+            T, N = self.num_transitions_per_env, self.num_envs
+            self.time_outs = torch.zeros(T, N, 1, dtype=torch.uint8, device=self.device)
+            self.last_values = torch.zeros(N, 1, dtype=torch.float32, device=self.device)
 
     def shadow_slot(self, s):
         """(obs_bf16[s], priv_bf16[s]) for the policy launch that reads slot s, which thereby becomes valid; None without shadows."""
@@ -125,15 +135,22 @@ class RolloutStorage:
         self.step = 0
         self.shadow_valid = [False] * self.num_transitions_per_env
 
-    def compute_returns(self, last_values, gamma, lam, stats_hook=None):
+    def compute_returns(self, last_values, gamma, lam, stats_hook=None, time_outs=None):
+        """rollout_storage.py:122-136.  time_outs (native extension, deferred values): `rewards` holds RAW rewards; the time-out
+        bootstrap r += gamma * V * time_outs is applied (and written back) as the scan loads them (hgym_gae_bootstrap)."""
         from hgym import _lib as L
         T, N = self.num_transitions_per_env, self.num_envs
         if not self.rewards.is_cuda:
             raise RuntimeError("RolloutStorage.compute_returns runs on the HIP path only (storage is on %s)" % self.device)
         s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         lv = last_values.reshape(N).contiguous()
-        L.check(L.lib.hgym_gae(T, N, L.fptr(self.rewards), L.fptr(self.values), L.u8ptr(self.dones), L.fptr(lv), gamma, lam,
-                               L.fptr(self.returns), L.fptr(self.advantages), L.f64ptr(self._stats), s), "hgym_gae")
+        if time_outs is not None:
+            L.check(L.lib.hgym_gae_bootstrap(T, N, L.fptr(self.rewards), L.fptr(self.values), L.u8ptr(self.dones), L.u8ptr(time_outs), L.fptr(lv),
+                                             gamma, lam, L.fptr(self.returns), L.fptr(self.advantages), L.f64ptr(self._stats), s),
+                    "hgym_gae_bootstrap")
+        else:
+            L.check(L.lib.hgym_gae(T, N, L.fptr(self.rewards), L.fptr(self.values), L.u8ptr(self.dones), L.fptr(lv), gamma, lam,
+                                   L.fptr(self.returns), L.fptr(self.advantages), L.f64ptr(self._stats), s), "hgym_gae")
         if stats_hook is not None:
             stats_hook(self._stats)               # multi-GPU: all-reduce (sum, sumsq, count) for a global normalisation
         L.check(L.lib.hgym_adv_normalize(T * N, L.fptr(self.advantages), L.f64ptr(self._stats), s), "hgym_adv_normalize")

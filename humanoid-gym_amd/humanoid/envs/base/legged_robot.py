@@ -434,10 +434,30 @@ class LeggedRobot(BaseTask):
         # book-keeping around the step) must keep getting its own code, i.e. the act() + step() path
         own_step = type(self).step is LeggedRobot.step and type(self).post_physics_step is LeggedRobot.post_physics_step
         own_step = own_step and not getattr(self, "_custom_terms", None)       # user-defined reward terms: the two-launch step
-        return bool(own_step and not generic and not c.use_ref_actions and c.frame_stack == 15 and c.c_frame_stack == 3 and self.num_envs % 32 == 0
-                    and nc.precision == self._L.BF16 and nc.actor_layers == 4 and nc.critic_layers == 4 and nc.actor_dims[1] == 512
-                    and nc.critic_dims[1] == 768 and nc.num_actions == 12 and 2 * (self.num_envs // 32) <= max(cus, 1)
-                    and getattr(self.cfg.env, "send_timeouts", False))
+        return self.rollout_fused_mode(net) == "inline"
+
+    def rollout_fused_mode(self, net):
+        """"inline": hgym_rollout_step with the critic's tiles beside the actor's (one actor + one critic workgroup per 32 envs fit the
+        chip in one round: up to 4096 envs on 256 CUs); "deferred": the launch without critic tiles (values = NULL: one actor + env
+        workgroup per 32 envs, up to 8192 envs) and the critic once over the stored rows after the rollout (PPO.deferred_values);
+        None: the two-launch path.  HGYM_ROLLOUT_CRITIC=inline|deferred|auto (default auto) restricts / forces the choice."""
+        c, nc = self._ncfg, net.cfg
+        generic = c.custom_origins or c.terrain_curriculum or c.num_height_points > 0 or c.command_curriculum or not c.heading_command
+        cus = max(int(self._L.lib.hgym_device_cus()), 1)
+        own_step = type(self).step is LeggedRobot.step and type(self).post_physics_step is LeggedRobot.post_physics_step
+        own_step = own_step and not getattr(self, "_custom_terms", None)       # user-defined reward terms: the two-launch step
+        ok = bool(own_step and not generic and not c.use_ref_actions and c.frame_stack == 15 and c.c_frame_stack == 3 and self.num_envs % 32 == 0
+                  and nc.precision == self._L.BF16 and nc.actor_layers == 4 and nc.critic_layers == 4 and nc.actor_dims[1] == 512
+                  and nc.critic_dims[1] == 768 and nc.num_actions == 12 and getattr(self.cfg.env, "send_timeouts", False))
+        if not ok:
+            return None
+        want = os.environ.get("HGYM_ROLLOUT_CRITIC", "auto").lower()
+        tiles = self.num_envs // 32
+        if want != "deferred" and 2 * tiles <= cus:
+            return "inline"
+        if want != "inline" and tiles <= cus:
+            return "deferred"
+        return None
 
     def rollout_begin(self, step_counter, num_steps):
         if getattr(self, "_pending_fin", None) is not None:
@@ -461,6 +481,19 @@ class LeggedRobot(BaseTask):
         sh = None if shadow is None else net.shadow_struct(*shadow)
         L = self._L
         parity = (self._ro_T - 1 - i) & 1
+        if out["values"] is None:           # deferred values (hgym_rollout_step with values = NULL): no critic tiles, hence none of their side jobs
+            assert ahead is None and shadow_next is None and sink["values"] is None
+            o = self._buf.out_struct(next_obs, next_priv, sink, True, alt=bool(parity))
+            prev = self._ro_prev
+            L.check(L.lib.hgym_rollout_step(C.byref(net.cfg), C.byref(net.struct), C.byref(self._ncfg), C.byref(self._sim_s), C.byref(self._st_s),
+                                            C.byref(o), C.byref(prev[0]) if prev is not None else None, L.fptr(obs), L.fptr(priv),
+                                            int(seed) & 0xFFFFFFFFFFFFFFFF, L.fptr(out["actions"]), L.fptr(out["mu"]), L.fptr(out["sigma"]),
+                                            L.fptr(out["logp"]), None, C.c_void_p(self._buf.rollout_scratch.data_ptr()), parity,
+                                            None if sh is None else C.byref(sh), self._stream()), "hgym_rollout_step")
+            self._ro_prev = (o, parity, sink)
+            self._ro_ahead = self._ro_l0 = None
+            self.obs_buf, self.privileged_obs_buf = next_obs, next_priv
+            return
         o = self._buf.out_struct(next_obs, next_priv, sink, True, alt=bool(parity))
         if not self._rows_ahead:
             ahead = None

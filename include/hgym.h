@@ -38,7 +38,8 @@ extern "C" {
                              *    (same version, later: frames written into obs_ahead / priv_ahead for an env that resets in the same step are
                              *    zeroed by the NEXT hgym_rollout_step call -- see HgymEnvOut.obs_ahead; layouts and call sequence unchanged)
                              * 7: HgymComm.wait_ticks (bound of the direct exchange's waits) + hgym_comm_status; a communicator stays usable
-                             *    after an expired wait (the done counter is per call) */
+                             *    after an expired wait (the done counter is per call); HgymEnvOut.t_time_outs, hgym_critic_values,
+                             *    hgym_gae_bootstrap and hgym_rollout_step with values = NULL (the critic run once after the rollout) */
 
 enum {
     HGYM_OK = 0,
@@ -263,6 +264,12 @@ typedef struct HgymEnvOut {
     const float* l0_ready;
     void* obs_bf16_ahead;
     int64_t ld_obs_bf16_ahead;
+    /* header v7, transition sink with DEFERRED values (t_rewards set, t_values NULL): nothing inside a rollout consumes V(s_t) except the
+     * time-out bootstrap r += gamma * V * time_outs (ppo.py:107-108) and the GAE that follows the rollout, and the weights do not change
+     * while it is collected -- so the critic may run ONCE over all stored rows afterwards (hgym_critic_values) instead of once per
+     * step.  The finaliser then stores the RAW reward in t_rewards and, here, the flags the bootstrap would have used (the stale-by-design
+     * extras["time_outs"] of this step, (N,) uint8); hgym_gae_bootstrap applies the same fp32 expression when it loads r_t. */
+    uint8_t* t_time_outs;
 } HgymEnvOut;
 #define HGYM_LOG_STATS 256
 
@@ -357,6 +364,11 @@ int32_t hgym_gae(int32_t T, int32_t n, const float* rewards, const float* values
 
 /* advantages = (adv - mean) / (std_unbiased + 1e-8) from stats (possibly all-reduced by the caller). */
 int32_t hgym_adv_normalize(int64_t count, float* advantages, const double* stats, void* stream);
+/* hgym_gae for a rollout collected with deferred values (HgymEnvOut.t_time_outs): rewards (T, n) holds the RAW rewards and is
+ * overwritten with r_t + gamma * (V_t * time_outs_t) -- PPO.process_env_step's bootstrap (ppo.py:107-108), the three fp32 roundings of
+ * hgym_store_step -- before the scan uses it, so that afterwards every storage column is what the per-step path leaves. */
+int32_t hgym_gae_bootstrap(int32_t T, int32_t n, float* rewards, const float* values, const uint8_t* dones, const uint8_t* time_outs,
+                           const float* last_values, float gamma, float lam, float* returns, float* advantages, double* stats, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Actor / critic (algo/ppo/actor_critic.py) and PPO update (algo/ppo/ppo.py:119-184)
@@ -449,6 +461,11 @@ typedef struct HgymObsShadow {
 /* leading dimension (elements) of the bf16 shadow of net `which`'s input rows (0 actor: obs, 1 critic: privileged obs), or 0 when
  * this configuration does not take the fused bf16 path */
 int64_t hgym_net_shadow_ld(const HgymNetConfig* cfg, int32_t which);
+/* The critic over M stored privileged-observation rows in one call (ActorCritic.evaluate, actor_critic.py:127-129, on every slot of a
+ * finished rollout): values (M,) fp32; shadow->priv (optional) receives the bf16 of the rows, as the per-step policy launches leave it.
+ * M may exceed HgymNetConfig.max_batch (the rows are walked in pieces). */
+int32_t hgym_critic_values(const HgymNetConfig* cfg, const HgymNet* net, int64_t M, const float* priv, float* values,
+                           const HgymObsShadow* shadow, void* stream);
 
 /* PPO.act (ppo.py:91-101): mu = actor(obs); sigma = std; a = mu + sigma*z; V = critic(priv);
  * logp = sum log N(a; mu, sigma).  z (M,12) standard normal draws or NULL -> Philox(seed, *step_counter).
@@ -487,6 +504,12 @@ int32_t hgym_policy_act_fin(const HgymNetConfig* cfg, const HgymNet* net, int32_
  * critic workgroups of step t compute for step t + 1).  Supported: the XBot-L default options (none of the generic ones, no use_ref_actions),
  * 15 / 3 history, contiguous [136][N] state, SoA sim tensors, N a multiple of 32, the bf16 fused net path;
  * HGYM_E_UNSUPPORTED otherwise (callers fall back to hgym_policy_act_fin + hgym_env_step_synth).
+ * values = NULL (header v7, deferred values): no critic tiles -- the grid is the N / 32 actor + env workgroups and the finaliser, every
+ * workgroup draws its own step's random numbers and copies its own history rows (the critic workgroups' side jobs), and the
+ * sinks of out / prev_out must be of the deferred kind (t_values NULL, t_time_outs set); obs_ahead / obs_older_ready / l0_* stay
+ * NULL / 0; `priv` is not read and the shadow's priv member is not written (hgym_critic_values does both after the rollout).  This is
+ * the form for more than half a chip of envs (N / 32 > CUs / 2: 8192 envs per MI355X), where the critic's tiles would need the
+ * compute units of a second round.
  * ---------------------------------------------------------------------------------------------- */
 #define HGYM_ROLLOUT_SCRATCH_HEADER_BYTES 512
 #define HGYM_ROLLOUT_DRAW_BYTES_PER_ENV 1000      /* two parities x 125 floats */

@@ -9,7 +9,9 @@ CSRC = os.path.join(os.path.dirname(os.path.dirname(HERE)), "humanoid-gym_amd", 
 
 
 def build(force=False):
-    deps = [SRC] + [os.path.join(CSRC, f) for f in ("hgym_env_math.hpp", "hgym_common.hpp")]
+    # every header the emulation compiles (a stale library after a struct change in include/hgym.h reads the ctypes structs wrongly)
+    deps = [SRC, os.path.join(os.path.dirname(os.path.dirname(HERE)), "include", "hgym.h")] + \
+           [os.path.join(CSRC, f) for f in ("hgym_env_math.hpp", "hgym_common.hpp", "hgym_finalize.hpp")]
     if not force and os.path.exists(LIB) and all(os.path.getmtime(d) <= os.path.getmtime(LIB) for d in deps):
         return LIB
     subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--offload-arch=gfx950", "-O2", "-std=c++17",

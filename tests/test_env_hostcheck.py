@@ -181,3 +181,43 @@ def test_finaliser_one_pass_form_equals_the_general_one_host(N, nthreads, resets
         assert torch.equal(eto, to) and bool((acc[:22] == 0).all())
     boot = val * eto.float()
     assert torch.equal(rw, rew + torch.tensor(0.994, dtype=torch.float32) * boot)
+
+
+@pytest.mark.parametrize("N,nthreads,resets", [(4096, 512, 5), (4096, 1024, 0), (40, 64, 3), (37, 64, 2)])
+def test_finaliser_deferred_sink_stores_raw_rewards_and_bootstrap_flags_host(N, nthreads, resets):
+    """The transition sink of the deferred kind (HgymEnvOut.t_values NULL, t_time_outs set; header v7): both forms of the finaliser store
+    the RAW reward, the dones and the flags the bootstrap would have used -- the stale-by-design extras["time_outs"] AFTER this step's
+    refresh (only when an env reset: legged_robot.py:173-174) -- bit for bit the same, and `rew + gamma * (V * flags)` formed later is
+    exactly what the immediate sink stores (ppo.py:107-108)."""
+    from hgym import EnvBuffers, default_env_config
+    be = EC.HostBackend(envs_per_block=8, nthreads=64)
+    outs = []
+    for kind in ("deferred general", "deferred one-pass", "immediate"):
+        cfg = default_env_config(N, seed=1)
+        buf = EnvBuffers(cfg, "cpu")
+        gg = torch.Generator().manual_seed(N * 11 + 3)
+        buf.rew.copy_(torch.randn(N, generator=gg))
+        buf.reset.copy_(torch.rand(N, generator=gg) < 0.3)
+        buf.time_out.copy_(torch.rand(N, generator=gg) < 0.4)
+        buf.extras_time_outs.copy_(torch.rand(N, generator=gg) < 0.5)
+        buf.episode_acc.copy_(torch.randn(24, generator=gg))
+        buf.counters[1] = resets
+        values = torch.randn(N, generator=gg)
+        sink = dict(values=None if kind != "immediate" else values, rewards=torch.full((N,), float("nan")), dones=torch.zeros(N, dtype=torch.bool),
+                    time_outs=torch.full((N,), 7, dtype=torch.uint8), step=torch.zeros(1, dtype=torch.int64), gamma=0.994)
+        st, out = buf.state_struct(), buf.out_struct(sink=sink)
+        rc = be.lib.hc_finalize_forms(C.byref(cfg), C.byref(st), C.byref(out), nthreads, int(kind == "deferred one-pass"))
+        if kind == "deferred one-pass" and N % 8:
+            assert rc == 1 and torch.isnan(sink["rewards"]).all() and bool((sink["time_outs"] == 7).all())
+            outs.append(None)
+            continue
+        assert rc == 0
+        outs.append((sink["rewards"].clone(), sink["dones"].clone(), sink["time_outs"].clone(), buf.extras_time_outs.clone(), buf.rew.clone(), values))
+    gen, one, imm = outs
+    rw, dn, to, eto, rew, val = gen
+    assert torch.equal(rw, rew) and torch.equal(to.bool(), eto.bool()) and bool((to <= 1).all())
+    if one is not None:
+        for x, y in zip(gen[:4], one[:4]):
+            assert torch.equal(x, y)
+    assert torch.equal(imm[1], dn) and bool((imm[2] == 7).all())                     # the immediate sink never touches t_time_outs
+    assert torch.equal(imm[0], rew + torch.tensor(0.994, dtype=torch.float32) * (val * to.float()))

@@ -475,6 +475,49 @@ def test_first_layer_carried_across_launches_changes_nothing(monkeypatch, kb0):
     assert torch.isfinite(a["params"]).all()
 
 
+def test_deferred_values_rollout_equals_inline_rollout(monkeypatch):
+    """OnPolicyRunner.learn with the critic deferred (HGYM_ROLLOUT_CRITIC=deferred: launches without critic tiles + ONE critic pass behind
+    the last step, the path of more than 4096 envs per GPU) against the inline form from the same seeds, 2048 envs, three iterations
+    (eager, capture + replay, replay).  The first rollout must agree bit for bit in everything the actor and the env produce --
+    observations, actions, log-probs, dones -- and to the bf16 path's tolerance in what depends on V(s_t): values, bootstrapped
+    rewards, returns; both runs train (finite, moving parameters); the deferred run's graph replays end with the critic pass."""
+    from humanoid.algo import PPO
+    PPO.precision = "bf16"
+    outs = {}
+    for mode in ("inline", "deferred"):
+        monkeypatch.setenv("HGYM_ROLLOUT_CRITIC", mode)
+        torch.manual_seed(5)
+        np.random.seed(5)
+        r = _runner(2048, 31)
+        assert r.env.rollout_fused_mode(r.alg.net) == mode
+        p0 = r.alg.net.params.clone()
+        snap = {}
+        orig = r.alg.compute_returns
+
+        def spy(last, orig=orig, snap=snap, r=r):
+            orig(last)
+            if not snap:
+                st = r.alg.storage
+                torch.cuda.synchronize()
+                snap.update(obs=st.observations.clone(), act=st.actions.clone(), logp=st.actions_log_prob.clone(), dones=st.dones.clone(),
+                            val=st.values.clone(), rew=st.rewards.clone(), ret=st.returns.clone(), priv_sh=st._priv_bf16.clone(),
+                            valid=list(st.shadow_valid))
+        r.alg.compute_returns = spy
+        r.learn(num_learning_iterations=3, init_at_random_ep_len=True)
+        torch.cuda.synchronize()
+        assert r._graph is not None and torch.isfinite(r.alg.net.params).all() and not torch.equal(r.alg.net.params, p0)
+        assert int(r.alg.net.opt_state[1]) == 24 and float(r.alg.storage.values.abs().max()) > 0
+        outs[mode] = snap
+        del r
+    a, b = outs["inline"], outs["deferred"]
+    for k in ("obs", "act", "logp", "dones", "priv_sh"):
+        assert torch.equal(a[k], b[k]), k
+    assert all(a["valid"]) and all(b["valid"]) and int(a["dones"].sum()) >= 10
+    for k, tol in (("val", 2e-2), ("rew", 2e-2), ("ret", 2e-2)):
+        err = float((a[k] - b[k]).abs().max() / a[k].abs().max())
+        assert err <= tol, (k, err)
+
+
 def test_runner_update_reads_the_shadow_the_rollout_wrote(monkeypatch):
     """End to end: two learning iterations with the shadow (default) and without (HGYM_SHADOW=0) from the same seeds end in
     bit-identical parameters, and the shadow slots hold the bf16 of the stored observation rows."""

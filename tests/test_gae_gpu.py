@@ -85,3 +85,42 @@ def test_store_step_gpu():
     torch.cuda.synchronize()
     np.testing.assert_allclose(out_r.cpu().numpy(), want.numpy(), rtol=1e-6, atol=1e-7)
     assert torch.equal(out_d.cpu().bool(), dn)
+
+
+@pytest.mark.parametrize("T,N", [(60, 4096), (24, 100), (130, 37)])
+def test_gae_bootstrap_equals_store_step_then_gae(T, N):
+    """hgym_gae_bootstrap (deferred values, header v7) on RAW rewards + the bootstrap's time-out flags == hgym_store_step's bootstrap
+    (ppo.py:107-108) followed by hgym_gae: returns, advantages, statistics AND the rewards column it writes back, bit for bit."""
+    import ctypes as C
+    from hgym import _lib as L
+    g = torch.Generator(device="cuda").manual_seed(T * 1000 + N)
+    r = lambda *s: torch.randn(*s, device="cuda", generator=g)
+    raw, val, lv = r(T, N), r(T, N), r(N)
+    dones = (torch.rand(T, N, device="cuda", generator=g) < 0.03).to(torch.uint8)
+    tos = (torch.rand(T, N, device="cuda", generator=g) < 0.1).to(torch.uint8)
+    gamma, lam = 0.994, 0.9
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    boot = torch.empty_like(raw)
+    dslot = torch.empty_like(dones)
+    for t in range(T):
+        L.check(L.lib.hgym_store_step(N, L.fptr(raw[t]), L.fptr(val[t]), L.u8ptr(tos[t]), L.u8ptr(dones[t]), gamma, L.fptr(boot[t]),
+                                      L.u8ptr(dslot[t]), s), "hgym_store_step")
+    out = {}
+    for kind in ("two steps", "bootstrap"):
+        ret, adv, stats = torch.empty(T, N, device="cuda"), torch.empty(T, N, device="cuda"), torch.zeros(3, dtype=torch.float64, device="cuda")
+        if kind == "two steps":
+            rew = boot.clone()
+            L.check(L.lib.hgym_gae(T, N, L.fptr(rew), L.fptr(val), L.u8ptr(dones), L.fptr(lv), gamma, lam, L.fptr(ret), L.fptr(adv),
+                                   L.f64ptr(stats), s), "hgym_gae")
+        else:
+            rew = raw.clone()
+            L.check(L.lib.hgym_gae_bootstrap(T, N, L.fptr(rew), L.fptr(val), L.u8ptr(dones), L.u8ptr(tos), L.fptr(lv), gamma, lam, L.fptr(ret),
+                                             L.fptr(adv), L.f64ptr(stats), s), "hgym_gae_bootstrap")
+        torch.cuda.synchronize()
+        out[kind] = (rew, ret, adv, stats)
+    assert int((tos != 0).sum()) > 0 and not torch.equal(out["two steps"][0], raw)
+    assert torch.equal(out["bootstrap"][0], out["two steps"][0])                    # the column written back = the per-step path's
+    assert torch.equal(out["bootstrap"][1], out["two steps"][1]) and torch.equal(out["bootstrap"][2], out["two steps"][2])
+    assert float(out["bootstrap"][3][2]) == float(T * N)
+    # (the statistics are fp64 atomics over the workgroups: equal to rounding)
+    assert torch.allclose(out["bootstrap"][3], out["two steps"][3], rtol=1e-12, atol=0)

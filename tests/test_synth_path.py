@@ -283,3 +283,112 @@ def test_two_launch_rollout_8192_envs_vs_oracle_gpu(monkeypatch):
               % (T, counts), flips[0])
     assert counts["push"] == 1 and counts["timeout"] >= 3 and counts["reset"] > counts["timeout"] and counts["boot"] >= 3
     assert int(buf.counters[0]) == 392 + T and int(alg._sample_step) == T
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N", [8192, 4096])
+def test_deferred_values_rollout_vs_oracle_gpu(monkeypatch, N):
+    """the fused rollout launch WITHOUT critic tiles (hgym_rollout_step with values = NULL: one actor + env
+    workgroup per 32 envs, 8192 envs in one round) and the critic ONCE over the stored rows afterwards (hgym_critic_values), driven as
+    OnPolicyRunner.learn drives it, 20 steps, against oracle/synth_env_oracle.py fed the stored actions.
+      * dones bit-exact, next observations / privileged observations 1e-5, the RAW rewards of the sink 1e-5 (threshold flips counted);
+      * the bootstrap flags the finaliser stored == the oracle's stale-by-design extras["time_outs"], bit-exact;
+      * storage.values (one 64-row-tile pass over all slots) == ActorCritic.evaluate of each slot (the per-step launches' kernel) to the
+        bf16 path's tolerance, last_values likewise;
+      * after compute_returns: rewards == raw + gamma * (V * flags) EXACTLY (ppo.py:107-108 in fp32), returns / advantages vs the
+        oracle's GAE on those columns 1e-5 (rollout_storage.py:122-136).
+    N = 4096 runs the same path where the inline form would also fit (HGYM_ROLLOUT_CRITIC=deferred).
+    Reference: /root/reference/humanoid/algo/ppo/on_policy_runner.py:129-141,160-165."""
+    from humanoid.algo import PPO
+    from humanoid.envs import task_registry
+    from humanoid.utils import get_args
+    from oracle import ppo_oracle as P
+    PPO.precision = "bf16"
+    monkeypatch.setenv("HGYM_GRAPH", "0")
+    monkeypatch.setenv("HGYM_ROLLOUT_CRITIC", "deferred" if N <= 4096 else "auto")
+    torch.manual_seed(97)
+    np.random.seed(97)
+    T = 20
+    args = get_args(["--task=humanoid_ppo", "--headless", "--num_envs", str(N), "--seed", "29"])
+    task_registry.train_cfgs[args.task].seed = 29
+    task_registry.train_cfgs[args.task].runner.num_steps_per_env = T
+    try:
+        env, _ = task_registry.make_env(name=args.task, args=args)
+        runner, _ = task_registry.make_alg_runner(env=env, name=args.task, args=args, log_root=None)
+    finally:
+        task_registry.train_cfgs[args.task].runner.num_steps_per_env = 60
+    alg, buf = runner.alg, env._buf
+    assert env.rollout_fused_mode(alg.net) == "deferred" and not env.rollout_fused_supported(alg.net)
+    seed = int(env._ncfg.seed)
+    g = torch.Generator().manual_seed(6)
+    SC.plant(buf, None, g, csc=394)
+    torch.cuda.synchronize()
+    o = SC.oracle_from_buffers(buf)
+    st = alg.storage
+    assert st.num_transitions_per_env == T
+    obs_all, priv_all = st._obs_all, st._priv_all
+    obs_all[0].copy_(env.get_observations())
+    priv_all[0].copy_(env.get_privileged_observations())
+    alg.env_stores_transitions = True
+    with torch.inference_mode():
+        env.rollout_begin(alg._sample_step, T)
+        obs, pobs = obs_all[0], priv_all[0]
+        for i in range(T):
+            alg.fused_rollout_step(env, i, obs, pobs, obs_all[i + 1], priv_all[i + 1], deferred=True)
+            obs, pobs = obs_all[i + 1], priv_all[i + 1]
+        env.rollout_end()
+        torch.cuda.synchronize()
+        raw = st.rewards.clone()
+        assert float(st.values.abs().max()) == 0.0           # nothing has evaluated the critic yet
+        alg.deferred_values()
+        torch.cuda.synchronize()
+    flips = [0]
+    counts = dict(reset=0, timeout=0, push=0, boot=0)
+    for i in range(T):
+        a = st.actions[i].cpu()
+        obs_o, priv_o, rew_o, reset_o, info = S.synth_step(o, seed, a)
+        rew_dev = raw[i].view(-1).cpu()
+        d = (rew_dev - o.rew).abs()
+        bad = (d > (EC.ATOL + EC.RTOL * o.rew.abs())).nonzero().flatten().tolist()
+        for e in bad:                               # low_speed threshold flips (tests/synth_common.py): counted, re-synchronised
+            assert float(d[e]) <= SC.LOW_SPEED_QUANTUM, (i, e, float(d[e]))
+            o.episode_sums[e, K.REWARD_NAMES.index("low_speed")] += (rew_dev[e] - o.rew[e])
+            o.rew[e] = rew_dev[e]
+        flips[0] += len(bad)
+        EC.exact(st.dones[i].view(-1), reset_o, "dones %d" % i)
+        EC.exact(st.time_outs[i].view(-1).bool(), o.extras_time_outs.bool(), "bootstrap flags %d" % i)
+        EC.close(obs_all[i + 1], obs_o, "next obs %d" % i)
+        EC.close(priv_all[i + 1], priv_o, "next privileged obs %d" % i)
+        counts["reset"] += int(reset_o.sum())
+        counts["timeout"] += int(o.time_out.sum())
+        counts["push"] += int(info["pushed"])
+        counts["boot"] += int(o.extras_time_outs.sum())
+    assert flips[0] <= 2, flips
+    o.rew = buf.rew.cpu().clone() if flips[0] else o.rew
+    EC.compare_state(SC.Holder(buf), o, "after the deferred-values rollout", check_obs=False)
+    # the one-pass critic against the per-step launches' kernel on the same rows, and its bf16 shadow rows
+    with torch.inference_mode():
+        worst = 0.0
+        for i in (0, 1, T // 2, T - 1):
+            v_step = alg.actor_critic.evaluate(priv_all[i]).view(-1)
+            worst = max(worst, float((st.values[i].view(-1) - v_step).abs().max() / v_step.abs().max()))
+        v_last = alg.actor_critic.evaluate(priv_all[T]).view(-1)
+        worst = max(worst, float((st.last_values.view(-1) - v_last).abs().max() / v_last.abs().max()))
+    assert worst <= 2e-2, worst
+    assert all(st.shadow_valid) and torch.equal(st._priv_bf16[:, :, :219], st.privileged_observations.to(torch.bfloat16))
+    assert torch.equal(st._obs_bf16[:, :, :705], st.observations.to(torch.bfloat16))
+    # compute_returns: the bootstrap applied as the scan loads the rewards, the column written back
+    alg.compute_returns(priv_all[T])
+    torch.cuda.synchronize()
+    gam = torch.tensor(alg.gamma, dtype=torch.float32)
+    want_rew = raw.cpu() + gam * (st.values.cpu() * st.time_outs.cpu().float())
+    assert torch.equal(st.rewards.cpu(), want_rew)
+    assert int((want_rew != raw.cpu()).sum()) >= 3
+    ret_o, adv_o = P.gae_returns(want_rew.view(T, N), st.values.cpu().view(T, N), st.dones.cpu().view(T, N).bool(), st.last_values.cpu().view(N),
+                                 alg.gamma, alg.lam)
+    np.testing.assert_allclose(st.returns.cpu().view(T, N).numpy(), ret_o.numpy(), rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(st.advantages.cpu().view(T, N).numpy(), P.normalize_advantages(adv_o).numpy(), rtol=1e-4, atol=2e-5)
+    SC.report("fused rollout step WITHOUT critic tiles + one critic pass (deferred values), N=%d, %d steps vs oracle: %s; one-pass vs per-step "
+              "critic: %.2e" % (N, T, counts, worst), flips[0])
+    assert counts["push"] == 1 and counts["timeout"] >= 3 and counts["reset"] > counts["timeout"] and counts["boot"] >= 3
+    assert int(buf.counters[0]) == 394 + T and int(alg._sample_step) == T
