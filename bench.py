@@ -536,8 +536,9 @@ def main():
                      value=r["value"], unit="env-steps/s", steps=k_steps, warmup=k_warm, ms_per_step=r["ms_per_step"],
                      collection_ms=r["collection_ms"], ppo_update_ms=r["ppo_update_ms"])
             if r.get("kernels"):
-                # configs[3] is the HBM stress of the env step: report THAT kernel's roofline for it
-                e["roofline"] = _roofline_obj(r["kernels"], pick="env_step_kernel" if c == "envs8192" else None)
+                # configs[3] is the HBM stress of the env step: report the roofline of the kernel that contains it -- since round 5 the fused
+                # rollout launch without critic tiles (the critic runs once behind the rollout: "mlp_fwd_kernel<32>" class in kernels[])
+                e["roofline"] = _roofline_obj(r["kernels"], pick="rollout_step_kernel" if c == "envs8192" else None)
             extra.append(e)
 
     if dist is not None:

@@ -423,27 +423,21 @@ class LeggedRobot(BaseTask):
     # (include/hgym.h: hgym_rollout_begin / _step / _end).  Used by OnPolicyRunner when nothing on the host needs the per-step
     # results; every other caller keeps act() + step().
     def rollout_fused_supported(self, net):
-        """XBot-L default options (none of the generic ones), 15 / 3 history, a whole number of 32-env blocks, the bf16 fused net
-        path with XBot-L's first hidden widths, and one actor + one critic workgroup per 32 envs fitting the chip in one round.
-        (Beyond that -- 8192 envs, BASELINE configs[3] -- the two-launch path with 64-row policy tiles is faster: every CU streaming
-        the weights of a 32-row tile saturates the L2 -> CU path; measured, profiles/r03_seq_rollout_8192_negative_result.txt.)"""
-        c, nc = self._ncfg, net.cfg
-        generic = c.custom_origins or c.terrain_curriculum or c.num_height_points > 0 or c.command_curriculum or not c.heading_command
-        cus = int(self._L.lib.hgym_device_cus())
-        # the fused launch never calls step(): a task class that overrides step() / post_physics_step() (a wrapper, extra
-        # book-keeping around the step) must keep getting its own code, i.e. the act() + step() path
-        own_step = type(self).step is LeggedRobot.step and type(self).post_physics_step is LeggedRobot.post_physics_step
-        own_step = own_step and not getattr(self, "_custom_terms", None)       # user-defined reward terms: the two-launch step
+        """The fused rollout launch WITH the critic's tiles inline serves this env / net (rollout_fused_mode == "inline")."""
         return self.rollout_fused_mode(net) == "inline"
 
     def rollout_fused_mode(self, net):
         """"inline": hgym_rollout_step with the critic's tiles beside the actor's (one actor + one critic workgroup per 32 envs fit the
         chip in one round: up to 4096 envs on 256 CUs); "deferred": the launch without critic tiles (values = NULL: one actor + env
-        workgroup per 32 envs, up to 8192 envs) and the critic once over the stored rows after the rollout (PPO.deferred_values);
-        None: the two-launch path.  HGYM_ROLLOUT_CRITIC=inline|deferred|auto (default auto) restricts / forces the choice."""
+        workgroup per 32 envs, up to 8192 envs) and the critic once over the stored rows after the rollout (PPO.deferred_values) --
+        8192 envs: collection 3.68 -> 3.49 ms against the two-launch path, same call (profiles/r05d_deferred_values_ab.txt; round 3's
+        attempt WITH the critic's tiles in a second round of workgroups lost: profiles/r03_seq_rollout_8192_negative_result.txt); at
+        4096 envs the inline form wins (2.15 vs 2.76 ms: half the chip would idle); None: the two-launch path.  HGYM_ROLLOUT_CRITIC=inline|deferred|auto (default auto) restricts / forces the choice."""
         c, nc = self._ncfg, net.cfg
         generic = c.custom_origins or c.terrain_curriculum or c.num_height_points > 0 or c.command_curriculum or not c.heading_command
         cus = max(int(self._L.lib.hgym_device_cus()), 1)
+        # the fused launch never calls step(): a task class that overrides step() / post_physics_step() (a wrapper, extra
+        # book-keeping around the step) must keep getting its own code, i.e. the act() + step() path
         own_step = type(self).step is LeggedRobot.step and type(self).post_physics_step is LeggedRobot.post_physics_step
         own_step = own_step and not getattr(self, "_custom_terms", None)       # user-defined reward terms: the two-launch step
         ok = bool(own_step and not generic and not c.use_ref_actions and c.frame_stack == 15 and c.c_frame_stack == 3 and self.num_envs % 32 == 0
