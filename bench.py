@@ -392,6 +392,19 @@ def run_config(args, task, num_envs, rank, world, local, dist, steps, warmup, lo
                         note="stream time between the last backward kernel and the start of hgym_ppo_apply (HIP events on the compute stream, "
                              "one eager profiling iteration per backend, rank 0); includes waiting for the slowest rank.  budget = what an "
                              "efficiency of 0.9 leaves per minibatch: (iteration - exposed) x (1 / 0.9 - 1) / minibatches")
+            # SURVEY 8(e)'s parity target for N > 1: exact equality of the parameters across ranks after every step.  Checked here after all the
+            # timed + profiling iterations: a 64-bit sum of the parameter bits and the learning rate of every rank, gathered and compared
+            # (a stale cache line or a lost exchange in either backend would show up as a difference)
+            try:
+                pbits = runner.alg.net.params.view(torch.int32).to(torch.int64)
+                sig = torch.stack([pbits.sum(), (pbits * (torch.arange(pbits.numel(), device=pbits.device) % 8191 + 1)).sum(),
+                                   torch.tensor(runner.alg.learning_rate, dtype=torch.float64, device=pbits.device).view(torch.int64)])
+                sigs = [torch.zeros_like(sig) for _ in range(world)]
+                dist.all_gather(sigs, sig)
+                comm["replicas_identical_after_run"] = bool(all(torch.equal(x, sigs[0]) for x in sigs))
+                comm["optimizer_steps"] = int(float(runner.alg.net.opt_state[1]))
+            except Exception as e:      # noqa: BLE001
+                comm["replicas_check_error"] = str(e)
             c = getattr(runner.alg, "_comm", None)
             if c is not None:
                 try:
@@ -581,7 +594,8 @@ def main():
         if head.get("comm"):
             c = head["comm"]
             summ["comm"] = dict(used=c.get("used_in_timed_run"), fallback_reason=c.get("fallback_reason"),
-                                exposed_us_per_minibatch=c.get("exposed_us_per_minibatch"), within_budget=c.get("within_budget"))
+                                exposed_us_per_minibatch=c.get("exposed_us_per_minibatch"), within_budget=c.get("within_budget"),
+                                replicas_identical_after_run=c.get("replicas_identical_after_run"))
         out["summary"] = summ
         print(json.dumps(out))
     if dist is not None:

@@ -241,7 +241,12 @@ class P2PComm:
             L.check(L.lib.hgym_comm_alloc(self.nbytes, C.byref(base)), "hgym_comm_alloc")
             self._base = base.value
             self._handle = (C.c_ubyte * 64)()
-            L.check(L.lib.hgym_comm_ipc_export(base, self._handle), "hgym_comm_ipc_export")
+            try:
+                L.check(L.lib.hgym_comm_ipc_export(base, self._handle), "hgym_comm_ipc_export")
+            except Exception:
+                L.lib.hgym_comm_free(base)        # (nobody else will: the constructor's caller never gets the object)
+                self._base = None
+                raise
         self.data = torch.as_tensor(_DevMem(self._base, self.count, "<f4"), device=self.device)
         self.status = torch.as_tensor(_DevMem(self._base + self._stat_off, 16, "<i8"), device=self.device)
 

@@ -356,6 +356,7 @@ def test_bench_spawns_its_own_ranks(tmp_path):
     assert out["comm"]["minibatches_per_iter"] == 8 and out["comm"]["exposed_us_per_minibatch"] >= 0
     assert out["comm"]["mode"] == "auto" and out["comm"]["used_in_timed_run"] in ("p2p", "collective")
     assert (out["comm"]["fallback_reason"] is None) == (out["comm"]["used_in_timed_run"] == "p2p"), out["comm"]
+    assert out["comm"]["replicas_identical_after_run"] is True and out["comm"]["optimizer_steps"] > 0, out["comm"]
     assert out["roofline"]["frac"] > 0
     # the line ends with the compact block: the last 2 000 bytes (what the driver's record keeps) carry the headline's split
     tail = lines[0][-2000:]
