@@ -455,6 +455,32 @@ def place_rank_on_host(local, world):
         return dict(threads=1, pinned=False, note=str(e))
 
 
+def compact_summary(out, head, extra, world):
+    """The block the JSON line ENDS with (< 1.5 KB): a reader that keeps only the tail of the line (the driver's record keeps 2 000 bytes) still
+    has the headline's split, the big kernels and the baselines.  Everything in it repeats a field of the line."""
+    summ = dict(value=head["value"], n_gpus=world, ms_per_step=head["ms_per_step"], collection_ms=head["collection_ms"],
+                ppo_update_ms=head["ppo_update_ms"])
+    if head.get("kernels"):
+        big = {}
+        for k in head["kernels"]:
+            if k["kernel"] in ("mlp_fb_kernel", "dw_kernel", "rollout_step_kernel", "env_step_kernel", "mlp_fwd_kernel<32>"):
+                big[k["kernel"]] = dict(us=round(k["avg_launch_us"], 2), n=k["launches_per_iter"], frac=round(k["frac"], 4), bound=k["bound"],
+                                        traffic_MB=None if not k.get("traffic") else round(k["traffic"] / 1e6, 1),
+                                        share=round(k["share_of_iteration"], 3))
+        summ["kernels"] = big
+    if out.get("cpu_baseline"):
+        summ["cpu_baseline"] = dict(value=out["cpu_baseline"]["value"], cores=out["cpu_baseline"]["cores"], kind=out["cpu_baseline"]["kind"])
+    if extra:
+        summ["configs"] = {e["name"]: dict(value=round(e["value"]), collection_ms=round(e["collection_ms"], 3),
+                                           ppo_update_ms=round(e["ppo_update_ms"], 3)) for e in extra}
+    if head.get("comm"):
+        c = head["comm"]
+        summ["comm"] = dict(used=c.get("used_in_timed_run"), fallback_reason=c.get("fallback_reason"),
+                            exposed_us_per_minibatch=c.get("exposed_us_per_minibatch"), within_budget=c.get("within_budget"),
+                            replicas_identical_after_run=c.get("replicas_identical_after_run"))
+    return summ
+
+
 def spawn_ranks(args):
     """`python bench.py --gpus N` without a torch.distributed environment: run the same command line under
     torch.distributed.run, one rank per GPU, rendezvous on 127.0.0.1 (the container hostname may not resolve)."""
@@ -574,29 +600,7 @@ def main():
             out["configs"] = extra
         if not args.no_cpu_baseline and world == 1:      # the CPU baseline leg belongs to the N=1 run only
             out["cpu_baseline"] = cpu_baseline(N, T)
-        # The line ENDS with a compact block (< 1.5 KB): a reader that keeps only the tail of the line (the driver's record keeps 2 000
-        # bytes) still has the headline's split, the three big kernels and the baselines.  Everything in it repeats a field above.
-        summ = dict(value=head["value"], n_gpus=world, ms_per_step=head["ms_per_step"], collection_ms=head["collection_ms"],
-                    ppo_update_ms=head["ppo_update_ms"])
-        if head.get("kernels"):
-            big = {}
-            for k in head["kernels"]:
-                if k["kernel"] in ("mlp_fb_kernel", "dw_kernel", "rollout_step_kernel", "env_step_kernel", "mlp_fwd_kernel<32>"):
-                    big[k["kernel"]] = dict(us=round(k["avg_launch_us"], 2), n=k["launches_per_iter"], frac=round(k["frac"], 4), bound=k["bound"],
-                                            traffic_MB=None if not k.get("traffic") else round(k["traffic"] / 1e6, 1),
-                                            share=round(k["share_of_iteration"], 3))
-            summ["kernels"] = big
-        if out.get("cpu_baseline"):
-            summ["cpu_baseline"] = dict(value=out["cpu_baseline"]["value"], cores=out["cpu_baseline"]["cores"], kind=out["cpu_baseline"]["kind"])
-        if extra:
-            summ["configs"] = {e["name"]: dict(value=round(e["value"]), collection_ms=round(e["collection_ms"], 3),
-                                               ppo_update_ms=round(e["ppo_update_ms"], 3)) for e in extra}
-        if head.get("comm"):
-            c = head["comm"]
-            summ["comm"] = dict(used=c.get("used_in_timed_run"), fallback_reason=c.get("fallback_reason"),
-                                exposed_us_per_minibatch=c.get("exposed_us_per_minibatch"), within_budget=c.get("within_budget"),
-                                replicas_identical_after_run=c.get("replicas_identical_after_run"))
-        out["summary"] = summ
+        out["summary"] = compact_summary(out, head, extra, world)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

@@ -70,3 +70,48 @@ def test_measurement_scripts_compile():
     for sh in glob.glob(os.path.join(root, "tools", "*.sh")):
         for name in re.findall(r"tools/([A-Za-z0-9_]+\.(?:py|sh))", open(sh).read()):
             assert os.path.exists(os.path.join(root, "tools", name)), "%s names tools/%s" % (os.path.basename(sh), name)
+
+
+def test_compact_summary_fits_the_tail_of_the_line():
+    """bench.py ends its JSON line with `summary` (the driver's record keeps the last 2 000 bytes): with every
+    optional part present -- five kernel entries, four extra configurations, the comm block, the CPU baseline -- it stays below 1 500
+    bytes and carries the headline's split."""
+    import json
+    b = _bench()
+    ks = [dict(kernel=k, avg_launch_us=281.123456, launches_per_iter=8, frac=0.231234, bound="mfma", traffic=749.6e6, share_of_iteration=0.367891)
+          for k in ("mlp_fb_kernel", "dw_kernel", "rollout_step_kernel", "env_step_kernel", "mlp_fwd_kernel<32>", "gae_kernel")]
+    head = dict(value=40576972.31859024, ms_per_step=6.056637199799297, collection_ms=2.1931596994400024, ppo_update_ms=3.8346933126449585, kernels=ks,
+                comm=dict(used_in_timed_run="collective", fallback_reason="first direct exchange failed (rank 7: a bounded wait (2.0 s) expired)",
+                          exposed_us_per_minibatch=71.23456789, within_budget=True, replicas_identical_after_run=True))
+    extra = [dict(name=n, value=45968663.123, collection_ms=3.46123456, ppo_update_ms=7.18812345) for n in ("envs8192", "logging_on", "dwl_head", "fp32")]
+    out = dict(cpu_baseline=dict(value=23105.59911003899, cores=16, kind="port"))
+    s = b.compact_summary(out, head, extra, 8)
+    txt = json.dumps(s)
+    assert len(txt) < 1500, len(txt)
+    assert s["collection_ms"] == head["collection_ms"] and s["ppo_update_ms"] == head["ppo_update_ms"] and s["n_gpus"] == 8
+    assert set(s["kernels"]) == {"mlp_fb_kernel", "dw_kernel", "rollout_step_kernel", "env_step_kernel", "mlp_fwd_kernel<32>"}
+    assert s["comm"]["replicas_identical_after_run"] is True and set(s["configs"]) == {"envs8192", "logging_on", "dwl_head", "fp32"}
+
+
+def test_rank_placement_partitions_the_allowed_cores(monkeypatch):
+    """bench.py --gpus N: every rank gets its own block of the cores the process may run on (no two launch threads on one core), one intra-op
+    thread; HGYM_PIN=0 leaves the affinity alone."""
+    import torch
+    b = _bench()
+    if not hasattr(os, "sched_setaffinity"):
+        return
+    allowed = sorted(os.sched_getaffinity(0))
+    calls = []
+    monkeypatch.setattr(os, "sched_setaffinity", lambda pid, cores: calls.append(list(cores)))
+    nt = torch.get_num_threads()
+    try:
+        world = 2 if len(allowed) >= 4 else 1
+        blocks = [b.place_rank_on_host(r, world) for r in range(world)]
+        if len(allowed) // world >= 2:
+            assert all(x["pinned"] for x in blocks) and len(calls) == world
+            assert not (set(calls[0]) & set(calls[-1])) or world == 1
+            assert all(set(c) <= set(allowed) and 2 <= len(c) <= 16 for c in calls)
+        monkeypatch.setenv("HGYM_PIN", "0")
+        assert b.place_rank_on_host(0, world)["pinned"] is False
+    finally:
+        torch.set_num_threads(nt)
