@@ -1,4 +1,10 @@
-"""python humanoid-gym_amd/humanoid/scripts/train.py --task=humanoid_ppo --headless  (reference scripts/train.py:36-43)."""
+"""python humanoid-gym_amd/humanoid/scripts/train.py --task=humanoid_ppo --headless  (reference scripts/train.py:36-43).
+
+Several GPUs of one node: the same command line under torch.distributed.run, one process per GPU --
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29500 \\
+           humanoid-gym_amd/humanoid/scripts/train.py --task=humanoid_ppo --headless --num_envs 4096
+-- every rank owns --num_envs envs on its own GPU (its own env stream: helpers.shard_seed) and the ranks exchange [gradient | KL] once
+per minibatch (algo/ppo/dist_utils.py); rank 0 alone logs and writes checkpoints (the replicas are bit-identical)."""
 import os
 import sys
 
@@ -6,12 +12,32 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 
 from humanoid.envs import *  # noqa: F401,F403,E402
 from humanoid.utils import get_args, task_registry  # noqa: E402
+from humanoid.utils.helpers import init_distributed  # noqa: E402
 
 
 def train(args):
+    rank, world = init_distributed(args)
     env, env_cfg = task_registry.make_env(name=args.task, args=args)
-    ppo_runner, train_cfg = task_registry.make_alg_runner(env=env, name=args.task, args=args)
+    ppo_runner, train_cfg = task_registry.make_alg_runner(env=env, name=args.task, args=args, **({} if rank == 0 else {"log_root": None}))
     ppo_runner.learn(num_learning_iterations=train_cfg.runner.max_iterations, init_at_random_ep_len=True)
+    if os.environ.get("HGYM_TRAIN_SIGNATURE"):      # tests: a signature of this rank's final parameters (replicas must agree bit for bit)
+        import json
+        import torch
+        net = ppo_runner.alg.net
+        bits = net.params.view(torch.int32).to(torch.int64)
+        json.dump(dict(world=world, steps=int(float(net.opt_state[1])), lr=float(net.opt_state[0]),
+                       params=[int(bits.sum()), int((bits * (torch.arange(bits.numel(), device=bits.device) % 8191 + 1)).sum())],
+                       comm=getattr(ppo_runner.alg, "comm_report", None)),
+                  open(os.path.join(os.environ["HGYM_TRAIN_SIGNATURE"], "rank%d.json" % rank), "w"))
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.synchronize()
+        if getattr(ppo_runner.alg, "_comm", None) is not None:
+            ppo_runner.alg._comm.close()
+        dist.barrier()
+        dist.destroy_process_group()
+    return ppo_runner
 
 
 if __name__ == "__main__":

@@ -56,6 +56,33 @@ def shard_seed(seed):
     return seed if seed == -1 else int(seed) + 100003 * rank
 
 
+def init_distributed(args):
+    """One process per GPU under `python -m torch.distributed.run` (WORLD_SIZE > 1 in the environment): join the process group (backend
+    "nccl" = RCCL over xGMI; HGYM_DIST_BACKEND=gloo lets ranks share a GPU in tests), bind this rank to ITS GPU and point --sim_device /
+    --rl_device at it.  Returns (rank, world_size); in a single process (0, 1) and nothing is touched.  The reference is single-process (its
+    `--horovod` flag is dead, helpers.py:207-212): this is the N > 1 entry of the native stack -- envs shard across the ranks (every rank
+    draws its own stream: shard_seed), PPO.update exchanges [gradient | KL] once per minibatch (algo/ppo/dist_utils.py)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        return 0, 1
+    import torch.distributed as dist
+    rank, local = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise RuntimeError("init_distributed: no GPU visible (the hot path has no CPU fallback)")
+    local = local % torch.cuda.device_count()
+    torch.cuda.set_device(local)
+    if not dist.is_initialized():
+        backend = os.environ.get("HGYM_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
+    dev = "cuda:%d" % local
+    args.sim_device = args.rl_device = dev
+    args.compute_device_id = args.sim_device_id = local
+    return rank, world
+
+
 def parse_sim_params(args, cfg):
     """The reference builds gymapi.SimParams for PhysX here; the synthetic physics backend only needs dt."""
     sim = cfg.get("sim", {}) if isinstance(cfg, dict) else {}

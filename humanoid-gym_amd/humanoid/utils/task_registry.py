@@ -62,7 +62,9 @@ class TaskRegistry:
         runner_class = eval(all_cfg["runner_class_name"])
         runner = runner_class(env, all_cfg, log_dir, device=args.rl_device)
         if train_cfg.runner.resume:
-            resume_path = get_load_path(log_root, load_run=train_cfg.runner.load_run, checkpoint=train_cfg.runner.checkpoint)
+            # (log_root=None -- a rank > 0 of a multi-GPU run, which does not log -- still resumes from the experiment's default directory)
+            load_root = log_root if log_root is not None else os.path.join(LEGGED_GYM_ROOT_DIR, "logs", train_cfg.runner.experiment_name)
+            resume_path = get_load_path(load_root, load_run=train_cfg.runner.load_run, checkpoint=train_cfg.runner.checkpoint)
             print(f"Loading model from: {resume_path}")
             runner.load(resume_path, load_optimizer=False)
         return runner, train_cfg

@@ -45,3 +45,38 @@ def test_train_play_sim2sim_command_lines(task, exp, golden_dir):
         shutil.rmtree(logs, ignore_errors=True)
         if os.path.exists(os.path.join(ROOT, "play_states.png")):
             os.remove(os.path.join(ROOT, "play_states.png"))
+
+
+def test_train_py_under_torchrun_two_ranks(tmp_path):
+    """`scripts/train.py` as README / INTEGRATION.md launch it on several GPUs: under torch.distributed.run, one process per GPU
+    (here two ranks sharing the one GPU over gloo, HGYM_DIST_BACKEND).  helpers.init_distributed joins the group and binds the rank to its
+    device; rank 0 alone logs and checkpoints; the gradient exchange picks itself (HGYM_COMM=auto); both ranks end with the same
+    parameters -- checked by the run itself through a hook file (HGYM_TRAIN_SIGNATURE)."""
+    import json
+    import socket
+    from humanoid import LEGGED_GYM_ROOT_DIR
+    exp = "XBot_e2e_ddp"
+    logs = os.path.join(LEGGED_GYM_ROOT_DIR, "logs", exp)
+    shutil.rmtree(logs, ignore_errors=True)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, PYTHONPATH=PKG + os.pathsep + os.environ.get("PYTHONPATH", ""), HGYM_DIST_BACKEND="gloo",
+               HGYM_TRAIN_SIGNATURE=str(tmp_path), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    try:
+        p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                            "--master-port", str(port), os.path.join(SCRIPTS, "train.py"), "--task=humanoid_ppo", "--headless", "--num_envs", "128",
+                            "--max_iterations", "3", "--experiment_name", exp, "--run_name", "ddp"],
+                           cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stdout[-3000:] + "\n" + p.stderr[-3000:]
+        assert p.stdout.count("Learning iteration 2/3") == 1, p.stdout[-2000:]           # rank 0 alone logs
+        runs = glob.glob(os.path.join(logs, "*_ddp"))
+        assert len(runs) == 1 and os.path.exists(os.path.join(runs[0], "model_3.pt"))    # ... and checkpoints
+        sig = [json.load(open(os.path.join(str(tmp_path), "rank%d.json" % r))) for r in range(2)]
+        assert sig[0]["world"] == sig[1]["world"] == 2 and sig[0]["steps"] == sig[1]["steps"] == 24
+        assert sig[0]["params"] == sig[1]["params"] and sig[0]["lr"] == sig[1]["lr"]      # bit-identical replicas
+        assert sig[0]["comm"]["mode"] == "auto" and sig[0]["comm"]["used"] == sig[1]["comm"]["used"]
+    finally:
+        shutil.rmtree(logs, ignore_errors=True)
