@@ -298,6 +298,7 @@ def _single_rank_worker(rank, world, port, out_dir, collectives):
     torch.cuda.set_device(0)
     if collectives:
         os.environ["HGYM_DIST_SINGLE"] = "1"
+        os.environ["HGYM_COMM"] = "rccl"       # this test is about the COLLECTIVE's stream ordering (auto would probe and may pick the direct kernel)
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     from humanoid.algo import PPO
     PPO.precision = "bf16"
