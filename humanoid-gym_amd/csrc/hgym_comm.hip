@@ -21,6 +21,15 @@
 //   B  every workgroup release-fences and bumps a local counter; the last one stores seq into slot B[r] of every rank's flag block.
 //      Workgroup 0 waits for B[q] >= seq for all q before it exits: when my kernel completes, every shard of my buffer holds its
 //      final sum and no peer still reads my gradient -- the next kernel on the stream (hgym_ppo_apply) may read and overwrite it.
+// Visibility across devices (what the protocol relies on; between processes on ONE device all of it is trivially true, which is why
+// dist_utils.P2PComm.probe_verify checks several rounds of CHANGING data at first contact and falls back to the collective on a wrong sum):
+//   * my gradient, written by the previous kernel, is in memory when phase A's flag goes out: the kernel boundary is at least an
+//     agent-scope release, which on a device with one L2 per XCD writes every L2 back (no flag-side fence could: it would reach one XCD);
+//   * a peer's loads of it are not served from a line of an earlier call: the system-scope acquire fence behind phase A's wait
+//     invalidates the reader's L1 / L2 (the mapping of a peer's fine-grained buffer is uncached anyway);
+//   * my sums are in every peer's memory before flag B: every workgroup's system-scope release fence (L2 write-back + vmcnt(0): remote
+//     stores are acknowledged by the remote memory), then the agent-scope counter, then the last workgroup's flag stores;
+//   * the next kernel on my stream reads what the peers stored into MY buffer: its kernel-start acquire invalidates my caches.
 // Every wait is BOUNDED (HgymComm.wait_ticks of the 100 MHz wall clock; 0 = 15 s): on expiry the kernel writes status[0] = 1 (sticky) and
 // status[1] = seq, skips the sum and STILL runs phase B's book-keeping -- the local done counter counts one call and is reset by the call's
 // last workgroup, so a communicator that has seen a time-out stays usable (the payload of that call is garbage; the caller decides:

@@ -73,6 +73,7 @@ def broadcast_parameters(params):
 
 
 PROBE_CALLS = 20
+PROBE_ROUNDS = 6          # check rounds of probe_verify (the contribution changes every round)
 PROBE_WAIT_S = 2.0
 _REPORT = {}
 
@@ -316,28 +317,36 @@ class P2PComm:
         return (s[9] - s[8]) * 0.01, (s[10] - s[9]) * 0.01
 
     def probe_verify(self, device):
-        """First contact, local part (make_comm agrees on the result over all ranks): (ok, note).  A known pattern through the direct
-        kernel -- rank q contributes (q + 1) x [1 .. 7 repeating], the sum is W (W + 1) / 2 x the pattern, exact in fp32.  The wait is
-        bounded by PROBE_WAIT_S."""
+        """First contact, local part (make_comm agrees on the result over all ranks): (ok, note).  PROBE_ROUNDS known patterns through
+        the direct kernel back to back, as training issues it: a kernel on this stream writes the contribution, the exchange follows
+        with no host synchronisation in between, the result is copied aside, the next round overwrites the buffer.  Rank q contributes
+        (q + 1) (k + 1) x [1 .. 7 repeating] in round k, the sum is W (W + 1) / 2 (k + 1) x the pattern, exact in fp32 -- a value that
+        changes every round, so a peer's (or this device's) stale cache line of an earlier round shows up as a wrong sum here, not as
+        a silently diverged replica later.  Every wait is bounded by PROBE_WAIT_S."""
         W, n = self.world, self.count
         self.set_wait(PROBE_WAIT_S)
         pat = (torch.arange(n, device=device, dtype=torch.float32) % 7.0) + 1.0
-        self.data.copy_(pat * float(self.rank + 1))
+        got = torch.zeros(PROBE_ROUNDS, n, device=device, dtype=torch.float32)
+        self.data.zero_()
         torch.cuda.synchronize(device)
         dist.barrier()
         skip = _inject("timeout")
-        if skip:
-            self.seq += 1                     # this rank's kernel never runs: the peers' waits expire
-        else:
+        for k in range(PROBE_ROUNDS):
+            if skip:
+                self.seq += 1                 # this rank's kernel never runs: the peers' waits expire
+                continue
+            torch.mul(pat, float((self.rank + 1) * (k + 1)), out=self.data)
             self.allreduce()
+            got[k].copy_(self.data)
         s = self.read_status()
         if s[0] != 0:
             return False, "a bounded wait (%.1f s) expired" % PROBE_WAIT_S
-        want = pat * float(W * (W + 1) // 2)
-        if _inject("sum"):
-            want = want + 1.0
-        if not skip and not torch.equal(self.data, want):
-            return False, "wrong sum in %d of %d elements" % (int((self.data != want).sum()), n)
+        for k in range(PROBE_ROUNDS):
+            want = pat * float(W * (W + 1) // 2 * (k + 1))
+            if _inject("sum"):
+                want = want + 1.0
+            if not skip and not torch.equal(got[k], want):
+                return False, "wrong sum in %d of %d elements (round %d of %d)" % (int((got[k] != want).sum()), n, k + 1, PROBE_ROUNDS)
         return True, None
 
     def probe_time(self, device):
