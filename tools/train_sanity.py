@@ -7,6 +7,7 @@ import torch
 from humanoid.envs import task_registry
 from humanoid.utils import get_args
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+every = int(os.environ.get("HGYM_SANITY_EVERY", "10"))             # HGYM_PRECISION=f32: the reference's own arithmetic, same seed
 task = sys.argv[2] if len(sys.argv) > 2 else "humanoid_ppo"       # humanoid_dwl_ppo: + the denoising head's MSE
 a = get_args(["--task=" + task, "--headless", "--num_envs", "4096"])
 env, _ = task_registry.make_env(name=a.task, args=a)
@@ -16,10 +17,10 @@ for it in range(iters):
     os.environ["HGYM_ASYNC"] = "0"
     runner.learn(num_learning_iterations=1, init_at_random_ep_len=(it == 0))
     o = alg.net.opt_state.cpu()
-    if it % 10 == 0 or it == iters - 1:
+    if it % every == 0 or it == iters - 1:
         st = alg.storage
         n = max(float(o[7]), 1.0)
-        print("it %3d  value_loss %.5f  surrogate %+.5f  kl %.5f  lr %.2e  |grad| %.3f  mean_rew/step %.4f  std %.3f  finite %s%s" % (
+        print("it %4d  value_loss %.5f  surrogate %+.5f  kl %.5f  lr %.2e  |grad| %.3f  mean_rew/step %.4f  std %.3f  ep_len %.1f  finite %s%s" % (
             it, float(o[4]) / n, float(o[3]) / n, float(o[2]) / n, float(o[0]), float(o[6]), float(st.rewards.mean()),
-            float(alg.actor_critic.std.detach().mean()), bool(torch.isfinite(alg.net.params).all()),
+            float(alg.actor_critic.std.detach().mean()), float(env.episode_length_buf.float().mean()), bool(torch.isfinite(alg.net.params).all()),
             ("  denoise_mse %.5f" % (float(o[10]) / n)) if "dwl" in task else ""), flush=True)
