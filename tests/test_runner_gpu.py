@@ -261,3 +261,48 @@ def test_full_size_rollout_storage_is_self_consistent():
             assert float(priv[t + 1][gone][:, :2 * 73].abs().max()) == 0.0
     assert int(dones.sum()) > 0                                  # resets did occur in the window
     assert torch.isfinite(st.rewards).all() and torch.isfinite(obs).all() and torch.isfinite(priv).all()
+
+
+@pytest.mark.parametrize("precision", ["bf16", "f32"])
+def test_other_frame_stacks_and_a_ragged_env_count_train(precision, tmp_path):
+    """What the reference's config CAN resize (humanoid_config.py:40-45: frame_stack, c_frame_stack -> num_observations,
+    num_privileged_obs; any num_envs; train_cfg's rollout length / minibatch count): 100 envs, 4 x 47 actor inputs, 2 x 73 critic
+    inputs, 24 steps per rollout in 2 minibatches, through make_env / make_alg_runner / learn with logging on.  The env runs the
+    runtime-sized env_step_kernel (tests/test_env_gpu.py::test_generic_frame_stack_gpu pins it against the oracle), the storage and the
+    update take their widths from the env; here: shapes, finiteness, the optimiser's step count, a checkpoint that loads back."""
+    from humanoid.algo import PPO
+    from humanoid.envs import task_registry
+    from humanoid.utils import get_args
+    PPO.precision = precision
+    try:
+        args = get_args(["--task=humanoid_ppo", "--headless", "--num_envs", "100", "--seed", "11"])
+        import copy
+        env_cfg, train_cfg = (copy.deepcopy(c) for c in task_registry.get_cfgs(name=args.task))     # (the registry hands out its singletons)
+        env_cfg.env.frame_stack, env_cfg.env.c_frame_stack = 4, 2
+        env_cfg.env.num_observations = 4 * env_cfg.env.num_single_obs
+        env_cfg.env.num_privileged_obs = 2 * env_cfg.env.single_num_privileged_obs
+        train_cfg.runner.num_steps_per_env = 24
+        train_cfg.algorithm.num_mini_batches = 2
+        env, _ = task_registry.make_env(name=args.task, args=args, env_cfg=env_cfg)
+        assert (env.num_envs, env.num_obs, env.num_privileged_obs) == (100, 188, 146)
+        runner, _ = task_registry.make_alg_runner(env=env, name=args.task, args=args, train_cfg=train_cfg, log_root=str(tmp_path))
+        ac = runner.alg.actor_critic
+        assert ac.actor[0].in_features == 188 and ac.critic[0].in_features == 146
+        runner.learn(num_learning_iterations=3, init_at_random_ep_len=True)
+        torch.cuda.synchronize()
+        st = runner.alg.storage
+        assert tuple(st.observations.shape) == (24, 100, 188) and tuple(st.privileged_observations.shape) == (24, 100, 146)
+        net = runner.alg.net
+        assert torch.isfinite(net.params).all() and int(net.opt_state[1]) == 3 * 2 * 2      # 2 epochs x 2 minibatches x 3 iterations
+        assert torch.isfinite(st.returns).all() and torch.isfinite(st.advantages).all()
+        path = os.path.join(runner.log_dir, "model_3.pt")
+        assert os.path.exists(path)
+        before = net.params.clone()
+        net.params.zero_()
+        runner.load(path)
+        assert torch.equal(net.params, before)
+        obs = env.get_observations()
+        act = runner.get_inference_policy(device=env.device)(obs)
+        assert tuple(act.shape) == (100, 12) and torch.isfinite(act).all()
+    finally:
+        PPO.precision = "bf16"
