@@ -5,7 +5,7 @@ src = sys.argv[1]
 flt = sys.argv[2] if len(sys.argv) > 2 else ""
 extra = ["-ffp-contract=off"] if any(k in src for k in ("env", "gae", "rollout")) else []
 out = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", "/tmp/_kr.o",
-                      "-Rpass-analysis=kernel-resource-usage", "-I/root/repo/include"] + extra, capture_output=True, text=True).stderr
+                      "-Rpass-analysis=kernel-resource-usage", "-I/root/repo/include"] + extra + sys.argv[3:], capture_output=True, text=True).stderr
 cur = None
 rows = {}
 for line in out.splitlines():
