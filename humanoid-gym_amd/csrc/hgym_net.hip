@@ -55,6 +55,7 @@ struct WsLayout {
     int64_t slabs;           // [splits][P] fp32
     int64_t partials;        // [MAX_LOSS_BLOCKS][16] fp32
     int64_t zeros;           // 4 KiB that nothing ever writes (the workspace arrives zero-filled)
+    int64_t sqn;             // [SQN_BLOCKS] fp64 per-workgroup sums of sqnorm_prologue_kernel + its arrival counter (zero between launches)
     int64_t total_bytes;
     int fused;               // 1: bf16 fast path (three fused kernels) is usable for this configuration
     int64_t Mpad;            // fused path: batch padded to the 64-row tile
@@ -62,6 +63,7 @@ struct WsLayout {
 };
 
 constexpr int MAX_LOSS_BLOCKS = 8192;   // 256 samples each: minibatches up to 2 M samples
+constexpr int SQN_BLOCKS = 256;         // workgroups of sqnorm_prologue_kernel
 
 static bool fused_supported(const HgymNetConfig* c) {
     if (c->precision != HGYM_BF16 || c->actor_layers != 4 || c->critic_layers != 4) return false;
@@ -169,6 +171,7 @@ static int32_t ws_layout(const HgymNetConfig* c, WsLayout* w) {
     w->slabs = take((int64_t)w->splits * w->Ps * 4);
     w->partials = take((int64_t)MAX_LOSS_BLOCKS * LOSS_PARTIALS * 4);
     w->zeros = take(4096);
+    w->sqn = take((SQN_BLOCKS + 2) * 8);
     w->total_bytes = off;
     return HGYM_OK;
 }
@@ -533,28 +536,16 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const SegTable tab, i
     }
 }
 
-// inv_w: 1 / world_size -- with several ranks `g` holds the all-reduced SUM and the mean is formed here and in adam_kernel
-// (fp32 product, what `grad.mul_(1 / world)` would have stored); 1.0f for one rank, which is exact.
-__global__ __launch_bounds__(256) void sqnorm_kernel(int64_t P, const float* __restrict__ g, float inv_w, double* __restrict__ opt) {
-    __shared__ double red[4];
-    double s = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (int64_t)gridDim.x * blockDim.x) {
-        const float gi = g[i] * inv_w;
-        s += (double)gi * (double)gi;
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(&opt[9], red[0] + red[1] + red[2] + red[3]);
-}
+// (inv_w: 1 / world_size -- with several ranks the gradient vector holds the all-reduced SUM and the mean is formed in sqnorm_prologue_kernel and in
+// adam_kernel: an fp32 product, what `grad.mul_(1 / world)` would have stored; 1.0f for one rank, which is exact.)
 
-// ppo.py:140-148 (adaptive-KL learning rate, python-double arithmetic) + Adam step counter + norm accumulator reset
-__global__ void apply_prologue_kernel(const HgymPPOConfig p, const float* __restrict__ kl_slot, float inv_w, double* __restrict__ opt) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// ppo.py:140-148 (adaptive-KL learning rate, python-double arithmetic) + Adam step counter + the squared norm Adam will clip with: `sq` when
+// this call determined it itself (sqnorm_prologue_kernel), 0 when a norm pass follows, untouched when the gradient call left it (have_sq < 0)
+__device__ __forceinline__ void apply_prologue(const HgymPPOConfig& p, const float* __restrict__ kl_slot, float inv_w, double* __restrict__ opt,
+                                               int have_sq, double sq) {
     if (p.world_size > 1) opt[8] = (double)(kl_slot[0] * inv_w);     // mean over ranks of the minibatch KL: same LR branch everywhere
     if (opt[13] == opt[1] && opt[1] > 0.0) {     // the gradient call already took this step's prologue (marker: ppo_scalars_block) and the
-        if (p.world_size > 1 || !p.grad_norm_ready) opt[9] = 0.0;     // caller applies with another configuration: not a second time
+        if (have_sq >= 0) opt[9] = have_sq ? sq : 0.0;                // caller applies with another configuration: not a second time
         return;
     }
     if (p.adaptive_lr) {
@@ -573,7 +564,51 @@ __global__ void apply_prologue_kernel(const HgymPPOConfig p, const float* __rest
     opt[11] = (double)(float)(opt[0] / bc1);      // step size
     opt[12] = (double)(float)sqrt(bc2);
     opt[13] = t;                                  // marker: this step's prologue is done (adam_kernel clears it)
-    if (p.world_size > 1 || !p.grad_norm_ready) opt[9] = 0.0;   // sqnorm_kernel follows (rank MEAN after an all-reduce / foreign gradients)
+    if (have_sq >= 0) opt[9] = have_sq ? sq : 0.0;
+}
+__global__ void apply_prologue_kernel(const HgymPPOConfig p, const float* __restrict__ kl_slot, float inv_w, double* __restrict__ opt) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    // (a norm pass follows this launch only when the caller could not reuse the gradient call's: several ranks / foreign gradients)
+    apply_prologue(p, kl_slot, inv_w, opt, (p.world_size > 1 || !p.grad_norm_ready) ? 0 : -1, 0.0);
+}
+
+// The two launches hgym_ppo_apply used to start with when the norm of the gradient call cannot be reused (several ranks: the norm is of the
+// rank MEAN; foreign gradients) -- the prologue and the squared-norm pass -- as one: every workgroup leaves its fp64 partial sum, the last one
+// to arrive adds the SQN_BLOCKS partials in a fixed order (no atomics on the sum: the same bits on every rank and in every run) and takes the
+// prologue with the total.  part[SQN_BLOCKS] is the arrival counter (an unsigned int, zero between launches: the last workgroup resets it).
+__global__ __launch_bounds__(256) void sqnorm_prologue_kernel(int64_t P, const float* __restrict__ g, float inv_w, const HgymPPOConfig p,
+                                                              const float* __restrict__ kl_slot, double* __restrict__ opt,
+                                                              double* __restrict__ part) {
+    __shared__ double red[4];
+    __shared__ unsigned int s_last;
+    double s = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (int64_t)gridDim.x * blockDim.x) {
+        const float gi = g[i] * inv_w;
+        s += (double)gi * (double)gi;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    unsigned int* counter = reinterpret_cast<unsigned int*>(part + SQN_BLOCKS);
+    if (threadIdx.x == 0) {
+        part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+        __threadfence();
+        s_last = atomicAdd(counter, 1u) == gridDim.x - 1u ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    double v = threadIdx.x < gridDim.x ? reinterpret_cast<const volatile double*>(part)[threadIdx.x] : 0.0;      // (behind the fence: the peers' partials)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        *counter = 0u;
+        apply_prologue(p, kl_slot, inv_w, opt, 1, red[0] + red[1] + red[2] + red[3]);
+    }
 }
 
 // writes one master weight into every compute-precision operand copy of its layer
@@ -1261,10 +1296,11 @@ struct NetRunner {
     int32_t apply(const HgymPPOConfig& ppo) {
         prof_begin(HGYM_PROF_APPLY, s);
         const float inv_w = ppo.world_size > 1 ? (float)(1.0 / (double)ppo.world_size) : 1.0f;
-        if (!prologue_in_grad(ppo))
-            hipLaunchKernelGGL(apply_prologue_kernel, dim3(1), dim3(64), 0, s, ppo, net.grads + w.P, inv_w, net.opt_state);
         if (ppo.world_size > 1 || !ppo.grad_norm_ready)        // else: reduce_slabs_kernel left the squared norm in opt[9]
-            hipLaunchKernelGGL(sqnorm_kernel, dim3(256), dim3(256), 0, s, w.P, net.grads, inv_w, net.opt_state);
+            hipLaunchKernelGGL(sqnorm_prologue_kernel, dim3(SQN_BLOCKS), dim3(256), 0, s, w.P, net.grads, inv_w, ppo, net.grads + w.P, net.opt_state,
+                               at<double>(w.sqn));
+        else if (!prologue_in_grad(ppo))
+            hipLaunchKernelGGL(apply_prologue_kernel, dim3(1), dim3(64), 0, s, ppo, net.grads + w.P, inv_w, net.opt_state);
         const SegTable tab = segments(false);
         // 256 workgroups per segment: the two first-layer matrices hold 57 % of the parameters, and 64 workgroups (a quarter of
         // the CUs) walked them in 22 dependent load -> store rounds per lane (30.7 us; 18.1 us with 256, 20.8 us with 512)

@@ -492,3 +492,36 @@ def test_ppo_iteration_full_width_bf16_fused_kernels_vs_reference(capsys):
     # while every tensor as a whole keeps its direction and length -- that is the statement asserted.
     for name, d in cmp_p.items():
         assert d["rel_l2"] <= BF16_DP_TOL["rel_l2"] and d["cos"] >= BF16_DP_TOL["cos"] and abs(d["norm_ratio"] - 1) <= BF16_DP_TOL["norm"], (name, d)
+
+
+def test_norm_pass_of_apply_is_one_launch_and_reproducible():
+    """hgym_ppo_apply's own norm pass (several ranks / foreign gradients): per-workgroup fp64 partial sums added in a fixed order by the last
+    workgroup to arrive, which also takes the prologue (sqnorm_prologue_kernel) -- no atomics on the sum.  The same state applied five times
+    gives the same bits (norm, learning rate, parameters); the norm is the fp64 norm of the rank mean to 1e-12; the arrival counter is left
+    at zero, so a second apply on the same net works."""
+    from hgym import NetBuffers, make_net_config, make_ppo_config
+    outs = []
+    for rep in range(5):
+        torch.manual_seed(3)
+        cfg = make_net_config(705, 219, 12, [512, 256, 128], [768, 256, 128], "bf16", 512)
+        net = NetBuffers(cfg, "cuda", learning_rate=1e-3)
+        for k, v in net.views.items():
+            v.copy_(torch.randn(v.shape, device="cuda") * 0.05)
+        net.sync_shadow()
+        g = torch.randn(net.P, device="cuda") * 3.0
+        net.grads.copy_(g)
+        net.grads_ext[net.P] = 0.02
+        net.ppo_apply(make_ppo_config(world_size=4))
+        torch.cuda.synchronize()
+        want = float((g.double() * float(np.float32(0.25))).pow(2).sum().sqrt())
+        assert abs(float(net.opt_state[6]) - float(np.float32(want))) <= 1e-6 * want       # opt[6] = the fp32 norm the clip used
+        assert abs(float(net.opt_state[9]) - want * want) <= 1e-12 * want * want
+        outs.append((net.opt_state.clone(), net.params.clone(), net.adam_v.clone()))
+        if rep == 0:                                  # a second step on the same net: the counter was reset
+            net.grads.copy_(g)
+            net.grads_ext[net.P] = 0.02
+            net.ppo_apply(make_ppo_config(world_size=4))
+            torch.cuda.synchronize()
+            assert int(net.opt_state[1]) == 2 and torch.isfinite(net.params).all()
+    for o in outs[1:]:
+        assert torch.equal(o[0], outs[0][0]) and torch.equal(o[1], outs[0][1]) and torch.equal(o[2], outs[0][2])
