@@ -49,8 +49,8 @@ EXTRA_CONFIGS = ("envs8192", "logging", "dwl", "fp32")
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=10)
-    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--steps", type=int, default=20)         # warm-up 5, >= 20 timed iterations
+    p.add_argument("--warmup", type=int, default=5)
     p.add_argument("--num-envs", type=int, default=4096, help="envs per GPU (weak scaling)")
     p.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
     p.add_argument("--task", default="humanoid_ppo", choices=["humanoid_ppo", "humanoid_dwl_ppo"],
