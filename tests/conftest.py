@@ -35,3 +35,9 @@ def pytest_terminal_summary(terminalreporter, exitstatus, config):
         terminalreporter.write_sep("-", "internal-Philox parity runs: forgiven low_speed threshold flips")
         for what, flips in rep:
             terminalreporter.write_line("flips forgiven: %d  | %s" % (flips, what))
+    br = sys.modules.get("bf16_report")
+    brep = getattr(br, "REPORT", None) if br is not None else None
+    if brep:
+        terminalreporter.write_sep("-", "bf16 MFMA path: measured error vs the asserted bar (SURVEY.md 8c: 1e-2)")
+        for what, err, bar in brep:
+            terminalreporter.write_line("bf16 err %.3e  (bar %.0e)  | %s" % (err, bar, what))

@@ -382,3 +382,54 @@ def run_generic_golden(backend, golden_dir):
         moved += int(t > 0 and list(G["cmd_range_x"][t]) != list(G["cmd_range_x"][t - 1]))
     assert moved == 1
     return env
+
+
+def run_reset_golden(backend, golden_dir):
+    """LeggedRobot.reset() (legged_robot.py:110-115, base_task.py:140-145) replayed from env_reset_trace.npz, the
+    trace recorded from the reference: warm-up steps, hgym_env_reset_all with the reference's reset_idx(all) draws, the state the
+    reference's zero-action step finds at its entry, and everything that step leaves (two envs reset AGAIN in it)."""
+    import os
+    G = np.load(os.path.join(golden_dir, "env_reset_trace.npz"))
+    Tn = lambda a: torch.from_numpy(np.asarray(a))
+    N = G["friction"].shape[0]
+    env = EnvUnderTest(backend, N, Tn(G["friction"]), Tn(G["body_mass"]), sim_layout="aos")
+    env.prime(Tn(G["prime_u_dof"]), Tn(G["prime_u_cmd"]), Tn(G["prime_z_obs"]))
+    backend.sync()
+    env.buf.episode_length.copy_(Tn(G["init_ep_len"]))
+    env.buf.counters[0] = int(G["init_common_step_counter"])
+
+    def step(g, a_in, tag):
+        frame = (Tn(g("root")), Tn(g("dof")), Tn(g("contact")), Tn(g("rigid")))
+        env.step(a_in, frame, Tn(g("u_delay")), Tn(g("z_act")), Tn(g("u_cmd")), Tn(g("u_dof")), Tn(g("u_push")), Tn(g("z_obs")))
+        b = env.buf
+        exact(b.reset, g("reset"), tag + " reset")
+        exact(b.time_out, g("time_out"), tag + " time_out")
+        exact(b.episode_length, g("ep_len"), tag + " ep_len")
+        exact(b.extras_time_outs, g("extras_time_outs"), tag + " extras time_outs")
+        close(b.rew, g("rew"), tag + " rew")
+        close(b.view("torques"), g("torques"), tag + " torques", atol=2e-5)
+        close(b.view("actions"), g("actions"), tag + " actions")
+        close(b.view("commands"), g("commands"), tag + " commands")
+        close(b.view("episode_sums"), g("episode_sums"), tag + " episode_sums")
+        close(b.root, g("root_after"), tag + " root")
+        close(b.dof_state, g("dof_after"), tag + " dof")
+        close(b.extras_episode, g("extras_episode"), tag + " extras episode", rtol=1e-5, atol=1e-7)
+        close(b.obs, g("obs"), tag + " obs")
+        close(b.priv_obs, g("priv"), tag + " priv")
+
+    for t in range(G["warm_rew"].shape[0]):
+        step(lambda k, t=t: G["warm_" + k][t], Tn(G["warm_actions_in"][t]), "warm-up step %d" % t)
+    env.reset_all(Tn(G["reset_u_dof"]), Tn(G["reset_u_cmd"]))
+    backend.sync()
+    b = env.buf
+    assert float(b.obs_ring.abs().max()) == 0.0 and float(b.priv_ring.abs().max()) == 0.0      # both history rings zeroed
+    close(b.view("commands"), G["entry_commands"], "commands after reset_all")
+    exact(b.episode_length, G["entry_ep_len"], "ep_len after reset_all")
+    close(b.root, G["entry_root"], "root after reset_all")
+    close(b.dof_state, G["entry_dof"], "dof after reset_all")
+    assert float(b.view("episode_sums").abs().max()) == 0.0
+    close(b.view("last_actions"), G["entry_last_actions"], "last_actions after reset_all")
+    close(b.view("last_dof_vel"), G["entry_last_dof_vel"], "last_dof_vel after reset_all")
+    close(b.view("feet_air_time"), G["entry_feet_air_time"], "feet_air_time after reset_all")
+    step(lambda k: G["step_" + k], torch.zeros(N, 12), "zero-action step of reset()")
+    assert int(G["step_reset"].sum()) == 2

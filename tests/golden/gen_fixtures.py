@@ -13,6 +13,7 @@ Needs /root/reference (present only in the build container).  Outputs (all small
   tests/golden/env_trace_refact.npz the same with cfg.env.use_ref_actions
   tests/golden/env_trace_generic.npz  the same on a trimesh terrain map with terrain + command curricula and height measurements
   tests/golden/env_trace_yawrate.npz  the same with cfg.commands.heading_command = False
+  tests/golden/env_reset_trace.npz  LeggedRobot.reset() (reset_idx(all) + a zero-action step) on an env that has already stepped
   tests/golden/ppo_update.npz       PPO.act / process_env_step / compute_returns / update on a small net
   tests/golden/ppo_update_full.npz  the same at the FULL XBot-L layer widths (inputs regenerated from a seed: ppo_full_case.py)
 The oracle (oracle/*.py) is pinned against these in tests/test_oracle_env_golden.py and tests/test_oracle_algo_golden.py
@@ -328,6 +329,155 @@ def gen_env_trace(R, N=32, S=36, seed=11, use_ref_actions=False, name="env_trace
 
 
 # ------------------------------------------------------------------------------------------------
+def gen_env_reset_trace(R, N=16, S0=3, seed=15, name="env_reset_trace.npz"):
+    """LeggedRobot.reset() = BaseTask.reset(): reset_idx(all envs) + ONE zero-action step (legged_robot.py:110-115, base_task.py:140-145),
+    called on an env that has already stepped S0 times.  Records the S0 warm-up steps (inputs + draws), the draws
+    of reset_idx(arange(N)), the state at the entry of the zero-action step (i.e. right after reset_idx) and everything the step leaves."""
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    g = torch.Generator().manual_seed(seed)
+    fr = 0.1 + 1.9 * torch.rand(N, 1, generator=g)
+    bm = 15.0 + 10.0 * torch.rand(N, 1, generator=g) - 5.0
+    e, cfg = H.make_ref_env(N, frictions=fr, body_mass=bm)
+    ids_log = []
+    orig_resample, orig_reset_dofs = e._resample_commands, e._reset_dofs
+
+    def resample(env_ids):
+        ids_log.append(("cmd", env_ids.clone()))
+        return orig_resample(env_ids)
+
+    def reset_dofs(env_ids):
+        ids_log.append(("dof", env_ids.clone()))
+        return orig_reset_dofs(env_ids)
+
+    e._resample_commands, e._reset_dofs = resample, reset_dofs
+
+    def take(log, prefix):
+        tag, t = log.pop(0)
+        assert tag.startswith(prefix), (tag, prefix)
+        return t
+
+    def scatter(ids, vals, width):
+        full = torch.zeros(N, width)
+        if len(ids):
+            full[ids] = vals.view(len(ids), width)
+        return full
+
+    H.RECORDER.enabled = True
+    with H.recording_rng():
+        H.finish_init(e)
+    log = H.RECORDER.pop_all()
+    del ids_log[:]
+    out = dict(friction=npy(fr), body_mass=npy(bm), prime_u_dof=npy(take(log, "rand_float")))
+    out["prime_u_cmd"] = npy(torch.cat([take(log, "rand_float") for _ in range(3)], dim=1))
+    out["prime_z_obs"] = npy(take(log, "randn_like"))
+    assert not log
+    ep = torch.randint(5, 2000, (N,), generator=g)
+    ep[0:3] = torch.tensor([2399, 798, 2397])               # a time-out and a command resample inside the warm-up
+    e.episode_length_buf = ep.clone()
+    e.common_step_counter = 40
+    out["init_ep_len"] = npy(ep)
+    out["init_common_step_counter"] = 40
+    frames = [H.synth_sim_state(g, N) for _ in range(S0 + 1)]
+    frames[S0][2].view(N, H.NUM_BODIES, 3)[[2, 7], 0, 2] = 3.0      # two base-link contacts: the zero-action step resets those envs AGAIN
+    counter = {"n": 0, "t": 0}
+
+    def simulate(sim):
+        counter["n"] += 1
+        if counter["n"] % cfg.control.decimation == 0:
+            H.write_sim_state(e, frames[counter["t"]])
+
+    e.gym.simulate = simulate
+
+    def split_step_draws(log, ids, reset):
+        """The draws of ONE XBotLFreeEnv.step, scattered to env-indexed tables (the layout of gen_env_trace)."""
+        u_delay = take(log, "rand(").view(N)
+        z_act = take(log, "randn_like")
+        kind, cb_ids = ids.pop(0)
+        assert kind == "cmd"
+        u_cmd = torch.zeros(N, 6)
+        u_cmd[:, 0:3] = scatter(cb_ids, torch.cat([take(log, "rand_float") for _ in range(3)], dim=1), 3)
+        pushed = (e.common_step_counter % cfg.domain_rand.push_interval == 0)
+        u_push = torch.zeros(N, 5)
+        if pushed:
+            u_push[:, 0:2] = take(log, "rand_float")
+            u_push[:, 2:5] = take(log, "rand_float")
+        u_dof = torch.zeros(N, 12)
+        if bool(reset.any()):
+            kind, r_ids = ids.pop(0)
+            assert kind == "dof"
+            u_dof = scatter(r_ids, take(log, "rand_float"), 12)
+            kind, r_ids2 = ids.pop(0)
+            assert kind == "cmd" and torch.equal(r_ids, r_ids2)
+            u_cmd[:, 3:6] = scatter(r_ids, torch.cat([take(log, "rand_float") for _ in range(3)], dim=1), 3)
+        z_obs = take(log, "randn_like")
+        assert not log and not ids, (log, ids)
+        return dict(u_delay=u_delay, z_act=z_act, u_cmd=u_cmd, u_dof=u_dof, u_push=u_push, z_obs=z_obs, pushed=torch.tensor(bool(pushed)))
+
+    def outputs(obs, priv, rew, reset, extras):
+        return dict(obs=obs, priv=priv, rew=rew, reset=reset, time_out=e.time_out_buf, commands=e.commands, ep_len=e.episode_length_buf,
+                    episode_sums=torch.stack([e.episode_sums[k] for k in e.reward_names], dim=1), torques=e.torques, actions=e.actions,
+                    extras_time_outs=extras["time_outs"],
+                    extras_episode=torch.stack([extras["episode"]["rew_" + k] for k in e.reward_names]),
+                    root_after=e.root_states, dof_after=e.dof_state)
+
+    warm = {}
+    for t in range(S0):
+        counter["t"] = t
+        a_in = torch.randn(N, 12, generator=g) * 1.5
+        with H.recording_rng():
+            res = e.step(a_in.clone())
+        log, ids = H.RECORDER.pop_all(), ids_log[:]
+        del ids_log[:]
+        vals = dict(actions_in=a_in, root=frames[t][0], dof=frames[t][1], contact=frames[t][2], rigid=frames[t][3])
+        vals.update(split_step_draws(log, ids, res[3]))
+        vals.update(outputs(*res))
+        for k, v in vals.items():
+            warm.setdefault(k, []).append(npy(v))
+    for k, v in warm.items():
+        out["warm_" + k] = np.stack(v)
+
+    # ---- reset(): snapshot the env at the entry of its zero-action step, i.e. right after reset_idx(all)
+    counter["t"] = S0
+    orig_step = e.step
+    entry = {}
+
+    def step_spy(actions):
+        assert float(actions.abs().max()) == 0.0 and tuple(actions.shape) == (N, 12)
+        entry.update(commands=npy(e.commands), ep_len=npy(e.episode_length_buf), root=npy(e.root_states), dof=npy(e.dof_state),
+                     episode_sums=npy(torch.stack([e.episode_sums[k] for k in e.reward_names], dim=1)),
+                     last_actions=npy(e.last_actions), last_dof_vel=npy(e.last_dof_vel), feet_air_time=npy(e.feet_air_time),
+                     obs_history_absmax=np.array(max(float(f.abs().max()) for f in e.obs_history)),
+                     critic_history_absmax=np.array(max(float(f.abs().max()) for f in e.critic_history)),
+                     extras_episode=npy(torch.stack([e.extras["episode"]["rew_" + k] for k in e.reward_names])))
+        return orig_step(actions)
+
+    e.step = step_spy
+    with H.recording_rng():
+        obs, priv = e.reset()
+    e.step = orig_step
+    log, ids = H.RECORDER.pop_all(), ids_log[:]
+    del ids_log[:]
+    kind, r_ids = ids.pop(0)
+    assert kind == "dof" and torch.equal(r_ids, torch.arange(N))
+    out["reset_u_dof"] = npy(take(log, "rand_float"))
+    kind, r_ids = ids.pop(0)
+    assert kind == "cmd" and torch.equal(r_ids, torch.arange(N))
+    out["reset_u_cmd"] = npy(torch.cat([take(log, "rand_float") for _ in range(3)], dim=1))
+    for k, v in entry.items():
+        out["entry_" + k] = v
+    vals = dict(root=frames[S0][0], dof=frames[S0][1], contact=frames[S0][2], rigid=frames[S0][3])
+    vals.update(split_step_draws(log, ids, e.reset_buf))
+    vals.update(outputs(obs, priv, e.rew_buf, e.reset_buf, e.extras))
+    for k, v in vals.items():
+        out["step_" + k] = npy(v)
+    np.savez_compressed(os.path.join(HERE, name), **out)
+    print("%s N=%d warm-up steps=%d (resets %d) | resets in the zero-action step=%d size=%.2f MB" % (
+        name, N, S0, int(out["warm_reset"].sum()), int(out["step_reset"].sum()), os.path.getsize(os.path.join(HERE, name)) / 1e6))
+    H.RECORDER.enabled = False
+
+
+# ------------------------------------------------------------------------------------------------
 def gen_ppo_update(R, N=24, T=8, seed=3):
     """Drive the reference PPO through one full iteration on a small actor/critic (same 705/219/12 interface)."""
     torch.manual_seed(seed)
@@ -491,6 +641,9 @@ if __name__ == "__main__":
     if "--only-generic" in sys.argv:
         gen_env_trace(R, N=32, S=20, seed=13, name="env_trace_generic.npz", generic=True)
         sys.exit(0)
+    if "--only-reset" in sys.argv:
+        gen_env_reset_trace(R)
+        sys.exit(0)
     if "--only-yawrate" in sys.argv:
         gen_env_trace(R, N=16, S=14, seed=14, name="env_trace_yawrate.npz", heading_command=False)
         sys.exit(0)
@@ -502,5 +655,6 @@ if __name__ == "__main__":
         gen_env_trace(R, N=16, S=16, seed=12, use_ref_actions=True, name="env_trace_refact.npz")
         gen_env_trace(R, N=32, S=20, seed=13, name="env_trace_generic.npz", generic=True)
         gen_env_trace(R, N=16, S=14, seed=14, name="env_trace_yawrate.npz", heading_command=False)
+        gen_env_reset_trace(R)
         gen_ppo_update(R)
         gen_ppo_update_full(R)

@@ -55,6 +55,47 @@ def test_golden_trace_gpu(hip, golden_dir, name):
             EC.close(b.priv_obs, G["priv_step%d" % t], "priv %d" % t)
 
 
+def test_reset_golden_trace_gpu(hip, golden_dir):
+    """SURVEY.md 8a row E14 on the device: LeggedRobot.reset() = hgym_env_reset_all + a zero-action step, replayed from the trace recorded
+    from the reference's own reset() (legged_robot.py:110-115; tests/golden/gen_fixtures.py::gen_env_reset_trace)."""
+    EC.run_reset_golden(hip, golden_dir)
+
+
+def test_reset_all_then_step_gpu(hip):
+    """The same against the oracle on seeded inputs (the -m gpu twin of test_env_hostcheck.py::test_reset_all_then_step_host), at a
+    size that spans several workgroups, plus reset() with the generic options on (terrain curriculum inside reset_idx(all))."""
+    N = 300
+    counts, env, o = EC.run_random_trace(hip, N, steps=3, seed=5)
+    g = torch.Generator().manual_seed(1)
+    u_dof, u_cmd3 = torch.rand(N, 12, generator=g), torch.rand(N, 3, generator=g)
+    o._reset_masked(torch.ones(N, dtype=torch.bool), u_dof, u_cmd3)
+    env.reset_all(u_dof, u_cmd3)
+    hip.sync()
+    assert float(env.buf.obs_ring.abs().max()) == 0.0 and float(env.buf.priv_ring.abs().max()) == 0.0
+    EC.close(env.buf.view("commands"), o.commands, "commands after reset_all")
+    EC.exact(env.buf.episode_length, o.ep_len, "ep_len after reset_all")
+    EC.close(env.buf.root_view(), o.sim.root, "root after reset_all")
+    frame = EC.synth_frames(g, N)
+    a = torch.zeros(N, 12)
+    nz = [torch.rand(N, generator=g), torch.randn(N, 12, generator=g), torch.rand(N, 6, generator=g),
+          torch.rand(N, 12, generator=g), torch.rand(N, 5, generator=g), torch.randn(N, 47, generator=g)]
+    o.pre_physics(a, nz[0], nz[1]); o.pd_torques(); o.sim.load(*frame); o.post_physics(*nz[2:])
+    env.step(a, frame, *nz)
+    EC.compare_state(env, o, "step after reset_all")
+    # generic options: the terrain curriculum also runs in reset_idx(all)
+    counts, env, o = EC.run_random_trace(hip, 44, steps=6, seed=321, sim_layout="soa", generic=True, track_sum=5.0)
+    g = torch.Generator().manual_seed(2)
+    N = 44
+    u_dof, u_cmd3 = torch.rand(N, 12, generator=g), torch.rand(N, 3, generator=g)
+    u_xy, r_level = torch.rand(N, 2, generator=g), torch.randint(0, 5, (N,), generator=g)
+    o._reset_masked(torch.ones(N, dtype=torch.bool), u_dof, u_cmd3, u_xy, r_level)
+    env.reset_all(u_dof, u_cmd3, u_xy, r_level)
+    hip.sync()
+    EC.exact(env.buf.terrain_levels, o.terrain.levels, "levels after reset_all")
+    EC.close(env.buf.root_view(), o.sim.root, "root after reset_all (generic)")
+    EC.close(env.buf.view("commands"), o.commands, "commands after reset_all (generic)")
+
+
 @pytest.mark.parametrize("N,layout,steps", [(37, "soa", 20), (256, "aos", 16), (4096, "soa", 12), (8192, "soa", 8)])
 def test_random_trace_gpu(hip, N, layout, steps):
     counts, env, o = EC.run_random_trace(hip, N, steps=steps, seed=100 + N, sim_layout=layout,

@@ -121,6 +121,11 @@ def test_generic_frame_stack_host():
     EC.run_random_trace(be, 12, steps=12, seed=7, frame_stack=4, c_frame_stack=2)
 
 
+def test_reset_golden_trace_host(host, golden_dir):
+    """LeggedRobot.reset() as recorded from the reference (tests/golden/env_reset_trace.npz) through the kernel source."""
+    EC.run_reset_golden(host, golden_dir)
+
+
 def test_reset_all_then_step_host():
     """LeggedRobot.reset(): reset_idx(all) + a zero-action step (legged_robot.py:112-117)."""
     be = EC.HostBackend()

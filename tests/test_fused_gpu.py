@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 import torch
 
+import bf16_report as BR
 from oracle import ppo_oracle as P
 from oracle import xbot_constants as K
 
@@ -29,7 +30,7 @@ def _rel(a, b):
 @pytest.mark.parametrize("M", [1, 31, 64, 100, 4096, 5000, 20000])
 def test_fused_forward_ragged_sizes_vs_oracle(M):
     """Both tile shapes of mlp_fwd_kernel (32-row rollout tiles below 16 384 rows, 64-row tiles above), batch sizes that
-    are not tile multiples, with and without a row gather.  bf16 operands, fp32 accumulate: <= 2e-2 of the output scale."""
+    are not tile multiples, with and without a row gather.  bf16 operands, fp32 accumulate: <= 1e-2 of the output scale (measured errors in the terminal summary)."""
     g = torch.Generator().manual_seed(M)
     p = P.Params.random(705, 219, 12, K.ACTOR_HIDDEN, K.CRITIC_HIDDEN, g)
     net = _net("bf16", max(M, 64))
@@ -39,8 +40,8 @@ def test_fused_forward_ragged_sizes_vs_oracle(M):
     mu = net.forward(0, obs.cuda())
     v = net.forward(1, priv.cuda())
     torch.cuda.synchronize()
-    assert _rel(mu.cpu(), P.mlp_forward(obs, p.actor)) <= 2e-2
-    assert _rel(v.cpu(), P.mlp_forward(priv, p.critic)) <= 2e-2
+    BR.check("fused forward vs fp32 oracle, actor mu", _rel(mu.cpu(), P.mlp_forward(obs, p.actor)))
+    BR.check("fused forward vs fp32 oracle, critic value", _rel(v.cpu(), P.mlp_forward(priv, p.critic)))
 
 
 def test_fused_act_matches_unfused_sampling_arithmetic():
@@ -60,8 +61,8 @@ def test_fused_act_matches_unfused_sampling_arithmetic():
     np.testing.assert_allclose(out["actions"].cpu().numpy(), (mu + sg * z).numpy(), rtol=1e-6, atol=1e-6)
     lp = P.gaussian_log_prob(out["actions"].cpu(), mu, sg)
     np.testing.assert_allclose(out["logp"].cpu().numpy(), lp.numpy(), rtol=1e-5, atol=1e-4)
-    assert _rel(mu, P.mlp_forward(obs, p.actor)) <= 2e-2
-    assert _rel(out["values"].cpu(), P.mlp_forward(priv, p.critic)) <= 2e-2
+    BR.check("fused policy step vs fp32 oracle, actor mu", _rel(mu, P.mlp_forward(obs, p.actor)))
+    BR.check("fused policy step vs fp32 oracle, critic value", _rel(out["values"].cpu(), P.mlp_forward(priv, p.critic)))
 
 
 BF16_OPERAND_TOL = 5e-3     # fused kernels vs the bf16-operand oracle, per tensor, rel-L2 (measured 1.1e-3 at B=333, 6.6e-4 at B=4096)
@@ -517,9 +518,8 @@ def test_deferred_values_rollout_equals_inline_rollout(monkeypatch):
     for k in ("obs", "act", "logp", "dones", "priv_sh"):
         assert torch.equal(a[k], b[k]), k
     assert all(a["valid"]) and all(b["valid"]) and int(a["dones"].sum()) >= 10
-    for k, tol in (("val", 2e-2), ("rew", 2e-2), ("ret", 2e-2)):
-        err = float((a[k] - b[k]).abs().max() / a[k].abs().max())
-        assert err <= tol, (k, err)
+    for k in ("val", "rew", "ret"):       # the two tile shapes of the critic (32 rows inline, 64 rows one pass) round differently
+        BR.check("deferred-values rollout vs inline rollout, %s" % k, float((a[k] - b[k]).abs().max() / a[k].abs().max()))
 
 
 def test_runner_update_reads_the_shadow_the_rollout_wrote(monkeypatch):

@@ -156,3 +156,59 @@ def test_generic_trace_matches_reference(golden_dir):
     assert ups >= 5 and downs >= 5                                          # both curriculum directions exercised
     assert o.cmd_range_x == [-0.8, 1.0] and [float(v) for v in G["cmd_range_x"][0]] == [-0.3, 0.6]   # the command range widened once
     assert float(np.abs(G["measured_heights"]).max()) > 0.01                # heights really sampled a non-flat map
+
+
+# ------------------------------------------------------------------------------------------------
+# LeggedRobot.reset(): reset_idx(all) + a zero-action step, recorded from the reference on an env that has stepped
+def test_reset_trace_matches_reference(golden_dir):
+    """legged_robot.py:110-115 / base_task.py:140-145 on env_reset_trace.npz: the warm-up steps, the state right after reset_idx(all)
+    (what the reference's zero-action step finds at its entry) and everything that step leaves -- bit for bit."""
+    G = _load(golden_dir, "env_reset_trace.npz")
+    N = G["friction"].shape[0]
+    o = XBotEnvOracle(N, frictions=T(G["friction"]), body_mass=T(G["body_mass"]))
+    o.prime(T(G["prime_u_dof"]), T(G["prime_u_cmd"]), T(G["prime_z_obs"]))
+    o.ep_len = T(G["init_ep_len"]).clone()
+    o.common_step_counter = int(G["init_common_step_counter"])
+
+    def step(pre, a_in):
+        o.pre_physics(a_in, T(G[pre + "u_delay"]), T(G[pre + "z_act"]))
+        tq = o.pd_torques()
+        o.sim.load(T(G[pre + "root"]), T(G[pre + "dof"]), T(G[pre + "contact"]), T(G[pre + "rigid"]))
+        obs, priv, rew, reset, info = o.post_physics(T(G[pre + "u_cmd"]), T(G[pre + "u_dof"]), T(G[pre + "u_push"]), T(G[pre + "z_obs"]))
+        return tq, obs, priv, rew, reset
+
+    def check(tag, res, g):
+        tq, obs, priv, rew, reset = res
+        assert torch.equal(reset, T(g("reset"))) and torch.equal(o.time_out, T(g("time_out"))) and torch.equal(o.ep_len, T(g("ep_len"))), tag
+        assert torch.equal(tq, T(g("torques"))) and torch.equal(o.actions, T(g("actions"))), tag
+        assert torch.equal(rew, T(g("rew"))) and torch.equal(o.commands, T(g("commands"))) and torch.equal(o.episode_sums, T(g("episode_sums"))), tag
+        assert torch.equal(torch.clip(obs, -C.CLIP_OBS, C.CLIP_OBS), T(g("obs"))) and torch.equal(torch.clip(priv, -C.CLIP_OBS, C.CLIP_OBS), T(g("priv"))), tag
+        assert torch.equal(o.sim.root, T(g("root_after"))), tag
+        assert torch.equal(torch.stack((o.sim.dof_pos, o.sim.dof_vel), -1).view(-1, 2), T(g("dof_after"))), tag
+        assert torch.equal(o.extras_time_outs, T(g("extras_time_outs"))), tag
+        np.testing.assert_allclose(o.extras_episode.numpy(), g("extras_episode"), rtol=2e-6, atol=1e-9)
+
+    S0 = G["warm_rew"].shape[0]
+    for t in range(S0):
+        o_pre = lambda k, t=t: G["warm_" + k][t]
+        o.pre_physics(T(o_pre("actions_in")).clone(), T(o_pre("u_delay")), T(o_pre("z_act")))
+        tq = o.pd_torques()
+        o.sim.load(T(o_pre("root")), T(o_pre("dof")), T(o_pre("contact")), T(o_pre("rigid")))
+        obs, priv, rew, reset, info = o.post_physics(T(o_pre("u_cmd")), T(o_pre("u_dof")), T(o_pre("u_push")), T(o_pre("z_obs")))
+        check("warm-up step %d" % t, (tq, obs, priv, rew, reset), o_pre)
+    assert int(G["warm_reset"].sum()) >= 2 and int(G["warm_time_out"].sum()) >= 1
+    # reset_idx(arange(N)): legged_robot.py:163-215 for every env
+    o._reset_masked(torch.ones(N, dtype=torch.bool), T(G["reset_u_dof"]), T(G["reset_u_cmd"]))
+    assert torch.equal(o.commands, T(G["entry_commands"])) and torch.equal(o.ep_len, T(G["entry_ep_len"]))
+    assert torch.equal(o.sim.root, T(G["entry_root"]))
+    assert torch.equal(torch.stack((o.sim.dof_pos, o.sim.dof_vel), -1).view(-1, 2), T(G["entry_dof"]))
+    assert torch.equal(o.episode_sums, T(G["entry_episode_sums"])) and float(o.episode_sums.abs().max()) == 0.0
+    assert torch.equal(o.last_actions, T(G["entry_last_actions"])) and torch.equal(o.last_dof_vel, T(G["entry_last_dof_vel"]))
+    assert torch.equal(o.feet_air_time, T(G["entry_feet_air_time"]))
+    assert float(o.obs_hist.abs().max()) == float(G["entry_obs_history_absmax"]) == 0.0
+    assert float(o.priv_hist.abs().max()) == float(G["entry_critic_history_absmax"]) == 0.0
+    np.testing.assert_allclose(o.extras_episode.numpy(), G["entry_extras_episode"], rtol=2e-6, atol=1e-9)
+    # ... + the zero-action step
+    res = step("step_", torch.zeros(N, 12))
+    check("zero-action step", res, lambda k: G["step_" + k])
+    assert int(G["step_reset"].sum()) == 2 and int(G["step_ep_len"].min()) == 0 and int(G["step_ep_len"].max()) == 1

@@ -14,6 +14,8 @@ import numpy as np
 import pytest
 import torch
 
+import bf16_report as BR
+
 import env_common as EC
 import synth_common as SC
 from oracle import synth_env_oracle as S
@@ -374,7 +376,7 @@ def test_deferred_values_rollout_vs_oracle_gpu(monkeypatch, N):
             worst = max(worst, float((st.values[i].view(-1) - v_step).abs().max() / v_step.abs().max()))
         v_last = alg.actor_critic.evaluate(priv_all[T]).view(-1)
         worst = max(worst, float((st.last_values.view(-1) - v_last).abs().max() / v_last.abs().max()))
-    assert worst <= 2e-2, worst
+    BR.check("one-pass critic (64-row tiles) vs the per-step critic kernel", worst)
     assert all(st.shadow_valid) and torch.equal(st._priv_bf16[:, :, :219], st.privileged_observations.to(torch.bfloat16))
     assert torch.equal(st._obs_bf16[:, :, :705], st.observations.to(torch.bfloat16))
     # compute_returns: the bootstrap applied as the scan loads the rewards, the column written back
