@@ -112,13 +112,19 @@ def build(force=False, verbose=True):
     return LIB
 
 
-def build_variant(name, flags, verbose=False):
+def build_variant(name, flags, verbose=False, only=None):
     """Experiment builds for same-box A/B runs (tools/gpu_variants.sh): every source compiled with extra flags (-DHGYM_...)
-    into lib/variants/<name>/libhgym_hip.so; selected at run time with HGYM_LIB=<path>.  Never loaded by default."""
+    into lib/variants/<name>/libhgym_hip.so; selected at run time with HGYM_LIB=<path>.  Never loaded by default.
+    only: source files the flags apply to -- the others are linked from the default build's objects (lib/obj)."""
     vdir = os.path.join(LIBDIR, "variants", name)
     os.makedirs(vdir, exist_ok=True)
+    if only:
+        build(verbose=False)
     objs = []
     for f in sorted(x for x in os.listdir(CSRC) if x.endswith(".hip")):
+        if only and f not in only:
+            objs.append(os.path.join(OBJDIR, f.replace(".hip", ".o")))
+            continue
         obj = os.path.join(vdir, f.replace(".hip", ".o"))
         cmd = [HIPCC] + COMMON + EXTRA.get(f, []) + list(flags) + ["-c", os.path.join(CSRC, f), "-o", obj]
         if verbose:
@@ -131,8 +137,11 @@ def build_variant(name, flags, verbose=False):
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 2 and sys.argv[1] == "--variant":      # build.py --variant <name> <flags...>
-        print(build_variant(sys.argv[2], sys.argv[3:]))
+    if len(sys.argv) > 2 and sys.argv[1] == "--variant":      # build.py --variant <name> [--only a.hip,b.hip] <flags...>
+        rest, only = sys.argv[3:], None
+        if rest and rest[0] == "--only":
+            only, rest = set(rest[1].split(",")), rest[2:]
+        print(build_variant(sys.argv[2], rest, only=only))
         sys.exit(0)
     build(force="--force" in sys.argv)
     print(LIB)

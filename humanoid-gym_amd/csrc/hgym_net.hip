@@ -21,6 +21,9 @@ namespace hgym {
 
 // hgym_update.hip
 int32_t launch_mlp_fb(const FwdArgs& fb, const FbLoss& fl, bool shadow, int tiles, int nets, size_t lds, hipStream_t s);
+// hgym_update3.hip: the same tile on eight compute + four service wavefronts (hgym_fb3.hpp), for the shapes it is instantiated for
+bool fb3_supported(const FwdArgs& fb, int nets);
+int32_t launch_mlp_fb3(const FwdArgs& fb, const FbLoss& fl, int tiles, int nets, size_t lds, hipStream_t s);
 
 // ------------------------------------------------------------------------------------------------ layouts
 struct LayerLayout {
@@ -64,6 +67,8 @@ struct WsLayout {
 
 constexpr int MAX_LOSS_BLOCKS = 8192;   // 256 samples each: minibatches up to 2 M samples
 constexpr int SQN_BLOCKS = 256;         // workgroups of sqnorm_prologue_kernel
+
+constexpr bool kFb3Default = false;      // mlp_fb3_kernel instead of mlp_fb_kernel when HGYM_FB3 is unset
 
 static bool fused_supported(const HgymNetConfig* c) {
     if (c->precision != HGYM_BF16 || c->actor_layers != 4 || c->critic_layers != 4) return false;
@@ -1025,7 +1030,11 @@ struct NetRunner {
             fb.nets = nets;
             fb.dbg = phase_buffer((int64_t)tiles * nets);
             prof_begin(HGYM_PROF_MLP_FWD, s);
-            const int32_t rc_fb = launch_mlp_fb(fb, fl, shadow, tiles, nets, lds, s);      // (hgym_update.hip: the kernel's own code object)
+            // role-specialised wavefronts (mlp_fb3_kernel) where instantiated; HGYM_FB3=0 / 1 selects per call (A/B runs, equality test)
+            const char* e3 = getenv("HGYM_FB3");
+            const bool fb3 = shadow && (e3 ? atoi(e3) != 0 : kFb3Default) && fb3_supported(fb, nets);
+            const int32_t rc_fb = fb3 ? launch_mlp_fb3(fb, fl, tiles, nets, lds, s)
+                                      : launch_mlp_fb(fb, fl, shadow, tiles, nets, lds, s);      // (hgym_update.hip: the kernel's own code object)
             if (rc_fb) return rc_fb;
             double flops = 0.0;
             for (int i = 0; i < nets; ++i) {

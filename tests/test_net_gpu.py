@@ -98,6 +98,8 @@ def test_policy_act_vs_oracle():
     # = 393 216 draws (standard error of the mean 1.6e-3, of the variance 2.3e-3; the 1 % critical value of the Kolmogorov-Smirnov
     # statistic at that size is 1.63 / sqrt(n) = 2.6e-3)
     g2 = torch.Generator().manual_seed(77)
+    net = _net(705, 219, K.ACTOR_HIDDEN, K.CRITIC_HIDDEN, "bf16", 4096)       # the rollout's own kernel (32-row tiles, bf16 operands)
+    net.load_state_dict(dict(zip(NAMES, p.tensors())))
     obs2 = (torch.randn(4096, 705, generator=g2) * 2).clamp(-18, 18).cuda()
     priv2 = (torch.randn(4096, 219, generator=g2) * 2).clamp(-18, 18).cuda()
     zs = []
