@@ -50,8 +50,11 @@ constexpr int FB3_SL = FB3_NS * 64;                        // service lanes
 // FB3_WAVE_CLOCK (instrumented variant, tools/probe_fb3_waves.py): lane 0 of EVERY wavefront stamps the wall clock into
 // dbg[(workgroup * 16 + wave) * 8 + slot] -- the caller's phase buffer must hold 128 slots per workgroup
 #ifdef FB3_WAVE_CLOCK
+#ifndef FB3_WSLOTS
+#define FB3_WSLOTS 8
+#endif
 __device__ __forceinline__ void fb3_wstamp(long long* dbg, int wave, int lane, int slot) {
-    if (dbg && lane == 0) dbg[(((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + wave) * 8 + slot] = (long long)__builtin_amdgcn_s_memrealtime();
+    if (dbg && lane == 0) dbg[(((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + wave) * FB3_WSLOTS + slot] = (long long)__builtin_amdgcn_s_memrealtime();
 }
 #define FB3_WSTAMP(wave, lane, slot) fb3_wstamp(a.dbg, wave, lane, slot)
 #define FB3_PSTAMP(slot)
@@ -88,7 +91,7 @@ __device__ __forceinline__ void fb3_copy_out(const char* __restrict__ lds, char*
 
 // dZ_out = (dZ_in * W) .* elu'(H) on the resident tile, IN PLACE over H (every lane reads a block entry and later writes that very entry);
 // LDS only.  bwd_step (hgym_fused.hpp) is the form that also stores to HBM.
-template <int G, int MB, int NW, int D, int GR, class Next>
+template <int G, int MB, int NW, int D, int MODE = 0, int GR, class Next>      // MODE 1 / 2: NBBc % D == 0 / != 0 known at compile time
 __device__ __forceinline__ void fb3_bwd_step(WRing<GR, D>& R, const u32x4* __restrict__ WTf, int NBo, int NBBc, const char* in_lds, int CBin,
                                              char* h_lds, int wave, int lane, Next prime_next) {
     const int r = lane & 15, q = lane >> 4;
@@ -97,7 +100,7 @@ __device__ __forceinline__ void fb3_bwd_step(WRing<GR, D>& R, const u32x4* __res
     for (int nb0 = wave * G; nb0 < NBo; nb0 += NW * G) {
         f32x4 acc[MB][G];
         zero_acc<G, MB>(acc);
-        if (NBBc % D == 0) mma_stream<G, MB, D, 1>(R, WTf + HG_WOFF((int64_t)nb0 * NBBc * 64) + lane, HG_WSTR(NBBc * 64), NBBc, in_lds, CBin, lane, acc);
+        if (MODE == 1 || (MODE == 0 && NBBc % D == 0)) mma_stream<G, MB, D, 1>(R, WTf + HG_WOFF((int64_t)nb0 * NBBc * 64) + lane, HG_WSTR(NBBc * 64), NBBc, in_lds, CBin, lane, acc);
         else mma_ring<G, MB, D, 1>(R, WTf + HG_WOFF((int64_t)nb0 * NBBc * 64) + lane, HG_WSTR(NBBc * 64), 0, NBBc, NBBc, in_lds, CBin, lane, acc);
         const int nxt = nb0 + NW * G;
         if (nxt < NBo) wring_prime<G, D>(R, WTf + HG_WOFF((int64_t)nxt * NBBc * 64) + lane, HG_WSTR(NBBc * 64), NBBc);
@@ -459,6 +462,7 @@ __device__ __forceinline__ void fb3_body(const FwdArgs& a, const FbLoss& L, cons
 }
 
 // XBot-L's shape pair: (first hidden width, input chunks) = (512, 6) for the actor, (768, 2) for the critic (fb3_supported, hgym_update3.hip)
+#ifndef FB3_NO_KERNEL      // (hgym_fb4.hpp's translation unit takes the helpers above without a second copy of this kernel)
 __global__ __launch_bounds__(FB3_THREADS) void mlp_fb3_kernel(const FwdArgs a, const FbLoss L) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int which = a.net0 + blockIdx.y;
@@ -466,6 +470,7 @@ __global__ __launch_bounds__(FB3_THREADS) void mlp_fb3_kernel(const FwdArgs a, c
     if (n.layer[0].NB == 32) fb3_body<4, 1, 6>(a, L, n, which == 0, smem);
     else fb3_body<3, 2, 2>(a, L, n, which == 0, smem);
 }
+#endif
 
 }  // namespace hgym
 

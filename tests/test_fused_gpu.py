@@ -522,13 +522,16 @@ def test_deferred_values_rollout_equals_inline_rollout(monkeypatch):
         BR.check("deferred-values rollout vs inline rollout, %s" % k, float((a[k] - b[k]).abs().max() / a[k].abs().max()))
 
 
-@pytest.mark.parametrize("S,B", [(700, 333), (9000, 4096), (245760, 61440)])
-def test_update_on_role_specialised_wavefronts_equals_update_on_sixteen_wavefronts(monkeypatch, S, B):
+@pytest.mark.parametrize("S,B", [(700, 333), (500, 164), (9000, 4096), (245760, 61440)])
+@pytest.mark.parametrize("var", ["HGYM_FB3", "HGYM_FB4"])
+def test_update_on_role_specialised_wavefronts_equals_update_on_sixteen_wavefronts(monkeypatch, var, S, B):
     """`mlp_fb3_kernel` (csrc/hgym_fb3.hpp: 64-row tiles on eight compute + four service wavefronts, activations / gradients leave the
     compute waves through LDS only) against `mlp_fb_kernel`: every product sums over k in the same order, the epilogues and the loss code
     are the same instructions on the same values -- the whole gradient (and therefore H / dZ, which the weight-gradient products read) and the
     loss sums are BIT-identical; only the KL statistic may differ in its last fp32 bit (contraction of its expression is the compiler's
-    choice per kernel).  Ragged tail tiles (B = 333), the BASELINE minibatch (61 440 of 245 760).  Reference: /root/reference/humanoid/algo/ppo/ppo.py:128-171."""
+    choice per kernel).  HGYM_FB4: `mlp_fb4_kernel` (csrc/hgym_fb4.hpp), the same roles on 128-ROW tiles -- layer 0 and dZ0 in passes of 256
+    columns, H0 never resident (its pieces come back from L2 for layer 1 and for elu'), loss partials written per 64 rows in the 64-row kernel's
+    association order.  Ragged tail tiles (B = 333; B = 164: one and a half 128-row tiles), the BASELINE minibatch (61 440 of 245 760).  Reference: /root/reference/humanoid/algo/ppo/ppo.py:128-171."""
     from hgym import make_ppo_config, make_batch
     g = torch.Generator().manual_seed(7 * S + B)
     p = P.Params.random(705, 219, 12, K.ACTOR_HIDDEN, K.CRITIC_HIDDEN, g)
@@ -549,7 +552,9 @@ def test_update_on_role_specialised_wavefronts_equals_update_on_sixteen_wavefron
     batch = make_batch(obs, priv, act, val, adv, ret, lp_o, mu_o, sg_o, idx, obs_bf16=so, priv_bf16=sp)
     res = {}
     for mode in ("16 waves", "8 + 4", "8 + 4 again"):
-        monkeypatch.setenv("HGYM_FB3", "0" if mode == "16 waves" else "1")
+        monkeypatch.setenv("HGYM_FB3", "0")
+        monkeypatch.setenv("HGYM_FB4", "0")
+        monkeypatch.setenv(var, "0" if mode == "16 waves" else "1")
         net.grads_ext.zero_()
         net.opt_state[2:10] = 0.0
         net.ppo_grad(make_ppo_config(), batch)

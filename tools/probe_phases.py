@@ -50,6 +50,7 @@ def report(title, buf, nblk, names, half):
 
 
 nb = (B // 64) * 2
+TR = int(os.environ.get("HGYM_PROBE_TILE_ROWS", "64"))      # rows per tile of the update kernel under test (mlp_fb4_kernel: 128)
 buf = torch.zeros(nb * 8, dtype=torch.int64, device=dev)
 L.check(L.lib.hgym_prof_phase_buffer(C.c_void_p(buf.data_ptr()), buf.numel()))
 net.ppo_grad(ppo, batch)      # fwd and bwd both write (same grid): run bwd-only view second
@@ -64,7 +65,7 @@ report("fwd<64> (no stores, M=61440)", buf, nb, FWD, nb // 2)
 buf.zero_()
 net.ppo_grad(ppo, batch)
 torch.cuda.synchronize()
-report("mlp_fb<64> (forward + loss + dZ chain, B=61440)", buf, nb, FWD + ["loss + dZ chain"], nb // 2)
+report("mlp_fb<%d> (forward + loss + dZ chain, B=61440)" % TR, buf, (B // TR) * 2, FWD + ["loss + dZ chain"], B // TR)
 M = 4096
 o4, p4 = torch.randn(M, 705, device=dev), torch.randn(M, 219, device=dev)
 sc = torch.zeros(1, dtype=torch.int64, device=dev)
