@@ -25,7 +25,7 @@ EXTRA = {
 
 
 # Round 4: with hgym_net's device code object at 1.15 / 1.19 MB, runs of eight processes on one GPU aborted at random with
-# HSA_STATUS_ERROR_ILLEGAL_INSTRUCTION (0.87 - 0.99 MB: never; csrc/experiments/hgym_fb2.hip has the bisection).  Round 5's reproducer -- 1.1 MiB of
+# HSA_STATUS_ERROR_ILLEGAL_INSTRUCTION (0.87 - 0.99 MB: never; profiles/r04_fb2_128row_kernel.patch has the bisection in its hgym_fb2.hip).  Round 5's reproducer -- 1.1 MiB of
 # never-launched padding kernels as one extra code object -- passed 13 of 13 such runs (profiles/r05_code_object_abort_repro.txt): size alone is not
 # the trigger, a LAUNCHED kernel inside a > 1 MiB code object probably is.  The guard stays: every code object below CODE_OBJECT_LIMIT (-save-temps=obj
 # leaves the linked device code object of each translation unit next to its .o), every kernel inside the 128 KiB short-branch range (s_cbranch reaches

@@ -384,18 +384,10 @@ __device__ __forceinline__ void zero_acc(f32x4 (&acc)[MB][G]) {
 // of this wave's first strip (hidden_prime).  With AHEAD (8-wave tiles: registers to spare) `prime_next` is called before the
 // epilogue of the last strip, so the following layer's stream is in flight across the epilogue and the barrier; without it
 // the caller primes after the barrier.
-// HGYM_ABLATE_WADDR (timing ablation builds of hgym_update3.hip only, results wrong by design): every strip streams strip 0's fragments
-#ifdef HGYM_ABLATE_WADDR
-#define HG_WOFF(x) ((int64_t)0)
-#define HG_WSTR(x) 0
-#else
-#define HG_WOFF(x) (x)
-#define HG_WSTR(x) (x)
-#endif
 template <int G, int D, int GR>
 __device__ __forceinline__ void hidden_prime(WRing<GR, D>& R, const FusedLayer& L, int wave, int lane) {
     const int nb0 = wave * G;
-    if (nb0 < L.NB) wring_prime<G, D>(R, L.Wf + HG_WOFF((int64_t)nb0 * L.KB * 64) + lane, HG_WSTR(L.KB * 64), L.KB);
+    if (nb0 < L.NB) wring_prime<G, D>(R, L.Wf + (int64_t)nb0 * L.KB * 64 + lane, L.KB * 64, L.KB);
 }
 
 template <int G, int MB, int NW, int D, bool AHEAD, int GR, class Next>
@@ -405,12 +397,12 @@ __device__ __forceinline__ void hidden_layer(WRing<GR, D>& R, const FusedLayer& 
     for (int nb0 = wave * G; nb0 < L.NB; nb0 += NW * G) {
         f32x4 acc[MB][G];
         zero_acc<G, MB>(acc);
-        const u32x4* wl = L.Wf + HG_WOFF((int64_t)nb0 * L.KB * 64) + lane;
+        const u32x4* wl = L.Wf + (int64_t)nb0 * L.KB * 64 + lane;
         constexpr int XBF = NW <= 8 ? 1 : -1;
-        if (L.KB % D == 0) mma_stream<G, MB, D, XBF>(R, wl, HG_WSTR(L.KB * 64), L.KB, in_lds, CBin, lane, acc);
-        else mma_ring<G, MB, D, XBF>(R, wl, HG_WSTR(L.KB * 64), 0, L.KB, L.KB, in_lds, CBin, lane, acc);
+        if (L.KB % D == 0) mma_stream<G, MB, D, XBF>(R, wl, L.KB * 64, L.KB, in_lds, CBin, lane, acc);
+        else mma_ring<G, MB, D, XBF>(R, wl, L.KB * 64, 0, L.KB, L.KB, in_lds, CBin, lane, acc);
         const int nxt = nb0 + NW * G;
-        if (nxt < L.NB) wring_prime<G, D>(R, L.Wf + HG_WOFF((int64_t)nxt * L.KB * 64) + lane, HG_WSTR(L.KB * 64), L.KB);
+        if (nxt < L.NB) wring_prime<G, D>(R, L.Wf + (int64_t)nxt * L.KB * 64 + lane, L.KB * 64, L.KB);
         else if (AHEAD) { prime_next(); primed = true; }
         epilogue_elu<G, MB>(acc, bias, nb0, out_lds, L.NB, Hg, mbg0, lane);
     }
@@ -874,7 +866,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(const FwdArgs a) {
 template <int G, int D, int GR>
 __device__ __forceinline__ void bwd_prime(WRing<GR, D>& R, const u32x4* __restrict__ WTf, int NBo, int NBBc, int wave, int lane) {
     const int nb0 = wave * G;
-    if (nb0 < NBo) wring_prime<G, D>(R, WTf + HG_WOFF((int64_t)nb0 * NBBc * 64) + lane, HG_WSTR(NBBc * 64), NBBc);
+    if (nb0 < NBo) wring_prime<G, D>(R, WTf + (int64_t)nb0 * NBBc * 64 + lane, NBBc * 64, NBBc);
 }
 
 // HLDS / H_lds: the tile's y = elu(z) in LDS (block layout, NBo column blocks) instead of the global Hg -- the fused forward +

@@ -21,12 +21,6 @@ namespace hgym {
 
 // hgym_update.hip
 int32_t launch_mlp_fb(const FwdArgs& fb, const FbLoss& fl, bool shadow, int tiles, int nets, size_t lds, hipStream_t s);
-// hgym_update3.hip: the same tile on eight compute + four service wavefronts (hgym_fb3.hpp), for the shapes it is instantiated for
-bool fb3_supported(const FwdArgs& fb, int nets);
-int32_t launch_mlp_fb3(const FwdArgs& fb, const FbLoss& fl, int tiles, int nets, size_t lds, hipStream_t s);
-// hgym_update4.hip: 128-row tiles on the same roles (hgym_fb4.hpp)
-bool fb4_supported(const FwdArgs& fb, int nets);
-int32_t launch_mlp_fb4(const FwdArgs& fb, const FbLoss& fl, int nets, hipStream_t s);
 
 // ------------------------------------------------------------------------------------------------ layouts
 struct LayerLayout {
@@ -70,9 +64,6 @@ struct WsLayout {
 
 constexpr int MAX_LOSS_BLOCKS = 8192;   // 256 samples each: minibatches up to 2 M samples
 constexpr int SQN_BLOCKS = 256;         // workgroups of sqnorm_prologue_kernel
-
-constexpr bool kFb3Default = false;
-constexpr bool kFb4Default = false;      // mlp_fb4_kernel (128-row tiles) when HGYM_FB4 is unset      // mlp_fb3_kernel instead of mlp_fb_kernel when HGYM_FB3 is unset
 
 static bool fused_supported(const HgymNetConfig* c) {
     if (c->precision != HGYM_BF16 || c->actor_layers != 4 || c->critic_layers != 4) return false;
@@ -992,7 +983,7 @@ struct NetRunner {
         const int Bp = (int)round_up(B, 64);
         const int nets = aux_fb ? 3 : 2;
         // (128-row tiles on eight 256-register wavefronts -- round 4's mlp_fb2_kernel -- measured equal to slightly slower:
-        // profiles/r04_fb2_128row_tiles_negative_result.txt; its source is kept under csrc/experiments/, outside the library.)
+        // profiles/r04_fb2_128row_tiles_negative_result.txt; its source is profiles/r04_fb2_128row_kernel.patch; round 6 rebuilt the idea on role-specialised wavefronts at 64 and 128 rows: profiles/r06_fb3_role_specialised_wavefronts.txt.)
         const int tiles = Bp / 64;
         HG_REQUIRE(tiles <= MAX_LOSS_BLOCKS, HGYM_E_UNSUPPORTED, "minibatch %d too large for the loss partial buffer", B);
         HG_REQUIRE(B <= w.maxM, HGYM_E_SHAPE, "minibatch %d exceeds max_batch %lld", B, (long long)w.maxM);
@@ -1034,14 +1025,7 @@ struct NetRunner {
             fb.nets = nets;
             fb.dbg = phase_buffer((int64_t)tiles * nets);
             prof_begin(HGYM_PROF_MLP_FWD, s);
-            // role-specialised wavefronts (mlp_fb3_kernel) where instantiated; HGYM_FB3=0 / 1 selects per call (A/B runs, equality test)
-            const char* e3 = getenv("HGYM_FB3");
-            const bool fb3 = shadow && (e3 ? atoi(e3) != 0 : kFb3Default) && fb3_supported(fb, nets);
-            const char* e4 = getenv("HGYM_FB4");
-            const bool fb4 = shadow && (e4 ? atoi(e4) != 0 : kFb4Default) && fb4_supported(fb, nets);
-            const int32_t rc_fb = fb4 ? launch_mlp_fb4(fb, fl, nets, s)
-                                : fb3 ? launch_mlp_fb3(fb, fl, tiles, nets, lds, s)
-                                      : launch_mlp_fb(fb, fl, shadow, tiles, nets, lds, s);      // (hgym_update.hip: the kernel's own code object)
+            const int32_t rc_fb = launch_mlp_fb(fb, fl, shadow, tiles, nets, lds, s);      // (hgym_update.hip: the kernel's own code object)
             if (rc_fb) return rc_fb;
             double flops = 0.0;
             for (int i = 0; i < nets; ++i) {

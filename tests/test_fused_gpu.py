@@ -522,54 +522,6 @@ def test_deferred_values_rollout_equals_inline_rollout(monkeypatch):
         BR.check("deferred-values rollout vs inline rollout, %s" % k, float((a[k] - b[k]).abs().max() / a[k].abs().max()))
 
 
-@pytest.mark.parametrize("S,B", [(700, 333), (500, 164), (9000, 4096), (245760, 61440)])
-@pytest.mark.parametrize("var", ["HGYM_FB3", "HGYM_FB4"])
-def test_update_on_role_specialised_wavefronts_equals_update_on_sixteen_wavefronts(monkeypatch, var, S, B):
-    """`mlp_fb3_kernel` (csrc/hgym_fb3.hpp: 64-row tiles on eight compute + four service wavefronts, activations / gradients leave the
-    compute waves through LDS only) against `mlp_fb_kernel`: every product sums over k in the same order, the epilogues and the loss code
-    are the same instructions on the same values -- the whole gradient (and therefore H / dZ, which the weight-gradient products read) and the
-    loss sums are BIT-identical; only the KL statistic may differ in its last fp32 bit (contraction of its expression is the compiler's
-    choice per kernel).  HGYM_FB4: `mlp_fb4_kernel` (csrc/hgym_fb4.hpp), the same roles on 128-ROW tiles -- layer 0 and dZ0 in passes of 256
-    columns, H0 never resident (its pieces come back from L2 for layer 1 and for elu'), loss partials written per 64 rows in the 64-row kernel's
-    association order.  Ragged tail tiles (B = 333; B = 164: one and a half 128-row tiles), the BASELINE minibatch (61 440 of 245 760).  Reference: /root/reference/humanoid/algo/ppo/ppo.py:128-171."""
-    from hgym import make_ppo_config, make_batch
-    g = torch.Generator().manual_seed(7 * S + B)
-    p = P.Params.random(705, 219, 12, K.ACTOR_HIDDEN, K.CRITIC_HIDDEN, g)
-    net = _net("bf16", max(B, 512))
-    net.load_state_dict(dict(zip(NAMES, p.tensors())))
-    dev = "cuda"
-    gd = torch.Generator(device=dev).manual_seed(S)
-    obs, priv = torch.randn(S, 705, device=dev, generator=gd).clamp_(-18, 18), torch.randn(S, 219, device=dev, generator=gd).clamp_(-18, 18)
-    act, mu_o = torch.randn(S, 12, device=dev, generator=gd), torch.randn(S, 12, device=dev, generator=gd) * 0.3
-    sg_o = torch.rand(S, 12, device=dev, generator=gd) * 0.5 + 0.75
-    val, adv, ret = (torch.randn(S, device=dev, generator=gd) for _ in range(3))
-    lp_o = -12.0 + torch.randn(S, device=dev, generator=gd)
-    idx = torch.randperm(S, device=dev, generator=gd)[:B].contiguous()
-    so = torch.zeros(S, 768, dtype=torch.bfloat16, device=dev)
-    sp = torch.zeros(S, 256, dtype=torch.bfloat16, device=dev)
-    so[:, :705] = obs.to(torch.bfloat16)
-    sp[:, :219] = priv.to(torch.bfloat16)
-    batch = make_batch(obs, priv, act, val, adv, ret, lp_o, mu_o, sg_o, idx, obs_bf16=so, priv_bf16=sp)
-    res = {}
-    for mode in ("16 waves", "8 + 4", "8 + 4 again"):
-        monkeypatch.setenv("HGYM_FB3", "0")
-        monkeypatch.setenv("HGYM_FB4", "0")
-        monkeypatch.setenv(var, "0" if mode == "16 waves" else "1")
-        net.grads_ext.zero_()
-        net.opt_state[2:10] = 0.0
-        net.ppo_grad(make_ppo_config(), batch)
-        torch.cuda.synchronize()
-        res[mode] = (net.grads_ext.clone(), net.opt_state.clone())
-    assert float(res["16 waves"][0][:-1].abs().max()) > 0
-    for mode in ("8 + 4", "8 + 4 again"):
-        assert torch.equal(res[mode][0][:-1], res["16 waves"][0][:-1]), mode               # every gradient tensor, bit for bit
-        np.testing.assert_allclose(float(res[mode][0][-1]), float(res["16 waves"][0][-1]), rtol=1e-6)    # the KL slot
-        o, w = res[mode][1], res["16 waves"][1]
-        assert torch.equal(o[3:8], w[3:8])                                                  # surrogate / value / entropy sums, counters
-        np.testing.assert_allclose(o[[2, 8]].cpu().numpy(), w[[2, 8]].cpu().numpy(), rtol=1e-6)
-        np.testing.assert_allclose(float(o[9]), float(w[9]), rtol=1e-12)
-
-
 def test_runner_update_reads_the_shadow_the_rollout_wrote(monkeypatch):
     """End to end: two learning iterations with the shadow (default) and without (HGYM_SHADOW=0) from the same seeds end in
     bit-identical parameters, and the shadow slots hold the bf16 of the stored observation rows."""
