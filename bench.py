@@ -449,8 +449,19 @@ def place_rank_on_host(local, world):
             return dict(threads=1, pinned=False, note="fewer than 2 cores per rank")
         per = min(per, 16)
         mine = cores[local * per:(local + 1) * per]
+        # every thread that exists already (the HIP runtime's, torch's pools) as well as the calling one: sched_setaffinity(0, ..) alone
+        # moves only the caller, and threads created from now on inherit ITS mask -- which is why main() calls this before
+        # the process group (RCCL / gloo helper threads) exists
+        tids = [int(t) for t in os.listdir("/proc/self/task")] if os.path.isdir("/proc/self/task") else [0]
+        moved = 0
+        for tid in tids:
+            try:
+                os.sched_setaffinity(tid, mine)
+                moved += 1
+            except OSError:
+                pass
         os.sched_setaffinity(0, mine)
-        return dict(threads=1, pinned=True, cores=[mine[0], mine[-1]], cores_per_rank=per)
+        return dict(threads=1, pinned=True, cores=[mine[0], mine[-1]], cores_per_rank=per, threads_moved=moved, before_process_group=True)
     except OSError as e:
         return dict(threads=1, pinned=False, note=str(e))
 
@@ -505,6 +516,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # host placement FIRST (LOCAL_RANK / WORLD_SIZE are in the environment): whatever creates threads below inherits the rank's core block
+    host_placement = place_rank_on_host(local % max(world, 1), world) if world > 1 else None
     assert torch.cuda.is_available(), "bench.py measures the MI355X hot path; no GPU visible"
     local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
@@ -517,7 +530,7 @@ def main():
         else:
             dist.init_process_group(backend)
     assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
-    args.host_placement = place_rank_on_host(local, world) if world > 1 else None
+    args.host_placement = host_placement
     os.environ["HGYM_PRECISION"] = args.precision
     from humanoid.algo import PPO
     PPO.precision = args.precision

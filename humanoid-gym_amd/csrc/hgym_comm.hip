@@ -94,6 +94,10 @@ __global__ __launch_bounds__(COMM_THREADS) void p2p_allreduce_kernel(const CommA
     if (!arrived && t == 0) {
         c.status[0] = 1;
         c.status[1] = (long long)c.seq;
+        // ... and remember it for this call's last workgroup, which tells the peers (below): a rank whose wait expired has NOT summed its
+        // shard, so nobody's vector is good -- the verdict must be the same on every rank (a late rank used to see both flags
+        // of the rank that gave up on it and finish with status 0)
+        __hip_atomic_store(myf + 17, c.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (arrived) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
@@ -131,12 +135,22 @@ __global__ __launch_bounds__(COMM_THREADS) void p2p_allreduce_kernel(const CommA
     __syncthreads();
     if (s_last) {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "");
+        // slot 24 + rank of every flag block: "rank gave up in call seq" -- stored (and released) in front of the completion flag, so whoever
+        // sees this rank's completion flag of the call also sees its verdict
+        const bool gave_up = __hip_atomic_load(myf + 17, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == c.seq;
+        if (gave_up && t < c.world) st_sys(c.flags[t] + 24 + c.rank, c.seq);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
         if (t < c.world) st_sys(c.flags[t] + 8 + c.rank, c.seq);
     }
     if (blockIdx.x == 0) {
         if (t < 64) {
             // (after an expired phase-A wait the peers' completion flags cannot be expected either: no second bounded wait)
-            const bool ok = arrived ? wait_slots(myf + 8, c.world, c.seq, lane, c.wait_ticks) : false;
+            bool ok = arrived ? wait_slots(myf + 8, c.world, c.seq, lane, c.wait_ticks) : false;
+            if (ok) {       // every rank completed the call: did any of them give up on somebody?
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+                const bool bad = lane < c.world && ld_sys(myf + 24 + lane) == c.seq;
+                ok = !__any(bad);
+            }
             if (t == 0) {
                 if (!ok) {
                     c.status[0] = 1;

@@ -66,6 +66,37 @@ def allreduce_adv_stats(stats):
     return stats
 
 
+class ReplicaMismatch(RuntimeError):
+    """The data-parallel replicas no longer hold the same parameters (check_replicas) -- or some rank's direct exchange reported an
+    expired wait: training must stop on EVERY rank, in the same iteration."""
+
+
+def check_replicas(params, lr=None, comm_expired=0, what=""):
+    """Collective (every rank, same program point): an exact digest of the flat parameter vector -- the int32 view summed in int64, the
+    same with position weights, the learning rate's bits -- plus this rank's count of expired waits of the direct exchange, all-gathered
+    and compared on every rank, so that all ranks take the same decision.  A stale cache line over xGMI, a time-out that one rank saw
+    and another did not, a lost gradient: whatever made the replicas differ raises ReplicaMismatch everywhere instead of letting N
+    different policies train on.  Cost: two reductions over 926 105 words, one 4-word all-gather, one host synchronisation -- called every
+    save_interval iterations and at the end of learn() (OnPolicyRunner), never inside the timed step.  Returns the digest (list of ints)."""
+    if not active():
+        return None
+    bits = params.detach().view(torch.int32).to(torch.int64)
+    w = torch.arange(1, bits.numel() + 1, device=bits.device, dtype=torch.int64)
+    lr_bits = int(torch.as_tensor(float(lr) if lr is not None else 0.0, dtype=torch.float64).view(torch.int64))
+    mine = torch.stack([bits.sum(), (bits * (w & 0xffff)).sum(), torch.as_tensor(lr_bits, device=bits.device),
+                        torch.as_tensor(int(comm_expired), device=bits.device, dtype=torch.int64)])
+    got = [torch.empty_like(mine) for _ in range(world_size())]
+    dist.all_gather(got, mine)
+    rows = [g.tolist() for g in got]
+    expired = [q for q, r in enumerate(rows) if r[3] != 0]
+    if expired:
+        raise ReplicaMismatch("%s: the direct gradient exchange reported expired waits on rank(s) %s: replicas can no longer be trusted" % (what, expired))
+    diff = [q for q, r in enumerate(rows) if r[:3] != rows[0][:3]]
+    if diff:
+        raise ReplicaMismatch("%s: parameter digest of rank(s) %s differs from rank 0's (%s vs %s)" % (what, diff, rows[diff[0]][:3], rows[0][:3]))
+    return rows[0][:3]
+
+
 def broadcast_parameters(params):
     if active():
         for p in params:
@@ -162,16 +193,17 @@ def make_comm(count, device):
     ok, why = _agree(comm.connected, err)
     if not ok:
         return give_up("hipIpcOpenMemHandle failed (%s)" % why, comm)
-    if mode == "both":
-        return comm
-    # ---- 3: first contact: a known pattern through the direct kernel ...
+    # ---- 3: first contact: a known pattern through the direct kernel (also for "both": bench.py runs real updates through it) ...
     try:
         ok_local, note = comm.probe_verify(device)
     except Exception as e:          # noqa: BLE001
         ok_local, note = False, "raised %r" % (e,)
     ok, why = _agree(ok_local, note)
+    _REPORT["first_contact_verified"] = bool(ok)
     if not ok:
         return give_up("first direct exchange failed (%s)" % why, comm)
+    if mode == "both":
+        return comm
     # ---- 4: ... then both exchanges timed (the same calls on every rank: nothing in here returns early)
     try:
         probe = comm.probe_time(device)
@@ -323,13 +355,22 @@ class P2PComm:
         (q + 1) (k + 1) x [1 .. 7 repeating] in round k, the sum is W (W + 1) / 2 (k + 1) x the pattern, exact in fp32 -- a value that
         changes every round, so a peer's (or this device's) stale cache line of an earlier round shows up as a wrong sum here, not as
         a silently diverged replica later.  Every wait is bounded by PROBE_WAIT_S."""
+        # The ONE collective call in here (the barrier that lines the ranks up in front of round 0) is made unconditionally: whatever fails
+        # locally before it (an allocation, a launch) is recorded and reported afterwards, so no rank is ever left alone in the barrier
+        # while its peer is already in make_comm's agreement (ADVICE r05).
         W, n = self.world, self.count
-        self.set_wait(PROBE_WAIT_S)
-        pat = (torch.arange(n, device=device, dtype=torch.float32) % 7.0) + 1.0
-        got = torch.zeros(PROBE_ROUNDS, n, device=device, dtype=torch.float32)
-        self.data.zero_()
-        torch.cuda.synchronize(device)
+        err, pat, got = None, None, None
+        try:
+            self.set_wait(PROBE_WAIT_S)
+            pat = (torch.arange(n, device=device, dtype=torch.float32) % 7.0) + 1.0
+            got = torch.zeros(PROBE_ROUNDS, n, device=device, dtype=torch.float32)
+            self.data.zero_()
+            torch.cuda.synchronize(device)
+        except Exception as e:          # noqa: BLE001
+            err = e
         dist.barrier()
+        if err is not None:
+            return False, "set-up of the first exchange raised %r" % (err,)
         skip = _inject("timeout")
         for k in range(PROBE_ROUNDS):
             if skip:
@@ -352,31 +393,49 @@ class P2PComm:
 
     def probe_time(self, device):
         """PROBE_CALLS calls of each exchange on the real payload size between barriers, HIP-event timed: dict(p2p_us, collective_us),
-        or dict(error) -- never returns before every collective call of the sequence has been made."""
-        scratch = torch.zeros(self.count, device=device, dtype=torch.float32)
-        self.data.zero_()
-        self.set_wait(0.5)
-
-        def timed(fn):
-            for _ in range(3):
-                fn()
+        or dict(error).  The collective sequence -- one agreement, two barriers, 3 + PROBE_CALLS all-reduces -- is the same on every rank
+        whatever happens locally: allocations come first and are agreed on (a rank that cannot allocate the scratch tensor makes EVERY
+        rank skip the timing), local GPU work is wrapped and its error reported at the end, collective calls are never skipped."""
+        err, scratch = None, None
+        try:
+            scratch = torch.zeros(self.count, device=device, dtype=torch.float32)
+            self.data.zero_()
+            self.set_wait(0.5)
             torch.cuda.synchronize(device)
+        except Exception as e:          # noqa: BLE001
+            err = e
+        ok, why = _agree(err is None, err)
+        if not ok:
+            return dict(error="set-up of the timing probe failed (%s)" % why)
+        local = []
+
+        def guarded(fn):
+            try:
+                return fn()
+            except Exception as e:      # noqa: BLE001 -- recorded; the collective sequence goes on
+                local.append(e)
+                return None
+
+        def timed(fn, collective):
+            run = fn if collective else (lambda: guarded(fn))       # a collective call is never wrapped away
+            for _ in range(3):
+                run()
+            guarded(lambda: torch.cuda.synchronize(device))
             dist.barrier()
             ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(PROBE_CALLS)]
             for a, b in ev:
                 a.record()
-                fn()
+                run()
                 b.record()
-            torch.cuda.synchronize(device)
-            return sum(a.elapsed_time(b) for a, b in ev) / len(ev) * 1e3
+            return guarded(lambda: (torch.cuda.synchronize(device), sum(a.elapsed_time(b) for a, b in ev) / len(ev) * 1e3)[1])
 
-        t_p2p = timed(self.allreduce)
-        s = self.read_status()
-        t_coll = timed(lambda: finish(start_sum(scratch)))
-        self.data.zero_()
-        torch.cuda.synchronize(device)
-        self.set_wait(None)
-        if s[0] != 0:
+        t_p2p = timed(self.allreduce, False)
+        s = guarded(self.read_status)
+        t_coll = timed(lambda: finish(start_sum(scratch)), True)
+        guarded(lambda: (self.data.zero_(), torch.cuda.synchronize(device), self.set_wait(None)))
+        if local:
+            return dict(error="timing the exchanges raised %r" % (local[0],))
+        if s is None or s[0] != 0:
             return dict(error="a bounded wait expired while timing the direct exchange")
         return dict(p2p_us=t_p2p, collective_us=t_coll)
 

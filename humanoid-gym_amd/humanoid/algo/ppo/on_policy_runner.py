@@ -280,6 +280,8 @@ class OnPolicyRunner:
                 mean_value_loss, mean_surrogate_loss = alg.update(sync=False) if (async_iters or async_log) else alg.update()
                 if zero_copy:                       # storage.clear() rotated slot T into slot 0
                     obs, critic_obs = obs_all[0], priv_all[0]
+                if it % self.save_interval == 0:
+                    self._check_replicas("iteration %d" % it)       # (data-parallel runs only; collective: every rank, same iteration)
                 stop = time.time()
                 learn_time = stop - start
                 if async_iters:
@@ -336,11 +338,31 @@ class OnPolicyRunner:
             self.last_collection_time = sum(a.elapsed_time(b) for a, b, _ in marks) * 1e-3 / len(marks)
             self.last_learn_time = sum(b.elapsed_time(c) for _, b, c in marks) * 1e-3 / len(marks)
         self.current_learning_iteration += num_learning_iterations
+        self._check_replicas("end of learn() at iteration %d" % self.current_learning_iteration)
         if self.log_dir is not None:
             self.save(os.path.join(self.log_dir, "model_{}.pt".format(self.current_learning_iteration)), wait=False)
             self.wait_for_saves()           # as in the reference, every checkpoint of this call is on disk when learn() returns
 
     # ------------------------------------------------------------------
+    def _check_replicas(self, what):
+        """Data-parallel training: every save_interval iterations and at the end of learn() the ranks compare an exact digest of their
+        parameters (and whether any rank's direct gradient exchange saw an expired wait) and ALL raise dist_utils.ReplicaMismatch if they
+        differ -- a replica that silently diverged (a stale line over xGMI, a time-out only one rank noticed) would otherwise train on as
+        a different policy.  No-op on one rank.  HGYM_REPLICA_CHECK=0 switches it off."""
+        from . import dist_utils
+        if not dist_utils.active() or os.environ.get("HGYM_REPLICA_CHECK", "1") == "0":
+            return None
+        alg = self.alg
+        net = getattr(alg, "net", None)
+        if net is None:
+            return None
+        expired = 0
+        comm = getattr(alg, "_comm", None)
+        if comm is not None and (getattr(alg, "_comm_p2p", False) or getattr(alg, "_comm_direct_used", False)):
+            expired = int(comm.read_status()[0] != 0)
+        self.last_replica_digest = dist_utils.check_replicas(net.params, lr=float(net.opt_state[0]), comm_expired=expired, what=what)
+        return self.last_replica_digest
+
     def _log_snapshot(self, env, alg, slot):
         """Enqueue the device -> pinned-host copies of everything one iteration's log block needs (the optimiser's scalar state:
         loss sums, learning rate; the env's log sink: extras["episode"] sums and the last-100-episodes rings; the mean action

@@ -128,6 +128,7 @@ class PPO:
         self._comm_p2p = self._comm is not None and dist_utils.comm_backend() == "p2p"
         self._comm_pin = None
         self.comm_report = dist_utils.comm_report()     # mode, used, fallback_reason, probe timings (bench.py prints it)
+        self._comm_direct_used = False      # the direct kernel has carried at least one real gradient (also under HGYM_COMM=both)
         self.comm_flip = False      # bench.py: use the OTHER exchange for the next update() (timing both in its profiling iterations)
         self.net = hgym.NetBuffers(cfg, self.device, learning_rate=self._lr0, grads_ext=None if self._comm is None else self._comm.data)
         dist_utils.broadcast_parameters(ac.parameters())   # identical initial parameters on every rank
@@ -166,13 +167,13 @@ class PPO:
         learn(), the asynchronous log's snapshot): raises dist_utils.CommTimeout if a bounded wait of any call expired -- that
         minibatch's gradient was garbage and the replicas have diverged, so training must not go on silently.  words: a host copy
         of the status block taken earlier (comm_status_snapshot); None: synchronise and read it now."""
-        if self._comm is None or not self._comm_p2p:
+        if self._comm is None or not (self._comm_p2p or self._comm_direct_used):      # (HGYM_COMM=both: bench.py's comm_flip updates ran it)
             return
         self._comm.raise_if_expired(self._comm.read_status() if words is None else words)
 
     def comm_status_snapshot(self, slot):
         """Stream-ordered device -> pinned-host copy of the status block (no host wait); the caller reads it after its own event."""
-        if self._comm is None or not self._comm_p2p:
+        if self._comm is None or not (self._comm_p2p or self._comm_direct_used):
             return None
         if self._comm_pin is None:
             self._comm_pin = [torch.zeros(16, dtype=torch.int64).pin_memory() for _ in range(2)]
@@ -333,6 +334,7 @@ class PPO:
                             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                             ev[0].record()
                         self._comm.allreduce()
+                        self._comm_direct_used = True
                     else:
                         h = dist_utils.start_sum(net.grads_ext)
                         if probe:

@@ -102,7 +102,8 @@ def test_rank_placement_partitions_the_allowed_cores(monkeypatch):
         return
     allowed = sorted(os.sched_getaffinity(0))
     calls = []
-    monkeypatch.setattr(os, "sched_setaffinity", lambda pid, cores: calls.append(list(cores)))
+    tids = []
+    monkeypatch.setattr(os, "sched_setaffinity", lambda pid, cores: (tids.append(pid), calls.append(list(cores)) if pid == 0 else None))
     nt = torch.get_num_threads()
     try:
         world = 2 if len(allowed) >= 4 else 1
@@ -111,6 +112,8 @@ def test_rank_placement_partitions_the_allowed_cores(monkeypatch):
             assert all(x["pinned"] for x in blocks) and len(calls) == world
             assert not (set(calls[0]) & set(calls[-1])) or world == 1
             assert all(set(c) <= set(allowed) and 2 <= len(c) <= 16 for c in calls)
+            # every thread that already exists is moved, not only the caller: this process's main thread id among them
+            assert all(x["threads_moved"] >= 1 for x in blocks) and os.getpid() in tids
         monkeypatch.setenv("HGYM_PIN", "0")
         assert b.place_rank_on_host(0, world)["pinned"] is False
     finally:

@@ -106,3 +106,48 @@ def test_two_rank_exchanges(tmp_path):
     std = torch.sqrt((s[1] - s[0] * s[0] / n) / (n - 1))
     got = torch.cat([(r[i]["adv"] - mean.float()) / (std.float() + 1e-8) for i in range(2)], dim=1)
     np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=1e-5, atol=1e-6)
+
+
+def _replica_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "humanoid-gym_amd"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from humanoid.algo.ppo import dist_utils as D
+    g = torch.Generator().manual_seed(5)
+    params = torch.randn(926105, generator=g)
+    res = {}
+    res["same"] = D.check_replicas(params, lr=1e-3, what="identical replicas")
+    for name, mutate, kw in (("one_ulp", lambda p: p.view(torch.int32).__setitem__(777, p.view(torch.int32)[777] + (1 if rank == 1 else 0)), {}),
+                             ("swap", lambda p: None, {}), ("lr", lambda p: None, dict(lr=1e-3 if rank == 0 else 1.0000001e-3)),
+                             ("expired", lambda p: None, dict(comm_expired=1 if rank == 1 else 0))):
+        p = params.clone()
+        if name == "swap" and rank == 1:                    # two elements exchanged: same plain sum, caught by the weighted one
+            p[10], p[11] = params[11].clone(), params[10].clone()
+        mutate(p)
+        try:
+            D.check_replicas(p, **dict(dict(lr=1e-3), **kw), what=name)
+            res[name] = None
+        except D.ReplicaMismatch as e:
+            res[name] = str(e)
+    t = torch.tensor([float(rank + 1)])
+    dist.all_reduce(t)                                      # every rank left every check in step
+    res["total"] = float(t)
+    torch.save(res, os.path.join(out_dir, "p%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+def test_replica_digest_check_raises_on_every_rank(tmp_path):
+    """dist_utils.check_replicas (OnPolicyRunner runs it every save_interval iterations and at the end of learn()): identical
+    replicas pass with the same digest on both ranks; ONE parameter that differs in its last bit, two exchanged elements, a learning rate
+    that differs in its last digit, or an expired wait of the direct exchange reported by one rank raise ReplicaMismatch on BOTH ranks --
+    and the ranks are in step afterwards."""
+    port = 29800 + (os.getpid() % 2000)
+    mp.spawn(_replica_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r = [torch.load(os.path.join(str(tmp_path), "p%d.pt" % i)) for i in range(2)]
+    assert r[0]["same"] == r[1]["same"] and r[0]["same"] is not None
+    for name in ("one_ulp", "swap", "lr", "expired"):
+        assert r[0][name] and r[1][name], (name, r[0][name], r[1][name])
+    assert "expired" in r[0]["expired"] and "differs" in r[0]["one_ulp"]
+    assert r[0]["total"] == r[1]["total"] == 3.0
