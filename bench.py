@@ -331,16 +331,32 @@ def run_config(args, task, num_envs, rank, world, local, dist, steps, warmup, lo
         coll, learn = runner.last_collection_time, runner.last_learn_time     # per iteration (HIP events / host clock when logging)
         barrier()
         elapsed = time.perf_counter() - t0
-        ckpt_s = getattr(runner, "save_time_s", 0.0) - save0                  # checkpoint writes inside the timed region (logging runs)
+        ckpt_s = getattr(runner, "save_time_s", 0.0) - save0                  # checkpoint time of the TRAINING thread inside the timed region (logging runs)
+        # the final checkpoint is handed to the background writer (HGYM_ASYNC_SAVE, default on): learn() does not wait for the file.  What
+        # the writer still needs is measured here, outside the timed region, and reported next to the value
+        t1 = time.perf_counter()
+        if hasattr(runner, "wait_for_saves"):
+            runner.wait_for_saves()
+        ckpt_wait_s = time.perf_counter() - t1
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if dist is not None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax)
     res = dict(value=T * N * world * steps / elapsed, ms_per_step=elapsed / steps * 1e3, ppo_update_ms=learn * 1e3,
                collection_ms=coll * 1e3, T=T, N=N, obs=env.num_obs, priv=env.num_privileged_obs)
+    it_ms = sorted(getattr(runner, "last_iteration_ms", None) or [])
+    if len(it_ms) == steps and log_root is None:
+        # per-iteration device times of the timed call (HIP events on the launch stream, read after the region): the contract's `value` is
+        # K steps over the region's wall time (a mean); SURVEY 8(d) asks for the median of >= 20 iterations -- both are in the line
+        med = it_ms[len(it_ms) // 2] if len(it_ms) % 2 else 0.5 * (it_ms[len(it_ms) // 2 - 1] + it_ms[len(it_ms) // 2])
+        res["iteration_ms"] = dict(median=med, mean=sum(it_ms) / len(it_ms), min=it_ms[0], max=it_ms[-1], n=len(it_ms),
+                                   value_at_median=T * N * world / (med * 1e-3), source="HIP events per iteration, this rank")
     if log_root is not None:
         res["checkpoint_ms_total"] = ckpt_s * 1e3
         res["value_without_checkpoints"] = T * N * world * steps / max(elapsed - ckpt_s, 1e-9)
+        res["final_checkpoint_wait_ms_after_learn"] = ckpt_wait_s * 1e3
+        res["value_including_final_checkpoint_wait"] = T * N * world * steps / (elapsed + ckpt_wait_s)
+        res["async_save"] = os.environ.get("HGYM_ASYNC_SAVE", "1") != "0"
     if want_roofline:
         # live per-kernel timing with HIP events on the launch stream (hgym_prof_*).  Events cannot be recorded inside a
         # replayed HIP graph, so these two iterations run the rollout eagerly (same kernels, same launch order).  EVERY rank
@@ -405,6 +421,17 @@ def run_config(args, task, num_envs, rank, world, local, dist, steps, warmup, lo
                 comm["optimizer_steps"] = int(float(runner.alg.net.opt_state[1]))
             except Exception as e:      # noqa: BLE001
                 comm["replicas_check_error"] = str(e)
+            # every rank's own iteration times of the timed call (HIP events on its stream): a rank that is slow on the host or on the device
+            # shows up here, next to the exchange's exposed wait (which contains the wait for the slowest rank)
+            try:
+                it_ms = sorted(getattr(runner, "last_iteration_ms", None) or [0.0])
+                mine = dict(rank=rank, min=it_ms[0], median=it_ms[len(it_ms) // 2], max=it_ms[-1], n=len(it_ms))
+                allr = [None] * world
+                dist.all_gather_object(allr, mine)
+                comm["per_rank_iteration_ms"] = allr
+                comm["slowest_over_fastest_rank_median"] = max(r_["median"] for r_ in allr) / max(min(r_["median"] for r_ in allr), 1e-9)
+            except Exception as e:      # noqa: BLE001
+                comm["per_rank_error"] = str(e)
             c = getattr(runner.alg, "_comm", None)
             if c is not None:
                 try:
@@ -582,8 +609,14 @@ def main():
                 continue
             if "checkpoint_ms_total" in r:
                 e.update(checkpoint_ms_total=r["checkpoint_ms_total"], value_without_checkpoints=r["value_without_checkpoints"],
-                         checkpoint_note="`value` includes the checkpoint(s) OnPolicyRunner.learn writes inside the timed region (the final "
-                                         "model_<it>.pt of the call); value_without_checkpoints = the same run with their host time taken out")
+                         final_checkpoint_wait_ms_after_learn=r["final_checkpoint_wait_ms_after_learn"],
+                         value_including_final_checkpoint_wait=r["value_including_final_checkpoint_wait"], async_save=r["async_save"],
+                         checkpoint_note="`value`: learn() of K iterations incl. what its checkpoint (the final model_<it>.pt) costs the training "
+                                         "thread and the device (snapshot to pinned host memory behind the update); the file itself is written by a "
+                                         "background thread (HGYM_ASYNC_SAVE, default on) that learn() does not wait for -- "
+                                         "final_checkpoint_wait_ms_after_learn is how long the bench then waited for it, "
+                                         "value_including_final_checkpoint_wait charges that wait to the run; value_without_checkpoints = the run "
+                                         "with the training thread's checkpoint time taken out")
             e.update(workload=_workload("humanoid_dwl_ppo" if c == "dwl" else "humanoid_ppo", r["N"], r["T"]), envs_per_gpu=r["N"],
                      value=r["value"], unit="env-steps/s", steps=k_steps, warmup=k_warm, ms_per_step=r["ms_per_step"],
                      collection_ms=r["collection_ms"], ppo_update_ms=r["ppo_update_ms"])
@@ -593,6 +626,21 @@ def main():
                 e["roofline"] = _roofline_obj(r["kernels"], pick="rollout_step_kernel" if c == "envs8192" else None)
             extra.append(e)
 
+    n1 = None
+    if dist is not None and world > 1 and os.environ.get("HGYM_BENCH_N1_REF", "1") != "0":
+        # the same workload on ONE rank of this very job (rank 0 alone, the others idle at the barrier): what the N-rank value is to be
+        # divided by -- same box, same minute, same library (the driver computes its own efficiency from separate runs; this one is printed
+        # so that a single N-rank call is self-contained)
+        if rank == 0:
+            os.environ["HGYM_DIST_OFF"] = "1"
+            try:
+                r1 = run_config(args, args.task, args.num_envs, 0, 1, local, None, min(args.steps, 10), min(args.warmup, 3), want_roofline=False, quiet=True)
+                n1 = dict(value=r1["value"], ms_per_step=r1["ms_per_step"], steps=min(args.steps, 10),
+                          weak_scaling_efficiency_in_this_call=head["value"] / (world * r1["value"]),
+                          note="rank 0 alone (HGYM_DIST_OFF=1) right after the %d-rank run, the other ranks idle" % world)
+            except Exception as e:      # noqa: BLE001
+                n1 = dict(error=str(e))
+            del os.environ["HGYM_DIST_OFF"]
     if dist is not None:
         dist.barrier()
     if rank == 0:
@@ -609,6 +657,8 @@ def main():
             out["roofline"] = _roofline_obj(head["kernels"])
         if head.get("comm"):
             out["comm"] = head["comm"]
+            if n1 is not None:
+                out["comm"]["n1_reference"] = n1
         if extra:
             out["configs"] = extra
         if not args.no_cpu_baseline and world == 1:      # the CPU baseline leg belongs to the N=1 run only

@@ -105,7 +105,9 @@ __global__ __launch_bounds__(256) void gae_kernel(int T, int N, float* __restric
             }
         }
     }
-    // advantage statistics for the normalisation: wave reduce -> block reduce -> one fp64 atomic pair per block
+    // advantage statistics for the normalisation: wave reduce -> block reduce -> per-workgroup partial sums in the caller's scratch
+    // (stats + 4), added up IN A FIXED ORDER by the last workgroup to arrive (stats[3] holds the arrival counter): the same bits in every
+    // run and on every rank, like the gradient norm (sqnorm_prologue_kernel) -- fp64 atomics on two words summed in arrival order
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         sum1 += __shfl_down(sum1, off, 64);
@@ -116,15 +118,42 @@ __global__ __launch_bounds__(256) void gae_kernel(int T, int N, float* __restric
         s_sum[wave][1] = sum2;
     }
     __syncthreads();
+    __shared__ int s_last;
+    double* __restrict__ part = stats + 4;
+    unsigned int* cnt = reinterpret_cast<unsigned int*>(stats + 3);
     if (tid == 0) {
-        atomicAdd(&stats[0], s_sum[0][0] + s_sum[1][0] + s_sum[2][0] + s_sum[3][0]);
-        atomicAdd(&stats[1], s_sum[0][1] + s_sum[1][1] + s_sum[2][1] + s_sum[3][1]);
-        if (blockIdx.x == 0) stats[2] = (double)T * (double)N;
+        part[2 * blockIdx.x] = s_sum[0][0] + s_sum[1][0] + s_sum[2][0] + s_sum[3][0];
+        part[2 * blockIdx.x + 1] = s_sum[0][1] + s_sum[1][1] + s_sum[2][1] + s_sum[3][1];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        const unsigned int done = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (done == gridDim.x - 1u) ? 1 : 0;
     }
-}
-
-__global__ void zero_stats_kernel(double* stats) {
-    if (threadIdx.x < 3) stats[threadIdx.x] = 0.0;
+    __syncthreads();
+    if (s_last) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        double a = 0.0, b = 0.0;
+        for (int i = tid; i < (int)gridDim.x; i += 256) {      // thread t: workgroups t, t + 256, ... in that order
+            a += part[2 * i];
+            b += part[2 * i + 1];
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            a += __shfl_down(a, off, 64);
+            b += __shfl_down(b, off, 64);
+        }
+        __syncthreads();
+        if (lane == 0) {
+            s_sum[wave][0] = a;
+            s_sum[wave][1] = b;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            stats[0] = s_sum[0][0] + s_sum[1][0] + s_sum[2][0] + s_sum[3][0];
+            stats[1] = s_sum[0][1] + s_sum[1][1] + s_sum[2][1] + s_sum[3][1];
+            stats[2] = (double)T * (double)N;
+            __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // the next call counts from zero
+        }
+    }
 }
 
 // rollout_storage.py:136: (adv - mean) / (std_unbiased + 1e-8), mean/std from fp64 sums, arithmetic in fp32
@@ -217,7 +246,6 @@ int32_t hgym_gae(int32_t T, int32_t n, const float* rewards, const float* values
                  float gamma, float lam, float* returns, float* advantages, double* stats, void* stream) {
     HG_REQUIRE(T > 0 && n > 0, HGYM_E_SHAPE, "T=%d n=%d", T, n);
     HG_REQUIRE(rewards && values && dones && last_values && returns && advantages && stats, HGYM_E_BADARG, "null pointer");
-    hipLaunchKernelGGL(zero_stats_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, stats);
     prof_begin(HGYM_PROF_GAE, (hipStream_t)stream);
     hipLaunchKernelGGL(gae_kernel<false>, dim3(ceil_div(n, GAE_ENVS)), dim3(256), 0, (hipStream_t)stream, T, n, const_cast<float*>(rewards), values,
                        dones, nullptr, last_values, gamma, lam, returns, advantages, stats);
@@ -230,7 +258,6 @@ int32_t hgym_gae_bootstrap(int32_t T, int32_t n, float* rewards, const float* va
                            const float* last_values, float gamma, float lam, float* returns, float* advantages, double* stats, void* stream) {
     HG_REQUIRE(T > 0 && n > 0, HGYM_E_SHAPE, "T=%d n=%d", T, n);
     HG_REQUIRE(rewards && values && dones && time_outs && last_values && returns && advantages && stats, HGYM_E_BADARG, "null pointer");
-    hipLaunchKernelGGL(zero_stats_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, stats);
     prof_begin(HGYM_PROF_GAE, (hipStream_t)stream);
     hipLaunchKernelGGL(gae_kernel<true>, dim3(ceil_div(n, GAE_ENVS)), dim3(256), 0, (hipStream_t)stream, T, n, rewards, values, dones, time_outs,
                        last_values, gamma, lam, returns, advantages, stats);

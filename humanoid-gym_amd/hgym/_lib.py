@@ -267,3 +267,9 @@ def i64ptr(t):
 
 def f64ptr(t):
     return None if t is None else C.cast(t.data_ptr(), c_f64_p)
+
+
+def gae_stats(n, device):
+    """The `stats` buffer of hgym_gae / hgym_gae_bootstrap for n envs: HGYM_GAE_STATS_DOUBLES(n) zero-filled doubles (include/hgym.h)."""
+    import torch
+    return torch.zeros(4 + 2 * ((int(n) + 15) // 16), dtype=torch.float64, device=device)

@@ -32,8 +32,8 @@ def active():
     """True when the update has to go through the collectives: more than one rank -- or ONE rank with HGYM_DIST_SINGLE=1, which
     issues every collective of the N > 1 path on a one-rank group (results must not change; this is how the RCCL stream
     ordering is exercised on a box with a single GPU, tests/test_dist_gpu.py)."""
-    if not (dist.is_available() and dist.is_initialized()):
-        return False
+    if not (dist.is_available() and dist.is_initialized()) or os.environ.get("HGYM_DIST_OFF") == "1":
+        return False        # (HGYM_DIST_OFF=1: a rank of a running group trains ALONE -- bench.py's same-box N = 1 reference line)
     return dist.get_world_size() > 1 or os.environ.get("HGYM_DIST_SINGLE") == "1"
 
 

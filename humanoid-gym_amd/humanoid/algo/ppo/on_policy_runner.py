@@ -337,11 +337,16 @@ class OnPolicyRunner:
                 alg.check_comm()                # the asynchronous loop read nothing back: the exchange's status word, once per call
             self.last_collection_time = sum(a.elapsed_time(b) for a, b, _ in marks) * 1e-3 / len(marks)
             self.last_learn_time = sum(b.elapsed_time(c) for _, b, c in marks) * 1e-3 / len(marks)
+            # per-iteration device times of this call (ms; iteration k's start event to iteration k + 1's, i.e. including whatever idles
+            # between them): bench.py reports their median next to the mean ("median of >= 20")
+            self.last_iteration_ms = [marks[k][0].elapsed_time(marks[k + 1][0]) for k in range(len(marks) - 1)] + [marks[-1][0].elapsed_time(marks[-1][2])]
         self.current_learning_iteration += num_learning_iterations
         self._check_replicas("end of learn() at iteration %d" % self.current_learning_iteration)
         if self.log_dir is not None:
             self.save(os.path.join(self.log_dir, "model_{}.pt".format(self.current_learning_iteration)), wait=False)
-            self.wait_for_saves()           # as in the reference, every checkpoint of this call is on disk when learn() returns
+            if os.environ.get("HGYM_ASYNC_SAVE", "1") == "0":
+                self.wait_for_saves()       # (synchronous path: nothing is pending; kept for symmetry)
+            # else: the background writer finishes the file; wait_for_saves() / load() / interpreter exit wait for it (save()'s docstring)
 
     # ------------------------------------------------------------------
     def _check_replicas(self, what):
@@ -459,16 +464,19 @@ class OnPolicyRunner:
 
     def save(self, path, infos=None, wait=True):
         """on_policy_runner.py:274-281 (same dict, same keys).  wait=True (the reference's semantics, and what a direct caller gets): the
-        file is on disk when the call returns; learn() passes wait=False for its own checkpoints and waits once, before it returns.  On the device path the tensors are first copied to pinned host memory
-        stream-side (behind whatever the update has enqueued -- the host does not wait) and pickled + written by a background
-        thread, so a checkpoint inside a training run costs the training thread ~0.1 ms instead of a device sync + 6-15 ms;
-        `wait_for_saves()` (called by learn() before it returns, by load(), and at interpreter exit) waits for the files.
-        OPT-IN (HGYM_ASYNC_SAVE=1): it pays for runs that checkpoint often; in bench.py's 6-iteration logging window the only
-        checkpoint is the last one, which learn() has to wait for anyway, and the writer thread's wake-up made that wait 5-75 ms
-        instead of a steady 5 ms (tools/probe_logging.py, profiles/r04_async_checkpoint_ab.txt).  Default: the synchronous torch.save."""
+        file is on disk when the call returns.  On the device path the tensors are first copied to pinned host memory stream-side (behind
+        whatever the update has enqueued -- the host does not wait) and pickled + written by a background thread, so a checkpoint costs the
+        training thread ~0.1 ms instead of a device sync + 5-15 ms.  learn() passes wait=False for ALL its checkpoints, the final one
+        included (round 6: default; `test_background_checkpoint_equals_the_synchronous_one`): the file of the last iteration is complete a
+        few milliseconds AFTER learn() returns -- `wait_for_saves()` (called by load(), by the next save(wait=True), and at interpreter
+        exit, which is when scripts/train.py ends) waits for it.  A caller that reads model_<it>.pt from the same process right after
+        learn() calls runner.wait_for_saves() first; HGYM_ASYNC_SAVE=0 restores the reference's blocking torch.save everywhere.
+        (Round 4 kept this opt-in because learn() then WAITED for the final file and the writer thread's wake-up made that wait 5-75 ms
+        instead of a steady 5 ms, profiles/r04_async_checkpoint_ab.txt; with nothing waiting inside learn() that jitter is off the
+        training thread.)"""
         t0 = time.time()
         net = getattr(self.alg, "net", None)
-        if (net is None or not str(self.device).startswith("cuda") or os.environ.get("HGYM_ASYNC_SAVE", "0") != "1"
+        if (net is None or not str(self.device).startswith("cuda") or os.environ.get("HGYM_ASYNC_SAVE", "1") == "0"
                 or not hasattr(self.alg.actor_critic, "_net")):
             torch.save({"model_state_dict": self.alg.actor_critic.state_dict(),
                         "optimizer_state_dict": self.alg.optimizer.state_dict(),

@@ -50,7 +50,7 @@ class RolloutStorage:
         self.sigma = z(T, N, *actions_shape)
         self.num_transitions_per_env, self.num_envs = T, N
         self.saved_hidden_states_a = self.saved_hidden_states_c = None
-        self._stats = z(3, dtype=torch.float64)
+        self._stats = z(4 + 2 * ((N + 15) // 16), dtype=torch.float64)      # HGYM_GAE_STATS_DOUBLES(N): [sum, sum of squares, count | counter, partials]
         self.step = 0
         # optional bf16 shadows of the two observation buffers (enable_shadow): written by the policy launch that reads the slot,
         # read by the update instead of the fp32 rows
@@ -152,7 +152,7 @@ class RolloutStorage:
             L.check(L.lib.hgym_gae(T, N, L.fptr(self.rewards), L.fptr(self.values), L.u8ptr(self.dones), L.fptr(lv), gamma, lam,
                                    L.fptr(self.returns), L.fptr(self.advantages), L.f64ptr(self._stats), s), "hgym_gae")
         if stats_hook is not None:
-            stats_hook(self._stats)               # multi-GPU: all-reduce (sum, sumsq, count) for a global normalisation
+            stats_hook(self._stats[:3])           # multi-GPU: all-reduce (sum, sumsq, count) for a global normalisation
         L.check(L.lib.hgym_adv_normalize(T * N, L.fptr(self.advantages), L.f64ptr(self._stats), s), "hgym_adv_normalize")
 
     def get_statistics(self):

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define HGYM_VERSION 7      /* 2: HgymEnvOut carries the logging sink; hgym_rollout_*, hgym_ppo_grad_part, hgym_net_param_offset
+#define HGYM_VERSION 8      /* 2: HgymEnvOut carries the logging sink; hgym_rollout_*, hgym_ppo_grad_part, hgym_net_param_offset
                              * 3: the rollout scratch block grows with the env count (HGYM_ROLLOUT_SCRATCH_BYTES(num_envs))
                              * 4: bf16 observation shadow: HgymObsShadow argument of the policy launches, HgymBatch.obs_bf16 /
                              *    priv_bf16, hgym_net_shadow_ld
@@ -39,7 +39,9 @@ extern "C" {
                              *    zeroed by the NEXT hgym_rollout_step call -- see HgymEnvOut.obs_ahead; layouts and call sequence unchanged)
                              * 7: HgymComm.wait_ticks (bound of the direct exchange's waits) + hgym_comm_status; a communicator stays usable
                              *    after an expired wait (the done counter is per call); HgymEnvOut.t_time_outs, hgym_critic_values,
-                             *    hgym_gae_bootstrap and hgym_rollout_step with values = NULL (the critic run once after the rollout) */
+                             *    hgym_gae_bootstrap and hgym_rollout_step with values = NULL (the critic run once after the rollout)
+                             * 8: hgym_gae / hgym_gae_bootstrap: `stats` is HGYM_GAE_STATS_DOUBLES(n) doubles (per-workgroup partial sums + arrival
+                             *    counter behind the three results), the advantage statistics are summed in a fixed order */
 
 enum {
     HGYM_OK = 0,
@@ -357,7 +359,11 @@ int32_t hgym_randperm(int64_t n, uint64_t seed, uint64_t draw, int64_t* out, voi
 
 /* RolloutStorage.compute_returns (rollout_storage.py:122-136): GAE(lambda) as a wavefront suffix scan.
  * rewards/values/returns/advantages are (T,N) time-major fp32, dones (T,N) uint8, last_values (N,).
- * stats: 3 doubles on the device [sum adv, sum adv^2, count], accumulated (zeroed by this call). */
+ * stats: HGYM_GAE_STATS_DOUBLES(n) doubles on the device, ZERO-FILLED ONCE by the caller: [0] sum adv, [1] sum adv^2, [2] count are
+ * WRITTEN by the call; [3] is the arrival counter of the call's workgroups (left zero again), [4 ..) their partial sums, which the
+ * last workgroup to arrive adds up in workgroup order -- the statistics have the same bits in every run and on every rank (header v8;
+ * until v7 three doubles accumulated with fp64 atomics in arrival order).  One call at a time per stats buffer. */
+#define HGYM_GAE_STATS_DOUBLES(n) (4 + 2 * (((n) + 15) / 16))
 int32_t hgym_gae(int32_t T, int32_t n, const float* rewards, const float* values, const uint8_t* dones,
                  const float* last_values, float gamma, float lam, float* returns, float* advantages,
                  double* stats, void* stream);

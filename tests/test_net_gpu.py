@@ -143,7 +143,7 @@ def _run_iteration(G, precision):
         L.check(L.lib.hgym_store_step(N, L.fptr(rew), L.fptr(st["values"][t]), L.u8ptr(to), L.u8ptr(dones[t]), 0.994,
                                       L.fptr(st["rewards"][t]), L.u8ptr(dslot), s))
     last_v = net.forward(1, T(G["last_priv"]).to(dev).contiguous()).view(N).contiguous()
-    stats = torch.zeros(3, dtype=torch.float64, device=dev)
+    stats = L.gae_stats(N, dev)
     vals2d = st["values"].view(Tn, N)
     L.check(L.lib.hgym_gae(Tn, N, L.fptr(st["rewards"]), L.fptr(vals2d), L.u8ptr(dones), L.fptr(last_v), 0.994, 0.9,
                            L.fptr(st["returns"]), L.fptr(st["advantages"]), L.f64ptr(stats), s))

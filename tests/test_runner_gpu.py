@@ -64,6 +64,7 @@ def test_training_iterations_and_checkpoint(tmp_path):
     # the storage rows really are what the env produced: slot t+1 history = slot t shifted (non-reset envs)
     keep = ~st.dones[3].view(-1).bool()
     assert torch.equal(st.observations[4][keep][:, :14 * 47], st.observations[3][keep][:, 47:])
+    runner.wait_for_saves()            # learn() hands its checkpoints to the background writer (HGYM_ASYNC_SAVE, default on) and returns
     ckpts = [f for f in os.listdir(runner.log_dir) if f.startswith("model_")]
     assert "model_3.pt" in ckpts and "model_0.pt" in ckpts
     ck = torch.load(os.path.join(runner.log_dir, "model_3.pt"), map_location="cpu")
@@ -295,6 +296,7 @@ def test_other_frame_stacks_and_a_ragged_env_count_train(precision, tmp_path):
         net = runner.alg.net
         assert torch.isfinite(net.params).all() and int(net.opt_state[1]) == 3 * 2 * 2      # 2 epochs x 2 minibatches x 3 iterations
         assert torch.isfinite(st.returns).all() and torch.isfinite(st.advantages).all()
+        runner.wait_for_saves()
         path = os.path.join(runner.log_dir, "model_3.pt")
         assert os.path.exists(path)
         before = net.params.clone()
