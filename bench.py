@@ -214,7 +214,7 @@ def cpu_baseline(num_envs, T=60, full_minibatch=True, allow_reference=True):
 
 
 # ------------------------------------------------------------------------------------------------ GPU runs
-def collect_pmc_traffic():
+def collect_pmc_traffic(num_envs=4096):
     """roofline.traffic measured in this run: rocprofv3 --kernel-trace --pmc <counter> (one pass per counter, as
     MI355X_MICROARCH.md's HBM section prescribes) around tools/traffic_run.py -- a 256 MiB streaming kernel for the FETCH_SIZE
     calibration, then 4 iterations of this bench's headline workload -- converted by tools/pmc_to_json.py.  Returns the dict of
@@ -231,7 +231,8 @@ def collect_pmc_traffic():
         d = os.path.join(tmp, ctr)
         try:
             r = subprocess.run([rp, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "t", "--", sys.executable,
-                                os.path.join(ROOT, "tools", "traffic_run.py")], cwd=tmp, env=dict(os.environ, TMPDIR=tmp),
+                                os.path.join(ROOT, "tools", "traffic_run.py")], cwd=tmp,
+                               env=dict(os.environ, TMPDIR=tmp, HGYM_TRAFFIC_ENVS=str(num_envs)),
                                capture_output=True, text=True, timeout=300)
         except subprocess.TimeoutExpired:
             sys.stderr.write("--pmc: %s pass exceeded its 300 s limit; quoting the committed file instead\n" % ctr)
@@ -245,13 +246,13 @@ def collect_pmc_traffic():
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import pmc_to_json
     with contextlib.redirect_stdout(io.StringIO()):
-        pmc_to_json.main(csvs["FETCH_SIZE"], csvs["WRITE_SIZE"], out, float(1 << 28))
+        pmc_to_json.main(csvs["FETCH_SIZE"], csvs["WRITE_SIZE"], out, float(1 << 28), num_envs)
     res = json.load(open(out))
     shutil.rmtree(tmp, ignore_errors=True)
     return res
 
 
-def _roofline(L, runner, elapsed_per_iter_ms, precision, n_profiled_iters, traffic_ok=True, pmc=None):
+def _roofline(L, runner, elapsed_per_iter_ms, precision, n_profiled_iters, traffic_ok=True, pmc=None, pmc_only=False):
     mfma_peak = MFMA_BF16_PEAK_TFLOPS if precision == "bf16" else 157.3
     classes = [  # (class id, kernel, bound)
         (L.PROF_ROLLOUT, "rollout_step_kernel", "hbm"),      # policy act + env step + previous finaliser, one launch per vec-step
@@ -262,14 +263,15 @@ def _roofline(L, runner, elapsed_per_iter_ms, precision, n_profiled_iters, traff
         (L.PROF_APPLY, "sqnorm+adam_kernel", "hbm"), (L.PROF_GAE, "gae_kernel", "hbm")]
     traffic, source, counters = {}, None, {}
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")     # HBM bytes per launch from rocprofv3 --pmc passes
-    if os.path.exists(tpath) and traffic_ok:        # SQ / TCC counter passes are not repeated in the run: quoted from the committed file
+    committed = os.path.exists(tpath) and not pmc_only     # pmc_only: another size than the committed file's -- only this run's own passes count
+    if committed and traffic_ok:                    # SQ / TCC counter passes are not repeated in the run: quoted from the committed file
         counters = json.load(open(tpath)).get("counters", {})
     if pmc is not None and traffic_ok:
         traffic = pmc.get("kernels", {})
         counters = pmc.get("counters", counters)
         source = dict(kind="measured in this run", how="rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE, separate passes (bench.py --pmc)",
-                      fetch_calibration=pmc.get("fetch_calibration"))
-    elif os.path.exists(tpath) and traffic_ok:     # the counters were collected on the headline workload: they say nothing about another size
+                      fetch_calibration=pmc.get("fetch_calibration"), variants=pmc.get("variants"))
+    elif committed and traffic_ok:                 # the counters were collected on the headline workload: they say nothing about another size
         tj = json.load(open(tpath))
         traffic = tj.get("kernels", {})
         counters = tj.get("counters", {})
@@ -283,6 +285,8 @@ def _roofline(L, runner, elapsed_per_iter_ms, precision, n_profiled_iters, traff
         peak, unit, scale = (HBM_PEAK_GBS, "GB/s", 1e9) if bound == "hbm" else (mfma_peak, "TFLOP/s", 1e12)
         ach = work / (ms * 1e-3) / scale
         tr = traffic.get(name)
+        if tr is None and name == "mlp_fwd_kernel<32>":     # the policy class's launch is the 64-row form where the critic runs once behind the rollout
+            tr = traffic.get("mlp_fwd_kernel")
         ks.append(dict(kernel=name, bound=bound, launches_per_iter=n // n_profiled_iters, avg_launch_us=ms / n * 1e3, achieved=ach,
                        peak=peak, unit=unit, frac=ach / peak, share_of_iteration=ms / n_profiled_iters / elapsed_per_iter_ms,
                        traffic=tr, traffic_source=source if tr else None,
@@ -323,6 +327,12 @@ def run_config(args, task, num_envs, rank, world, local, dist, steps, warmup, lo
     # into the HIP graph the timed iterations replay (a capture inside the timed region would not be the steady state)
     with (contextlib.redirect_stdout(io.StringIO()) if log_root is not None else contextlib.nullcontext()):
         runner.learn(num_learning_iterations=max(warmup, 2), init_at_random_ep_len=True)
+        if hasattr(runner, "wait_for_saves"):
+            # the warm-up's checkpoints (model_0.pt, model_<W>.pt) belong to the warm-up: with the background writer (HGYM_ASYNC_SAVE, default
+            # on) the process's FIRST torch.save -- ~70 ms of cold pickling in the writer thread -- would otherwise run under the timed
+            # iterations and take the interpreter lock from the launching thread (18.6 instead of 6.4 ms/iteration over 6 iterations,
+            # profiles/r06_async_checkpoint_default.txt); a run of 150 iterations with three checkpoints inside shows no such cost
+            runner.wait_for_saves()
         barrier()
         t0 = time.perf_counter()
         # K learning iterations, enqueued back to back (the runner reads nothing back between iterations when it does not log)
@@ -376,9 +386,12 @@ def run_config(args, task, num_envs, rank, world, local, dist, steps, warmup, lo
         torch.cuda.synchronize()
         os.environ["HGYM_GRAPH"] = "1"
         if rank == 0:
+            pmc_by_envs = getattr(args, "pmc_by_envs", None) or {}
+            std = task == "humanoid_ppo" and args.precision == "bf16"
             res["kernels"] = _roofline(L, runner, res["ms_per_step"], args.precision, 2,
-                                       traffic_ok=(task == "humanoid_ppo" and num_envs == 4096 and args.precision == "bf16"),
-                                       pmc=getattr(args, "pmc_result", None))
+                                       traffic_ok=std and (num_envs == 4096 or num_envs in pmc_by_envs),
+                                       pmc=pmc_by_envs.get(num_envs) if num_envs != 4096 else getattr(args, "pmc_result", None),
+                                       pmc_only=num_envs != 4096)
             L.lib.hgym_prof_enable(0)
         if world > 1 and runner.alg.comm_timing:
             ev = runner.alg.comm_timing
@@ -498,6 +511,9 @@ def compact_summary(out, head, extra, world):
     has the headline's split, the big kernels and the baselines.  Everything in it repeats a field of the line."""
     summ = dict(value=head["value"], n_gpus=world, ms_per_step=head["ms_per_step"], collection_ms=head["collection_ms"],
                 ppo_update_ms=head["ppo_update_ms"])
+    if head.get("iteration_ms"):
+        summ["iteration_ms_median"] = round(head["iteration_ms"]["median"], 4)
+        summ["value_at_median"] = round(head["iteration_ms"]["value_at_median"])
     if head.get("kernels"):
         big = {}
         for k in head["kernels"]:
@@ -568,6 +584,13 @@ def main():
             and args.num_envs == 4096 and args.precision == "bf16"):
         os.environ["HGYM_BENCH_CHILD"] = "1"            # tools/traffic_run.py runs this file again: not recursively
         args.pmc_result = collect_pmc_traffic()
+        args.pmc_by_envs = {}
+        if "envs8192" in args.configs.split(","):
+            # BASELINE configs[3] (8192 envs, SURVEY 8d's HBM stress): its own counter passes -- the launches differ (no critic tiles, one
+            # critic pass behind the rollout, gae_kernel<BOOT>), so the 4096-env bytes say nothing about them
+            r8 = collect_pmc_traffic(8192)
+            if r8 is not None:
+                args.pmc_by_envs[8192] = r8
         del os.environ["HGYM_BENCH_CHILD"]
     head = run_config(args, args.task, args.num_envs, rank, world, local, dist, args.steps, args.warmup,
                       want_roofline=not args.no_roofline)
@@ -653,6 +676,8 @@ def main():
                        "minibatch": T * N // 4, "parallelism": "dp%d (env shards, RCCL grad all-reduce)" % world, "logging": False},
             "ppo_update_ms": head["ppo_update_ms"], "collection_ms": head["collection_ms"],
         }
+        if head.get("iteration_ms"):
+            out["iteration_ms"] = head["iteration_ms"]      # per-iteration HIP-event times of the timed call: median / mean / min / max
         if head.get("kernels"):
             out["roofline"] = _roofline_obj(head["kernels"])
         if head.get("comm"):

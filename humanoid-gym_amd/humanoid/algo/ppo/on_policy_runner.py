@@ -6,6 +6,7 @@ env writes its observations straight into the next rollout-storage slot.  Episod
 device and is read back once per iteration (the reference syncs the host every step, :146-152)."""
 import atexit
 import os
+import sys
 import queue
 import statistics
 import threading
@@ -49,6 +50,13 @@ class _CheckpointWriter:
         self.q.put(job)
 
     def _run(self):
+        # this thread's CPU tensor work stays on this thread: the default intra-op pool is one thread per host core (128+ on the GPU boxes), and a
+        # parallel region opened from here -- a 3.7 MB copy is enough -- wakes all of them next to the thread that launches the kernels
+        # (measured: sporadic 50-350 ms stalls of a checkpoint job and, now and then, of the training thread; profiles/r06_async_checkpoint_default.txt)
+        try:
+            torch.set_num_threads(1)
+        except Exception:      # noqa: BLE001
+            pass
         while True:
             job = self.q.get()
             try:
@@ -513,8 +521,12 @@ class OnPolicyRunner:
 
             def job():
                 try:
+                    tj = [time.perf_counter()]
                     done.synchronize()
-                    cut = lambda t, o, shp: t[o:o + int(torch.Size(shp).numel())].view(shp).clone()
+                    tj.append(time.perf_counter())
+                    # views INTO the snapshot, no copies: torch.save writes each flat buffer once (tensors that share a storage are
+                    # pickled as offset + shape into it), torch.load hands back the same named tensors
+                    cut = lambda t, o, shp: t[o:o + int(torch.Size(shp).numel())].view(shp)
                     lr, step = float(buf["opt"][0]), float(buf["opt"][1])
                     model = {k: cut(buf["params"], o, shp) for k, o, shp in layout}
                     state = {i: dict(step=torch.tensor(step), exp_avg=cut(buf["m"], o, shp), exp_avg_sq=cut(buf["v"], o, shp))
@@ -524,8 +536,14 @@ class OnPolicyRunner:
                           "optimizer_state_dict": dict(state=state, param_groups=[dict(group, params=list(range(len(state))))]),
                           "iter": it, "infos": infos}
                     tmp = path + ".tmp%d" % os.getpid()
+                    tj.append(time.perf_counter())
                     torch.save(ck, tmp)
+                    tj.append(time.perf_counter())
                     os.replace(tmp, path)
+                    tj.append(time.perf_counter())
+                    if os.environ.get("HGYM_SAVE_TRACE"):
+                        sys.stderr.write("writer job %s: event %.2f, cut %.2f, torch.save %.2f, rename %.2f ms\n" % (
+                            os.path.basename(path), *[(b - a) * 1e3 for a, b in zip(tj, tj[1:])]))
                 finally:
                     buf["busy"].set()
             _WRITER.submit(job)
