@@ -285,8 +285,15 @@ def _roofline(L, runner, elapsed_per_iter_ms, precision, n_profiled_iters, traff
         peak, unit, scale = (HBM_PEAK_GBS, "GB/s", 1e9) if bound == "hbm" else (mfma_peak, "TFLOP/s", 1e12)
         ach = work / (ms * 1e-3) / scale
         tr = traffic.get(name)
-        if tr is None and name == "mlp_fwd_kernel<32>":     # the policy class's launch is the 64-row form where the critic runs once behind the rollout
-            tr = traffic.get("mlp_fwd_kernel")
+        if name == "mlp_fwd_kernel<32>" and traffic.get("mlp_fwd_kernel") is not None:
+            # the policy class holds the 64-row form too where the critic runs once behind the rollout (8192 envs: four passes of it + the
+            # 32-row bootstrap launch): launch-weighted mean of the two instantiations' bytes, as avg_launch_us is the mean of their times
+            det = (pmc or {}).get("detail", {})
+            a, b = det.get("mlp_fwd_kernel<32>"), det.get("mlp_fwd_kernel")
+            if a and b:
+                tr = (a["hbm_bytes"] * a["launches"] + b["hbm_bytes"] * b["launches"]) / (a["launches"] + b["launches"])
+            elif tr is None:
+                tr = traffic.get("mlp_fwd_kernel")
         ks.append(dict(kernel=name, bound=bound, launches_per_iter=n // n_profiled_iters, avg_launch_us=ms / n * 1e3, achieved=ach,
                        peak=peak, unit=unit, frac=ach / peak, share_of_iteration=ms / n_profiled_iters / elapsed_per_iter_ms,
                        traffic=tr, traffic_source=source if tr else None,
