@@ -193,6 +193,7 @@ HG_HD uint32_t perm_mix(uint32_t x) {
     x ^= x >> 16;
     return x;
 }
+HG_HD uint64_t perm_key(uint64_t seed, uint64_t draw) { return (seed ^ (draw * 0x9e3779b97f4a7c15ull)) * 0xd1342543de82ef95ull + draw; }
 HG_HD int64_t perm_index(int64_t i, int64_t n, int half_bits, uint32_t k0, uint32_t k1) {
     const uint32_t mask = (1u << half_bits) - 1u;
     uint64_t x = (uint64_t)i;
@@ -214,18 +215,40 @@ __global__ __launch_bounds__(256) void randperm_kernel(int64_t n, int half_bits,
         out[i] = perm_index(i, n, half_bits, k0, k1);
 }
 
+// The same permutation with the draw number read from device memory (header v9): nothing in the launch's arguments changes from one
+// learning iteration to the next, so a captured update (HIP graph) replays it -- the caller advances *draw on the device.
+__global__ __launch_bounds__(256) void randperm_dev_kernel(int64_t n, int half_bits, uint64_t seed, const int64_t* __restrict__ draw_p,
+                                                           int64_t* __restrict__ out) {
+    const uint64_t draw = (uint64_t)draw_p[0];
+    const uint64_t key = perm_key(seed, draw);
+    const uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = perm_index(i, n, half_bits, k0, k1);
+}
+
 }  // namespace hgym
 
 using namespace hgym;
 
 extern "C" {
 
+int32_t hgym_randperm_dev(int64_t n, uint64_t seed, const int64_t* draw, int64_t* out, void* stream) {
+    HG_REQUIRE(n > 0 && n <= ((int64_t)1 << 40), HGYM_E_SHAPE, "n=%lld", (long long)n);
+    HG_REQUIRE(out && draw, HGYM_E_BADARG, "null pointer");
+    int half_bits = 1;
+    while (((int64_t)1 << (2 * half_bits)) < n) ++half_bits;
+    const int blocks = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+    hipLaunchKernelGGL(randperm_dev_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n, half_bits, seed, draw, out);
+    HG_CHECK_LAUNCH("randperm_dev_kernel");
+    return HGYM_OK;
+}
+
 int32_t hgym_randperm(int64_t n, uint64_t seed, uint64_t draw, int64_t* out, void* stream) {
     HG_REQUIRE(n > 0 && n <= ((int64_t)1 << 40), HGYM_E_SHAPE, "n=%lld", (long long)n);
     HG_REQUIRE(out, HGYM_E_BADARG, "null output");
     int half_bits = 1;
     while (((int64_t)1 << (2 * half_bits)) < n) ++half_bits;
-    const uint64_t key = (seed ^ (draw * 0x9e3779b97f4a7c15ull)) * 0xd1342543de82ef95ull + draw;
+    const uint64_t key = perm_key(seed, draw);
     const int blocks = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
     hipLaunchKernelGGL(randperm_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n, half_bits, (uint32_t)key, (uint32_t)(key >> 32), out);
     HG_CHECK_LAUNCH("randperm_kernel");

@@ -64,6 +64,7 @@ struct WsLayout {
 
 constexpr int MAX_LOSS_BLOCKS = 8192;   // 256 samples each: minibatches up to 2 M samples
 constexpr int SQN_BLOCKS = 256;         // workgroups of sqnorm_prologue_kernel
+constexpr int RSN_X = 96;               // workgroups per segment of reduce_slabs_kernel
 
 static bool fused_supported(const HgymNetConfig* c) {
     if (c->precision != HGYM_BF16 || c->actor_layers != 4 || c->critic_layers != 4) return false;
@@ -482,6 +483,14 @@ struct SegTable {
 // Also accumulates the squared norm of the finished gradient into opt[9] (zeroed by ppo_scalars_kernel earlier in the same
 // hgym_ppo_grad): with one rank that IS the norm clip_grad_norm_ needs, and hgym_ppo_apply skips its own pass over the
 // gradient.  (Segments whose gradient is already final -- splits == 0 -- are only read.)
+// The norm is the ONE sum of the training step left on fp64 atomics in arrival order (1 632 workgroups, one non-returning atomicAdd each): its
+// last bits can differ from run to run, which reaches the result only if the fp32-rounded clip coefficient flips (a 1e-16 relative change
+// against fp32's 6e-8 spacing: ~2e-9 per optimiser step; parameters of the captured-update test are bit-identical run to run).  Round 6 built
+// the order-fixed forms -- per-workgroup partials + last arriver with a release fence per workgroup: 65 us instead of 11 (every fence writes the
+// XCD's L2 back while the others fill it with gradient lines); write-through partials + acknowledged store + returning counter atomic, one and two
+// levels: 26-29 us (three to six dependent memory-side round trips at the tail of an 11 us kernel) -- and kept the atomics: 0.12-0.4 ms per
+// iteration for a bit that does not reach the parameters (profiles/r06_update_graph_and_norm_order.txt).  With several ranks the norm is
+// sqnorm_prologue_kernel's, which IS order-fixed (256 workgroups, one launch).
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(const SegTable tab, int64_t P, const float* __restrict__ slabs,
                                                            float* __restrict__ grads, double* __restrict__ opt) {
     __shared__ double red[4];
@@ -953,7 +962,7 @@ struct NetRunner {
             }
         if (tab.n == 0) return HGYM_OK;
         prof_begin(HGYM_PROF_REDUCE, s);
-        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(96, tab.n), dim3(256), 0, s, tab, w.Ps, at<float>(w.slabs), net.grads, net.opt_state);
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(RSN_X, tab.n), dim3(256), 0, s, tab, w.Ps, at<float>(w.slabs), net.grads, net.opt_state);
         prof_end(HGYM_PROF_REDUCE, s, (double)elems * 4.0 * (w.dw_splits + 1));
         HG_CHECK_LAUNCH("reduce_slabs_kernel");
         return HGYM_OK;
@@ -1284,7 +1293,7 @@ struct NetRunner {
             if (rc) return rc;
         }
         const SegTable tab = segments(true);
-        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(96, tab.n), dim3(256), 0, s, tab, w.Ps, at<float>(w.slabs), net.grads, net.opt_state);
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(RSN_X, tab.n), dim3(256), 0, s, tab, w.Ps, at<float>(w.slabs), net.grads, net.opt_state);
         HG_CHECK_LAUNCH("reduce_slabs_kernel");
         return HGYM_OK;
     }

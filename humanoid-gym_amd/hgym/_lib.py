@@ -171,6 +171,7 @@ SYMBOLS = {
     "hgym_measure_heights": (C.c_int32, [_P(EnvConfig), _P(EnvState), C.c_void_p]),
     "hgym_store_step": (C.c_int32, [C.c_int32, c_float_p, c_float_p, c_u8_p, c_u8_p, C.c_float, c_float_p, c_u8_p, C.c_void_p]),
     "hgym_randperm": (C.c_int32, [C.c_int64, C.c_uint64, C.c_uint64, c_i64_p, C.c_void_p]),
+    "hgym_randperm_dev": (C.c_int32, [C.c_int64, C.c_uint64, c_i64_p, c_i64_p, C.c_void_p]),
     "hgym_gae": (C.c_int32, [C.c_int32, C.c_int32, c_float_p, c_float_p, c_u8_p, c_float_p, C.c_float, C.c_float,
                              c_float_p, c_float_p, c_f64_p, C.c_void_p]),
     "hgym_adv_normalize": (C.c_int32, [C.c_int64, c_float_p, c_f64_p, C.c_void_p]),

@@ -105,6 +105,8 @@ class OnPolicyRunner:
         self.last_collection_time = self.last_learn_time = 0.0
         self._graph = None           # captured rollout (HIP graph) and the tensors it owns
         self._graph_warm = False
+        self._update_graph = None    # captured compute_returns() + update() (second HIP graph)
+        self._update_warm = False
         _, _ = self.env.reset()
 
     # ------------------------------------------------------------------
@@ -241,6 +243,13 @@ class OnPolicyRunner:
         gkey = (id(env), id(alg.storage), log_on, log_sink, sink_ok, defer_ok, fuse_mode, getattr(alg, "gamma", None),
                 env.native_config_digest() if hasattr(env, "native_config_digest") else None,
                 getattr(env, "_rows_ahead", None), getattr(env, "_l0_ahead", None), getattr(alg.storage, "_obs_bf16", None) is not None)
+        # the update as a second captured graph (HGYM_GRAPH_UPDATE=0: eager, as until round 5): only where nothing on the host reads the
+        # update's results inside the iteration (the asynchronous loops) and every launch argument is iteration-invariant
+        graph_update = bool(use_graph and (async_iters or async_log) and hasattr(alg, "update_capturable") and alg.update_capturable()
+                            and os.environ.get("HGYM_GRAPH_UPDATE", "1") != "0")
+        ukey = (gkey, alg.update_graph_key(), deferred) if graph_update else None
+        if not graph_update:
+            self._update_graph = None
         tot_iter = self.current_learning_iteration + num_learning_iterations
         try:
             for it in range(self.current_learning_iteration, tot_iter):
@@ -284,8 +293,36 @@ class OnPolicyRunner:
                     stop = time.time()
                     collection_time = stop - start
                     start = stop
-                    alg.compute_returns(critic_obs)
-                mean_value_loss, mean_surrogate_loss = alg.update(sync=False) if (async_iters or async_log) else alg.update()
+                    ug = self._update_graph
+                    replayed_update = False
+                    if graph_update and ug is not None and ug["key"] == ukey and self._graph is not None and self._graph["key"] == gkey:
+                        # steady state: the whole iteration is two graph launches (rollout, update) with the phase event between them
+                        ug["graph"].replay()
+                        alg.after_update_replay()
+                        replayed_update = True
+                    elif not (graph_update and self._update_warm and self._graph is not None and self._graph["key"] == gkey):
+                        alg.compute_returns(critic_obs)
+                if replayed_update:
+                    mean_value_loss = mean_surrogate_loss = None
+                elif graph_update and self._update_warm and self._graph is not None and self._graph["key"] == gkey:
+                    # the rollout has just been captured (or is replayed) and the update has run eagerly at least once: capture
+                    # compute_returns() + update(sync=False) -- ~45 launches per iteration that otherwise come from Python + ctypes on every
+                    # rank -- into a second graph.  Nothing in their arguments changes between iterations: the permutation's draw number,
+                    # Adam's step, the learning rate and the exchange's call number are read on the device (PPO.update_capturable)
+                    ugraph = torch.cuda.CUDAGraph()
+                    torch.cuda.synchronize()
+                    # (inside inference mode like the rollout's capture: capture_begin updates the generator's graph-state tensors in
+                    # place, and the first capture created them as inference tensors)
+                    with torch.inference_mode():
+                        with torch.cuda.graph(ugraph, capture_error_mode="thread_local"):
+                            alg.compute_returns(critic_obs)
+                            alg.update(sync=False)
+                    self._update_graph = dict(graph=ugraph, key=ukey)
+                    ugraph.replay()                 # capture does not execute (update()'s host book-keeping has run once, for this replay)
+                    mean_value_loss = mean_surrogate_loss = None
+                else:
+                    mean_value_loss, mean_surrogate_loss = alg.update(sync=False) if (async_iters or async_log) else alg.update()
+                    self._update_warm = True
                 if zero_copy:                       # storage.clear() rotated slot T into slot 0
                     obs, critic_obs = obs_all[0], priv_all[0]
                 if it % self.save_interval == 0:
@@ -469,6 +506,7 @@ class OnPolicyRunner:
     def invalidate_graph(self):
         """Drop the captured rollout; the next learn() iteration runs eagerly and the one after re-captures."""
         self._graph, self._graph_warm = None, False
+        self._update_graph, self._update_warm = None, False
 
     def save(self, path, infos=None, wait=True):
         """on_policy_runner.py:274-281 (same dict, same keys).  wait=True (the reference's semantics, and what a direct caller gets): the

@@ -148,6 +148,7 @@ class PPO:
         self._sample_step = torch.zeros(1, dtype=torch.int64, device=self.device)
         self._perm_seed = (torch.initial_seed() * 0x9E3779B97F4A7C15 + 0xABCD + 104729 * self._rank) & 0xFFFFFFFFFFFFFFFF
         self._perm_draws = 0
+        self._perm_draws_dev = torch.zeros(1, dtype=torch.int64, device=self.device)      # the same number where a captured update reads it
         ac._sample_step = self._sample_step
         # exploration-noise key: from the run's seed (as the permutation key above) and the rank
         ac._sample_seed = (torch.initial_seed() * 0xD1342543DE82EF95 + 0x5EED + 7919 * self._rank) & 0xFFFFFFFFFFFFFFFF
@@ -161,6 +162,8 @@ class PPO:
         LeggedRobot.seek, which the runner calls next to this.)"""
         self._sample_step.fill_(int(iteration) * int(steps_per_iteration))
         self._perm_draws = int(iteration)
+        with torch.inference_mode():
+            self._perm_draws_dev.fill_(int(iteration))
 
     def check_comm(self, words=None):
         """The direct exchange's status word, read where the host synchronises anyway (the end of a synchronous update, the end of
@@ -291,6 +294,37 @@ class PPO:
         self.storage.compute_returns(last_values, self.gamma, self.lam, stats_hook=dist_utils.allreduce_adv_stats)
 
     # ------------------------------------------------------------------ update
+    def update_capturable(self):
+        """True when compute_returns() + update(sync=False) enqueue the same launches with the same arguments in every iteration, i.e. may
+        be captured into a HIP graph and replayed (OnPolicyRunner): the device permutation (its draw number is read on the device), no
+        timing probes inside the update, and either one rank or the direct gradient exchange with its call number on the device -- a
+        torch.distributed collective (RCCL / gloo) stays eager."""
+        if self.permutation != "device" or self.comm_timing is not None or self._check_shadow:
+            return False
+        if not dist_utils.active():
+            return True
+        return bool(self._comm is not None and self._comm_p2p and not self.comm_flip and getattr(self._comm, "capturable", False))
+
+    def update_graph_key(self):
+        """Everything host-side that compute_returns() / update() bake into their launches: a change re-captures."""
+        import ctypes as C
+        return (bytes(C.string_at(C.addressof(self._ppo_cfg), C.sizeof(self._ppo_cfg))), self.num_learning_epochs, self.num_mini_batches,
+                float(self.gamma), float(self.lam), self.permutation, self._perm_seed, id(self.storage), id(self.net),
+                bool(dist_utils.active()), bool(self._comm_p2p))
+
+    def after_update_replay(self):
+        """Host-side book-keeping of one replayed compute_returns() + update(sync=False): what the Python of those two calls changes on the
+        host besides enqueueing work (kept next to update() so that the two stay in step)."""
+        st = self.storage
+        if self.permutation == "device":
+            self._perm_draws += 1
+        self._deferred_ready = False
+        st.step = 0
+        st.shadow_valid = [False] * st.num_transitions_per_env
+        if dist_utils.active() and self._comm is not None and self._comm_p2p:
+            self._comm_direct_used = True
+            self._comm.seq += self.num_learning_epochs * self.num_mini_batches
+
     def update(self, sync=True):
         """ppo.py:119-184.  Returns (mean_value_loss, mean_surrogate_loss) as floats -- the one host read-back of the
         update.  sync=False (native extension, used by the runner when nothing is logged): no read-back, returns
@@ -301,8 +335,16 @@ class PPO:
         mb = batch // self.num_mini_batches
         # one permutation for every epoch (rollout_storage.py:149,165-170)
         if self.permutation == "device":
-            self._perm_draws += 1
-            perm = st.permutation(self.num_mini_batches * mb, self._perm_seed, self._perm_draws)
+            # the draw number lives on the device as well: the launch reads it there, so a captured update (OnPolicyRunner's second HIP
+            # graph) draws a NEW permutation at every replay.  Eager calls re-seat the device copy from the host count first (the host
+            # count is what seek() / a checkpoint resume set); under capture nothing is re-seated -- replays continue the device count and
+            # after_update_replay() advances the host's.
+            with torch.inference_mode():        # (the counter may have been created under the runner's inference mode)
+                if not torch.cuda.is_current_stream_capturing():
+                    self._perm_draws_dev.fill_(self._perm_draws)
+                self._perm_draws += 1
+                self._perm_draws_dev.add_(1)
+            perm = st.permutation(self.num_mini_batches * mb, self._perm_seed, self._perm_draws_dev)
         else:
             perm = torch.randperm(self.num_mini_batches * mb, device=self.device)
         fl = lambda t: t.flatten(0, 1)
@@ -316,7 +358,7 @@ class PPO:
         sh = dict(obs_bf16=sh[0], priv_bf16=sh[1]) if sh is not None else {}
         net.opt_state[2:8] = 0.0               # the per-update sums [2..5], [7] (and the informational last norm [6]): one fill
         if self._ppo_cfg.aux_coef > 0.0:
-            net.opt_state[10] = 0.0
+            net.opt_state[10:11] = 0.0     # (a slice: a fill kernel -- an indexed scalar store is a host-to-device copy, which a stream capture refuses)
         for _ in range(self.num_learning_epochs):
             for i in range(self.num_mini_batches):
                 idx = perm[i * mb:(i + 1) * mb]

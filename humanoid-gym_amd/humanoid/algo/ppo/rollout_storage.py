@@ -164,12 +164,17 @@ class RolloutStorage:
 
     def permutation(self, n, seed, draw):
         """The minibatch permutation (reference :149, torch.randperm) as one hgym_randperm launch: a bijection of [0, n) keyed
-        by (seed, draw), written into a buffer this object keeps."""
+        by (seed, draw), written into a buffer this object keeps.  draw: an int, or a one-element int64 DEVICE tensor holding it
+        (hgym_randperm_dev: the launch's arguments are then the same in every iteration -- what a captured update replays)."""
         from hgym import _lib as L
         if getattr(self, "_perm", None) is None or self._perm.numel() != n:
             self._perm = torch.empty(n, dtype=torch.int64, device=self.device)
-        L.check(L.lib.hgym_randperm(n, int(seed) & 0xFFFFFFFFFFFFFFFF, int(draw), L.i64ptr(self._perm),
-                                    C.c_void_p(torch.cuda.current_stream().cuda_stream)), "hgym_randperm")
+        s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        if torch.is_tensor(draw):
+            assert draw.dtype == torch.int64 and draw.is_cuda and draw.numel() == 1
+            L.check(L.lib.hgym_randperm_dev(n, int(seed) & 0xFFFFFFFFFFFFFFFF, L.i64ptr(draw), L.i64ptr(self._perm), s), "hgym_randperm_dev")
+        else:
+            L.check(L.lib.hgym_randperm(n, int(seed) & 0xFFFFFFFFFFFFFFFF, int(draw), L.i64ptr(self._perm), s), "hgym_randperm")
         return self._perm
 
     def mini_batch_generator(self, num_mini_batches, num_epochs=8):

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define HGYM_VERSION 8      /* 2: HgymEnvOut carries the logging sink; hgym_rollout_*, hgym_ppo_grad_part, hgym_net_param_offset
+#define HGYM_VERSION 9      /* 2: HgymEnvOut carries the logging sink; hgym_rollout_*, hgym_ppo_grad_part, hgym_net_param_offset
                              * 3: the rollout scratch block grows with the env count (HGYM_ROLLOUT_SCRATCH_BYTES(num_envs))
                              * 4: bf16 observation shadow: HgymObsShadow argument of the policy launches, HgymBatch.obs_bf16 /
                              *    priv_bf16, hgym_net_shadow_ld
@@ -41,7 +41,9 @@ extern "C" {
                              *    after an expired wait (the done counter is per call); HgymEnvOut.t_time_outs, hgym_critic_values,
                              *    hgym_gae_bootstrap and hgym_rollout_step with values = NULL (the critic run once after the rollout)
                              * 8: hgym_gae / hgym_gae_bootstrap: `stats` is HGYM_GAE_STATS_DOUBLES(n) doubles (per-workgroup partial sums + arrival
-                             *    counter behind the three results), the advantage statistics are summed in a fixed order */
+                             *    counter behind the three results), the advantage statistics are summed in a fixed order
+                             * 9: hgym_randperm_dev (draw number on the device); hgym_comm_allreduce(seq = 0): the call number kept on the device
+                             *    (status[2]); hgym_comm_sum64 -- what a captured update needs: no launch argument changes between iterations */
 
 enum {
     HGYM_OK = 0,
@@ -356,6 +358,10 @@ int32_t hgym_store_step(int32_t n, const float* rew, const float* values, const 
  * [0, n), is a bijection of [0, n) keyed by (seed, draw) -- a 6-round Feistel network, cycle-walked; one launch, no scratch
  * (torch.randperm on the device: a sort, 125 us per iteration at the XBot-L batch). */
 int32_t hgym_randperm(int64_t n, uint64_t seed, uint64_t draw, int64_t* out, void* stream);
+/* header v9: the same permutation with the draw number read from DEVICE memory (*draw, one int64 the caller advances with a device
+ * operation): the launch's arguments do not change from one learning iteration to the next, so an update captured into a HIP graph
+ * (OnPolicyRunner: the whole iteration is two graph replays) draws a new permutation at every replay. */
+int32_t hgym_randperm_dev(int64_t n, uint64_t seed, const int64_t* draw, int64_t* out, void* stream);
 
 /* RolloutStorage.compute_returns (rollout_storage.py:122-136): GAE(lambda) as a wavefront suffix scan.
  * rewards/values/returns/advantages are (T,N) time-major fp32, dones (T,N) uint8, last_values (N,).

@@ -207,6 +207,39 @@ def test_graph_replay_equals_eager_rollout(monkeypatch):
         assert torch.equal(a, b)
 
 
+def test_captured_update_equals_eager_update(monkeypatch):
+    """Header v9 / round 6: compute_returns() + update() replayed from a second HIP graph (the whole iteration = two graph launches) against the
+    same five iterations with the update's ~45 launches issued from Python (HGYM_GRAPH_UPDATE=0): parameters, Adam moments, optimiser
+    scalars (learning-rate decisions, step count, loss sums), the last permutation and the storage bit-identical; the permutation's draw
+    number on the device equals the host's count, and a sixth and seventh iteration through a SECOND learn() call (same graphs, still
+    valid) keep it so."""
+    from humanoid.algo import PPO
+    PPO.precision = "bf16"
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("HGYM_GRAPH_UPDATE", mode)
+        torch.manual_seed(4321)
+        np.random.seed(4321)
+        r = _runner(256, 78)
+        r.env.episode_length_buf = torch.arange(256, device="cuda") * 7
+        r.learn(num_learning_iterations=5, init_at_random_ep_len=False)
+        r.learn(num_learning_iterations=2, init_at_random_ep_len=False)
+        torch.cuda.synchronize()
+        alg, st = r.alg, r.alg.storage
+        assert (r._update_graph is not None) == (mode == "1") and r._graph is not None
+        assert alg._perm_draws == 7 and int(alg._perm_draws_dev) == 7
+        assert int(alg.net.opt_state[1]) == 7 * alg.num_learning_epochs * alg.num_mini_batches
+        opt = alg.net.opt_state.clone()
+        opt[9] = 0.0        # internal: the squared gradient norm, summed with fp64 atomics in arrival order (reduce_slabs_kernel's comment) -- its
+        #                     last bits differ from run to run under EITHER launch mechanism; the norm it rounds to ([6]) is compared
+        outs[mode] = (alg.net.params.clone(), alg.net.adam_m.clone(), alg.net.adam_v.clone(), opt, st._perm.clone(),
+                      st._obs_all.clone(), st.returns.clone(), st.advantages.clone(), alg._sample_step.clone())
+        del r
+    names = ("params", "adam_m", "adam_v", "opt_state", "perm", "obs_all", "returns", "advantages", "sample_step")
+    for nm, a, b in zip(names, outs["1"], outs["0"]):
+        assert torch.equal(a, b), (nm, (a != b).nonzero()[:8].tolist(), a.flatten()[:16].tolist(), b.flatten()[:16].tolist())
+
+
 @pytest.mark.parametrize("graph", ["0", "1"])
 def test_fused_rollout_step_equals_act_then_step(monkeypatch, graph):
     """hgym_rollout_step (ONE launch per vec-step: actor tile + env step of the same 32 envs, critic tile, the previous step's

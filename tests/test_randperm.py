@@ -46,6 +46,11 @@ def test_kernel_matches_oracle(n):
     for seed, draw in [(5, 1), (0xFFFF_FFFF_FFFF_FFFF, 77), (123456789, 0)]:
         L.check(L.lib.hgym_randperm(n, seed, draw, L.i64ptr(out), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
         assert np.array_equal(out.cpu().numpy(), feistel_permutation(n, seed, draw)), (n, seed, draw)
+        # header v9: the draw number read on the device (what a captured update replays) -- the same permutation
+        out2 = torch.empty_like(out)
+        ctr = torch.tensor([draw], dtype=torch.int64, device="cuda")
+        L.check(L.lib.hgym_randperm_dev(n, seed, L.i64ptr(ctr), L.i64ptr(out2), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        assert torch.equal(out, out2)
 
 
 @pytest.mark.gpu
