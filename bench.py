@@ -362,6 +362,9 @@ def run_config(args, task, num_envs, rank, world, local, dist, steps, warmup, lo
     res = dict(value=T * N * world * steps / elapsed, ms_per_step=elapsed / steps * 1e3, ppo_update_ms=learn * 1e3,
                collection_ms=coll * 1e3, T=T, N=N, obs=env.num_obs, priv=env.num_privileged_obs)
     it_ms = sorted(getattr(runner, "last_iteration_ms", None) or [])
+    it_ms_timed = list(it_ms)                   # (the roofline leg below calls learn() again: keep the timed call's own list)
+    update_graph = getattr(runner, "_update_graph", None) is not None     # compute_returns() + update() replayed from the second HIP graph
+    res["update_graph"] = update_graph
     if len(it_ms) == steps and log_root is None:
         # per-iteration device times of the timed call (HIP events on the launch stream, read after the region): the contract's `value` is
         # K steps over the region's wall time (a mean); SURVEY 8(d) asks for the median of >= 20 iterations -- both are in the line
@@ -444,8 +447,8 @@ def run_config(args, task, num_envs, rank, world, local, dist, steps, warmup, lo
             # every rank's own iteration times of the timed call (HIP events on its stream): a rank that is slow on the host or on the device
             # shows up here, next to the exchange's exposed wait (which contains the wait for the slowest rank)
             try:
-                it_ms = sorted(getattr(runner, "last_iteration_ms", None) or [0.0])
-                mine = dict(rank=rank, min=it_ms[0], median=it_ms[len(it_ms) // 2], max=it_ms[-1], n=len(it_ms))
+                it_ms = it_ms_timed or [0.0]
+                mine = dict(rank=rank, min=it_ms[0], median=it_ms[len(it_ms) // 2], max=it_ms[-1], n=len(it_ms), update_graph=update_graph)
                 allr = [None] * world
                 dist.all_gather_object(allr, mine)
                 comm["per_rank_iteration_ms"] = allr
@@ -683,6 +686,8 @@ def main():
                        "minibatch": T * N // 4, "parallelism": "dp%d (env shards, RCCL grad all-reduce)" % world, "logging": False},
             "ppo_update_ms": head["ppo_update_ms"], "collection_ms": head["collection_ms"],
         }
+        out["launches"] = ("two HIP-graph replays per iteration (rollout: 60 launches; compute_returns + update: ~45 launches)" if head.get("update_graph")
+                           else "rollout replayed from a HIP graph, update issued from Python (HGYM_GRAPH_UPDATE=0 or not capturable)")
         if head.get("iteration_ms"):
             out["iteration_ms"] = head["iteration_ms"]      # per-iteration HIP-event times of the timed call: median / mean / min / max
         if head.get("kernels"):

@@ -78,10 +78,21 @@ __device__ __forceinline__ bool wait_slots(const uint32_t* slots, int world, uin
     return __all(ok);
 }
 
-__global__ __launch_bounds__(COMM_THREADS) void p2p_allreduce_kernel(const CommArgs c) {
+// seq == 0 in the arguments (header v9): the call number lives on the device -- status[2] holds the number of the last call, every workgroup
+// reads it on entry, the call's last workgroup (which all of them have counted on by then) writes it back.  The launch's arguments are then
+// the same for every call: what a captured HIP graph replays.
+__device__ __forceinline__ uint32_t call_number(uint32_t seq_arg, const long long* last) {
+    if (seq_arg != 0u) return seq_arg;
+    uint32_t s = (uint32_t)__hip_atomic_load(last, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    return s ? s : 1u;      // 1 .. 2^32 - 1, never 0 (a zero-filled flag block means "call 0 has arrived")
+}
+
+__global__ __launch_bounds__(COMM_THREADS) void p2p_allreduce_kernel(CommArgs c) {
     const int t = threadIdx.x, lane = t & 63;
     __shared__ int s_ok;
     uint32_t* myf = c.flags[c.rank];
+    const bool dev_seq = c.seq == 0u;
+    c.seq = call_number(c.seq, c.status + 2);
     if (blockIdx.x == 0 && t == 0) c.status[8] = (long long)__builtin_amdgcn_s_memrealtime();
     // ---- A: my gradient is complete (written by the previous kernel on this stream); tell everyone, wait for everyone
     if (blockIdx.x == 0 && t < c.world) st_sys(c.flags[t] + c.rank, c.seq);
@@ -130,7 +141,10 @@ __global__ __launch_bounds__(COMM_THREADS) void p2p_allreduce_kernel(const CommA
     if (t == 0) {
         const uint32_t done = __hip_atomic_fetch_add(myf + 16, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
         s_last = (done == gridDim.x - 1u) ? 1 : 0;
-        if (s_last) __hip_atomic_store(myf + 16, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // every workgroup of this call has counted
+        if (s_last) {
+            __hip_atomic_store(myf + 16, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // every workgroup of this call has counted
+            if (dev_seq) __hip_atomic_store(c.status + 2, (long long)c.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ... and has read the call number
+        }
     }
     __syncthreads();
     if (s_last) {
@@ -160,6 +174,73 @@ __global__ __launch_bounds__(COMM_THREADS) void p2p_allreduce_kernel(const CommA
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    }
+}
+
+// hgym_comm_sum64 (header v9): the per-iteration all-reduce of the advantage statistics -- n <= 3 doubles -- over the same peer mappings, so that
+// a data-parallel update has NO torch.distributed call left in it and can be captured.  One wavefront.  Rank r stores {v0, v1, v2} and then the
+// call number as a tag into slot [parity][r] of EVERY rank's aux block; lane q waits for the tag of slot [parity][q] in its own block, then the
+// wave adds the slots in rank order q = 0 .. W - 1 (fp64, the same association on every rank: bit-identical results).  Two slot sets, used
+// alternately: a rank can be one call ahead of a peer that has not read the previous call's slots yet, never two (it needs that peer's
+// arrival of the call in between).  The call number is status[3]; waits are bounded like the gradient exchange's (status[0] = 1 on expiry).
+struct Sum64Args {
+    double* aux[HGYM_COMM_MAX_RANKS];
+    long long* status;
+    double* vals;
+    int world, rank, n;
+    long long wait_ticks;
+};
+
+__global__ __launch_bounds__(64) void p2p_sum64_kernel(const Sum64Args c) {
+    const int lane = threadIdx.x;
+    const uint32_t seq = call_number(0u, c.status + 3);
+    const int par = (int)(seq & 1u);
+    __shared__ double s_v[HGYM_COMM_MAX_RANKS][4];
+    double mine[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        if (i < c.n) mine[i] = c.vals[i];
+    if (lane < c.world) {
+        double* slot = c.aux[lane] + ((int64_t)par * HGYM_COMM_MAX_RANKS + c.rank) * 4;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) __hip_atomic_store(slot + 1 + i, mine[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    if (lane < c.world) {
+        unsigned long long* tag = reinterpret_cast<unsigned long long*>(c.aux[lane] + ((int64_t)par * HGYM_COMM_MAX_RANKS + c.rank) * 4);
+        __hip_atomic_store(tag, (unsigned long long)seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    bool ok = true;
+    if (lane < c.world) {
+        const unsigned long long* tag = reinterpret_cast<const unsigned long long*>(c.aux[c.rank] + ((int64_t)par * HGYM_COMM_MAX_RANKS + lane) * 4);
+        uint32_t spins = 0;
+        const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
+        while ((uint32_t)__hip_atomic_load(tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
+            if (++spins < 1024u) __builtin_amdgcn_s_sleep(8);
+            else __builtin_amdgcn_s_sleep(127);
+            if ((spins & 255u) == 0u && (long long)__builtin_amdgcn_s_memrealtime() - t0 > c.wait_ticks) { ok = false; break; }
+        }
+    }
+    ok = __all(ok);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    if (ok && lane < c.world) {
+        const double* slot = c.aux[c.rank] + ((int64_t)par * HGYM_COMM_MAX_RANKS + lane) * 4;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) s_v[lane][i] = __hip_atomic_load(slot + 1 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __syncthreads();
+    if (lane == 0) {
+        if (ok) {
+            for (int i = 0; i < c.n; ++i) {
+                double t = s_v[0][i];
+                for (int q = 1; q < c.world; ++q) t += s_v[q][i];
+                c.vals[i] = t;
+            }
+        } else {
+            c.status[0] = 1;
+            c.status[1] = (long long)seq;
+        }
+        __hip_atomic_store(c.status + 3, (long long)seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -224,8 +305,7 @@ int32_t hgym_comm_ipc_close(void* dev_ptr) {
 
 int32_t hgym_comm_allreduce(const HgymComm* c, uint32_t seq, void* stream) {
     HG_REQUIRE(c && c->world >= 1 && c->world <= HGYM_COMM_MAX_RANKS && c->rank >= 0 && c->rank < c->world, HGYM_E_BADARG, "bad communicator");
-    HG_REQUIRE(c->count > 0 && c->count % 4 == 0 && c->status && seq != 0, HGYM_E_BADARG, "count=%lld (a positive multiple of 4), seq=%u (>= 1)",
-               (long long)c->count, seq);
+    HG_REQUIRE(c->count > 0 && c->count % 4 == 0 && c->status, HGYM_E_BADARG, "count=%lld (a positive multiple of 4)", (long long)c->count);
     CommArgs a;
     memset(&a, 0, sizeof(a));
     for (int q = 0; q < c->world; ++q) {
@@ -244,6 +324,26 @@ int32_t hgym_comm_allreduce(const HgymComm* c, uint32_t seq, void* stream) {
     hipLaunchKernelGGL(p2p_allreduce_kernel, dim3(COMM_BLOCKS), dim3(COMM_THREADS), 0, (hipStream_t)stream, a);
     prof_end(HGYM_PROF_COMM, (hipStream_t)stream, (double)c->count * 4.0 * 2.0 * (c->world - 1) / c->world);
     HG_CHECK_LAUNCH("p2p_allreduce_kernel");
+    return HGYM_OK;
+}
+
+int32_t hgym_comm_sum64(const HgymComm* c, double* vals, int32_t n, void* stream) {
+    HG_REQUIRE(c && c->world >= 1 && c->world <= HGYM_COMM_MAX_RANKS && c->rank >= 0 && c->rank < c->world, HGYM_E_BADARG, "bad communicator");
+    HG_REQUIRE(vals && n >= 1 && n <= 3 && c->status, HGYM_E_BADARG, "n=%d (1 .. 3)", n);
+    Sum64Args a;
+    memset(&a, 0, sizeof(a));
+    for (int q = 0; q < c->world; ++q) {
+        HG_REQUIRE(c->aux[q] && ((uintptr_t)c->aux[q] & 7) == 0, HGYM_E_BADARG, "rank %d: null / unaligned aux block", q);
+        a.aux[q] = c->aux[q];
+    }
+    a.status = (long long*)c->status;
+    a.vals = vals;
+    a.world = c->world;
+    a.rank = c->rank;
+    a.n = n;
+    a.wait_ticks = c->wait_ticks > 0 ? (long long)c->wait_ticks : COMM_WAIT_TICKS;
+    hipLaunchKernelGGL(p2p_sum64_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a);
+    HG_CHECK_LAUNCH("p2p_sum64_kernel");
     return HGYM_OK;
 }
 

@@ -124,7 +124,7 @@ class Net(C.Structure):
 
 class Comm(C.Structure):
     _fields_ = [("world", C.c_int32), ("rank", C.c_int32), ("data", c_float_p * 8), ("flags", C.POINTER(C.c_uint32) * 8),
-                ("count", C.c_int64), ("status", c_i64_p), ("wait_ticks", C.c_int64)]
+                ("count", C.c_int64), ("status", c_i64_p), ("wait_ticks", C.c_int64), ("aux", c_f64_p * 8)]
 
 
 class Batch(C.Structure):
@@ -153,6 +153,7 @@ SYMBOLS = {
     "hgym_comm_ipc_close": (C.c_int32, [C.c_void_p]),
     "hgym_comm_allreduce": (C.c_int32, [_P(Comm), C.c_uint32, C.c_void_p]),
     "hgym_comm_status": (C.c_int32, [_P(Comm), c_i64_p, C.c_void_p]),
+    "hgym_comm_sum64": (C.c_int32, [_P(Comm), c_f64_p, C.c_int32, C.c_void_p]),
     "hgym_version": (C.c_int32, []),
     "hgym_last_error": (C.c_char_p, []),
     "hgym_device_cus": (C.c_int32, []),

@@ -267,7 +267,12 @@ class P2PComm:
         self.device = torch.device(device)
         self._flag_off = (self.count * 4 + 255) // 256 * 256
         self._stat_off = self._flag_off + 256
-        self.nbytes = self._stat_off + 256
+        self._aux_off = self._stat_off + 256            # hgym_comm_sum64's slots: HGYM_COMM_AUX_DOUBLES (2 x 8 x 4) doubles
+        self.nbytes = self._aux_off + 512
+        # header v9: the call numbers live on the device (status[2] / status[3]) and the advantage statistics travel through the same
+        # mappings: an update that uses this communicator issues the same launches with the same arguments every iteration and has no
+        # torch.distributed call in it -- PPO.update_capturable
+        self.capturable = True
         self._base, self._peer, self.connected, self.seq = None, [None] * self.world, False, 0
         base = C.c_void_p()
         with torch.cuda.device(self.device):
@@ -311,6 +316,7 @@ class P2PComm:
         for q in range(self.world):
             c.data[q] = C.cast(C.c_void_p(self._peer[q]), L.c_float_p)
             c.flags[q] = C.cast(C.c_void_p(self._peer[q] + self._flag_off), C.POINTER(C.c_uint32))
+            c.aux[q] = C.cast(C.c_void_p(self._peer[q] + self._aux_off), L.c_f64_p)
         c.status = C.cast(C.c_void_p(self._base + self._stat_off), L.c_i64_p)
         c.wait_ticks = 0
         self.struct = c
@@ -321,12 +327,27 @@ class P2PComm:
         self.struct.wait_ticks = 0 if seconds is None else max(1, int(seconds * 1e8))
 
     def allreduce(self):
-        """In-place SUM over the ranks of `data`, enqueued on the current stream (the same call sequence on every rank)."""
+        """In-place SUM over the ranks of `data`, enqueued on the current stream (the same call sequence on every rank).  The call number
+        is the device's (hgym_comm_allreduce(seq = 0), header v9: status[2], advanced by the kernel): the launch is the same every time,
+        so a captured update replays it; `seq` here only counts the calls this object has enqueued (replays are added by the caller)."""
         self.seq += 1
         L, C = self._L, self._C
-        seq32 = (self.seq - 1) % 0xFFFFFFFF + 1          # 1 .. 2^32 - 1, never 0 (a zero-filled flag block means "call 0 has arrived")
-        L.check(L.lib.hgym_comm_allreduce(C.byref(self.struct), seq32, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)),
+        L.check(L.lib.hgym_comm_allreduce(C.byref(self.struct), 0, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)),
                 "hgym_comm_allreduce")
+
+    def skip_call(self):
+        """This rank does NOT take part in the next exchange (the fault-injection path of the start-up check): the call number moves on
+        as if it had, on the host and on the device."""
+        self.seq += 1
+        self.status[2] += 1
+
+    def sum64(self, t):
+        """In-place SUM over the ranks of t (<= 3 doubles on this device), enqueued on the current stream: the advantage statistics
+        of the global batch (hgym_comm_sum64: rank-ordered fp64 sum, bit-identical on every rank; call number on the device)."""
+        assert t.dtype == torch.float64 and t.is_cuda and t.is_contiguous() and 1 <= t.numel() <= 3
+        L, C = self._L, self._C
+        L.check(L.lib.hgym_comm_sum64(C.byref(self.struct), L.f64ptr(t), int(t.numel()), C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)),
+                "hgym_comm_sum64")
 
     def read_status(self):
         """Synchronises the current stream; the 16 status words as a list of ints."""
@@ -374,7 +395,7 @@ class P2PComm:
         skip = _inject("timeout")
         for k in range(PROBE_ROUNDS):
             if skip:
-                self.seq += 1                 # this rank's kernel never runs: the peers' waits expire
+                self.skip_call()              # this rank's kernel never runs: the peers' waits expire
                 continue
             torch.mul(pat, float((self.rank + 1) * (k + 1)), out=self.data)
             self.allreduce()
@@ -383,6 +404,16 @@ class P2PComm:
             # enqueued without a host synchronisation in between
             if (k == 0 or k == PROBE_ROUNDS - 1) and self.read_status()[0] != 0:
                 return False, "a bounded wait (%.1f s) expired" % PROBE_WAIT_S
+        # ... and the small fp64 exchange of the advantage statistics (hgym_comm_sum64), three rounds of changing values, exact in fp64
+        if not skip:
+            for k in range(3):
+                st = torch.tensor([float(self.rank + 1 + k), 0.5 * (self.rank + 1) * (k + 1), 4096.0], dtype=torch.float64, device=device)
+                self.sum64(st)
+                want64 = [W * (W + 1) / 2.0 + W * k, 0.5 * (k + 1) * W * (W + 1) / 2.0, 4096.0 * W]
+                if self.read_status()[0] != 0:
+                    return False, "a bounded wait (%.1f s) of the statistics exchange expired" % PROBE_WAIT_S
+                if st.tolist() != want64:
+                    return False, "wrong sum in the statistics exchange (round %d: %s, expected %s)" % (k + 1, st.tolist(), want64)
         for k in range(PROBE_ROUNDS):
             want = pat * float(W * (W + 1) // 2 * (k + 1))
             if _inject("sum"):

@@ -284,14 +284,23 @@ class PPO:
             st.shadow_valid = [True] * T
         self._deferred_ready = True
 
+    def _adv_stats(self, stats):
+        """(sum adv, sum adv^2, count) of this rank's shard -> of the global batch, in place: through the direct exchange's mappings when that
+        is what the gradients use (hgym_comm_sum64: rank-ordered fp64 sum, no torch.distributed call -- the update stays capturable), else
+        the collective."""
+        if dist_utils.active() and self._comm is not None and self._comm_p2p and not self.comm_flip:
+            self._comm.sum64(stats)
+            return stats
+        return dist_utils.allreduce_adv_stats(stats)
+
     def compute_returns(self, last_critic_obs):
         if getattr(self, "_deferred_ready", False):       # deferred_values() has evaluated the bootstrap observation with the rest
             self._deferred_ready = False
-            self.storage.compute_returns(self.storage.last_values, self.gamma, self.lam, stats_hook=dist_utils.allreduce_adv_stats,
+            self.storage.compute_returns(self.storage.last_values, self.gamma, self.lam, stats_hook=self._adv_stats,
                                          time_outs=self.storage.time_outs)
             return
         last_values = self.actor_critic.evaluate(last_critic_obs)
-        self.storage.compute_returns(last_values, self.gamma, self.lam, stats_hook=dist_utils.allreduce_adv_stats)
+        self.storage.compute_returns(last_values, self.gamma, self.lam, stats_hook=self._adv_stats)
 
     # ------------------------------------------------------------------ update
     def update_capturable(self):

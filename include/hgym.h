@@ -593,7 +593,7 @@ int32_t hgym_ppo_apply(const HgymNetConfig* cfg, const HgymPPOConfig* ppo, const
  * caller over whatever it has -- torch.distributed's all_gather_object here), opens the peers' (hgym_comm_ipc_open) and fills an
  * HgymComm: data[q] = rank q's payload (count floats, count % 4 == 0; data[rank] is the caller's own -- the flat [gradient | KL] vector
  * lives there, HgymNet.grads points into it), flags[q] = rank q's flag block (HGYM_COMM_FLAG_WORDS zero-filled uint32), status = 16
- * int64 of the caller's own buffer.  hgym_comm_allreduce(seq = 1, 2, 3, ... -- the same sequence on every rank) enqueues ONE kernel that
+ * int64 of the caller's own buffer.  hgym_comm_allreduce(seq = 1, 2, 3, ... -- the same sequence on every rank; or 0, below) enqueues ONE kernel that
  * leaves the rank-ordered fp32 SUM in every rank's data (bit-identical on all ranks): arrival flags, each rank sums its 1 / world shard
  * from all buffers and stores the result into all buffers, completion flags.  Waits are bounded (wait_ticks of the 100 MHz wall clock,
  * 0 = 15 s): on expiry status[0] = 1 (sticky until the caller clears it), status[1] = the seq of the call, that call's payload is
@@ -610,6 +610,8 @@ typedef struct HgymComm {
     int64_t count;
     int64_t* status;
     int64_t wait_ticks;     /* v7: bound of every wait inside hgym_comm_allreduce, 100 MHz ticks; 0 = the default (15 s) */
+    double* aux[HGYM_COMM_MAX_RANKS];   /* v9: aux[q] = rank q's block of HGYM_COMM_AUX_DOUBLES zero-filled doubles in the same fine-grained
+                                         * allocation (hgym_comm_sum64's slots); NULL everywhere if hgym_comm_sum64 is not used */
 } HgymComm;
 int32_t hgym_comm_alloc(int64_t bytes, void** dev_ptr);
 int32_t hgym_comm_free(void* dev_ptr);
@@ -617,6 +619,17 @@ int32_t hgym_comm_ipc_export(void* dev_ptr, void* handle_out);
 int32_t hgym_comm_ipc_open(const void* handle, void** dev_ptr);
 int32_t hgym_comm_ipc_close(void* dev_ptr);
 int32_t hgym_comm_allreduce(const HgymComm* comm, uint32_t seq, void* stream);
+/* header v9 -- what lets a data-parallel update be captured into a HIP graph (no launch argument changes from call to call, no
+ * torch.distributed call inside):
+ *   hgym_comm_allreduce(seq = 0): the call number is kept on the device -- status[2] = number of the last call, read by the kernel on
+ *   entry and advanced by it; all ranks must use the same form for the same call (a communicator is driven either with explicit numbers
+ *   or with 0 throughout);
+ *   hgym_comm_sum64: in-place SUM over the ranks of n <= 3 doubles at `vals` (device memory of the caller) -- the per-iteration
+ *   (sum adv, sum adv^2, count) of RolloutStorage.compute_returns' normalisation (rollout_storage.py:132-136 over the global batch) --
+ *   through aux[]: one wavefront, tagged slots, summed in rank order (bit-identical on all ranks); its call number is status[3];
+ *   bounded waits as above (status[0] = 1 on expiry). */
+#define HGYM_COMM_AUX_DOUBLES (2 * HGYM_COMM_MAX_RANKS * 4)
+int32_t hgym_comm_sum64(const HgymComm* comm, double* vals, int32_t n, void* stream);
 int32_t hgym_comm_status(const HgymComm* comm, int64_t* host16, void* stream);
 
 /* ------------------------------------------------------------------------------------------------

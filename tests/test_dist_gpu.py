@@ -31,7 +31,7 @@ def _all_done_or_timed_out(out_dir, world, prefix, limit_s=60.0):
     return False
 
 
-def _worker(rank, world, port, out_dir, backend="gloo", num_envs=256, iters=4, comm="rccl", inject=""):
+def _worker(rank, world, port, out_dir, backend="gloo", num_envs=256, iters=4, comm="rccl", inject="", timing=True):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "humanoid-gym_amd"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -58,7 +58,8 @@ def _worker(rank, world, port, out_dir, backend="gloo", num_envs=256, iters=4, c
     assert runner.alg._world == world
     p_init = runner.alg.net.params.clone()
     friction, commands0, seed = env.env_frictions.clone().cpu(), env.commands.clone().cpu(), int(env._ncfg.seed)
-    runner.alg.comm_timing = []
+    if timing:          # (event pairs around every exchange: keeps the update eager -- PPO.update_capturable)
+        runner.alg.comm_timing = []
     runner.learn(num_learning_iterations=iters, init_at_random_ep_len=True)     # eager, capture + replay, replay, replay
     torch.cuda.synchronize()
     net = runner.alg.net
@@ -87,7 +88,8 @@ def _worker(rank, world, port, out_dir, backend="gloo", num_envs=256, iters=4, c
         assert not want_p2p
     torch.save(dict(p_init=p_init.cpu(), params=net.params.cpu(), lr=float(net.opt_state[0]), steps=float(net.opt_state[1]),
                     obs=runner.alg.storage._obs_all[1].cpu(), graph=runner._graph is not None, friction=friction, commands0=commands0,
-                    env_seed=seed, comm_events=len(runner.alg.comm_timing), split=net.bucket_split, P=net.P, p2p=p2p, report=rep),
+                    env_seed=seed, comm_events=len(runner.alg.comm_timing or []), update_graph=runner._update_graph is not None,
+                    comm_calls=(runner.alg._comm.seq if runner.alg._comm is not None else 0), split=net.bucket_split, P=net.P, p2p=p2p, report=rep),
                os.path.join(out_dir, "r%d.pt.tmp" % rank))
     os.replace(os.path.join(out_dir, "r%d.pt.tmp" % rank), os.path.join(out_dir, "r%d.pt" % rank))
     if want_p2p and not _all_done_or_timed_out(out_dir, world, "r"):
@@ -175,6 +177,12 @@ def _p2p_unit_worker(rank, world, port, out_dir, count, calls):
 
 def _p2p_unit_calls(comm, vec, rank, world, calls, times):
     import time
+
+    def sum_in_order(xs):       # python floats are doubles: the kernel's rank-ordered fp64 sum
+        t = xs[0]
+        for x in xs[1:]:
+            t = t + x
+        return t
     worst = 0.0
     for k in range(calls):
         comm.data.copy_(vec(rank, k))
@@ -183,7 +191,13 @@ def _p2p_unit_calls(comm, vec, rank, world, calls, times):
             if rank % 2 == 1:
                 time.sleep(0.05)
         comm.allreduce()
+        # header v9: three doubles through the same mappings (the advantage statistics' path), a function of (rank, call) as well
+        st = torch.tensor([1.5 + rank + 0.25 * k, (rank + 1) * 1e-3 * (k + 1), 4096.0 * (k + 1)], dtype=torch.float64, device="cuda")
+        comm.sum64(st)
         times.append(comm.check())
+        want64 = [sum_in_order([1.5 + q + 0.25 * k for q in range(world)]), sum_in_order([(q + 1) * 1e-3 * (k + 1) for q in range(world)]),
+                  sum_in_order([4096.0 * (k + 1)] * world)]
+        assert st.tolist() == want64, (rank, k, st.tolist(), want64)
         want = vec(0, k)
         for q in range(1, world):
             want = want + vec(q, k)               # rank order, fp32: what the kernel forms
@@ -234,6 +248,27 @@ def test_two_ranks_one_gpu_p2p_exchange_equals_collective(tmp_path):
     assert torch.isfinite(a["params"]).all() and not torch.equal(a["params"], a["p_init"])
     assert torch.equal(a["params"], c["params"]) and a["lr"] == c["lr"]
     assert a["p2p"] is not None and c["p2p"] is None
+
+
+@pytest.mark.timeout(900)
+def test_two_ranks_one_gpu_captured_update_with_the_direct_exchange(tmp_path):
+    """Header v9 / VERDICT r05 item 6: with the direct exchange nothing in the update needs the host -- the gradient exchange's call
+    number and the permutation's draw number are read on the device, the advantage statistics travel through hgym_comm_sum64 -- so
+    compute_returns() + update() are captured into the second HIP graph on every rank and the iteration is two graph launches per rank.
+    Two ranks on one GPU, 5 iterations (eager, capture, three replays): both ranks hold bit-identical parameters, and they equal the run
+    whose update is issued from Python (the eager p2p run, which in turn equals the gloo run: test above)."""
+    port = 32100 + (os.getpid() % 2000)
+    os.makedirs(str(tmp_path / "graph"))
+    os.makedirs(str(tmp_path / "eager"))
+    mp.spawn(_worker, args=(2, port, str(tmp_path / "graph"), "gloo", 256, 5, "p2p", "", False), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port + 1, str(tmp_path / "eager"), "gloo", 256, 5, "p2p"), nprocs=2, join=True)
+    a, b = (torch.load(os.path.join(str(tmp_path / "graph"), "r%d.pt" % i)) for i in range(2))
+    c = torch.load(os.path.join(str(tmp_path / "eager"), "r0.pt"))
+    assert a["update_graph"] and b["update_graph"] and not c["update_graph"]
+    assert torch.equal(a["params"], b["params"]) and a["lr"] == b["lr"] and a["steps"] == b["steps"] == 40
+    assert torch.isfinite(a["params"]).all() and not torch.equal(a["params"], a["p_init"])
+    assert torch.equal(a["params"], c["params"]) and a["lr"] == c["lr"]
+    assert a["p2p"] is not None and a["comm_calls"] == c["comm_calls"]
 
 
 @pytest.mark.timeout(900)
