@@ -483,14 +483,12 @@ struct SegTable {
 // Also accumulates the squared norm of the finished gradient into opt[9] (zeroed by ppo_scalars_kernel earlier in the same
 // hgym_ppo_grad): with one rank that IS the norm clip_grad_norm_ needs, and hgym_ppo_apply skips its own pass over the
 // gradient.  (Segments whose gradient is already final -- splits == 0 -- are only read.)
-// The norm is the ONE sum of the training step left on fp64 atomics in arrival order (1 632 workgroups, one non-returning atomicAdd each): its
-// last bits can differ from run to run, which reaches the result only if the fp32-rounded clip coefficient flips (a 1e-16 relative change
-// against fp32's 6e-8 spacing: ~2e-9 per optimiser step; parameters of the captured-update test are bit-identical run to run).  Round 6 built
-// the order-fixed forms -- per-workgroup partials + last arriver with a release fence per workgroup: 65 us instead of 11 (every fence writes the
-// XCD's L2 back while the others fill it with gradient lines); write-through partials + acknowledged store + returning counter atomic, one and two
-// levels: 26-29 us (three to six dependent memory-side round trips at the tail of an 11 us kernel) -- and kept the atomics: 0.12-0.4 ms per
-// iteration for a bit that does not reach the parameters (profiles/r06_update_graph_and_norm_order.txt).  With several ranks the norm is
-// sqnorm_prologue_kernel's, which IS order-fixed (256 workgroups, one launch).
+// The norm stays on fp64 atomics in arrival order (1 632 workgroups, one non-returning atomicAdd each) -- made order-INDEPENDENT by rounding every
+// partial to a common quantum first (below): exact additions commute.  Round 6 first built the order-fixed forms -- per-workgroup partials + last
+// arriver with a release fence per workgroup: 65 us instead of 11 (every fence writes the XCD's L2 back while the others fill it with gradient
+// lines); write-through partials + acknowledged store + returning counter atomic, on one and on two levels: 26-29 us (three to six dependent
+// memory-side round trips at the tail of an 11 us kernel) -- and dropped them (profiles/r06_update_graph_and_norm_order.txt).  With several ranks
+// the norm is sqnorm_prologue_kernel's, which is order-fixed (256 workgroups, one launch).
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(const SegTable tab, int64_t P, const float* __restrict__ slabs,
                                                            float* __restrict__ grads, double* __restrict__ opt) {
     __shared__ double red[4];
@@ -540,7 +538,13 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const SegTable tab, i
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sq;
     __syncthreads();
     if (threadIdx.x == 0) {
-        const double t = red[0] + red[1] + red[2] + red[3];
+        // Pre-rounded to a common quantum (2^-46): every partial, and therefore every intermediate value of opt[9], is an integer multiple of
+        // it, so while the total stays below 2^53 quanta = 128 (a gradient norm of 11.3, eleven times the clip threshold) the fp64 additions
+        // are EXACT -- and exact additions commute: the atomics may arrive in any order, the sum has the same bits.  (Above 128 the additions
+        // round again and the last bits depend on the order, as they always did; the step is then clipped by more than 11x and sees `total`
+        // as a float.)  Cost of the rounding: at most 1 632 x 2^-47 = 1.2e-11 absolute on the squared norm.
+        double t = red[0] + red[1] + red[2] + red[3];
+        t = __builtin_rint(t * 0x1p46) * 0x1p-46;
         if (t != 0.0) atomicAdd(&opt[9], t);
     }
 }
