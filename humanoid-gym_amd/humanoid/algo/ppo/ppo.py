@@ -99,6 +99,8 @@ class PPO:
         self._rank = 0
         if torch.distributed.is_available() and torch.distributed.is_initialized():
             self._world, self._rank = torch.distributed.get_world_size(), torch.distributed.get_rank()
+            if not dist_utils.active():      # HGYM_DIST_OFF=1: this rank of a running group trains ALONE (bench.py's same-box N = 1 reference) --
+                self._world = 1              # no exchange, so apply must not form a mean over ranks either
 
     # ------------------------------------------------------------------
     @property
