@@ -52,7 +52,7 @@ def main():
     out = ["# profiles/ -- index", "",
            "Every number DESIGN.md, README.md or bench.py quotes comes from a file here.  One line per file: what it is / the claim it supports",
            "(notes and patches: their own first line).  Regenerate with `python tools/profiles_index.py`.  The closing measurement of a round is",
-           "`rNN_final_*` / the highest letter of that round (`r06k_*`: round 6, 138 GPU tests + smoke green, 40.7 M env-steps/s).", ""]
+           "`rNN_final_*` / the highest letter of that round (`r06s_*`: round 6, 141 GPU tests + smoke green, 40.8 M env-steps/s).", ""]
     for rnd in sorted(rounds, key=lambda r: (r[0] != "r", r)):
         out += ["## " + rnd, "", "| file | what it shows |", "|---|---|"]
         out += ["| `%s` | %s |" % (f, describe(f).replace("|", "/")) for f in rounds[rnd]]
